@@ -1,0 +1,317 @@
+"""Generate the golden fixtures under tests/golden/ by IMPORTING the reference (read-only) in the
+build container.  Nothing from /root/reference is copied: the fixtures hold inputs (or the seeds of
+pixelsynth_amd/synthetic.py generators) and the reference's OUTPUTS only.
+
+Shims needed to import the reference here (none of them is copied into the repo):
+  * pytorch3d is absent -> empty stub modules (project_pts* are pure torch and never touch it);
+  * models/lmconv/get_custom_order.so is cpython-37m -> the reference's own Cython C is compiled by
+    oracle/build_oracle.py into oracle/_ref/ and registered under the expected module name;
+  * no GPU here -> torch.Tensor.cuda is patched to identity and np.int (removed in numpy>=1.24)
+    is aliased to int, so that models/lmconv/sample.py:sample() itself can run on CPU.
+
+Run:  python tests/golden/make_golden.py        (about 2 minutes)
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+
+from oracle import build_oracle  # noqa: E402
+from pixelsynth_amd import synthetic as syn  # noqa: E402
+sys.path.insert(0, HERE)
+import cases  # noqa: E402
+
+
+def _import_reference():
+    ref_so = build_oracle.build_ref()
+    spec = importlib.util.spec_from_file_location("get_custom_order", ref_so)
+    gco = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gco)
+    sys.modules["models.lmconv.get_custom_order"] = gco
+    for name in ["pytorch3d", "pytorch3d.structures", "pytorch3d.renderer", "pytorch3d.renderer.points"]:
+        sys.modules[name] = types.ModuleType(name)
+    sys.modules["pytorch3d.structures"].Pointclouds = object
+    sys.modules["pytorch3d.renderer"].compositing = object
+    sys.modules["pytorch3d.renderer.points"].rasterize_points = object
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    np.int = int
+    import models.lmconv
+    models.lmconv.get_custom_order = gco
+    import models.lmconv.masking as masking
+    from models.lmconv.model import OurPixelCNN
+    from models.lmconv.layers import PONO, gated_resnet, nin
+    from models.lmconv.locally_masked_convolution import locally_masked_conv2d
+    from models.lmconv.sample import sample
+    from models.lmconv.utils import concat_elu
+    from models.projection.z_buffer_manipulator import PtsManipulator
+    return dict(gco=gco, masking=masking, OurPixelCNN=OurPixelCNN, PONO=PONO, gated_resnet=gated_resnet,
+                nin=nin, lmconv=locally_masked_conv2d, sample=sample, concat_elu=concat_elu,
+                PtsManipulator=PtsManipulator)
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def make_net(R, seed):
+    net = R["OurPixelCNN"](nr_resnet=2, nr_filters=80, input_channels=512, nr_logistic_mix=10,
+                           kernel_size=(3, 3), max_dilation=2, weight_norm=False,
+                           feature_norm_op=lambda c: R["PONO"](), dropout_prob=0, conv_bias=True,
+                           conv_mask_weight=False, rematerialize=False, binarize=False).eval()
+    sd = {k: t(v) for k, v in syn.pixelcnn_state_dict(seed).items()}
+    missing = net.load_state_dict(sd, strict=True)
+    return net
+
+
+def poses():
+    """(name, cams, RT2, RT2inv, depth range) used for the projection fixtures."""
+    out = []
+    cam = syn.demo_cameras(1)
+    for name, yaw in [("demo_L", -0.6), ("demo_R", 0.6), ("demo_small", 0.05), ("demo_identity", 0.0)]:
+        RTinv, RT = syn.yaw_pose(cam["P"], yaw)
+        out.append((name, cam, RT, RTinv, (1.0, 100.0)))
+    RTinv, RT = syn.circle_pose(cam["P"], 5, 64)
+    out.append(("demo_circle5", cam, RT, RTinv, (1.0, 100.0)))
+    cam = syn.mp3d_cameras(1)
+    for name, yaw in [("mp3d_yaw", 0.4), ("mp3d_back", 2.8)]:
+        RTinv, RT = syn.yaw_pose(cam["P"], yaw, pitch=0.1)
+        out.append((name, cam, RT, RTinv, (0.5, 10.0)))
+    return out
+
+
+def gen_projection(R):
+    ns = types.SimpleNamespace(splatter="xyblending", learn_default_feature=True, radius=4, pp_pixel=128)
+    fx = {}
+    for W in (8, 16):
+        pm = R["PtsManipulator"](W, C=3, opt=ns)
+        fx[f"xyzs_W{W}"] = pm.xyzs.numpy().copy()
+    pm256 = R["PtsManipulator"](256, C=3, opt=ns)
+    fx["xyzs_W256_stride97"] = pm256.xyzs.numpy()[:, :, ::97].copy()
+    names = []
+    for name, cam, RT2, RT2inv, (lo, hi) in poses():
+        names.append(name)
+        for W, stride in ((16, 1), (256, 61)):
+            pm = pm256 if W == 256 else R["PtsManipulator"](W, C=3, opt=ns)
+            d = syn.depth_uniform(7, 2, W, lo, hi)
+            B = d.shape[0]
+            rep = lambda m: t(np.repeat(m, B, 0))
+            with torch.no_grad():
+                s = pm.project_pts(t(d).view(B, 1, -1), rep(cam["K"]), rep(cam["Kinv"]), rep(cam["P"]),
+                                   rep(cam["Pinv"]), rep(RT2), rep(RT2inv))
+            fx[f"proj_{name}_W{W}"] = s.numpy()[:, :, ::stride].copy()
+        fx[f"pose_{name}_RT2"] = RT2
+        fx[f"pose_{name}_RT2inv"] = RT2inv
+    fx["pose_names"] = np.array(names)
+    # near-zero z: points whose projected |z| < EPS must become (-10, +10, +10)
+    cam = syn.demo_cameras(1)
+    RTinv, RT = syn.yaw_pose(cam["P"], 1.5)
+    pm = R["PtsManipulator"](16, C=3, opt=ns)
+    d = syn.depth_uniform(3, 1, 16, 0.001, 0.02)
+    s = pm.project_pts(t(d).view(1, 1, -1), t(cam["K"]), t(cam["Kinv"]), t(cam["P"]), t(cam["Pinv"]),
+                       t(RT), t(RTinv))
+    fx["proj_epscase_depth"] = d
+    fx["proj_epscase_RT2"] = RT
+    fx["proj_epscase_out"] = s.numpy()
+    # cumulative (scene mode): W=16, half of the pixels "new", a prior cloud of 100 points
+    W = 16
+    pm = R["PtsManipulator"](W, C=3, opt=ns)
+    rs = np.random.RandomState(11)
+    last_bg = (rs.rand(1, W * W) > 0.5)
+    n_new = int(last_bg.sum())
+    d_new = (rs.rand(1, 1, n_new).astype(np.float32) * 9 + 1)
+    prior = rs.randn(1, 4, 100).astype(np.float32) * 2
+    prior[:, 2] = -np.abs(prior[:, 2]) - 0.5
+    prior[:, 3] = 1
+    RT3inv, _ = syn.yaw_pose(cam["P"], 0.1)
+    RTinv2, RT2 = syn.yaw_pose(cam["P"], 0.3)
+    # force the EPS branch on 3 prior points: choose p with (RT2 @ RT3inv @ p).z ~ 1e-3
+    M = RT2[0].astype(np.float64) @ RT3inv[0].astype(np.float64)
+    for k in range(3):
+        prior[0, :, k] = (np.linalg.inv(M) @ np.array([0.3 * k, -0.2, 0.001 * (k - 1), 1.0])).astype(np.float32)
+    with torch.no_grad():
+        s, cloud = pm.project_pts_cumulative(t(d_new), t(cam["K"]), t(cam["Kinv"]), t(cam["P"]), t(cam["Pinv"]),
+                                             t(RT2), t(RTinv2), t(prior), t(last_bg).view(1, 1, -1), t(RT3inv))
+    fx.update(cum_last_bg=last_bg, cum_depth_new=d_new, cum_prior=prior, cum_RT2=RT2, cum_RT3inv=RT3inv,
+              cum_sampler=s.numpy(), cum_cloud=cloud.numpy())
+    # cumulative without prior / mask (first frame of a scene)
+    d0 = syn.depth_uniform(5, 1, W, 1, 10)
+    with torch.no_grad():
+        s0, cloud0 = pm.project_pts_cumulative(t(d0).view(1, 1, -1), t(cam["K"]), t(cam["Kinv"]), t(cam["P"]),
+                                               t(cam["Pinv"]), t(RT2), t(RTinv2), None, None, None)
+    fx.update(cum0_depth=d0, cum0_sampler=s0.numpy(), cum0_cloud=cloud0.numpy())
+    np.savez_compressed(os.path.join(HERE, "projection.npz"), **fx)
+    print("projection.npz", len(fx))
+
+
+def gen_orders_masks(R):
+    fx = {}
+    names = []
+    for name, D in syn.distance_maps():
+        names.append(name)
+        d = D.copy()
+        order = R["masking"].get_generation_order_idx("custom", 32, 32, d, (16, 16))
+        fx[f"order_{name}"] = np.asarray(order).astype(np.int16)
+        assert (d == D * 10000).all()  # the reference mutates its argument
+    fx["names"] = np.array(names)
+    for name in ("halfplane_x", "island", "rand0", "all_fg", "ring", "rand4"):
+        order = fx[f"order_{name}"].astype(np.int64)
+        for tag, dil, typ in (("A1", 1, "A"), ("B1", 1, "B"), ("B2", 2, "B")):
+            m = R["masking"].get_unfolded_masks(order, 32, 32, k=3, dilation=dil, mask_type=typ)
+            fx[f"mask_{name}_{tag}"] = np.packbits(m.numpy()[0].astype(np.uint8), axis=1)
+    # small non-32 grid (8x8) as an edge case of the mask builder
+    rs = np.random.RandomState(5)
+    D8 = rs.randint(-3, 4, size=(8, 8)).astype(np.int64)
+    o8 = R["masking"].get_generation_order_idx("custom", 8, 8, D8.copy(), (4, 4))
+    fx["order8_D"] = D8
+    fx["order8"] = np.asarray(o8).astype(np.int16)
+    for tag, dil, typ in (("A1", 1, "A"), ("B1", 1, "B"), ("B2", 2, "B")):
+        fx[f"mask8_{tag}"] = R["masking"].get_unfolded_masks(o8, 8, 8, k=3, dilation=dil, mask_type=typ).numpy()
+    np.savez_compressed(os.path.join(HERE, "orders_masks.npz"), **fx)
+    print("orders_masks.npz", len(fx))
+
+
+def gen_lmconv_layers(R):
+    fx = {}
+    for name, ci, co, dil, H in cases.LAYER_CASES:
+        c = cases.layer_case(name)
+        layer = R["lmconv"](ci, co, kernel_size=(3, 3), dilation=dil, bias=True)
+        with torch.no_grad():
+            layer.weight.copy_(t(c["w"]))
+            layer.bias.copy_(t(c["b"]))
+            mrep = t(c["m"]).unsqueeze(1).repeat(1, ci, 1, 1).view(c["B"] * ci, 9, H * H)
+            y = layer(t(c["x"]), mrep)
+        fx[f"{name}_y"] = y.numpy()
+    np.savez_compressed(os.path.join(HERE, "lmconv_layers.npz"), **fx)
+    print("lmconv_layers.npz", len(fx))
+
+
+def gen_blocks(R):
+    """gated_resnet (with and without skip), PONO, nin, concat_elu."""
+    fx = {}
+    conv_op = lambda cin, cout: R["lmconv"](cin, cout, kernel_size=(3, 3), bias=True, mask_weight=False)
+    for skip in (0, 1):
+        c = cases.gated_case(skip)
+        blk = R["gated_resnet"](80, conv_op, lambda ch: R["PONO"](), R["concat_elu"], skip_connection=skip,
+                                dropout_prob=0).eval()
+        blk.load_state_dict({k: t(v) for k, v in c["sd"].items()}, strict=True)
+        L = c["H"] * c["H"]
+        with torch.no_grad():
+            mrep = t(c["m"]).unsqueeze(1).repeat(1, 160, 1, 1).view(c["B"] * 160, 9, L)
+            y = blk(t(c["x"]), a=None if c["a"] is None else t(c["a"]), mask=mrep)
+        fx[f"gr{skip}_y"] = y.numpy()
+    c = cases.small_case()
+    fx["pono_y"] = R["PONO"]()(t(c["x"])).numpy()
+    fx["celu_y"] = R["concat_elu"](t(c["x"])).numpy()
+    lin = R["nin"](80, 512).eval()
+    lin.load_state_dict({k: t(v) for k, v in c["nin_sd"].items()}, strict=True)
+    with torch.no_grad():
+        fx["nin_y"] = lin(t(c["x"])).numpy()
+    np.savez_compressed(os.path.join(HERE, "blocks.npz"), **fx)
+    print("blocks.npz", len(fx))
+
+
+def masks_from_order(R, order):
+    mi = R["masking"].get_unfolded_masks(order, 32, 32, k=3, dilation=1, mask_type="A")
+    mu = R["masking"].get_unfolded_masks(order, 32, 32, k=3, dilation=1, mask_type="B")
+    md = R["masking"].get_unfolded_masks(order, 32, 32, k=3, dilation=2, mask_type="B")
+    rep = lambda m, c: m[0:1].repeat(c, 1, 1).view(-1, 9, 1024)
+    return rep(mi, 513), rep(mu, 160), rep(md, 80)
+
+
+def gen_network(R):
+    """Full OurPixelCNN logits for 2 weight seeds x orders; subset of positions stored."""
+    fx = {}
+    dmaps = dict(syn.distance_maps())
+    pos = np.random.RandomState(3).permutation(1024)[:48]
+    fx["positions"] = pos
+    for wi, (wseed, oname) in enumerate([(0, "halfplane_x"), (1, "rand0")]):
+        net = make_net(R, wseed)
+        order = R["masking"].get_generation_order_idx("custom", 32, 32, dmaps[oname].copy(), (16, 16))
+        masks = masks_from_order(R, order)
+        codes = syn.codes(100 + wi, 1)
+        x = torch.nn.functional.one_hot(t(codes), 512).permute(0, 3, 1, 2).float()
+        with torch.no_grad():
+            logits = net([x, *masks], sample=True)
+        lg = logits[0].reshape(512, 1024).numpy()
+        fx[f"net{wi}_wseed"] = np.array(wseed)
+        fx[f"net{wi}_order_name"] = np.array(oname)
+        fx[f"net{wi}_codes_seed"] = np.array(100 + wi)
+        fx[f"net{wi}_logits_sub"] = lg[:, pos].copy()
+        fx[f"net{wi}_logits_sum"] = lg.astype(np.float64).sum(0)  # per-position checksum
+    np.savez_compressed(os.path.join(HERE, "network.npz"), **fx)
+    print("network.npz", len(fx))
+
+
+def gen_ar_trace(R):
+    """The reference's own sample() (models/lmconv/sample.py:8-73), run on CPU through the shims.
+
+    Background: right part of the grid + a foreground island whose order indices fall after the first
+    sampled index.  seed=1 -> exercises the 'seed extra draws' loop.  Stores the final one-hot argmax,
+    and (teacher-forcing check) the logits of ONE full forward on the completed grid at the sampled
+    positions -- asserted here to be bit-equal to the per-step logits the loop saw."""
+    fx = {}
+    net = make_net(R, 0)
+    bg32 = np.zeros((32, 32), np.float32)
+    bg32[:, 22:] = 1
+    bg32[12:15, 26:29] = 0  # foreground island inside the background
+    fgb = (bg32 == 0).astype(np.uint8)
+    sys.path.insert(0, ROOT)
+    from oracle import c_oracle
+    D = c_oracle.signed_distance(fgb, (bg32 == 1).astype(np.uint8))
+    order = R["masking"].get_generation_order_idx("custom", 32, 32, D.copy(), (16, 16))
+    masks = masks_from_order(R, order)
+    codes = syn.codes(200, 1)
+    args = types.SimpleNamespace(num_classes=512, dataloader_seed=0)
+    seen = []
+    orig_forward = net.forward
+
+    def spy(x, sample=False, **kw):
+        out = orig_forward(x, sample=sample, **kw)
+        seen.append(out.detach().clone())
+        return out
+    net.forward = spy
+    with torch.no_grad():
+        data, loss = R["sample"](net, [order], *masks, t(codes), [3, 32, 32], args, seed=1, temperature=0.7,
+                                 background_mask=t(bg32)[None])
+    net.forward = orig_forward
+    final = data.argmax(1)[0].numpy()
+    region = [(int(i), int(j)) for i, j in order if bg32[i, j] == 1]
+    assert len(seen) == len(region)
+    with torch.no_grad():
+        full = net([data, *masks], sample=True)
+    step_logits = np.stack([seen[n][0, :, i, j].numpy() for n, (i, j) in enumerate(region)])
+    full_logits = np.stack([full[0, :, i, j].numpy() for (i, j) in region])
+    causal_maxdiff = float(np.abs(step_logits - full_logits).max())
+    print("AR trace: steps", len(region), "max|step - full| =", causal_maxdiff)
+    fx.update(D=D, order=np.asarray(order).astype(np.int16), bg32=bg32, codes_seed=np.array(200),
+              wseed=np.array(0), seed=np.array(1), temperature=np.array(0.7), final_codes=final.astype(np.int16),
+              step_logits=step_logits[::4].astype(np.float32), causal_maxdiff=np.array(causal_maxdiff),
+              n_steps=np.array(len(region)), loss=np.array(float(loss)))
+    np.savez_compressed(os.path.join(HERE, "ar_trace.npz"), **fx)
+    print("ar_trace.npz", len(fx))
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    R = _import_reference()
+    which = sys.argv[1:] or ["projection", "orders", "layers", "blocks", "network", "ar"]
+    if "projection" in which:
+        gen_projection(R)
+    if "orders" in which:
+        gen_orders_masks(R)
+    if "layers" in which:
+        gen_lmconv_layers(R)
+    if "blocks" in which:
+        gen_blocks(R)
+    if "network" in which:
+        gen_network(R)
+    if "ar" in which:
+        gen_ar_trace(R)
