@@ -1,0 +1,81 @@
+"""ctypes binding of libpixelsynth_hip.so (the C ABI declared in include/pixelsynth_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a call fails, a RuntimeError
+is raised.  Nothing here (or anywhere under pixelsynth_amd/) imports oracle/.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpixelsynth_hip.so")
+_lib = None
+
+c_void_p, c_int, c_float, c_double, c_size_t = (ctypes.c_void_p, ctypes.c_int, ctypes.c_float,
+                                                 ctypes.c_double, ctypes.c_size_t)
+
+_PROTOS = {
+    "ps_abi_version": (c_int, []),
+    "ps_last_error": (ctypes.c_char_p, []),
+    "ps_project_pts_f32": (c_int, [c_void_p] * 5 + [c_int, c_int, c_void_p, c_void_p]),
+    "ps_project_pts_cumulative_f32": (c_int, [c_void_p] * 8 + [c_int] * 4 + [c_void_p] * 3),
+    "ps_splat_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_double]),
+    "ps_splat_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_double, c_int, c_float, c_int,
+                             c_int, c_int] + [c_void_p] * 6 + [c_size_t, c_void_p]),
+    "ps_project_splat_f32": (c_int, [c_void_p] * 6 + [c_int, c_int, c_int, c_double, c_int, c_float, c_int, c_int,
+                                                      c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "ps_generation_order": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "ps_custom_order": (c_int, [c_int, c_int, c_void_p, c_void_p]),
+    "ps_kernel_masks_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "ps_lmconv_forward_f32": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                      c_int, c_int, c_void_p, c_void_p]),
+}
+
+
+def exported_symbols():
+    """Names every entry point include/pixelsynth_hip.h declares (used by the CPU load test)."""
+    return sorted(_PROTOS)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -m pixelsynth_amd.build` "
+                "(there is no CPU/PyTorch fallback for the HIP path)")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _PROTOS.items():
+            if not hasattr(L, name):
+                continue  # optional symbols are checked by tests/test_abi.py
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().ps_last_error()
+        raise RuntimeError(f"{what} failed (rc={rc}): {msg.decode() if msg else '?'}")
+
+
+def ptr(t):
+    """Device (or host) pointer of a contiguous torch tensor / numpy array, or None."""
+    if t is None:
+        return None
+    if hasattr(t, "data_ptr"):
+        return ctypes.c_void_p(t.data_ptr())
+    return ctypes.c_void_p(t.ctypes.data)
+
+
+def current_stream():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("pixelsynth_amd HIP path needs tensors on the ROCm device "
+                               "(got a CPU tensor; there is no CPU fallback)")

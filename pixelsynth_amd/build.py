@@ -1,0 +1,54 @@
+"""Build libpixelsynth_hip.so in-tree for gfx950 (hipcc cross-compiles without a GPU).
+
+    python -m pixelsynth_amd.build [--force]
+
+One object per translation unit (splat.hip is built with -ffp-contract=off because its index paths
+must be bit-exact; lmconv.hip keeps FMA contraction), linked into pixelsynth_amd/libpixelsynth_hip.so.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libpixelsynth_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+
+UNITS = [
+    ("splat.hip", ["-ffp-contract=off"]),
+    ("lmconv.hip", []),
+    ("host_order.cpp", []),
+]
+COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
+
+
+def _deps():
+    return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [
+        os.path.join(os.path.dirname(HERE), "include", "pixelsynth_hip.h")]
+
+
+def build(force=False, verbose=True):
+    objs = []
+    dep_m = max(os.path.getmtime(d) for d in _deps())
+    for src, flags in UNITS:
+        sp = os.path.join(CSRC, src)
+        if not os.path.exists(sp):
+            continue
+        obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(sp), dep_m):
+            cmd = [HIPCC, "-x", "hip", "-c", sp, "-o", obj] + COMMON + flags
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+        objs.append(obj)
+    if force or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
+        cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

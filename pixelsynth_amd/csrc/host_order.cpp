@@ -1,0 +1,153 @@
+// host_order.cpp -- host-side integer glue between the splat and the AR sampler:
+// block reduction of the background mask, 5x5 chamfer distance transforms, the greedy frontier
+// generation order and the per-location 3x3 kernel masks.
+//
+// Replaces (behind the C ABI): ZbufferModelPts.get_masks_for_batch (models/z_buffermodel.py:641-701),
+// get_custom_order.custom_idx (models/lmconv/get_custom_order.pyx:4-124, the reference's Cython
+// native module) and masking.kernel_masks / get_unfolded_masks (models/lmconv/masking.py:287-349).
+// Pure C++17, no GPU work: the data is a 32x32 grid and the algorithm is a sequential heap walk.
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <queue>
+#include <tuple>
+#include <vector>
+
+#include "ps_common.h"
+
+namespace {
+
+// cv2.distanceTransform(src, DIST_L2, 5): two-pass chamfer, 16.16 fixed point, metrics
+// (1, 1.4, 2.1969); portable OpenCV definition (DESIGN.md "third-party semantics").
+struct Chamfer5 {
+    static constexpr uint32_t INIT = 0x7FFFFFFF >> 2;
+    // forward-pass neighbourhood (dy, dx, metric id); the backward pass mirrors it
+    static constexpr int NB[8][3] = {{-2, -1, 2}, {-2, 1, 2}, {-1, -2, 2}, {-1, -1, 1},
+                                     {-1, 0, 0},  {-1, 1, 1}, {-1, 2, 2},  {0, -1, 0}};
+    static void run(const uint8_t *src, int H, int W, float *out)
+    {
+        const uint32_t metric[3] = {65536u, (uint32_t)std::lrint((double)1.4f * 65536.0),
+                                    (uint32_t)std::lrint((double)2.1969f * 65536.0)};
+        const int B = 2, step = W + 2 * B;
+        std::vector<uint32_t> buf((size_t)step * (H + 2 * B), INIT);
+        auto at = [&](int y, int x) -> uint32_t & { return buf[(size_t)(y + B) * step + (x + B)]; };
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x) {
+                if (!src[(size_t)y * W + x]) { at(y, x) = 0; continue; }
+                uint32_t best = 0xFFFFFFFFu;
+                for (auto &nb : NB) best = std::min(best, at(y + nb[0], x + nb[1]) + metric[nb[2]]);
+                at(y, x) = best;
+            }
+        for (int y = H - 1; y >= 0; --y)
+            for (int x = W - 1; x >= 0; --x) {
+                uint32_t best = at(y, x);
+                if (best > metric[0]) {
+                    for (auto &nb : NB) best = std::min(best, at(y - nb[0], x - nb[1]) + metric[nb[2]]);
+                    at(y, x) = best;
+                }
+                out[(size_t)y * W + x] = (float)std::min(best, INIT) * (1.0f / 65536.0f);
+            }
+    }
+};
+constexpr int Chamfer5::NB[8][3];
+
+void custom_order(int rows, int cols, int64_t *d, int32_t *order)
+{
+    const int L = rows * cols;
+    for (int i = 0; i < L; ++i) d[i] *= 10000;                                    // .pyx:26
+    const int start = (int)(std::max_element(d, d + L) - d);                      // first argmax, .pyx:55-56
+    int c = start % rows, r = (start - c) / rows;
+    using Item = std::tuple<int64_t, int, int>;                                   // (-distance, r, c)
+    std::priority_queue<Item, std::vector<Item>, std::greater<Item>> frontier;
+    std::vector<uint8_t> seen((size_t)L, 0);
+    seen[(size_t)r * cols + c] = 1;
+    int n = 0;
+    order[2 * n] = r; order[2 * n + 1] = c; ++n;
+    static const int STEP[4][2] = {{-1, 0}, {1, 0}, {0, -1}, {0, 1}};              // Up, Down, Left, Right .pyx:65-80
+    while (n < L) {
+        for (auto &s : STEP) {
+            const int rr = r + s[0], cc = c + s[1];
+            if (rr < 0 || rr >= rows || cc < 0 || cc >= cols || seen[(size_t)rr * cols + cc]) continue;
+            seen[(size_t)rr * cols + cc] = 1;
+            frontier.emplace(-d[(size_t)rr * cols + cc], rr, cc);
+        }
+        std::tie(std::ignore, r, c) = frontier.top();
+        frontier.pop();
+        order[2 * n] = r; order[2 * n + 1] = c; ++n;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int ps_abi_version(void) { return PS_ABI_VERSION; }
+const char *ps_last_error(void) { return ps::last_error_ref().c_str(); }
+
+int ps_custom_order(int rows, int cols, int64_t *distances, int32_t *order)
+{
+    PS_REQUIRE(distances && order, "custom_order: null pointer");
+    PS_REQUIRE(rows > 0 && rows == cols, "custom_order: rows == cols > 0 required (reference asserts it)");
+    custom_order(rows, cols, distances, order);
+    return PS_OK;
+}
+
+int ps_generation_order(const uint8_t *bg, int S, int G, int32_t *order, uint8_t *bg_blocks, int64_t *distances)
+{
+    PS_REQUIRE(bg && order && bg_blocks, "generation_order: null pointer");
+    PS_REQUIRE(S > 0 && G > 0 && S % G == 0, "generation_order: S must be a multiple of G");
+    const int blk = S / G, L = G * G;
+    std::vector<uint8_t> fgb((size_t)L), bgb((size_t)L);
+    for (int by = 0; by < G; ++by)
+        for (int bx = 0; bx < G; ++bx) {
+            int ones = 0;
+            for (int y = 0; y < blk; ++y)
+                for (int x = 0; x < blk; ++x) ones += bg[(size_t)(by * blk + y) * S + bx * blk + x] != 0;
+            // AvgPool2d(blk) then .astype(uint8): 1 only when the block mean is exactly 1 (:646-647,668-669)
+            bgb[(size_t)by * G + bx] = ones == blk * blk;
+            fgb[(size_t)by * G + bx] = ones == 0;
+        }
+    std::vector<float> fd((size_t)L), bd((size_t)L);
+    Chamfer5::run(fgb.data(), G, G, fd.data());
+    Chamfer5::run(bgb.data(), G, G, bd.data());
+    std::vector<int64_t> D((size_t)L);
+    for (int i = 0; i < L; ++i) D[i] = (int64_t)((double)fd[i] - (double)bd[i]);   // float64 subtract, trunc (:675)
+    if (distances) std::memcpy(distances, D.data(), sizeof(int64_t) * (size_t)L);
+    custom_order(G, G, D.data(), order);
+    std::memcpy(bg_blocks, bgb.data(), (size_t)L);
+    return PS_OK;
+}
+
+int ps_kernel_masks_f32(const int32_t *order, int L, int nrows, int ncols, int k, int dilation, int mask_type_b,
+                        float *masks)
+{
+    PS_REQUIRE(order && masks, "kernel_masks: null pointer");
+    PS_REQUIRE(k > 0 && (k & 1) && dilation > 0, "kernel_masks: k must be odd, dilation > 0");
+    PS_REQUIRE(L == nrows * ncols, "kernel_masks: order must visit every location once (L=%d, grid=%d)", L,
+               nrows * ncols);
+    // rank[q] = position of location q in the generation order; a tap is open iff its neighbour
+    // was generated earlier (masking.py:318-334 builds the same relation with a growing set).
+    std::vector<int32_t> rank((size_t)L, -1);
+    for (int i = 0; i < L; ++i) {
+        const int r = order[2 * i], c = order[2 * i + 1];
+        PS_REQUIRE(r >= 0 && r < nrows && c >= 0 && c < ncols, "kernel_masks: order entry %d out of the grid", i);
+        PS_REQUIRE(rank[(size_t)r * ncols + c] < 0, "kernel_masks: location (%d,%d) visited twice", r, c);
+        rank[(size_t)r * ncols + c] = i;
+    }
+    const int h = k / 2;
+    for (int dr = -h; dr <= h; ++dr)
+        for (int dc = -h; dc <= h; ++dc) {
+            float *m = masks + (size_t)((dr + h) * k + (dc + h)) * L;
+            for (int r = 0; r < nrows; ++r)
+                for (int c = 0; c < ncols; ++c) {
+                    const int q = r * ncols + c;
+                    if (dr == 0 && dc == 0) { m[q] = mask_type_b ? 1.0f : 0.0f; continue; }
+                    const int rr = r + dr * dilation, cc = c + dc * dilation;
+                    const bool in = rr >= 0 && rr < nrows && cc >= 0 && cc < ncols;
+                    m[q] = (in && rank[(size_t)rr * ncols + cc] < rank[q]) ? 1.0f : 0.0f;
+                }
+        }
+    return PS_OK;
+}
+
+}  // extern "C"

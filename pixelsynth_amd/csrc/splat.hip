@@ -1,0 +1,657 @@
+// splat.hip -- depth un-projection + camera transform + soft z-buffer splat for gfx950 (MI355X).
+//
+// Replaces, behind the C ABI of include/pixelsynth_hip.h:
+//   PtsManipulator.project_pts / project_pts_cumulative   models/projection/z_buffer_manipulator.py:50-83, 221-266
+//   RasterizePointsXYsBlending.forward                    models/layers/z_buffer_layers.py:55-131
+//   + PyTorch3D rasterize_points / compositing it calls   (third party, semantics in DESIGN.md)
+//
+// Pipeline (all on the caller's stream, no host sync, no allocation):
+//   k_project        1 thread / point: p = grid*depth, X = K (RT2 RT1inv) Kinv p, divide, EPS rule
+//   k_bin_count      conservative pixel bbox of each point's disc -> 8x8-pixel tiles, per-tile counts
+//   k_scan           exclusive scan of the B*tiles counters (one workgroup)
+//   k_bin_fill       64-bit keys (z bits << 32 | point index) appended to each touched tile's list
+//   k_sort_small/big per-tile sort of the keys (normalised bitonic network; LDS, or global for huge
+//                    lists).  Keys are unique, so the order -- ascending (z, index), PyTorch3D's CPU
+//                    tie-break -- is deterministic whatever order the atomics filled the list in.
+//   k_composite      one wave64 per tile, one lane per pixel: walk the sorted list front to back,
+//                    exact strict disc test, alpha from dist^2, blend on the fly, stop at K hits.
+//                    Nothing of size (S,S,K) is ever materialised unless the debug outputs are asked for.
+//   k_dilate         k x k binary dilation of the "no hit" mask (LDS tile + halo, separable max)
+//
+// Integer/index paths are bit-exact against oracle/ (this file is built with -ffp-contract=off: the
+// disc test dx*dx+dy*dy < r*r and the z ordering must not be perturbed by FMA contraction).
+#include <cmath>
+
+#include "ps_common.h"
+
+namespace {
+
+constexpr int TILE = 8;                  // pixels per tile edge: 64 pixels = one wave64
+constexpr float PS_EPS = 1e-2f;          // z_buffer_manipulator.py:8
+constexpr uint32_t CULLED = 0xFFFFFFFFu;
+constexpr int SORT_SMALL_CAP = 1024;     // keys sorted in LDS by one wave
+constexpr int SORT_BIG_CAP = 8192;       // keys sorted in LDS by a 1024-thread workgroup
+
+// ------------------------------------------------------------------------------------------
+// projection
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void mat4_vec(const float *M, const float *v, float *o)
+{
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float acc = M[i * 4 + 0] * v[0];
+        acc = acc + M[i * 4 + 1] * v[1];
+        acc = acc + M[i * 4 + 2] * v[2];
+        acc = acc + M[i * 4 + 3] * v[3];
+        o[i] = acc;
+    }
+}
+
+// sampler of one projected homogeneous point; X[2] is EPS-overwritten like the reference (:70-74)
+__device__ __forceinline__ void finish_point(float *X, float &sx, float &sy, float &sz)
+{
+    const bool bad = fabsf(X[2]) < PS_EPS;
+    if (bad) X[2] = PS_EPS;
+    float x = X[0] / (-X[2]);
+    float y = X[1] / (-X[2]);
+    float z = X[2];
+    if (bad) { x = -10.0f; y = -10.0f; z = -10.0f; }
+    sx = x * 1.0f;
+    sy = y * -1.0f;
+    sz = z * -1.0f;
+}
+
+// LAYOUT 0: sampler (B,3,NT) as the reference returns it; LAYOUT 1: (B,NT,3) with x,y negated, i.e.
+// exactly what PyTorch3D's rasterizer is handed after z_buffer_layers.py:71-72.
+// PRIOR: the source is a homogeneous prior cloud (B,4,n) transformed by K (RT2 RT3inv)  (:244-247).
+template <int LAYOUT, bool PRIOR>
+__global__ __launch_bounds__(256) void k_project(const float *__restrict__ src,
+                                                 const int32_t *__restrict__ new_index,
+                                                 const float *__restrict__ K,
+                                                 const float *__restrict__ Kinv,
+                                                 const float *__restrict__ RTa_inv,
+                                                 const float *__restrict__ RT2, int W, int n,
+                                                 int out_n, int out_off, float *__restrict__ out,
+                                                 float *__restrict__ cloud)
+{
+    __shared__ float sRT[16], sK[16], sKinv[16];
+    const int b = blockIdx.y;
+    if (threadIdx.x < 16) {
+        const int i = threadIdx.x >> 2, j = threadIdx.x & 3;
+        const float *A = RT2 + b * 16, *Bm = RTa_inv + b * 16;
+        float acc = A[i * 4 + 0] * Bm[0 * 4 + j];
+        acc = acc + A[i * 4 + 1] * Bm[1 * 4 + j];
+        acc = acc + A[i * 4 + 2] * Bm[2 * 4 + j];
+        acc = acc + A[i * 4 + 3] * Bm[3 * 4 + j];
+        sRT[threadIdx.x] = acc;
+        sK[threadIdx.x] = K[b * 16 + threadIdx.x];
+        if (!PRIOR) sKinv[threadIdx.x] = Kinv[b * 16 + threadIdx.x];
+    }
+    __syncthreads();
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    float X[4];
+    if (PRIOR) {
+        float p[4], w[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p[r] = src[((size_t)b * 4 + r) * n + t];
+        mat4_vec(sRT, p, w);
+        mat4_vec(sK, w, X);
+    } else {
+        const int g = new_index ? new_index[(size_t)b * n + t] : t;
+        const int gx = g % W, gy = g / W;
+        const float den = (float)(W - 1);
+        const float xs = (float)gx / den * 2.0f - 1.0f;  // linspace(0,W-1,W)/(W-1)*2-1  (:38-39)
+        const float ys = (float)gy / den * 2.0f - 1.0f;
+        const float d = src[(size_t)b * n + t];
+        float p[4] = {xs * d, (-ys) * d, -1.0f * d, 1.0f};
+        float c[4], w[4];
+        mat4_vec(sKinv, p, c);
+        mat4_vec(sRT, c, w);
+        mat4_vec(sK, w, X);
+    }
+    float sx, sy, sz;
+    finish_point(X, sx, sy, sz);
+    const int o = out_off + t;
+    if (LAYOUT == 0) {
+        out[((size_t)b * 3 + 0) * out_n + o] = sx;
+        out[((size_t)b * 3 + 1) * out_n + o] = sy;
+        out[((size_t)b * 3 + 2) * out_n + o] = sz;
+    } else {
+        float *q = out + ((size_t)b * out_n + o) * 3;
+        q[0] = -sx;
+        q[1] = -sy;
+        q[2] = sz;
+    }
+    if (cloud) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cloud[((size_t)b * 4 + r) * out_n + o] = X[r];
+    }
+}
+
+// z_buffer_layers.py:71-72 -- the reference negates x,y of the caller's tensor in place
+__global__ void k_negate_xy(float *pts, size_t npts)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npts) return;
+    pts[i * 3 + 1] = -pts[i * 3 + 1];
+    pts[i * 3 + 0] = -pts[i * 3 + 0];
+}
+
+// ------------------------------------------------------------------------------------------
+// binning
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float pix_to_ndc(int i, int S) { return -1.0f + (2 * i + 1.0f) / S; }
+
+// Conservative range of pixel indices whose centre can pass the strict disc test, per axis.
+// PyTorch3D tests output pixel xi against PixToNdc(S-1-xi); c is the point in reversed-index units.
+__device__ __forceinline__ bool axis_range(float p, int S, float hw, int &lo_px, int &hi_px)
+{
+    const float c = ((p + 1.0f) * S - 1.0f) * 0.5f;
+    float lo = c - hw, hi = c + hw;
+    if (!(hi >= 0.0f) || !(lo <= (float)(S - 1))) return false;  // also rejects NaN / inf
+    lo = fmaxf(lo, 0.0f);
+    hi = fminf(hi, (float)(S - 1));
+    const int ilo = (int)ceilf(lo), ihi = (int)floorf(hi);
+    if (ilo > ihi) return false;
+    lo_px = S - 1 - ihi;
+    hi_px = S - 1 - ilo;
+    return true;
+}
+
+__device__ __forceinline__ uint32_t point_bbox(const float *p, int S, float hw)
+{
+    const float px = p[0], py = p[1], pz = p[2];
+    if (!(pz >= 0.0f)) return CULLED;  // PyTorch3D skips pz < 0; NaN z is skipped too (documented)
+    int x0, x1, y0, y1;
+    if (!axis_range(px, S, hw, x0, x1) || !axis_range(py, S, hw, y0, y1)) return CULLED;
+    return (uint32_t)(x0 / TILE) | ((uint32_t)(y0 / TILE) << 8) | ((uint32_t)(x1 / TILE) << 16) |
+           ((uint32_t)(y1 / TILE) << 24);
+}
+
+__global__ __launch_bounds__(256) void k_bin_count(const float *__restrict__ pts, int N, int S,
+                                                   float hw, int tilesX, int NT,
+                                                   uint32_t *__restrict__ bbox,
+                                                   uint32_t *__restrict__ tile_count)
+{
+    const int b = blockIdx.y;
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const uint32_t bb = point_bbox(pts + ((size_t)b * N + n) * 3, S, hw);
+    bbox[(size_t)b * N + n] = bb;
+    if (bb == CULLED) return;
+    const int tx0 = bb & 255, ty0 = (bb >> 8) & 255, tx1 = (bb >> 16) & 255, ty1 = bb >> 24;
+    for (int ty = ty0; ty <= ty1; ++ty)
+        for (int tx = tx0; tx <= tx1; ++tx) atomicAdd(&tile_count[(size_t)b * NT + ty * tilesX + tx], 1u);
+}
+
+// exclusive scan of M counters in place; counters[M] receives the total.  One workgroup.
+__global__ __launch_bounds__(1024) void k_scan(uint32_t *__restrict__ counters, int M)
+{
+    __shared__ uint32_t part[1024];
+    const int t = threadIdx.x;
+    const int per = (M + 1023) / 1024;
+    const int beg = t * per, end = min(M, beg + per);
+    uint32_t s = 0;
+    for (int i = beg; i < end; ++i) s += counters[i];
+    part[t] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        uint32_t v = (t >= off) ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[t] - s;
+    for (int i = beg; i < end; ++i) {
+        const uint32_t c = counters[i];
+        counters[i] = run;
+        run += c;
+    }
+    if (t == 1023) counters[M] = part[1023];
+}
+
+__global__ __launch_bounds__(256) void k_bin_fill(const float *__restrict__ pts, int N, int tilesX,
+                                                  int NT, const uint32_t *__restrict__ bbox,
+                                                  const uint32_t *__restrict__ tile_off,
+                                                  uint32_t *__restrict__ tile_cursor,
+                                                  uint64_t *__restrict__ keys)
+{
+    const int b = blockIdx.y;
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const uint32_t bb = bbox[(size_t)b * N + n];
+    if (bb == CULLED) return;
+    const float z = pts[((size_t)b * N + n) * 3 + 2];
+    const uint32_t zkey = (z == 0.0f) ? 0u : __float_as_uint(z);  // -0.0 == +0.0 in the tuple compare
+    const uint64_t key = ((uint64_t)zkey << 32) | (uint32_t)n;
+    const int tx0 = bb & 255, ty0 = (bb >> 8) & 255, tx1 = (bb >> 16) & 255, ty1 = bb >> 24;
+    for (int ty = ty0; ty <= ty1; ++ty)
+        for (int tx = tx0; tx <= tx1; ++tx) {
+            const size_t t = (size_t)b * NT + ty * tilesX + tx;
+            const uint32_t pos = tile_off[t] + atomicAdd(&tile_cursor[t], 1u);
+            keys[pos] = key;
+        }
+}
+
+// ------------------------------------------------------------------------------------------
+// per-tile sort: normalised bitonic network (every comparator ascending), so elements beyond n act
+// as +inf without being stored.  `a` is LDS or global memory.
+// ------------------------------------------------------------------------------------------
+template <int THREADS, typename Ptr>
+__device__ __forceinline__ void bitonic_sort(Ptr a, int n)
+{
+    int P = 1;
+    while (P < n) P <<= 1;
+    const int half = P >> 1;
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int p = threadIdx.x; p < half; p += THREADS) {
+                int i, l;
+                if (j == (k >> 1)) {
+                    const int blk = p / j, w = p - blk * j;
+                    i = blk * k + w;
+                    l = blk * k + k - 1 - w;
+                } else {
+                    i = 2 * j * (p / j) + (p % j);
+                    l = i + j;
+                }
+                if (l < n) {
+                    const uint64_t x = a[i], y = a[l];
+                    if (x > y) { a[i] = y; a[l] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// one wave per tile; lists longer than SORT_SMALL_CAP are queued for k_sort_big
+__global__ __launch_bounds__(64) void k_sort_small(uint64_t *__restrict__ keys,
+                                                   const uint32_t *__restrict__ tile_off,
+                                                   uint32_t *__restrict__ worklist)
+{
+    __shared__ uint64_t s[SORT_SMALL_CAP];
+    const uint32_t t = blockIdx.x;
+    const uint32_t beg = tile_off[t], n = tile_off[t + 1] - beg;
+    if (n < 2) return;
+    if (n > SORT_SMALL_CAP) {
+        if (threadIdx.x == 0) worklist[1 + atomicAdd(&worklist[0], 1u)] = t;
+        return;
+    }
+    for (uint32_t i = threadIdx.x; i < n; i += 64) s[i] = keys[beg + i];
+    __syncthreads();
+    bitonic_sort<64>(s, (int)n);
+    for (uint32_t i = threadIdx.x; i < n; i += 64) keys[beg + i] = s[i];
+}
+
+__global__ __launch_bounds__(1024) void k_sort_big(uint64_t *__restrict__ keys,
+                                                   const uint32_t *__restrict__ tile_off,
+                                                   const uint32_t *__restrict__ worklist)
+{
+    __shared__ uint64_t s[SORT_BIG_CAP];
+    const uint32_t cnt = worklist[0];
+    for (uint32_t w = blockIdx.x; w < cnt; w += gridDim.x) {
+        const uint32_t t = worklist[1 + w];
+        const uint32_t beg = tile_off[t], n = tile_off[t + 1] - beg;
+        if (n <= SORT_BIG_CAP) {
+            for (uint32_t i = threadIdx.x; i < n; i += 1024) s[i] = keys[beg + i];
+            __syncthreads();
+            bitonic_sort<1024>(s, (int)n);
+            for (uint32_t i = threadIdx.x; i < n; i += 1024) keys[beg + i] = s[i];
+            __syncthreads();
+        } else {
+            bitonic_sort<1024>(keys + beg, (int)n);  // rare: degenerate clouds piling into one tile
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// composite: one wave per 8x8 tile, one lane per pixel
+// ------------------------------------------------------------------------------------------
+constexpr int CG = 4;  // channels accumulated per wave; grid.z walks channel groups
+
+__device__ __forceinline__ float bcast(float v, int lane)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+template <int MODE, bool DEBUG_OUT, bool RECIP>
+__global__ __launch_bounds__(64) void k_composite(
+    const uint64_t *__restrict__ keys, const uint32_t *__restrict__ tile_off,
+    const float *__restrict__ pts, const float *__restrict__ feat, int N, int C, int S, int tilesX,
+    int NT, float r2, float denom, float tau, int K, float *__restrict__ out_feat,
+    uint8_t *__restrict__ bg0, int32_t *__restrict__ out_idx, float *__restrict__ out_zbuf,
+    float *__restrict__ out_dist)
+{
+    const int tile = blockIdx.x, b = blockIdx.y, c0 = blockIdx.z * CG;
+    const int lane = threadIdx.x;
+    const int tx = tile % tilesX, ty = tile / tilesX;
+    const int xi = tx * TILE + (lane & 7), yi = ty * TILE + (lane >> 3);
+    const bool valid = xi < S && yi < S;
+    const float xf = pix_to_ndc(S - 1 - xi, S), yf = pix_to_ndc(S - 1 - yi, S);
+    const uint32_t beg = tile_off[(size_t)b * NT + tile], end = tile_off[(size_t)b * NT + tile + 1];
+    const int ncg = min(CG, C - c0);
+    const size_t pix = ((size_t)b * S + yi) * S + xi;
+
+    float acc[CG];
+#pragma unroll
+    for (int c = 0; c < CG; ++c) acc[c] = 0.0f;
+    float cum = 1.0f, tsum = 0.0f;
+    int cnt = 0;
+
+    for (int pass = (MODE == PS_ACC_WSUMNORM ? 0 : 1); pass < 2; ++pass) {
+        cnt = 0;
+        if (MODE == PS_ACC_WSUMNORM && pass == 1 && tsum < 1e-4f) tsum = 1e-4f;
+        for (uint32_t base = beg; base < end; base += 64) {
+            const int m = min(64u, end - base);
+            // cooperative stage: lane j fetches record j of this batch
+            float rx = INFINITY, ry = 0.0f, rz = 0.0f;
+            float rf[CG];
+#pragma unroll
+            for (int c = 0; c < CG; ++c) rf[c] = 0.0f;
+            uint32_t rn = 0;
+            if (lane < m) {
+                rn = (uint32_t)keys[base + lane];
+                const float *p = pts + ((size_t)b * N + rn) * 3;
+                rx = p[0];
+                ry = p[1];
+                rz = p[2];
+                if (pass == 1) {
+#pragma unroll
+                    for (int c = 0; c < CG; ++c)
+                        if (c < ncg) rf[c] = feat[((size_t)b * C + c0 + c) * N + rn];
+                }
+            }
+#pragma unroll 1
+            for (int j8 = 0; j8 < 64; j8 += 8) {
+                if (j8 >= m) break;
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) {
+                    const int j = j8 + jj;
+                    // Broadcasts are wave-uniform reads (v_readlane ignores EXEC), hoisted out of the
+                    // divergent hit branch.  Lanes >= m carry rx = +inf: dx*dx = inf never passes.
+                    const float sx = bcast(rx, j);
+                    const float sy = bcast(ry, j);
+                    float sf[CG];
+#pragma unroll
+                    for (int c = 0; c < CG; ++c) sf[c] = bcast(rf[c], j);
+                    const uint32_t sn = DEBUG_OUT ? (uint32_t)__builtin_amdgcn_readlane((int)rn, j) : 0u;
+                    const float sz = DEBUG_OUT ? bcast(rz, j) : 0.0f;
+                    const float dx = sx - xf, dy = sy - yf;
+                    const float d2 = dx * dx + dy * dy;
+                    if (valid && d2 < r2 && cnt < K) {
+                        float d = RECIP ? d2 * denom : d2 / denom;
+                        d = fminf(fmaxf(d, 1e-3f), 1.0f);
+                        float a = 1.0f - sqrtf(d);
+                        if (tau != 1.0f) a = powf(a, tau);
+                        if (MODE == PS_ACC_WSUMNORM && pass == 0) {
+                            tsum = tsum + a;
+                        } else {
+#pragma unroll
+                            for (int c = 0; c < CG; ++c) {
+                                const float f = sf[c];
+                                if (MODE == PS_ACC_ALPHACOMPOSITE) acc[c] = acc[c] + f * cum * a;
+                                else if (MODE == PS_ACC_WSUM) acc[c] = acc[c] + f * a;
+                                else acc[c] = acc[c] + f * a / tsum;
+                            }
+                            if (MODE == PS_ACC_ALPHACOMPOSITE) cum = cum * (1.0f - a);
+                            if (DEBUG_OUT && blockIdx.z == 0) {
+                                if (out_idx) out_idx[pix * K + cnt] = (int32_t)(b * N + sn);
+                                if (out_zbuf) out_zbuf[pix * K + cnt] = sz;
+                                if (out_dist) out_dist[pix * K + cnt] = d2;
+                            }
+                        }
+                        ++cnt;
+                    }
+                }
+            }
+            if (__all((cnt >= K) || !valid)) break;
+        }
+    }
+    if (!valid) return;
+#pragma unroll
+    for (int c = 0; c < CG; ++c)
+        if (c < ncg) out_feat[((size_t)b * C + c0 + c) * S * S + (size_t)yi * S + xi] = acc[c];
+    if (blockIdx.z == 0) {
+        bg0[pix] = (uint8_t)(cnt == 0);
+        if (DEBUG_OUT) {
+            for (int k = cnt; k < K; ++k) {
+                if (out_idx) out_idx[pix * K + k] = -1;
+                if (out_zbuf) out_zbuf[pix * K + k] = -1.0f;
+                if (out_dist) out_dist[pix * K + k] = -1.0f;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// background-mask dilation: conv2d(ones k x k, zero pad k//2) > 0   (z_buffer_layers.py:105-110)
+// ------------------------------------------------------------------------------------------
+constexpr int DT = 32;        // output tile edge
+constexpr int DMAXH = 15;     // supports ksize <= 31
+__global__ __launch_bounds__(256) void k_dilate(const uint8_t *__restrict__ bg0, int S, int h,
+                                                uint8_t *__restrict__ bg)
+{
+    __shared__ uint8_t in[DT + 2 * DMAXH][DT + 2 * DMAXH + 2];
+    __shared__ uint8_t row[DT + 2 * DMAXH][DT];
+    const int b = blockIdx.z;
+    const int x0 = blockIdx.x * DT, y0 = blockIdx.y * DT;
+    const int E = DT + 2 * h;
+    for (int i = threadIdx.x; i < E * E; i += 256) {
+        const int ly = i / E, lx = i % E;
+        const int y = y0 + ly - h, x = x0 + lx - h;
+        in[ly][lx] = (y >= 0 && y < S && x >= 0 && x < S) ? bg0[((size_t)b * S + y) * S + x] : 0;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < E * DT; i += 256) {
+        const int ly = i / DT, lx = i % DT;
+        uint8_t m = 0;
+        for (int d = 0; d <= 2 * h; ++d) m |= in[ly][lx + d];
+        row[ly][lx] = m;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < DT * DT; i += 256) {
+        const int ly = i / DT, lx = i % DT;
+        const int y = y0 + ly, x = x0 + lx;
+        if (y >= S || x >= S) continue;
+        uint8_t m = 0;
+        for (int d = 0; d <= 2 * h; ++d) m |= row[ly + d][lx];
+        bg[((size_t)b * S + y) * S + x] = m ? 1 : 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+struct SplatPlan {
+    int tilesX, NT, max_tiles_pp;
+    float hw;
+    size_t off_pts, off_bbox, off_count, off_cursor, off_work, off_bg0, off_keys, total;
+};
+
+SplatPlan make_plan(int B, int N, int S, double radius_px)
+{
+    SplatPlan p;
+    p.tilesX = (S + TILE - 1) / TILE;
+    p.NT = p.tilesX * p.tilesX;
+    p.hw = (float)(radius_px * 1.0001 + 0.01);
+    const int span_px = (int)(2.0 * p.hw) + 2;
+    const int span_t = (span_px + TILE - 2) / TILE + 1;
+    p.max_tiles_pp = span_t * span_t;
+    size_t o = 0;
+    const size_t M = (size_t)B * p.NT;
+    p.off_pts = o;    o = ps::align_up(o + (size_t)B * N * 3 * sizeof(float), 256);
+    p.off_bbox = o;   o = ps::align_up(o + (size_t)B * N * sizeof(uint32_t), 256);
+    p.off_count = o;  o = ps::align_up(o + (M + 1) * sizeof(uint32_t), 256);
+    p.off_cursor = o; o = ps::align_up(o + M * sizeof(uint32_t), 256);
+    p.off_work = o;   o = ps::align_up(o + (M + 1) * sizeof(uint32_t), 256);
+    p.off_bg0 = o;    o = ps::align_up(o + (size_t)B * S * S, 256);
+    p.off_keys = o;   o = ps::align_up(o + (size_t)B * N * p.max_tiles_pp * sizeof(uint64_t), 256);
+    p.total = o;
+    return p;
+}
+
+template <int MODE>
+void launch_composite(bool debug, bool recip, dim3 grid, hipStream_t st, const uint64_t *keys,
+                      const uint32_t *tile_off, const float *pts, const float *feat, int N, int C,
+                      int S, int tilesX, int NT, float r2, float denom, float tau, int K,
+                      float *out_feat, uint8_t *bg0, int32_t *out_idx, float *out_zbuf,
+                      float *out_dist)
+{
+#define PS_COMPOSITE(DBG, RCP)                                                                     \
+    hipLaunchKernelGGL((k_composite<MODE, DBG, RCP>), grid, dim3(64), 0, st, keys, tile_off, pts,  \
+                       feat, N, C, S, tilesX, NT, r2, denom, tau, K, out_feat, bg0, out_idx,       \
+                       out_zbuf, out_dist)
+    if (debug) { if (recip) PS_COMPOSITE(true, true); else PS_COMPOSITE(true, false); }
+    else       { if (recip) PS_COMPOSITE(false, true); else PS_COMPOSITE(false, false); }
+#undef PS_COMPOSITE
+}
+
+// rasterize + composite + dilate on pts (B,N,3) already in PyTorch3D orientation (x,y negated)
+int splat_core(const float *pts, const float *feat, int B, int N, int C, int S, double radius_px,
+               int K, float tau, int rad_pow, int accumulation, int bg_ksize, float *out_feat,
+               uint8_t *out_bg, int32_t *out_idx, float *out_zbuf, float *out_dist, char *ws,
+               const SplatPlan &p, hipStream_t st)
+{
+    const size_t M = (size_t)B * p.NT;
+    uint32_t *bbox = (uint32_t *)(ws + p.off_bbox);
+    uint32_t *tile_off = (uint32_t *)(ws + p.off_count);
+    uint32_t *cursor = (uint32_t *)(ws + p.off_cursor);
+    uint32_t *work = (uint32_t *)(ws + p.off_work);
+    uint8_t *bg0 = (uint8_t *)(ws + p.off_bg0);
+    uint64_t *keys = (uint64_t *)(ws + p.off_keys);
+
+    // radius exactly as the reference computes it: python double, then float at the PyTorch3D call
+    const double radius = radius_px / (double)S * 2.0;            // z_buffer_layers.py:77
+    const float rf = (float)radius;
+    const float r2 = rf * rf;
+    const float denom = (float)pow(radius, (double)rad_pow);       // :89
+    int e = 0;
+    const bool pow2 = std::frexp(denom, &e) == 0.5f;               // then d2/denom == d2*(1/denom) exactly
+    const float denom_arg = pow2 ? 1.0f / denom : denom;
+
+    // counters (count + cursor + worklist are adjacent) start from zero every call
+    PS_HIP_CHECK(hipMemsetAsync(ws + p.off_count, 0, p.off_bg0 - p.off_count, st));
+    const dim3 gpt((N + 255) / 256, B);
+    hipLaunchKernelGGL(k_bin_count, gpt, dim3(256), 0, st, pts, N, S, p.hw, p.tilesX, p.NT, bbox, tile_off);
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, tile_off, (int)M);
+    hipLaunchKernelGGL(k_bin_fill, gpt, dim3(256), 0, st, pts, N, p.tilesX, p.NT, bbox, tile_off, cursor, keys);
+    hipLaunchKernelGGL(k_sort_small, dim3((unsigned)M), dim3(64), 0, st, keys, tile_off, work);
+    hipLaunchKernelGGL(k_sort_big, dim3(128), dim3(1024), 0, st, keys, tile_off, work);
+    const dim3 gc(p.NT, B, (C + CG - 1) / CG);
+    const bool debug = out_idx || out_zbuf || out_dist;
+    switch (accumulation) {
+    case PS_ACC_ALPHACOMPOSITE:
+        launch_composite<PS_ACC_ALPHACOMPOSITE>(debug, pow2, gc, st, keys, tile_off, pts, feat, N, C, S, p.tilesX,
+                                                p.NT, r2, denom_arg, tau, K, out_feat, bg0, out_idx, out_zbuf, out_dist);
+        break;
+    case PS_ACC_WSUM:
+        launch_composite<PS_ACC_WSUM>(debug, pow2, gc, st, keys, tile_off, pts, feat, N, C, S, p.tilesX, p.NT, r2,
+                                      denom_arg, tau, K, out_feat, bg0, out_idx, out_zbuf, out_dist);
+        break;
+    default:
+        launch_composite<PS_ACC_WSUMNORM>(debug, pow2, gc, st, keys, tile_off, pts, feat, N, C, S, p.tilesX, p.NT,
+                                          r2, denom_arg, tau, K, out_feat, bg0, out_idx, out_zbuf, out_dist);
+        break;
+    }
+    const dim3 gd((S + DT - 1) / DT, (S + DT - 1) / DT, B);
+    hipLaunchKernelGGL(k_dilate, gd, dim3(256), 0, st, bg0, S, bg_ksize / 2, out_bg);
+    PS_LAUNCH_CHECK();
+    return PS_OK;
+}
+
+int check_splat_args(int B, int N, int C, int S, double radius_px, int K, int accumulation, int bg_ksize)
+{
+    PS_REQUIRE(B > 0 && N > 0 && C > 0 && S > 1 && K > 0, "splat: B,N,C,K must be > 0 and S > 1");
+    PS_REQUIRE(S <= 2048, "splat: image size %d > 2048 unsupported", S);
+    PS_REQUIRE(radius_px > 0 && radius_px <= 64, "splat: radius_px %.3f out of range (0,64]", radius_px);
+    PS_REQUIRE(accumulation >= 0 && accumulation <= 2, "splat: unknown accumulation %d", accumulation);
+    PS_REQUIRE(bg_ksize >= 1 && (bg_ksize & 1) && bg_ksize <= 2 * DMAXH + 1, "splat: bg_ksize %d must be odd and <= %d",
+               bg_ksize, 2 * DMAXH + 1);
+    PS_REQUIRE((size_t)B * N < 0x7FFFFFFFull, "splat: B*N overflows the packed int32 index");
+    return PS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t ps_splat_workspace_bytes(int B, int N, int S, double radius_px)
+{
+    if (B <= 0 || N <= 0 || S <= 1 || radius_px <= 0) return 0;
+    return make_plan(B, N, S, radius_px).total;
+}
+
+int ps_project_pts_f32(const float *depth, const float *K, const float *Kinv, const float *RT1inv,
+                       const float *RT2, int B, int W, float *sampler, void *stream)
+{
+    PS_REQUIRE(depth && K && Kinv && RT1inv && RT2 && sampler, "project_pts: null pointer");
+    PS_REQUIRE(B > 0 && W > 1, "project_pts: B > 0 and W > 1 required");
+    const int N = W * W;
+    hipLaunchKernelGGL((k_project<0, false>), dim3((N + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, depth,
+                       (const int32_t *)nullptr, K, Kinv, RT1inv, RT2, W, N, N, 0, sampler, (float *)nullptr);
+    PS_LAUNCH_CHECK();
+    return PS_OK;
+}
+
+int ps_project_pts_cumulative_f32(const float *depth_new, const int32_t *new_index, const float *prior,
+                                  const float *K, const float *Kinv, const float *RT1inv, const float *RT2,
+                                  const float *RT3inv, int B, int W, int n_new, int n_prior, float *sampler,
+                                  float *cloud, void *stream)
+{
+    PS_REQUIRE(K && Kinv && RT1inv && RT2 && sampler && cloud, "project_pts_cumulative: null pointer");
+    PS_REQUIRE(B > 0 && W > 1 && n_new >= 0 && n_prior >= 0 && n_new + n_prior > 0, "project_pts_cumulative: bad sizes");
+    PS_REQUIRE(new_index || n_new == W * W || n_new == 0, "project_pts_cumulative: n_new != W*W needs new_index");
+    PS_REQUIRE(n_prior == 0 || (prior && RT3inv), "project_pts_cumulative: prior cloud needs RT3inv");
+    const int NTt = n_new + n_prior;
+    hipStream_t st = (hipStream_t)stream;
+    if (n_new > 0) {
+        PS_REQUIRE(depth_new, "project_pts_cumulative: depth_new is null");
+        hipLaunchKernelGGL((k_project<0, false>), dim3((n_new + 255) / 256, B), dim3(256), 0, st, depth_new, new_index,
+                           K, Kinv, RT1inv, RT2, W, n_new, NTt, 0, sampler, cloud);
+    }
+    if (n_prior > 0)
+        hipLaunchKernelGGL((k_project<0, true>), dim3((n_prior + 255) / 256, B), dim3(256), 0, st, prior,
+                           (const int32_t *)nullptr, K, Kinv, RT3inv, RT2, W, n_prior, NTt, n_new, sampler, cloud);
+    PS_LAUNCH_CHECK();
+    return PS_OK;
+}
+
+int ps_splat_f32(float *pts, const float *feat, int B, int N, int C, int S, double radius_px, int K, float tau,
+                 int rad_pow, int accumulation, int bg_ksize, float *out_feat, uint8_t *out_bg, int32_t *out_idx,
+                 float *out_zbuf, float *out_dist, void *workspace, size_t workspace_bytes, void *stream)
+{
+    PS_REQUIRE(pts && feat && out_feat && out_bg && workspace, "splat: null pointer");
+    if (int rc = check_splat_args(B, N, C, S, radius_px, K, accumulation, bg_ksize)) return rc;
+    const SplatPlan p = make_plan(B, N, S, radius_px);
+    if (workspace_bytes < p.total)
+        return ps::fail(PS_ERR_WORKSPACE, "splat: workspace %zu < required %zu bytes", workspace_bytes, p.total);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t npts = (size_t)B * N;
+    hipLaunchKernelGGL(k_negate_xy, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, st, pts, npts);
+    return splat_core(pts, feat, B, N, C, S, radius_px, K, tau, rad_pow, accumulation, bg_ksize, out_feat, out_bg,
+                      out_idx, out_zbuf, out_dist, (char *)workspace, p, st);
+}
+
+int ps_project_splat_f32(const float *depth, const float *feat, const float *K, const float *Kinv,
+                         const float *RT1inv, const float *RT2, int B, int C, int S, double radius_px, int Kpp,
+                         float tau, int rad_pow, int accumulation, int bg_ksize, float *out_feat, uint8_t *out_bg,
+                         void *workspace, size_t workspace_bytes, void *stream)
+{
+    PS_REQUIRE(depth && feat && K && Kinv && RT1inv && RT2 && out_feat && out_bg && workspace,
+               "project_splat: null pointer");
+    const int N = S * S;
+    if (int rc = check_splat_args(B, N, C, S, radius_px, Kpp, accumulation, bg_ksize)) return rc;
+    const SplatPlan p = make_plan(B, N, S, radius_px);
+    if (workspace_bytes < p.total)
+        return ps::fail(PS_ERR_WORKSPACE, "project_splat: workspace %zu < required %zu bytes", workspace_bytes, p.total);
+    hipStream_t st = (hipStream_t)stream;
+    float *pts = (float *)((char *)workspace + p.off_pts);
+    hipLaunchKernelGGL((k_project<1, false>), dim3((N + 255) / 256, B), dim3(256), 0, st, depth,
+                       (const int32_t *)nullptr, K, Kinv, RT1inv, RT2, S, N, N, 0, pts, (float *)nullptr);
+    return splat_core(pts, feat, B, N, C, S, radius_px, Kpp, tau, rad_pow, accumulation, bg_ksize, out_feat, out_bg,
+                      nullptr, nullptr, nullptr, (char *)workspace, p, st);
+}
+
+}  // extern "C"

@@ -1,0 +1,257 @@
+"""GPU parity tests of the reprojection + soft z-buffer splat (through the C ABI) against the oracle.
+
+Bar: bit-exact for the integer / index paths (idx, background mask, K-selection, z order);
+projection bit-exact against the C oracle (same operation order) and within 2e-5 of the reference
+golden vectors; composited features <= 1e-6 abs (stated per test)."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle
+from pixelsynth_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def opts(**kw):
+    o = dict(splatter="xyblending", learn_default_feature=True, radius=4, pp_pixel=128, tau=1.0, rad_pow=2,
+             accumulation="alphacomposite", background_smoothing_kernel_size=13)
+    o.update(kw)
+    return types.SimpleNamespace(**o)
+
+
+def make_splatter(S, K, radius=4, **kw):
+    from pixelsynth_amd.layers.z_buffer_layers import RasterizePointsXYsBlending
+    o = opts(radius=radius, pp_pixel=K, **kw)
+    return RasterizePointsXYsBlending(3, True, radius, S, K, o).to(dev())
+
+
+def cloud(seed, B, N, spread=1.2, zlo=-0.2):
+    rs = np.random.RandomState(seed)
+    pts = np.empty((B, N, 3), np.float32)
+    pts[..., :2] = (rs.rand(B, N, 2) * 2 - 1) * spread
+    pts[..., 2] = rs.rand(B, N) * 5 + zlo
+    return pts
+
+
+def run_splat(sp, pts, feat):
+    tp = torch.from_numpy(pts).to(dev())
+    tf = torch.from_numpy(feat).to(dev())
+    out, bg, idx, zbuf, dist = sp(tp, tf, return_debug=True)
+    torch.cuda.synchronize()
+    return dict(feat=out.cpu().numpy(), bg=bg.cpu().numpy(), idx=idx.cpu().numpy(), zbuf=zbuf.cpu().numpy(),
+                dist=dist.cpu().numpy(), pts_after=tp.cpu().numpy())
+
+
+def check(got, ref, feat_tol=1e-6):
+    assert np.array_equal(got["idx"], ref["idx"]), f"idx mismatch: {(got['idx'] != ref['idx']).sum()} entries"
+    assert np.array_equal(got["zbuf"], ref["zbuf"])
+    assert np.array_equal(got["dist"], ref["dist"])
+    assert np.array_equal(got["bg"], ref["bg"])
+    assert np.array_equal(got["pts_after"], ref["pts_after"], equal_nan=True)  # in-place negation side effect
+    np.testing.assert_allclose(got["feat"], ref["feat"], rtol=0, atol=feat_tol)
+
+
+@pytest.mark.parametrize("S,N,K,radius", [(32, 700, 8, 4), (64, 5000, 16, 4), (20, 300, 4, 2.5), (48, 2000, 128, 6)])
+def test_rasterize_bit_exact_small(S, N, K, radius):
+    pts = cloud(S + N, 2, N)
+    pts[0, : N // 10, 2] = 1.25  # z ties -> ascending point index
+    pts[1, :5, 2] = 0.0
+    pts[1, 5:8, 2] = -0.0
+    pts[1, 8:10, 0] = np.inf
+    pts[1, 10:12, 1] = np.nan
+    feat = np.random.RandomState(1).rand(2, 3, N).astype(np.float32) * 2 - 1
+    sp = make_splatter(S, K, radius)
+    check(run_splat(sp, pts, feat), c_oracle.splat_forward(pts, feat, S, radius_px=radius, K=K))
+
+
+def test_edge_cases():
+    S, K = 32, 8
+    sp = make_splatter(S, K)
+    feat = np.ones((1, 3, 64), np.float32)
+    # all points behind the camera / off screen: everything is background, features zero
+    pts = cloud(5, 1, 64)
+    pts[..., 2] = -1.0
+    got = run_splat(sp, pts, feat)
+    assert got["bg"].all() and (got["idx"] == -1).all() and (got["feat"] == 0).all()
+    pts = cloud(6, 1, 64)
+    pts[..., 0] += 10
+    got = run_splat(sp, pts, feat)
+    assert got["bg"].all() and (got["feat"] == 0).all()
+    # a single point
+    pts = np.array([[[0.1, -0.2, 2.0]]], np.float32)
+    check(run_splat(sp, pts, np.ones((1, 3, 1), np.float32)), c_oracle.splat_forward(pts, np.ones((1, 3, 1), np.float32), S, K=K))
+
+
+@pytest.mark.parametrize("N", [3000, 20000])
+def test_degenerate_pileup_exercises_big_sort(N):
+    """All points inside one tile: list > 1024 (LDS workgroup sort) and > 8192 (global-memory sort)."""
+    S, K = 32, 128
+    rs = np.random.RandomState(N)
+    pts = np.empty((1, N, 3), np.float32)
+    pts[..., :2] = rs.rand(1, N, 2) * 0.2 - 0.1
+    pts[..., 2] = rs.randint(1, 40, size=(1, N)).astype(np.float32) * 0.25  # many z ties
+    feat = rs.rand(1, 3, N).astype(np.float32)
+    sp = make_splatter(S, K)
+    check(run_splat(sp, pts, feat), c_oracle.splat_forward(pts, feat, S, K=K))
+
+
+@pytest.mark.parametrize("acc,tau,tol", [("wsum", 1.0, 1e-5), ("wsumnorm", 1.0, 1e-6), ("alphacomposite", 0.5, 1e-5),
+                                         ("wsumnorm", 2.0, 1e-5)])
+def test_accumulation_modes(acc, tau, tol):
+    S, N, K = 40, 3000, 16
+    pts = cloud(11, 2, N)
+    feat = np.random.RandomState(2).rand(2, 3, N).astype(np.float32)
+    sp = make_splatter(S, K, accumulation=acc, tau=tau, background_smoothing_kernel_size=5)
+    ref = c_oracle.splat_forward(pts, feat, S, K=K, accumulation=acc, tau=tau, bg_ksize=5)
+    check(run_splat(sp, pts, feat), ref, feat_tol=tol)
+
+
+def test_many_channels_and_rad_pow():
+    """C=7 (two channel groups) and a non power-of-two radius (true division path)."""
+    from pixelsynth_amd.layers.z_buffer_layers import RasterizePointsXYsBlending
+    S, N, K = 24, 800, 8
+    pts = cloud(13, 1, N)
+    feat = np.random.RandomState(4).rand(1, 7, N).astype(np.float32)
+    o = opts(radius=3, pp_pixel=K, rad_pow=2, background_smoothing_kernel_size=3)
+    sp = RasterizePointsXYsBlending(7, True, 3, S, K, o).to(dev())
+    check(run_splat(sp, pts, feat), c_oracle.splat_forward(pts, feat, S, radius_px=3, K=K, bg_ksize=3), feat_tol=1e-6)
+
+
+def _manip(W, K=128):
+    from pixelsynth_amd.projection.z_buffer_manipulator import PtsManipulator
+    return PtsManipulator(W, C=3, opt=opts(pp_pixel=K)).to(dev())
+
+
+def tt(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev())
+
+
+def test_project_pts_vs_oracle_and_golden(golden_dir):
+    fx = np.load(os.path.join(golden_dir, "projection.npz"))
+    cam = syn.demo_cameras(1)
+    for name in ("demo_L", "demo_R", "demo_circle5"):
+        RT2 = fx[f"pose_{name}_RT2"]
+        for W, stride in ((16, 1), (256, 61)):
+            pm = _manip(W)
+            d = syn.depth_uniform(7, 2, W, 1.0, 100.0)
+            rep = lambda m: tt(np.repeat(m, 2, 0))
+            s = pm.project_pts(tt(d).view(2, 1, -1), rep(cam["K"]), rep(cam["Kinv"]), rep(cam["P"]), rep(cam["Pinv"]),
+                               rep(RT2), rep(fx[f"pose_{name}_RT2inv"])).cpu().numpy()
+            np.testing.assert_allclose(s[:, :, ::stride], fx[f"proj_{name}_W{W}"], rtol=2e-5, atol=2e-5)
+            ref = c_oracle.project_pts(d, np.repeat(cam["K"], 2, 0), np.repeat(cam["Kinv"], 2, 0),
+                                       np.repeat(cam["Pinv"], 2, 0), np.repeat(RT2, 2, 0), W)
+            assert np.array_equal(s, ref), f"{name} W{W}: {np.abs(s - ref).max()}"
+
+
+def test_project_pts_cumulative_vs_golden(golden_dir):
+    fx = np.load(os.path.join(golden_dir, "projection.npz"))
+    cam = syn.demo_cameras(1)
+    pm = _manip(16)
+    RT2inv = np.linalg.inv(fx["cum_RT2"].astype(np.float64)).astype(np.float32)
+    s, cloud_ = pm.project_pts_cumulative(tt(fx["cum_depth_new"]), tt(cam["K"]), tt(cam["Kinv"]), tt(cam["P"]),
+                                          tt(cam["Pinv"]), tt(fx["cum_RT2"]), tt(RT2inv), tt(fx["cum_prior"]),
+                                          tt(fx["cum_last_bg"]).view(1, 1, -1), tt(fx["cum_RT3inv"]))
+    np.testing.assert_allclose(s.cpu().numpy(), fx["cum_sampler"], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(cloud_.cpu().numpy(), fx["cum_cloud"], rtol=2e-5, atol=2e-5)
+    rs, rc = c_oracle.project_pts_cumulative(fx["cum_depth_new"], fx["cum_last_bg"], fx["cum_prior"], cam["K"],
+                                             cam["Kinv"], cam["Pinv"], fx["cum_RT2"], fx["cum_RT3inv"], 16)
+    assert np.array_equal(s.cpu().numpy(), rs) and np.array_equal(cloud_.cpu().numpy(), rc)
+
+
+def _frame_inputs(B, S, seed=0, smooth=False, yaw=0.6):
+    cam = syn.demo_cameras(B)
+    RT2inv, RT2 = syn.yaw_pose(cam["P"], yaw)
+    img = syn.image(seed, B, 3, S)
+    depth = (syn.depth_smooth if smooth else syn.depth_uniform)(seed + 1, B, S, 1.0, 100.0)
+    return cam, RT2, RT2inv, img, depth
+
+
+@pytest.mark.parametrize("smooth", [False, True])
+def test_forward_justpts_full_size_vs_oracle(smooth):
+    """256x256, K=128, r=4 (the shipped configuration), B=2: fused project+splat == oracle project -> oracle splat."""
+    B, S = 2, 256
+    cam, RT2, RT2inv, img, depth = _frame_inputs(B, S, seed=3, smooth=smooth)
+    pm = _manip(S)
+    feat, bg = pm.forward_justpts(tt(img), tt(depth), tt(cam["K"]), tt(cam["Kinv"]), tt(cam["P"]), tt(cam["Pinv"]),
+                                  tt(RT2), tt(RT2inv))
+    sampler = c_oracle.project_pts(depth, cam["K"], cam["Kinv"], cam["Pinv"], RT2, S)
+    ref = c_oracle.splat_forward(np.ascontiguousarray(sampler.transpose(0, 2, 1)), img.reshape(B, 3, -1), S)
+    assert np.array_equal(bg.cpu().numpy(), ref["bg"])
+    np.testing.assert_allclose(feat.cpu().numpy(), ref["feat"], rtol=0, atol=1e-6)
+    assert 0.05 < ref["bg"].mean() < 0.98
+    # the unfused route (project_pts -> permute -> splatter) gives the same bits, and exposes idx
+    s = pm.project_pts(tt(depth).view(B, 1, -1), tt(cam["K"]), tt(cam["Kinv"]), tt(cam["P"]), tt(cam["Pinv"]), tt(RT2), tt(RT2inv))
+    pc = s.permute(0, 2, 1).contiguous()
+    f2, bg2, idx, zbuf, dist = pm.splatter(pc, tt(img).view(B, 3, -1), return_debug=True)
+    assert torch.equal(f2, feat) and torch.equal(bg2, bg)
+    assert np.array_equal(idx.cpu().numpy(), ref["idx"])
+    assert np.array_equal(dist.cpu().numpy(), ref["dist"])
+
+
+def test_batch32_properties():
+    """C2 shape: B=32 clouds of 65536 points.  Full oracle comparison on 2 frames, size-independent
+    properties on all: batch independence (frame b of the batch == the same frame run alone), determinism
+    (two runs give identical bits), linearity in the features."""
+    B, S = 32, 256
+    cam, RT2, RT2inv, img, depth = _frame_inputs(B, S, seed=7)
+    for b in range(B):  # a different pose per frame
+        inv, rt = syn.yaw_pose(cam["P"][b:b + 1], -0.6 + 1.2 * b / (B - 1))
+        RT2[b], RT2inv[b] = rt[0], inv[0]
+    pm = _manip(S)
+    args = (tt(cam["K"]), tt(cam["Kinv"]), tt(cam["P"]), tt(cam["Pinv"]), tt(RT2), tt(RT2inv))
+    f1, bg1 = pm.forward_justpts(tt(img), tt(depth), *args)
+    f2, bg2 = pm.forward_justpts(tt(img), tt(depth), *args)
+    assert torch.equal(f1, f2) and torch.equal(bg1, bg2)
+    for b in (0, 13, 31):
+        sl = slice(b, b + 1)
+        fa, ba = pm.forward_justpts(tt(img[sl]), tt(depth[sl]), *[a[sl] for a in args])
+        assert torch.equal(fa[0], f1[b]) and torch.equal(ba[0], bg1[b])
+    f3, _ = pm.forward_justpts(tt(img * 2), tt(depth), *args)
+    torch.testing.assert_close(f3, 2 * f1, rtol=1e-6, atol=1e-6)
+    for b in (5, 20):
+        sampler = c_oracle.project_pts(depth[b:b + 1], cam["K"][b:b + 1], cam["Kinv"][b:b + 1], cam["Pinv"][b:b + 1],
+                                       RT2[b:b + 1], S)
+        ref = c_oracle.splat_forward(np.ascontiguousarray(sampler.transpose(0, 2, 1)), img[b:b + 1].reshape(1, 3, -1), S)
+        assert np.array_equal(bg1[b].cpu().numpy(), ref["bg"][0])
+        np.testing.assert_allclose(f1[b].cpu().numpy(), ref["feat"][0], rtol=0, atol=1e-6)
+
+
+def test_cumulative_scene_step_vs_oracle():
+    """forward_justpts_cumulative (scene mode): new points filtered by the last mask + a prior cloud."""
+    S = 64
+    cam, RT2, RT2inv, img, depth = _frame_inputs(1, S, seed=9, yaw=0.3)
+    pm = _manip(S, K=32)
+    r0 = pm.forward_justpts_cumulative(tt(img), tt(depth), tt(cam["K"]), tt(cam["Kinv"]), tt(cam["P"]), tt(cam["Pinv"]),
+                                       tt(RT2), tt(RT2inv), None, None, None, None)
+    feat0, bg0, cloud0, src0 = r0
+    s0, c0 = c_oracle.project_pts_cumulative(depth, None, None, cam["K"], cam["Kinv"], cam["Pinv"], RT2, None, S)
+    assert np.array_equal(cloud0.cpu().numpy(), c0)
+    ref0 = c_oracle.splat_forward(np.ascontiguousarray(s0.transpose(0, 2, 1)), img.reshape(1, 3, -1), S, K=32)
+    assert np.array_equal(bg0.cpu().numpy(), ref0["bg"])
+    # second step: current view becomes the source, target yaw 0.45
+    RT3inv = RT2inv
+    RTinv_b, RT_b = syn.yaw_pose(cam["P"], 0.45)
+    img2 = syn.image(21, 1, 3, S)
+    depth2 = syn.depth_uniform(22, 1, S, 1.0, 100.0)
+    n_bg = int(ref0["bg"].sum())
+    assert 0 < n_bg < S * S
+    feat1, bg1, cloud1, src1 = pm.forward_justpts_cumulative(
+        tt(img2), tt(depth2), tt(cam["K"]), tt(cam["Kinv"]), tt(RT2), tt(RT2inv), tt(RT_b), tt(RTinv_b), cloud0, src0,
+        bg0, tt(RT3inv))
+    m = ref0["bg"].reshape(1, -1)
+    s1, c1 = c_oracle.project_pts_cumulative(depth2.reshape(1, -1)[m].reshape(1, 1, -1), m, c0, cam["K"], cam["Kinv"],
+                                             RT2inv, RT_b, RT3inv, S)
+    assert np.array_equal(cloud1.cpu().numpy(), c1)
+    src_ref = np.concatenate([img2.reshape(1, 3, -1)[:, :, m[0]], img.reshape(1, 3, -1)], axis=2)
+    assert np.array_equal(src1.cpu().numpy(), src_ref)
+    ref1 = c_oracle.splat_forward(np.ascontiguousarray(s1.transpose(0, 2, 1)), src_ref, S, K=32)
+    assert np.array_equal(bg1.cpu().numpy(), ref1["bg"])
+    np.testing.assert_allclose(feat1.cpu().numpy(), ref1["feat"], rtol=0, atol=1e-6)
