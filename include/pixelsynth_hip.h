@@ -108,14 +108,79 @@ int ps_kernel_masks_f32(const int32_t *order, int L, int nrows, int ncols, int k
  * Locally masked convolution / PixelCNN (models/lmconv)
  * ---------------------------------------------------------------------------------------- */
 
+/* Scratch bytes ps_lmconv_forward_f32 needs (device memory, caller-owned). */
+size_t ps_lmconv_workspace_bytes(int B, int Ci, int Co, int H, int W);
+
 /* _locally_masked_conv2d.forward  (models/lmconv/locally_masked_convolution.py:11-50), 3x3:
  *   x (B,Ci,H,W) f32 ; mask (B,9,H*W) f32 (the reference passes it repeated Ci times, (B*Ci,9,L),
  *   identical across channels -- the caller hands over one copy per image; mask_batch_stride = 0
- *   broadcasts one mask to the whole batch) ; weight (Co,Ci,3,3) ; bias (Co) or NULL
+ *   broadcasts one mask to the whole batch, otherwise 9*H*W) ; weight (Co,Ci,3,3) ; bias (Co) or NULL
  *   -> y (B,Co,H,W).  padding = dilation (:118-120). */
 int ps_lmconv_forward_f32(const float *x, const float *mask, size_t mask_batch_stride,
                           const float *weight, const float *bias, int B, int Ci, int Co, int H,
-                          int W, int dilation, float *y, void *stream);
+                          int W, int dilation, float *y, void *workspace, size_t workspace_bytes,
+                          void *stream);
+
+/* ---- OurPixelCNN with PixelSynth's configuration (models/z_buffermodel.py:62-74):
+ *      nr_resnet=2, nr_filters=80, input_channels=512, 3x3 kernels, max_dilation=2, PONO norms,
+ *      weight_norm=False on the convs, weight-normed nin's, dropout 0.
+ * The handle owns device copies of the weights (re-packed for MFMA), the per-location activation
+ * caches and its scratch; it is created once and destroyed explicitly. */
+typedef struct ps_pixelcnn ps_pixelcnn;
+
+#define PS_PIXELCNN_NUM_PARAMS 93
+/* params: 93 HOST pointers to f32 tensors in the reference state_dict order of OurPixelCNN
+ * (models/lmconv/model.py:61-108; the order is spelled out in pixelsynth_amd/lmconv/model.py:PARAM_KEYS):
+ * down_layers.{0..2}.u_stream.*.{conv_input.weight,conv_input.bias,nin_skip.lin_a.bias,
+ * nin_skip.lin_a.weight_g,nin_skip.lin_a.weight_v,conv_out.weight,conv_out.bias},
+ * up_layers.{0..2}.u_stream.{0,1}.{conv_input.weight,.bias,conv_out.weight,.bias}, u_init.{weight,bias},
+ * downsize_u_stream.{0,1}.{weight,bias}, upsize_u_stream.{0,1}.{weight,bias},
+ * nin_out.lin_a.{bias,weight_g,weight_v}.   H x W = code grid (32 x 32), max_frames = most images
+ * evaluated at once. */
+int ps_pixelcnn_create(const float *const *params, int n_params, int H, int W, int max_frames,
+                       ps_pixelcnn **out);
+void ps_pixelcnn_destroy(ps_pixelcnn *h);
+
+/* OurPixelCNN.forward(sample=True) on one-hot input (models/lmconv/model.py:110-155):
+ *   codes (F,H*W) int32: the class of the one-hot input at each location, -1 = all-zero input
+ *   (a not-yet-sampled location, models/lmconv/sample.py:47);
+ *   mask_init / mask_undilated / mask_dilated (F,9,H*W) f32 (one copy per image, see above)
+ *   -> logits (F,512,H,W) f32. */
+int ps_pixelcnn_forward_f32(ps_pixelcnn *h, const int32_t *codes, const float *mask_init,
+                            const float *mask_undilated, const float *mask_dilated, int F,
+                            float *logits, void *stream);
+
+/* The autoregressive loop of sample() (models/lmconv/sample.py:8-73), exact incremental form: every
+ * location is evaluated once, in generation order, as a single column through the network against
+ * cached activations (valid because every mask only admits locations that precede in the order).
+ *   codes (F,L) int32 in/out: observed codes; entries of the sample region are overwritten;
+ *   order (F,L) int32: row-major location index visited at each order position;
+ *   sample_region (F,L) uint8 by LOCATION: 1 = sample this location (sample.py:24-41);
+ *   forced (F,L) int32 by location or NULL: teacher-forced codes (parity tests);
+ *   uniforms (F,L) f32 by location or NULL: u in [0,1) for the inverse-CDF draw from
+ *     softmax(logits / temperature) (sample.py:60-63; RNG streams differ from torch.multinomial);
+ *   out_logits (F,L,512) f32 by location or NULL: the logits each location was decided from.
+ * Exactly one of forced / uniforms must be given.
+ *   first_step: order positions < first_step are not walked one by one: they must all be observed
+ *   (not in the sample region) in every image, and are covered by one whole-grid pass
+ *   (0 is always valid; the caller knows the orders, it built them on the host).
+ * Asynchronous: the loop is replayed as a hipGraph on a stream owned by the handle, fenced against
+ * the caller's stream with events on both sides. */
+int ps_pixelcnn_ar_run(ps_pixelcnn *h, int32_t *codes, const int32_t *order,
+                       const uint8_t *sample_region, const float *mask_init,
+                       const float *mask_undilated, const float *mask_dilated, const int32_t *forced,
+                       const float *uniforms, float temperature, int F, int first_step,
+                       float *out_logits, void *stream);
+
+/* One order position of the loop above for callers that draw the sample themselves (the drop-in
+ * sample() keeps torch.multinomial): evaluates the column of location order[f][step] for every
+ * image and writes its logits (F,512).  step == first_step additionally (re)builds the caches with
+ * one whole-grid pass on the current codes (sample-region entries must be -1 at that point).  The
+ * caller writes the chosen code into codes before the next call. */
+int ps_pixelcnn_ar_step(ps_pixelcnn *h, const int32_t *codes, const int32_t *order,
+                        const float *mask_init, const float *mask_undilated,
+                        const float *mask_dilated, int F, int step, int first_step, float *logits,
+                        void *stream);
 
 #ifdef __cplusplus
 }

@@ -26,8 +26,14 @@ _PROTOS = {
     "ps_generation_order": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "ps_custom_order": (c_int, [c_int, c_int, c_void_p, c_void_p]),
     "ps_kernel_masks_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "ps_lmconv_workspace_bytes": (c_size_t, [c_int] * 5),
     "ps_lmconv_forward_f32": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
-                                      c_int, c_int, c_void_p, c_void_p]),
+                                      c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "ps_pixelcnn_create": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "ps_pixelcnn_destroy": (None, [c_void_p]),
+    "ps_pixelcnn_forward_f32": (c_int, [c_void_p] * 5 + [c_int, c_void_p, c_void_p]),
+    "ps_pixelcnn_ar_run": (c_int, [c_void_p] * 9 + [c_float, c_int, c_int, c_void_p, c_void_p]),
+    "ps_pixelcnn_ar_step": (c_int, [c_void_p] * 6 + [c_int, c_int, c_int, c_void_p, c_void_p]),
 }
 
 

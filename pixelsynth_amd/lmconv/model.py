@@ -1,0 +1,247 @@
+"""OurPixelCNN on MI355X -- drop-in for the reference's models/lmconv/model.py (same constructor, same
+parameter names/shapes so reference checkpoints load, same forward signature).
+
+With PixelSynth's configuration (models/z_buffermodel.py:62-74: nr_resnet=2, nr_filters=80,
+input_channels=512, 3x3, max_dilation=2, weight_norm=False, PONO norms, dropout 0, no mask weight)
+and one-hot (or all-zero) input, forward() runs entirely inside the HIP engine
+(ps_pixelcnn_forward_f32: csrc/lmconv.hip).  Any other configuration / input runs layer by layer
+like the reference, every masked conv on the HIP lmconv kernel.
+"""
+import ctypes
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.nn.utils import weight_norm as wn
+
+from .. import _lib
+from .layers import PONO, gated_resnet, identity, nin
+from .locally_masked_convolution import compact_mask, locally_masked_conv2d
+from .utils import concat_elu
+
+DOWN_NR = (2, 3, 3)
+
+
+def _param_keys():
+    keys = []
+    for i in range(3):
+        for j in range(DOWN_NR[i]):
+            p = f"down_layers.{i}.u_stream.{j}."
+            keys += [p + "conv_input.weight", p + "conv_input.bias", p + "nin_skip.lin_a.bias",
+                     p + "nin_skip.lin_a.weight_g", p + "nin_skip.lin_a.weight_v", p + "conv_out.weight",
+                     p + "conv_out.bias"]
+    for i in range(3):
+        for j in range(2):
+            p = f"up_layers.{i}.u_stream.{j}."
+            keys += [p + "conv_input.weight", p + "conv_input.bias", p + "conv_out.weight", p + "conv_out.bias"]
+    keys += ["u_init.weight", "u_init.bias"]
+    for name in ("downsize_u_stream", "upsize_u_stream"):
+        for i in range(2):
+            keys += [f"{name}.{i}.weight", f"{name}.{i}.bias"]
+    keys += ["nin_out.lin_a.bias", "nin_out.lin_a.weight_g", "nin_out.lin_a.weight_v"]
+    return keys
+
+
+PARAM_KEYS = _param_keys()  # the reference state_dict order; ps_pixelcnn_create expects exactly this order
+assert len(PARAM_KEYS) == 93
+
+
+class PixelCNNEngine:
+    """Owns a ps_pixelcnn handle (device weights re-packed for MFMA + activation caches)."""
+
+    def __init__(self, state_dict, H=32, W=32, max_frames=1):
+        arrs = [np.ascontiguousarray(state_dict[k].detach().cpu().numpy() if hasattr(state_dict[k], "detach")
+                                     else state_dict[k], dtype=np.float32) for k in PARAM_KEYS]
+        self._keep = arrs
+        ptrs = (ctypes.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+        self.handle = ctypes.c_void_p()
+        self.H, self.W, self.L, self.max_frames = H, W, H * W, max_frames
+        rc = _lib.lib().ps_pixelcnn_create(ptrs, len(arrs), H, W, max_frames, ctypes.byref(self.handle))
+        _lib.check(rc, "ps_pixelcnn_create")
+
+    def close(self):
+        if getattr(self, "handle", None):
+            _lib.lib().ps_pixelcnn_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # masks: (F,9,L) f32 contiguous device tensors
+    def forward(self, codes, mask_init, mask_undilated, mask_dilated):
+        """codes (F,L) or (F,H,W) int32 (-1 = zero input) -> logits (F,512,H,W)."""
+        F_ = codes.shape[0]
+        codes = codes.reshape(F_, self.L).to(torch.int32).contiguous()
+        _lib.require_cuda(codes, mask_init, mask_undilated, mask_dilated)
+        logits = torch.empty(F_, 512, self.H, self.W, dtype=torch.float32, device=codes.device)
+        rc = _lib.lib().ps_pixelcnn_forward_f32(self.handle, _lib.ptr(codes), _lib.ptr(mask_init),
+                                                _lib.ptr(mask_undilated), _lib.ptr(mask_dilated), F_,
+                                                _lib.ptr(logits), _lib.current_stream())
+        _lib.check(rc, "ps_pixelcnn_forward_f32")
+        return logits
+
+    def ar_run(self, codes, order, region, mask_init, mask_undilated, mask_dilated, temperature=1.0, forced=None,
+               uniforms=None, first_step=0, want_logits=False):
+        """In-place AR completion of codes (F,L) int32.  order (F,L) int32 location per order position,
+        region (F,L) uint8 by location.  Returns out_logits (F,L,512) or None."""
+        F_ = codes.shape[0]
+        _lib.require_cuda(codes, order, region, mask_init, mask_undilated, mask_dilated)
+        assert codes.dtype == torch.int32 and codes.is_contiguous()
+        out = torch.empty(F_, self.L, 512, dtype=torch.float32, device=codes.device) if want_logits else None
+        rc = _lib.lib().ps_pixelcnn_ar_run(
+            self.handle, _lib.ptr(codes), _lib.ptr(order), _lib.ptr(region), _lib.ptr(mask_init),
+            _lib.ptr(mask_undilated), _lib.ptr(mask_dilated), _lib.ptr(forced), _lib.ptr(uniforms),
+            float(temperature), F_, int(first_step), _lib.ptr(out), _lib.current_stream())
+        _lib.check(rc, "ps_pixelcnn_ar_run")
+        return out
+
+    def ar_step(self, codes, order, mask_init, mask_undilated, mask_dilated, step, first_step):
+        F_ = codes.shape[0]
+        logits = torch.empty(F_, 512, dtype=torch.float32, device=codes.device)
+        rc = _lib.lib().ps_pixelcnn_ar_step(self.handle, _lib.ptr(codes), _lib.ptr(order), _lib.ptr(mask_init),
+                                            _lib.ptr(mask_undilated), _lib.ptr(mask_dilated), F_, int(step),
+                                            int(first_step), _lib.ptr(logits), _lib.current_stream())
+        _lib.check(rc, "ps_pixelcnn_ar_step")
+        return logits
+
+
+class OurPixelCNNLayer_up(nn.Module):
+    def __init__(self, nr_resnet, nr_filters, resnet_nonlinearity, conv_op, feature_norm_op=None,
+                 kernel_size=(5, 5), weight_norm=True, dropout_prob=0.5, rematerialize=False):
+        super(OurPixelCNNLayer_up, self).__init__()
+        self.nr_resnet = nr_resnet
+        self.u_stream = nn.ModuleList([gated_resnet(nr_filters, conv_op, feature_norm_op, resnet_nonlinearity,
+                                                    skip_connection=0, dropout_prob=dropout_prob)
+                                       for _ in range(nr_resnet)])
+
+    def forward(self, u, mask=None):
+        u_list = []
+        for i in range(self.nr_resnet):
+            u = self.u_stream[i](u, mask=mask)
+            u_list += [u]
+        return u_list
+
+
+class OurPixelCNNLayer_down(nn.Module):
+    def __init__(self, nr_resnet, nr_filters, resnet_nonlinearity, conv_op, feature_norm_op=None,
+                 kernel_size=(5, 5), weight_norm=True, dropout_prob=0.5, rematerialize=False):
+        super(OurPixelCNNLayer_down, self).__init__()
+        self.nr_resnet = nr_resnet
+        self.u_stream = nn.ModuleList([gated_resnet(nr_filters, conv_op, feature_norm_op, resnet_nonlinearity,
+                                                    skip_connection=1, dropout_prob=dropout_prob)
+                                       for _ in range(nr_resnet)])
+
+    def forward(self, u, u_list, mask=None):
+        for i in range(self.nr_resnet):
+            a = u_list.pop()
+            u = self.u_stream[i](u, a=a, mask=mask)
+        return u
+
+
+class OurPixelCNN(nn.Module):
+    def __init__(self, nr_resnet=5, nr_filters=80, nr_logistic_mix=10, resnet_nonlinearity='concat_elu',
+                 input_channels=3, kernel_size=(5, 5), max_dilation=2, weight_norm=True, feature_norm_op=None,
+                 dropout_prob=0.5, conv_bias=True, conv_mask_weight=False, rematerialize=False, binarize=False):
+        super(OurPixelCNN, self).__init__()
+        assert resnet_nonlinearity == 'concat_elu'
+        self.resnet_nonlinearity = lambda x: concat_elu(x)
+        self.init_padding = None
+        self.binarize = binarize
+        mk = lambda cin, cout, dil=1: locally_masked_conv2d(cin, cout, kernel_size=kernel_size, dilation=dil,
+                                                            bias=conv_bias, mask_weight=conv_mask_weight)
+        if weight_norm:
+            conv_op_init = lambda cin, cout: wn(mk(cin, cout))
+            conv_op_dilated = lambda cin, cout: wn(mk(cin, cout, max_dilation))
+            conv_op = lambda cin, cout: wn(mk(cin, cout))
+        else:
+            conv_op_init = lambda cin, cout: mk(cin, cout)
+            conv_op_dilated = lambda cin, cout: mk(cin, cout, max_dilation)
+            conv_op = lambda cin, cout: mk(cin, cout)
+        down_nr_resnet = [nr_resnet] + [nr_resnet + 1] * 2
+        self.down_layers = nn.ModuleList([OurPixelCNNLayer_down(down_nr_resnet[i], nr_filters,
+                                                                self.resnet_nonlinearity, conv_op, feature_norm_op,
+                                                                kernel_size=kernel_size, weight_norm=weight_norm,
+                                                                dropout_prob=dropout_prob) for i in range(3)])
+        self.up_layers = nn.ModuleList([OurPixelCNNLayer_up(nr_resnet, nr_filters, self.resnet_nonlinearity, conv_op,
+                                                            feature_norm_op, kernel_size=kernel_size,
+                                                            weight_norm=weight_norm, dropout_prob=dropout_prob)
+                                        for _ in range(3)])
+        self.u_init = conv_op_init(input_channels + 1, nr_filters)
+        self.downsize_u_stream = nn.ModuleList([conv_op_dilated(nr_filters, nr_filters) for _ in range(2)])
+        self.upsize_u_stream = nn.ModuleList([conv_op_dilated(nr_filters, nr_filters) for _ in range(2)])
+        self.norm_init = feature_norm_op(nr_filters) if feature_norm_op else identity
+        self.norm_ds = nn.ModuleList([feature_norm_op(nr_filters) for _ in range(2)]) if feature_norm_op else None
+        self.norm_us = nn.ModuleList([feature_norm_op(nr_filters) for _ in range(2)]) if feature_norm_op else None
+        if self.binarize:
+            self.nin_out = nin(nr_filters, 2, weight_norm=True)
+        else:
+            self.nin_out = nin(nr_filters, 512, weight_norm=True)
+        self._engine_ok = (nr_resnet == 2 and nr_filters == 80 and input_channels == 512 and
+                           tuple(kernel_size) == (3, 3) and max_dilation == 2 and not weight_norm and
+                           conv_bias and not conv_mask_weight and not binarize and dropout_prob == 0 and
+                           feature_norm_op is not None and isinstance(feature_norm_op(nr_filters), PONO))
+        self._engine = None
+        self._engine_sig = None
+
+    # ---- HIP engine -------------------------------------------------------------------------
+    def engine(self, H=32, W=32, max_frames=1):
+        """The ps_pixelcnn handle for the current parameters (rebuilt when they change)."""
+        if not self._engine_ok:
+            raise RuntimeError("the fused HIP PixelCNN engine implements PixelSynth's OurPixelCNN configuration only")
+        sd = self.state_dict()
+        sig = (H, W, tuple((sd[k].data_ptr(), sd[k]._version) for k in PARAM_KEYS))
+        if self._engine is None or self._engine_sig != sig or self._engine.max_frames < max_frames:
+            if self._engine is not None:
+                self._engine.close()
+            self._engine = PixelCNNEngine(sd, H, W, max(max_frames, getattr(self._engine, "max_frames", 1)))
+            self._engine_sig = sig
+        return self._engine
+
+    @staticmethod
+    def onehot_to_codes(x):
+        """(B,C,H,W) one-hot / all-zero float input -> (codes (B,H,W) int32 with -1 for zero, is_valid bool tensor)."""
+        mx, am = x.max(dim=1)
+        mn = x.min(dim=1)[0]
+        sm = x.sum(dim=1)
+        onehot = (mx == 1) & (sm == 1) & (mn == 0)
+        zero = (mx == 0) & (mn == 0)
+        codes = torch.where(onehot, am, torch.full_like(am, -1)).to(torch.int32)
+        return codes, (onehot | zero).all()
+
+    def forward(self, x, sample=False, mask_init=None, mask_undilated=None, mask_dilated=None):
+        if isinstance(x, list):
+            mask_init, mask_undilated, mask_dilated = x[1], x[2], x[3]
+            x = x[0]
+        B, C, H, W = x.shape
+        if self._engine_ok and x.is_cuda:
+            codes, ok = self.onehot_to_codes(x)
+            if bool(ok):  # one device->host sync; callers that hold codes use engine() directly
+                eng = self.engine(H, W, B)
+                return eng.forward(codes, compact_mask(mask_init, B, C + 1), compact_mask(mask_undilated, B, 160),
+                                   compact_mask(mask_dilated, B, 80))
+        return self._forward_layers(x, sample, mask_init, mask_undilated, mask_dilated)
+
+    def _forward_layers(self, x, sample, mask_init, mask_undilated, mask_dilated):
+        """The reference's layer-by-layer forward (model.py:118-155); every lmconv is the HIP kernel."""
+        xs = [int(y) for y in x.size()]
+        padding = torch.ones(xs[0], 1, xs[2], xs[3], device=x.device, dtype=x.dtype)
+        x = torch.cat((x, padding), 1)
+        u_list = [self.norm_init(self.u_init(x, mask=mask_init), mask=mask_undilated)]
+        for i in range(2):
+            u_list += self.up_layers[i](u_list[-1], mask=mask_undilated)
+            u_list += [self.downsize_u_stream[i](u_list[-1], mask=mask_dilated)]
+            if self.norm_ds:
+                u_list[-1] = self.norm_ds[i](u_list[-1], mask=mask_dilated)
+        u_list += self.up_layers[2](u_list[-1], mask=mask_undilated)
+        u = u_list.pop()
+        for i in range(2):
+            u = self.down_layers[i](u, u_list, mask=mask_undilated)
+            u = self.upsize_u_stream[i](u, mask=mask_dilated)
+            if self.norm_us:
+                u = self.norm_us[i](u, mask=mask_dilated)
+        u = self.down_layers[2](u, u_list, mask=mask_undilated)
+        return self.nin_out(F.elu(u))

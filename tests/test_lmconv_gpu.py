@@ -1,0 +1,252 @@
+"""GPU parity tests of the locally-masked PixelCNN path (through the C ABI).
+
+Tolerances (fp32 throughout, MFMA f32 = fma-chain numerics): single layer 2e-5 abs; gated block 5e-5;
+full-network logits 1e-4 abs against the reference golden vectors (33 fp32 layers deep);
+incremental (column) evaluation vs whole-grid evaluation of the SAME kernels: bit-exact."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+from oracle import c_oracle, lmconv_oracle as lo
+from pixelsynth_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def tt(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def norm_op(_c):
+    from pixelsynth_amd.lmconv.layers import PONO
+    return PONO()
+
+
+def make_net(seed=0):
+    from pixelsynth_amd.lmconv.model import OurPixelCNN
+    net = OurPixelCNN(nr_resnet=2, nr_filters=80, input_channels=512, nr_logistic_mix=10, kernel_size=(3, 3),
+                      max_dilation=2, weight_norm=False, feature_norm_op=norm_op, dropout_prob=0, conv_bias=True,
+                      conv_mask_weight=False, rematerialize=False, binarize=False).eval()
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in syn.pixelcnn_state_dict(seed).items()}, strict=True)
+    return net.to(DEV)
+
+
+def masks_for(order):
+    return tuple(tt(c_oracle.unfolded_masks(order, 32, 32, 3, dil, typ)) for dil, typ in ((1, "A"), (1, "B"), (2, "B")))
+
+
+def test_lmconv_layers_vs_reference_golden(golden_dir):
+    from pixelsynth_amd.lmconv.locally_masked_convolution import locally_masked_conv2d
+    fx = np.load(os.path.join(golden_dir, "lmconv_layers.npz"))
+    for name, ci, co, dil, H in cases.LAYER_CASES:
+        c = cases.layer_case(name)
+        layer = locally_masked_conv2d(ci, co, kernel_size=(3, 3), dilation=dil, bias=True).to(DEV)
+        with torch.no_grad():
+            layer.weight.copy_(tt(c["w"]))
+            layer.bias.copy_(tt(c["b"]))
+            # the reference layout: mask repeated over input channels, (B*Ci, 9, L)
+            mrep = tt(c["m"]).unsqueeze(1).repeat(1, ci, 1, 1).view(c["B"] * ci, 9, H * H)
+            y = layer(tt(c["x"]), mrep)
+            y2 = layer(tt(c["x"]), tt(c["m"]))  # compact (B,9,L) form
+        np.testing.assert_allclose(y.cpu().numpy(), fx[f"{name}_y"], rtol=1e-5, atol=2e-5, err_msg=name)
+        assert torch.equal(y, y2)
+
+
+def test_lmconv_broadcast_mask_and_no_bias():
+    from pixelsynth_amd.lmconv.locally_masked_convolution import lmconv_forward
+    rs = np.random.RandomState(0)
+    x = rs.randn(3, 7, 6, 9).astype(np.float32)  # non-square grid, ragged channels
+    w = rs.randn(5, 7, 3, 3).astype(np.float32)
+    m = (rs.rand(1, 9, 54) > 0.5).astype(np.float32)
+    y = lmconv_forward(tt(x), tt(m), tt(w), None, dilation=2).cpu()
+    ref = lo.lmconv(torch.from_numpy(x), torch.from_numpy(m), torch.from_numpy(w), None, dilation=2)
+    np.testing.assert_allclose(y.numpy(), ref.numpy(), rtol=1e-5, atol=2e-5)
+
+
+def test_blocks_vs_reference_golden(golden_dir):
+    from pixelsynth_amd.lmconv.layers import PONO, gated_resnet, nin
+    from pixelsynth_amd.lmconv.locally_masked_convolution import locally_masked_conv2d
+    from pixelsynth_amd.lmconv.utils import concat_elu
+    fx = np.load(os.path.join(golden_dir, "blocks.npz"))
+    conv_op = lambda cin, cout: locally_masked_conv2d(cin, cout, kernel_size=(3, 3), bias=True, mask_weight=False)
+    for skip in (0, 1):
+        c = cases.gated_case(skip)
+        blk = gated_resnet(80, conv_op, norm_op, concat_elu, skip_connection=skip, dropout_prob=0).eval()
+        blk.load_state_dict({k: torch.from_numpy(v) for k, v in c["sd"].items()}, strict=True)
+        blk = blk.to(DEV)
+        with torch.no_grad():
+            y = blk(tt(c["x"]), a=None if c["a"] is None else tt(c["a"]), mask=tt(c["m"]))
+        np.testing.assert_allclose(y.cpu().numpy(), fx[f"gr{skip}_y"], rtol=1e-5, atol=5e-5)
+    c = cases.small_case()
+    np.testing.assert_allclose(PONO()(tt(c["x"])).cpu().numpy(), fx["pono_y"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(concat_elu(tt(c["x"])).cpu().numpy(), fx["celu_y"], rtol=1e-6, atol=1e-6)
+    lin = nin(80, 512).eval()
+    lin.load_state_dict({k: torch.from_numpy(v) for k, v in c["nin_sd"].items()}, strict=True)
+    with torch.no_grad():
+        y = lin.to(DEV)(tt(c["x"]))
+    np.testing.assert_allclose(y.cpu().numpy(), fx["nin_y"], rtol=1e-5, atol=2e-5)
+
+
+def test_network_logits_vs_reference_golden(golden_dir):
+    fx = np.load(os.path.join(golden_dir, "network.npz"))
+    dmaps = dict(syn.distance_maps())
+    pos = fx["positions"]
+    for wi in range(2):
+        net = make_net(int(fx[f"net{wi}_wseed"]))
+        order, _ = c_oracle.custom_idx(32, 32, dmaps[str(fx[f"net{wi}_order_name"])])
+        mi, mu, md = masks_for(order)
+        codes = syn.codes(int(fx[f"net{wi}_codes_seed"]), 1)
+        x = torch.nn.functional.one_hot(tt(codes), 512).permute(0, 3, 1, 2).float()
+        # reference calling convention: list input, masks repeated per input channel
+        rep = lambda m, c: m[0:1].repeat(c, 1, 1).view(-1, 9, 1024)
+        with torch.no_grad():
+            logits = net([x, rep(mi, 513), rep(mu, 160), rep(md, 80)], sample=True)
+            layered = net._forward_layers(x, True, mi, mu, md)
+        lg = logits[0].reshape(512, 1024).cpu().numpy()
+        np.testing.assert_allclose(lg[:, pos], fx[f"net{wi}_logits_sub"], rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(lg.astype(np.float64).sum(0), fx[f"net{wi}_logits_sum"], rtol=0, atol=2e-2)
+        np.testing.assert_allclose(layered.cpu().numpy(), logits.cpu().numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_network_zero_input_and_batch():
+    """All-zero (not yet sampled) locations + a batch of different images/orders vs the torch twin."""
+    net = make_net(2)
+    sd = {k: torch.from_numpy(v) for k, v in syn.pixelcnn_state_dict(2).items()}
+    dmaps = dict(syn.distance_maps())
+    names = ["corner", "rand2", "island_l1"]
+    eng = net.engine(32, 32, 3)
+    codes = syn.codes(5, 3).reshape(3, 1024).astype(np.int32)
+    codes[0, 500:] = -1
+    codes[2, ::3] = -1
+    orders = [c_oracle.custom_idx(32, 32, dmaps[n])[0] for n in names]
+    ms = [np.concatenate([c_oracle.unfolded_masks(o, 32, 32, 3, dil, typ) for o in orders]) for dil, typ in
+          ((1, "A"), (1, "B"), (2, "B"))]
+    logits = eng.forward(tt(codes), *[tt(m) for m in ms]).cpu().numpy()
+    for b in range(3):
+        x = torch.zeros(1, 512, 1024)
+        valid = codes[b] >= 0
+        x[0, codes[b][valid], np.nonzero(valid)[0]] = 1
+        with torch.no_grad():
+            ref = lo.pixelcnn_forward(sd, x.view(1, 512, 32, 32), *[torch.from_numpy(m[b:b + 1]) for m in ms])
+        np.testing.assert_allclose(logits[b], ref[0].numpy(), rtol=1e-4, atol=1e-4)
+
+
+def _ar_setup(fx):
+    bg32 = fx["bg32"]
+    order = fx["order"].astype(np.int32)
+    region = lo.sample_region(order, bg32)
+    order_loc = (order[:, 0] * 32 + order[:, 1]).astype(np.int32)[None]
+    reg = np.zeros((1, 1024), np.uint8)
+    reg[0, region[:, 0] * 32 + region[:, 1]] = 1
+    first = int(np.nonzero(reg[0][order_loc[0]])[0][0])
+    return order, region, order_loc, reg, first
+
+
+def test_ar_teacher_forced_vs_reference_sample_trace(golden_dir):
+    """Teacher-force the codes the REFERENCE's own sample() drew (CPU run, tests/golden/ar_trace.npz) and compare
+    the logits each position was decided from with the logits the reference's loop saw at that step."""
+    fx = np.load(os.path.join(golden_dir, "ar_trace.npz"))
+    net = make_net(int(fx["wseed"]))
+    eng = net.engine(32, 32, 1)
+    order, region, order_loc, reg, first = _ar_setup(fx)
+    assert len(region) == int(fx["n_steps"]) and first > 0
+    mi, mu, md = masks_for(order)
+    codes0 = syn.codes(int(fx["codes_seed"]), 1).reshape(1, 1024).astype(np.int32)
+    final = fx["final_codes"].astype(np.int32).reshape(1, 1024)
+    assert np.array_equal(final[reg == 0], codes0[reg == 0])  # observed codes untouched by the reference
+    outs = []
+    for fs in (first, 0):
+        c = tt(codes0.copy())
+        out = eng.ar_run(c, tt(order_loc), tt(reg), mi, mu, md, temperature=0.7, forced=tt(final), first_step=fs,
+                         want_logits=True)
+        torch.cuda.synchronize()
+        assert np.array_equal(c.cpu().numpy(), final)
+        outs.append(out.cpu().numpy())
+    got = np.stack([outs[0][0, i * 32 + j] for i, j in region])[::4]
+    np.testing.assert_allclose(got, fx["step_logits"], rtol=1e-4, atol=1e-4)
+    # positions walked by both runs carry identical bits (first_step only skips a prefix)
+    walked = order_loc[0][first:]
+    assert np.array_equal(outs[0][0, walked], outs[1][0, walked])
+    # incremental column evaluation == ONE whole-grid forward on the completed grid, bit for bit
+    full = eng.forward(tt(final), mi, mu, md)[0].reshape(512, 1024).t().cpu().numpy()
+    assert np.array_equal(outs[1][0], full)
+
+
+def test_ar_fused_sampling_inverse_cdf_and_determinism():
+    net = make_net(3)
+    F_ = 3
+    eng = net.engine(32, 32, F_)
+    bgs = syn.background_masks(256)
+    names = ["right_half", "half_plus_island", "ragged"]
+    infos = [c_oracle.masks_for_background(bgs[n], 32) for n in names]
+    order_loc = np.stack([(i["order"][:, 0] * 32 + i["order"][:, 1]) for i in infos]).astype(np.int32)
+    reg = np.stack([i["bg32"].reshape(-1) for i in infos]).astype(np.uint8)
+    ms = [tt(np.concatenate([i[k] for i in infos])) for k in ("mask_init", "mask_undilated", "mask_dilated")]
+    first = min(int(np.nonzero(reg[b][order_loc[b]])[0][0]) for b in range(F_))
+    codes0 = syn.codes(9, F_).reshape(F_, 1024).astype(np.int32)
+    u = np.random.RandomState(4).rand(F_, 1024).astype(np.float32)
+    runs = []
+    for _ in range(2):
+        c = tt(codes0.copy())
+        out = eng.ar_run(c, tt(order_loc), tt(reg), *ms, temperature=0.7, uniforms=tt(u), first_step=first,
+                         want_logits=True)
+        torch.cuda.synchronize()
+        runs.append((c.cpu().numpy(), out.cpu().numpy()))
+    assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1])  # deterministic
+    codes, logits = runs[0]
+    assert np.array_equal(codes[reg == 0], codes0[reg == 0])
+    assert (codes[reg == 1] >= 0).all() and (codes[reg == 1] < 512).all()
+    # each draw is the inverse CDF of softmax(logits/T) at u (float64 host check, 1e-5 slack at bin edges)
+    bad = 0
+    for b in range(F_):
+        for q in np.nonzero(reg[b])[0]:
+            p = np.exp((logits[b, q].astype(np.float64) / np.float32(0.7)) - (logits[b, q] / np.float32(0.7)).max())
+            cdf = np.cumsum(p) / p.sum()
+            k = codes[b, q]
+            lo_, hi_ = (cdf[k - 1] if k > 0 else 0.0), cdf[k]
+            if not (lo_ - 1e-5 <= u[b, q] <= hi_ + 1e-5):
+                bad += 1
+    assert bad == 0
+    # batch independence: image 1 alone gives the same codes
+    eng1 = make_net(3).engine(32, 32, 1)
+    c = tt(codes0[1:2].copy())
+    eng1.ar_run(c, tt(order_loc[1:2]), tt(reg[1:2]), *[m[1:2].contiguous() for m in ms], temperature=0.7,
+                uniforms=tt(u[1:2]), first_step=first)
+    assert np.array_equal(c.cpu().numpy()[0], codes[1])
+    # the sampled grid is self-consistent: one whole-grid forward reproduces the logits it was drawn from
+    full = eng.forward(tt(codes), *ms).reshape(F_, 512, 1024).permute(0, 2, 1).cpu().numpy()
+    for b in range(F_):
+        walked = order_loc[b][first:]
+        assert np.array_equal(full[b][walked], logits[b][walked])
+
+
+def test_sample_dropin_modes_agree():
+    """sample() with the reference's signature: 'reference' (full forward per step) and 'multinomial'
+    (incremental) modes see identical logits, hence draw identical codes with torch.multinomial."""
+    from pixelsynth_amd.lmconv.sample import sample
+    net = make_net(1)
+    bg = np.zeros((256, 256), bool)
+    bg[:, 232:] = True  # 3 code columns -> 96 sampled positions
+    info = c_oracle.masks_for_background(bg, 32)
+    order = [info["order"].astype(np.int64)]
+    masks = [tt(info[k]).repeat(c, 1, 1) for k, c in (("mask_init", 513), ("mask_undilated", 160), ("mask_dilated", 80))]
+    codes = tt(syn.codes(31, 1))
+    bm = tt(info["bg32"].astype(np.float32))[None]
+    res = {}
+    for mode in ("reference", "multinomial", "fused"):
+        args = types.SimpleNamespace(num_classes=512, dataloader_seed=0, ar_mode=mode)
+        with torch.no_grad():
+            data, loss = sample(net, order, *masks, codes, [3, 32, 32], args, seed=1, temperature=0.7, background_mask=bm)
+        assert data.shape == (1, 512, 32, 32) and torch.all(data.sum(1) == 1)
+        res[mode] = data.argmax(1).cpu().numpy()
+        assert np.isfinite(float(loss))
+    keep = info["bg32"] == 0
+    for mode in res:
+        assert np.array_equal(res[mode][0][keep], syn.codes(31, 1)[0][keep])  # observed codes are never touched
+    assert np.array_equal(res["reference"], res["multinomial"])
+    assert (res["fused"][0][~keep] != syn.codes(31, 1)[0][~keep]).mean() > 0.9  # really resampled
