@@ -1,0 +1,241 @@
+#!/usr/bin/env python
+"""bench.py -- novel-view frames/sec @256x256 (reproject + AR outpaint) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+One STEP = one pass of the hot path over one batch of V independent novel views of a source image
+(BASELINE.json config C5's per-GPU shard: 1 source x 16 views; at --gpus 8 the job is exactly C5 =
+8 sources x 16 views): reprojection + soft z-buffer splat, generation order + masks
+(a7-a9), autoregressive outpainting of the 32x32 VQ code grid (a13).  Inputs are synthetic and
+already resident in HBM when the timed region starts; weights are random-init with the reference's
+shapes.  The VQ-VAE / depth / refinement networks around the path are out of scope, so the
+codes of the reprojected view are synthetic.  Weak scaling: every rank renders its own V views; the only
+collective is the RCCL all_gather of the finished frames (no data-path exchange).
+
+Prints ONE JSON line (rank 0) with the contract fields plus `roofline` and `cpu_baseline`.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("DEBUG", "False")
+
+from pixelsynth_amd import _lib, synthetic as syn  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP32_MFMA_PEAK_TF = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2 peak
+
+
+def make_opts():
+    return types.SimpleNamespace(
+        W=256, use_rgb_features=True, splatter="xyblending", learn_default_feature=True, radius=4, pp_pixel=128,
+        tau=1.0, rad_pow=2, accumulation="alphacomposite", background_smoothing_kernel_size=13, min_z=1.0,
+        max_z=100.0, rotation=0.6, direction="R", temperature=0.7, model_setting="gen_img", seed=0, homography=False)
+
+
+def build_model(device):
+    from pixelsynth_amd.z_buffermodel import ZbufferModelPts
+    model = ZbufferModelPts(make_opts()).eval()
+    model.outpaint2.load_state_dict({k: torch.from_numpy(v) for k, v in syn.pixelcnn_state_dict(0).items()})
+    return model.to(device)
+
+
+def make_inputs(rank, V, device, smooth=True):
+    S = 256
+    img = np.repeat(syn.image(1000 + rank, 1, 3, S), V, 0)
+    depth = np.repeat((syn.depth_smooth if smooth else syn.depth_uniform)(2000 + rank, 1, S, 1.0, 100.0), V, 0)
+    cam = syn.demo_cameras(V)
+    yaws = np.linspace(-0.6, 0.6, V) if V > 1 else np.array([0.6])
+    RT2 = np.empty((V, 4, 4), np.float32)
+    RT2inv = np.empty((V, 4, 4), np.float32)
+    for v in range(V):
+        inv, rt = syn.yaw_pose(cam["P"][v:v + 1], float(yaws[v]))
+        RT2[v], RT2inv[v] = rt[0], inv[0]
+    codes = syn.codes(3000 + rank, V)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    dev = dict(img=t(img), depth=t(depth), K=t(cam["K"]), Kinv=t(cam["Kinv"]), P=t(cam["P"]), Pinv=t(cam["Pinv"]),
+               RT2=t(RT2), RT2inv=t(RT2inv), codes=t(codes),
+               uniforms=t(np.random.RandomState(4000 + rank).rand(V, 1024).astype(np.float32)))
+    host = dict(img=img, depth=depth, cam=cam, RT2=RT2, RT2inv=RT2inv, codes=codes, yaws=yaws)
+    return dev, host
+
+
+def run_step(model, d, world, gather_bufs):
+    out = model.outpaint_views(d["img"], d["depth"], d["K"], d["Kinv"], d["P"], d["Pinv"], d["RT2"], d["RT2inv"],
+                               d["codes"], temperature=0.7, uniforms=d["uniforms"])
+    if world > 1:  # finished frames of every rank, RCCL all_gather over xGMI
+        torch.distributed.all_gather_into_tensor(gather_bufs[0], out["gen_fs"])
+        torch.distributed.all_gather_into_tensor(gather_bufs[1], out["codes"].contiguous())
+    return out
+
+
+def measure_roofline(model, d, out, V):
+    """Per-launch duration of the dominant kernel (k_gemm, column mode) with HIP events on the stream it is
+    launched on, against its algorithmic work (ps_pixelcnn_time_column_step)."""
+    plan = out["plan"]
+    eng = model.outpaint2.engine(32, 32, V)
+    c32 = out["codes"].reshape(V, 1024).to(torch.int32).contiguous()
+    step = min(1023, plan.first_step + (1024 - plan.first_step) // 2)
+    launches = (ctypes.c_int * 5)()
+    total_ms = (ctypes.c_float * 5)()
+    flops = ctypes.c_double()
+    wbytes = ctypes.c_double()
+    reps = 20
+    rc = _lib.lib().ps_pixelcnn_time_column_step(
+        eng.handle, _lib.ptr(c32), _lib.ptr(plan.order_loc), _lib.ptr(plan.mask_init), _lib.ptr(plan.mask_undilated),
+        _lib.ptr(plan.mask_dilated), V, step, reps, ctypes.cast(launches, ctypes.c_void_p),
+        ctypes.cast(total_ms, ctypes.c_void_p), ctypes.cast(ctypes.byref(flops), ctypes.c_void_p),
+        ctypes.cast(ctypes.byref(wbytes), ctypes.c_void_p), _lib.current_stream())
+    _lib.check(rc, "ps_pixelcnn_time_column_step")
+    n_gemm = launches[0] // reps
+    avg_us = total_ms[0] * 1e3 / max(1, launches[0])
+    bytes_per_launch = wbytes.value / n_gemm
+    flops_per_launch = flops.value / n_gemm
+    gbs = bytes_per_launch / (avg_us * 1e-6) / 1e9
+    tfs = flops_per_launch / (avg_us * 1e-6) / 1e12
+    per_class = {name: {"launches_per_step": launches[i] // reps,
+                        "avg_us": round(total_ms[i] * 1e3 / max(1, launches[i]), 3)}
+                 for i, name in enumerate(["k_gemm", "k_post", "k_uinit", "k_post_logits"])}
+    return {"bound": "hbm", "kernel": "k_gemm<column> (masked-conv / nin column step, weight stream)",
+            "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5),
+            "traffic": None, "algorithmic_bytes_per_launch": round(bytes_per_launch),
+            "avg_launch_us": round(avg_us, 3), "launches_per_ar_step": n_gemm,
+            "mfma_view": {"achieved": round(tfs, 4), "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                          "frac": round(tfs / FP32_MFMA_PEAK_TF, 6),
+                          "algorithmic_flops_per_launch": round(flops_per_launch)},
+            "per_kernel_class": per_class}
+
+
+def cpu_baseline(host, out, V, budget_s=20.0):
+    """The oracle (CPU restatement of the reference path, kind 'port') on this box's host cores, on a
+    bounded sample: one view's project+splat+order/masks, plus a few reference-style AR steps (one full
+    fp32 network forward per sampled code, models/lmconv/sample.py:54-57) extrapolated to the view's
+    number of sampled codes."""
+    from oracle import c_oracle, lmconv_oracle as lo
+    v = V - 1  # the +0.6 rad view (largest outpainting region of the sweep)
+    t0 = time.perf_counter()
+    cam = {k: a[v:v + 1] for k, a in host["cam"].items()}
+    sampler = c_oracle.project_pts(host["depth"][v:v + 1], cam["K"], cam["Kinv"], cam["Pinv"], host["RT2"][v:v + 1], 256)
+    ref = c_oracle.splat_forward(np.ascontiguousarray(sampler.transpose(0, 2, 1)), host["img"][v:v + 1].reshape(1, 3, -1), 256)
+    t_splat = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    info = c_oracle.masks_for_background(ref["bg"][0], 32)
+    t_plan = time.perf_counter() - t0
+    n_sampled = int(info["bg32"].sum())
+    sd = {k: torch.from_numpy(a) for k, a in syn.pixelcnn_state_dict(0).items()}
+    masks = tuple(torch.from_numpy(info[k]) for k in ("mask_init", "mask_undilated", "mask_dilated"))
+    codes = torch.from_numpy(host["codes"][v:v + 1])
+    x = torch.nn.functional.one_hot(codes, 512).permute(0, 3, 1, 2).float()
+    with torch.no_grad():
+        lo.pixelcnn_forward(sd, x, *masks)  # warm-up
+        t0 = time.perf_counter()
+        n = 0
+        while n < 8 or (time.perf_counter() - t0 < budget_s and n < 64):
+            lo.pixelcnn_forward(sd, x, *masks)
+            n += 1
+        t_step = (time.perf_counter() - t0) / n
+    frame_s = t_splat + t_plan + n_sampled * t_step
+    mean_sampled = float(np.mean(out["plan"].n_sampled))
+    frame_mean_s = t_splat + t_plan + mean_sampled * t_step
+    return {"value": round(1.0 / frame_mean_s, 5), "unit": "frames/s", "cores": int(torch.get_num_threads()),
+            "kind": "port",
+            "sample": (f"1 of {V} views on the host: oracle project+splat {t_splat:.3f}s (C/OpenMP) + order/masks "
+                       f"{t_plan * 1e3:.1f}ms + {n} reference-style AR steps at {t_step * 1e3:.1f} ms/step (one full fp32 "
+                       f"forward per sampled code, torch CPU), extrapolated to the sweep's mean of {mean_sampled:.0f} "
+                       f"sampled codes/view (the +0.6 rad view alone: {n_sampled} codes, {frame_s:.1f} s/frame)"),
+            "host_cpus": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--views", type=int, default=16, help="independent novel views per GPU per step")
+    ap.add_argument("--depth", choices=["smooth", "uniform"], default="smooth")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nnodes=1 "
+                             f"--nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port P bench.py --gpus {args.gpus} ...")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.distributed.init_process_group("nccl", device_id=device)
+
+    V = args.views
+    model = build_model(device)
+    d, host = make_inputs(rank, V, device, smooth=args.depth == "smooth")
+    gather_bufs = None
+    if world > 1:
+        gather_bufs = (torch.empty(world * V, 3, 256, 256, device=device), torch.empty(world * V, 32, 32, dtype=torch.int32, device=device))
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    out = None
+    for _ in range(args.warmup):
+        out = run_step(model, d, world, gather_bufs)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = run_step(model, d, world, gather_bufs)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if rank == 0:
+        frames = V * world * args.steps
+        plan = out["plan"]
+        res = {
+            "metric": "novel-view frames/sec @256x256 (reproject+AR outpaint)",
+            "value": round(frames / elapsed, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": (f"C5 per-GPU shard (= C3 batched): 1 source x {V} independent novel views per GPU per step "
+                                    "(yaw sweep +-0.6 rad, demo cameras, 256x256 RGB features, "
+                                    f"{args.depth} depth 1..100, K=128 r=4 alphacomposite splat, 13x13 mask dilation, "
+                                    "custom generation order, exact incremental AR over the 32x32 code grid, T=0.7)"),
+                       "views_per_gpu": V, "image": "256x256", "code_grid": "32x32", "num_classes": 512,
+                       "ar_steps_walked": 1024 - plan.first_step,
+                       "sampled_codes_per_view_mean": round(float(np.mean(plan.n_sampled)), 1),
+                       "parallelism": f"views sharded over {world} GPU(s), RCCL all_gather of finished frames"},
+        }
+        if world == 1:
+            try:
+                res["roofline"] = measure_roofline(model, d, out, V)
+            except Exception as e:  # measurement aid must not sink the headline number
+                res["roofline"] = {"error": repr(e)}
+            if not args.no_cpu_baseline:
+                try:
+                    res["cpu_baseline"] = cpu_baseline(host, out, V)
+                except Exception as e:
+                    res["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

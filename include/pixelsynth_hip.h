@@ -104,6 +104,16 @@ int ps_custom_order(int rows, int cols, int64_t *distances, int32_t *order);
 int ps_kernel_masks_f32(const int32_t *order, int L, int nrows, int ncols, int k, int dilation,
                         int mask_type_b, float *masks);
 
+/* Batched host glue of ZbufferModelPts.get_masks_for_batch (models/z_buffermodel.py:641-701) in the
+ * compact form the HIP sampler consumes: for each of the B background masks bg (B,S,S) uint8:
+ *   order_loc (B,L) int32: row-major location visited at each order position (L = G*G);
+ *   region (B,L) uint8 by location: 1 = block entirely background = sampled (sample.py:24-41);
+ *   mask_init / mask_undilated / mask_dilated (B,9,L) f32: type A dil 1, type B dil 1, type B dil 2
+ *   (one copy per image instead of the reference's x513 / x160 / x80 channel repeats, :697-699);
+ *   first_step: smallest order position that is sampled in any image (L if none). */
+int ps_ar_plan(const uint8_t *bg, int B, int S, int G, int32_t *order_loc, uint8_t *region,
+               float *mask_init, float *mask_undilated, float *mask_dilated, int32_t *first_step);
+
 /* ------------------------------------------------------------------------------------------
  * Locally masked convolution / PixelCNN (models/lmconv)
  * ---------------------------------------------------------------------------------------- */
@@ -181,6 +191,20 @@ int ps_pixelcnn_ar_step(ps_pixelcnn *h, const int32_t *codes, const int32_t *ord
                         const float *mask_init, const float *mask_undilated,
                         const float *mask_dilated, int F, int step, int first_step, float *logits,
                         void *stream);
+
+/* Measurement aid for bench.py (not part of the reference surface): evaluates `reps` column steps
+ * eagerly on `stream` at order position `step` with a HIP event pair around every kernel launch and
+ * returns, per kernel class, the number of launches and their summed duration in ms:
+ *   [0] k_gemm (masked convs + nin's on MFMA)  [1] k_post (PONO/ELU/gate)  [2] k_uinit
+ *   [3] k_post_logits  [4] reserved.
+ * gemm_flops_per_step / gemm_weight_bytes_per_step: algorithmic work of the k_gemm launches of ONE
+ * step (dense 2*Co*Cin*taps*F flops; fp32 weight bytes streamed once per launch).  Synchronises. */
+#define PS_PROF_NTAGS 5
+int ps_pixelcnn_time_column_step(ps_pixelcnn *h, const int32_t *codes, const int32_t *order,
+                                 const float *mask_init, const float *mask_undilated,
+                                 const float *mask_dilated, int F, int step, int reps, int *launches,
+                                 float *total_ms, double *gemm_flops_per_step,
+                                 double *gemm_weight_bytes_per_step, void *stream);
 
 #ifdef __cplusplus
 }

@@ -24,6 +24,7 @@ _PROTOS = {
     "ps_project_splat_f32": (c_int, [c_void_p] * 6 + [c_int, c_int, c_int, c_double, c_int, c_float, c_int, c_int,
                                                       c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "ps_generation_order": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "ps_ar_plan": (c_int, [c_void_p, c_int, c_int, c_int] + [c_void_p] * 6),
     "ps_custom_order": (c_int, [c_int, c_int, c_void_p, c_void_p]),
     "ps_kernel_masks_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "ps_lmconv_workspace_bytes": (c_size_t, [c_int] * 5),
@@ -33,6 +34,7 @@ _PROTOS = {
     "ps_pixelcnn_destroy": (None, [c_void_p]),
     "ps_pixelcnn_forward_f32": (c_int, [c_void_p] * 5 + [c_int, c_void_p, c_void_p]),
     "ps_pixelcnn_ar_run": (c_int, [c_void_p] * 9 + [c_float, c_int, c_int, c_void_p, c_void_p]),
+    "ps_pixelcnn_time_column_step": (c_int, [c_void_p] * 6 + [c_int, c_int, c_int] + [c_void_p] * 5),
     "ps_pixelcnn_ar_step": (c_int, [c_void_p] * 6 + [c_int, c_int, c_int, c_void_p, c_void_p]),
 }
 
@@ -49,6 +51,9 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python -m pixelsynth_amd.build` "
                 "(there is no CPU/PyTorch fallback for the HIP path)")
+        # torch must be imported first: it brings its own libamdhip64/libhsa-runtime64, and this library has
+        # to bind to THAT runtime instance (same streams, same allocations) instead of loading a second one.
+        import torch  # noqa: F401
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in _PROTOS.items():
             if not hasattr(L, name):

@@ -119,6 +119,34 @@ int ps_generation_order(const uint8_t *bg, int S, int G, int32_t *order, uint8_t
 }
 
 int ps_kernel_masks_f32(const int32_t *order, int L, int nrows, int ncols, int k, int dilation, int mask_type_b,
+                        float *masks);
+
+int ps_ar_plan(const uint8_t *bg, int B, int S, int G, int32_t *order_loc, uint8_t *region, float *mask_init,
+               float *mask_undilated, float *mask_dilated, int32_t *first_step)
+{
+    PS_REQUIRE(bg && order_loc && region && mask_init && mask_undilated && mask_dilated, "ar_plan: null pointer");
+    PS_REQUIRE(B > 0 && S > 0 && G > 0 && S % G == 0, "ar_plan: bad sizes");
+    const int L = G * G;
+    std::vector<int32_t> order((size_t)L * 2);
+    int first = L;
+    for (int b = 0; b < B; ++b) {
+        uint8_t *reg = region + (size_t)b * L;
+        if (int rc = ps_generation_order(bg + (size_t)b * S * S, S, G, order.data(), reg, nullptr)) return rc;
+        int32_t *ol = order_loc + (size_t)b * L;
+        for (int i = 0; i < L; ++i) {
+            ol[i] = order[2 * i] * G + order[2 * i + 1];
+            if (reg[ol[i]] && i < first) first = i;
+        }
+        const size_t mo = (size_t)b * 9 * L;
+        if (int rc = ps_kernel_masks_f32(order.data(), L, G, G, 3, 1, 0, mask_init + mo)) return rc;
+        if (int rc = ps_kernel_masks_f32(order.data(), L, G, G, 3, 1, 1, mask_undilated + mo)) return rc;
+        if (int rc = ps_kernel_masks_f32(order.data(), L, G, G, 3, 2, 1, mask_dilated + mo)) return rc;
+    }
+    if (first_step) *first_step = first;
+    return PS_OK;
+}
+
+int ps_kernel_masks_f32(const int32_t *order, int L, int nrows, int ncols, int k, int dilation, int mask_type_b,
                         float *masks)
 {
     PS_REQUIRE(order && masks, "kernel_masks: null pointer");

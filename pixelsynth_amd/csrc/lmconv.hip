@@ -397,6 +397,10 @@ struct ps_pixelcnn {
     hipGraph_t graph = nullptr;          // step graph of the last ar_run (kept alive until replaced)
     hipGraphExec_t graph_exec = nullptr;
     bool use_graph = true;
+    // bench.py profiling aid (ps_pixelcnn_time_column_step): event pair around every launch, by kernel tag
+    struct ProfRec { int tag; hipEvent_t e0, e1; };
+    std::vector<ProfRec> *prof = nullptr;
+    double prof_gemm_flops = 0.0, prof_gemm_wbytes = 0.0;
 };
 
 namespace {
@@ -441,6 +445,21 @@ struct Ctx {
     bool logits_nchw = false;  // grid mode: (F,512,H,W) like the reference, else (nitems,512)
 };
 
+enum { TAG_GEMM = 0, TAG_POST = 1, TAG_UINIT = 2, TAG_POST_LOGITS = 3, TAG_SAMPLE = 4 };
+
+template <typename Fn>
+void timed(const Ctx &c, int tag, Fn &&launch)
+{
+    if (!c.h->prof) { launch(); return; }
+    ps_pixelcnn::ProfRec r{tag, nullptr, nullptr};
+    (void)hipEventCreate(&r.e0);
+    (void)hipEventCreate(&r.e1);
+    (void)hipEventRecord(r.e0, c.st);
+    launch();
+    (void)hipEventRecord(r.e1, c.st);
+    c.h->prof->push_back(r);
+}
+
 void launch_gemm(const Ctx &c, GemmArgs &a)
 {
     a.H = c.h->H; a.W = c.h->W; a.L = c.h->L;
@@ -452,8 +471,17 @@ void launch_gemm(const Ctx &c, GemmArgs &a)
     const int tiles = (c.nitems + 15) / 16;
     a.tiles_per_block = c.column ? 1 : 8;
     const dim3 grid(a.Co_pad / 16, a.ntaps, (tiles + a.tiles_per_block - 1) / a.tiles_per_block);
-    if (c.column) hipLaunchKernelGGL(k_gemm<true>, grid, dim3(64), 0, c.st, a);
-    else hipLaunchKernelGGL(k_gemm<false>, grid, dim3(64), 0, c.st, a);
+    if (c.h->prof) {  // algorithmic work of this launch: dense 2*Co*Cin per tap and item; weights streamed once
+        for (int t = 0; t < a.ntaps; ++t) {
+            const int co = a.Co_pad;  // 80, 160, 512: no padding in the PixelSynth configuration
+            c.h->prof_gemm_flops += 2.0 * co * a.Cin * c.nitems;
+            c.h->prof_gemm_wbytes += 4.0 * co * a.Cin;
+        }
+    }
+    timed(c, TAG_GEMM, [&]() {
+        if (c.column) hipLaunchKernelGGL(k_gemm<true>, grid, dim3(64), 0, c.st, a);
+        else hipLaunchKernelGGL(k_gemm<false>, grid, dim3(64), 0, c.st, a);
+    });
 }
 
 void conv_taps(GemmArgs &a, const float *in, int ld, const float *wp, int Cin, int Co_pad, int dil, const float *mask)
@@ -475,8 +503,10 @@ void launch_post(const Ctx &c, PostArgs &p)
     p.L = c.h->L;
     p.order = c.order;
     p.step_ptr = c.h->step;
-    if (c.column) hipLaunchKernelGGL((k_post<KIND, true>), dim3(c.nitems), dim3(128), 0, c.st, p);
-    else hipLaunchKernelGGL((k_post<KIND, false>), dim3(c.nitems), dim3(128), 0, c.st, p);
+    timed(c, TAG_POST, [&]() {
+        if (c.column) hipLaunchKernelGGL((k_post<KIND, true>), dim3(c.nitems), dim3(128), 0, c.st, p);
+        else hipLaunchKernelGGL((k_post<KIND, false>), dim3(c.nitems), dim3(128), 0, c.st, p);
+    });
 }
 
 // One evaluation of the network over the context's items (whole grid or one column per frame).
@@ -487,8 +517,10 @@ void run_network(const Ctx &c, float *logits)
     {   // u_init + norm_init  (model.py:132)
         UinitArgs u{c.codes, c.m.init, (size_t)9 * h->L, h->uinit_w, h->uinit_b, h->R[0], h->E[0], h->H, h->W, h->L,
                     c.order, h->step};
-        if (c.column) hipLaunchKernelGGL(k_uinit<true>, dim3(c.nitems), dim3(128), 0, c.st, u);
-        else hipLaunchKernelGGL(k_uinit<false>, dim3(c.nitems), dim3(128), 0, c.st, u);
+        timed(c, TAG_UINIT, [&]() {
+            if (c.column) hipLaunchKernelGGL(k_uinit<true>, dim3(c.nitems), dim3(128), 0, c.st, u);
+            else hipLaunchKernelGGL(k_uinit<false>, dim3(c.nitems), dim3(128), 0, c.st, u);
+        });
     }
     auto gated = [&](int g) {
         const ps_pixelcnn::Gated &G = h->gated[g];
@@ -530,8 +562,10 @@ void run_network(const Ctx &c, float *logits)
     PostArgs p{};
     p.partial = h->partial; p.nitems = c.nitems; p.Co_pad = NCLS; p.L = h->L; p.bias = h->out_b;
     p.logits = logits; p.logits_nchw = c.logits_nchw ? 1 : 0; p.order = c.order; p.step_ptr = h->step;
-    if (c.column) hipLaunchKernelGGL(k_post_logits<true>, dim3(c.nitems), dim3(256), 0, c.st, p);
-    else hipLaunchKernelGGL(k_post_logits<false>, dim3(c.nitems), dim3(256), 0, c.st, p);
+    timed(c, TAG_POST_LOGITS, [&]() {
+        if (c.column) hipLaunchKernelGGL(k_post_logits<true>, dim3(c.nitems), dim3(256), 0, c.st, p);
+        else hipLaunchKernelGGL(k_post_logits<false>, dim3(c.nitems), dim3(256), 0, c.st, p);
+    });
 }
 
 int check_handle(ps_pixelcnn *h, int F)
@@ -721,6 +755,40 @@ int ps_pixelcnn_ar_run(ps_pixelcnn *h, int32_t *codes, const int32_t *order, con
         PS_HIP_CHECK(hipEventRecord(h->ev_out, st));
         PS_HIP_CHECK(hipStreamWaitEvent(caller, h->ev_out, 0));
     }
+    return PS_OK;
+}
+
+int ps_pixelcnn_time_column_step(ps_pixelcnn *h, const int32_t *codes, const int32_t *order, const float *mask_init,
+                                 const float *mask_undilated, const float *mask_dilated, int F, int step, int reps,
+                                 int *launches, float *total_ms, double *gemm_flops_per_step,
+                                 double *gemm_weight_bytes_per_step, void *stream)
+{
+    if (int rc = check_handle(h, F)) return rc;
+    PS_REQUIRE(codes && order && mask_init && mask_undilated && mask_dilated && launches && total_ms,
+               "pixelcnn_time_column_step: null pointer");
+    PS_REQUIRE(step >= 0 && step < h->L && reps > 0, "pixelcnn_time_column_step: bad step / reps");
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<ps_pixelcnn::ProfRec> recs;
+    hipLaunchKernelGGL(k_set_step, dim3(1), dim3(1), 0, st, h->step, step);
+    Ctx c{h, true, F, F, codes, order, Masks{mask_init, mask_undilated, mask_dilated}, st};
+    run_network(c, h->col_logits);  // untimed warm-up
+    h->prof = &recs;
+    h->prof_gemm_flops = h->prof_gemm_wbytes = 0.0;
+    for (int r = 0; r < reps; ++r) run_network(c, h->col_logits);
+    h->prof = nullptr;
+    PS_HIP_CHECK(hipStreamSynchronize(st));
+    for (int t = 0; t < PS_PROF_NTAGS; ++t) { launches[t] = 0; total_ms[t] = 0.0f; }
+    for (auto &r : recs) {
+        float ms = 0.0f;
+        (void)hipEventElapsedTime(&ms, r.e0, r.e1);
+        launches[r.tag] += 1;
+        total_ms[r.tag] += ms;
+        (void)hipEventDestroy(r.e0);
+        (void)hipEventDestroy(r.e1);
+    }
+    if (gemm_flops_per_step) *gemm_flops_per_step = h->prof_gemm_flops / reps;
+    if (gemm_weight_bytes_per_step) *gemm_weight_bytes_per_step = h->prof_gemm_wbytes / reps;
+    PS_LAUNCH_CHECK();
     return PS_OK;
 }
 
