@@ -46,30 +46,33 @@ struct GemmTap {
     int ld;            // channels per location in `in`
 };
 
+// ==========================================================================================
+// whole-grid mode: items = (frame, location) pairs of the full grid
+// ==========================================================================================
 struct GemmArgs {
     GemmTap tap[MAX_TAPS];
     int ntaps, Cin, Co_pad, H, W, L, nitems, tiles_per_block;
     const float *mask;
     size_t mask_fstride;
-    const int32_t *order;     // COLUMN mode: (F,L) location visited at each order position
-    const int32_t *step_ptr;  // COLUMN mode: current order position (device memory, graph-replayable)
-    float *partial;           // [ntaps][nitems][Co_pad]
+    float *partial;  // [ntaps][nitems][Co_pad]
 };
 
-template <bool COLUMN>
-__device__ __forceinline__ void item_map(int item, int L, const int32_t *order, const int32_t *step_ptr, int &f, int &q)
+// 5 channel groups (80 input channels) of one tap: all ten 16-byte operand loads are issued before the
+// 20 MFMAs; even groups accumulate into acc0, odd groups into acc1 (two independent chains).  Both the
+// whole-grid and the column kernels go through this function, so their summation order is identical.
+__device__ __forceinline__ void mfma_chunk5(const f32x4 (&av)[5], const f32x4 (&bv)[5], f32x4 &acc0, f32x4 &acc1)
 {
-    if (COLUMN) {
-        f = item;
-        q = order[(size_t)f * L + *step_ptr];
-    } else {
-        f = item / L;
-        q = item - f * L;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        f32x4 &acc = (j & 1) ? acc1 : acc0;
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].x, bv[j].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].y, bv[j].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].z, bv[j].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].w, bv[j].w, acc, 0, 0, 0);
     }
 }
 
 // grid (Co_pad/16, ntaps, item blocks), one wave per block
-template <bool COLUMN>
 __global__ __launch_bounds__(64) void k_gemm(GemmArgs a)
 {
     const int lane = threadIdx.x, i = lane & 15, kk = lane >> 4;
@@ -77,6 +80,7 @@ __global__ __launch_bounds__(64) void k_gemm(GemmArgs a)
     const GemmTap tp = a.tap[blockIdx.y];
     const int ngroups = a.Cin >> 4;
     const float *wbase = tp.w + ((size_t)kk * a.Co_pad + o0 + i) * 4;
+    const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
     for (int tt = 0; tt < a.tiles_per_block; ++tt) {
         const int tile = blockIdx.z * a.tiles_per_block + tt;
         if (tile * 16 >= a.nitems) break;
@@ -85,8 +89,7 @@ __global__ __launch_bounds__(64) void k_gemm(GemmArgs a)
         const float *src = nullptr;
         float mv = 0.0f;
         if (valid) {
-            int f, q;
-            item_map<COLUMN>(item, a.L, a.order, a.step_ptr, f, q);
+            const int f = item / a.L, q = item - f * a.L;
             const int r = q / a.W, c = q - r * a.W;
             const int rr = r + tp.dr, cc = c + tp.dc;
             if (rr >= 0 && rr < a.H && cc >= 0 && cc < a.W) {
@@ -95,202 +98,436 @@ __global__ __launch_bounds__(64) void k_gemm(GemmArgs a)
             }
         }
         const bool live = valid && mv != 0.0f;
-        f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+        f32x4 acc0 = zero, acc1 = zero;
         if (__any(live)) {
-#pragma unroll 2
-            for (int g = 0; g < ngroups; ++g) {
+            int g = 0;
+            for (; g + 5 <= ngroups; g += 5) {
+                f32x4 av[5], bv[5];
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    av[j] = *(const f32x4 *)(wbase + (size_t)(g + j) * 16 * a.Co_pad);
+                    bv[j] = live ? *(const f32x4 *)(src + 16 * (g + j)) * mv : zero;
+                }
+                mfma_chunk5(av, bv, acc0, acc1);
+            }
+            for (; g < ngroups; ++g) {  // ragged channel counts of the generic lmconv entry point only
                 const f32x4 av = *(const f32x4 *)(wbase + (size_t)g * 16 * a.Co_pad);
-                f32x4 bv = {0.0f, 0.0f, 0.0f, 0.0f};
-                if (live) bv = *(const f32x4 *)(src + 16 * g) * mv;
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc, 0, 0, 0);
+                const f32x4 bv = live ? *(const f32x4 *)(src + 16 * g) * mv : zero;
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc0, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc0, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc0, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc0, 0, 0, 0);
             }
         }
         // D: row (output channel) = kk*4 + reg, col (item) = i
         if (valid)
-            *(f32x4 *)(a.partial + ((size_t)blockIdx.y * a.nitems + item) * a.Co_pad + o0 + kk * 4) = acc;
+            *(f32x4 *)(a.partial + ((size_t)blockIdx.y * a.nitems + item) * a.Co_pad + o0 + kk * 4) = acc0 + acc1;
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// per-item post ops
+// per-item post ops, shared by the whole-grid kernels and the column-step prologue.  An item is
+// handled by 16 lanes; lane `sub` owns channels sub + 16*k, k = 0..4 (NF = 80).  Every reduction uses
+// the same association order in both modes, so column steps and whole-grid passes agree bit for bit.
 // ------------------------------------------------------------------------------------------
-struct PostArgs {
-    const float *partial;
-    int nslots, nitems, Co_pad, L;
-    const float *bias, *bias2;
-    const float *Rin;
-    float *Rout, *Eout, *Xout;
-    float *logits;      // POST_LOGITS output
-    int logits_nchw;    // 1: (F,512,H,W)   0: (nitems,512)
-    const int32_t *order, *step_ptr;
-};
-
 __device__ __forceinline__ float elu1(float x) { return x > 0.0f ? x : (expf(x) - 1.0f); }
 
-// block-wide sum over `n` (<= 128) values, one per thread (threads >= n pass 0)
-__device__ __forceinline__ float block_sum128(float v, float *sh)
+__device__ __forceinline__ float sum16(float v)
 {
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
-    __syncthreads();
-    const float s = sh[0] + sh[1];
-    __syncthreads();
-    return s;
+    v += __shfl_xor(v, 8, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 1, 64);
+    return v;
 }
 
-// PONO over NF channels held one per thread (threads < NF) (models/lmconv/layers.py:231-236)
-__device__ __forceinline__ float pono80(float x, bool act, float *sh)
+// PONO over the NF channels of one item (models/lmconv/layers.py:231-236), unbiased variance, eps 1e-5
+__device__ __forceinline__ void pono16x5(float (&v)[5])
 {
-    const float mean = block_sum128(act ? x : 0.0f, sh) / (float)NF;
-    const float d = act ? x - mean : 0.0f;
-    const float var = block_sum128(d * d, sh) / (float)(NF - 1);  // unbiased
-    return d / sqrtf(var + 1e-5f);
+    const float mean = sum16((((v[0] + v[1]) + v[2]) + v[3]) + v[4]) / (float)NF;
+    float d[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) d[k] = v[k] - mean;
+    const float ss = sum16((((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]) + d[3] * d[3]) + d[4] * d[4]);
+    const float sd = sqrtf(ss / (float)(NF - 1) + 1e-5f);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) v[k] = d[k] / sd;
 }
 
 enum { POST_CONVIN = 0, POST_GATE = 1, POST_DIL = 2 };
 
-template <int KIND, bool COLUMN>
-__global__ __launch_bounds__(128) void k_post(PostArgs a)
+// KIND = POST_CONVIN: out = PONO(sum conv_input + b) [+ nin_skip + b2]            (layers.py:153-156)
+//        POST_GATE:   out = rin + PONO(p) * sigmoid(g), (p,g) = sum conv_out + b   (layers.py:159-163)
+//        POST_DIL:    out = PONO(sum dilated conv + b)                             (model.py:138-140,148-150)
+template <int KIND>
+__device__ __forceinline__ void post_item(const float *__restrict__ P, int nitems, int item, int Co_pad,
+                                          const float *__restrict__ bias, const float *__restrict__ bias2,
+                                          bool has_skip, const float *__restrict__ rin, int sub, float (&out)[5])
 {
-    __shared__ float sh[2];
-    const int item = blockIdx.x, o = threadIdx.x;
-    const bool act = o < NF;
-    int f, q;
-    item_map<COLUMN>(item, a.L, a.order, a.step_ptr, f, q);
-    const size_t loc = (size_t)f * a.L + q;
-    const int nmain = 9;
-    float v = 0.0f, g = 0.0f;
-    if (act) {
-        v = a.bias[o];
-        for (int s = 0; s < nmain; ++s) v += a.partial[((size_t)s * a.nitems + item) * a.Co_pad + o];
-        if (KIND == POST_GATE) {
-            g = a.bias[o + NF];
-            for (int s = 0; s < nmain; ++s) g += a.partial[((size_t)s * a.nitems + item) * a.Co_pad + o + NF];
+    float v[5], g[5];
+    float pv[9][5], pg[9][5];
+    float sk[5];
+#pragma unroll
+    for (int s = 0; s < 9; ++s) {  // every load is issued before the first add (one L2 round trip, not nine)
+        const float *row = P + ((size_t)s * nitems + item) * Co_pad;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            pv[s][k] = row[sub + 16 * k];
+            if (KIND == POST_GATE) pg[s][k] = row[sub + 16 * k + NF];
         }
     }
-    float n = pono80(v, act, sh);
-    if (!act) return;
-    if (KIND == POST_CONVIN) {
-        if (a.nslots > nmain) n += a.partial[((size_t)nmain * a.nitems + item) * a.Co_pad + o] + a.bias2[o];
-        a.Xout[loc * (2 * NF) + o] = elu1(n);
-        a.Xout[loc * (2 * NF) + NF + o] = elu1(-n);
-    } else {
-        float u = n;
-        if (KIND == POST_GATE) u = a.Rin[loc * NF + o] + n * (1.0f / (1.0f + expf(-g)));
-        a.Rout[loc * NF + o] = u;
-        a.Eout[loc * (2 * NF) + o] = elu1(u);
-        a.Eout[loc * (2 * NF) + NF + o] = elu1(-u);
+    if (KIND == POST_CONVIN && has_skip) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) sk[k] = P[((size_t)9 * nitems + item) * Co_pad + sub + 16 * k] + bias2[sub + 16 * k];
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const int c = sub + 16 * k;
+        v[k] = bias[c];
+        if (KIND == POST_GATE) g[k] = bias[c + NF];
+#pragma unroll
+        for (int s = 0; s < 9; ++s) {
+            v[k] += pv[s][k];
+            if (KIND == POST_GATE) g[k] += pg[s][k];
+        }
+    }
+    pono16x5(v);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const int c = sub + 16 * k;
+        if (KIND == POST_CONVIN) {
+            if (has_skip) v[k] += sk[k];
+            out[k] = v[k];
+        } else if (KIND == POST_GATE) {
+            out[k] = rin[c] + v[k] * (1.0f / (1.0f + expf(-g[k])));
+        } else {
+            out[k] = v[k];
+        }
     }
 }
 
-template <bool COLUMN>
-__global__ __launch_bounds__(256) void k_post_logits(PostArgs a)
+// u_init on one-hot input as a gather, type-A mask (model.py:132):
+//   y[o] = b[o] + sum_t m_t * (W[t][512][o] + W[t][code(nbr_t)][o]) ; then norm_init (PONO)
+__device__ __forceinline__ void uinit_item(const int32_t *__restrict__ codes_f, const float *mA /*9 values*/,
+                                           const float *__restrict__ w, const float *__restrict__ bias, int q, int H,
+                                           int W, int sub, float (&out)[5])
 {
-    const int item = blockIdx.x;
-    int f, q;
-    item_map<COLUMN>(item, a.L, a.order, a.step_ptr, f, q);
-    for (int o = threadIdx.x; o < NCLS; o += 256) {
-        const float v = a.bias[o] + a.partial[(size_t)item * a.Co_pad + o];
-        if (a.logits_nchw) a.logits[((size_t)f * NCLS + o) * a.L + q] = v;
-        else a.logits[(size_t)item * NCLS + o] = v;
+    const int r = q / W, c0 = q - r * W;
+    float v[5];
+    int code[9];
+    float mv[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int rr = r + t / 3 - 1, cc = c0 + t % 3 - 1;
+        const bool in = rr >= 0 && rr < H && cc >= 0 && cc < W;
+        mv[t] = in ? mA[t] : 0.0f;
+        code[t] = (in && mv[t] != 0.0f) ? codes_f[rr * W + cc] : -1;
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) v[k] = bias[sub + 16 * k];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        if (mv[t] == 0.0f) continue;
+        const float *w1 = w + ((size_t)t * (NCLS + 1) + NCLS) * NF;
+        const float *wc = w + ((size_t)t * (NCLS + 1) + (code[t] >= 0 ? code[t] : 0)) * NF;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            float x = w1[sub + 16 * k];
+            if (code[t] >= 0) x += wc[sub + 16 * k];
+            v[k] += mv[t] * x;
+        }
+    }
+    pono16x5(v);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) out[k] = v[k];
+}
+
+__device__ __forceinline__ void store_raw_celu(float *R, float *E, size_t loc, int sub, const float (&u)[5])
+{
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const int c = sub + 16 * k;
+        R[loc * NF + c] = u[k];
+        E[loc * (2 * NF) + c] = elu1(u[k]);
+        E[loc * (2 * NF) + NF + c] = elu1(-u[k]);
     }
 }
 
-// u_init on one-hot input as a gather (type-A mask): y[o] = b[o] + sum_t m_t (W[t][code(nbr_t)][o] + W[t][512][o])
+struct PostArgs {
+    const float *partial;
+    int nitems, Co_pad, L, has_skip;
+    const float *bias, *bias2;
+    const float *Rin;
+    float *Rout, *Eout, *Xout;
+};
+
+// whole-grid post op: 16 items per 256-thread block
+template <int KIND>
+__global__ __launch_bounds__(256) void k_post_grid(PostArgs a)
+{
+    const int item = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
+    if (item >= a.nitems) return;  // whole 16-lane groups leave together
+    const size_t loc = item;       // item = f*L + q
+    float out[5];
+    post_item<KIND>(a.partial, a.nitems, item, a.Co_pad, a.bias, a.bias2, a.has_skip != 0,
+                    KIND == POST_GATE ? a.Rin + loc * NF : nullptr, sub, out);
+    if (KIND == POST_CONVIN) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int c = sub + 16 * k;
+            a.Xout[loc * (2 * NF) + c] = elu1(out[k]);
+            a.Xout[loc * (2 * NF) + NF + c] = elu1(-out[k]);
+        }
+    } else {
+        store_raw_celu(a.Rout, a.Eout, loc, sub, out);
+    }
+}
+
 struct UinitArgs {
     const int32_t *codes;  // (F,L), -1 = all-zero input
     const float *mask;     // mask_init (F,9,L)
-    size_t mask_fstride;
     const float *w;        // [9][513][NF]
     const float *bias;
     float *Rout, *Eout;
-    int H, W, L;
-    const int32_t *order, *step_ptr;
+    int H, W, L, nitems;
 };
 
-template <bool COLUMN>
-__global__ __launch_bounds__(128) void k_uinit(UinitArgs a)
+__global__ __launch_bounds__(256) void k_uinit_grid(UinitArgs a)
 {
-    __shared__ float sh[2];
-    const int item = blockIdx.x, o = threadIdx.x;
-    const bool act = o < NF;
-    int f, q;
-    item_map<COLUMN>(item, a.L, a.order, a.step_ptr, f, q);
-    const int r = q / a.W, c = q - r * a.W;
-    float v = 0.0f;
-    if (act) {
-        v = a.bias[o];
-        for (int t = 0; t < 9; ++t) {
-            const int rr = r + t / 3 - 1, cc = c + t % 3 - 1;
-            if (rr < 0 || rr >= a.H || cc < 0 || cc >= a.W) continue;
-            const float mv = a.mask[(size_t)f * a.mask_fstride + (size_t)t * a.L + q];
-            if (mv == 0.0f) continue;
-            const int code = a.codes[(size_t)f * a.L + rr * a.W + cc];
-            float w = a.w[((size_t)t * (NCLS + 1) + NCLS) * NF + o];
-            if (code >= 0) w += a.w[((size_t)t * (NCLS + 1) + code) * NF + o];
-            v += mv * w;
+    const int item = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
+    if (item >= a.nitems) return;
+    const int f = item / a.L, q = item - f * a.L;
+    float mA[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) mA[t] = a.mask[((size_t)f * 9 + t) * a.L + q];
+    float u[5];
+    uinit_item(a.codes + (size_t)f * a.L, mA, a.w, a.bias, q, a.H, a.W, sub, u);
+    store_raw_celu(a.Rout, a.Eout, (size_t)item, sub, u);
+}
+
+// logits = nin_out partial + bias; nchw: (F,512,H,W) like the reference, else (nitems,512)
+__global__ __launch_bounds__(256) void k_logits_grid(const float *partial, const float *bias, int nitems, int L,
+                                                     int nchw, float *logits)
+{
+    const int item = blockIdx.x;
+    const int f = item / L, q = item - f * L;
+    for (int o = threadIdx.x; o < NCLS; o += 256) {
+        const float v = bias[o] + partial[(size_t)item * NCLS + o];
+        if (nchw) logits[((size_t)f * NCLS + o) * L + q] = v;
+        else logits[(size_t)item * NCLS + o] = v;
+    }
+}
+
+// ==========================================================================================
+// column mode: one location per frame per order position (the incremental AR step)
+// ==========================================================================================
+struct StepCtx {
+    int step, q;
+    float m[3][9];  // mask values of location q: [0] type A dil 1, [1] type B dil 1, [2] type B dil 2
+};
+
+struct CtxArgs {
+    StepCtx *ctx;
+    const int32_t *order;
+    const float *mask[3];
+    int F, L;
+};
+
+__device__ __forceinline__ void ctx_fill(const CtxArgs &a, int f, int step, int t /*thread 0..31*/)
+{
+    if (step >= a.L) {
+        if (t == 0) a.ctx[f].step = step;
+        return;
+    }
+    const int q = a.order[(size_t)f * a.L + step];
+    if (t < 27) a.ctx[f].m[t / 9][t % 9] = a.mask[t / 9][((size_t)f * 9 + t % 9) * a.L + q];
+    if (t == 27) { a.ctx[f].step = step; a.ctx[f].q = q; }
+}
+
+__global__ __launch_bounds__(32) void k_ctx_init(CtxArgs a, int step) { ctx_fill(a, blockIdx.x, step, threadIdx.x); }
+
+enum { PRO_UINIT = 0, PRO_CONVIN = 1, PRO_GATE = 2, PRO_DIL = 3 };
+enum { IN_CELU = 0, IN_RAW = 1, IN_ELU = 2 };
+
+struct ColArgs {
+    GemmTap tap[MAX_TAPS];
+    int ntaps, Cin, Co_pad, H, W, L, F, center_tap, mask_kind;
+    float *partial;            // this stage: [ntaps][F][Co_pad]
+    const StepCtx *ctx;
+    // prologue: the post op of the PREVIOUS stage, evaluated by the centre-tap blocks
+    const float *prev_partial;
+    int prev_Co_pad, prev_has_skip;
+    const float *prev_bias, *prev_bias2;
+    const float *Rin;
+    float *Rout, *Eout, *Xout;  // caches written by the (blockIdx.x == 0) centre-tap block
+    const int32_t *codes;       // PRO_UINIT
+    const float *uinit_w, *uinit_b;
+};
+
+constexpr int SIN_LD = 2 * NF + 4;
+
+// grid (ceil(Co_pad/64), ntaps, ceil(F/16)); 4 waves = 4 output-channel tiles sharing one tap.
+// Non-centre taps read finished columns of earlier order positions from the caches; the centre tap is
+// the current location, whose input is produced here from the previous stage's tap slots.
+template <int PRO, int IN>
+__global__ __launch_bounds__(256) void k_col(ColArgs a)
+{
+    constexpr int NG = (IN == IN_CELU) ? 10 : 5;  // 16-channel groups of the input: 160 or 80 channels
+    __shared__ __attribute__((aligned(16))) float sIn[16][SIN_LD];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tapi = blockIdx.y;
+    const GemmTap tp = a.tap[tapi];
+    const int f0 = blockIdx.z * 16;
+    const bool center = tapi == a.center_tap;
+    const int cot = blockIdx.x * 4 + wave;
+    const bool has_tile = cot * 16 < a.Co_pad;
+    const int o0 = cot * 16, i = lane & 15, kk = lane >> 4;
+    const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+
+    // (1) the weight operands do not depend on anything computed this step: get them in flight first
+    f32x4 av[NG];
+    if (has_tile) {
+        const float *wbase = tp.w + ((size_t)kk * a.Co_pad + o0 + i) * 4;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) av[g] = *(const f32x4 *)(wbase + (size_t)g * 16 * a.Co_pad);
+    }
+
+    // (2) centre tap: the current location's input = post op of the previous stage (16 lanes per item)
+    if (center) {
+        const int jl = tid >> 4, sub = tid & 15;
+        const int f = f0 + jl;
+        if (f < a.F) {
+            const int q = a.ctx[f].q;
+            const size_t loc = (size_t)f * a.L + q;
+            float u[5];
+            if (PRO == PRO_UINIT) {
+                float mA[9];
+#pragma unroll
+                for (int t = 0; t < 9; ++t) mA[t] = a.ctx[f].m[0][t];
+                uinit_item(a.codes + (size_t)f * a.L, mA, a.uinit_w, a.uinit_b, q, a.H, a.W, sub, u);
+            } else if (PRO == PRO_CONVIN) {
+                post_item<POST_CONVIN>(a.prev_partial, a.F, f, a.prev_Co_pad, a.prev_bias, a.prev_bias2,
+                                       a.prev_has_skip != 0, nullptr, sub, u);
+            } else if (PRO == PRO_GATE) {
+                post_item<POST_GATE>(a.prev_partial, a.F, f, a.prev_Co_pad, a.prev_bias, nullptr, false,
+                                     a.Rin + loc * NF, sub, u);
+            } else {
+                post_item<POST_DIL>(a.prev_partial, a.F, f, a.prev_Co_pad, a.prev_bias, nullptr, false, nullptr, sub, u);
+            }
+            const bool writer = blockIdx.x == 0;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const int c = sub + 16 * k;
+                const float ep = elu1(u[k]), en = elu1(-u[k]);
+                if (IN == IN_CELU) { sIn[jl][c] = ep; sIn[jl][NF + c] = en; }
+                else if (IN == IN_RAW) sIn[jl][c] = u[k];
+                else sIn[jl][c] = ep;
+                if (writer) {
+                    if (PRO == PRO_CONVIN) {
+                        a.Xout[loc * (2 * NF) + c] = ep;
+                        a.Xout[loc * (2 * NF) + NF + c] = en;
+                    } else {
+                        a.Rout[loc * NF + c] = u[k];
+                        a.Eout[loc * (2 * NF) + c] = ep;
+                        a.Eout[loc * (2 * NF) + NF + c] = en;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (!has_tile) return;
+
+    // (3) the activation operands: LDS for the centre tap, finished columns in the caches otherwise
+    const int f = f0 + i;
+    const bool valid = f < a.F;
+    const float *src = nullptr;
+    float mv = 0.0f;
+    if (valid) {
+        const int q = a.ctx[f].q;
+        const int r = q / a.W, c = q - r * a.W;
+        const int rr = r + tp.dr, cc = c + tp.dc;
+        if (rr >= 0 && rr < a.H && cc >= 0 && cc < a.W) {
+            mv = tp.mask_row >= 0 ? a.ctx[f].m[a.mask_kind][tp.mask_row] : 1.0f;
+            src = tp.in + ((size_t)f * a.L + rr * a.W + cc) * tp.ld + 4 * kk;
         }
     }
-    const float u = pono80(v, act, sh);
-    if (!act) return;
-    const size_t loc = (size_t)f * a.L + q;
-    a.Rout[loc * NF + o] = u;
-    a.Eout[loc * (2 * NF) + o] = elu1(u);
-    a.Eout[loc * (2 * NF) + NF + o] = elu1(-u);
+    const bool live = valid && mv != 0.0f;
+    f32x4 acc0 = zero, acc1 = zero;
+    if (__any(live)) {
+        f32x4 bv[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            bv[g] = zero;
+            if (live) {
+                if (center) bv[g] = *(const f32x4 *)(&sIn[i][16 * g + 4 * kk]) * mv;
+                else bv[g] = *(const f32x4 *)(src + 16 * g) * mv;
+            }
+        }
+        // (4) two independent accumulation chains, same order as the whole-grid kernel
+#pragma unroll
+        for (int g0 = 0; g0 < NG; g0 += 5) {
+            const f32x4 (&a5)[5] = *reinterpret_cast<const f32x4 (*)[5]>(&av[g0]);
+            const f32x4 (&b5)[5] = *reinterpret_cast<const f32x4 (*)[5]>(&bv[g0]);
+            mfma_chunk5(a5, b5, acc0, acc1);
+        }
+    }
+    if (valid) *(f32x4 *)(a.partial + ((size_t)tapi * a.F + f) * a.Co_pad + o0 + kk * 4) = acc0 + acc1;
 }
 
 // ------------------------------------------------------------------------------------------
-// sampling (models/lmconv/sample.py:60-66): softmax(logits/T), one categorical draw, one-hot write
+// end of an order position: logits = nin_out + bias, categorical draw (models/lmconv/sample.py:60-66:
+// softmax(logits/T), one draw, one-hot write), then the context of the next position.
 // ------------------------------------------------------------------------------------------
-struct SampleArgs {
-    const float *logits;      // (F,512) of this step
-    int32_t *codes;           // (F,L)
-    const int32_t *order;
+struct FinishArgs {
+    const float *partial;     // nin_out slot [F][512]
+    const float *bias;
+    CtxArgs cx;
+    int32_t *codes;           // (F,L) or null (logits only)
     const uint8_t *region;    // (F,L) by location
     const int32_t *forced;    // (F,L) by location or null
     const float *uniforms;    // (F,L) by location or null
     float *out_logits;        // (F,L,512) by location or null
-    const int32_t *step_ptr;
+    float *step_logits;       // (F,512) or null
     float temperature;
-    int L;
+    int advance;              // 1: write the context of step+1
 };
 
-__global__ __launch_bounds__(512) void k_sample(SampleArgs a)
+__global__ __launch_bounds__(512) void k_finish(FinishArgs a)
 {
     __shared__ float sh[NCLS];
     __shared__ float red[8];
-    const int f = blockIdx.x, o = threadIdx.x;
-    const int q = a.order[(size_t)f * a.L + *a.step_ptr];
-    const size_t loc = (size_t)f * a.L + q;
-    const float lg = a.logits[(size_t)f * NCLS + o];
+    const int f = blockIdx.x, o = threadIdx.x, L = a.cx.L;
+    const int step = a.cx.ctx[f].step, q = a.cx.ctx[f].q;
+    const size_t loc = (size_t)f * L + q;
+    const float lg = a.partial[(size_t)f * NCLS + o] + a.bias[o];
     if (a.out_logits) a.out_logits[loc * NCLS + o] = lg;
-    if (!a.region[loc]) return;
-    if (a.forced) {
+    if (a.step_logits) a.step_logits[(size_t)f * NCLS + o] = lg;
+    const bool draw = a.codes && a.region[loc];
+    if (draw && a.forced) {
         if (o == 0) a.codes[loc] = a.forced[loc];
-        return;
-    }
-    const float x = lg / a.temperature;
-    float m = x;
-    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off, 64));
-    if ((o & 63) == 0) red[o >> 6] = m;
-    __syncthreads();
-    m = red[0];
-    for (int w = 1; w < 8; ++w) m = fmaxf(m, red[w]);
-    sh[o] = expf(x - m);
-    __syncthreads();
-    for (int off = 1; off < NCLS; off <<= 1) {  // inclusive scan
-        const float v = o >= off ? sh[o - off] : 0.0f;
+    } else if (draw) {
+        const float x = lg / a.temperature;
+        float m = x;
+        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off, 64));
+        if ((o & 63) == 0) red[o >> 6] = m;
         __syncthreads();
-        sh[o] += v;
+        m = red[0];
+        for (int w = 1; w < 8; ++w) m = fmaxf(m, red[w]);
+        sh[o] = expf(x - m);
         __syncthreads();
+        for (int off = 1; off < NCLS; off <<= 1) {  // inclusive scan
+            const float v = o >= off ? sh[o - off] : 0.0f;
+            __syncthreads();
+            sh[o] += v;
+            __syncthreads();
+        }
+        const float target = a.uniforms[loc] * sh[NCLS - 1];
+        const int cnt = __syncthreads_count(sh[o] <= target);  // classes whose cdf is <= target
+        if (o == 0) a.codes[loc] = min(cnt, NCLS - 1);
     }
-    const float target = a.uniforms[loc] * sh[NCLS - 1];
-    const bool below = sh[o] <= target;  // chosen = number of classes whose cdf is <= target
-    const int cnt = __syncthreads_count(below);
-    if (o == 0) a.codes[loc] = min(cnt, NCLS - 1);
+    __syncthreads();  // every thread has read ctx[f] before it is advanced
+    if (a.advance && o < 32) ctx_fill(a.cx, f, step + 1, o);
 }
 
 __global__ void k_mask_codes(int32_t *codes, const uint8_t *region, size_t n)
@@ -298,9 +535,6 @@ __global__ void k_mask_codes(int32_t *codes, const uint8_t *region, size_t n)
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n && region[i]) codes[i] = -1;
 }
-
-__global__ void k_set_step(int32_t *step, int v) { *step = v; }
-__global__ void k_inc_step(int32_t *step) { *step += 1; }
 
 // ------------------------------------------------------------------------------------------
 // generic NCHW lmconv helpers
@@ -390,8 +624,10 @@ struct ps_pixelcnn {
     struct Dil { float *w, *b; int node_in, node_out; } dil[4];
     float *uinit_w = nullptr, *uinit_b = nullptr, *out_w = nullptr, *out_b = nullptr;
     float *R[NNODE], *E[NNODE], *X[NGATED];
-    float *partial = nullptr, *col_logits = nullptr;
-    int32_t *step = nullptr;
+    float *partial = nullptr;                 // whole-grid tap slots [10][maxF*L][160]
+    float *col_partial[2] = {nullptr, nullptr};  // column-mode tap slots, ping-pong between stages
+    float *col_logits = nullptr;
+    StepCtx *ctx = nullptr;
     hipStream_t stream = nullptr;   // internal stream for graph capture/replay
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
     hipGraph_t graph = nullptr;          // step graph of the last ar_run (kept alive until replaced)
@@ -435,137 +671,184 @@ void release_graph(ps_pixelcnn *h)
 
 struct Masks { const float *init, *und, *dil; };
 
-struct Ctx {
-    ps_pixelcnn *h;
-    bool column;
-    int F, nitems;
-    const int32_t *codes, *order;
-    Masks m;
-    hipStream_t st;
-    bool logits_nchw = false;  // grid mode: (F,512,H,W) like the reference, else (nitems,512)
-};
-
-enum { TAG_GEMM = 0, TAG_POST = 1, TAG_UINIT = 2, TAG_POST_LOGITS = 3, TAG_SAMPLE = 4 };
+enum { TAG_GEMM = 0, TAG_POST = 1, TAG_UINIT = 2, TAG_LOGITS = 3, TAG_FINISH = 4 };
 
 template <typename Fn>
-void timed(const Ctx &c, int tag, Fn &&launch)
+void timed(ps_pixelcnn *h, hipStream_t st, int tag, Fn &&launch)
 {
-    if (!c.h->prof) { launch(); return; }
+    if (!h->prof) { launch(); return; }
     ps_pixelcnn::ProfRec r{tag, nullptr, nullptr};
     (void)hipEventCreate(&r.e0);
     (void)hipEventCreate(&r.e1);
-    (void)hipEventRecord(r.e0, c.st);
+    (void)hipEventRecord(r.e0, st);
     launch();
-    (void)hipEventRecord(r.e1, c.st);
-    c.h->prof->push_back(r);
+    (void)hipEventRecord(r.e1, st);
+    h->prof->push_back(r);
 }
 
-void launch_gemm(const Ctx &c, GemmArgs &a)
-{
-    a.H = c.h->H; a.W = c.h->W; a.L = c.h->L;
-    a.nitems = c.nitems;
-    a.mask_fstride = (size_t)9 * c.h->L;
-    a.order = c.order;
-    a.step_ptr = c.h->step;
-    a.partial = c.h->partial;
-    const int tiles = (c.nitems + 15) / 16;
-    a.tiles_per_block = c.column ? 1 : 8;
-    const dim3 grid(a.Co_pad / 16, a.ntaps, (tiles + a.tiles_per_block - 1) / a.tiles_per_block);
-    if (c.h->prof) {  // algorithmic work of this launch: dense 2*Co*Cin per tap and item; weights streamed once
-        for (int t = 0; t < a.ntaps; ++t) {
-            const int co = a.Co_pad;  // 80, 160, 512: no padding in the PixelSynth configuration
-            c.h->prof_gemm_flops += 2.0 * co * a.Cin * c.nitems;
-            c.h->prof_gemm_wbytes += 4.0 * co * a.Cin;
-        }
-    }
-    timed(c, TAG_GEMM, [&]() {
-        if (c.column) hipLaunchKernelGGL(k_gemm<true>, grid, dim3(64), 0, c.st, a);
-        else hipLaunchKernelGGL(k_gemm<false>, grid, dim3(64), 0, c.st, a);
-    });
-}
-
-void conv_taps(GemmArgs &a, const float *in, int ld, const float *wp, int Cin, int Co_pad, int dil, const float *mask)
+template <typename Args>
+void conv_taps(Args &a, const float *in, int ld, const float *wp, int Cin, int Co_pad, int dil)
 {
     a.ntaps = 9;
     a.Cin = Cin;
     a.Co_pad = Co_pad;
-    a.mask = mask;
     const size_t per_tap = (size_t)Cin * Co_pad;
     for (int t = 0; t < 9; ++t)
         a.tap[t] = GemmTap{in, wp + t * per_tap, (t / 3 - 1) * dil, (t % 3 - 1) * dil, t, ld};
 }
 
-template <int KIND>
-void launch_post(const Ctx &c, PostArgs &p)
+// ------------------------------------------------------------------------------------------
+// whole-grid evaluation (reference-faithful forward; cache build before the column steps)
+// logits: null (caches only), (F,512,H,W) when nchw, else (F*L,512) by location
+// ------------------------------------------------------------------------------------------
+void run_grid(ps_pixelcnn *h, int F, const int32_t *codes, const Masks &m, float *logits, bool nchw, hipStream_t st)
 {
-    p.partial = c.h->partial;
-    p.nitems = c.nitems;
-    p.L = c.h->L;
-    p.order = c.order;
-    p.step_ptr = c.h->step;
-    timed(c, TAG_POST, [&]() {
-        if (c.column) hipLaunchKernelGGL((k_post<KIND, true>), dim3(c.nitems), dim3(128), 0, c.st, p);
-        else hipLaunchKernelGGL((k_post<KIND, false>), dim3(c.nitems), dim3(128), 0, c.st, p);
-    });
-}
-
-// One evaluation of the network over the context's items (whole grid or one column per frame).
-// logits: (F,512,H,W) in grid mode, (F,512) in column mode; may be null in grid mode (cache build only).
-void run_network(const Ctx &c, float *logits)
-{
-    ps_pixelcnn *h = c.h;
+    const int nitems = F * h->L;
+    const int pblocks = (nitems + 15) / 16;
+    auto gemm = [&](GemmArgs &a, const float *mask) {
+        a.H = h->H; a.W = h->W; a.L = h->L; a.nitems = nitems;
+        a.mask = mask; a.mask_fstride = (size_t)9 * h->L; a.partial = h->partial; a.tiles_per_block = 8;
+        const int tiles = (nitems + 15) / 16;
+        hipLaunchKernelGGL(k_gemm, dim3(a.Co_pad / 16, a.ntaps, (tiles + 7) / 8), dim3(64), 0, st, a);
+    };
     {   // u_init + norm_init  (model.py:132)
-        UinitArgs u{c.codes, c.m.init, (size_t)9 * h->L, h->uinit_w, h->uinit_b, h->R[0], h->E[0], h->H, h->W, h->L,
-                    c.order, h->step};
-        timed(c, TAG_UINIT, [&]() {
-            if (c.column) hipLaunchKernelGGL(k_uinit<true>, dim3(c.nitems), dim3(128), 0, c.st, u);
-            else hipLaunchKernelGGL(k_uinit<false>, dim3(c.nitems), dim3(128), 0, c.st, u);
-        });
+        UinitArgs u{codes, m.init, h->uinit_w, h->uinit_b, h->R[0], h->E[0], h->H, h->W, h->L, nitems};
+        hipLaunchKernelGGL(k_uinit_grid, dim3(pblocks), dim3(256), 0, st, u);
     }
     auto gated = [&](int g) {
         const ps_pixelcnn::Gated &G = h->gated[g];
         GemmArgs a{};
-        conv_taps(a, h->E[G.node_in], 2 * NF, G.w_in, 2 * NF, NF, 1, c.m.und);      // conv_input (layers.py:153)
+        conv_taps(a, h->E[G.node_in], 2 * NF, G.w_in, 2 * NF, NF, 1);                 // conv_input (layers.py:153)
         if (G.node_skip >= 0) {                                                         // nin_skip   (layers.py:155-156)
             a.tap[9] = GemmTap{h->E[G.node_skip], G.w_skip, 0, 0, -1, 2 * NF};
             a.ntaps = 10;
         }
-        launch_gemm(c, a);
-        PostArgs p{};
-        p.nslots = a.ntaps; p.Co_pad = NF; p.bias = G.b_in; p.bias2 = G.b_skip; p.Xout = h->X[g];
-        launch_post<POST_CONVIN>(c, p);
+        gemm(a, m.und);
+        PostArgs p{h->partial, nitems, NF, h->L, G.node_skip >= 0, G.b_in, G.b_skip, nullptr, nullptr, nullptr, h->X[g]};
+        hipLaunchKernelGGL(k_post_grid<POST_CONVIN>, dim3(pblocks), dim3(256), 0, st, p);
         GemmArgs b{};
-        conv_taps(b, h->X[g], 2 * NF, G.w_out, 2 * NF, 2 * NF, 1, c.m.und);          // conv_out   (layers.py:159)
-        launch_gemm(c, b);
-        PostArgs q{};
-        q.nslots = 9; q.Co_pad = 2 * NF; q.bias = G.b_out; q.Rin = h->R[G.node_in];
-        q.Rout = h->R[G.node_out]; q.Eout = h->E[G.node_out];
-        launch_post<POST_GATE>(c, q);                                                   // gate + residual (:160-163)
+        conv_taps(b, h->X[g], 2 * NF, G.w_out, 2 * NF, 2 * NF, 1);                     // conv_out   (layers.py:159)
+        gemm(b, m.und);
+        PostArgs q{h->partial, nitems, 2 * NF, h->L, 0, G.b_out, nullptr, h->R[G.node_in], h->R[G.node_out],
+                   h->E[G.node_out], nullptr};
+        hipLaunchKernelGGL(k_post_grid<POST_GATE>, dim3(pblocks), dim3(256), 0, st, q);   // gate + residual (:160-163)
     };
     auto dilated = [&](int d) {
         const ps_pixelcnn::Dil &D = h->dil[d];
         GemmArgs a{};
-        conv_taps(a, h->R[D.node_in], NF, D.w, NF, NF, 2, c.m.dil);                   // model.py:138,148
-        launch_gemm(c, a);
-        PostArgs p{};
-        p.nslots = 9; p.Co_pad = NF; p.bias = D.b; p.Rout = h->R[D.node_out]; p.Eout = h->E[D.node_out];
-        launch_post<POST_DIL>(c, p);
+        conv_taps(a, h->R[D.node_in], NF, D.w, NF, NF, 2);                              // model.py:138,148
+        gemm(a, m.dil);
+        PostArgs p{h->partial, nitems, NF, h->L, 0, D.b, nullptr, nullptr, h->R[D.node_out], h->E[D.node_out], nullptr};
+        hipLaunchKernelGGL(k_post_grid<POST_DIL>, dim3(pblocks), dim3(256), 0, st, p);
     };
     gated(0); gated(1); dilated(0); gated(2); gated(3); dilated(1); gated(4); gated(5);     // up pass
     gated(6); gated(7); dilated(2); gated(8); gated(9); gated(10); dilated(3);              // down pass
     gated(11); gated(12); gated(13);
     if (!logits) return;
     GemmArgs a{};                                                                         // nin_out(elu(u)) model.py:153
-    a.ntaps = 1; a.Cin = NF; a.Co_pad = NCLS; a.mask = nullptr;
+    a.ntaps = 1; a.Cin = NF; a.Co_pad = NCLS;
     a.tap[0] = GemmTap{h->E[NNODE - 1], h->out_w, 0, 0, -1, 2 * NF};
-    launch_gemm(c, a);
-    PostArgs p{};
-    p.partial = h->partial; p.nitems = c.nitems; p.Co_pad = NCLS; p.L = h->L; p.bias = h->out_b;
-    p.logits = logits; p.logits_nchw = c.logits_nchw ? 1 : 0; p.order = c.order; p.step_ptr = h->step;
-    timed(c, TAG_POST_LOGITS, [&]() {
-        if (c.column) hipLaunchKernelGGL(k_post_logits<true>, dim3(c.nitems), dim3(256), 0, c.st, p);
-        else hipLaunchKernelGGL(k_post_logits<false>, dim3(c.nitems), dim3(256), 0, c.st, p);
+    gemm(a, nullptr);
+    hipLaunchKernelGGL(k_logits_grid, dim3(nitems), dim3(256), 0, st, h->partial, h->out_b, nitems, h->L, nchw ? 1 : 0,
+                       logits);
+}
+
+// ------------------------------------------------------------------------------------------
+// one column step: 33 k_col launches (each evaluates the previous stage's post op in its centre-tap
+// blocks) + k_finish.  h->ctx must describe the current order position.
+// ------------------------------------------------------------------------------------------
+struct Prev {
+    int pro = PRO_UINIT;
+    const float *partial = nullptr, *bias = nullptr, *bias2 = nullptr, *Rin = nullptr;
+    int Co_pad = 0, has_skip = 0;
+    float *Rout = nullptr, *Eout = nullptr, *Xout = nullptr;
+};
+
+template <int IN>
+void launch_col(ps_pixelcnn *h, hipStream_t st, int pro, const ColArgs &a, dim3 grid)
+{
+    timed(h, st, TAG_GEMM, [&]() {
+        switch (pro) {
+        case PRO_UINIT: hipLaunchKernelGGL((k_col<PRO_UINIT, IN>), grid, dim3(256), 0, st, a); break;
+        case PRO_CONVIN: hipLaunchKernelGGL((k_col<PRO_CONVIN, IN>), grid, dim3(256), 0, st, a); break;
+        case PRO_GATE: hipLaunchKernelGGL((k_col<PRO_GATE, IN>), grid, dim3(256), 0, st, a); break;
+        default: hipLaunchKernelGGL((k_col<PRO_DIL, IN>), grid, dim3(256), 0, st, a); break;
+        }
     });
+}
+
+void run_column(ps_pixelcnn *h, int F, const int32_t *codes, FinishArgs fin, hipStream_t st)
+{
+    int stage = 0;
+    Prev prev;  // stage 0's prologue is u_init itself
+    prev.Rout = h->R[0];
+    prev.Eout = h->E[0];
+    auto stage_launch = [&](ColArgs &a, int in_form, int mask_kind, int center) {
+        a.H = h->H; a.W = h->W; a.L = h->L; a.F = F;
+        a.center_tap = center; a.mask_kind = mask_kind;
+        a.partial = h->col_partial[stage & 1];
+        a.ctx = h->ctx;
+        a.prev_partial = prev.partial; a.prev_Co_pad = prev.Co_pad; a.prev_has_skip = prev.has_skip;
+        a.prev_bias = prev.bias; a.prev_bias2 = prev.bias2; a.Rin = prev.Rin;
+        a.Rout = prev.Rout; a.Eout = prev.Eout; a.Xout = prev.Xout;
+        a.codes = codes; a.uinit_w = h->uinit_w; a.uinit_b = h->uinit_b;
+        const dim3 grid((a.Co_pad + 63) / 64, a.ntaps, (F + 15) / 16);
+        if (h->prof)
+            for (int t = 0; t < a.ntaps; ++t) {
+                h->prof_gemm_flops += 2.0 * a.Co_pad * a.Cin * F;
+                h->prof_gemm_wbytes += 4.0 * a.Co_pad * a.Cin;
+            }
+        if (in_form == IN_CELU) launch_col<IN_CELU>(h, st, prev.pro, a, grid);
+        else if (in_form == IN_RAW) launch_col<IN_RAW>(h, st, prev.pro, a, grid);
+        else launch_col<IN_ELU>(h, st, prev.pro, a, grid);
+        prev = Prev();
+        prev.partial = a.partial;
+        prev.Co_pad = a.Co_pad;
+        ++stage;
+    };
+    auto gated = [&](int g) {
+        const ps_pixelcnn::Gated &G = h->gated[g];
+        ColArgs a{};
+        conv_taps(a, h->E[G.node_in], 2 * NF, G.w_in, 2 * NF, NF, 1);
+        if (G.node_skip >= 0) {
+            a.tap[9] = GemmTap{h->E[G.node_skip], G.w_skip, 0, 0, -1, 2 * NF};
+            a.ntaps = 10;
+        }
+        stage_launch(a, IN_CELU, 1, 4);
+        prev.pro = PRO_CONVIN; prev.bias = G.b_in; prev.bias2 = G.b_skip; prev.has_skip = G.node_skip >= 0;
+        prev.Xout = h->X[g];
+        ColArgs b{};
+        conv_taps(b, h->X[g], 2 * NF, G.w_out, 2 * NF, 2 * NF, 1);
+        stage_launch(b, IN_CELU, 1, 4);
+        prev.pro = PRO_GATE; prev.bias = G.b_out; prev.Rin = h->R[G.node_in];
+        prev.Rout = h->R[G.node_out]; prev.Eout = h->E[G.node_out];
+    };
+    auto dilated = [&](int d) {
+        const ps_pixelcnn::Dil &D = h->dil[d];
+        ColArgs a{};
+        conv_taps(a, h->R[D.node_in], NF, D.w, NF, NF, 2);
+        stage_launch(a, IN_RAW, 2, 4);
+        prev.pro = PRO_DIL; prev.bias = D.b; prev.Rout = h->R[D.node_out]; prev.Eout = h->E[D.node_out];
+    };
+    gated(0); gated(1); dilated(0); gated(2); gated(3); dilated(1); gated(4); gated(5);
+    gated(6); gated(7); dilated(2); gated(8); gated(9); gated(10); dilated(3);
+    gated(11); gated(12); gated(13);
+    ColArgs a{};  // nin_out(elu(u)): one unmasked centre tap; its prologue is the last gate
+    a.ntaps = 1; a.Cin = NF; a.Co_pad = NCLS;
+    a.tap[0] = GemmTap{h->E[NNODE - 1], h->out_w, 0, 0, -1, 2 * NF};
+    stage_launch(a, IN_ELU, 1, 0);
+    fin.partial = prev.partial;
+    fin.bias = h->out_b;
+    timed(h, st, TAG_FINISH, [&]() { hipLaunchKernelGGL(k_finish, dim3(F), dim3(512), 0, st, fin); });
+}
+
+CtxArgs make_ctx_args(ps_pixelcnn *h, const int32_t *order, const Masks &m, int F)
+{
+    CtxArgs cx{};
+    cx.ctx = h->ctx; cx.order = order;
+    cx.mask[0] = m.init; cx.mask[1] = m.und; cx.mask[2] = m.dil;
+    cx.F = F; cx.L = h->L;
+    return cx;
 }
 
 int check_handle(ps_pixelcnn *h, int F)
@@ -652,7 +935,9 @@ int ps_pixelcnn_create(const float *const *params, int n_params, int H, int W, i
     if (locs * NCLS > pfloats) pfloats = locs * NCLS;
     if ((rc = dev_alloc(h, &h->partial, pfloats))) return fail_out(rc);
     if ((rc = dev_alloc(h, &h->col_logits, (size_t)max_frames * NCLS))) return fail_out(rc);
-    if ((rc = dev_alloc(h, &h->step, 4))) return fail_out(rc);
+    for (int k = 0; k < 2; ++k)
+        if ((rc = dev_alloc(h, &h->col_partial[k], (size_t)MAX_TAPS * max_frames * NCLS))) return fail_out(rc);
+    if ((rc = dev_alloc(h, &h->ctx, (size_t)max_frames))) return fail_out(rc);
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_out, hipEventDisableTiming) != hipSuccess) {
@@ -679,8 +964,7 @@ int ps_pixelcnn_forward_f32(ps_pixelcnn *h, const int32_t *codes, const float *m
 {
     if (int rc = check_handle(h, F)) return rc;
     PS_REQUIRE(codes && mask_init && mask_undilated && mask_dilated && logits, "pixelcnn_forward: null pointer");
-    Ctx c{h, false, F, F * h->L, codes, nullptr, Masks{mask_init, mask_undilated, mask_dilated}, (hipStream_t)stream, true};
-    run_network(c, logits);
+    run_grid(h, F, codes, Masks{mask_init, mask_undilated, mask_dilated}, logits, true, (hipStream_t)stream);
     PS_LAUNCH_CHECK();
     return PS_OK;
 }
@@ -694,13 +978,13 @@ int ps_pixelcnn_ar_step(ps_pixelcnn *h, const int32_t *codes, const int32_t *ord
     PS_REQUIRE(step >= 0 && step < h->L && first_step >= 0 && first_step <= step, "pixelcnn_ar_step: bad step");
     hipStream_t st = (hipStream_t)stream;
     const Masks m{mask_init, mask_undilated, mask_dilated};
-    if (step == first_step) {
-        Ctx g{h, false, F, F * h->L, codes, nullptr, m, st};
-        run_network(g, nullptr);
-    }
-    hipLaunchKernelGGL(k_set_step, dim3(1), dim3(1), 0, st, h->step, step);
-    Ctx c{h, true, F, F, codes, order, m, st};
-    run_network(c, logits);
+    if (step == first_step) run_grid(h, F, codes, m, nullptr, false, st);
+    FinishArgs fin{};
+    fin.cx = make_ctx_args(h, order, m, F);
+    hipLaunchKernelGGL(k_ctx_init, dim3(F), dim3(32), 0, st, fin.cx, step);
+    fin.step_logits = logits;
+    fin.temperature = 1.0f;
+    run_column(h, F, codes, fin, st);
     PS_LAUNCH_CHECK();
     return PS_OK;
 }
@@ -718,36 +1002,32 @@ int ps_pixelcnn_ar_run(ps_pixelcnn *h, int32_t *codes, const int32_t *order, con
     hipStream_t caller = (hipStream_t)stream;
     hipStream_t st = h->use_graph ? h->stream : caller;
     if (h->use_graph) {  // hand over from the caller's stream to the internal (capturable) one
+        release_graph(h);
         PS_HIP_CHECK(hipEventRecord(h->ev_in, caller));
         PS_HIP_CHECK(hipStreamWaitEvent(st, h->ev_in, 0));
     }
     const Masks m{mask_init, mask_undilated, mask_dilated};
     const size_t n = (size_t)F * h->L;
     hipLaunchKernelGGL(k_mask_codes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, codes, sample_region, n);
-    Ctx g{h, false, F, F * h->L, codes, nullptr, m, st};
     // whole-grid pass: exact for every location that precedes the first sampled one; with out_logits it also
     // yields their logits, by location (the walked positions are overwritten by the column steps)
-    run_network(g, out_logits);
-    hipLaunchKernelGGL(k_set_step, dim3(1), dim3(1), 0, st, h->step, first_step);
+    run_grid(h, F, codes, m, out_logits, false, st);
+    FinishArgs fin{};
+    fin.cx = make_ctx_args(h, order, m, F);
+    fin.codes = codes; fin.region = sample_region; fin.forced = forced; fin.uniforms = uniforms;
+    fin.out_logits = out_logits; fin.temperature = temperature; fin.advance = 1;
+    hipLaunchKernelGGL(k_ctx_init, dim3(F), dim3(32), 0, st, fin.cx, first_step);
     PS_LAUNCH_CHECK();
     const int nsteps = h->L - first_step;
     if (nsteps > 0) {
-        Ctx c{h, true, F, F, codes, order, m, st};
-        SampleArgs s{h->col_logits, codes, order, sample_region, forced, uniforms, out_logits, h->step, temperature, h->L};
-        auto body = [&]() {
-            run_network(c, h->col_logits);
-            hipLaunchKernelGGL(k_sample, dim3(F), dim3(512), 0, st, s);
-            hipLaunchKernelGGL(k_inc_step, dim3(1), dim3(1), 0, st, h->step);
-        };
         if (h->use_graph) {
-            release_graph(h);
             PS_HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-            body();
+            run_column(h, F, codes, fin, st);
             PS_HIP_CHECK(hipStreamEndCapture(st, &h->graph));
             PS_HIP_CHECK(hipGraphInstantiate(&h->graph_exec, h->graph, nullptr, nullptr, 0));
             for (int sidx = 0; sidx < nsteps; ++sidx) PS_HIP_CHECK(hipGraphLaunch(h->graph_exec, st));
         } else {
-            for (int sidx = 0; sidx < nsteps; ++sidx) body();
+            for (int sidx = 0; sidx < nsteps; ++sidx) run_column(h, F, codes, fin, st);
         }
     }
     PS_LAUNCH_CHECK();
@@ -769,12 +1049,15 @@ int ps_pixelcnn_time_column_step(ps_pixelcnn *h, const int32_t *codes, const int
     PS_REQUIRE(step >= 0 && step < h->L && reps > 0, "pixelcnn_time_column_step: bad step / reps");
     hipStream_t st = (hipStream_t)stream;
     std::vector<ps_pixelcnn::ProfRec> recs;
-    hipLaunchKernelGGL(k_set_step, dim3(1), dim3(1), 0, st, h->step, step);
-    Ctx c{h, true, F, F, codes, order, Masks{mask_init, mask_undilated, mask_dilated}, st};
-    run_network(c, h->col_logits);  // untimed warm-up
+    FinishArgs fin{};
+    fin.cx = make_ctx_args(h, order, Masks{mask_init, mask_undilated, mask_dilated}, F);
+    fin.step_logits = h->col_logits;
+    fin.temperature = 1.0f;
+    hipLaunchKernelGGL(k_ctx_init, dim3(F), dim3(32), 0, st, fin.cx, step);
+    run_column(h, F, codes, fin, st);  // untimed warm-up
     h->prof = &recs;
     h->prof_gemm_flops = h->prof_gemm_wbytes = 0.0;
-    for (int r = 0; r < reps; ++r) run_network(c, h->col_logits);
+    for (int r = 0; r < reps; ++r) run_column(h, F, codes, fin, st);
     h->prof = nullptr;
     PS_HIP_CHECK(hipStreamSynchronize(st));
     for (int t = 0; t < PS_PROF_NTAGS; ++t) { launches[t] = 0; total_ms[t] = 0.0f; }
@@ -824,11 +1107,11 @@ int ps_lmconv_forward_f32(const float *x, const float *mask, size_t mask_batch_s
     hipLaunchKernelGGL(k_nchw_to_cl, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, st, x, B, Ci, Cp, L, xcl);
     hipLaunchKernelGGL(k_pack_conv, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, st, weight, Co, Ci, Cop, Cp, wp);
     GemmArgs a{};
-    conv_taps(a, xcl, Cp, wp, Cp, Cop, dilation, mask);
-    a.H = H; a.W = W; a.L = L; a.nitems = B * L; a.mask_fstride = mask_batch_stride;
-    a.order = nullptr; a.step_ptr = nullptr; a.partial = partial; a.tiles_per_block = 8;
+    conv_taps(a, xcl, Cp, wp, Cp, Cop, dilation);
+    a.H = H; a.W = W; a.L = L; a.nitems = B * L; a.mask = mask; a.mask_fstride = mask_batch_stride;
+    a.partial = partial; a.tiles_per_block = 8;
     const int tiles = (a.nitems + 15) / 16;
-    hipLaunchKernelGGL(k_gemm<false>, dim3(Cop / 16, 9, (tiles + 7) / 8), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(k_gemm, dim3(Cop / 16, 9, (tiles + 7) / 8), dim3(64), 0, st, a);
     hipLaunchKernelGGL(k_reduce_nchw, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, st, partial, bias, B, Co, Cop, L, y);
     PS_LAUNCH_CHECK();
     return PS_OK;
