@@ -79,40 +79,42 @@ def run_step(model, d, world, gather_bufs):
 
 
 def measure_roofline(model, d, out, V):
-    """Per-launch duration of the dominant kernel (k_gemm, column mode) with HIP events on the stream it is
-    launched on, against its algorithmic work (ps_pixelcnn_time_column_step)."""
+    """Per-launch duration of the two kernels of an AR order position, measured with HIP events on the stream
+    they are launched on (ps_pixelcnn_time_column_step), against their dense algorithmic work.
+    The dominant one is k_chain: the sequential centre-tap chain (33 dependent 1x1 products + post ops +
+    draw), one workgroup (= one CU) per 16 frames, fp32 MFMA bound inside that CU."""
     plan = out["plan"]
     eng = model.outpaint2.engine(32, 32, V)
     c32 = out["codes"].reshape(V, 1024).to(torch.int32).contiguous()
     step = min(1023, plan.first_step + (1024 - plan.first_step) // 2)
-    launches = (ctypes.c_int * 5)()
-    total_ms = (ctypes.c_float * 5)()
-    flops = ctypes.c_double()
-    wbytes = ctypes.c_double()
-    reps = 20
+    launches = (ctypes.c_int * 2)()
+    total_ms = (ctypes.c_float * 2)()
+    flops = (ctypes.c_double * 2)()
+    wbytes = (ctypes.c_double * 2)()
+    reps = 50
     rc = _lib.lib().ps_pixelcnn_time_column_step(
         eng.handle, _lib.ptr(c32), _lib.ptr(plan.order_loc), _lib.ptr(plan.mask_init), _lib.ptr(plan.mask_undilated),
         _lib.ptr(plan.mask_dilated), V, step, reps, ctypes.cast(launches, ctypes.c_void_p),
-        ctypes.cast(total_ms, ctypes.c_void_p), ctypes.cast(ctypes.byref(flops), ctypes.c_void_p),
-        ctypes.cast(ctypes.byref(wbytes), ctypes.c_void_p), _lib.current_stream())
+        ctypes.cast(total_ms, ctypes.c_void_p), ctypes.cast(flops, ctypes.c_void_p),
+        ctypes.cast(wbytes, ctypes.c_void_p), _lib.current_stream())
     _lib.check(rc, "ps_pixelcnn_time_column_step")
-    n_gemm = launches[0] // reps
-    avg_us = total_ms[0] * 1e3 / max(1, launches[0])
-    bytes_per_launch = wbytes.value / n_gemm
-    flops_per_launch = flops.value / n_gemm
-    gbs = bytes_per_launch / (avg_us * 1e-6) / 1e9
-    tfs = flops_per_launch / (avg_us * 1e-6) / 1e12
-    per_class = {name: {"launches_per_step": launches[i] // reps,
-                        "avg_us": round(total_ms[i] * 1e3 / max(1, launches[i]), 3)}
-                 for i, name in enumerate(["k_gemm", "k_post", "k_uinit", "k_post_logits"])}
-    return {"bound": "hbm", "kernel": "k_gemm<column> (masked-conv / nin column step, weight stream)",
-            "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5),
-            "traffic": None, "algorithmic_bytes_per_launch": round(bytes_per_launch),
-            "avg_launch_us": round(avg_us, 3), "launches_per_ar_step": n_gemm,
-            "mfma_view": {"achieved": round(tfs, 4), "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                          "frac": round(tfs / FP32_MFMA_PEAK_TF, 6),
-                          "algorithmic_flops_per_launch": round(flops_per_launch)},
-            "per_kernel_class": per_class}
+    us = [total_ms[i] * 1e3 / max(1, launches[i]) for i in range(2)]
+    active_cus = (V + 15) // 16
+    tf_chain = flops[1] / (us[1] * 1e-6) / 1e12
+    tf_nbr = flops[0] / (us[0] * 1e-6) / 1e12
+    gb_nbr = wbytes[0] / (us[0] * 1e-6) / 1e9
+    return {"bound": "mfma", "kernel": "k_chain (centre-tap chain of one AR order position, 1 workgroup per 16 frames)",
+            "achieved": round(tf_chain, 4), "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+            "frac": round(tf_chain / FP32_MFMA_PEAK_TF, 6), "traffic": None,
+            "algorithmic_flops_per_launch": round(flops[1]), "avg_launch_us": round(us[1], 3),
+            "active_cus": active_cus,
+            "frac_of_active_cus_peak": round(tf_chain / (FP32_MFMA_PEAK_TF * active_cus / 256.0), 4),
+            "k_nbr": {"what": "neighbour-tap partial sums of all 32 masked convs (whole chip, masked taps skipped)",
+                      "avg_launch_us": round(us[0], 3), "dense_flops_per_launch": round(flops[0]),
+                      "dense_tflops": round(tf_nbr, 4), "frac_mfma": round(tf_nbr / FP32_MFMA_PEAK_TF, 6),
+                      "weight_bytes_per_launch": round(wbytes[0]), "weight_stream_GBs": round(gb_nbr, 2),
+                      "frac_hbm": round(gb_nbr / HBM_PEAK_GBS, 5)},
+            "launches_per_ar_position": 2}
 
 
 def cpu_baseline(host, out, V, budget_s=20.0):

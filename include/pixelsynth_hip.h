@@ -174,8 +174,9 @@ int ps_pixelcnn_forward_f32(ps_pixelcnn *h, const int32_t *codes, const float *m
  *   first_step: order positions < first_step are not walked one by one: they must all be observed
  *   (not in the sample region) in every image, and are covered by one whole-grid pass
  *   (0 is always valid; the caller knows the orders, it built them on the host).
- * Asynchronous: the loop is replayed as a hipGraph on a stream owned by the handle, fenced against
- * the caller's stream with events on both sides. */
+ * Asynchronous on the caller's stream (two launches per order position).  With PS_AR_GRAPH=1 in the
+ * environment at handle creation the loop is replayed as a hipGraph on a stream owned by the handle,
+ * fenced against the caller's stream with events on both sides. */
 int ps_pixelcnn_ar_run(ps_pixelcnn *h, int32_t *codes, const int32_t *order,
                        const uint8_t *sample_region, const float *mask_init,
                        const float *mask_undilated, const float *mask_dilated, const int32_t *forced,
@@ -192,19 +193,19 @@ int ps_pixelcnn_ar_step(ps_pixelcnn *h, const int32_t *codes, const int32_t *ord
                         const float *mask_dilated, int F, int step, int first_step, float *logits,
                         void *stream);
 
-/* Measurement aid for bench.py (not part of the reference surface): evaluates `reps` column steps
- * eagerly on `stream` at order position `step` with a HIP event pair around every kernel launch and
- * returns, per kernel class, the number of launches and their summed duration in ms:
- *   [0] k_gemm (masked convs + nin's on MFMA)  [1] k_post (PONO/ELU/gate)  [2] k_uinit
- *   [3] k_post_logits  [4] reserved.
- * gemm_flops_per_step / gemm_weight_bytes_per_step: algorithmic work of the k_gemm launches of ONE
- * step (dense 2*Co*Cin*taps*F flops; fp32 weight bytes streamed once per launch).  Synchronises. */
-#define PS_PROF_NTAGS 5
+/* Measurement aid for bench.py (not part of the reference surface): evaluates `reps` order positions
+ * eagerly on `stream` (at position `step`, without drawing) with a HIP event pair around every kernel
+ * launch and returns, per kernel class, the number of launches and their summed duration in ms:
+ *   [0] k_nbr   (neighbour-tap partial sums of all 32 masked convs, MFMA, whole chip)
+ *   [1] k_chain (centre-tap chain + post ops + draw, one workgroup per 16 frames)
+ * flops_per_launch / weight_bytes_per_launch [2]: dense algorithmic work of one launch of each class
+ * (2*Co*Cin per tap and frame; fp32 weight bytes streamed once).  Synchronises the stream. */
+#define PS_PROF_NTAGS 2
 int ps_pixelcnn_time_column_step(ps_pixelcnn *h, const int32_t *codes, const int32_t *order,
                                  const float *mask_init, const float *mask_undilated,
                                  const float *mask_dilated, int F, int step, int reps, int *launches,
-                                 float *total_ms, double *gemm_flops_per_step,
-                                 double *gemm_weight_bytes_per_step, void *stream);
+                                 float *total_ms, double *flops_per_launch,
+                                 double *weight_bytes_per_launch, void *stream);
 
 #ifdef __cplusplus
 }

@@ -32,6 +32,13 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Pointers that reach a kernel through a descriptor in memory (StageDesc) are "generic" to the compiler,
+// which then emits FLAT loads/stores.  FLAT ops also count on lgkmcnt, so an LDS-only barrier
+// (s_waitcnt lgkmcnt(0)) would drain every weight / slot prefetch in flight.  All descriptor pointers
+// are device-global memory: say so, and get global_load / global_store.
+#define PS_G(T, p) ((__attribute__((address_space(1))) T *)(p))
+#define PS_GC(T, p) ((const __attribute__((address_space(1))) T *)(p))
+
 constexpr int NF = 80;        // nr_filters          (models/z_buffermodel.py:63)
 constexpr int NCLS = 512;     // input_channels / classes
 constexpr int NNODE = 19;     // u0..u8 (up pass) + d0..d9 (down pass)
@@ -46,20 +53,15 @@ struct GemmTap {
     int ld;            // channels per location in `in`
 };
 
-// ==========================================================================================
-// whole-grid mode: items = (frame, location) pairs of the full grid
-// ==========================================================================================
-struct GemmArgs {
-    GemmTap tap[MAX_TAPS];
-    int ntaps, Cin, Co_pad, H, W, L, nitems, tiles_per_block;
-    const float *mask;
-    size_t mask_fstride;
-    float *partial;  // [ntaps][nitems][Co_pad]
-};
+// Split-K slots of a masked 3x3 conv.  Every consumer adds them in this order:
+//   y = ((bias + NA) + C) + NB          (+ SKIP after the norm, layers.py:155-156)
+enum { SLOT_NA = 0 /* taps 0..3 */, SLOT_C = 1 /* tap 4, the location itself */, SLOT_NB = 2 /* taps 5..8 */,
+       SLOT_SKIP = 3 /* nin_skip 1x1 */ };
 
 // 5 channel groups (80 input channels) of one tap: all ten 16-byte operand loads are issued before the
-// 20 MFMAs; even groups accumulate into acc0, odd groups into acc1 (two independent chains).  Both the
-// whole-grid and the column kernels go through this function, so their summation order is identical.
+// 20 MFMAs; even groups accumulate into acc0, odd groups into acc1 (two independent chains).  Every
+// kernel goes through this function and walks taps / chunks in the same order, so the whole-grid
+// pass and the column steps produce identical bits.
 __device__ __forceinline__ void mfma_chunk5(const f32x4 (&av)[5], const f32x4 (&bv)[5], f32x4 &acc0, f32x4 &acc1)
 {
 #pragma unroll
@@ -72,34 +74,50 @@ __device__ __forceinline__ void mfma_chunk5(const f32x4 (&av)[5], const f32x4 (&
     }
 }
 
-// grid (Co_pad/16, ntaps, item blocks), one wave per block
+// ==========================================================================================
+// whole-grid mode: items = (frame, location) pairs of the full grid
+// ==========================================================================================
+struct GemmArgs {
+    GemmTap tap[MAX_TAPS];
+    int slot_first[5];  // slot s covers taps [slot_first[s], slot_first[s+1])
+    int nslots, Cin, Co_pad, H, W, L, nitems, tiles_per_block;
+    const float *mask;
+    size_t mask_fstride;
+    float *partial;  // [nslots][nitems][Co_pad]
+};
+
+// grid (Co_pad/16, nslots, item blocks), one wave per block
 __global__ __launch_bounds__(64) void k_gemm(GemmArgs a)
 {
     const int lane = threadIdx.x, i = lane & 15, kk = lane >> 4;
-    const int o0 = blockIdx.x * 16;
-    const GemmTap tp = a.tap[blockIdx.y];
+    const int o0 = blockIdx.x * 16, slot = blockIdx.y;
     const int ngroups = a.Cin >> 4;
-    const float *wbase = tp.w + ((size_t)kk * a.Co_pad + o0 + i) * 4;
     const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
     for (int tt = 0; tt < a.tiles_per_block; ++tt) {
         const int tile = blockIdx.z * a.tiles_per_block + tt;
         if (tile * 16 >= a.nitems) break;
         const int item = tile * 16 + i;
         const bool valid = item < a.nitems;
-        const float *src = nullptr;
-        float mv = 0.0f;
+        int f = 0, r = 0, c = 0, q = 0;
         if (valid) {
-            const int f = item / a.L, q = item - f * a.L;
-            const int r = q / a.W, c = q - r * a.W;
+            f = item / a.L;
+            q = item - f * a.L;
+            r = q / a.W;
+            c = q - r * a.W;
+        }
+        f32x4 acc0 = zero, acc1 = zero;
+        for (int t = a.slot_first[slot]; t < a.slot_first[slot + 1]; ++t) {
+            const GemmTap tp = a.tap[t];
+            const float *src = nullptr;
+            float mv = 0.0f;
             const int rr = r + tp.dr, cc = c + tp.dc;
-            if (rr >= 0 && rr < a.H && cc >= 0 && cc < a.W) {
+            if (valid && rr >= 0 && rr < a.H && cc >= 0 && cc < a.W) {
                 mv = tp.mask_row >= 0 ? a.mask[(size_t)f * a.mask_fstride + (size_t)tp.mask_row * a.L + q] : 1.0f;
                 src = tp.in + ((size_t)f * a.L + rr * a.W + cc) * tp.ld + 4 * kk;
             }
-        }
-        const bool live = valid && mv != 0.0f;
-        f32x4 acc0 = zero, acc1 = zero;
-        if (__any(live)) {
+            const bool live = mv != 0.0f;
+            if (!__any(live)) continue;  // a masked tap adds exact zeros: skipping it does not change the bits
+            const float *wbase = tp.w + ((size_t)kk * a.Co_pad + o0 + i) * 4;
             int g = 0;
             for (; g + 5 <= ngroups; g += 5) {
                 f32x4 av[5], bv[5];
@@ -121,94 +139,88 @@ __global__ __launch_bounds__(64) void k_gemm(GemmArgs a)
         }
         // D: row (output channel) = kk*4 + reg, col (item) = i
         if (valid)
-            *(f32x4 *)(a.partial + ((size_t)blockIdx.y * a.nitems + item) * a.Co_pad + o0 + kk * 4) = acc0 + acc1;
+            *(f32x4 *)(a.partial + ((size_t)slot * a.nitems + item) * a.Co_pad + o0 + kk * 4) = acc0 + acc1;
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// per-item post ops, shared by the whole-grid kernels and the column-step prologue.  An item is
-// handled by 16 lanes; lane `sub` owns channels sub + 16*k, k = 0..4 (NF = 80).  Every reduction uses
-// the same association order in both modes, so column steps and whole-grid passes agree bit for bit.
+// per-item post ops, shared by the whole-grid kernels and the column chain.  An item is handled by
+// 16 lanes; lane `sub` owns channels sub + 16*k, k = 0..4 (NF = 80): every per-channel access of a wave is a
+// 64-byte run per item (measured faster than 5 contiguous channels per lane, whose 20-byte lane stride
+// touches 5x the cache lines per instruction).  Every reduction uses the same
+// association order in both modes, so column steps and whole-grid passes agree bit for bit.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ float elu1(float x) { return x > 0.0f ? x : (expf(x) - 1.0f); }
+// Elementwise math of the post ops.  These sit on the sequential critical path of every AR order position
+// (k_chain), so they use the hardware transcendental units directly (v_exp_f32 / v_rcp_f32 / v_rsq_f32,
+// ~1 ulp) instead of the libm-exact sequences; the result stays ~1e-7 relative to the exact value,
+// far inside the 1e-4 logit tolerance, and both evaluation modes share these functions bit for bit.
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+__device__ __forceinline__ float elu1(float x) { return x > 0.0f ? x : (fast_exp(x) - 1.0f); }
+// concat_elu of one value: (elu(x), elu(-x)) with a single exponential (utils.py:31-35)
+__device__ __forceinline__ void celu_pair(float x, float &ep, float &en)
+{
+    const float e = fast_exp(-fabsf(x)) - 1.0f;
+    ep = x > 0.0f ? x : e;
+    en = x > 0.0f ? e : -x;
+}
+__device__ __forceinline__ float sigmoid1(float x) { return __builtin_amdgcn_rcpf(1.0f + fast_exp(-x)); }
 
+// all-reduce over the 16 lanes of an item with DPP row rotations (no LDS round trips).  Rotation by
+// 8, 4, 2, 1 pairs each lane with the same partners as an xor butterfly (the partial sums are periodic
+// with the rotation distance), and a+b == b+a bitwise, so every lane ends with identical bits.
+template <int N>
+__device__ __forceinline__ float row_ror(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + N, 0xf, 0xf, false));
+}
 __device__ __forceinline__ float sum16(float v)
 {
-    v += __shfl_xor(v, 8, 64);
-    v += __shfl_xor(v, 4, 64);
-    v += __shfl_xor(v, 2, 64);
-    v += __shfl_xor(v, 1, 64);
+    v += row_ror<8>(v);
+    v += row_ror<4>(v);
+    v += row_ror<2>(v);
+    v += row_ror<1>(v);
     return v;
 }
 
 // PONO over the NF channels of one item (models/lmconv/layers.py:231-236), unbiased variance, eps 1e-5
 __device__ __forceinline__ void pono16x5(float (&v)[5])
 {
-    const float mean = sum16((((v[0] + v[1]) + v[2]) + v[3]) + v[4]) / (float)NF;
+    const float mean = sum16((((v[0] + v[1]) + v[2]) + v[3]) + v[4]) * (1.0f / (float)NF);
     float d[5];
 #pragma unroll
     for (int k = 0; k < 5; ++k) d[k] = v[k] - mean;
     const float ss = sum16((((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]) + d[3] * d[3]) + d[4] * d[4]);
-    const float sd = sqrtf(ss / (float)(NF - 1) + 1e-5f);
+    const float inv = __builtin_amdgcn_rsqf(ss * (1.0f / (float)(NF - 1)) + 1e-5f);
 #pragma unroll
-    for (int k = 0; k < 5; ++k) v[k] = d[k] / sd;
+    for (int k = 0; k < 5; ++k) v[k] = d[k] * inv;
 }
+
+__device__ __forceinline__ float slot_sum(float bias, float na, float c, float nb) { return ((bias + na) + c) + nb; }
 
 enum { POST_CONVIN = 0, POST_GATE = 1, POST_DIL = 2 };
 
-// KIND = POST_CONVIN: out = PONO(sum conv_input + b) [+ nin_skip + b2]            (layers.py:153-156)
-//        POST_GATE:   out = rin + PONO(p) * sigmoid(g), (p,g) = sum conv_out + b   (layers.py:159-163)
-//        POST_DIL:    out = PONO(sum dilated conv + b)                             (model.py:138-140,148-150)
+// v (and g for the gate): conv output INCLUDING bias, already slot-summed by the caller.
+// KIND = POST_CONVIN: out = PONO(v) [+ skip]                         (layers.py:153-156)
+//        POST_GATE:   out = rin + PONO(v) * sigmoid(g)                (layers.py:159-163)
+//        POST_DIL:    out = PONO(v)                                   (model.py:138-140,148-150)
 template <int KIND>
-__device__ __forceinline__ void post_item(const float *__restrict__ P, int nitems, int item, int Co_pad,
-                                          const float *__restrict__ bias, const float *__restrict__ bias2,
-                                          bool has_skip, const float *__restrict__ rin, int sub, float (&out)[5])
+__device__ __forceinline__ void post_math(float (&v)[5], const float (&g)[5], const float (&skip)[5], bool has_skip,
+                                          const float (&rin)[5], float (&out)[5])
 {
-    float v[5], g[5];
-    float pv[9][5], pg[9][5];
-    float sk[5];
-#pragma unroll
-    for (int s = 0; s < 9; ++s) {  // every load is issued before the first add (one L2 round trip, not nine)
-        const float *row = P + ((size_t)s * nitems + item) * Co_pad;
-#pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            pv[s][k] = row[sub + 16 * k];
-            if (KIND == POST_GATE) pg[s][k] = row[sub + 16 * k + NF];
-        }
-    }
-    if (KIND == POST_CONVIN && has_skip) {
-#pragma unroll
-        for (int k = 0; k < 5; ++k) sk[k] = P[((size_t)9 * nitems + item) * Co_pad + sub + 16 * k] + bias2[sub + 16 * k];
-    }
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {
-        const int c = sub + 16 * k;
-        v[k] = bias[c];
-        if (KIND == POST_GATE) g[k] = bias[c + NF];
-#pragma unroll
-        for (int s = 0; s < 9; ++s) {
-            v[k] += pv[s][k];
-            if (KIND == POST_GATE) g[k] += pg[s][k];
-        }
-    }
     pono16x5(v);
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
-        const int c = sub + 16 * k;
-        if (KIND == POST_CONVIN) {
-            if (has_skip) v[k] += sk[k];
-            out[k] = v[k];
-        } else if (KIND == POST_GATE) {
-            out[k] = rin[c] + v[k] * (1.0f / (1.0f + expf(-g[k])));
-        } else {
-            out[k] = v[k];
-        }
+        if (KIND == POST_CONVIN) out[k] = has_skip ? v[k] + skip[k] : v[k];
+        else if (KIND == POST_GATE) out[k] = rin[k] + v[k] * sigmoid1(g[k]);
+        else out[k] = v[k];
     }
 }
 
-// u_init on one-hot input as a gather, type-A mask (model.py:132):
-//   y[o] = b[o] + sum_t m_t * (W[t][512][o] + W[t][code(nbr_t)][o]) ; then norm_init (PONO)
-__device__ __forceinline__ void uinit_item(const int32_t *__restrict__ codes_f, const float *mA /*9 values*/,
+// u_init on one-hot input as a gather, type-A mask (model.py:132), BEFORE norm_init:
+//   y[o] = b[o] + sum_t m_t * (W[t][512][o] + W[t][code(nbr_t)][o])
+// Only earlier order positions contribute (the centre of a type-A mask is 0), so in column mode this
+// belongs to the neighbour kernel, not to the chain.
+__device__ __forceinline__ void uinit_gather(const int32_t *__restrict__ codes_f, const float *mA /*9 values*/,
                                            const float *__restrict__ w, const float *__restrict__ bias, int q, int H,
                                            int W, int sub, float (&out)[5])
 {
@@ -237,7 +249,6 @@ __device__ __forceinline__ void uinit_item(const int32_t *__restrict__ codes_f, 
             v[k] += mv[t] * x;
         }
     }
-    pono16x5(v);
 #pragma unroll
     for (int k = 0; k < 5; ++k) out[k] = v[k];
 }
@@ -247,14 +258,16 @@ __device__ __forceinline__ void store_raw_celu(float *R, float *E, size_t loc, i
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
         const int c = sub + 16 * k;
+        float ep, en;
+        celu_pair(u[k], ep, en);
         R[loc * NF + c] = u[k];
-        E[loc * (2 * NF) + c] = elu1(u[k]);
-        E[loc * (2 * NF) + NF + c] = elu1(-u[k]);
+        E[loc * (2 * NF) + c] = ep;
+        E[loc * (2 * NF) + NF + c] = en;
     }
 }
 
 struct PostArgs {
-    const float *partial;
+    const float *partial;  // [slots][nitems][Co_pad]
     int nitems, Co_pad, L, has_skip;
     const float *bias, *bias2;
     const float *Rin;
@@ -268,15 +281,29 @@ __global__ __launch_bounds__(256) void k_post_grid(PostArgs a)
     const int item = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
     if (item >= a.nitems) return;  // whole 16-lane groups leave together
     const size_t loc = item;       // item = f*L + q
-    float out[5];
-    post_item<KIND>(a.partial, a.nitems, item, a.Co_pad, a.bias, a.bias2, a.has_skip != 0,
-                    KIND == POST_GATE ? a.Rin + loc * NF : nullptr, sub, out);
+    const size_t ss = (size_t)a.nitems * a.Co_pad;
+    const float *P = a.partial + (size_t)item * a.Co_pad;
+    float v[5], g[5], skip[5], rin[5], out[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const int c = sub + 16 * k;
+        v[k] = slot_sum(a.bias[c], P[SLOT_NA * ss + c], P[SLOT_C * ss + c], P[SLOT_NB * ss + c]);
+        g[k] = skip[k] = rin[k] = 0.0f;
+        if (KIND == POST_GATE) {
+            g[k] = slot_sum(a.bias[c + NF], P[SLOT_NA * ss + c + NF], P[SLOT_C * ss + c + NF], P[SLOT_NB * ss + c + NF]);
+            rin[k] = a.Rin[loc * NF + c];
+        }
+        if (KIND == POST_CONVIN && a.has_skip) skip[k] = P[SLOT_SKIP * ss + c] + a.bias2[c];
+    }
+    post_math<KIND>(v, g, skip, a.has_skip != 0, rin, out);
     if (KIND == POST_CONVIN) {
 #pragma unroll
         for (int k = 0; k < 5; ++k) {
             const int c = sub + 16 * k;
-            a.Xout[loc * (2 * NF) + c] = elu1(out[k]);
-            a.Xout[loc * (2 * NF) + NF + c] = elu1(-out[k]);
+            float ep, en;
+            celu_pair(out[k], ep, en);
+            a.Xout[loc * (2 * NF) + c] = ep;
+            a.Xout[loc * (2 * NF) + NF + c] = en;
         }
     } else {
         store_raw_celu(a.Rout, a.Eout, loc, sub, out);
@@ -301,7 +328,8 @@ __global__ __launch_bounds__(256) void k_uinit_grid(UinitArgs a)
 #pragma unroll
     for (int t = 0; t < 9; ++t) mA[t] = a.mask[((size_t)f * 9 + t) * a.L + q];
     float u[5];
-    uinit_item(a.codes + (size_t)f * a.L, mA, a.w, a.bias, q, a.H, a.W, sub, u);
+    uinit_gather(a.codes + (size_t)f * a.L, mA, a.w, a.bias, q, a.H, a.W, sub, u);
+    pono16x5(u);  // norm_init
     store_raw_celu(a.Rout, a.Eout, (size_t)item, sub, u);
 }
 
@@ -312,14 +340,22 @@ __global__ __launch_bounds__(256) void k_logits_grid(const float *partial, const
     const int item = blockIdx.x;
     const int f = item / L, q = item - f * L;
     for (int o = threadIdx.x; o < NCLS; o += 256) {
-        const float v = bias[o] + partial[(size_t)item * NCLS + o];
+        const float v = partial[(size_t)item * NCLS + o] + bias[o];
         if (nchw) logits[((size_t)f * NCLS + o) * L + q] = v;
         else logits[(size_t)item * NCLS + o] = v;
     }
 }
 
 // ==========================================================================================
-// column mode: one location per frame per order position (the incremental AR step)
+// column mode: one location per frame per order position (the incremental AR step).
+// Two launches per order position:
+//   k_nbr    every NEIGHBOUR-tap partial sum (slots NA, NB) of all 32 masked convs at once.  They only
+//            read finished columns of earlier order positions, so they do not depend on this
+//            position's chain and run fully parallel (one wave = one stage x slot x 16 channels).
+//   k_chain  one workgroup per 16 frames walks the 33 stages in order.  Only the centre taps
+//            (1x1 products on the fresh activation) and the post ops are sequential; activations go
+//            stage to stage through LDS, weights stream from L2.  Ends with the categorical draw and
+//            the context of the next order position.
 // ==========================================================================================
 struct StepCtx {
     int step, q;
@@ -348,142 +384,113 @@ __global__ __launch_bounds__(32) void k_ctx_init(CtxArgs a, int step) { ctx_fill
 
 enum { PRO_UINIT = 0, PRO_CONVIN = 1, PRO_GATE = 2, PRO_DIL = 3 };
 enum { IN_CELU = 0, IN_RAW = 1, IN_ELU = 2 };
+constexpr int NST = 33;       // 14 x (conv_input, conv_out) + 4 dilated convs + nin_out
+constexpr int NBR_LD = 2 * NF;
+constexpr int SIN_LD = 2 * NF + 4;
+constexpr int SL_LD = NCLS + 4;
+constexpr int CHAIN_WAVES = 10;
 
-struct ColArgs {
-    GemmTap tap[MAX_TAPS];
-    int ntaps, Cin, Co_pad, H, W, L, F, center_tap, mask_kind;
-    float *partial;            // this stage: [ntaps][F][Co_pad]
-    const StepCtx *ctx;
-    // prologue: the post op of the PREVIOUS stage, evaluated by the centre-tap blocks
-    const float *prev_partial;
-    int prev_Co_pad, prev_has_skip;
-    const float *prev_bias, *prev_bias2;
-    const float *Rin;
-    float *Rout, *Eout, *Xout;  // caches written by the (blockIdx.x == 0) centre-tap block
-    const int32_t *codes;       // PRO_UINIT
-    const float *uinit_w, *uinit_b;
+struct __attribute__((aligned(16))) StageDesc {
+    // control words first, 16-byte aligned: k_chain fetches them with two ds_read_b128 per stage
+    int pro, in_form, save_slot /* keep this u in LDS, -1 */, p_has_skip;
+    int NG, Co_pad, center_tap, skip_slot /* saved u_k feeding w_skip, -1 */;
+    const float *w;       // packed weights [taps][NG*4][Co_pad][4]
+    const float *w_skip;  // packed nin_skip [40][80][4] or null
+    const float *in;      // cache the neighbour taps gather from (E / X / R at earlier order positions)
+    int in_ld, dil, mask_kind, has_nbr;
+    // prologue of this stage = post op of the previous stage
+    const float *pbias, *pbias2;
+    float *outR, *outE, *outX;  // caches the prologue writes at the current location
 };
 
-constexpr int SIN_LD = 2 * NF + 4;
+struct NbrWork { int stage, half, cog; };
 
-// grid (ceil(Co_pad/64), ntaps, ceil(F/16)); 4 waves = 4 output-channel tiles sharing one tap.
-// Non-centre taps read finished columns of earlier order positions from the caches; the centre tap is
-// the current location, whose input is produced here from the previous stage's tap slots.
-template <int PRO, int IN>
-__global__ __launch_bounds__(256) void k_col(ColArgs a)
+struct NbrArgs {
+    const StageDesc *stages;
+    const NbrWork *work;
+    const StepCtx *ctx;
+    float *nbr;   // [NST][2][F][NBR_LD]
+    float *upre;  // [F][NF] u_init before norm_init
+    const int32_t *codes;
+    const float *uinit_w, *uinit_b;
+    int nwork, H, W, L, F;
+};
+
+template <int NG>
+__device__ __forceinline__ void nbr_taps(const StageDesc &sd, const NbrArgs &a, int half, int o0, int f, bool valid,
+                                         int i, int kk, f32x4 &acc0, f32x4 &acc1)
 {
-    constexpr int NG = (IN == IN_CELU) ? 10 : 5;  // 16-channel groups of the input: 160 or 80 channels
-    __shared__ __attribute__((aligned(16))) float sIn[16][SIN_LD];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int tapi = blockIdx.y;
-    const GemmTap tp = a.tap[tapi];
-    const int f0 = blockIdx.z * 16;
-    const bool center = tapi == a.center_tap;
-    const int cot = blockIdx.x * 4 + wave;
-    const bool has_tile = cot * 16 < a.Co_pad;
-    const int o0 = cot * 16, i = lane & 15, kk = lane >> 4;
     const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
-
-    // (1) the weight operands do not depend on anything computed this step: get them in flight first
-    f32x4 av[NG];
-    if (has_tile) {
-        const float *wbase = tp.w + ((size_t)kk * a.Co_pad + o0 + i) * 4;
-#pragma unroll
-        for (int g = 0; g < NG; ++g) av[g] = *(const f32x4 *)(wbase + (size_t)g * 16 * a.Co_pad);
-    }
-
-    // (2) centre tap: the current location's input = post op of the previous stage (16 lanes per item)
-    if (center) {
-        const int jl = tid >> 4, sub = tid & 15;
-        const int f = f0 + jl;
-        if (f < a.F) {
-            const int q = a.ctx[f].q;
-            const size_t loc = (size_t)f * a.L + q;
-            float u[5];
-            if (PRO == PRO_UINIT) {
-                float mA[9];
-#pragma unroll
-                for (int t = 0; t < 9; ++t) mA[t] = a.ctx[f].m[0][t];
-                uinit_item(a.codes + (size_t)f * a.L, mA, a.uinit_w, a.uinit_b, q, a.H, a.W, sub, u);
-            } else if (PRO == PRO_CONVIN) {
-                post_item<POST_CONVIN>(a.prev_partial, a.F, f, a.prev_Co_pad, a.prev_bias, a.prev_bias2,
-                                       a.prev_has_skip != 0, nullptr, sub, u);
-            } else if (PRO == PRO_GATE) {
-                post_item<POST_GATE>(a.prev_partial, a.F, f, a.prev_Co_pad, a.prev_bias, nullptr, false,
-                                     a.Rin + loc * NF, sub, u);
-            } else {
-                post_item<POST_DIL>(a.prev_partial, a.F, f, a.prev_Co_pad, a.prev_bias, nullptr, false, nullptr, sub, u);
-            }
-            const bool writer = blockIdx.x == 0;
-#pragma unroll
-            for (int k = 0; k < 5; ++k) {
-                const int c = sub + 16 * k;
-                const float ep = elu1(u[k]), en = elu1(-u[k]);
-                if (IN == IN_CELU) { sIn[jl][c] = ep; sIn[jl][NF + c] = en; }
-                else if (IN == IN_RAW) sIn[jl][c] = u[k];
-                else sIn[jl][c] = ep;
-                if (writer) {
-                    if (PRO == PRO_CONVIN) {
-                        a.Xout[loc * (2 * NF) + c] = ep;
-                        a.Xout[loc * (2 * NF) + NF + c] = en;
-                    } else {
-                        a.Rout[loc * NF + c] = u[k];
-                        a.Eout[loc * (2 * NF) + c] = ep;
-                        a.Eout[loc * (2 * NF) + NF + c] = en;
-                    }
-                }
-            }
-        }
-        __syncthreads();
-    }
-    if (!has_tile) return;
-
-    // (3) the activation operands: LDS for the centre tap, finished columns in the caches otherwise
-    const int f = f0 + i;
-    const bool valid = f < a.F;
-    const float *src = nullptr;
-    float mv = 0.0f;
+    int q = 0, r = 0, c = 0;
     if (valid) {
-        const int q = a.ctx[f].q;
-        const int r = q / a.W, c = q - r * a.W;
-        const int rr = r + tp.dr, cc = c + tp.dc;
-        if (rr >= 0 && rr < a.H && cc >= 0 && cc < a.W) {
-            mv = tp.mask_row >= 0 ? a.ctx[f].m[a.mask_kind][tp.mask_row] : 1.0f;
-            src = tp.in + ((size_t)f * a.L + rr * a.W + cc) * tp.ld + 4 * kk;
-        }
+        q = a.ctx[f].q;
+        r = q / a.W;
+        c = q - r * a.W;
     }
-    const bool live = valid && mv != 0.0f;
-    f32x4 acc0 = zero, acc1 = zero;
-    if (__any(live)) {
-        f32x4 bv[NG];
+    const size_t per_tap = (size_t)NG * 16 * sd.Co_pad;
 #pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            bv[g] = zero;
-            if (live) {
-                if (center) bv[g] = *(const f32x4 *)(&sIn[i][16 * g + 4 * kk]) * mv;
-                else bv[g] = *(const f32x4 *)(src + 16 * g) * mv;
-            }
+    for (int tt = 0; tt < 4; ++tt) {
+        const int t = half * 5 + tt;  // taps 0..3 or 5..8
+        const int rr = r + (t / 3 - 1) * sd.dil, cc = c + (t % 3 - 1) * sd.dil;
+        float mv = 0.0f;
+        const float *src = nullptr;
+        if (valid && rr >= 0 && rr < a.H && cc >= 0 && cc < a.W) {
+            mv = a.ctx[f].m[sd.mask_kind][t];
+            src = sd.in + ((size_t)f * a.L + rr * a.W + cc) * sd.in_ld + 4 * kk;
         }
-        // (4) two independent accumulation chains, same order as the whole-grid kernel
+        const bool live = mv != 0.0f;
+        if (!__any(live)) continue;
+        const float *wbase = sd.w + t * per_tap + ((size_t)kk * sd.Co_pad + o0 + i) * 4;
 #pragma unroll
         for (int g0 = 0; g0 < NG; g0 += 5) {
-            const f32x4 (&a5)[5] = *reinterpret_cast<const f32x4 (*)[5]>(&av[g0]);
-            const f32x4 (&b5)[5] = *reinterpret_cast<const f32x4 (*)[5]>(&bv[g0]);
-            mfma_chunk5(a5, b5, acc0, acc1);
+            f32x4 av[5], bv[5];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                av[j] = *PS_GC(f32x4, wbase + (size_t)(g0 + j) * 16 * sd.Co_pad);
+                bv[j] = live ? *PS_GC(f32x4, src + 16 * (g0 + j)) * mv : zero;
+            }
+            mfma_chunk5(av, bv, acc0, acc1);
         }
     }
-    if (valid) *(f32x4 *)(a.partial + ((size_t)tapi * a.F + f) * a.Co_pad + o0 + kk * 4) = acc0 + acc1;
 }
 
-// ------------------------------------------------------------------------------------------
-// end of an order position: logits = nin_out + bias, categorical draw (models/lmconv/sample.py:60-66:
-// softmax(logits/T), one draw, one-hot write), then the context of the next position.
-// ------------------------------------------------------------------------------------------
-struct FinishArgs {
-    const float *partial;     // nin_out slot [F][512]
-    const float *bias;
+// grid (work items, ceil(F/16)); 4 waves = 4 output-channel tiles of one (stage, slot)
+__global__ __launch_bounds__(256) void k_nbr(NbrArgs a)
+{
+    if ((int)blockIdx.x == a.nwork) {  // last work item: the u_init gather, 16 lanes per frame
+        const int f = blockIdx.y * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
+        if (f >= a.F) return;
+        float mA[9], v[5];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) mA[t] = a.ctx[f].m[0][t];
+        uinit_gather(a.codes + (size_t)f * a.L, mA, a.uinit_w, a.uinit_b, a.ctx[f].q, a.H, a.W, sub, v);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) a.upre[(size_t)f * NF + sub + 16 * k] = v[k];
+        return;
+    }
+    const NbrWork wk = a.work[blockIdx.x];
+    const StageDesc sd = a.stages[wk.stage];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, kk = lane >> 4;
+    const int cot = wk.cog * 4 + wave;
+    if (cot * 16 >= sd.Co_pad) return;
+    const int o0 = cot * 16;
+    const int f = blockIdx.y * 16 + i;
+    const bool valid = f < a.F;
+    f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = acc0;
+    if (sd.NG == 10) nbr_taps<10>(sd, a, wk.half, o0, f, valid, i, kk, acc0, acc1);
+    else nbr_taps<5>(sd, a, wk.half, o0, f, valid, i, kk, acc0, acc1);
+    if (valid) *(f32x4 *)(a.nbr + (((size_t)wk.stage * 2 + wk.half) * a.F + f) * NBR_LD + o0 + kk * 4) = acc0 + acc1;
+}
+
+struct ChainArgs {
+    const StageDesc *stages;
+    const float *nbr;
+    const float *upre;        // [F][NF] from k_nbr
     CtxArgs cx;
-    int32_t *codes;           // (F,L) or null (logits only)
+    const float *out_b;
+    int H, W, L, F;
+    // end of the order position
+    int32_t *codes;           // (F,L) written for sampled locations, or null (logits only)
     const uint8_t *region;    // (F,L) by location
     const int32_t *forced;    // (F,L) by location or null
     const float *uniforms;    // (F,L) by location or null
@@ -491,43 +498,312 @@ struct FinishArgs {
     float *step_logits;       // (F,512) or null
     float temperature;
     int advance;              // 1: write the context of step+1
+    unsigned long long *trace; // optional [NST][10] shader-clock stamps of workgroup 0 (tuning aid)
 };
 
-__global__ __launch_bounds__(512) void k_finish(FinishArgs a)
+// Workgroup barrier that only drains LDS traffic.  __syncthreads() also waits for every outstanding
+// global access (vmcnt(0)), which would serialise the weight / neighbour-slot prefetches of k_chain
+// against its two barriers per stage; the data exchanged between the waves here lives in LDS only.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// one centre-tap product: out[16 items][16 channels] = W (registers, loaded early) x LDS input rows
+template <int NG>
+__device__ __forceinline__ f32x4 center_tile(const f32x4 *av, const float (*sIn)[SIN_LD], int i, int kk)
 {
-    __shared__ float sh[NCLS];
-    __shared__ float red[8];
-    const int f = blockIdx.x, o = threadIdx.x, L = a.cx.L;
-    const int step = a.cx.ctx[f].step, q = a.cx.ctx[f].q;
-    const size_t loc = (size_t)f * L + q;
-    const float lg = a.partial[(size_t)f * NCLS + o] + a.bias[o];
-    if (a.out_logits) a.out_logits[loc * NCLS + o] = lg;
-    if (a.step_logits) a.step_logits[(size_t)f * NCLS + o] = lg;
-    const bool draw = a.codes && a.region[loc];
-    if (draw && a.forced) {
-        if (o == 0) a.codes[loc] = a.forced[loc];
-    } else if (draw) {
-        const float x = lg / a.temperature;
-        float m = x;
-        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off, 64));
-        if ((o & 63) == 0) red[o >> 6] = m;
-        __syncthreads();
-        m = red[0];
-        for (int w = 1; w < 8; ++w) m = fmaxf(m, red[w]);
-        sh[o] = expf(x - m);
-        __syncthreads();
-        for (int off = 1; off < NCLS; off <<= 1) {  // inclusive scan
-            const float v = o >= off ? sh[o - off] : 0.0f;
-            __syncthreads();
-            sh[o] += v;
-            __syncthreads();
+    const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+    f32x4 acc0 = zero, acc1 = zero;
+#pragma unroll
+    for (int g0 = 0; g0 < NG; g0 += 5) {
+        f32x4 a5[5], b5[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            a5[j] = av[g0 + j];
+            b5[j] = *(const f32x4 *)(&sIn[i][16 * (g0 + j) + 4 * kk]);
         }
-        const float target = a.uniforms[loc] * sh[NCLS - 1];
-        const int cnt = __syncthreads_count(sh[o] <= target);  // classes whose cdf is <= target
-        if (o == 0) a.codes[loc] = min(cnt, NCLS - 1);
+        mfma_chunk5(a5, b5, acc0, acc1);
     }
-    __syncthreads();  // every thread has read ctx[f] before it is advanced
-    if (a.advance && o < 32) ctx_fill(a.cx, f, step + 1, o);
+    return acc0 + acc1;
+}
+
+template <int NG>
+__device__ __forceinline__ void load_tile_weights(const float *__restrict__ w, int Co_pad, int o0, int i, int kk, f32x4 *av)
+{
+    const float *wbase = w + ((size_t)kk * Co_pad + o0 + i) * 4;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) av[g] = *PS_GC(f32x4, wbase + (size_t)g * 16 * Co_pad);
+}
+
+// operands of a prologue (post op of the previous stage), fetched one stage ahead as RAW values: no
+// arithmetic at fetch time, so nothing waits for the loads until the next stage consumes them
+struct PreOps { float pb[5], na[5], nb[5], pbg[5], nag[5], nbg[5], skb[5]; };
+
+template <int PRO>
+__device__ __forceinline__ void chain_prefetch(PreOps &p, const float *pbias, const float *pbias2, bool has_skip,
+                                               const float *nA, const float *nB, int sub)
+{
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const int c = sub + 16 * k;
+        p.pb[k] = PS_GC(float, pbias)[c];
+        p.na[k] = PS_GC(float, nA)[c];
+        p.nb[k] = PS_GC(float, nB)[c];
+        if (PRO == PRO_GATE) {
+            p.pbg[k] = PS_GC(float, pbias)[c + NF];
+            p.nag[k] = PS_GC(float, nA)[c + NF];
+            p.nbg[k] = PS_GC(float, nB)[c + NF];
+        }
+        if (PRO == PRO_CONVIN && has_skip) p.skb[k] = PS_GC(float, pbias2)[c];
+    }
+}
+
+// post op of the previous stage for one item: slots summed as ((bias + NA) + C) + NB like the whole-grid pass
+template <int PRO>
+__device__ __forceinline__ void chain_post(const PreOps &p, bool has_skip, const float (*sC)[SIN_LD],
+                                           const float (*sS)[NF + 4], int jl, int sub, const float (&ucur)[5],
+                                           float (&out)[5])
+{
+    float v[5], g[5], skip[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const int c = sub + 16 * k;
+        g[k] = skip[k] = 0.0f;
+        if (PRO == PRO_UINIT) {
+            v[k] = p.pb[k];  // u_init before norm_init, from k_nbr
+        } else {
+            v[k] = ((p.pb[k] + p.na[k]) + sC[jl][c]) + p.nb[k];
+            if (PRO == PRO_GATE) g[k] = ((p.pbg[k] + p.nag[k]) + sC[jl][c + NF]) + p.nbg[k];
+            if (PRO == PRO_CONVIN && has_skip) skip[k] = sS[jl][c] + p.skb[k];
+        }
+    }
+    if (PRO == PRO_CONVIN) post_math<POST_CONVIN>(v, g, skip, has_skip, ucur, out);
+    else if (PRO == PRO_GATE) post_math<POST_GATE>(v, g, skip, false, ucur, out);
+    else post_math<POST_DIL>(v, g, skip, false, ucur, out);  // PRO_UINIT: norm_init is the same PONO
+}
+
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+__global__ __launch_bounds__(CHAIN_WAVES * 64) void k_chain(ChainArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float sIn[16][SIN_LD];    // input of the centre tap
+    __shared__ __attribute__((aligned(16))) float sSkip[16][SIN_LD];  // concat_elu(u_k) feeding nin_skip
+    __shared__ __attribute__((aligned(16))) float sC[16][SIN_LD];     // centre-tap results
+    __shared__ __attribute__((aligned(16))) float sS[16][NF + 4];     // nin_skip results
+    __shared__ float sU[8][16][NF];                                   // u0..u7 of this location (skip connections)
+    __shared__ __attribute__((aligned(16))) float sL[16][SL_LD];      // nin_out results
+    __shared__ StageDesc sSt[NST];                                    // the chain description, read every stage
+    const int tid = threadIdx.x, wave = uni(tid >> 6), lane = tid & 63, i = lane & 15, kk = lane >> 4;
+    const int f0 = blockIdx.x * 16;
+    {
+        const int *src = (const int *)a.stages;
+        int *dst = (int *)sSt;
+        for (int k = tid; k < (int)(NST * sizeof(StageDesc) / 4); k += CHAIN_WAVES * 64) dst[k] = src[k];
+    }
+    // prologue role: 16 lanes per item
+    const int jl = tid >> 4, sub = tid & 15;
+    const int pf = f0 + jl;
+    const bool pact = tid < 256 && pf < a.F;
+    int pq = 0;
+    if (pact) pq = a.cx.ctx[pf].q;
+    const size_t ploc = (size_t)pf * a.L + pq;
+    float ucur[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    PreOps pre;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        pre.pb[k] = pre.na[k] = pre.nb[k] = pre.pbg[k] = pre.nag[k] = pre.nbg[k] = pre.skb[k] = 0.0f;
+        if (pact) pre.pb[k] = a.upre[(size_t)pf * NF + sub + 16 * k];  // stage 0: u_init before norm_init
+    }
+    if (tid < 256 && !pact) {  // rows of absent frames feed zeros into the MFMA tiles
+#pragma unroll
+        for (int k = 0; k < 5; ++k) { sIn[jl][sub + 16 * k] = 0.0f; sIn[jl][NF + sub + 16 * k] = 0.0f;
+                                      sSkip[jl][sub + 16 * k] = 0.0f; sSkip[jl][NF + sub + 16 * k] = 0.0f; }
+    }
+    __syncthreads();
+
+#define PS_TRACE(slot) do { if (a.trace && blockIdx.x == 0 && tid == 0) a.trace[s * 10 + (slot)] = clock64(); } while (0)
+    for (int s = 0; s < NST - 1; ++s) {
+        // stage control words: wave-uniform scalars, read once
+        typedef int i32x4 __attribute__((ext_vector_type(4)));
+        const i32x4 c0 = *(const i32x4 *)&sSt[s].pro, c1 = *(const i32x4 *)&sSt[s].NG;
+        const int pro = uni(c0.x), in_form = uni(c0.y), save_slot = uni(c0.z), p_has_skip = uni(c0.w), NG = uni(c1.x),
+                  Co_pad = uni(c1.y), center_tap = uni(c1.z);
+        const float *w = sSt[s].w, *w_skip = sSt[s].w_skip;
+        PS_TRACE(0);
+        // ---- (1) this stage's centre-tap weights: independent of everything computed here, issue first
+        const int ntile = Co_pad >> 4;
+        const bool main_w = wave < ntile, skip_w = !main_w && w_skip != nullptr && wave >= 5;
+        f32x4 av[10];
+        if (main_w) {
+            const float *wc = w + (size_t)center_tap * NG * 16 * Co_pad;
+            if (NG == 10) load_tile_weights<10>(wc, Co_pad, wave * 16, i, kk, av);
+            else load_tile_weights<5>(wc, Co_pad, wave * 16, i, kk, av);
+        } else if (skip_w) {
+            // nin_skip (layers.py:155-156): its input concat_elu(u_k) was staged in sSkip during the previous
+            // stage, so the five idle waves run it now, under the prologue of waves 0-3
+            load_tile_weights<10>(w_skip, NF, (wave - 5) * 16, i, kk, av);
+            const f32x4 r = center_tile<10>(av, sSkip, i, kk);
+            *(f32x4 *)(&sS[i][(wave - 5) * 16 + kk * 4]) = r;
+        }
+        PS_TRACE(5);
+        // ---- (2) prologue: post op of stage s-1 on the current location
+        if (pact) {
+            float out[5];
+            if (pro == PRO_CONVIN) chain_post<PRO_CONVIN>(pre, p_has_skip != 0, sC, sS, jl, sub, ucur, out);
+            else if (pro == PRO_GATE) chain_post<PRO_GATE>(pre, false, sC, sS, jl, sub, ucur, out);
+            else if (pro == PRO_DIL) chain_post<PRO_DIL>(pre, false, sC, sS, jl, sub, ucur, out);
+            else chain_post<PRO_UINIT>(pre, false, sC, sS, jl, sub, ucur, out);
+            PS_TRACE(6);
+            float ep[5], en[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) celu_pair(out[k], ep[k], en[k]);
+            if (in_form == IN_CELU) {
+#pragma unroll
+                for (int k = 0; k < 5; ++k) { sIn[jl][sub + 16 * k] = ep[k]; sIn[jl][NF + sub + 16 * k] = en[k]; }
+            } else {  // IN_RAW: dilated convs read the raw u
+#pragma unroll
+                for (int k = 0; k < 5; ++k) sIn[jl][sub + 16 * k] = out[k];
+            }
+            if (pro != PRO_CONVIN) {
+                float *outR = sSt[s].outR, *outE = sSt[s].outE;
+#pragma unroll
+                for (int k = 0; k < 5; ++k) {
+                    const int c = sub + 16 * k;
+                    ucur[k] = out[k];
+                    PS_G(float, outR)[ploc * NF + c] = out[k];
+                    PS_G(float, outE)[ploc * (2 * NF) + c] = ep[k];
+                    PS_G(float, outE)[ploc * (2 * NF) + NF + c] = en[k];
+                }
+                if (save_slot >= 0) {
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) sU[save_slot][jl][sub + 16 * k] = out[k];
+                }
+            } else {
+                float *outX = sSt[s].outX;
+#pragma unroll
+                for (int k = 0; k < 5; ++k) {
+                    const int c = sub + 16 * k;
+                    PS_G(float, outX)[ploc * (2 * NF) + c] = ep[k];
+                    PS_G(float, outX)[ploc * (2 * NF) + NF + c] = en[k];
+                }
+            }
+            PS_TRACE(7);
+            const int next_skip = uni(sSt[s + 1].skip_slot);
+            if (next_skip >= 0) {  // stage the NEXT stage's nin_skip input (u_k of this location, from the up pass)
+#pragma unroll
+                for (int k = 0; k < 5; ++k) {
+                    const int c = sub + 16 * k;
+                    float sp, sn;
+                    celu_pair(sU[next_skip][jl][c], sp, sn);
+                    sSkip[jl][c] = sp;
+                    sSkip[jl][NF + c] = sn;
+                }
+            }
+            PS_TRACE(8);
+            // ---- (3) raw operands of the next prologue (post op of THIS stage): k_nbr's slots + biases
+            const int npro = uni(sSt[s + 1].pro), nskip = uni(sSt[s + 1].p_has_skip);
+            const float *pbias = sSt[s + 1].pbias, *pbias2 = sSt[s + 1].pbias2;
+            const float *nA = a.nbr + (((size_t)s * 2 + 0) * a.F + pf) * NBR_LD;
+            const float *nB = a.nbr + (((size_t)s * 2 + 1) * a.F + pf) * NBR_LD;
+            if (npro == PRO_CONVIN) chain_prefetch<PRO_CONVIN>(pre, pbias, pbias2, nskip != 0, nA, nB, sub);
+            else if (npro == PRO_GATE) chain_prefetch<PRO_GATE>(pre, pbias, pbias2, false, nA, nB, sub);
+            else chain_prefetch<PRO_DIL>(pre, pbias, pbias2, false, nA, nB, sub);
+        }
+        PS_TRACE(1);
+        lds_barrier();
+        PS_TRACE(2);
+        // ---- (4) centre-tap products (and the nin_skip 1x1), one 16-channel tile per wave
+        if (main_w) {
+            const f32x4 r = NG == 10 ? center_tile<10>(av, sIn, i, kk) : center_tile<5>(av, sIn, i, kk);
+            *(f32x4 *)(&sC[i][wave * 16 + kk * 4]) = r;
+        }
+        PS_TRACE(3);
+        lds_barrier();
+        PS_TRACE(4);
+    }
+#undef PS_TRACE
+
+    {   // ---- nin_out(elu(u)) (model.py:153): its prologue is the last gate; 32 tiles over the 10 waves
+        const StageDesc &sd = sSt[NST - 1];
+        const int ntile = sd.Co_pad >> 4;
+        f32x4 avL[4][5];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ct = wave + r * CHAIN_WAVES;
+            if (ct < ntile) load_tile_weights<5>(sd.w, sd.Co_pad, ct * 16, i, kk, avL[r]);
+        }
+        if (pact) {
+            float out[5];
+            chain_post<PRO_GATE>(pre, false, sC, sS, jl, sub, ucur, out);
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const int c = sub + 16 * k;
+                float ep, en;
+                celu_pair(out[k], ep, en);
+                sIn[jl][c] = ep;
+                PS_G(float, sd.outR)[ploc * NF + c] = out[k];
+                PS_G(float, sd.outE)[ploc * (2 * NF) + c] = ep;
+                PS_G(float, sd.outE)[ploc * (2 * NF) + NF + c] = en;
+            }
+        }
+        lds_barrier();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ct = wave + r * CHAIN_WAVES;
+            if (ct < ntile) *(f32x4 *)(&sL[i][ct * 16 + kk * 4]) = center_tile<5>(avL[r], sIn, i, kk);
+        }
+        lds_barrier();
+    }
+
+    // ---- end of the order position: logits, categorical draw (sample.py:60-66), next context
+    for (int j = wave; j < 16; j += CHAIN_WAVES) {
+        const int f = f0 + j;
+        if (f >= a.F) continue;
+        const int q = a.cx.ctx[f].q;
+        const size_t loc = (size_t)f * a.L + q;
+        float lg[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) lg[k] = sL[j][lane * 8 + k] + a.out_b[lane * 8 + k];
+        if (a.out_logits) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a.out_logits[loc * NCLS + lane * 8 + k] = lg[k];
+        }
+        if (a.step_logits) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a.step_logits[(size_t)f * NCLS + lane * 8 + k] = lg[k];
+        }
+        if (!a.codes || !a.region[loc]) continue;
+        if (a.forced) {
+            if (lane == 0) a.codes[loc] = a.forced[loc];
+            continue;
+        }
+        float x[8], m = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { x[k] = lg[k] / a.temperature; m = fmaxf(m, x[k]); }
+        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+        float e[8], ls = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { e[k] = expf(x[k] - m); ls += e[k]; }
+        float incl = ls;  // inclusive scan of the per-lane sums (classes are lane-major)
+        for (int off = 1; off < 64; off <<= 1) {
+            const float t = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += t;
+        }
+        const float total = __shfl(incl, 63, 64);
+        const float target = a.uniforms[loc] * total;
+        float run = incl - ls;
+        int cnt = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { run += e[k]; cnt += run <= target ? 1 : 0; }  // classes whose cdf <= target
+        for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+        if (lane == 0) a.codes[loc] = min(cnt, NCLS - 1);
+    }
+    if (a.advance) {
+        __syncthreads();  // every read of ctx[f] above is done
+        const int j = tid >> 5, t = tid & 31;
+        if (j < 16 && f0 + j < a.F) {
+            const int step = a.cx.ctx[f0 + j].step;
+            ctx_fill(a.cx, f0 + j, step + 1, t);
+        }
+    }
 }
 
 __global__ void k_mask_codes(int32_t *codes, const uint8_t *region, size_t n)
@@ -572,9 +848,8 @@ __global__ void k_reduce_nchw(const float *partial, const float *bias, int B, in
     const int o = (i / L) % Co;
     const int b = i / ((size_t)L * Co);
     const size_t nitems = (size_t)B * L, item = (size_t)b * L + l;
-    float v = bias ? bias[o] : 0.0f;
-    for (int s = 0; s < 9; ++s) v += partial[(s * nitems + item) * Co_pad + o];
-    y[i] = v;
+    const size_t ss = nitems * Co_pad, at = item * Co_pad + o;
+    y[i] = slot_sum(bias ? bias[o] : 0.0f, partial[SLOT_NA * ss + at], partial[SLOT_C * ss + at], partial[SLOT_NB * ss + at]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -624,10 +899,14 @@ struct ps_pixelcnn {
     struct Dil { float *w, *b; int node_in, node_out; } dil[4];
     float *uinit_w = nullptr, *uinit_b = nullptr, *out_w = nullptr, *out_b = nullptr;
     float *R[NNODE], *E[NNODE], *X[NGATED];
-    float *partial = nullptr;                 // whole-grid tap slots [10][maxF*L][160]
-    float *col_partial[2] = {nullptr, nullptr};  // column-mode tap slots, ping-pong between stages
+    float *partial = nullptr;       // whole-grid slots [4][maxF*L][160]
+    float *nbr = nullptr;           // column mode: neighbour slots [NST][2][maxF][160]
+    float *upre = nullptr;          // column mode: u_init before norm_init [maxF][80]
     float *col_logits = nullptr;
     StepCtx *ctx = nullptr;
+    StageDesc *stages = nullptr;    // device copy of the 33-stage chain description
+    NbrWork *work = nullptr;
+    int nwork = 0;
     hipStream_t stream = nullptr;   // internal stream for graph capture/replay
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
     hipGraph_t graph = nullptr;          // step graph of the last ar_run (kept alive until replaced)
@@ -636,7 +915,7 @@ struct ps_pixelcnn {
     // bench.py profiling aid (ps_pixelcnn_time_column_step): event pair around every launch, by kernel tag
     struct ProfRec { int tag; hipEvent_t e0, e1; };
     std::vector<ProfRec> *prof = nullptr;
-    double prof_gemm_flops = 0.0, prof_gemm_wbytes = 0.0;
+    double flops_nbr = 0.0, flops_chain = 0.0, wbytes_nbr = 0.0, wbytes_chain = 0.0;  // dense work of one step, per frame
 };
 
 namespace {
@@ -671,7 +950,7 @@ void release_graph(ps_pixelcnn *h)
 
 struct Masks { const float *init, *und, *dil; };
 
-enum { TAG_GEMM = 0, TAG_POST = 1, TAG_UINIT = 2, TAG_LOGITS = 3, TAG_FINISH = 4 };
+enum { TAG_NBR = 0, TAG_CHAIN = 1 };
 
 template <typename Fn>
 void timed(ps_pixelcnn *h, hipStream_t st, int tag, Fn &&launch)
@@ -686,15 +965,16 @@ void timed(ps_pixelcnn *h, hipStream_t st, int tag, Fn &&launch)
     h->prof->push_back(r);
 }
 
-template <typename Args>
-void conv_taps(Args &a, const float *in, int ld, const float *wp, int Cin, int Co_pad, int dil)
+// 3x3 taps in slot order: NA = taps 0..3, C = tap 4, NB = taps 5..8 (+ optional SKIP appended by the caller)
+void conv_taps(GemmArgs &a, const float *in, int ld, const float *wp, int Cin, int Co_pad, int dil)
 {
-    a.ntaps = 9;
     a.Cin = Cin;
     a.Co_pad = Co_pad;
     const size_t per_tap = (size_t)Cin * Co_pad;
     for (int t = 0; t < 9; ++t)
         a.tap[t] = GemmTap{in, wp + t * per_tap, (t / 3 - 1) * dil, (t % 3 - 1) * dil, t, ld};
+    a.nslots = 3;
+    a.slot_first[0] = 0; a.slot_first[1] = 4; a.slot_first[2] = 5; a.slot_first[3] = 9; a.slot_first[4] = 9;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -709,7 +989,7 @@ void run_grid(ps_pixelcnn *h, int F, const int32_t *codes, const Masks &m, float
         a.H = h->H; a.W = h->W; a.L = h->L; a.nitems = nitems;
         a.mask = mask; a.mask_fstride = (size_t)9 * h->L; a.partial = h->partial; a.tiles_per_block = 8;
         const int tiles = (nitems + 15) / 16;
-        hipLaunchKernelGGL(k_gemm, dim3(a.Co_pad / 16, a.ntaps, (tiles + 7) / 8), dim3(64), 0, st, a);
+        hipLaunchKernelGGL(k_gemm, dim3(a.Co_pad / 16, a.nslots, (tiles + 7) / 8), dim3(64), 0, st, a);
     };
     {   // u_init + norm_init  (model.py:132)
         UinitArgs u{codes, m.init, h->uinit_w, h->uinit_b, h->R[0], h->E[0], h->H, h->W, h->L, nitems};
@@ -721,7 +1001,8 @@ void run_grid(ps_pixelcnn *h, int F, const int32_t *codes, const Masks &m, float
         conv_taps(a, h->E[G.node_in], 2 * NF, G.w_in, 2 * NF, NF, 1);                 // conv_input (layers.py:153)
         if (G.node_skip >= 0) {                                                         // nin_skip   (layers.py:155-156)
             a.tap[9] = GemmTap{h->E[G.node_skip], G.w_skip, 0, 0, -1, 2 * NF};
-            a.ntaps = 10;
+            a.slot_first[4] = 10;
+            a.nslots = 4;
         }
         gemm(a, m.und);
         PostArgs p{h->partial, nitems, NF, h->L, G.node_skip >= 0, G.b_in, G.b_skip, nullptr, nullptr, nullptr, h->X[g]};
@@ -746,7 +1027,8 @@ void run_grid(ps_pixelcnn *h, int F, const int32_t *codes, const Masks &m, float
     gated(11); gated(12); gated(13);
     if (!logits) return;
     GemmArgs a{};                                                                         // nin_out(elu(u)) model.py:153
-    a.ntaps = 1; a.Cin = NF; a.Co_pad = NCLS;
+    a.Cin = NF; a.Co_pad = NCLS; a.nslots = 1;
+    a.slot_first[0] = 0; a.slot_first[1] = 1;
     a.tap[0] = GemmTap{h->E[NNODE - 1], h->out_w, 0, 0, -1, 2 * NF};
     gemm(a, nullptr);
     hipLaunchKernelGGL(k_logits_grid, dim3(nitems), dim3(256), 0, st, h->partial, h->out_b, nitems, h->L, nchw ? 1 : 0,
@@ -754,92 +1036,72 @@ void run_grid(ps_pixelcnn *h, int F, const int32_t *codes, const Masks &m, float
 }
 
 // ------------------------------------------------------------------------------------------
-// one column step: 33 k_col launches (each evaluates the previous stage's post op in its centre-tap
-// blocks) + k_finish.  h->ctx must describe the current order position.
+// the 33-stage chain description consumed by k_nbr / k_chain (built once per handle)
 // ------------------------------------------------------------------------------------------
-struct Prev {
-    int pro = PRO_UINIT;
-    const float *partial = nullptr, *bias = nullptr, *bias2 = nullptr, *Rin = nullptr;
-    int Co_pad = 0, has_skip = 0;
-    float *Rout = nullptr, *Eout = nullptr, *Xout = nullptr;
-};
-
-template <int IN>
-void launch_col(ps_pixelcnn *h, hipStream_t st, int pro, const ColArgs &a, dim3 grid)
+int build_stage_table(ps_pixelcnn *h)
 {
-    timed(h, st, TAG_GEMM, [&]() {
-        switch (pro) {
-        case PRO_UINIT: hipLaunchKernelGGL((k_col<PRO_UINIT, IN>), grid, dim3(256), 0, st, a); break;
-        case PRO_CONVIN: hipLaunchKernelGGL((k_col<PRO_CONVIN, IN>), grid, dim3(256), 0, st, a); break;
-        case PRO_GATE: hipLaunchKernelGGL((k_col<PRO_GATE, IN>), grid, dim3(256), 0, st, a); break;
-        default: hipLaunchKernelGGL((k_col<PRO_DIL, IN>), grid, dim3(256), 0, st, a); break;
-        }
-    });
-}
-
-void run_column(ps_pixelcnn *h, int F, const int32_t *codes, FinishArgs fin, hipStream_t st)
-{
-    int stage = 0;
-    Prev prev;  // stage 0's prologue is u_init itself
-    prev.Rout = h->R[0];
-    prev.Eout = h->E[0];
-    auto stage_launch = [&](ColArgs &a, int in_form, int mask_kind, int center) {
-        a.H = h->H; a.W = h->W; a.L = h->L; a.F = F;
-        a.center_tap = center; a.mask_kind = mask_kind;
-        a.partial = h->col_partial[stage & 1];
-        a.ctx = h->ctx;
-        a.prev_partial = prev.partial; a.prev_Co_pad = prev.Co_pad; a.prev_has_skip = prev.has_skip;
-        a.prev_bias = prev.bias; a.prev_bias2 = prev.bias2; a.Rin = prev.Rin;
-        a.Rout = prev.Rout; a.Eout = prev.Eout; a.Xout = prev.Xout;
-        a.codes = codes; a.uinit_w = h->uinit_w; a.uinit_b = h->uinit_b;
-        const dim3 grid((a.Co_pad + 63) / 64, a.ntaps, (F + 15) / 16);
-        if (h->prof)
-            for (int t = 0; t < a.ntaps; ++t) {
-                h->prof_gemm_flops += 2.0 * a.Co_pad * a.Cin * F;
-                h->prof_gemm_wbytes += 4.0 * a.Co_pad * a.Cin;
-            }
-        if (in_form == IN_CELU) launch_col<IN_CELU>(h, st, prev.pro, a, grid);
-        else if (in_form == IN_RAW) launch_col<IN_RAW>(h, st, prev.pro, a, grid);
-        else launch_col<IN_ELU>(h, st, prev.pro, a, grid);
-        prev = Prev();
-        prev.partial = a.partial;
-        prev.Co_pad = a.Co_pad;
-        ++stage;
+    std::vector<StageDesc> st;
+    std::vector<NbrWork> work;
+    struct Prev { int pro; const float *bias, *bias2; int has_skip; float *R, *E, *X; int save; } prev;
+    prev = Prev{PRO_UINIT, nullptr, nullptr, 0, h->R[0], h->E[0], nullptr, 0};  // u0 is saved in LDS slot 0
+    auto push = [&](const float *w, const float *w_skip, const float *in, int in_ld, int NG, int Co, int dil,
+                    int mask_kind, int center, int has_nbr, int in_form, int skip_slot) {
+        StageDesc d{};
+        d.w = w; d.w_skip = w_skip; d.in = in; d.in_ld = in_ld; d.NG = NG; d.Co_pad = Co; d.dil = dil;
+        d.mask_kind = mask_kind; d.center_tap = center; d.has_nbr = has_nbr;
+        d.pro = prev.pro; d.in_form = in_form; d.skip_slot = skip_slot; d.save_slot = prev.save;
+        d.pbias = prev.bias; d.pbias2 = prev.bias2; d.p_has_skip = prev.has_skip;
+        d.outR = prev.R; d.outE = prev.E; d.outX = prev.X;
+        const int s = (int)st.size();
+        if (has_nbr)
+            for (int half = 0; half < 2; ++half)
+                for (int cog = 0; cog < (Co / 16 + 3) / 4; ++cog) work.push_back(NbrWork{s, half, cog});
+        // dense algorithmic work per frame of this stage (taps x 2*Co*Cin flops, fp32 weights once)
+        const double taps_nbr = has_nbr ? 8.0 : 0.0, cin = NG * 16.0;
+        h->flops_nbr += taps_nbr * 2.0 * Co * cin;
+        h->wbytes_nbr += taps_nbr * 4.0 * Co * cin;
+        h->flops_chain += 2.0 * Co * cin + (w_skip ? 2.0 * NF * 2 * NF : 0.0);
+        h->wbytes_chain += 4.0 * Co * cin + (w_skip ? 4.0 * NF * 2 * NF : 0.0);
+        st.push_back(d);
     };
     auto gated = [&](int g) {
         const ps_pixelcnn::Gated &G = h->gated[g];
-        ColArgs a{};
-        conv_taps(a, h->E[G.node_in], 2 * NF, G.w_in, 2 * NF, NF, 1);
-        if (G.node_skip >= 0) {
-            a.tap[9] = GemmTap{h->E[G.node_skip], G.w_skip, 0, 0, -1, 2 * NF};
-            a.ntaps = 10;
-        }
-        stage_launch(a, IN_CELU, 1, 4);
-        prev.pro = PRO_CONVIN; prev.bias = G.b_in; prev.bias2 = G.b_skip; prev.has_skip = G.node_skip >= 0;
-        prev.Xout = h->X[g];
-        ColArgs b{};
-        conv_taps(b, h->X[g], 2 * NF, G.w_out, 2 * NF, 2 * NF, 1);
-        stage_launch(b, IN_CELU, 1, 4);
-        prev.pro = PRO_GATE; prev.bias = G.b_out; prev.Rin = h->R[G.node_in];
-        prev.Rout = h->R[G.node_out]; prev.Eout = h->E[G.node_out];
+        push(G.w_in, G.w_skip, h->E[G.node_in], 2 * NF, 10, NF, 1, 1, 4, 1, IN_CELU, G.node_skip >= 0 ? G.node_skip : -1);
+        prev = Prev{PRO_CONVIN, G.b_in, G.b_skip, G.node_skip >= 0, nullptr, nullptr, h->X[g], -1};
+        push(G.w_out, nullptr, h->X[g], 2 * NF, 10, 2 * NF, 1, 1, 4, 1, IN_CELU, -1);
+        prev = Prev{PRO_GATE, G.b_out, nullptr, 0, h->R[G.node_out], h->E[G.node_out], nullptr, -1};
+        prev.save = (G.node_out >= 1 && G.node_out <= 7) ? G.node_out : -1;  // LDS slot k holds u_k
     };
     auto dilated = [&](int d) {
         const ps_pixelcnn::Dil &D = h->dil[d];
-        ColArgs a{};
-        conv_taps(a, h->R[D.node_in], NF, D.w, NF, NF, 2);
-        stage_launch(a, IN_RAW, 2, 4);
-        prev.pro = PRO_DIL; prev.bias = D.b; prev.Rout = h->R[D.node_out]; prev.Eout = h->E[D.node_out];
+        push(D.w, nullptr, h->R[D.node_in], NF, 5, NF, 2, 2, 4, 1, IN_RAW, -1);
+        prev = Prev{PRO_DIL, D.b, nullptr, 0, h->R[D.node_out], h->E[D.node_out], nullptr, -1};
+        prev.save = (D.node_out >= 1 && D.node_out <= 7) ? D.node_out : -1;
     };
     gated(0); gated(1); dilated(0); gated(2); gated(3); dilated(1); gated(4); gated(5);
     gated(6); gated(7); dilated(2); gated(8); gated(9); gated(10); dilated(3);
     gated(11); gated(12); gated(13);
-    ColArgs a{};  // nin_out(elu(u)): one unmasked centre tap; its prologue is the last gate
-    a.ntaps = 1; a.Cin = NF; a.Co_pad = NCLS;
-    a.tap[0] = GemmTap{h->E[NNODE - 1], h->out_w, 0, 0, -1, 2 * NF};
-    stage_launch(a, IN_ELU, 1, 0);
-    fin.partial = prev.partial;
-    fin.bias = h->out_b;
-    timed(h, st, TAG_FINISH, [&]() { hipLaunchKernelGGL(k_finish, dim3(F), dim3(512), 0, st, fin); });
+    push(h->out_w, nullptr, nullptr, 0, 5, NCLS, 1, 1, 0, 0, IN_ELU, -1);  // nin_out(elu(u)), prologue = last gate
+    if ((int)st.size() != NST) return ps::fail(PS_ERR_STATE, "stage table has %d entries, expected %d", (int)st.size(), NST);
+    if (int rc = dev_alloc(h, &h->stages, st.size())) return rc;
+    PS_HIP_CHECK(hipMemcpy(h->stages, st.data(), st.size() * sizeof(StageDesc), hipMemcpyHostToDevice));
+    if (int rc = dev_alloc(h, &h->work, work.size())) return rc;
+    PS_HIP_CHECK(hipMemcpy(h->work, work.data(), work.size() * sizeof(NbrWork), hipMemcpyHostToDevice));
+    h->nwork = (int)work.size();
+    return PS_OK;
+}
+
+// one order position: neighbour taps of every conv, then the centre-tap chain + draw.  h->ctx must
+// describe the current position.
+void run_column(ps_pixelcnn *h, int F, const int32_t *codes, ChainArgs ca, hipStream_t st)
+{
+    NbrArgs na{h->stages, h->work, h->ctx, h->nbr, h->upre, codes, h->uinit_w, h->uinit_b, h->nwork, h->H, h->W, h->L, F};
+    const int tiles = (F + 15) / 16;
+    timed(h, st, TAG_NBR, [&]() { hipLaunchKernelGGL(k_nbr, dim3(h->nwork + 1, tiles), dim3(256), 0, st, na); });
+    ca.stages = h->stages; ca.nbr = h->nbr; ca.upre = h->upre;
+    ca.out_b = h->out_b;
+    ca.H = h->H; ca.W = h->W; ca.L = h->L; ca.F = F;
+    timed(h, st, TAG_CHAIN, [&]() { hipLaunchKernelGGL(k_chain, dim3(tiles), dim3(CHAIN_WAVES * 64), 0, st, ca); });
 }
 
 CtxArgs make_ctx_args(ps_pixelcnn *h, const int32_t *order, const Masks &m, int F)
@@ -871,8 +1133,10 @@ int ps_pixelcnn_create(const float *const *params, int n_params, int H, int W, i
     for (int i = 0; i < n_params; ++i) PS_REQUIRE(params[i], "pixelcnn_create: tensor %d is null", i);
     ps_pixelcnn *h = new ps_pixelcnn();
     h->H = H; h->W = W; h->L = H * W; h->maxF = max_frames;
+    // Two launches per order position keep the host far ahead of the GPU, so the loop is launched eagerly on the
+    // caller's stream by default; PS_AR_GRAPH=1 replays it as a hipGraph on a stream owned by the handle instead.
     const char *env = getenv("PS_AR_GRAPH");
-    h->use_graph = !(env && env[0] == '0');
+    h->use_graph = env && env[0] == '1';
     int rc = PS_OK;
     auto fail_out = [&](int code) { ps_pixelcnn_destroy(h); return code; };
 
@@ -931,13 +1195,14 @@ int ps_pixelcnn_create(const float *const *params, int n_params, int H, int W, i
     }
     for (int g = 0; g < NGATED; ++g)
         if ((rc = dev_alloc(h, &h->X[g], locs * 2 * NF))) return fail_out(rc);
-    size_t pfloats = (size_t)MAX_TAPS * locs * 2 * NF;
+    size_t pfloats = (size_t)4 * locs * 2 * NF;
     if (locs * NCLS > pfloats) pfloats = locs * NCLS;
     if ((rc = dev_alloc(h, &h->partial, pfloats))) return fail_out(rc);
     if ((rc = dev_alloc(h, &h->col_logits, (size_t)max_frames * NCLS))) return fail_out(rc);
-    for (int k = 0; k < 2; ++k)
-        if ((rc = dev_alloc(h, &h->col_partial[k], (size_t)MAX_TAPS * max_frames * NCLS))) return fail_out(rc);
+    if ((rc = dev_alloc(h, &h->nbr, (size_t)NST * 2 * max_frames * NBR_LD))) return fail_out(rc);
+    if ((rc = dev_alloc(h, &h->upre, (size_t)max_frames * NF))) return fail_out(rc);
     if ((rc = dev_alloc(h, &h->ctx, (size_t)max_frames))) return fail_out(rc);
+    if ((rc = build_stage_table(h))) return fail_out(rc);
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_out, hipEventDisableTiming) != hipSuccess) {
@@ -979,12 +1244,12 @@ int ps_pixelcnn_ar_step(ps_pixelcnn *h, const int32_t *codes, const int32_t *ord
     hipStream_t st = (hipStream_t)stream;
     const Masks m{mask_init, mask_undilated, mask_dilated};
     if (step == first_step) run_grid(h, F, codes, m, nullptr, false, st);
-    FinishArgs fin{};
-    fin.cx = make_ctx_args(h, order, m, F);
-    hipLaunchKernelGGL(k_ctx_init, dim3(F), dim3(32), 0, st, fin.cx, step);
-    fin.step_logits = logits;
-    fin.temperature = 1.0f;
-    run_column(h, F, codes, fin, st);
+    ChainArgs ca{};
+    ca.cx = make_ctx_args(h, order, m, F);
+    hipLaunchKernelGGL(k_ctx_init, dim3(F), dim3(32), 0, st, ca.cx, step);
+    ca.step_logits = logits;
+    ca.temperature = 1.0f;
+    run_column(h, F, codes, ca, st);
     PS_LAUNCH_CHECK();
     return PS_OK;
 }
@@ -1012,22 +1277,22 @@ int ps_pixelcnn_ar_run(ps_pixelcnn *h, int32_t *codes, const int32_t *order, con
     // whole-grid pass: exact for every location that precedes the first sampled one; with out_logits it also
     // yields their logits, by location (the walked positions are overwritten by the column steps)
     run_grid(h, F, codes, m, out_logits, false, st);
-    FinishArgs fin{};
-    fin.cx = make_ctx_args(h, order, m, F);
-    fin.codes = codes; fin.region = sample_region; fin.forced = forced; fin.uniforms = uniforms;
-    fin.out_logits = out_logits; fin.temperature = temperature; fin.advance = 1;
-    hipLaunchKernelGGL(k_ctx_init, dim3(F), dim3(32), 0, st, fin.cx, first_step);
+    ChainArgs ca{};
+    ca.cx = make_ctx_args(h, order, m, F);
+    ca.codes = codes; ca.region = sample_region; ca.forced = forced; ca.uniforms = uniforms;
+    ca.out_logits = out_logits; ca.temperature = temperature; ca.advance = 1;
+    hipLaunchKernelGGL(k_ctx_init, dim3(F), dim3(32), 0, st, ca.cx, first_step);
     PS_LAUNCH_CHECK();
     const int nsteps = h->L - first_step;
     if (nsteps > 0) {
         if (h->use_graph) {
             PS_HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-            run_column(h, F, codes, fin, st);
+            run_column(h, F, codes, ca, st);
             PS_HIP_CHECK(hipStreamEndCapture(st, &h->graph));
             PS_HIP_CHECK(hipGraphInstantiate(&h->graph_exec, h->graph, nullptr, nullptr, 0));
             for (int sidx = 0; sidx < nsteps; ++sidx) PS_HIP_CHECK(hipGraphLaunch(h->graph_exec, st));
         } else {
-            for (int sidx = 0; sidx < nsteps; ++sidx) run_column(h, F, codes, fin, st);
+            for (int sidx = 0; sidx < nsteps; ++sidx) run_column(h, F, codes, ca, st);
         }
     }
     PS_LAUNCH_CHECK();
@@ -1040,8 +1305,8 @@ int ps_pixelcnn_ar_run(ps_pixelcnn *h, int32_t *codes, const int32_t *order, con
 
 int ps_pixelcnn_time_column_step(ps_pixelcnn *h, const int32_t *codes, const int32_t *order, const float *mask_init,
                                  const float *mask_undilated, const float *mask_dilated, int F, int step, int reps,
-                                 int *launches, float *total_ms, double *gemm_flops_per_step,
-                                 double *gemm_weight_bytes_per_step, void *stream)
+                                 int *launches, float *total_ms, double *flops_per_launch, double *weight_bytes_per_launch,
+                                 void *stream)
 {
     if (int rc = check_handle(h, F)) return rc;
     PS_REQUIRE(codes && order && mask_init && mask_undilated && mask_dilated && launches && total_ms,
@@ -1049,15 +1314,34 @@ int ps_pixelcnn_time_column_step(ps_pixelcnn *h, const int32_t *codes, const int
     PS_REQUIRE(step >= 0 && step < h->L && reps > 0, "pixelcnn_time_column_step: bad step / reps");
     hipStream_t st = (hipStream_t)stream;
     std::vector<ps_pixelcnn::ProfRec> recs;
-    FinishArgs fin{};
-    fin.cx = make_ctx_args(h, order, Masks{mask_init, mask_undilated, mask_dilated}, F);
-    fin.step_logits = h->col_logits;
-    fin.temperature = 1.0f;
-    hipLaunchKernelGGL(k_ctx_init, dim3(F), dim3(32), 0, st, fin.cx, step);
-    run_column(h, F, codes, fin, st);  // untimed warm-up
+    ChainArgs ca{};
+    ca.cx = make_ctx_args(h, order, Masks{mask_init, mask_undilated, mask_dilated}, F);
+    ca.step_logits = h->col_logits;
+    ca.temperature = 1.0f;
+    hipLaunchKernelGGL(k_ctx_init, dim3(F), dim3(32), 0, st, ca.cx, step);
+    run_column(h, F, codes, ca, st);  // untimed warm-up
+    if (const char *tp = getenv("PS_CHAIN_TRACE")) {  // tuning aid: per-stage shader-clock stamps of workgroup 0
+        unsigned long long *d = nullptr;
+        if (hipMalloc(&d, NST * 10 * 8) == hipSuccess) {
+            (void)hipMemsetAsync(d, 0, NST * 10 * 8, st);
+            ChainArgs ct = ca;
+            ct.trace = d;
+            run_column(h, F, codes, ct, st);
+            std::vector<unsigned long long> hst(NST * 10);
+            (void)hipStreamSynchronize(st);
+            (void)hipMemcpy(hst.data(), d, NST * 10 * 8, hipMemcpyDeviceToHost);
+            if (FILE *fp = fopen(tp, "w")) {
+                for (int s2 = 0; s2 < NST - 1; ++s2)
+                    fprintf(fp, "%d %llu %llu %llu %llu %llu %llu %llu %llu %llu\n", s2, hst[s2 * 10], hst[s2 * 10 + 5],
+                            hst[s2 * 10 + 6], hst[s2 * 10 + 7], hst[s2 * 10 + 8], hst[s2 * 10 + 1], hst[s2 * 10 + 2],
+                            hst[s2 * 10 + 3], hst[s2 * 10 + 4]);
+                fclose(fp);
+            }
+            (void)hipFree(d);
+        }
+    }
     h->prof = &recs;
-    h->prof_gemm_flops = h->prof_gemm_wbytes = 0.0;
-    for (int r = 0; r < reps; ++r) run_column(h, F, codes, fin, st);
+    for (int r = 0; r < reps; ++r) run_column(h, F, codes, ca, st);
     h->prof = nullptr;
     PS_HIP_CHECK(hipStreamSynchronize(st));
     for (int t = 0; t < PS_PROF_NTAGS; ++t) { launches[t] = 0; total_ms[t] = 0.0f; }
@@ -1069,8 +1353,8 @@ int ps_pixelcnn_time_column_step(ps_pixelcnn *h, const int32_t *codes, const int
         (void)hipEventDestroy(r.e0);
         (void)hipEventDestroy(r.e1);
     }
-    if (gemm_flops_per_step) *gemm_flops_per_step = h->prof_gemm_flops / reps;
-    if (gemm_weight_bytes_per_step) *gemm_weight_bytes_per_step = h->prof_gemm_wbytes / reps;
+    if (flops_per_launch) { flops_per_launch[TAG_NBR] = h->flops_nbr * F; flops_per_launch[TAG_CHAIN] = h->flops_chain * F; }
+    if (weight_bytes_per_launch) { weight_bytes_per_launch[TAG_NBR] = h->wbytes_nbr; weight_bytes_per_launch[TAG_CHAIN] = h->wbytes_chain; }
     PS_LAUNCH_CHECK();
     return PS_OK;
 }
@@ -1082,7 +1366,7 @@ size_t ps_lmconv_workspace_bytes(int B, int Ci, int Co, int H, int W)
     size_t o = 0;
     o = ps::align_up(o + (size_t)B * L * Cp * 4, 256);
     o = ps::align_up(o + 9 * Cp * Cop * 4, 256);
-    o = ps::align_up(o + 9 * (size_t)B * L * Cop * 4, 256);
+    o = ps::align_up(o + 3 * (size_t)B * L * Cop * 4, 256);
     return o;
 }
 
@@ -1111,7 +1395,7 @@ int ps_lmconv_forward_f32(const float *x, const float *mask, size_t mask_batch_s
     a.H = H; a.W = W; a.L = L; a.nitems = B * L; a.mask = mask; a.mask_fstride = mask_batch_stride;
     a.partial = partial; a.tiles_per_block = 8;
     const int tiles = (a.nitems + 15) / 16;
-    hipLaunchKernelGGL(k_gemm, dim3(Cop / 16, 9, (tiles + 7) / 8), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(k_gemm, dim3(Cop / 16, a.nslots, (tiles + 7) / 8), dim3(64), 0, st, a);
     hipLaunchKernelGGL(k_reduce_nchw, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, st, partial, bias, B, Co, Cop, L, y);
     PS_LAUNCH_CHECK();
     return PS_OK;
