@@ -29,7 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("DEBUG", "False")
 
-from pixelsynth_amd import _lib, synthetic as syn  # noqa: E402
+from pixelsynth_amd import _lib, distributed as D, synthetic as syn  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP32_MFMA_PEAK_TF = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2 peak
@@ -69,12 +69,12 @@ def make_inputs(rank, V, device, smooth=True):
     return dev, host
 
 
-def run_step(model, d, world, gather_bufs):
+def run_step(model, d, world):
     out = model.outpaint_views(d["img"], d["depth"], d["K"], d["Kinv"], d["P"], d["Pinv"], d["RT2"], d["RT2inv"],
                                d["codes"], temperature=0.7, uniforms=d["uniforms"])
-    if world > 1:  # finished frames of every rank, RCCL all_gather over xGMI
-        torch.distributed.all_gather_into_tensor(gather_bufs[0], out["gen_fs"])
-        torch.distributed.all_gather_into_tensor(gather_bufs[1], out["codes"].contiguous())
+    if world > 1:  # finished frames of every rank: the path's only collective, RCCL all_gather over xGMI
+        out["all_gen_fs"] = D.gather_frames(out["gen_fs"])
+        out["all_codes"] = D.gather_frames(out["codes"].contiguous())
     return out
 
 
@@ -184,28 +184,19 @@ def main():
     V = args.views
     model = build_model(device)
     d, host = make_inputs(rank, V, device, smooth=args.depth == "smooth")
-    gather_bufs = None
-    if world > 1:
-        gather_bufs = (torch.empty(world * V, 3, 256, 256, device=device), torch.empty(world * V, 32, 32, dtype=torch.int32, device=device))
-
     def barrier():
-        if world > 1:
-            torch.distributed.barrier()
+        D.barrier()
         torch.cuda.synchronize()
 
     out = None
     for _ in range(args.warmup):
-        out = run_step(model, d, world, gather_bufs)
+        out = run_step(model, d, world)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = run_step(model, d, world, gather_bufs)
+        out = run_step(model, d, world)
     barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    elapsed = D.max_over_ranks(time.perf_counter() - t0, device)
 
     if rank == 0:
         frames = V * world * args.steps

@@ -1,0 +1,51 @@
+"""Multi-GPU sharding of the novel-view path: one process per GPU, `torch.distributed` (backend "nccl" is
+RCCL on ROCm, over xGMI inside a node).
+
+The path shards without any exchange during compute: independent (source, target-view)
+pairs are dealt round-robin to the ranks, every rank holds its own copy of the (small) weights, and the
+only collective is the gather of finished frames.  Nothing here is specific to the GPU backend: the same
+code runs under "gloo" in the CPU tests.
+"""
+import torch
+import torch.distributed as dist
+
+
+def world():
+    return (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
+
+
+def shard_views(n_views, rank=None, world_size=None):
+    """Indices of the views rank `rank` renders: r, r+W, r+2W, ...  (the reference renders them one by one on
+    a single GPU: demo.py:247-251; docs/REALESTATE.md:74 recommends manual splits across GPUs)."""
+    if rank is None or world_size is None:
+        rank, world_size = world()
+    return list(range(rank, n_views, world_size))
+
+
+def gather_frames(local, n_views=None):
+    """all_gather of the finished frames.  local: (V_local, ...) tensor, same V_local on every rank (pad the
+    last round when n_views is not a multiple of the world size).  Returns (W*V_local, ...) ordered by VIEW
+    index when the views were dealt with shard_views (view v sits at row v); trimmed to n_views if given."""
+    rank, w = world()
+    if w == 1:
+        return local if n_views is None else local[:n_views]
+    bufs = [torch.empty_like(local) for _ in range(w)]
+    dist.all_gather(bufs, local.contiguous())
+    stacked = torch.stack(bufs, 1)                      # (V_local, W, ...): row v_local*W + r = view index
+    out = stacked.reshape(-1, *local.shape[1:])
+    return out if n_views is None else out[:n_views]
+
+
+def max_over_ranks(seconds, device=None):
+    """Slowest rank's wall time (bench.py contract: take the MAX over ranks)."""
+    rank, w = world()
+    if w == 1:
+        return float(seconds)
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def barrier():
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()

@@ -1,0 +1,81 @@
+"""CPU-only: the reference's import paths resolve to the mirrors, the mirrors keep the reference's
+parameter names/shapes (checkpoint compatibility), and the HIP ops refuse CPU tensors loudly."""
+import subprocess
+import sys
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from pixelsynth_amd import synthetic as syn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_aliases_resolve_in_a_fresh_interpreter():
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import pixelsynth_amd.compat as c; c.install_reference_aliases()\n"
+        "from models.lmconv.model import OurPixelCNN\n"
+        "from models.lmconv.sample import sample\n"
+        "from models.projection.z_buffer_manipulator import PtsManipulator\n"
+        "from models.layers.z_buffer_layers import RasterizePointsXYsBlending\n"
+        "import models.lmconv.masking as m\n"
+        "assert OurPixelCNN.__module__ == 'pixelsynth_amd.lmconv.model'\n"
+        "assert 'pytorch3d' not in sys.modules and 'cv2' not in sys.modules\n"
+        "print('ok')\n" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+
+
+def test_state_dict_keys_match_reference_order():
+    from pixelsynth_amd.lmconv.layers import PONO
+    from pixelsynth_amd.lmconv.model import PARAM_KEYS, OurPixelCNN
+    net = OurPixelCNN(nr_resnet=2, nr_filters=80, input_channels=512, nr_logistic_mix=10, kernel_size=(3, 3),
+                      max_dilation=2, weight_norm=False, feature_norm_op=lambda c: PONO(), dropout_prob=0, conv_bias=True,
+                      conv_mask_weight=False, rematerialize=False, binarize=False)
+    keys = list(net.state_dict().keys())
+    assert keys == PARAM_KEYS and len(keys) == 93        # the order the reference printed (SURVEY, probe)
+    ref = syn.pixelcnn_state_dict(0)
+    assert list(ref.keys()) == keys
+    for k, v in net.state_dict().items():
+        assert tuple(v.shape) == ref[k].shape, k
+    assert sum(p.numel() for p in net.parameters()) == 5587584  # 5 587 584 parameters
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in ref.items()}, strict=True)
+
+
+def test_splat_and_lmconv_refuse_cpu_tensors():
+    import types
+    from pixelsynth_amd.layers.z_buffer_layers import RasterizePointsXYsBlending
+    from pixelsynth_amd.lmconv.locally_masked_convolution import locally_masked_conv2d
+    from pixelsynth_amd.projection.z_buffer_manipulator import PtsManipulator
+    opt = types.SimpleNamespace(splatter="xyblending", learn_default_feature=True, radius=4, pp_pixel=8, tau=1.0,
+                                rad_pow=2, accumulation="alphacomposite", background_smoothing_kernel_size=13)
+    sp = RasterizePointsXYsBlending(3, True, 4, 16, 8, opt)
+    assert "default_feature" in dict(sp.named_parameters())
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        sp(torch.zeros(1, 10, 3), torch.zeros(1, 3, 10))
+    pm = PtsManipulator(16, C=3, opt=opt)
+    assert set(pm.state_dict().keys()) == {"xyzs", "splatter.default_feature"}
+    assert np.array_equal(pm.xyzs.numpy(), __import__("oracle.c_oracle", fromlist=["x"]).make_grid(16))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        pm.project_pts(torch.zeros(1, 1, 256), *[torch.eye(4)[None]] * 6)
+    conv = locally_masked_conv2d(4, 6)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        conv(torch.zeros(1, 4, 5, 5), torch.ones(1, 9, 25))
+
+
+def test_masking_mirror_matches_oracle():
+    from oracle import c_oracle
+    from pixelsynth_amd.lmconv import masking
+    D = dict(syn.distance_maps())["rand3"]
+    d = D.copy()
+    order = masking.get_generation_order_idx("custom", 32, 32, d, (16, 16))
+    ref, _ = c_oracle.custom_idx(32, 32, D)
+    assert np.array_equal(order, ref) and np.array_equal(d, D * 10000)
+    km = masking.kernel_masks(order, 32, 32, 3, 2, "B")
+    assert km.shape == (1024, 3, 3)
+    unf = masking.get_unfolded_masks(order, 32, 32, 3, 2, "B")
+    assert np.array_equal(unf.numpy(), c_oracle.unfolded_masks(ref, 32, 32, 3, 2, "B"))
+    assert np.array_equal(km.reshape(1024, 9).T.astype(np.float32), unf[0].numpy())
