@@ -11,16 +11,19 @@
 // Design (DESIGN.md "AR path"):
 //   * Activations live channels-last in per-location caches  R[node] (raw u, 80 ch),
 //     E[node] = concat_elu(u) (160 ch), X[g] = concat_elu(x) inside gated resnet g (160 ch).
-//   * Every masked conv / 1x1 is ONE kernel, k_gemm: out[item][o] = sum_tap sum_c W_tap[o][c] *
-//     mask_tap[item] * in[neighbour_tap(item)][c].  An "item" is a (frame, location) pair.  The 9 taps
-//     are split-K slots (one wave = 16 output channels x 1 tap x 16 items per MFMA tile), the weights
-//     are pre-packed [tap][c/4][o][4] so both MFMA operands are 16-byte loads, the products run on
-//     v_mfma_f32_16x16x4_f32 (exact fp32, fma-chain numerics).  Masked taps cost nothing but a zero store.
-//   * The same kernel serves the whole-grid forward (items = F*L, the reference-faithful mode and the
-//     cache build) and the incremental AR column step (items = F, location = order[f][step]).
-//   * k_post_* kernels reduce the tap slots in a fixed order (deterministic), add bias and apply
-//     PONO / concat-ELU / gate / residual, writing the caches the next stage reads.
-//   * The AR loop replays one captured hipGraph per order position; the step index lives in device memory.
+//   * Every masked conv / 1x1 is the same product: out[item][o] = sum_tap sum_c W_tap[o][c] * mask_tap[item] *
+//     in[neighbour_tap(item)][c], an "item" being a (frame, location) pair.  16 items x 16 output channels
+//     form one v_mfma_f32_16x16x4_f32 tile (exact fp32, fma-chain numerics); the weights are pre-packed
+//     [tap][c/4][o][4] so both MFMA operands are 16-byte loads; masked taps are skipped.
+//   * The taps are grouped in split-K slots NA (taps 0..3), C (the location itself), NB (taps 5..8) and SKIP
+//     (nin_skip); every consumer adds them as ((bias + NA) + C) + NB, and every kernel walks taps and
+//     80-channel chunks in the same order -- so the two evaluation modes below agree bit for bit.
+//   * Whole-grid mode (k_gemm + k_post_grid, items = F*L): the reference-faithful OurPixelCNN.forward and the
+//     cache build for the prefix of observed locations.
+//   * Column mode (the incremental AR step, items = F): two launches per order position.  k_nbr computes the
+//     NA/NB slots of all 32 convs at once (they only read finished columns of earlier positions); k_chain
+//     walks the 33 dependent stages inside one workgroup per 16 frames (centre-tap products on MFMA,
+//     post ops one wave per frame, LDS hand-off), draws the code and writes the next position's context.
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -144,18 +147,21 @@ __global__ __launch_bounds__(64) void k_gemm(GemmArgs a)
 }
 
 // ------------------------------------------------------------------------------------------
-// per-item post ops, shared by the whole-grid kernels and the column chain.  An item is handled by
-// 16 lanes; lane `sub` owns channels sub + 16*k, k = 0..4 (NF = 80): every per-channel access of a wave is a
-// 64-byte run per item (measured faster than 5 contiguous channels per lane, whose 20-byte lane stride
-// touches 5x the cache lines per instruction).  Every reduction uses the same
-// association order in both modes, so column steps and whole-grid passes agree bit for bit.
+// per-item post ops, shared by the whole-grid kernels and the column chain.  An item (one location of one
+// frame, NF = 80 channels) is handled by ONE WAVE: lane l owns channel l and, for l < 16, channel 64 + l
+// (NCH = 2 slots per lane, the second one mostly empty).  Keeping the per-lane work this small is what
+// bounds the serial prologue of every stage of k_chain.  Every reduction uses the same association
+// order in both modes, so column steps and whole-grid passes agree bit for bit.
 // ------------------------------------------------------------------------------------------
+constexpr int NCH = 2;
+__device__ __forceinline__ int chan(int lane, int k) { return lane + 64 * k; }
+__device__ __forceinline__ bool owns(int lane, int k) { return k == 0 || lane < NF - 64; }
+
 // Elementwise math of the post ops.  These sit on the sequential critical path of every AR order position
 // (k_chain), so they use the hardware transcendental units directly (v_exp_f32 / v_rcp_f32 / v_rsq_f32,
 // ~1 ulp) instead of the libm-exact sequences; the result stays ~1e-7 relative to the exact value,
 // far inside the 1e-4 logit tolerance, and both evaluation modes share these functions bit for bit.
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
-__device__ __forceinline__ float elu1(float x) { return x > 0.0f ? x : (fast_exp(x) - 1.0f); }
 // concat_elu of one value: (elu(x), elu(-x)) with a single exponential (utils.py:31-35)
 __device__ __forceinline__ void celu_pair(float x, float &ep, float &en)
 {
@@ -165,54 +171,58 @@ __device__ __forceinline__ void celu_pair(float x, float &ep, float &en)
 }
 __device__ __forceinline__ float sigmoid1(float x) { return __builtin_amdgcn_rcpf(1.0f + fast_exp(-x)); }
 
-// all-reduce over the 16 lanes of an item with DPP row rotations (no LDS round trips).  Rotation by
-// 8, 4, 2, 1 pairs each lane with the same partners as an xor butterfly (the partial sums are periodic
-// with the rotation distance), and a+b == b+a bitwise, so every lane ends with identical bits.
+// all-reduce over the 64 lanes of a wave: DPP row rotations inside each 16-lane row (rotation by 8, 4, 2, 1
+// pairs each lane with the same partners as an xor butterfly and a+b == b+a bitwise, so every lane of a
+// row ends with identical bits), then the four row sums are read with v_readlane and added in a fixed order.
 template <int N>
 __device__ __forceinline__ float row_ror(float v)
 {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + N, 0xf, 0xf, false));
 }
-__device__ __forceinline__ float sum16(float v)
+__device__ __forceinline__ float wave_sum(float v)
 {
     v += row_ror<8>(v);
     v += row_ror<4>(v);
     v += row_ror<2>(v);
     v += row_ror<1>(v);
-    return v;
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return ((r0 + r1) + r2) + r3;
 }
 
-// PONO over the NF channels of one item (models/lmconv/layers.py:231-236), unbiased variance, eps 1e-5
-__device__ __forceinline__ void pono16x5(float (&v)[5])
+// PONO over the NF channels of one item (models/lmconv/layers.py:231-236), unbiased variance, eps 1e-5.
+// Slots a lane does not own must hold 0 on entry and hold 0 on exit.
+__device__ __forceinline__ void pono_wave(float (&v)[NCH], int lane)
 {
-    const float mean = sum16((((v[0] + v[1]) + v[2]) + v[3]) + v[4]) * (1.0f / (float)NF);
-    float d[5];
-#pragma unroll
-    for (int k = 0; k < 5; ++k) d[k] = v[k] - mean;
-    const float ss = sum16((((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]) + d[3] * d[3]) + d[4] * d[4]);
+    const float mean = wave_sum(v[0] + v[1]) * (1.0f / (float)NF);
+    const float d0 = v[0] - mean, d1 = owns(lane, 1) ? v[1] - mean : 0.0f;
+    const float ss = wave_sum(d0 * d0 + d1 * d1);
     const float inv = __builtin_amdgcn_rsqf(ss * (1.0f / (float)(NF - 1)) + 1e-5f);
-#pragma unroll
-    for (int k = 0; k < 5; ++k) v[k] = d[k] * inv;
+    v[0] = d0 * inv;
+    v[1] = d1 * inv;
 }
 
 __device__ __forceinline__ float slot_sum(float bias, float na, float c, float nb) { return ((bias + na) + c) + nb; }
 
 enum { POST_CONVIN = 0, POST_GATE = 1, POST_DIL = 2 };
 
-// v (and g for the gate): conv output INCLUDING bias, already slot-summed by the caller.
+// v (and g for the gate): conv output INCLUDING bias, already slot-summed by the caller (0 in unowned slots).
 // KIND = POST_CONVIN: out = PONO(v) [+ skip]                         (layers.py:153-156)
 //        POST_GATE:   out = rin + PONO(v) * sigmoid(g)                (layers.py:159-163)
 //        POST_DIL:    out = PONO(v)                                   (model.py:138-140,148-150)
 template <int KIND>
-__device__ __forceinline__ void post_math(float (&v)[5], const float (&g)[5], const float (&skip)[5], bool has_skip,
-                                          const float (&rin)[5], float (&out)[5])
+__device__ __forceinline__ void post_math(float (&v)[NCH], const float (&g)[NCH], const float (&skip)[NCH], bool has_skip,
+                                          const float (&rin)[NCH], int lane, float (&out)[NCH])
 {
-    pono16x5(v);
+    pono_wave(v, lane);
 #pragma unroll
-    for (int k = 0; k < 5; ++k) {
+    for (int k = 0; k < NCH; ++k) {
         if (KIND == POST_CONVIN) out[k] = has_skip ? v[k] + skip[k] : v[k];
         else if (KIND == POST_GATE) out[k] = rin[k] + v[k] * sigmoid1(g[k]);
         else out[k] = v[k];
+        if (!owns(lane, k)) out[k] = 0.0f;
     }
 }
 
@@ -221,11 +231,11 @@ __device__ __forceinline__ void post_math(float (&v)[5], const float (&g)[5], co
 // Only earlier order positions contribute (the centre of a type-A mask is 0), so in column mode this
 // belongs to the neighbour kernel, not to the chain.
 __device__ __forceinline__ void uinit_gather(const int32_t *__restrict__ codes_f, const float *mA /*9 values*/,
-                                           const float *__restrict__ w, const float *__restrict__ bias, int q, int H,
-                                           int W, int sub, float (&out)[5])
+                                             const float *__restrict__ w, const float *__restrict__ bias, int q, int H,
+                                             int W, int lane, float (&out)[NCH])
 {
     const int r = q / W, c0 = q - r * W;
-    float v[5];
+    float v[NCH];
     int code[9];
     float mv[9];
 #pragma unroll
@@ -236,28 +246,30 @@ __device__ __forceinline__ void uinit_gather(const int32_t *__restrict__ codes_f
         code[t] = (in && mv[t] != 0.0f) ? codes_f[rr * W + cc] : -1;
     }
 #pragma unroll
-    for (int k = 0; k < 5; ++k) v[k] = bias[sub + 16 * k];
+    for (int k = 0; k < NCH; ++k) v[k] = owns(lane, k) ? bias[chan(lane, k)] : 0.0f;
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         if (mv[t] == 0.0f) continue;
         const float *w1 = w + ((size_t)t * (NCLS + 1) + NCLS) * NF;
         const float *wc = w + ((size_t)t * (NCLS + 1) + (code[t] >= 0 ? code[t] : 0)) * NF;
 #pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            float x = w1[sub + 16 * k];
-            if (code[t] >= 0) x += wc[sub + 16 * k];
+        for (int k = 0; k < NCH; ++k) {
+            if (!owns(lane, k)) continue;
+            float x = w1[chan(lane, k)];
+            if (code[t] >= 0) x += wc[chan(lane, k)];
             v[k] += mv[t] * x;
         }
     }
 #pragma unroll
-    for (int k = 0; k < 5; ++k) out[k] = v[k];
+    for (int k = 0; k < NCH; ++k) out[k] = v[k];
 }
 
-__device__ __forceinline__ void store_raw_celu(float *R, float *E, size_t loc, int sub, const float (&u)[5])
+__device__ __forceinline__ void store_raw_celu(float *R, float *E, size_t loc, int lane, const float (&u)[NCH])
 {
 #pragma unroll
-    for (int k = 0; k < 5; ++k) {
-        const int c = sub + 16 * k;
+    for (int k = 0; k < NCH; ++k) {
+        if (!owns(lane, k)) continue;
+        const int c = chan(lane, k);
         float ep, en;
         celu_pair(u[k], ep, en);
         R[loc * NF + c] = u[k];
@@ -274,39 +286,41 @@ struct PostArgs {
     float *Rout, *Eout, *Xout;
 };
 
-// whole-grid post op: 16 items per 256-thread block
+// whole-grid post op: one wave per item, 4 items per 256-thread block
 template <int KIND>
 __global__ __launch_bounds__(256) void k_post_grid(PostArgs a)
 {
-    const int item = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
-    if (item >= a.nitems) return;  // whole 16-lane groups leave together
+    const int item = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (item >= a.nitems) return;  // whole waves leave together
     const size_t loc = item;       // item = f*L + q
     const size_t ss = (size_t)a.nitems * a.Co_pad;
     const float *P = a.partial + (size_t)item * a.Co_pad;
-    float v[5], g[5], skip[5], rin[5], out[5];
+    float v[NCH], g[NCH], skip[NCH], rin[NCH], out[NCH];
 #pragma unroll
-    for (int k = 0; k < 5; ++k) {
-        const int c = sub + 16 * k;
+    for (int k = 0; k < NCH; ++k) {
+        v[k] = g[k] = skip[k] = rin[k] = 0.0f;
+        if (!owns(lane, k)) continue;
+        const int c = chan(lane, k);
         v[k] = slot_sum(a.bias[c], P[SLOT_NA * ss + c], P[SLOT_C * ss + c], P[SLOT_NB * ss + c]);
-        g[k] = skip[k] = rin[k] = 0.0f;
         if (KIND == POST_GATE) {
             g[k] = slot_sum(a.bias[c + NF], P[SLOT_NA * ss + c + NF], P[SLOT_C * ss + c + NF], P[SLOT_NB * ss + c + NF]);
             rin[k] = a.Rin[loc * NF + c];
         }
         if (KIND == POST_CONVIN && a.has_skip) skip[k] = P[SLOT_SKIP * ss + c] + a.bias2[c];
     }
-    post_math<KIND>(v, g, skip, a.has_skip != 0, rin, out);
+    post_math<KIND>(v, g, skip, a.has_skip != 0, rin, lane, out);
     if (KIND == POST_CONVIN) {
 #pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            const int c = sub + 16 * k;
+        for (int k = 0; k < NCH; ++k) {
+            if (!owns(lane, k)) continue;
+            const int c = chan(lane, k);
             float ep, en;
             celu_pair(out[k], ep, en);
             a.Xout[loc * (2 * NF) + c] = ep;
             a.Xout[loc * (2 * NF) + NF + c] = en;
         }
     } else {
-        store_raw_celu(a.Rout, a.Eout, loc, sub, out);
+        store_raw_celu(a.Rout, a.Eout, loc, lane, out);
     }
 }
 
@@ -321,16 +335,16 @@ struct UinitArgs {
 
 __global__ __launch_bounds__(256) void k_uinit_grid(UinitArgs a)
 {
-    const int item = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
+    const int item = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (item >= a.nitems) return;
     const int f = item / a.L, q = item - f * a.L;
     float mA[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) mA[t] = a.mask[((size_t)f * 9 + t) * a.L + q];
-    float u[5];
-    uinit_gather(a.codes + (size_t)f * a.L, mA, a.w, a.bias, q, a.H, a.W, sub, u);
-    pono16x5(u);  // norm_init
-    store_raw_celu(a.Rout, a.Eout, (size_t)item, sub, u);
+    float u[NCH];
+    uinit_gather(a.codes + (size_t)f * a.L, mA, a.w, a.bias, q, a.H, a.W, lane, u);
+    pono_wave(u, lane);  // norm_init
+    store_raw_celu(a.Rout, a.Eout, (size_t)item, lane, u);
 }
 
 // logits = nin_out partial + bias; nchw: (F,512,H,W) like the reference, else (nitems,512)
@@ -388,7 +402,7 @@ constexpr int NST = 33;       // 14 x (conv_input, conv_out) + 4 dilated convs +
 constexpr int NBR_LD = 2 * NF;
 constexpr int SIN_LD = 2 * NF + 4;
 constexpr int SL_LD = NCLS + 4;
-constexpr int CHAIN_WAVES = 10;
+constexpr int CHAIN_WAVES = 16;  // one wave per frame of the 16-frame tile in the post ops; waves 0..9 own the MFMA tiles
 
 struct __attribute__((aligned(16))) StageDesc {
     // control words first, 16-byte aligned: k_chain fetches them with two ds_read_b128 per stage
@@ -457,15 +471,16 @@ __device__ __forceinline__ void nbr_taps(const StageDesc &sd, const NbrArgs &a, 
 // grid (work items, ceil(F/16)); 4 waves = 4 output-channel tiles of one (stage, slot)
 __global__ __launch_bounds__(256) void k_nbr(NbrArgs a)
 {
-    if ((int)blockIdx.x == a.nwork) {  // last work item: the u_init gather, 16 lanes per frame
-        const int f = blockIdx.y * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
+    if ((int)blockIdx.x >= a.nwork) {  // last 4 work items: the u_init gather, one wave per frame
+        const int f = blockIdx.y * 16 + ((int)blockIdx.x - a.nwork) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
         if (f >= a.F) return;
-        float mA[9], v[5];
+        float mA[9], v[NCH];
 #pragma unroll
         for (int t = 0; t < 9; ++t) mA[t] = a.ctx[f].m[0][t];
-        uinit_gather(a.codes + (size_t)f * a.L, mA, a.uinit_w, a.uinit_b, a.ctx[f].q, a.H, a.W, sub, v);
+        uinit_gather(a.codes + (size_t)f * a.L, mA, a.uinit_w, a.uinit_b, a.ctx[f].q, a.H, a.W, lane, v);
 #pragma unroll
-        for (int k = 0; k < 5; ++k) a.upre[(size_t)f * NF + sub + 16 * k] = v[k];
+        for (int k = 0; k < NCH; ++k)
+            if (owns(lane, k)) a.upre[(size_t)f * NF + chan(lane, k)] = v[k];
         return;
     }
     const NbrWork wk = a.work[blockIdx.x];
@@ -499,6 +514,7 @@ struct ChainArgs {
     float temperature;
     int advance;              // 1: write the context of step+1
     unsigned long long *trace; // optional [NST][10] shader-clock stamps of workgroup 0 (tuning aid)
+    int ablate;                // tuning aid (PS_CHAIN_ABLATE): 1 no cache stores, 2 no slot prefetch, 4 no MFMA, 8 no post math
 };
 
 // Workgroup barrier that only drains LDS traffic.  __syncthreads() also waits for every outstanding
@@ -535,15 +551,16 @@ __device__ __forceinline__ void load_tile_weights(const float *__restrict__ w, i
 
 // operands of a prologue (post op of the previous stage), fetched one stage ahead as RAW values: no
 // arithmetic at fetch time, so nothing waits for the loads until the next stage consumes them
-struct PreOps { float pb[5], na[5], nb[5], pbg[5], nag[5], nbg[5], skb[5]; };
+struct PreOps { float pb[NCH], na[NCH], nb[NCH], pbg[NCH], nag[NCH], nbg[NCH], skb[NCH]; };
 
 template <int PRO>
 __device__ __forceinline__ void chain_prefetch(PreOps &p, const float *pbias, const float *pbias2, bool has_skip,
-                                               const float *nA, const float *nB, int sub)
+                                               const float *nA, const float *nB, int lane)
 {
 #pragma unroll
-    for (int k = 0; k < 5; ++k) {
-        const int c = sub + 16 * k;
+    for (int k = 0; k < NCH; ++k) {
+        if (!owns(lane, k)) continue;
+        const int c = chan(lane, k);
         p.pb[k] = PS_GC(float, pbias)[c];
         p.na[k] = PS_GC(float, nA)[c];
         p.nb[k] = PS_GC(float, nB)[c];
@@ -558,26 +575,26 @@ __device__ __forceinline__ void chain_prefetch(PreOps &p, const float *pbias, co
 
 // post op of the previous stage for one item: slots summed as ((bias + NA) + C) + NB like the whole-grid pass
 template <int PRO>
-__device__ __forceinline__ void chain_post(const PreOps &p, bool has_skip, const float (*sC)[SIN_LD],
-                                           const float (*sS)[NF + 4], int jl, int sub, const float (&ucur)[5],
-                                           float (&out)[5])
+__device__ __forceinline__ void chain_post(const PreOps &p, bool has_skip, const float *sCrow, const float *sSrow,
+                                           int lane, const float (&ucur)[NCH], float (&out)[NCH])
 {
-    float v[5], g[5], skip[5];
+    float v[NCH], g[NCH], skip[NCH];
 #pragma unroll
-    for (int k = 0; k < 5; ++k) {
-        const int c = sub + 16 * k;
-        g[k] = skip[k] = 0.0f;
+    for (int k = 0; k < NCH; ++k) {
+        v[k] = g[k] = skip[k] = 0.0f;
+        if (!owns(lane, k)) continue;
+        const int c = chan(lane, k);
         if (PRO == PRO_UINIT) {
             v[k] = p.pb[k];  // u_init before norm_init, from k_nbr
         } else {
-            v[k] = ((p.pb[k] + p.na[k]) + sC[jl][c]) + p.nb[k];
-            if (PRO == PRO_GATE) g[k] = ((p.pbg[k] + p.nag[k]) + sC[jl][c + NF]) + p.nbg[k];
-            if (PRO == PRO_CONVIN && has_skip) skip[k] = sS[jl][c] + p.skb[k];
+            v[k] = ((p.pb[k] + p.na[k]) + sCrow[c]) + p.nb[k];
+            if (PRO == PRO_GATE) g[k] = ((p.pbg[k] + p.nag[k]) + sCrow[c + NF]) + p.nbg[k];
+            if (PRO == PRO_CONVIN && has_skip) skip[k] = sSrow[c] + p.skb[k];
         }
     }
-    if (PRO == PRO_CONVIN) post_math<POST_CONVIN>(v, g, skip, has_skip, ucur, out);
-    else if (PRO == PRO_GATE) post_math<POST_GATE>(v, g, skip, false, ucur, out);
-    else post_math<POST_DIL>(v, g, skip, false, ucur, out);  // PRO_UINIT: norm_init is the same PONO
+    if (PRO == PRO_CONVIN) post_math<POST_CONVIN>(v, g, skip, has_skip, ucur, lane, out);
+    else if (PRO == PRO_GATE) post_math<POST_GATE>(v, g, skip, false, ucur, lane, out);
+    else post_math<POST_DIL>(v, g, skip, false, ucur, lane, out);  // PRO_UINIT: norm_init is the same PONO
 }
 
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -598,24 +615,24 @@ __global__ __launch_bounds__(CHAIN_WAVES * 64) void k_chain(ChainArgs a)
         int *dst = (int *)sSt;
         for (int k = tid; k < (int)(NST * sizeof(StageDesc) / 4); k += CHAIN_WAVES * 64) dst[k] = src[k];
     }
-    // prologue role: 16 lanes per item
-    const int jl = tid >> 4, sub = tid & 15;
-    const int pf = f0 + jl;
-    const bool pact = tid < 256 && pf < a.F;
+    // post-op role: wave w handles frame f0 + w of the tile
+    const int pf = f0 + wave;
+    const bool pact = pf < a.F;
     int pq = 0;
-    if (pact) pq = a.cx.ctx[pf].q;
+    if (pact) pq = uni(a.cx.ctx[pf].q);
     const size_t ploc = (size_t)pf * a.L + pq;
-    float ucur[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    const size_t off80 = ploc * NF, off160 = ploc * (2 * NF);                  // this location in the R / E,X caches
+    const float *nbr_item = a.nbr + (size_t)pf * NBR_LD;                       // this frame's rows of the k_nbr slots
+    const size_t nbr_half = (size_t)a.F * NBR_LD, nbr_stage = 2 * nbr_half;
+    float ucur[NCH] = {0.0f, 0.0f};
     PreOps pre;
 #pragma unroll
-    for (int k = 0; k < 5; ++k) {
+    for (int k = 0; k < NCH; ++k) {
         pre.pb[k] = pre.na[k] = pre.nb[k] = pre.pbg[k] = pre.nag[k] = pre.nbg[k] = pre.skb[k] = 0.0f;
-        if (pact) pre.pb[k] = a.upre[(size_t)pf * NF + sub + 16 * k];  // stage 0: u_init before norm_init
+        if (pact && owns(lane, k)) pre.pb[k] = a.upre[(size_t)pf * NF + chan(lane, k)];  // stage 0: u_init before norm_init
     }
-    if (tid < 256 && !pact) {  // rows of absent frames feed zeros into the MFMA tiles
-#pragma unroll
-        for (int k = 0; k < 5; ++k) { sIn[jl][sub + 16 * k] = 0.0f; sIn[jl][NF + sub + 16 * k] = 0.0f;
-                                      sSkip[jl][sub + 16 * k] = 0.0f; sSkip[jl][NF + sub + 16 * k] = 0.0f; }
+    if (!pact) {  // rows of absent frames feed zeros into the MFMA tiles
+        for (int c = lane; c < 2 * NF; c += 64) { sIn[wave][c] = 0.0f; sSkip[wave][c] = 0.0f; }
     }
     __syncthreads();
 
@@ -628,92 +645,96 @@ __global__ __launch_bounds__(CHAIN_WAVES * 64) void k_chain(ChainArgs a)
                   Co_pad = uni(c1.y), center_tap = uni(c1.z);
         const float *w = sSt[s].w, *w_skip = sSt[s].w_skip;
         PS_TRACE(0);
-        // ---- (1) this stage's centre-tap weights: independent of everything computed here, issue first
+        // ---- (1) this stage's centre-tap weights: independent of everything computed here, issue first.
+        //      Waves 0..9 own the tiles of the main product, waves 10..14 those of the nin_skip 1x1.
         const int ntile = Co_pad >> 4;
-        const bool main_w = wave < ntile, skip_w = !main_w && w_skip != nullptr && wave >= 5;
+        const bool main_w = wave < ntile, skip_w = w_skip != nullptr && wave >= 10 && wave < 15;
         f32x4 av[10];
         if (main_w) {
             const float *wc = w + (size_t)center_tap * NG * 16 * Co_pad;
             if (NG == 10) load_tile_weights<10>(wc, Co_pad, wave * 16, i, kk, av);
             else load_tile_weights<5>(wc, Co_pad, wave * 16, i, kk, av);
         } else if (skip_w) {
-            // nin_skip (layers.py:155-156): its input concat_elu(u_k) was staged in sSkip during the previous
-            // stage, so the five idle waves run it now, under the prologue of waves 0-3
-            load_tile_weights<10>(w_skip, NF, (wave - 5) * 16, i, kk, av);
-            const f32x4 r = center_tile<10>(av, sSkip, i, kk);
-            *(f32x4 *)(&sS[i][(wave - 5) * 16 + kk * 4]) = r;
+            load_tile_weights<10>(w_skip, NF, (wave - 10) * 16, i, kk, av);
         }
         PS_TRACE(5);
-        // ---- (2) prologue: post op of stage s-1 on the current location
+        // ---- (2) post op of stage s-1 on this wave's frame
         if (pact) {
-            float out[5];
-            if (pro == PRO_CONVIN) chain_post<PRO_CONVIN>(pre, p_has_skip != 0, sC, sS, jl, sub, ucur, out);
-            else if (pro == PRO_GATE) chain_post<PRO_GATE>(pre, false, sC, sS, jl, sub, ucur, out);
-            else if (pro == PRO_DIL) chain_post<PRO_DIL>(pre, false, sC, sS, jl, sub, ucur, out);
-            else chain_post<PRO_UINIT>(pre, false, sC, sS, jl, sub, ucur, out);
-            PS_TRACE(6);
-            float ep[5], en[5];
-#pragma unroll
-            for (int k = 0; k < 5; ++k) celu_pair(out[k], ep[k], en[k]);
-            if (in_form == IN_CELU) {
-#pragma unroll
-                for (int k = 0; k < 5; ++k) { sIn[jl][sub + 16 * k] = ep[k]; sIn[jl][NF + sub + 16 * k] = en[k]; }
-            } else {  // IN_RAW: dilated convs read the raw u
-#pragma unroll
-                for (int k = 0; k < 5; ++k) sIn[jl][sub + 16 * k] = out[k];
+            // (2a) consume the operands fetched during the previous stage ...
+            const PreOps cur = pre;
+            // (2b) ... and put the NEXT prologue's operands (k_nbr slots of THIS stage + biases) in flight before
+            //      the post-op math, whose dependent chain (LDS read, two wave reductions, exp/rcp) hides them
+            {
+                const int npro = uni(sSt[s + 1].pro), nskip = uni(sSt[s + 1].p_has_skip);
+                const float *pbias = sSt[s + 1].pbias, *pbias2 = sSt[s + 1].pbias2;
+                const float *nA = nbr_item + (size_t)s * nbr_stage, *nB = nA + nbr_half;
+                if (a.ablate & 2) {
+                } else if (npro == PRO_CONVIN) chain_prefetch<PRO_CONVIN>(pre, pbias, pbias2, nskip != 0, nA, nB, lane);
+                else if (npro == PRO_GATE) chain_prefetch<PRO_GATE>(pre, pbias, pbias2, false, nA, nB, lane);
+                else chain_prefetch<PRO_DIL>(pre, pbias, pbias2, false, nA, nB, lane);
             }
-            if (pro != PRO_CONVIN) {
-                float *outR = sSt[s].outR, *outE = sSt[s].outE;
+            PS_TRACE(8);
+            float out[NCH];
+            if (a.ablate & 8) {
 #pragma unroll
-                for (int k = 0; k < 5; ++k) {
-                    const int c = sub + 16 * k;
+                for (int k = 0; k < NCH; ++k) out[k] = owns(lane, k) ? cur.pb[k] + sC[wave][chan(lane, k)] : 0.0f;
+            } else if (pro == PRO_CONVIN) chain_post<PRO_CONVIN>(cur, p_has_skip != 0, sC[wave], sS[wave], lane, ucur, out);
+            else if (pro == PRO_GATE) chain_post<PRO_GATE>(cur, false, sC[wave], sS[wave], lane, ucur, out);
+            else if (pro == PRO_DIL) chain_post<PRO_DIL>(cur, false, sC[wave], sS[wave], lane, ucur, out);
+            else chain_post<PRO_UINIT>(cur, false, sC[wave], sS[wave], lane, ucur, out);
+            PS_TRACE(6);
+            float ep[NCH], en[NCH];
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) celu_pair(out[k], ep[k], en[k]);
+            const bool is_u = pro != PRO_CONVIN;
+            float *o1 = is_u ? sSt[s].outR : sSt[s].outX, *o2 = sSt[s].outE;
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                if (!owns(lane, k)) continue;
+                const int c = chan(lane, k);
+                if (in_form == IN_CELU) { sIn[wave][c] = ep[k]; sIn[wave][NF + c] = en[k]; }
+                else sIn[wave][c] = out[k];  // IN_RAW: dilated convs read the raw u
+                if (is_u) {
                     ucur[k] = out[k];
-                    PS_G(float, outR)[ploc * NF + c] = out[k];
-                    PS_G(float, outE)[ploc * (2 * NF) + c] = ep[k];
-                    PS_G(float, outE)[ploc * (2 * NF) + NF + c] = en[k];
+                    if (save_slot >= 0) sU[save_slot][wave][c] = out[k];
                 }
-                if (save_slot >= 0) {
-#pragma unroll
-                    for (int k = 0; k < 5; ++k) sU[save_slot][jl][sub + 16 * k] = out[k];
-                }
-            } else {
-                float *outX = sSt[s].outX;
-#pragma unroll
-                for (int k = 0; k < 5; ++k) {
-                    const int c = sub + 16 * k;
-                    PS_G(float, outX)[ploc * (2 * NF) + c] = ep[k];
-                    PS_G(float, outX)[ploc * (2 * NF) + NF + c] = en[k];
+                if (!(a.ablate & 1)) {
+                    if (is_u) {
+                        PS_G(float, o1)[off80 + c] = out[k];
+                        PS_G(float, o2)[off160 + c] = ep[k];
+                        PS_G(float, o2)[off160 + NF + c] = en[k];
+                    } else {
+                        PS_G(float, o1)[off160 + c] = ep[k];
+                        PS_G(float, o1)[off160 + NF + c] = en[k];
+                    }
                 }
             }
             PS_TRACE(7);
             const int next_skip = uni(sSt[s + 1].skip_slot);
             if (next_skip >= 0) {  // stage the NEXT stage's nin_skip input (u_k of this location, from the up pass)
 #pragma unroll
-                for (int k = 0; k < 5; ++k) {
-                    const int c = sub + 16 * k;
+                for (int k = 0; k < NCH; ++k) {
+                    if (!owns(lane, k)) continue;
+                    const int c = chan(lane, k);
                     float sp, sn;
-                    celu_pair(sU[next_skip][jl][c], sp, sn);
-                    sSkip[jl][c] = sp;
-                    sSkip[jl][NF + c] = sn;
+                    celu_pair(sU[next_skip][wave][c], sp, sn);
+                    sSkip[wave][c] = sp;
+                    sSkip[wave][NF + c] = sn;
                 }
             }
-            PS_TRACE(8);
-            // ---- (3) raw operands of the next prologue (post op of THIS stage): k_nbr's slots + biases
-            const int npro = uni(sSt[s + 1].pro), nskip = uni(sSt[s + 1].p_has_skip);
-            const float *pbias = sSt[s + 1].pbias, *pbias2 = sSt[s + 1].pbias2;
-            const float *nA = a.nbr + (((size_t)s * 2 + 0) * a.F + pf) * NBR_LD;
-            const float *nB = a.nbr + (((size_t)s * 2 + 1) * a.F + pf) * NBR_LD;
-            if (npro == PRO_CONVIN) chain_prefetch<PRO_CONVIN>(pre, pbias, pbias2, nskip != 0, nA, nB, sub);
-            else if (npro == PRO_GATE) chain_prefetch<PRO_GATE>(pre, pbias, pbias2, false, nA, nB, sub);
-            else chain_prefetch<PRO_DIL>(pre, pbias, pbias2, false, nA, nB, sub);
         }
         PS_TRACE(1);
         lds_barrier();
         PS_TRACE(2);
-        // ---- (4) centre-tap products (and the nin_skip 1x1), one 16-channel tile per wave
-        if (main_w) {
-            const f32x4 r = NG == 10 ? center_tile<10>(av, sIn, i, kk) : center_tile<5>(av, sIn, i, kk);
-            *(f32x4 *)(&sC[i][wave * 16 + kk * 4]) = r;
+        // ---- (4) centre-tap products and the nin_skip 1x1 (its input was staged one stage earlier)
+        if (!(a.ablate & 4)) {
+            if (main_w) {
+                const f32x4 r = NG == 10 ? center_tile<10>(av, sIn, i, kk) : center_tile<5>(av, sIn, i, kk);
+                *(f32x4 *)(&sC[i][wave * 16 + kk * 4]) = r;
+            } else if (skip_w) {
+                const f32x4 r = center_tile<10>(av, sSkip, i, kk);
+                *(f32x4 *)(&sS[i][(wave - 10) * 16 + kk * 4]) = r;
+            }
         }
         PS_TRACE(3);
         lds_barrier();
@@ -721,44 +742,43 @@ __global__ __launch_bounds__(CHAIN_WAVES * 64) void k_chain(ChainArgs a)
     }
 #undef PS_TRACE
 
-    {   // ---- nin_out(elu(u)) (model.py:153): its prologue is the last gate; 32 tiles over the 10 waves
+    {   // ---- nin_out(elu(u)) (model.py:153): its prologue is the last gate; 32 tiles, two per wave
         const StageDesc &sd = sSt[NST - 1];
         const int ntile = sd.Co_pad >> 4;
-        f32x4 avL[4][5];
+        f32x4 avL[2][5];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < 2; ++r) {
             const int ct = wave + r * CHAIN_WAVES;
             if (ct < ntile) load_tile_weights<5>(sd.w, sd.Co_pad, ct * 16, i, kk, avL[r]);
         }
         if (pact) {
-            float out[5];
-            chain_post<PRO_GATE>(pre, false, sC, sS, jl, sub, ucur, out);
+            float out[NCH];
+            chain_post<PRO_GATE>(pre, false, sC[wave], sS[wave], lane, ucur, out);
 #pragma unroll
-            for (int k = 0; k < 5; ++k) {
-                const int c = sub + 16 * k;
+            for (int k = 0; k < NCH; ++k) {
+                if (!owns(lane, k)) continue;
+                const int c = chan(lane, k);
                 float ep, en;
                 celu_pair(out[k], ep, en);
-                sIn[jl][c] = ep;
-                PS_G(float, sd.outR)[ploc * NF + c] = out[k];
-                PS_G(float, sd.outE)[ploc * (2 * NF) + c] = ep;
-                PS_G(float, sd.outE)[ploc * (2 * NF) + NF + c] = en;
+                sIn[wave][c] = ep;
+                PS_G(float, sd.outR)[off80 + c] = out[k];
+                PS_G(float, sd.outE)[off160 + c] = ep;
+                PS_G(float, sd.outE)[off160 + NF + c] = en;
             }
         }
         lds_barrier();
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < 2; ++r) {
             const int ct = wave + r * CHAIN_WAVES;
             if (ct < ntile) *(f32x4 *)(&sL[i][ct * 16 + kk * 4]) = center_tile<5>(avL[r], sIn, i, kk);
         }
         lds_barrier();
     }
 
-    // ---- end of the order position: logits, categorical draw (sample.py:60-66), next context
-    for (int j = wave; j < 16; j += CHAIN_WAVES) {
-        const int f = f0 + j;
-        if (f >= a.F) continue;
-        const int q = a.cx.ctx[f].q;
-        const size_t loc = (size_t)f * a.L + q;
+    // ---- end of the order position: logits, categorical draw (sample.py:60-66), next context; wave = frame
+    if (pact) {
+        const int f = pf, j = wave;
+        const size_t loc = ploc;
         float lg[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) lg[k] = sL[j][lane * 8 + k] + a.out_b[lane * 8 + k];
@@ -770,38 +790,35 @@ __global__ __launch_bounds__(CHAIN_WAVES * 64) void k_chain(ChainArgs a)
 #pragma unroll
             for (int k = 0; k < 8; ++k) a.step_logits[(size_t)f * NCLS + lane * 8 + k] = lg[k];
         }
-        if (!a.codes || !a.region[loc]) continue;
-        if (a.forced) {
-            if (lane == 0) a.codes[loc] = a.forced[loc];
-            continue;
+        if (a.codes && a.region[loc]) {
+            if (a.forced) {
+                if (lane == 0) a.codes[loc] = a.forced[loc];
+            } else {
+                float x[8], m = -INFINITY;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { x[k] = lg[k] / a.temperature; m = fmaxf(m, x[k]); }
+                for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+                float e[8], ls = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { e[k] = expf(x[k] - m); ls += e[k]; }
+                float incl = ls;  // inclusive scan of the per-lane sums (classes are lane-major)
+                for (int off = 1; off < 64; off <<= 1) {
+                    const float t = __shfl_up(incl, off, 64);
+                    if (lane >= off) incl += t;
+                }
+                const float total = __shfl(incl, 63, 64);
+                const float target = a.uniforms[loc] * total;
+                float run = incl - ls;
+                int cnt = 0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { run += e[k]; cnt += run <= target ? 1 : 0; }  // classes whose cdf <= target
+                for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+                if (lane == 0) a.codes[loc] = min(cnt, NCLS - 1);
+            }
         }
-        float x[8], m = -INFINITY;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { x[k] = lg[k] / a.temperature; m = fmaxf(m, x[k]); }
-        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-        float e[8], ls = 0.0f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { e[k] = expf(x[k] - m); ls += e[k]; }
-        float incl = ls;  // inclusive scan of the per-lane sums (classes are lane-major)
-        for (int off = 1; off < 64; off <<= 1) {
-            const float t = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += t;
-        }
-        const float total = __shfl(incl, 63, 64);
-        const float target = a.uniforms[loc] * total;
-        float run = incl - ls;
-        int cnt = 0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { run += e[k]; cnt += run <= target ? 1 : 0; }  // classes whose cdf <= target
-        for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
-        if (lane == 0) a.codes[loc] = min(cnt, NCLS - 1);
-    }
-    if (a.advance) {
-        __syncthreads();  // every read of ctx[f] above is done
-        const int j = tid >> 5, t = tid & 31;
-        if (j < 16 && f0 + j < a.F) {
-            const int step = a.cx.ctx[f0 + j].step;
-            ctx_fill(a.cx, f0 + j, step + 1, t);
+        if (a.advance) {  // this wave is the only reader of ctx[f] in this launch
+            const int step = a.cx.ctx[f].step;
+            if (lane < 32) ctx_fill(a.cx, f, step + 1, lane);
         }
     }
 }
@@ -984,7 +1001,7 @@ void conv_taps(GemmArgs &a, const float *in, int ld, const float *wp, int Cin, i
 void run_grid(ps_pixelcnn *h, int F, const int32_t *codes, const Masks &m, float *logits, bool nchw, hipStream_t st)
 {
     const int nitems = F * h->L;
-    const int pblocks = (nitems + 15) / 16;
+    const int pblocks = (nitems + 3) / 4;
     auto gemm = [&](GemmArgs &a, const float *mask) {
         a.H = h->H; a.W = h->W; a.L = h->L; a.nitems = nitems;
         a.mask = mask; a.mask_fstride = (size_t)9 * h->L; a.partial = h->partial; a.tiles_per_block = 8;
@@ -1097,7 +1114,7 @@ void run_column(ps_pixelcnn *h, int F, const int32_t *codes, ChainArgs ca, hipSt
 {
     NbrArgs na{h->stages, h->work, h->ctx, h->nbr, h->upre, codes, h->uinit_w, h->uinit_b, h->nwork, h->H, h->W, h->L, F};
     const int tiles = (F + 15) / 16;
-    timed(h, st, TAG_NBR, [&]() { hipLaunchKernelGGL(k_nbr, dim3(h->nwork + 1, tiles), dim3(256), 0, st, na); });
+    timed(h, st, TAG_NBR, [&]() { hipLaunchKernelGGL(k_nbr, dim3(h->nwork + 4, tiles), dim3(256), 0, st, na); });
     ca.stages = h->stages; ca.nbr = h->nbr; ca.upre = h->upre;
     ca.out_b = h->out_b;
     ca.H = h->H; ca.W = h->W; ca.L = h->L; ca.F = F;
@@ -1318,6 +1335,7 @@ int ps_pixelcnn_time_column_step(ps_pixelcnn *h, const int32_t *codes, const int
     ca.cx = make_ctx_args(h, order, Masks{mask_init, mask_undilated, mask_dilated}, F);
     ca.step_logits = h->col_logits;
     ca.temperature = 1.0f;
+    if (const char *ab = getenv("PS_CHAIN_ABLATE")) ca.ablate = atoi(ab);
     hipLaunchKernelGGL(k_ctx_init, dim3(F), dim3(32), 0, st, ca.cx, step);
     run_column(h, F, codes, ca, st);  // untimed warm-up
     if (const char *tp = getenv("PS_CHAIN_TRACE")) {  // tuning aid: per-stage shader-clock stamps of workgroup 0
