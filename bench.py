@@ -117,6 +117,42 @@ def measure_roofline(model, d, out, V):
             "launches_per_ar_position": 2}
 
 
+def extra_configs(device):
+    """The other single-GPU configurations BASELINE.json names, measured the same way (inputs resident, barrier-free
+    single stream, wall clock around synchronised steps): C3 = ONE view end to end (latency-bound: the AR chain
+    uses one CU), C2 = batch-32 reprojection + splat only."""
+    res = {}
+    m1 = build_model(device)
+    d1, _ = make_inputs(0, 1, device)
+    for _ in range(2):
+        o1 = run_step(m1, d1, 1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 3
+    for _ in range(n):
+        o1 = run_step(m1, d1, 1)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    res["C3_single_view"] = {"frames_per_s": round(1.0 / dt, 3), "ms_per_frame": round(dt * 1e3, 3),
+                             "sampled_codes": int(o1["plan"].n_sampled[0]), "ar_positions_walked": 1024 - o1["plan"].first_step}
+    d32, _ = make_inputs(1, 32, device)
+    pm = m1.pts_transformer
+    call = lambda: pm.forward_justpts(d32["img"], d32["depth"], d32["K"], d32["Kinv"], d32["P"], d32["Pinv"], d32["RT2"], d32["RT2inv"])
+    for _ in range(3):
+        call()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 10
+    for _ in range(n):
+        call()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    alg = 1900544.0 * 32  # SURVEY 8d: algorithmic bytes per frame of the splat
+    res["C2_splat_b32"] = {"frames_per_s": round(32 / dt, 1), "ms_per_batch": round(dt * 1e3, 3),
+                           "algorithmic_GBs": round(alg / dt / 1e9, 2), "frac_hbm": round(alg / dt / 1e9 / HBM_PEAK_GBS, 5)}
+    return res
+
+
 def cpu_baseline(host, out, V, budget_s=20.0):
     """The oracle (CPU restatement of the reference path, kind 'port') on this box's host cores, on a
     bounded sample: one view's project+splat+order/masks, plus a few reference-style AR steps (one full
@@ -165,6 +201,7 @@ def main():
     ap.add_argument("--views", type=int, default=16, help="independent novel views per GPU per step")
     ap.add_argument("--depth", choices=["smooth", "uniform"], default="smooth")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the C3 single-view / C2 splat-only side measurements")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -225,6 +262,11 @@ def main():
                     res["cpu_baseline"] = cpu_baseline(host, out, V)
                 except Exception as e:
                     res["cpu_baseline"] = {"error": repr(e)}
+            if not args.no_extra:
+                try:
+                    res["other_single_gpu_configs"] = extra_configs(device)
+                except Exception as e:
+                    res["other_single_gpu_configs"] = {"error": repr(e)}
         print(json.dumps(res), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
