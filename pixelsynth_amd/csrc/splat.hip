@@ -8,7 +8,8 @@
 // Pipeline (all on the caller's stream, no host sync, no allocation):
 //   k_project        1 thread / point: p = grid*depth, X = K (RT2 RT1inv) Kinv p, divide, EPS rule
 //   k_bin_count      conservative pixel bbox of each point's disc -> 8x8-pixel tiles, per-tile counts
-//   k_scan           exclusive scan of the B*tiles counters (one workgroup)
+//   k_scan           exclusive scan of each frame's tile counters (one workgroup per frame; every frame owns a
+//                    fixed slice of the key array, so no cross-frame scan)
 //   k_bin_fill       64-bit keys (z bits << 32 | point index) appended to each touched tile's list
 //   k_sort_small/big per-tile sort of the keys (normalised bitonic network; LDS, or global for huge
 //                    lists).  Keys are unique, so the order -- ascending (z, index), PyTorch3D's CPU
@@ -169,31 +170,57 @@ __device__ __forceinline__ uint32_t point_bbox(const float *p, int S, float hw)
            ((uint32_t)(y1 / TILE) << 24);
 }
 
+// Tiles per frame up to which a workgroup aggregates its tile counters in LDS before touching the global ones.
+// The 256 points of a workgroup are neighbours in the source image, so they land on a few dozen tiles: one
+// global atomic per (workgroup, touched tile) instead of one per (point, tile).
+constexpr int LDS_TILES = 4096;
+constexpr int MAX_TPP = 9;  // tiles per point kept in LDS ranks (larger footprints take the direct path)
+
 __global__ __launch_bounds__(256) void k_bin_count(const float *__restrict__ pts, int N, int S,
                                                    float hw, int tilesX, int NT,
                                                    uint32_t *__restrict__ bbox,
                                                    uint32_t *__restrict__ tile_count)
 {
+    __shared__ uint32_t cnt[LDS_TILES];
     const int b = blockIdx.y;
     const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
-    const uint32_t bb = point_bbox(pts + ((size_t)b * N + n) * 3, S, hw);
-    bbox[(size_t)b * N + n] = bb;
-    if (bb == CULLED) return;
-    const int tx0 = bb & 255, ty0 = (bb >> 8) & 255, tx1 = (bb >> 16) & 255, ty1 = bb >> 24;
-    for (int ty = ty0; ty <= ty1; ++ty)
-        for (int tx = tx0; tx <= tx1; ++tx) atomicAdd(&tile_count[(size_t)b * NT + ty * tilesX + tx], 1u);
+    const bool agg = NT <= LDS_TILES;
+    if (agg) {
+        for (int t = threadIdx.x; t < NT; t += 256) cnt[t] = 0;
+        __syncthreads();
+    }
+    if (n < N) {
+        const uint32_t bb = point_bbox(pts + ((size_t)b * N + n) * 3, S, hw);
+        bbox[(size_t)b * N + n] = bb;
+        if (bb != CULLED) {
+            const int tx0 = bb & 255, ty0 = (bb >> 8) & 255, tx1 = (bb >> 16) & 255, ty1 = bb >> 24;
+            for (int ty = ty0; ty <= ty1; ++ty)
+                for (int tx = tx0; tx <= tx1; ++tx) {
+                    if (agg) atomicAdd(&cnt[ty * tilesX + tx], 1u);
+                    else atomicAdd(&tile_count[(size_t)b * (NT + 1) + ty * tilesX + tx], 1u);
+                }
+        }
+    }
+    if (agg) {
+        __syncthreads();
+        for (int t = threadIdx.x; t < NT; t += 256)
+            if (cnt[t]) atomicAdd(&tile_count[(size_t)b * (NT + 1) + t], cnt[t]);
+    }
 }
 
-// exclusive scan of M counters in place; counters[M] receives the total.  One workgroup.
-__global__ __launch_bounds__(1024) void k_scan(uint32_t *__restrict__ counters, int M)
+// exclusive scan of one frame's NT tile counters in place (one workgroup per frame); the offsets are then
+// shifted by the frame's slice of the key array (frame_cap keys per frame), so no cross-frame scan is needed.
+// counters layout: (B, NT + 1); entry NT receives the end of the frame's last list.
+__global__ __launch_bounds__(1024) void k_scan(uint32_t *__restrict__ counters, int NT, uint32_t frame_cap)
 {
     __shared__ uint32_t part[1024];
     const int t = threadIdx.x;
-    const int per = (M + 1023) / 1024;
-    const int beg = t * per, end = min(M, beg + per);
+    uint32_t *c = counters + (size_t)blockIdx.x * (NT + 1);
+    const uint32_t base = blockIdx.x * frame_cap;
+    const int per = (NT + 1023) / 1024;
+    const int beg = t * per, end = min(NT, beg + per);
     uint32_t s = 0;
-    for (int i = beg; i < end; ++i) s += counters[i];
+    for (int i = beg; i < end; ++i) s += c[i];
     part[t] = s;
     __syncthreads();
     for (int off = 1; off < 1024; off <<= 1) {
@@ -202,13 +229,13 @@ __global__ __launch_bounds__(1024) void k_scan(uint32_t *__restrict__ counters, 
         part[t] += v;
         __syncthreads();
     }
-    uint32_t run = part[t] - s;
+    uint32_t run = base + part[t] - s;
     for (int i = beg; i < end; ++i) {
-        const uint32_t c = counters[i];
-        counters[i] = run;
-        run += c;
+        const uint32_t v = c[i];
+        c[i] = run;
+        run += v;
     }
-    if (t == 1023) counters[M] = part[1023];
+    if (t == 1023) c[NT] = base + part[1023];
 }
 
 __global__ __launch_bounds__(256) void k_bin_fill(const float *__restrict__ pts, int N, int tilesX,
@@ -217,21 +244,48 @@ __global__ __launch_bounds__(256) void k_bin_fill(const float *__restrict__ pts,
                                                   uint32_t *__restrict__ tile_cursor,
                                                   uint64_t *__restrict__ keys)
 {
+    __shared__ uint32_t cnt[LDS_TILES];       // per-tile count of this workgroup, then its base in the tile's list
+    __shared__ uint16_t rank[256][MAX_TPP];   // rank of each (point, tile) inside the workgroup's share
     const int b = blockIdx.y;
     const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
-    const uint32_t bb = bbox[(size_t)b * N + n];
-    if (bb == CULLED) return;
-    const float z = pts[((size_t)b * N + n) * 3 + 2];
-    const uint32_t zkey = (z == 0.0f) ? 0u : __float_as_uint(z);  // -0.0 == +0.0 in the tuple compare
-    const uint64_t key = ((uint64_t)zkey << 32) | (uint32_t)n;
+    uint32_t bb = CULLED;
+    if (n < N) bb = bbox[(size_t)b * N + n];
     const int tx0 = bb & 255, ty0 = (bb >> 8) & 255, tx1 = (bb >> 16) & 255, ty1 = bb >> 24;
-    for (int ty = ty0; ty <= ty1; ++ty)
-        for (int tx = tx0; tx <= tx1; ++tx) {
-            const size_t t = (size_t)b * NT + ty * tilesX + tx;
-            const uint32_t pos = tile_off[t] + atomicAdd(&tile_cursor[t], 1u);
-            keys[pos] = key;
-        }
+    const bool live = bb != CULLED;
+    // same-footprint decision for the whole workgroup (uniform branch): LDS aggregation or the direct path
+    const bool fits = !live || (tx1 - tx0 + 1) * (ty1 - ty0 + 1) <= MAX_TPP;
+    const bool agg = NT <= LDS_TILES && __syncthreads_and(fits);
+    uint64_t key = 0;
+    if (live) {
+        const float z = pts[((size_t)b * N + n) * 3 + 2];
+        const uint32_t zkey = (z == 0.0f) ? 0u : __float_as_uint(z);  // -0.0 == +0.0 in the tuple compare
+        key = ((uint64_t)zkey << 32) | (uint32_t)n;
+    }
+    if (!agg) {
+        if (live)
+            for (int ty = ty0; ty <= ty1; ++ty)
+                for (int tx = tx0; tx <= tx1; ++tx) {
+                    const int t = ty * tilesX + tx;
+                    keys[tile_off[(size_t)b * (NT + 1) + t] + atomicAdd(&tile_cursor[(size_t)b * NT + t], 1u)] = key;
+                }
+        return;
+    }
+    for (int t = threadIdx.x; t < NT; t += 256) cnt[t] = 0;
+    __syncthreads();
+    if (live) {
+        int k = 0;
+        for (int ty = ty0; ty <= ty1; ++ty)
+            for (int tx = tx0; tx <= tx1; ++tx) rank[threadIdx.x][k++] = (uint16_t)atomicAdd(&cnt[ty * tilesX + tx], 1u);
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < NT; t += 256)
+        if (cnt[t]) cnt[t] = tile_off[(size_t)b * (NT + 1) + t] + atomicAdd(&tile_cursor[(size_t)b * NT + t], cnt[t]);
+    __syncthreads();
+    if (live) {
+        int k = 0;
+        for (int ty = ty0; ty <= ty1; ++ty)
+            for (int tx = tx0; tx <= tx1; ++tx) keys[cnt[ty * tilesX + tx] + rank[threadIdx.x][k++]] = key;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -241,19 +295,20 @@ __global__ __launch_bounds__(256) void k_bin_fill(const float *__restrict__ pts,
 template <int THREADS, typename Ptr>
 __device__ __forceinline__ void bitonic_sort(Ptr a, int n)
 {
-    int P = 1;
-    while (P < n) P <<= 1;
-    const int half = P >> 1;
-    for (int k = 2; k <= P; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
+    int lp = 0;
+    while ((1 << lp) < n) ++lp;
+    const int half = (1 << lp) >> 1;
+    for (int lk = 1; lk <= lp; ++lk) {            // k = 2^lk: size of the bitonic blocks being merged
+        for (int lj = lk - 1; lj >= 0; --lj) {    // j = 2^lj: compare distance (powers of two: shifts, no divisions)
+            const int j = 1 << lj;
             for (int p = threadIdx.x; p < half; p += THREADS) {
+                const int blk = p >> lj, w = p & (j - 1);
                 int i, l;
-                if (j == (k >> 1)) {
-                    const int blk = p / j, w = p - blk * j;
-                    i = blk * k + w;
-                    l = blk * k + k - 1 - w;
+                if (lj == lk - 1) {               // first step of a merge: mirror inside the block of size k
+                    i = (blk << lk) + w;
+                    l = (blk << lk) + (1 << lk) - 1 - w;
                 } else {
-                    i = 2 * j * (p / j) + (p % j);
+                    i = (blk << (lj + 1)) + w;
                     l = i + j;
                 }
                 if (l < n) {
@@ -266,13 +321,13 @@ __device__ __forceinline__ void bitonic_sort(Ptr a, int n)
     }
 }
 
-// one wave per tile; lists longer than SORT_SMALL_CAP are queued for k_sort_big
+// one wave per tile (grid: tiles x frames); lists longer than SORT_SMALL_CAP are queued for k_sort_big
 __global__ __launch_bounds__(64) void k_sort_small(uint64_t *__restrict__ keys,
-                                                   const uint32_t *__restrict__ tile_off,
+                                                   const uint32_t *__restrict__ tile_off, int NT,
                                                    uint32_t *__restrict__ worklist)
 {
     __shared__ uint64_t s[SORT_SMALL_CAP];
-    const uint32_t t = blockIdx.x;
+    const uint32_t t = blockIdx.y * (NT + 1) + blockIdx.x;  // index into the (B, NT+1) offset table
     const uint32_t beg = tile_off[t], n = tile_off[t + 1] - beg;
     if (n < 2) return;
     if (n > SORT_SMALL_CAP) {
@@ -316,6 +371,14 @@ __device__ __forceinline__ float bcast(float v, int lane)
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
+// Two phases per batch of 64 sorted records (one record staged per lane, shared through LDS):
+//   1. every lane runs the exact strict disc test against all 64 records (wave-uniform LDS broadcasts) and
+//      keeps one bit per record -- cheap, branch-free;
+//   2. every lane walks only ITS OWN hits (ascending bit order = ascending (z, idx)), fetching the record from
+//      LDS: alpha from dist^2, front-to-back blend, stop at K hits.  ~50 hits per pixel instead of ~256
+//      predicated blend bodies per pixel.
+struct __attribute__((aligned(16))) SplatRec { float x, y, z; uint32_t n; float f[CG]; };
+
 template <int MODE, bool DEBUG_OUT, bool RECIP>
 __global__ __launch_bounds__(64) void k_composite(
     const uint64_t *__restrict__ keys, const uint32_t *__restrict__ tile_off,
@@ -324,13 +387,14 @@ __global__ __launch_bounds__(64) void k_composite(
     uint8_t *__restrict__ bg0, int32_t *__restrict__ out_idx, float *__restrict__ out_zbuf,
     float *__restrict__ out_dist)
 {
+    __shared__ SplatRec rec[64];
     const int tile = blockIdx.x, b = blockIdx.y, c0 = blockIdx.z * CG;
     const int lane = threadIdx.x;
     const int tx = tile % tilesX, ty = tile / tilesX;
     const int xi = tx * TILE + (lane & 7), yi = ty * TILE + (lane >> 3);
     const bool valid = xi < S && yi < S;
     const float xf = pix_to_ndc(S - 1 - xi, S), yf = pix_to_ndc(S - 1 - yi, S);
-    const uint32_t beg = tile_off[(size_t)b * NT + tile], end = tile_off[(size_t)b * NT + tile + 1];
+    const uint32_t beg = tile_off[(size_t)b * (NT + 1) + tile], end = tile_off[(size_t)b * (NT + 1) + tile + 1];
     const int ncg = min(CG, C - c0);
     const size_t pix = ((size_t)b * S + yi) * S + xi;
 
@@ -343,68 +407,73 @@ __global__ __launch_bounds__(64) void k_composite(
     for (int pass = (MODE == PS_ACC_WSUMNORM ? 0 : 1); pass < 2; ++pass) {
         cnt = 0;
         if (MODE == PS_ACC_WSUMNORM && pass == 1 && tsum < 1e-4f) tsum = 1e-4f;
-        for (uint32_t base = beg; base < end; base += 64) {
-            const int m = min(64u, end - base);
-            // cooperative stage: lane j fetches record j of this batch
-            float rx = INFINITY, ry = 0.0f, rz = 0.0f;
-            float rf[CG];
+        // software pipeline: the record of batch i+1 is fetched (two dependent global round trips: key -> point,
+        // features) while batch i is tested and blended
+        auto fetch = [&](uint32_t base) {
+            SplatRec r;
+            r.x = INFINITY; r.y = 0.0f; r.z = 0.0f; r.n = 0;  // lanes past the end carry x = +inf: never a hit
 #pragma unroll
-            for (int c = 0; c < CG; ++c) rf[c] = 0.0f;
-            uint32_t rn = 0;
-            if (lane < m) {
-                rn = (uint32_t)keys[base + lane];
-                const float *p = pts + ((size_t)b * N + rn) * 3;
-                rx = p[0];
-                ry = p[1];
-                rz = p[2];
+            for (int c = 0; c < CG; ++c) r.f[c] = 0.0f;
+            if (base < end && lane < (int)min(64u, end - base)) {
+                r.n = (uint32_t)keys[base + lane];
+                const float *p = pts + ((size_t)b * N + r.n) * 3;
+                r.x = p[0];
+                r.y = p[1];
+                r.z = p[2];
                 if (pass == 1) {
 #pragma unroll
                     for (int c = 0; c < CG; ++c)
-                        if (c < ncg) rf[c] = feat[((size_t)b * C + c0 + c) * N + rn];
+                        if (c < ncg) r.f[c] = feat[((size_t)b * C + c0 + c) * N + r.n];
                 }
             }
-#pragma unroll 1
-            for (int j8 = 0; j8 < 64; j8 += 8) {
-                if (j8 >= m) break;
-#pragma unroll
-                for (int jj = 0; jj < 8; ++jj) {
-                    const int j = j8 + jj;
-                    // Broadcasts are wave-uniform reads (v_readlane ignores EXEC), hoisted out of the
-                    // divergent hit branch.  Lanes >= m carry rx = +inf: dx*dx = inf never passes.
-                    const float sx = bcast(rx, j);
-                    const float sy = bcast(ry, j);
-                    float sf[CG];
-#pragma unroll
-                    for (int c = 0; c < CG; ++c) sf[c] = bcast(rf[c], j);
-                    const uint32_t sn = DEBUG_OUT ? (uint32_t)__builtin_amdgcn_readlane((int)rn, j) : 0u;
-                    const float sz = DEBUG_OUT ? bcast(rz, j) : 0.0f;
-                    const float dx = sx - xf, dy = sy - yf;
+            return r;
+        };
+        SplatRec rnext = fetch(beg);
+        for (uint32_t base = beg; base < end; base += 64) {
+            const SplatRec r = rnext;
+            rnext = fetch(base + 64);
+            __syncthreads();  // the previous batch's phase 2 is done with rec[]
+            rec[lane] = r;
+            __syncthreads();
+            // phase 1: hit bits
+            uint64_t hits = 0;
+            if (valid && cnt < K) {
+#pragma unroll 16
+                for (int j = 0; j < 64; ++j) {
+                    const float dx = rec[j].x - xf, dy = rec[j].y - yf;
                     const float d2 = dx * dx + dy * dy;
-                    if (valid && d2 < r2 && cnt < K) {
-                        float d = RECIP ? d2 * denom : d2 / denom;
-                        d = fminf(fmaxf(d, 1e-3f), 1.0f);
-                        float a = 1.0f - sqrtf(d);
-                        if (tau != 1.0f) a = powf(a, tau);
-                        if (MODE == PS_ACC_WSUMNORM && pass == 0) {
-                            tsum = tsum + a;
-                        } else {
+                    hits |= (uint64_t)(d2 < r2) << j;
+                }
+            }
+            // phase 2: this pixel's hits, front to back
+            while (hits && cnt < K) {
+                const int j = __builtin_ctzll(hits);
+                hits &= hits - 1;
+                const SplatRec h = rec[j];
+                const float dx = h.x - xf, dy = h.y - yf;
+                const float d2 = dx * dx + dy * dy;
+                float d = RECIP ? d2 * denom : d2 / denom;
+                d = fminf(fmaxf(d, 1e-3f), 1.0f);
+                float a = 1.0f - sqrtf(d);
+                if (tau != 1.0f) a = powf(a, tau);
+                if (MODE == PS_ACC_WSUMNORM && pass == 0) {
+                    tsum = tsum + a;
+                } else {
 #pragma unroll
-                            for (int c = 0; c < CG; ++c) {
-                                const float f = sf[c];
-                                if (MODE == PS_ACC_ALPHACOMPOSITE) acc[c] = acc[c] + f * cum * a;
-                                else if (MODE == PS_ACC_WSUM) acc[c] = acc[c] + f * a;
-                                else acc[c] = acc[c] + f * a / tsum;
-                            }
-                            if (MODE == PS_ACC_ALPHACOMPOSITE) cum = cum * (1.0f - a);
-                            if (DEBUG_OUT && blockIdx.z == 0) {
-                                if (out_idx) out_idx[pix * K + cnt] = (int32_t)(b * N + sn);
-                                if (out_zbuf) out_zbuf[pix * K + cnt] = sz;
-                                if (out_dist) out_dist[pix * K + cnt] = d2;
-                            }
-                        }
-                        ++cnt;
+                    for (int c = 0; c < CG; ++c) {
+                        const float f = h.f[c];
+                        if (MODE == PS_ACC_ALPHACOMPOSITE) acc[c] = acc[c] + f * cum * a;
+                        else if (MODE == PS_ACC_WSUM) acc[c] = acc[c] + f * a;
+                        else acc[c] = acc[c] + f * a / tsum;
+                    }
+                    if (MODE == PS_ACC_ALPHACOMPOSITE) cum = cum * (1.0f - a);
+                    if (DEBUG_OUT && blockIdx.z == 0) {
+                        if (out_idx) out_idx[pix * K + cnt] = (int32_t)(b * N + h.n);
+                        if (out_zbuf) out_zbuf[pix * K + cnt] = h.z;
+                        if (out_dist) out_dist[pix * K + cnt] = d2;
                     }
                 }
+                ++cnt;
             }
             if (__all((cnt >= K) || !valid)) break;
         }
@@ -483,7 +552,7 @@ SplatPlan make_plan(int B, int N, int S, double radius_px)
     const size_t M = (size_t)B * p.NT;
     p.off_pts = o;    o = ps::align_up(o + (size_t)B * N * 3 * sizeof(float), 256);
     p.off_bbox = o;   o = ps::align_up(o + (size_t)B * N * sizeof(uint32_t), 256);
-    p.off_count = o;  o = ps::align_up(o + (M + 1) * sizeof(uint32_t), 256);
+    p.off_count = o;  o = ps::align_up(o + (M + B) * sizeof(uint32_t), 256);   // (B, NT+1) counters -> offsets
     p.off_cursor = o; o = ps::align_up(o + M * sizeof(uint32_t), 256);
     p.off_work = o;   o = ps::align_up(o + (M + 1) * sizeof(uint32_t), 256);
     p.off_bg0 = o;    o = ps::align_up(o + (size_t)B * S * S, 256);
@@ -514,7 +583,6 @@ int splat_core(const float *pts, const float *feat, int B, int N, int C, int S, 
                uint8_t *out_bg, int32_t *out_idx, float *out_zbuf, float *out_dist, char *ws,
                const SplatPlan &p, hipStream_t st)
 {
-    const size_t M = (size_t)B * p.NT;
     uint32_t *bbox = (uint32_t *)(ws + p.off_bbox);
     uint32_t *tile_off = (uint32_t *)(ws + p.off_count);
     uint32_t *cursor = (uint32_t *)(ws + p.off_cursor);
@@ -535,9 +603,9 @@ int splat_core(const float *pts, const float *feat, int B, int N, int C, int S, 
     PS_HIP_CHECK(hipMemsetAsync(ws + p.off_count, 0, p.off_bg0 - p.off_count, st));
     const dim3 gpt((N + 255) / 256, B);
     hipLaunchKernelGGL(k_bin_count, gpt, dim3(256), 0, st, pts, N, S, p.hw, p.tilesX, p.NT, bbox, tile_off);
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, tile_off, (int)M);
+    hipLaunchKernelGGL(k_scan, dim3(B), dim3(1024), 0, st, tile_off, p.NT, (uint32_t)((size_t)N * p.max_tiles_pp));
     hipLaunchKernelGGL(k_bin_fill, gpt, dim3(256), 0, st, pts, N, p.tilesX, p.NT, bbox, tile_off, cursor, keys);
-    hipLaunchKernelGGL(k_sort_small, dim3((unsigned)M), dim3(64), 0, st, keys, tile_off, work);
+    hipLaunchKernelGGL(k_sort_small, dim3(p.NT, B), dim3(64), 0, st, keys, tile_off, p.NT, work);
     hipLaunchKernelGGL(k_sort_big, dim3(128), dim3(1024), 0, st, keys, tile_off, work);
     const dim3 gc(p.NT, B, (C + CG - 1) / CG);
     const bool debug = out_idx || out_zbuf || out_dist;
@@ -570,6 +638,7 @@ int check_splat_args(int B, int N, int C, int S, double radius_px, int K, int ac
     PS_REQUIRE(bg_ksize >= 1 && (bg_ksize & 1) && bg_ksize <= 2 * DMAXH + 1, "splat: bg_ksize %d must be odd and <= %d",
                bg_ksize, 2 * DMAXH + 1);
     PS_REQUIRE((size_t)B * N < 0x7FFFFFFFull, "splat: B*N overflows the packed int32 index");
+    PS_REQUIRE((size_t)B * N * 16 < 0xFFFFFFFFull, "splat: B*N too large for 32-bit key offsets");
     return PS_OK;
 }
 
