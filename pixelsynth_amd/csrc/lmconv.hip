@@ -147,15 +147,15 @@ __global__ __launch_bounds__(64) void k_gemm(GemmArgs a)
 }
 
 // ------------------------------------------------------------------------------------------
-// per-item post ops, shared by the whole-grid kernels and the column chain.  An item (one location of one
-// frame, NF = 80 channels) is handled by ONE WAVE: lane l owns channel l and, for l < 16, channel 64 + l
-// (NCH = 2 slots per lane, the second one mostly empty).  Keeping the per-lane work this small is what
-// bounds the serial prologue of every stage of k_chain.  Every reduction uses the same association
-// order in both modes, so column steps and whole-grid passes agree bit for bit.
+// per-item post ops, shared by the whole-grid kernels and the column chain.
+// The NF = 80 channels of an item are handled as 20 GROUPS of 4 consecutive channels (one f32x4): that is the
+// MFMA accumulator layout (lane (kk, i) of the wave owning output tile w holds channels 16w + 4kk .. +3 of
+// item i), so k_chain applies the post op directly on its accumulators with 16-byte slot / bias / cache
+// accesses.  The statistics of PONO are reduced in ONE association order everywhere: a group partial
+// ((y0 + y1) + y2) + y3, then the 20 partials added sequentially, group 0 first -- so column steps and
+// whole-grid passes agree bit for bit.
 // ------------------------------------------------------------------------------------------
-constexpr int NCH = 2;
-__device__ __forceinline__ int chan(int lane, int k) { return lane + 64 * k; }
-__device__ __forceinline__ bool owns(int lane, int k) { return k == 0 || lane < NF - 64; }
+constexpr int NGRP = NF / 4;  // 20
 
 // Elementwise math of the post ops.  These sit on the sequential critical path of every AR order position
 // (k_chain), so they use the hardware transcendental units directly (v_exp_f32 / v_rcp_f32 / v_rsq_f32,
@@ -169,73 +169,60 @@ __device__ __forceinline__ void celu_pair(float x, float &ep, float &en)
     ep = x > 0.0f ? x : e;
     en = x > 0.0f ? e : -x;
 }
+__device__ __forceinline__ void celu_pair4(const f32x4 &x, f32x4 &ep, f32x4 &en)
+{
+    float p0, p1, p2, p3, n0, n1, n2, n3;
+    celu_pair(x.x, p0, n0);
+    celu_pair(x.y, p1, n1);
+    celu_pair(x.z, p2, n2);
+    celu_pair(x.w, p3, n3);
+    ep = f32x4{p0, p1, p2, p3};
+    en = f32x4{n0, n1, n2, n3};
+}
 __device__ __forceinline__ float sigmoid1(float x) { return __builtin_amdgcn_rcpf(1.0f + fast_exp(-x)); }
+__device__ __forceinline__ f32x4 sigmoid4(const f32x4 &x) { return f32x4{sigmoid1(x.x), sigmoid1(x.y), sigmoid1(x.z), sigmoid1(x.w)}; }
 
-// all-reduce over the 64 lanes of a wave: DPP row rotations inside each 16-lane row (rotation by 8, 4, 2, 1
-// pairs each lane with the same partners as an xor butterfly and a+b == b+a bitwise, so every lane of a
-// row ends with identical bits), then the four row sums are read with v_readlane and added in a fixed order.
-template <int N>
-__device__ __forceinline__ float row_ror(float v)
-{
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + N, 0xf, 0xf, false));
-}
-__device__ __forceinline__ float wave_sum(float v)
-{
-    v += row_ror<8>(v);
-    v += row_ror<4>(v);
-    v += row_ror<2>(v);
-    v += row_ror<1>(v);
-    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
-    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
-    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
-    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
-    return ((r0 + r1) + r2) + r3;
-}
+__device__ __forceinline__ float group_sum(const f32x4 &v) { return ((v.x + v.y) + v.z) + v.w; }
+__device__ __forceinline__ float group_sumsq(const f32x4 &d) { return ((d.x * d.x + d.y * d.y) + d.z * d.z) + d.w * d.w; }
+// PONO statistics from the 20 group partials (models/lmconv/layers.py:231-236: unbiased variance, eps 1e-5)
+__device__ __forceinline__ float pono_mean(float total) { return total * (1.0f / (float)NF); }
+__device__ __forceinline__ float pono_inv(float ss_total) { return __builtin_amdgcn_rsqf(ss_total * (1.0f / (float)(NF - 1)) + 1e-5f); }
 
-// PONO over the NF channels of one item (models/lmconv/layers.py:231-236), unbiased variance, eps 1e-5.
-// Slots a lane does not own must hold 0 on entry and hold 0 on exit.
-__device__ __forceinline__ void pono_wave(float (&v)[NCH], int lane)
-{
-    const float mean = wave_sum(v[0] + v[1]) * (1.0f / (float)NF);
-    const float d0 = v[0] - mean, d1 = owns(lane, 1) ? v[1] - mean : 0.0f;
-    const float ss = wave_sum(d0 * d0 + d1 * d1);
-    const float inv = __builtin_amdgcn_rsqf(ss * (1.0f / (float)(NF - 1)) + 1e-5f);
-    v[0] = d0 * inv;
-    v[1] = d1 * inv;
-}
-
+// y = ((bias + NA) + C) + NB, element-wise on a group
+__device__ __forceinline__ f32x4 slot_sum4(const f32x4 &bias, const f32x4 &na, const f32x4 &c, const f32x4 &nb) { return ((bias + na) + c) + nb; }
 __device__ __forceinline__ float slot_sum(float bias, float na, float c, float nb) { return ((bias + na) + c) + nb; }
 
 enum { POST_CONVIN = 0, POST_GATE = 1, POST_DIL = 2 };
 
-// v (and g for the gate): conv output INCLUDING bias, already slot-summed by the caller (0 in unowned slots).
-// KIND = POST_CONVIN: out = PONO(v) [+ skip]                         (layers.py:153-156)
-//        POST_GATE:   out = rin + PONO(v) * sigmoid(g)                (layers.py:159-163)
-//        POST_DIL:    out = PONO(v)                                   (model.py:138-140,148-150)
+// n = PONO-normalised group.  KIND = POST_CONVIN: out = n [+ skip]              (layers.py:153-156)
+//                                   POST_GATE:   out = rin + n * sigmoid(g)      (layers.py:159-163)
+//                                   POST_DIL:    out = n                         (model.py:138-140,148-150)
 template <int KIND>
-__device__ __forceinline__ void post_math(float (&v)[NCH], const float (&g)[NCH], const float (&skip)[NCH], bool has_skip,
-                                          const float (&rin)[NCH], int lane, float (&out)[NCH])
+__device__ __forceinline__ f32x4 post_finish(const f32x4 &n, const f32x4 &g, const f32x4 &skip, bool has_skip, const f32x4 &rin)
 {
-    pono_wave(v, lane);
-#pragma unroll
-    for (int k = 0; k < NCH; ++k) {
-        if (KIND == POST_CONVIN) out[k] = has_skip ? v[k] + skip[k] : v[k];
-        else if (KIND == POST_GATE) out[k] = rin[k] + v[k] * sigmoid1(g[k]);
-        else out[k] = v[k];
-        if (!owns(lane, k)) out[k] = 0.0f;
-    }
+    if (KIND == POST_CONVIN) return has_skip ? n + skip : n;
+    if (KIND == POST_GATE) return rin + n * sigmoid4(g);
+    return n;
 }
 
-// u_init on one-hot input as a gather, type-A mask (model.py:132), BEFORE norm_init:
+// sequential sum of the 20 group partials held by lanes 0..19 of a wave (whole-grid kernels)
+__device__ __forceinline__ float lanes20_sum(float part)
+{
+    float tot = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(part), 0));
+#pragma unroll
+    for (int g = 1; g < NGRP; ++g) tot = tot + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(part), g));
+    return tot;
+}
+
+// u_init on one-hot input as a gather, type-A mask (model.py:132), BEFORE norm_init, for channel group `grp`:
 //   y[o] = b[o] + sum_t m_t * (W[t][512][o] + W[t][code(nbr_t)][o])
 // Only earlier order positions contribute (the centre of a type-A mask is 0), so in column mode this
 // belongs to the neighbour kernel, not to the chain.
-__device__ __forceinline__ void uinit_gather(const int32_t *__restrict__ codes_f, const float *mA /*9 values*/,
-                                             const float *__restrict__ w, const float *__restrict__ bias, int q, int H,
-                                             int W, int lane, float (&out)[NCH])
+__device__ __forceinline__ f32x4 uinit_gather4(const int32_t *__restrict__ codes_f, const float *mA /*9 values*/,
+                                               const float *__restrict__ w, const float *__restrict__ bias, int q, int H,
+                                               int W, int grp)
 {
     const int r = q / W, c0 = q - r * W;
-    float v[NCH];
     int code[9];
     float mv[9];
 #pragma unroll
@@ -245,37 +232,24 @@ __device__ __forceinline__ void uinit_gather(const int32_t *__restrict__ codes_f
         mv[t] = in ? mA[t] : 0.0f;
         code[t] = (in && mv[t] != 0.0f) ? codes_f[rr * W + cc] : -1;
     }
-#pragma unroll
-    for (int k = 0; k < NCH; ++k) v[k] = owns(lane, k) ? bias[chan(lane, k)] : 0.0f;
+    f32x4 v = *(const f32x4 *)(bias + 4 * grp);
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         if (mv[t] == 0.0f) continue;
-        const float *w1 = w + ((size_t)t * (NCLS + 1) + NCLS) * NF;
-        const float *wc = w + ((size_t)t * (NCLS + 1) + (code[t] >= 0 ? code[t] : 0)) * NF;
-#pragma unroll
-        for (int k = 0; k < NCH; ++k) {
-            if (!owns(lane, k)) continue;
-            float x = w1[chan(lane, k)];
-            if (code[t] >= 0) x += wc[chan(lane, k)];
-            v[k] += mv[t] * x;
-        }
+        f32x4 x = *(const f32x4 *)(w + ((size_t)t * (NCLS + 1) + NCLS) * NF + 4 * grp);
+        if (code[t] >= 0) x = x + *(const f32x4 *)(w + ((size_t)t * (NCLS + 1) + code[t]) * NF + 4 * grp);
+        v = v + x * mv[t];
     }
-#pragma unroll
-    for (int k = 0; k < NCH; ++k) out[k] = v[k];
+    return v;
 }
 
-__device__ __forceinline__ void store_raw_celu(float *R, float *E, size_t loc, int lane, const float (&u)[NCH])
+__device__ __forceinline__ void store_raw_celu4(float *R, float *E, size_t loc, int grp, const f32x4 &u)
 {
-#pragma unroll
-    for (int k = 0; k < NCH; ++k) {
-        if (!owns(lane, k)) continue;
-        const int c = chan(lane, k);
-        float ep, en;
-        celu_pair(u[k], ep, en);
-        R[loc * NF + c] = u[k];
-        E[loc * (2 * NF) + c] = ep;
-        E[loc * (2 * NF) + NF + c] = en;
-    }
+    f32x4 ep, en;
+    celu_pair4(u, ep, en);
+    *(f32x4 *)(R + loc * NF + 4 * grp) = u;
+    *(f32x4 *)(E + loc * (2 * NF) + 4 * grp) = ep;
+    *(f32x4 *)(E + loc * (2 * NF) + NF + 4 * grp) = en;
 }
 
 struct PostArgs {
@@ -286,7 +260,7 @@ struct PostArgs {
     float *Rout, *Eout, *Xout;
 };
 
-// whole-grid post op: one wave per item, 4 items per 256-thread block
+// whole-grid post op: one wave per item (lanes 0..19 own the 20 channel groups), 4 items per 256-thread block
 template <int KIND>
 __global__ __launch_bounds__(256) void k_post_grid(PostArgs a)
 {
@@ -294,33 +268,33 @@ __global__ __launch_bounds__(256) void k_post_grid(PostArgs a)
     if (item >= a.nitems) return;  // whole waves leave together
     const size_t loc = item;       // item = f*L + q
     const size_t ss = (size_t)a.nitems * a.Co_pad;
-    const float *P = a.partial + (size_t)item * a.Co_pad;
-    float v[NCH], g[NCH], skip[NCH], rin[NCH], out[NCH];
-#pragma unroll
-    for (int k = 0; k < NCH; ++k) {
-        v[k] = g[k] = skip[k] = rin[k] = 0.0f;
-        if (!owns(lane, k)) continue;
-        const int c = chan(lane, k);
-        v[k] = slot_sum(a.bias[c], P[SLOT_NA * ss + c], P[SLOT_C * ss + c], P[SLOT_NB * ss + c]);
+    const bool own = lane < NGRP;
+    const int c = 4 * (own ? lane : 0);
+    const float *P = a.partial + (size_t)item * a.Co_pad + c;
+    const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+    f32x4 y = zero, g = zero, skip = zero, rin = zero;
+    if (own) {
+        y = slot_sum4(*(const f32x4 *)(a.bias + c), *(const f32x4 *)(P + SLOT_NA * ss), *(const f32x4 *)(P + SLOT_C * ss),
+                      *(const f32x4 *)(P + SLOT_NB * ss));
         if (KIND == POST_GATE) {
-            g[k] = slot_sum(a.bias[c + NF], P[SLOT_NA * ss + c + NF], P[SLOT_C * ss + c + NF], P[SLOT_NB * ss + c + NF]);
-            rin[k] = a.Rin[loc * NF + c];
+            g = slot_sum4(*(const f32x4 *)(a.bias + c + NF), *(const f32x4 *)(P + SLOT_NA * ss + NF),
+                          *(const f32x4 *)(P + SLOT_C * ss + NF), *(const f32x4 *)(P + SLOT_NB * ss + NF));
+            rin = *(const f32x4 *)(a.Rin + loc * NF + c);
         }
-        if (KIND == POST_CONVIN && a.has_skip) skip[k] = P[SLOT_SKIP * ss + c] + a.bias2[c];
+        if (KIND == POST_CONVIN && a.has_skip) skip = *(const f32x4 *)(P + SLOT_SKIP * ss) + *(const f32x4 *)(a.bias2 + c);
     }
-    post_math<KIND>(v, g, skip, a.has_skip != 0, rin, lane, out);
+    const float mean = pono_mean(lanes20_sum(group_sum(y)));
+    const f32x4 d = y - mean;
+    const float inv = pono_inv(lanes20_sum(group_sumsq(d)));
+    if (!own) return;
+    const f32x4 out = post_finish<KIND>(d * inv, g, skip, a.has_skip != 0, rin);
     if (KIND == POST_CONVIN) {
-#pragma unroll
-        for (int k = 0; k < NCH; ++k) {
-            if (!owns(lane, k)) continue;
-            const int c = chan(lane, k);
-            float ep, en;
-            celu_pair(out[k], ep, en);
-            a.Xout[loc * (2 * NF) + c] = ep;
-            a.Xout[loc * (2 * NF) + NF + c] = en;
-        }
+        f32x4 ep, en;
+        celu_pair4(out, ep, en);
+        *(f32x4 *)(a.Xout + loc * (2 * NF) + c) = ep;
+        *(f32x4 *)(a.Xout + loc * (2 * NF) + NF + c) = en;
     } else {
-        store_raw_celu(a.Rout, a.Eout, loc, lane, out);
+        store_raw_celu4(a.Rout, a.Eout, loc, lane, out);
     }
 }
 
@@ -338,13 +312,16 @@ __global__ __launch_bounds__(256) void k_uinit_grid(UinitArgs a)
     const int item = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (item >= a.nitems) return;
     const int f = item / a.L, q = item - f * a.L;
+    const bool own = lane < NGRP;
     float mA[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) mA[t] = a.mask[((size_t)f * 9 + t) * a.L + q];
-    float u[NCH];
-    uinit_gather(a.codes + (size_t)f * a.L, mA, a.w, a.bias, q, a.H, a.W, lane, u);
-    pono_wave(u, lane);  // norm_init
-    store_raw_celu(a.Rout, a.Eout, (size_t)item, lane, u);
+    f32x4 y = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (own) y = uinit_gather4(a.codes + (size_t)f * a.L, mA, a.w, a.bias, q, a.H, a.W, lane);
+    const float mean = pono_mean(lanes20_sum(group_sum(y)));   // norm_init
+    const f32x4 d = y - mean;
+    const float inv = pono_inv(lanes20_sum(group_sumsq(d)));
+    if (own) store_raw_celu4(a.Rout, a.Eout, (size_t)item, lane, d * inv);
 }
 
 // logits = nin_out partial + bias; nchw: (F,512,H,W) like the reference, else (nitems,512)
@@ -471,16 +448,14 @@ __device__ __forceinline__ void nbr_taps(const StageDesc &sd, const NbrArgs &a, 
 // grid (work items, ceil(F/16)); 4 waves = 4 output-channel tiles of one (stage, slot)
 __global__ __launch_bounds__(256) void k_nbr(NbrArgs a)
 {
-    if ((int)blockIdx.x >= a.nwork) {  // last 4 work items: the u_init gather, one wave per frame
+    if ((int)blockIdx.x >= a.nwork) {  // last 4 work items: the u_init gather, one wave per frame, 20 groups of 4
         const int f = blockIdx.y * 16 + ((int)blockIdx.x - a.nwork) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-        if (f >= a.F) return;
-        float mA[9], v[NCH];
+        if (f >= a.F || lane >= NGRP) return;
+        float mA[9];
 #pragma unroll
         for (int t = 0; t < 9; ++t) mA[t] = a.ctx[f].m[0][t];
-        uinit_gather(a.codes + (size_t)f * a.L, mA, a.uinit_w, a.uinit_b, a.ctx[f].q, a.H, a.W, lane, v);
-#pragma unroll
-        for (int k = 0; k < NCH; ++k)
-            if (owns(lane, k)) a.upre[(size_t)f * NF + chan(lane, k)] = v[k];
+        *(f32x4 *)(a.upre + (size_t)f * NF + 4 * lane) =
+            uinit_gather4(a.codes + (size_t)f * a.L, mA, a.uinit_w, a.uinit_b, a.ctx[f].q, a.H, a.W, lane);
         return;
     }
     const NbrWork wk = a.work[blockIdx.x];
@@ -549,236 +524,186 @@ __device__ __forceinline__ void load_tile_weights(const float *__restrict__ w, i
     for (int g = 0; g < NG; ++g) av[g] = *PS_GC(f32x4, wbase + (size_t)g * 16 * Co_pad);
 }
 
-// operands of a prologue (post op of the previous stage), fetched one stage ahead as RAW values: no
-// arithmetic at fetch time, so nothing waits for the loads until the next stage consumes them
-struct PreOps { float pb[NCH], na[NCH], nb[NCH], pbg[NCH], nag[NCH], nbg[NCH], skb[NCH]; };
-
-template <int PRO>
-__device__ __forceinline__ void chain_prefetch(PreOps &p, const float *pbias, const float *pbias2, bool has_skip,
-                                               const float *nA, const float *nB, int lane)
-{
-#pragma unroll
-    for (int k = 0; k < NCH; ++k) {
-        if (!owns(lane, k)) continue;
-        const int c = chan(lane, k);
-        p.pb[k] = PS_GC(float, pbias)[c];
-        p.na[k] = PS_GC(float, nA)[c];
-        p.nb[k] = PS_GC(float, nB)[c];
-        if (PRO == PRO_GATE) {
-            p.pbg[k] = PS_GC(float, pbias)[c + NF];
-            p.nag[k] = PS_GC(float, nA)[c + NF];
-            p.nbg[k] = PS_GC(float, nB)[c + NF];
-        }
-        if (PRO == PRO_CONVIN && has_skip) p.skb[k] = PS_GC(float, pbias2)[c];
-    }
-}
-
-// post op of the previous stage for one item: slots summed as ((bias + NA) + C) + NB like the whole-grid pass
-template <int PRO>
-__device__ __forceinline__ void chain_post(const PreOps &p, bool has_skip, const float *sCrow, const float *sSrow,
-                                           int lane, const float (&ucur)[NCH], float (&out)[NCH])
-{
-    float v[NCH], g[NCH], skip[NCH];
-#pragma unroll
-    for (int k = 0; k < NCH; ++k) {
-        v[k] = g[k] = skip[k] = 0.0f;
-        if (!owns(lane, k)) continue;
-        const int c = chan(lane, k);
-        if (PRO == PRO_UINIT) {
-            v[k] = p.pb[k];  // u_init before norm_init, from k_nbr
-        } else {
-            v[k] = ((p.pb[k] + p.na[k]) + sCrow[c]) + p.nb[k];
-            if (PRO == PRO_GATE) g[k] = ((p.pbg[k] + p.nag[k]) + sCrow[c + NF]) + p.nbg[k];
-            if (PRO == PRO_CONVIN && has_skip) skip[k] = sSrow[c] + p.skb[k];
-        }
-    }
-    if (PRO == PRO_CONVIN) post_math<POST_CONVIN>(v, g, skip, has_skip, ucur, lane, out);
-    else if (PRO == PRO_GATE) post_math<POST_GATE>(v, g, skip, false, ucur, lane, out);
-    else post_math<POST_DIL>(v, g, skip, false, ucur, lane, out);  // PRO_UINIT: norm_init is the same PONO
-}
-
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+constexpr int SG_LD = NF + 4;  // row stride (floats) of the 80-channel LDS arrays, keeps f32x4 rows 16-byte aligned
+
+// One workgroup (16 waves) per tile of 16 frames.  Lane (kk, i) of a wave owning output tile w holds, after the
+// MFMA, channels 16w + 4kk .. +3 of frame i -- the post op of the stage is applied right there:
+//   A  centre-tap products (waves < Co/16) and the nin_skip 1x1 (waves 10..14)
+//   B  y = ((bias + NA) + acc) + NB with 16-byte loads fetched before the MFMAs; the gate half (waves 5..9)
+//      and the nin_skip result pass through LDS; the 20 group partials of the PONO statistics are
+//      exchanged through LDS (two LDS-only barriers), then waves 0..4 finish: normalise, skip / gate /
+//      residual, concat-ELU, write the next stage's input (LDS) and the caches (global, 16-byte stores).
+// Weights of stage s+1 are requested at the start of B(s); nothing waits on global memory at a barrier.
 __global__ __launch_bounds__(CHAIN_WAVES * 64) void k_chain(ChainArgs a)
 {
-    __shared__ __attribute__((aligned(16))) float sIn[16][SIN_LD];    // input of the centre tap
-    __shared__ __attribute__((aligned(16))) float sSkip[16][SIN_LD];  // concat_elu(u_k) feeding nin_skip
-    __shared__ __attribute__((aligned(16))) float sC[16][SIN_LD];     // centre-tap results
-    __shared__ __attribute__((aligned(16))) float sS[16][NF + 4];     // nin_skip results
-    __shared__ float sU[8][16][NF];                                   // u0..u7 of this location (skip connections)
-    __shared__ __attribute__((aligned(16))) float sL[16][SL_LD];      // nin_out results
-    __shared__ StageDesc sSt[NST];                                    // the chain description, read every stage
+    __shared__ __attribute__((aligned(16))) float sIn[16][SIN_LD];     // input of the centre taps
+    __shared__ __attribute__((aligned(16))) float sSkip[16][SIN_LD];   // concat_elu(u_k) feeding nin_skip
+    __shared__ __attribute__((aligned(16))) float sS[16][SG_LD];       // nin_skip results
+    __shared__ __attribute__((aligned(16))) float sG[16][SG_LD];       // gate half of conv_out
+    __shared__ __attribute__((aligned(16))) float sU[8][16][SG_LD];    // u0..u7 of this location (skip connections)
+    __shared__ __attribute__((aligned(16))) float sRed[2][16][NGRP];   // PONO group partials: sums, squared deviations
+    __shared__ __attribute__((aligned(16))) float sL[16][SL_LD];       // nin_out results
+    __shared__ StageDesc sSt[NST];                                     // the chain description
     const int tid = threadIdx.x, wave = uni(tid >> 6), lane = tid & 63, i = lane & 15, kk = lane >> 4;
     const int f0 = blockIdx.x * 16;
+    const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
     {
         const int *src = (const int *)a.stages;
         int *dst = (int *)sSt;
         for (int k = tid; k < (int)(NST * sizeof(StageDesc) / 4); k += CHAIN_WAVES * 64) dst[k] = src[k];
     }
-    // post-op role: wave w handles frame f0 + w of the tile
-    const int pf = f0 + wave;
-    const bool pact = pf < a.F;
-    int pq = 0;
-    if (pact) pq = uni(a.cx.ctx[pf].q);
-    const size_t ploc = (size_t)pf * a.L + pq;
-    const size_t off80 = ploc * NF, off160 = ploc * (2 * NF);                  // this location in the R / E,X caches
-    const float *nbr_item = a.nbr + (size_t)pf * NBR_LD;                       // this frame's rows of the k_nbr slots
+    // this lane's frame (column i of every MFMA tile) and its location
+    const int fi = f0 + i;
+    const bool vi = fi < a.F;
+    const int qi = vi ? a.cx.ctx[fi].q : 0;
+    const size_t off80 = ((size_t)fi * a.L + qi) * NF, off160 = 2 * off80;
+    const float *nbr_i = a.nbr + (size_t)fi * NBR_LD;
     const size_t nbr_half = (size_t)a.F * NBR_LD, nbr_stage = 2 * nbr_half;
-    float ucur[NCH] = {0.0f, 0.0f};
-    PreOps pre;
-#pragma unroll
-    for (int k = 0; k < NCH; ++k) {
-        pre.pb[k] = pre.na[k] = pre.nb[k] = pre.pbg[k] = pre.nag[k] = pre.nbg[k] = pre.skb[k] = 0.0f;
-        if (pact && owns(lane, k)) pre.pb[k] = a.upre[(size_t)pf * NF + chan(lane, k)];  // stage 0: u_init before norm_init
-    }
-    if (!pact) {  // rows of absent frames feed zeros into the MFMA tiles
-        for (int c = lane; c < 2 * NF; c += 64) { sIn[wave][c] = 0.0f; sSkip[wave][c] = 0.0f; }
+    const bool pw = wave < 5;                 // waves 0..4 own the 80 channels the post ops produce
+    const int c4 = 16 * wave + 4 * kk;        // this lane's channel group (as a tile wave)
+    const int grp = 4 * wave + kk;
+    f32x4 ucur = zero;
+    if (!vi && wave < 10) {  // columns of absent frames feed zeros into the MFMA tiles
+        *(f32x4 *)(&sIn[i][c4]) = zero;
+        *(f32x4 *)(&sSkip[i][c4]) = zero;
     }
     __syncthreads();
 
-#define PS_TRACE(slot) do { if (a.trace && blockIdx.x == 0 && tid == 0) a.trace[s * 10 + (slot)] = clock64(); } while (0)
-    for (int s = 0; s < NST - 1; ++s) {
-        // stage control words: wave-uniform scalars, read once
-        typedef int i32x4 __attribute__((ext_vector_type(4)));
-        const i32x4 c0 = *(const i32x4 *)&sSt[s].pro, c1 = *(const i32x4 *)&sSt[s].NG;
-        const int pro = uni(c0.x), in_form = uni(c0.y), save_slot = uni(c0.z), p_has_skip = uni(c0.w), NG = uni(c1.x),
-                  Co_pad = uni(c1.y), center_tap = uni(c1.z);
-        const float *w = sSt[s].w, *w_skip = sSt[s].w_skip;
-        PS_TRACE(0);
-        // ---- (1) this stage's centre-tap weights: independent of everything computed here, issue first.
-        //      Waves 0..9 own the tiles of the main product, waves 10..14 those of the nin_skip 1x1.
+    // PONO over the 80 channels of every frame + the stage-specific finish + hand-off.  Called by ALL waves
+    // (it contains the barriers); only waves 0..4 carry data.  kind: PRO_* of the consumer stage `nx`.
+    auto post_and_emit = [&](const f32x4 &y, int kind, int nx) {
+        if (pw) sRed[0][i][grp] = group_sum(y);
+        lds_barrier();
+        f32x4 d = zero;
+        if (pw) {
+            float tot = sRed[0][i][0];
+#pragma unroll
+            for (int g = 1; g < NGRP; ++g) tot = tot + sRed[0][i][g];
+            d = y - pono_mean(tot);
+            sRed[1][i][grp] = group_sumsq(d);
+        }
+        lds_barrier();
+        if (pw) {
+            float tot = sRed[1][i][0];
+#pragma unroll
+            for (int g = 1; g < NGRP; ++g) tot = tot + sRed[1][i][g];
+            const f32x4 n = d * pono_inv(tot);
+            f32x4 out;
+            if (kind == PRO_CONVIN) {
+                const bool hs = uni(sSt[nx].p_has_skip) != 0;
+                f32x4 skip = zero;
+                if (hs) skip = *(const f32x4 *)(&sS[i][c4]) + *PS_GC(f32x4, sSt[nx].pbias2 + c4);
+                out = post_finish<POST_CONVIN>(n, zero, skip, hs, zero);
+            } else if (kind == PRO_GATE) {
+                out = post_finish<POST_GATE>(n, *(const f32x4 *)(&sG[i][c4]), zero, false, ucur);
+            } else {
+                out = n;  // PRO_DIL, PRO_UINIT (norm_init)
+            }
+            f32x4 ep, en;
+            celu_pair4(out, ep, en);
+            const int in_form = uni(sSt[nx].in_form);
+            if (vi) {
+                if (in_form == IN_CELU) { *(f32x4 *)(&sIn[i][c4]) = ep; *(f32x4 *)(&sIn[i][NF + c4]) = en; }
+                else if (in_form == IN_RAW) *(f32x4 *)(&sIn[i][c4]) = out;
+                else *(f32x4 *)(&sIn[i][c4]) = ep;
+                if (kind == PRO_CONVIN) {
+                    float *X = sSt[nx].outX;
+                    *PS_G(f32x4, X + off160 + c4) = ep;
+                    *PS_G(f32x4, X + off160 + NF + c4) = en;
+                } else {
+                    float *R = sSt[nx].outR, *E = sSt[nx].outE;
+                    *PS_G(f32x4, R + off80 + c4) = out;
+                    *PS_G(f32x4, E + off160 + c4) = ep;
+                    *PS_G(f32x4, E + off160 + NF + c4) = en;
+                }
+            }
+            if (kind != PRO_CONVIN) {
+                ucur = out;
+                const int save_slot = uni(sSt[nx].save_slot);
+                if (save_slot >= 0) *(f32x4 *)(&sU[save_slot][i][c4]) = out;
+            }
+        } else if (wave >= 10 && wave < 15) {
+            // idle nin_skip waves stage the input of stage nx's nin_skip: concat_elu(u_k), k from the up pass
+            const int k = uni(sSt[nx].skip_slot);
+            if (k >= 0 && vi) {
+                const int cs = 16 * (wave - 10) + 4 * kk;
+                f32x4 ep, en;
+                celu_pair4(*(const f32x4 *)(&sU[k][i][cs]), ep, en);
+                *(f32x4 *)(&sSkip[i][cs]) = ep;
+                *(f32x4 *)(&sSkip[i][NF + cs]) = en;
+            }
+        }
+        lds_barrier();
+    };
+
+    // weights of the first stage, then u0 = norm_init(u_init) from k_nbr's gather
+    f32x4 av[10];
+    auto fetch_weights = [&](int s2) {
+        const int NG = uni(sSt[s2].NG), Co_pad = uni(sSt[s2].Co_pad), center_tap = uni(sSt[s2].center_tap);
+        const float *w = sSt[s2].w, *w_skip = sSt[s2].w_skip;
         const int ntile = Co_pad >> 4;
-        const bool main_w = wave < ntile, skip_w = w_skip != nullptr && wave >= 10 && wave < 15;
-        f32x4 av[10];
-        if (main_w) {
+        if (s2 == NST - 1) {  // nin_out: 32 tiles, two per wave (av[0..4], av[5..9])
+            load_tile_weights<5>(w, Co_pad, wave * 16, i, kk, av);
+            load_tile_weights<5>(w, Co_pad, (wave + CHAIN_WAVES) * 16, i, kk, av + 5);
+        } else if (wave < ntile) {
             const float *wc = w + (size_t)center_tap * NG * 16 * Co_pad;
             if (NG == 10) load_tile_weights<10>(wc, Co_pad, wave * 16, i, kk, av);
             else load_tile_weights<5>(wc, Co_pad, wave * 16, i, kk, av);
-        } else if (skip_w) {
+        } else if (w_skip != nullptr && wave >= 10 && wave < 15) {
             load_tile_weights<10>(w_skip, NF, (wave - 10) * 16, i, kk, av);
         }
+    };
+    fetch_weights(0);
+    {
+        f32x4 y = zero;
+        if (pw && vi) y = *PS_GC(f32x4, a.upre + (size_t)fi * NF + c4);
+        post_and_emit(y, PRO_UINIT, 0);
+    }
+
+#define PS_TRACE(slot) do { if (a.trace && blockIdx.x == 0 && tid == 0) a.trace[s * 10 + (slot)] = clock64(); } while (0)
+    for (int s = 0; s < NST - 1; ++s) {
+        const int NG = uni(sSt[s].NG), ntile = uni(sSt[s].Co_pad) >> 4;
+        const bool has_skip_w = sSt[s].w_skip != nullptr;
+        const bool tile_w = wave < ntile, skip_w = has_skip_w && wave >= 10 && wave < 15;
+        const int kind = uni(sSt[s + 1].pro);  // the post op that follows this stage
+        PS_TRACE(0);
+        // ---- operands of y = ((bias + NA) + acc) + NB for this lane's group: in flight under the MFMAs
+        f32x4 b4 = zero, na4 = zero, nb4 = zero;
+        if (tile_w && vi) {
+            b4 = *PS_GC(f32x4, sSt[s + 1].pbias + c4);
+            na4 = *PS_GC(f32x4, nbr_i + (size_t)s * nbr_stage + c4);
+            nb4 = *PS_GC(f32x4, nbr_i + (size_t)s * nbr_stage + nbr_half + c4);
+        }
         PS_TRACE(5);
-        // ---- (2) post op of stage s-1 on this wave's frame
-        if (pact) {
-            // (2a) consume the operands fetched during the previous stage ...
-            const PreOps cur = pre;
-            // (2b) ... and put the NEXT prologue's operands (k_nbr slots of THIS stage + biases) in flight before
-            //      the post-op math, whose dependent chain (LDS read, two wave reductions, exp/rcp) hides them
-            {
-                const int npro = uni(sSt[s + 1].pro), nskip = uni(sSt[s + 1].p_has_skip);
-                const float *pbias = sSt[s + 1].pbias, *pbias2 = sSt[s + 1].pbias2;
-                const float *nA = nbr_item + (size_t)s * nbr_stage, *nB = nA + nbr_half;
-                if (a.ablate & 2) {
-                } else if (npro == PRO_CONVIN) chain_prefetch<PRO_CONVIN>(pre, pbias, pbias2, nskip != 0, nA, nB, lane);
-                else if (npro == PRO_GATE) chain_prefetch<PRO_GATE>(pre, pbias, pbias2, false, nA, nB, lane);
-                else chain_prefetch<PRO_DIL>(pre, pbias, pbias2, false, nA, nB, lane);
-            }
-            PS_TRACE(8);
-            float out[NCH];
-            if (a.ablate & 8) {
-#pragma unroll
-                for (int k = 0; k < NCH; ++k) out[k] = owns(lane, k) ? cur.pb[k] + sC[wave][chan(lane, k)] : 0.0f;
-            } else if (pro == PRO_CONVIN) chain_post<PRO_CONVIN>(cur, p_has_skip != 0, sC[wave], sS[wave], lane, ucur, out);
-            else if (pro == PRO_GATE) chain_post<PRO_GATE>(cur, false, sC[wave], sS[wave], lane, ucur, out);
-            else if (pro == PRO_DIL) chain_post<PRO_DIL>(cur, false, sC[wave], sS[wave], lane, ucur, out);
-            else chain_post<PRO_UINIT>(cur, false, sC[wave], sS[wave], lane, ucur, out);
-            PS_TRACE(6);
-            float ep[NCH], en[NCH];
-#pragma unroll
-            for (int k = 0; k < NCH; ++k) celu_pair(out[k], ep[k], en[k]);
-            const bool is_u = pro != PRO_CONVIN;
-            float *o1 = is_u ? sSt[s].outR : sSt[s].outX, *o2 = sSt[s].outE;
-#pragma unroll
-            for (int k = 0; k < NCH; ++k) {
-                if (!owns(lane, k)) continue;
-                const int c = chan(lane, k);
-                if (in_form == IN_CELU) { sIn[wave][c] = ep[k]; sIn[wave][NF + c] = en[k]; }
-                else sIn[wave][c] = out[k];  // IN_RAW: dilated convs read the raw u
-                if (is_u) {
-                    ucur[k] = out[k];
-                    if (save_slot >= 0) sU[save_slot][wave][c] = out[k];
-                }
-                if (!(a.ablate & 1)) {
-                    if (is_u) {
-                        PS_G(float, o1)[off80 + c] = out[k];
-                        PS_G(float, o2)[off160 + c] = ep[k];
-                        PS_G(float, o2)[off160 + NF + c] = en[k];
-                    } else {
-                        PS_G(float, o1)[off160 + c] = ep[k];
-                        PS_G(float, o1)[off160 + NF + c] = en[k];
-                    }
-                }
-            }
-            PS_TRACE(7);
-            const int next_skip = uni(sSt[s + 1].skip_slot);
-            if (next_skip >= 0) {  // stage the NEXT stage's nin_skip input (u_k of this location, from the up pass)
-#pragma unroll
-                for (int k = 0; k < NCH; ++k) {
-                    if (!owns(lane, k)) continue;
-                    const int c = chan(lane, k);
-                    float sp, sn;
-                    celu_pair(sU[next_skip][wave][c], sp, sn);
-                    sSkip[wave][c] = sp;
-                    sSkip[wave][NF + c] = sn;
-                }
-            }
-        }
-        PS_TRACE(1);
-        lds_barrier();
-        PS_TRACE(2);
-        // ---- (4) centre-tap products and the nin_skip 1x1 (its input was staged one stage earlier)
-        if (!(a.ablate & 4)) {
-            if (main_w) {
-                const f32x4 r = NG == 10 ? center_tile<10>(av, sIn, i, kk) : center_tile<5>(av, sIn, i, kk);
-                *(f32x4 *)(&sC[i][wave * 16 + kk * 4]) = r;
-            } else if (skip_w) {
-                const f32x4 r = center_tile<10>(av, sSkip, i, kk);
-                *(f32x4 *)(&sS[i][(wave - 10) * 16 + kk * 4]) = r;
-            }
-        }
-        PS_TRACE(3);
-        lds_barrier();
+        // ---- A: centre-tap products
+        f32x4 acc = zero;
+        if (tile_w) acc = NG == 10 ? center_tile<10>(av, sIn, i, kk) : center_tile<5>(av, sIn, i, kk);
+        else if (skip_w) *(f32x4 *)(&sS[i][16 * (wave - 10) + 4 * kk]) = center_tile<10>(av, sSkip, i, kk);
+        PS_TRACE(6);
+        // ---- weights of the next stage: requested now, consumed after three barriers
+        fetch_weights(s + 1);
+        // ---- B: post op on the accumulators
+        const f32x4 y = slot_sum4(b4, na4, acc, nb4);
+        if (kind == PRO_GATE && wave >= 5 && wave < 10) *(f32x4 *)(&sG[i][c4 - NF]) = y;
+        PS_TRACE(7);
+        post_and_emit(y, kind, s + 1);
         PS_TRACE(4);
     }
 #undef PS_TRACE
 
-    {   // ---- nin_out(elu(u)) (model.py:153): its prologue is the last gate; 32 tiles, two per wave
-        const StageDesc &sd = sSt[NST - 1];
-        const int ntile = sd.Co_pad >> 4;
-        f32x4 avL[2][5];
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int ct = wave + r * CHAIN_WAVES;
-            if (ct < ntile) load_tile_weights<5>(sd.w, sd.Co_pad, ct * 16, i, kk, avL[r]);
-        }
-        if (pact) {
-            float out[NCH];
-            chain_post<PRO_GATE>(pre, false, sC[wave], sS[wave], lane, ucur, out);
-#pragma unroll
-            for (int k = 0; k < NCH; ++k) {
-                if (!owns(lane, k)) continue;
-                const int c = chan(lane, k);
-                float ep, en;
-                celu_pair(out[k], ep, en);
-                sIn[wave][c] = ep;
-                PS_G(float, sd.outR)[off80 + c] = out[k];
-                PS_G(float, sd.outE)[off160 + c] = ep;
-                PS_G(float, sd.outE)[off160 + NF + c] = en;
-            }
-        }
-        lds_barrier();
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int ct = wave + r * CHAIN_WAVES;
-            if (ct < ntile) *(f32x4 *)(&sL[i][ct * 16 + kk * 4]) = center_tile<5>(avL[r], sIn, i, kk);
-        }
-        lds_barrier();
-    }
+    // ---- nin_out(elu(u)) (model.py:153): 32 tiles, two per wave; its input was emitted by the last gate
+    *(f32x4 *)(&sL[i][wave * 16 + kk * 4]) = center_tile<5>(av, sIn, i, kk);
+    *(f32x4 *)(&sL[i][(wave + CHAIN_WAVES) * 16 + kk * 4]) = center_tile<5>(av + 5, sIn, i, kk);
+    lds_barrier();
 
     // ---- end of the order position: logits, categorical draw (sample.py:60-66), next context; wave = frame
-    if (pact) {
+    const int pf = f0 + wave;
+    if (pf < a.F) {
         const int f = pf, j = wave;
-        const size_t loc = ploc;
+        const int pq = uni(a.cx.ctx[f].q);
+        const size_t loc = (size_t)f * a.L + pq;
         float lg[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) lg[k] = sL[j][lane * 8 + k] + a.out_b[lane * 8 + k];
@@ -816,9 +741,12 @@ __global__ __launch_bounds__(CHAIN_WAVES * 64) void k_chain(ChainArgs a)
                 if (lane == 0) a.codes[loc] = min(cnt, NCLS - 1);
             }
         }
-        if (a.advance) {  // this wave is the only reader of ctx[f] in this launch
-            const int step = a.cx.ctx[f].step;
-            if (lane < 32) ctx_fill(a.cx, f, step + 1, lane);
+    }
+    if (a.advance) {
+        __syncthreads();  // every lane of the workgroup has read its ctx[fi].q by now (kernel start), and the draws are done
+        if (pf < a.F) {
+            const int step = a.cx.ctx[pf].step;
+            if (lane < 32) ctx_fill(a.cx, pf, step + 1, lane);
         }
     }
 }
