@@ -108,7 +108,8 @@ __global__ __launch_bounds__(64) void k_gemm(GemmArgs a)
             r = q / a.W;
             c = q - r * a.W;
         }
-        f32x4 acc0 = zero, acc1 = zero;
+        // slot value = taps of the slot added in order, each tap from fresh accumulators: P_t = acc0 + acc1
+        f32x4 tot = zero;
         for (int t = a.slot_first[slot]; t < a.slot_first[slot + 1]; ++t) {
             const GemmTap tp = a.tap[t];
             const float *src = nullptr;
@@ -119,7 +120,8 @@ __global__ __launch_bounds__(64) void k_gemm(GemmArgs a)
                 src = tp.in + ((size_t)f * a.L + rr * a.W + cc) * tp.ld + 4 * kk;
             }
             const bool live = mv != 0.0f;
-            if (!__any(live)) continue;  // a masked tap adds exact zeros: skipping it does not change the bits
+            if (!__any(live)) continue;  // a masked tap is an exact zero: skipping it does not change the bits
+            f32x4 acc0 = zero, acc1 = zero;
             const float *wbase = tp.w + ((size_t)kk * a.Co_pad + o0 + i) * 4;
             int g = 0;
             for (; g + 5 <= ngroups; g += 5) {
@@ -139,10 +141,11 @@ __global__ __launch_bounds__(64) void k_gemm(GemmArgs a)
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc0, 0, 0, 0);
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc0, 0, 0, 0);
             }
+            tot = tot + (acc0 + acc1);
         }
         // D: row (output channel) = kk*4 + reg, col (item) = i
         if (valid)
-            *(f32x4 *)(a.partial + ((size_t)slot * a.nitems + item) * a.Co_pad + o0 + kk * 4) = acc0 + acc1;
+            *(f32x4 *)(a.partial + ((size_t)slot * a.nitems + item) * a.Co_pad + o0 + kk * 4) = tot;
     }
 }
 
@@ -407,45 +410,43 @@ struct NbrArgs {
     int nwork, H, W, L, F;
 };
 
+// one neighbour tap of one conv for 16 frames x 16 output channels, from fresh accumulators
 template <int NG>
-__device__ __forceinline__ void nbr_taps(const StageDesc &sd, const NbrArgs &a, int half, int o0, int f, bool valid,
-                                         int i, int kk, f32x4 &acc0, f32x4 &acc1)
+__device__ __forceinline__ f32x4 nbr_tap(const StageDesc &sd, const NbrArgs &a, int t, int o0, int f, bool valid, int i, int kk)
 {
     const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
-    int q = 0, r = 0, c = 0;
+    float mv = 0.0f;
+    const float *src = nullptr;
     if (valid) {
-        q = a.ctx[f].q;
-        r = q / a.W;
-        c = q - r * a.W;
-    }
-    const size_t per_tap = (size_t)NG * 16 * sd.Co_pad;
-#pragma unroll
-    for (int tt = 0; tt < 4; ++tt) {
-        const int t = half * 5 + tt;  // taps 0..3 or 5..8
+        const int q = a.ctx[f].q;
+        const int r = q / a.W, c = q - r * a.W;
         const int rr = r + (t / 3 - 1) * sd.dil, cc = c + (t % 3 - 1) * sd.dil;
-        float mv = 0.0f;
-        const float *src = nullptr;
-        if (valid && rr >= 0 && rr < a.H && cc >= 0 && cc < a.W) {
+        if (rr >= 0 && rr < a.H && cc >= 0 && cc < a.W) {
             mv = a.ctx[f].m[sd.mask_kind][t];
             src = sd.in + ((size_t)f * a.L + rr * a.W + cc) * sd.in_ld + 4 * kk;
         }
-        const bool live = mv != 0.0f;
-        if (!__any(live)) continue;
-        const float *wbase = sd.w + t * per_tap + ((size_t)kk * sd.Co_pad + o0 + i) * 4;
-#pragma unroll
-        for (int g0 = 0; g0 < NG; g0 += 5) {
-            f32x4 av[5], bv[5];
-#pragma unroll
-            for (int j = 0; j < 5; ++j) {
-                av[j] = *PS_GC(f32x4, wbase + (size_t)(g0 + j) * 16 * sd.Co_pad);
-                bv[j] = live ? *PS_GC(f32x4, src + 16 * (g0 + j)) * mv : zero;
-            }
-            mfma_chunk5(av, bv, acc0, acc1);
-        }
     }
+    const bool live = mv != 0.0f;
+    if (!__any(live)) return zero;
+    f32x4 acc0 = zero, acc1 = zero;
+    const float *wbase = sd.w + (size_t)t * NG * 16 * sd.Co_pad + ((size_t)kk * sd.Co_pad + o0 + i) * 4;
+    f32x4 av[NG], bv[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        av[g] = *PS_GC(f32x4, wbase + (size_t)g * 16 * sd.Co_pad);
+        bv[g] = live ? *PS_GC(f32x4, src + 16 * g) * mv : zero;
+    }
+#pragma unroll
+    for (int g0 = 0; g0 < NG; g0 += 5) {
+        const f32x4 (&a5)[5] = *reinterpret_cast<const f32x4 (*)[5]>(&av[g0]);
+        const f32x4 (&b5)[5] = *reinterpret_cast<const f32x4 (*)[5]>(&bv[g0]);
+        mfma_chunk5(a5, b5, acc0, acc1);
+    }
+    return acc0 + acc1;
 }
 
-// grid (work items, ceil(F/16)); 4 waves = 4 output-channel tiles of one (stage, slot)
+// grid (work items + 4, ceil(F/16)); a work item = (stage, slot NA|NB, 16 output channels); its 4 waves take
+// the 4 taps of the slot and the partials are added in tap order (the order k_gemm uses)
 __global__ __launch_bounds__(256) void k_nbr(NbrArgs a)
 {
     if ((int)blockIdx.x >= a.nwork) {  // last 4 work items: the u_init gather, one wave per frame, 20 groups of 4
@@ -458,18 +459,24 @@ __global__ __launch_bounds__(256) void k_nbr(NbrArgs a)
             uinit_gather4(a.codes + (size_t)f * a.L, mA, a.uinit_w, a.uinit_b, a.ctx[f].q, a.H, a.W, lane);
         return;
     }
+    __shared__ __attribute__((aligned(16))) float sP[4][16][20];
     const NbrWork wk = a.work[blockIdx.x];
     const StageDesc sd = a.stages[wk.stage];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, kk = lane >> 4;
-    const int cot = wk.cog * 4 + wave;
-    if (cot * 16 >= sd.Co_pad) return;
-    const int o0 = cot * 16;
+    const int o0 = wk.cog * 16;
     const int f = blockIdx.y * 16 + i;
     const bool valid = f < a.F;
-    f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = acc0;
-    if (sd.NG == 10) nbr_taps<10>(sd, a, wk.half, o0, f, valid, i, kk, acc0, acc1);
-    else nbr_taps<5>(sd, a, wk.half, o0, f, valid, i, kk, acc0, acc1);
-    if (valid) *(f32x4 *)(a.nbr + (((size_t)wk.stage * 2 + wk.half) * a.F + f) * NBR_LD + o0 + kk * 4) = acc0 + acc1;
+    const int t = wk.half * 5 + wave;  // taps 0..3 (NA) or 5..8 (NB)
+    const f32x4 part = sd.NG == 10 ? nbr_tap<10>(sd, a, t, o0, f, valid, i, kk) : nbr_tap<5>(sd, a, t, o0, f, valid, i, kk);
+    *(f32x4 *)(&sP[wave][i][kk * 4]) = part;
+    __syncthreads();
+    if (wave == 0 && valid) {
+        const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+        f32x4 tot = zero;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) tot = tot + *(const f32x4 *)(&sP[w][i][kk * 4]);
+        *(f32x4 *)(a.nbr + (((size_t)wk.stage * 2 + wk.half) * a.F + f) * NBR_LD + o0 + kk * 4) = tot;
+    }
 }
 
 struct ChainArgs {
@@ -1000,7 +1007,7 @@ int build_stage_table(ps_pixelcnn *h)
         const int s = (int)st.size();
         if (has_nbr)
             for (int half = 0; half < 2; ++half)
-                for (int cog = 0; cog < (Co / 16 + 3) / 4; ++cog) work.push_back(NbrWork{s, half, cog});
+                for (int cog = 0; cog < Co / 16; ++cog) work.push_back(NbrWork{s, half, cog});
         // dense algorithmic work per frame of this stage (taps x 2*Co*Cin flops, fp32 weights once)
         const double taps_nbr = has_nbr ? 8.0 : 0.0, cin = NG * 16.0;
         h->flops_nbr += taps_nbr * 2.0 * Co * cin;
