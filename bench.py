@@ -211,12 +211,20 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nnodes=1 "
                              f"--nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port P bench.py --gpus {args.gpus} ...")
+    # PS_BENCH_DRYRUN_ONE_GPU=1: every rank uses cuda:0 and the gloo backend -- exercises the multi-rank control
+    # flow on a single-GPU box (the numbers of such a run mean nothing)
+    dry = os.environ.get("PS_BENCH_DRYRUN_ONE_GPU") == "1"
+    if dry:
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.distributed.init_process_group("nccl", device_id=device)
+        if dry:
+            torch.distributed.init_process_group("gloo")
+        else:
+            torch.distributed.init_process_group("nccl", device_id=device)
 
     V = args.views
     model = build_model(device)
@@ -233,7 +241,7 @@ def main():
     for _ in range(args.steps):
         out = run_step(model, d, world)
     barrier()
-    elapsed = D.max_over_ranks(time.perf_counter() - t0, device)
+    elapsed = D.max_over_ranks(time.perf_counter() - t0, None if dry else device)
 
     if rank == 0:
         frames = V * world * args.steps

@@ -29,8 +29,13 @@ def gather_frames(local, n_views=None):
     rank, w = world()
     if w == 1:
         return local if n_views is None else local[:n_views]
-    bufs = [torch.empty_like(local) for _ in range(w)]
-    dist.all_gather(bufs, local.contiguous())
+    staged = local.contiguous()
+    if staged.is_cuda and dist.get_backend() == "gloo":
+        staged = staged.cpu()  # gloo has no device all_gather: host staging (tests / single-GPU dry runs only)
+    bufs = [torch.empty_like(staged) for _ in range(w)]
+    dist.all_gather(bufs, staged)
+    if staged.device != local.device:
+        bufs = [b.to(local.device) for b in bufs]
     stacked = torch.stack(bufs, 1)                      # (V_local, W, ...): row v_local*W + r = view index
     out = stacked.reshape(-1, *local.shape[1:])
     return out if n_views is None else out[:n_views]
