@@ -23,6 +23,7 @@ UNITS = [
     ("host_order.cpp", []),
 ]
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
+COMMON += os.environ.get("PS_EXTRA_HIPCC_FLAGS", "").split()  # tuning builds, e.g. -DPS_CHAIN_TRACE_BUILD
 
 
 def _deps():

@@ -27,6 +27,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "ps_common.h"
@@ -62,20 +63,33 @@ enum { SLOT_NA = 0 /* taps 0..3 */, SLOT_C = 1 /* tap 4, the location itself */,
        SLOT_SKIP = 3 /* nin_skip 1x1 */ };
 
 // 5 channel groups (80 input channels) of one tap: all ten 16-byte operand loads are issued before the
-// 20 MFMAs; even groups accumulate into acc0, odd groups into acc1 (two independent chains).  Every
-// kernel goes through this function and walks taps / chunks in the same order, so the whole-grid
-// pass and the column steps produce identical bits.
-__device__ __forceinline__ void mfma_chunk5(const f32x4 (&av)[5], const f32x4 (&bv)[5], f32x4 &acc0, f32x4 &acc1)
+// 20 MFMAs; group j of the chunk accumulates into acc[j] (five independent chains, so consecutive MFMAs
+// never wait on each other).  v_mfma_f32_16x16x4_f32 is a chain of four fused multiply-adds in ascending k
+// (tools/mfma_semantics.hip: 0 mismatches in 2^20), so chain j of output o is, in order,
+//     for group g in (j, 5 + j, ...): for c in 0..3: for kk in 0..3: acc = fma(W[o][16g + 4kk + c], x[16g + 4kk + c], acc)
+// and the tap's value is chunk_total(acc).  Every kernel -- MFMA or VALU -- walks taps, chunks and chains in this
+// order, so the whole-grid pass and the column steps produce identical bits.
+struct Acc5 { f32x4 v[5]; };
+__device__ __forceinline__ Acc5 acc5_zero()
+{
+    const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+    return Acc5{{z, z, z, z, z}};
+}
+__device__ __forceinline__ void mfma_chunk5(const f32x4 (&av)[5], const f32x4 (&bv)[5], Acc5 &acc)
 {
 #pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        f32x4 &acc = (j & 1) ? acc1 : acc0;
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].x, bv[j].x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].y, bv[j].y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].z, bv[j].z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].w, bv[j].w, acc, 0, 0, 0);
-    }
+    for (int j = 0; j < 5; ++j) acc.v[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].x, bv[j].x, acc.v[j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) acc.v[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].y, bv[j].y, acc.v[j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) acc.v[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].z, bv[j].z, acc.v[j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) acc.v[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].w, bv[j].w, acc.v[j], 0, 0, 0);
 }
+// value of one tap from its five chains
+template <typename T>
+__device__ __forceinline__ T chain_total(const T &a0, const T &a1, const T &a2, const T &a3, const T &a4) { return (((a0 + a1) + a2) + a3) + a4; }
+__device__ __forceinline__ f32x4 chunk_total(const Acc5 &a) { return chain_total(a.v[0], a.v[1], a.v[2], a.v[3], a.v[4]); }
 
 // ==========================================================================================
 // whole-grid mode: items = (frame, location) pairs of the full grid
@@ -108,7 +122,7 @@ __global__ __launch_bounds__(64) void k_gemm(GemmArgs a)
             r = q / a.W;
             c = q - r * a.W;
         }
-        // slot value = taps of the slot added in order, each tap from fresh accumulators: P_t = acc0 + acc1
+        // slot value = taps of the slot added in order, each tap from fresh accumulators: P_t = chunk_total(acc)
         f32x4 tot = zero;
         for (int t = a.slot_first[slot]; t < a.slot_first[slot + 1]; ++t) {
             const GemmTap tp = a.tap[t];
@@ -121,7 +135,7 @@ __global__ __launch_bounds__(64) void k_gemm(GemmArgs a)
             }
             const bool live = mv != 0.0f;
             if (!__any(live)) continue;  // a masked tap is an exact zero: skipping it does not change the bits
-            f32x4 acc0 = zero, acc1 = zero;
+            Acc5 acc = acc5_zero();
             const float *wbase = tp.w + ((size_t)kk * a.Co_pad + o0 + i) * 4;
             int g = 0;
             for (; g + 5 <= ngroups; g += 5) {
@@ -131,17 +145,18 @@ __global__ __launch_bounds__(64) void k_gemm(GemmArgs a)
                     av[j] = *(const f32x4 *)(wbase + (size_t)(g + j) * 16 * a.Co_pad);
                     bv[j] = live ? *(const f32x4 *)(src + 16 * (g + j)) * mv : zero;
                 }
-                mfma_chunk5(av, bv, acc0, acc1);
+                mfma_chunk5(av, bv, acc);
             }
             for (; g < ngroups; ++g) {  // ragged channel counts of the generic lmconv entry point only
                 const f32x4 av = *(const f32x4 *)(wbase + (size_t)g * 16 * a.Co_pad);
                 const f32x4 bv = live ? *(const f32x4 *)(src + 16 * g) * mv : zero;
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc0, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc0, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc0, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc0, 0, 0, 0);
+                f32x4 &a0 = acc.v[0];
+                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, a0, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, a0, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, a0, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, a0, 0, 0, 0);
             }
-            tot = tot + (acc0 + acc1);
+            tot = tot + chunk_total(acc);
         }
         // D: row (output channel) = kk*4 + reg, col (item) = i
         if (valid)
@@ -155,8 +170,8 @@ __global__ __launch_bounds__(64) void k_gemm(GemmArgs a)
 // MFMA accumulator layout (lane (kk, i) of the wave owning output tile w holds channels 16w + 4kk .. +3 of
 // item i), so k_chain applies the post op directly on its accumulators with 16-byte slot / bias / cache
 // accesses.  The statistics of PONO are reduced in ONE association order everywhere: a group partial
-// ((y0 + y1) + y2) + y3, then the 20 partials added sequentially, group 0 first -- so column steps and
-// whole-grid passes agree bit for bit.
+// ((y0 + y1) + y2) + y3, then the 20 partials through the fixed tree of tree20_lanes / tree20_array -- so column
+// steps and whole-grid passes agree bit for bit.
 // ------------------------------------------------------------------------------------------
 constexpr int NGRP = NF / 4;  // 20
 
@@ -208,13 +223,33 @@ __device__ __forceinline__ f32x4 post_finish(const f32x4 &n, const f32x4 &g, con
     return n;
 }
 
-// sequential sum of the 20 group partials held by lanes 0..19 of a wave (whole-grid kernels)
-__device__ __forceinline__ float lanes20_sum(float part)
+// Sum of the 20 group partials of an item, in ONE association order everywhere: a balanced tree over the group
+// index (pairs, quads, octets, sixteen), groups 16..19 as their own tree, then row0 + row1.
+//   lanes form: lanes 0..19 of a wave hold the partials (lanes 20..31 are made 0); four DPP adds + two lane reads
+//   array form: the same tree written out (k_chain reads the partials of an item from LDS)
+template <int CTRL>
+__device__ __forceinline__ float dpp_xadd(float x)
 {
-    float tot = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(part), 0));
+    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, false);
+    return x + __int_as_float(moved);
+}
+__device__ __forceinline__ float tree20_lanes(float part, bool own)
+{
+    float x = own ? part : 0.0f;
+    x = dpp_xadd<0xB1>(x);    // quad_perm [1,0,3,2]: pairs
+    x = dpp_xadd<0x4E>(x);    // quad_perm [2,3,0,1]: quads
+    x = dpp_xadd<0x141>(x);   // row_half_mirror: octets
+    x = dpp_xadd<0x140>(x);   // row_mirror: the 16 groups of a row
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 0)) +
+           __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 16));
+}
+__device__ __forceinline__ float tree20_array(const float *p)
+{
+    float a[10];
 #pragma unroll
-    for (int g = 1; g < NGRP; ++g) tot = tot + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(part), g));
-    return tot;
+    for (int k = 0; k < 10; ++k) a[k] = p[2 * k] + p[2 * k + 1];
+    const float b0 = a[0] + a[1], b1 = a[2] + a[3], b2 = a[4] + a[5], b3 = a[6] + a[7], b4 = a[8] + a[9];
+    return ((b0 + b1) + (b2 + b3)) + b4;
 }
 
 // u_init on one-hot input as a gather, type-A mask (model.py:132), BEFORE norm_init, for channel group `grp`:
@@ -286,9 +321,9 @@ __global__ __launch_bounds__(256) void k_post_grid(PostArgs a)
         }
         if (KIND == POST_CONVIN && a.has_skip) skip = *(const f32x4 *)(P + SLOT_SKIP * ss) + *(const f32x4 *)(a.bias2 + c);
     }
-    const float mean = pono_mean(lanes20_sum(group_sum(y)));
+    const float mean = pono_mean(tree20_lanes(group_sum(y), own));
     const f32x4 d = y - mean;
-    const float inv = pono_inv(lanes20_sum(group_sumsq(d)));
+    const float inv = pono_inv(tree20_lanes(group_sumsq(d), own));
     if (!own) return;
     const f32x4 out = post_finish<KIND>(d * inv, g, skip, a.has_skip != 0, rin);
     if (KIND == POST_CONVIN) {
@@ -321,9 +356,9 @@ __global__ __launch_bounds__(256) void k_uinit_grid(UinitArgs a)
     for (int t = 0; t < 9; ++t) mA[t] = a.mask[((size_t)f * 9 + t) * a.L + q];
     f32x4 y = {0.0f, 0.0f, 0.0f, 0.0f};
     if (own) y = uinit_gather4(a.codes + (size_t)f * a.L, mA, a.w, a.bias, q, a.H, a.W, lane);
-    const float mean = pono_mean(lanes20_sum(group_sum(y)));   // norm_init
+    const float mean = pono_mean(tree20_lanes(group_sum(y), own));   // norm_init
     const f32x4 d = y - mean;
-    const float inv = pono_inv(lanes20_sum(group_sumsq(d)));
+    const float inv = pono_inv(tree20_lanes(group_sumsq(d), own));
     if (own) store_raw_celu4(a.Rout, a.Eout, (size_t)item, lane, d * inv);
 }
 
@@ -395,6 +430,9 @@ struct __attribute__((aligned(16))) StageDesc {
     // prologue of this stage = post op of the previous stage
     const float *pbias, *pbias2;
     float *outR, *outE, *outX;  // caches the prologue writes at the current location
+    // the centre-tap (+ nin_skip) weights again, laid out for k_chain1: [nstep][nchain][4]
+    const float *wv;
+    int nchain, nstep, pad0, pad1;
 };
 
 struct NbrWork { int stage, half, cog; };
@@ -428,7 +466,7 @@ __device__ __forceinline__ f32x4 nbr_tap(const StageDesc &sd, const NbrArgs &a, 
     }
     const bool live = mv != 0.0f;
     if (!__any(live)) return zero;
-    f32x4 acc0 = zero, acc1 = zero;
+    Acc5 acc = acc5_zero();
     const float *wbase = sd.w + (size_t)t * NG * 16 * sd.Co_pad + ((size_t)kk * sd.Co_pad + o0 + i) * 4;
     f32x4 av[NG], bv[NG];
 #pragma unroll
@@ -440,9 +478,9 @@ __device__ __forceinline__ f32x4 nbr_tap(const StageDesc &sd, const NbrArgs &a, 
     for (int g0 = 0; g0 < NG; g0 += 5) {
         const f32x4 (&a5)[5] = *reinterpret_cast<const f32x4 (*)[5]>(&av[g0]);
         const f32x4 (&b5)[5] = *reinterpret_cast<const f32x4 (*)[5]>(&bv[g0]);
-        mfma_chunk5(a5, b5, acc0, acc1);
+        mfma_chunk5(a5, b5, acc);
     }
-    return acc0 + acc1;
+    return chunk_total(acc);
 }
 
 // grid (work items + 4, ceil(F/16)); a work item = (stage, slot NA|NB, 16 output channels); its 4 waves take
@@ -481,6 +519,7 @@ __global__ __launch_bounds__(256) void k_nbr(NbrArgs a)
 
 struct ChainArgs {
     const StageDesc *stages;
+    const int *ctl1;          // k_chain1's per-stage control records (C1_CTL_DWORDS dwords each), read with scalar loads
     const float *nbr;
     const float *upre;        // [F][NF] from k_nbr
     CtxArgs cx;
@@ -499,6 +538,31 @@ struct ChainArgs {
     int ablate;                // tuning aid (PS_CHAIN_ABLATE): 1 no cache stores, 2 no slot prefetch, 4 no MFMA, 8 no post math
 };
 
+// categorical draw from logits / T by inverse CDF with one uniform (sample.py:60-66); lane l holds classes 8l..8l+7
+__device__ __forceinline__ int draw_code(const float (&lg)[8], float temperature, float u, int lane)
+{
+    float x[8], m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { x[k] = lg[k] / temperature; m = fmaxf(m, x[k]); }
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    float e[8], ls = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { e[k] = expf(x[k] - m); ls += e[k]; }
+    float incl = ls;  // inclusive scan of the per-lane sums (classes are lane-major)
+    for (int off = 1; off < 64; off <<= 1) {
+        const float tv = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += tv;
+    }
+    const float total = __shfl(incl, 63, 64);
+    const float target = u * total;
+    float run = incl - ls;
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { run += e[k]; cnt += run <= target ? 1 : 0; }  // classes whose cdf <= target
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+    return min(cnt, NCLS - 1);
+}
+
 // Workgroup barrier that only drains LDS traffic.  __syncthreads() also waits for every outstanding
 // global access (vmcnt(0)), which would serialise the weight / neighbour-slot prefetches of k_chain
 // against its two barriers per stage; the data exchanged between the waves here lives in LDS only.
@@ -508,8 +572,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 template <int NG>
 __device__ __forceinline__ f32x4 center_tile(const f32x4 *av, const float (*sIn)[SIN_LD], int i, int kk)
 {
-    const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
-    f32x4 acc0 = zero, acc1 = zero;
+    Acc5 acc = acc5_zero();
 #pragma unroll
     for (int g0 = 0; g0 < NG; g0 += 5) {
         f32x4 a5[5], b5[5];
@@ -518,9 +581,9 @@ __device__ __forceinline__ f32x4 center_tile(const f32x4 *av, const float (*sIn)
             a5[j] = av[g0 + j];
             b5[j] = *(const f32x4 *)(&sIn[i][16 * (g0 + j) + 4 * kk]);
         }
-        mfma_chunk5(a5, b5, acc0, acc1);
+        mfma_chunk5(a5, b5, acc);
     }
-    return acc0 + acc1;
+    return chunk_total(acc);
 }
 
 template <int NG>
@@ -585,18 +648,12 @@ __global__ __launch_bounds__(CHAIN_WAVES * 64) void k_chain(ChainArgs a)
         lds_barrier();
         f32x4 d = zero;
         if (pw) {
-            float tot = sRed[0][i][0];
-#pragma unroll
-            for (int g = 1; g < NGRP; ++g) tot = tot + sRed[0][i][g];
-            d = y - pono_mean(tot);
+            d = y - pono_mean(tree20_array(&sRed[0][i][0]));
             sRed[1][i][grp] = group_sumsq(d);
         }
         lds_barrier();
         if (pw) {
-            float tot = sRed[1][i][0];
-#pragma unroll
-            for (int g = 1; g < NGRP; ++g) tot = tot + sRed[1][i][g];
-            const f32x4 n = d * pono_inv(tot);
+            const f32x4 n = d * pono_inv(tree20_array(&sRed[1][i][0]));
             f32x4 out;
             if (kind == PRO_CONVIN) {
                 const bool hs = uni(sSt[nx].p_has_skip) != 0;
@@ -726,26 +783,8 @@ __global__ __launch_bounds__(CHAIN_WAVES * 64) void k_chain(ChainArgs a)
             if (a.forced) {
                 if (lane == 0) a.codes[loc] = a.forced[loc];
             } else {
-                float x[8], m = -INFINITY;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) { x[k] = lg[k] / a.temperature; m = fmaxf(m, x[k]); }
-                for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-                float e[8], ls = 0.0f;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) { e[k] = expf(x[k] - m); ls += e[k]; }
-                float incl = ls;  // inclusive scan of the per-lane sums (classes are lane-major)
-                for (int off = 1; off < 64; off <<= 1) {
-                    const float t = __shfl_up(incl, off, 64);
-                    if (lane >= off) incl += t;
-                }
-                const float total = __shfl(incl, 63, 64);
-                const float target = a.uniforms[loc] * total;
-                float run = incl - ls;
-                int cnt = 0;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) { run += e[k]; cnt += run <= target ? 1 : 0; }  // classes whose cdf <= target
-                for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
-                if (lane == 0) a.codes[loc] = min(cnt, NCLS - 1);
+                const int code = draw_code(lg, a.temperature, a.uniforms[loc], lane);
+                if (lane == 0) a.codes[loc] = code;
             }
         }
     }
@@ -756,6 +795,409 @@ __global__ __launch_bounds__(CHAIN_WAVES * 64) void k_chain(ChainArgs a)
             if (lane < 32) ctx_fill(a.cx, pf, step + 1, lane);
         }
     }
+}
+
+// ==========================================================================================
+// k_chain1: the same 33-stage chain on the vector ALU, one workgroup per FPW frames.
+// With few frames per GPU the MFMA chain fills 1/16 of one tile per frame and one CU per 16 frames; here
+// every frame gets its own CU (fp32 FMA on the VALU has the same peak as fp32 MFMA on gfx950) and nothing
+// is padded.  Thread t of a stage owns ONE chain (output o, accumulator j) of mfma_chunk5's order --
+// 16 or 32 dependent v_fma_f32 -- with its weights in registers (layout [step][chain][4], one coalesced
+// 16-byte load per step, fetched a full stage ahead) and the input read from LDS as broadcasts.  The five
+// chain values per output meet in LDS; the frame's post op (PONO, gate / skip / residual, concat-ELU) is
+// done by ONE wave with DPP-free lane reads, exactly like k_post_grid.  Two LDS-only barriers per stage.
+// ==========================================================================================
+constexpr int C1_THREADS = 1024;
+constexpr int C1_MAXCHAIN = 800;   // 5 x 160, or 5 x 80 + 5 x 80 (conv_input + nin_skip)
+constexpr int SX_LD = 2 * NF;
+constexpr int C1_OUT_STEPS = 12;
+constexpr int VALU_CHAIN_MAX_FRAMES = 1024;  // above this the 16-frame MFMA tiles win (256 CUs x 4 rounds)   // nin_out: thread (o, part): part 0 = chains 0..2, part 1 = chains 3..4
+
+template <int NGL, int FPW>
+__device__ __forceinline__ void valu_chain(const f32x4 *w /*4 * NGL steps*/, const float *xbase, int j, float (&acc)[FPW])
+{
+#pragma unroll
+    for (int f = 0; f < FPW; ++f) acc[f] = 0.0f;
+#pragma unroll
+    for (int gl = 0; gl < NGL; ++gl) {
+        const int g = 5 * gl + j;
+        f32x4 xv[FPW][4];
+#pragma unroll
+        for (int f = 0; f < FPW; ++f)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) xv[f][kk] = *(const f32x4 *)(xbase + f * SX_LD + 16 * g + 4 * kk);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const f32x4 wv = w[gl * 4 + c];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int f = 0; f < FPW; ++f) acc[f] = __builtin_fmaf(wv[kk], xv[f][kk][c], acc[f]);
+        }
+    }
+}
+
+#ifdef PS_WEIGHTS_NT
+#define PS_WLOAD(p) __builtin_nontemporal_load(PS_GC(f32x4, p))
+#else
+#define PS_WLOAD(p) (*PS_GC(f32x4, p))
+#endif
+// Always EXACTLY eight loads, whatever the stage and thread: s_waitcnt counts are static, so a path that issued
+// fewer loads than another would force the compiler to wait for everything (vmcnt(0)) before the chain that
+// consumes the PREVIOUS fetch -- i.e. to wait for the prefetch it has just issued.  Four-step stages and threads
+// beyond the last chain re-read valid addresses instead.
+__device__ __forceinline__ void load_chain_weights(const float *wv, int nchain, int nstep, int t, f32x4 (&w)[8])
+{
+    const float *base = wv + (size_t)min(t, nchain - 1) * 4;
+    const size_t stride = (size_t)nchain * 4;
+    const float *hi = nstep == 8 ? base + 4 * stride : base;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) w[st] = PS_WLOAD(base + st * stride);
+#pragma unroll
+    for (int st = 0; st < 4; ++st) w[4 + st] = PS_WLOAD(hi + st * stride);
+}
+
+// Control record of one stage for k_chain1, C1_CTL_DWORDS dwords in constant memory: record 0 describes the u0
+// post op (norm_init), record 1 + s stage s and the post op that follows it, record NST the nin_out chains.
+// Every role fetches its fields with scalar loads one stage ahead, so no wave ever waits on a descriptor.
+constexpr int C1_CTL_DWORDS = 24;
+enum { CTL_CO = 0, CTL_NCHAIN = 1, CTL_NG = 2, CTL_NSTEP = 3, CTL_WV = 4, CTL_BIAS = 6, CTL_KIND = 8, CTL_HAS_SKIP = 9,
+       CTL_IN_FORM = 10, CTL_SAVE_SLOT = 11, CTL_SKIP_SLOT = 12, CTL_BIAS2 = 14, CTL_R = 16, CTL_E = 18, CTL_X = 20 };
+typedef const __attribute__((address_space(4))) int *CtlInt;
+typedef const __attribute__((address_space(4))) unsigned long long *CtlU64;
+__device__ __forceinline__ int ctl_i(const int *ctl, int rec, int field) { return ((CtlInt)ctl)[rec * C1_CTL_DWORDS + field]; }
+template <typename T>
+__device__ __forceinline__ T *ctl_p(const int *ctl, int rec, int field)
+{
+    return (T *)((CtlU64)ctl)[(rec * C1_CTL_DWORDS + field) >> 1];
+}
+struct ChainCtl { int Co, nchain, NG, nstep; const float *wv; };
+struct PostCtl { int Co, kind, has_skip, in_form, save_slot, skip_slot; const float *bias, *bias2; };
+struct StoreCtl { int kind; float *R, *E, *X; };
+__device__ __forceinline__ ChainCtl load_chain_ctl(const int *ctl, int rec)
+{
+    return ChainCtl{ctl_i(ctl, rec, CTL_CO), ctl_i(ctl, rec, CTL_NCHAIN), ctl_i(ctl, rec, CTL_NG), ctl_i(ctl, rec, CTL_NSTEP),
+                    ctl_p<const float>(ctl, rec, CTL_WV)};
+}
+__device__ __forceinline__ PostCtl load_post_ctl(const int *ctl, int rec)
+{
+    return PostCtl{ctl_i(ctl, rec, CTL_CO), ctl_i(ctl, rec, CTL_KIND), ctl_i(ctl, rec, CTL_HAS_SKIP), ctl_i(ctl, rec, CTL_IN_FORM),
+                   ctl_i(ctl, rec, CTL_SAVE_SLOT), ctl_i(ctl, rec, CTL_SKIP_SLOT), ctl_p<const float>(ctl, rec, CTL_BIAS),
+                   ctl_p<const float>(ctl, rec, CTL_BIAS2)};
+}
+__device__ __forceinline__ StoreCtl load_store_ctl(const int *ctl, int rec)
+{
+    return StoreCtl{ctl_i(ctl, rec, CTL_KIND), ctl_p<float>(ctl, rec, CTL_R), ctl_p<float>(ctl, rec, CTL_E), ctl_p<float>(ctl, rec, CTL_X)};
+}
+
+template <int FPW>
+__global__ __launch_bounds__(C1_THREADS) void k_chain1(ChainArgs a)
+{
+    static_assert(FPW >= 1 && FPW <= 2, "waves 0..12 run the chains, wave 13 stores, the last FPW waves do the post ops");
+    __shared__ __attribute__((aligned(16))) float sX[FPW][SX_LD];        // input of the centre taps
+    __shared__ __attribute__((aligned(16))) float sSkip[FPW][SX_LD];     // concat_elu(u_k) feeding nin_skip
+    __shared__ __attribute__((aligned(16))) float sP[FPW][C1_MAXCHAIN];  // chain values of the stage
+    __shared__ __attribute__((aligned(16))) float sU[8][FPW][NF];        // u0..u7 of this location
+    __shared__ __attribute__((aligned(16))) float sOut[FPW][3][NF];      // (u, elu(u), elu(-u)) on their way to the caches
+    __shared__ __attribute__((aligned(16))) float sPL[FPW][5][NCLS];     // chain values of nin_out
+    const int t = threadIdx.x, wave = uni(t >> 6), lane = t & 63;
+    const int f0 = blockIdx.x * FPW;
+    const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+    // Roles, each in its own wave-uniform branch (so their registers do not add up):
+    //   waves 0..12         one chain per thread and stage
+    //   wave 13             cache stores: lanes 20f..20f+19 carry frame f's finished values from LDS to R / E / X
+    //   waves 16-FPW..15    post op of one frame each, lanes 0..19 = its 20 channel groups
+    constexpr int NW = C1_THREADS / 64, STORE_WAVE = 13;
+    const int pf = wave - (NW - FPW);  // frame slot of a post wave, negative otherwise
+    const bool pwave = pf >= 0, swave = wave == STORE_WAVE;
+    const int slot = pwave ? pf : lane / NGRP;  // frame slot this lane serves as post / store lane
+    const int grp = pwave ? lane : lane - slot * NGRP;
+    const int pfr = f0 + slot;
+    const bool own = (pwave ? lane < NGRP : (swave && slot < FPW)) && pfr < a.F;
+    const int c4 = own ? 4 * grp : 0;
+    const int pq = own ? a.cx.ctx[pfr].q : 0;
+    const size_t off80 = ((size_t)(own ? pfr : 0) * a.L + pq) * NF, off160 = 2 * off80;
+    // chain role: 80-output stages hold chains t = j * 80 + o (then the nin_skip chains), 160-output ones j * 160 + o
+    const int q80 = t / NF, j160 = t / (2 * NF);
+    const int j80 = q80 >= 5 ? q80 - 5 : q80;
+    if (t < FPW * SX_LD) { (&sX[0][0])[t] = 0.0f; (&sSkip[0][0])[t] = 0.0f; }  // absent frames feed zeros
+    __syncthreads();
+
+#ifdef PS_CHAIN_TRACE_BUILD  // tuning builds only: the stamps' stores perturb the waitcnt placement
+#define PS_TRACE1(who, slot) do { if (a.trace && blockIdx.x == 0 && (who)) a.trace[s * 10 + (slot)] = clock64(); } while (0)
+#else
+#define PS_TRACE1(who, slot) do { } while (0)
+#endif
+    f32x4 wo[C1_OUT_STEPS];
+    const int opart = t >> 9;  // nin_out role: thread (o = t & 511, part): part 0 = chains 0..2, part 1 = chains 3..4
+    auto load_out_weights = [&]() {
+        const float *wo_base = ctl_p<const float>(a.ctl1, NST, CTL_WV) + (size_t)t * 4;
+#pragma unroll
+        for (int st = 0; st < 8; ++st) wo[st] = *PS_GC(f32x4, wo_base + (size_t)st * C1_THREADS * 4);
+        if (opart == 0) {
+#pragma unroll
+            for (int st = 8; st < C1_OUT_STEPS; ++st) wo[st] = *PS_GC(f32x4, wo_base + (size_t)st * C1_THREADS * 4);
+        }
+    };
+
+    // nin_out(elu(u)) (model.py:153); called at the end of every role's branch, so wo never crosses a join
+    auto nin_out_chains = [&]() {
+        const int o = t & (NCLS - 1);
+#pragma unroll
+        for (int cj = 0; cj < 3; ++cj) {
+            if (opart == 1 && cj == 2) break;
+            const int j = opart * 3 + cj;
+            float acc[FPW];
+            valu_chain<1, FPW>(&wo[cj * 4], &sX[0][0], j, acc);
+#pragma unroll
+            for (int f = 0; f < FPW; ++f) sPL[f][j][o] = acc[f];
+        }
+        lds_barrier();
+    };
+
+    if (pwave) {
+        // ================= post waves: one frame each, two barriers per stage =================
+        const float *nbr_f = a.nbr + (size_t)(own ? pfr : 0) * NBR_LD + c4;
+        const size_t nbr_half = (size_t)a.F * NBR_LD, nbr_stage = 2 * nbr_half;
+        f32x4 ucur = zero;
+        // bias and neighbour-tap slots of a stage's post op: y = ((bias + NA) + centre) + NB; fetched one stage ahead
+        struct Ops { f32x4 b, na, nb, bg, nag, nbg, b2; };
+        // (always exactly seven loads from valid addresses, in every lane: static s_waitcnt counts -- see
+        // load_chain_weights; kinds without a gate half / skip re-read the main operands)
+        auto load_ops = [&](int s, const PostCtl &c, Ops &o) {
+            const float *nb = nbr_f + (size_t)s * nbr_stage;
+            const int gofs = c.kind == PRO_GATE ? NF : 0;
+            const float *b2 = c.has_skip ? c.bias2 : c.bias;
+            o.b = *PS_GC(f32x4, c.bias + c4);
+            o.na = *PS_GC(f32x4, nb);
+            o.nb = *PS_GC(f32x4, nb + nbr_half);
+            o.bg = *PS_GC(f32x4, c.bias + gofs + c4);
+            o.nag = *PS_GC(f32x4, nb + gofs);
+            o.nbg = *PS_GC(f32x4, nb + nbr_half + gofs);
+            o.b2 = *PS_GC(f32x4, b2 + c4);
+        };
+        // PONO + finish + hand-off to the next stage; then the input of that stage's nin_skip, concat_elu(u_k) of a
+        // node this wave saved earlier
+        auto post_and_emit = [&](const f32x4 &y, const f32x4 &g, const f32x4 &skip, const PostCtl &c) {
+            const float mean = pono_mean(tree20_lanes(group_sum(y), own));
+            const f32x4 d = y - mean;
+            const float inv = pono_inv(tree20_lanes(group_sumsq(d), own));
+            if (!own) return;
+            const f32x4 n = d * inv;
+            f32x4 out;
+            if (c.kind == PRO_CONVIN) out = post_finish<POST_CONVIN>(n, zero, skip, c.has_skip != 0, zero);
+            else if (c.kind == PRO_GATE) out = post_finish<POST_GATE>(n, g, zero, false, ucur);
+            else out = n;  // PRO_DIL, PRO_UINIT (norm_init)
+            f32x4 ep, en;
+            celu_pair4(out, ep, en);
+            float *x = &sX[pf][c4];
+            if (c.in_form == IN_CELU) { *(f32x4 *)x = ep; *(f32x4 *)(x + NF) = en; }
+            else if (c.in_form == IN_RAW) *(f32x4 *)x = out;
+            else *(f32x4 *)x = ep;
+            *(f32x4 *)(&sOut[pf][1][c4]) = ep;
+            *(f32x4 *)(&sOut[pf][2][c4]) = en;
+            if (c.kind != PRO_CONVIN) {
+                *(f32x4 *)(&sOut[pf][0][c4]) = out;
+                ucur = out;
+                if (c.save_slot >= 0) *(f32x4 *)(&sU[c.save_slot][pf][c4]) = out;
+            }
+            if (c.skip_slot >= 0) {
+                f32x4 sp, sn;
+                celu_pair4(*(const f32x4 *)(&sU[c.skip_slot][pf][c4]), sp, sn);
+                *(f32x4 *)(&sSkip[pf][c4]) = sp;
+                *(f32x4 *)(&sSkip[pf][NF + c4]) = sn;
+            }
+        };
+        PostCtl cur = load_post_ctl(a.ctl1, 0), nxt = load_post_ctl(a.ctl1, 1), nn = load_post_ctl(a.ctl1, 2);
+        auto post_stage = [&](int s, const Ops &ocur, Ops &onxt) {
+            cur = nxt;                                              // record 1 + s
+            nxt = nn;                                               // record 2 + s, requested a stage ago
+            if (s + 2 < NST - 1) nn = load_post_ctl(a.ctl1, 3 + s);
+            PS_TRACE1(t == C1_THREADS - 64, 0);
+            // operands of the NEXT post op, issued while this wave waits for the chains: the vector-memory queue is
+            // empty now, whereas after the barrier the chain waves fill it with the next stage's weights and any
+            // load issued behind them would stall this wave (the critical path) for the whole burst
+            if (s + 1 < NST - 1) load_ops(s + 1, nxt, onxt);
+            lds_barrier();   // the chains of this stage are in sP
+            PS_TRACE1(t == C1_THREADS - 64, 1);
+            const int Co = cur.Co;
+            f32x4 y = zero, g = zero, skip = zero;
+            if (own) {
+                const float *P = &sP[pf][c4];
+                y = slot_sum4(ocur.b, ocur.na, chain_total(*(const f32x4 *)P, *(const f32x4 *)(P + Co), *(const f32x4 *)(P + 2 * Co),
+                                                           *(const f32x4 *)(P + 3 * Co), *(const f32x4 *)(P + 4 * Co)), ocur.nb);
+                if (cur.kind == PRO_GATE) {
+                    const float *G = P + NF;
+                    g = slot_sum4(ocur.bg, ocur.nag, chain_total(*(const f32x4 *)G, *(const f32x4 *)(G + Co), *(const f32x4 *)(G + 2 * Co),
+                                                                 *(const f32x4 *)(G + 3 * Co), *(const f32x4 *)(G + 4 * Co)), ocur.nbg);
+                }
+                if (cur.has_skip) {
+                    const float *S = P + 5 * Co;
+                    skip = chain_total(*(const f32x4 *)S, *(const f32x4 *)(S + NF), *(const f32x4 *)(S + 2 * NF),
+                                       *(const f32x4 *)(S + 3 * NF), *(const f32x4 *)(S + 4 * NF)) + ocur.b2;
+                }
+            }
+            PS_TRACE1(t == C1_THREADS - 64 && y.x != 12345.0f, 2);
+            post_and_emit(y, g, skip, cur);
+            PS_TRACE1(t == C1_THREADS - 64, 3);
+            lds_barrier();
+            PS_TRACE1(t == C1_THREADS - 64, 4);
+        };
+        Ops oA{zero, zero, zero, zero, zero, zero, zero}, oB = oA;
+        load_ops(0, nxt, oA);
+        {   // u0 = norm_init(u_init) from k_nbr's gather
+            f32x4 y = zero;
+            if (own) y = *PS_GC(f32x4, a.upre + (size_t)pfr * NF + c4);
+            post_and_emit(y, zero, zero, cur);
+            lds_barrier();
+        }
+        for (int s = 0; s < NST - 3; s += 2) {
+            post_stage(s, oA, oB);
+            post_stage(s + 1, oB, oA);
+        }
+        post_stage(NST - 3, oA, oB);
+        load_out_weights();  // (peeled: keeps these 48 registers out of the loop)
+        post_stage(NST - 2, oB, oA);
+        nin_out_chains();
+    } else if (swave) {
+        // ================= store wave: finished values LDS -> caches, off everybody's critical path =================
+        auto store_stage = [&](const StoreCtl &c) {  // what the post op of the record produced
+            if (!own) return;
+            const f32x4 ep = *(const f32x4 *)(&sOut[slot][1][c4]), en = *(const f32x4 *)(&sOut[slot][2][c4]);
+            if (c.kind == PRO_CONVIN) {
+                *PS_G(f32x4, c.X + off160 + c4) = ep;
+                *PS_G(f32x4, c.X + off160 + NF + c4) = en;
+            } else {
+                const f32x4 out = *(const f32x4 *)(&sOut[slot][0][c4]);
+                *PS_G(f32x4, c.R + off80 + c4) = out;
+                *PS_G(f32x4, c.E + off160 + c4) = ep;
+                *PS_G(f32x4, c.E + off160 + NF + c4) = en;
+            }
+        };
+        StoreCtl sc = load_store_ctl(a.ctl1, 0);
+        lds_barrier();
+        store_stage(sc);
+        for (int s = 0; s < NST - 2; ++s) {
+            sc = load_store_ctl(a.ctl1, 1 + s);
+            lds_barrier();   // (LDS reads of store_stage are complete: lds_barrier waits lgkmcnt(0) first)
+            lds_barrier();
+            store_stage(sc);
+        }
+        sc = load_store_ctl(a.ctl1, NST - 1);
+        load_out_weights();
+        lds_barrier();
+        lds_barrier();
+        store_stage(sc);
+        nin_out_chains();
+    } else {
+        // ================= chain waves: one chain per thread and stage =================
+        f32x4 wA[8], wB[8];
+        ChainCtl cc = load_chain_ctl(a.ctl1, 1), cn = load_chain_ctl(a.ctl1, 2), cnn = cn;
+        auto chain_stage = [&](int s, const f32x4 (&wcur)[8], f32x4 (&wnxt)[8], auto last) {
+            PS_TRACE1(t == 0, 5);
+            if (t < cc.nchain) {
+                const bool main = cc.Co == 2 * NF || q80 < 5;
+                const int j = cc.Co == 2 * NF ? j160 : j80;
+                const float *xb = main ? &sX[0][0] : &sSkip[0][0];
+                float acc[FPW];
+                if (cc.NG == 10) valu_chain<2, FPW>(wcur, xb, j, acc);
+                else valu_chain<1, FPW>(wcur, xb, j, acc);
+#pragma unroll
+                for (int f = 0; f < FPW; ++f) sP[f][t] = acc[f];
+            }
+            if (last) load_out_weights();
+            PS_TRACE1(t == 0 && sP[0][0] != 12345.0f, 6);
+            lds_barrier();
+            PS_TRACE1(t == 0, 7);
+            // the record two stages ahead: a scalar load shares lgkmcnt with the LDS reads of the chain and returns
+            // out of order, so it is issued here, where this wave only waits for the post op anyway
+            if (!last) cnn = load_chain_ctl(a.ctl1, 3 + s);  // (record NST at the end: rotated in, never used as a stage)
+            // Weights of the next stage.  The vector-memory queue is shallow: issuing these 13 x 8 KB takes the CU
+            // ~1700 cycles and blocks the issuing wave, so it happens here, under the post op, not ahead of the chain.
+            if (!last) load_chain_weights(cn.wv, cn.nchain, cn.nstep, t, wnxt);
+            lds_barrier();
+            PS_TRACE1(t == 0, 8);
+            cc = cn;
+            cn = cnn;
+        };
+        load_chain_weights(cc.wv, cc.nchain, cc.nstep, t, wA);
+        lds_barrier();
+        for (int s = 0; s < NST - 3; s += 2) {
+            chain_stage(s, wA, wB, std::false_type{});
+            chain_stage(s + 1, wB, wA, std::false_type{});
+        }
+        chain_stage(NST - 3, wA, wB, std::false_type{});
+        chain_stage(NST - 2, wB, wA, std::true_type{});
+        nin_out_chains();
+    }
+#undef PS_TRACE1
+
+
+    // ---- end of the order position: logits, categorical draw (sample.py:60-66), next context
+    const bool pvalid = pwave && pfr < a.F;
+    if (pvalid) {
+        const int f = pfr;
+        const int fq = uni(a.cx.ctx[f].q);
+        const size_t loc = (size_t)f * a.L + fq;
+        float lg[8];
+        {
+            const float *Lp = &sPL[pf][0][lane * 8];
+            const f32x4 lo = chain_total(*(const f32x4 *)Lp, *(const f32x4 *)(Lp + NCLS), *(const f32x4 *)(Lp + 2 * NCLS),
+                                         *(const f32x4 *)(Lp + 3 * NCLS), *(const f32x4 *)(Lp + 4 * NCLS));
+            const f32x4 hi = chain_total(*(const f32x4 *)(Lp + 4), *(const f32x4 *)(Lp + NCLS + 4), *(const f32x4 *)(Lp + 2 * NCLS + 4),
+                                         *(const f32x4 *)(Lp + 3 * NCLS + 4), *(const f32x4 *)(Lp + 4 * NCLS + 4));
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { lg[k] = lo[k] + a.out_b[lane * 8 + k]; lg[4 + k] = hi[k] + a.out_b[lane * 8 + 4 + k]; }
+        }
+        if (a.out_logits) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a.out_logits[loc * NCLS + lane * 8 + k] = lg[k];
+        }
+        if (a.step_logits) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a.step_logits[(size_t)f * NCLS + lane * 8 + k] = lg[k];
+        }
+        if (a.codes && a.region[loc]) {
+            if (a.forced) {
+                if (lane == 0) a.codes[loc] = a.forced[loc];
+            } else {
+                const int code = draw_code(lg, a.temperature, a.uniforms[loc], lane);
+                if (lane == 0) a.codes[loc] = code;
+            }
+        }
+    }
+    if (a.advance) {
+        __syncthreads();  // every wave read its ctx[f].q above / at kernel start; the draws are done
+        if (pvalid && lane < 32) ctx_fill(a.cx, pfr, a.cx.ctx[pfr].step + 1, lane);
+    }
+}
+
+// repack the centre tap (+ nin_skip) of a stage for k_chain1: out[step][chain][4]
+__global__ void k_pack_valu(const float *wc, const float *wskip, int Co, int nchain, int nstep, float *out)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nstep * nchain * 4) return;
+    const int kk = idx & 3, t = (idx >> 2) % nchain, st = (idx >> 2) / nchain;
+    const int gl = st >> 2, c = st & 3;
+    const bool main = t < 5 * Co;
+    const int t2 = main ? t : t - 5 * Co, n = main ? Co : NF;
+    const int j = t2 / n, o = t2 - j * n;
+    const int ch = 16 * (5 * gl + j) + 4 * kk + c;
+    const float *w = main ? wc : wskip;
+    out[idx] = w[((size_t)(ch >> 2) * n + o) * 4 + (ch & 3)];
+}
+
+// nin_out for k_chain1: out[step 0..11][thread 0..1023][4]; thread (o = t & 511, part = t >> 9)
+__global__ void k_pack_valu_out(const float *wo /*[20][512][4]*/, float *out)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= C1_OUT_STEPS * C1_THREADS * 4) return;
+    const int kk = idx & 3, t = (idx >> 2) & (C1_THREADS - 1), st = (idx >> 2) / C1_THREADS;
+    const int o = t & (NCLS - 1), part = t >> 9;
+    const int cj = st >> 2, c = st & 3;
+    if (part == 1 && cj == 2) { out[idx] = 0.0f; return; }
+    const int ch = 16 * (part * 3 + cj) + 4 * kk + c;
+    out[idx] = wo[((size_t)(ch >> 2) * NCLS + o) * 4 + (ch & 3)];
 }
 
 __global__ void k_mask_codes(int32_t *codes, const uint8_t *region, size_t n)
@@ -857,6 +1299,7 @@ struct ps_pixelcnn {
     float *col_logits = nullptr;
     StepCtx *ctx = nullptr;
     StageDesc *stages = nullptr;    // device copy of the 33-stage chain description
+    int *ctl1 = nullptr;            // the same for k_chain1 (scalar-load records)
     NbrWork *work = nullptr;
     int nwork = 0;
     hipStream_t stream = nullptr;   // internal stream for graph capture/replay
@@ -864,6 +1307,7 @@ struct ps_pixelcnn {
     hipGraph_t graph = nullptr;          // step graph of the last ar_run (kept alive until replaced)
     hipGraphExec_t graph_exec = nullptr;
     bool use_graph = true;
+    int chain_kernel = 0;  // 0 = by frame count, 1 = k_chain1 (VALU, one CU per frame), 2 = k_chain (MFMA, 16 frames per CU); PS_CHAIN_KERNEL
     // bench.py profiling aid (ps_pixelcnn_time_column_step): event pair around every launch, by kernel tag
     struct ProfRec { int tag; hipEvent_t e0, e1; };
     std::vector<ProfRec> *prof = nullptr;
@@ -1035,6 +1479,45 @@ int build_stage_table(ps_pixelcnn *h)
     gated(11); gated(12); gated(13);
     push(h->out_w, nullptr, nullptr, 0, 5, NCLS, 1, 1, 0, 0, IN_ELU, -1);  // nin_out(elu(u)), prologue = last gate
     if ((int)st.size() != NST) return ps::fail(PS_ERR_STATE, "stage table has %d entries, expected %d", (int)st.size(), NST);
+    for (int k = 0; k < NST; ++k) {  // the centre taps again in k_chain1's [step][chain][4] layout
+        StageDesc &d = st[k];
+        float *wv = nullptr;
+        if (k == NST - 1) {
+            const int n = C1_OUT_STEPS * C1_THREADS * 4;
+            if (int rc = dev_alloc(h, &wv, (size_t)n)) return rc;
+            hipLaunchKernelGGL(k_pack_valu_out, dim3((n + 255) / 256), dim3(256), 0, 0, d.w, wv);
+            d.nchain = C1_THREADS; d.nstep = C1_OUT_STEPS;
+        } else {
+            d.nchain = 5 * d.Co_pad + (d.w_skip ? 5 * NF : 0);
+            d.nstep = 4 * (d.NG / 5);
+            const int n = d.nstep * d.nchain * 4;
+            if (int rc = dev_alloc(h, &wv, (size_t)n)) return rc;
+            hipLaunchKernelGGL(k_pack_valu, dim3((n + 255) / 256), dim3(256), 0, 0,
+                               d.w + (size_t)d.center_tap * d.NG * 16 * d.Co_pad, d.w_skip, d.Co_pad, d.nchain, d.nstep, wv);
+        }
+        d.wv = wv;
+    }
+    PS_HIP_CHECK(hipDeviceSynchronize());
+    {   // k_chain1's control records
+        std::vector<int> ctl((size_t)(NST + 1) * C1_CTL_DWORDS, 0);
+        auto put_p = [&](int rec, int field, const void *ptr) { memcpy(&ctl[(size_t)rec * C1_CTL_DWORDS + field], &ptr, 8); };
+        auto put_post = [&](int rec, const StageDesc &nx) {  // the post op feeding stage `nx`
+            int *c = &ctl[(size_t)rec * C1_CTL_DWORDS];
+            c[CTL_KIND] = nx.pro; c[CTL_HAS_SKIP] = nx.pro == PRO_CONVIN && nx.p_has_skip; c[CTL_IN_FORM] = nx.in_form;
+            c[CTL_SAVE_SLOT] = nx.save_slot; c[CTL_SKIP_SLOT] = nx.skip_slot;
+            put_p(rec, CTL_BIAS, nx.pbias); put_p(rec, CTL_BIAS2, nx.pbias2);
+            put_p(rec, CTL_R, nx.outR); put_p(rec, CTL_E, nx.outE); put_p(rec, CTL_X, nx.outX);
+        };
+        put_post(0, st[0]);
+        for (int k = 0; k < NST; ++k) {
+            int *c = &ctl[(size_t)(1 + k) * C1_CTL_DWORDS];
+            c[CTL_CO] = st[k].Co_pad; c[CTL_NCHAIN] = st[k].nchain; c[CTL_NG] = st[k].NG; c[CTL_NSTEP] = st[k].nstep;
+            put_p(1 + k, CTL_WV, st[k].wv);
+            if (k + 1 < NST) put_post(1 + k, st[k + 1]);
+        }
+        if (int rc = dev_alloc(h, &h->ctl1, ctl.size())) return rc;
+        PS_HIP_CHECK(hipMemcpy(h->ctl1, ctl.data(), ctl.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
     if (int rc = dev_alloc(h, &h->stages, st.size())) return rc;
     PS_HIP_CHECK(hipMemcpy(h->stages, st.data(), st.size() * sizeof(StageDesc), hipMemcpyHostToDevice));
     if (int rc = dev_alloc(h, &h->work, work.size())) return rc;
@@ -1049,11 +1532,16 @@ void run_column(ps_pixelcnn *h, int F, const int32_t *codes, ChainArgs ca, hipSt
 {
     NbrArgs na{h->stages, h->work, h->ctx, h->nbr, h->upre, codes, h->uinit_w, h->uinit_b, h->nwork, h->H, h->W, h->L, F};
     const int tiles = (F + 15) / 16;
-    timed(h, st, TAG_NBR, [&]() { hipLaunchKernelGGL(k_nbr, dim3(h->nwork + 4, tiles), dim3(256), 0, st, na); });
-    ca.stages = h->stages; ca.nbr = h->nbr; ca.upre = h->upre;
+    if (!(h->prof && getenv("PS_PROF_SKIP_NBR")))  // tuning aid: time the chain alone (its weights then stay in L2)
+        timed(h, st, TAG_NBR, [&]() { hipLaunchKernelGGL(k_nbr, dim3(h->nwork + 4, tiles), dim3(256), 0, st, na); });
+    ca.stages = h->stages; ca.ctl1 = h->ctl1; ca.nbr = h->nbr; ca.upre = h->upre;
     ca.out_b = h->out_b;
     ca.H = h->H; ca.W = h->W; ca.L = h->L; ca.F = F;
-    timed(h, st, TAG_CHAIN, [&]() { hipLaunchKernelGGL(k_chain, dim3(tiles), dim3(CHAIN_WAVES * 64), 0, st, ca); });
+    // few frames: one CU per frame on the vector ALU; many: 16-frame MFMA tiles (same bits either way)
+    if (h->chain_kernel == 1 || (h->chain_kernel == 0 && F <= VALU_CHAIN_MAX_FRAMES))
+        timed(h, st, TAG_CHAIN, [&]() { hipLaunchKernelGGL(k_chain1<1>, dim3(F), dim3(C1_THREADS), 0, st, ca); });
+    else
+        timed(h, st, TAG_CHAIN, [&]() { hipLaunchKernelGGL(k_chain, dim3(tiles), dim3(CHAIN_WAVES * 64), 0, st, ca); });
 }
 
 CtxArgs make_ctx_args(ps_pixelcnn *h, const int32_t *order, const Masks &m, int F)
@@ -1089,6 +1577,7 @@ int ps_pixelcnn_create(const float *const *params, int n_params, int H, int W, i
     // caller's stream by default; PS_AR_GRAPH=1 replays it as a hipGraph on a stream owned by the handle instead.
     const char *env = getenv("PS_AR_GRAPH");
     h->use_graph = env && env[0] == '1';
+    if (const char *ck = getenv("PS_CHAIN_KERNEL")) h->chain_kernel = !strcmp(ck, "valu") ? 1 : !strcmp(ck, "mfma") ? 2 : 0;
     int rc = PS_OK;
     auto fail_out = [&](int code) { ps_pixelcnn_destroy(h); return code; };
 
