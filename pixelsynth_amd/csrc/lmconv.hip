@@ -166,17 +166,16 @@ __global__ __launch_bounds__(64) void k_gemm(GemmArgs a)
 
 // ------------------------------------------------------------------------------------------
 // per-item post ops, shared by the whole-grid kernels and the column chain.
-// The NF = 80 channels of an item are handled as 20 GROUPS of 4 consecutive channels (one f32x4): that is the
-// MFMA accumulator layout (lane (kk, i) of the wave owning output tile w holds channels 16w + 4kk .. +3 of
-// item i), so k_chain applies the post op directly on its accumulators with 16-byte slot / bias / cache
-// accesses.  The statistics of PONO are reduced in ONE association order everywhere: a group partial
-// ((y0 + y1) + y2) + y3, then the 20 partials through the fixed tree of tree20_lanes / tree20_array -- so column
-// steps and whole-grid passes agree bit for bit.
+// One wave per item, one channel per lane: lane l owns channel l ("A") and, for l < 16, channel 64 + l ("B").
+// The statistics of PONO are reduced in ONE association order everywhere (pono_total): v_l = A_l + B_l, a
+// butterfly over the lanes of each row of 16 (DPP), then (row0 + row1) + (row2 + row3) -- so column steps and
+// whole-grid passes agree bit for bit.
 // ------------------------------------------------------------------------------------------
-constexpr int NGRP = NF / 4;  // 20
+constexpr int NGRP = NF / 4;  // 20 groups of 4 channels (u_init gather of k_nbr)
+constexpr int NB_LANES = NF - 64;  // 16 lanes carry a second channel
 
 // Elementwise math of the post ops.  These sit on the sequential critical path of every AR order position
-// (k_chain), so they use the hardware transcendental units directly (v_exp_f32 / v_rcp_f32 / v_rsq_f32,
+// (k_chain1), so they use the hardware transcendental units directly (v_exp_f32 / v_rcp_f32 / v_rsq_f32,
 // ~1 ulp) instead of the libm-exact sequences; the result stays ~1e-7 relative to the exact value,
 // far inside the 1e-4 logit tolerance, and both evaluation modes share these functions bit for bit.
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
@@ -187,78 +186,53 @@ __device__ __forceinline__ void celu_pair(float x, float &ep, float &en)
     ep = x > 0.0f ? x : e;
     en = x > 0.0f ? e : -x;
 }
-__device__ __forceinline__ void celu_pair4(const f32x4 &x, f32x4 &ep, f32x4 &en)
-{
-    float p0, p1, p2, p3, n0, n1, n2, n3;
-    celu_pair(x.x, p0, n0);
-    celu_pair(x.y, p1, n1);
-    celu_pair(x.z, p2, n2);
-    celu_pair(x.w, p3, n3);
-    ep = f32x4{p0, p1, p2, p3};
-    en = f32x4{n0, n1, n2, n3};
-}
 __device__ __forceinline__ float sigmoid1(float x) { return __builtin_amdgcn_rcpf(1.0f + fast_exp(-x)); }
-__device__ __forceinline__ f32x4 sigmoid4(const f32x4 &x) { return f32x4{sigmoid1(x.x), sigmoid1(x.y), sigmoid1(x.z), sigmoid1(x.w)}; }
 
-__device__ __forceinline__ float group_sum(const f32x4 &v) { return ((v.x + v.y) + v.z) + v.w; }
-__device__ __forceinline__ float group_sumsq(const f32x4 &d) { return ((d.x * d.x + d.y * d.y) + d.z * d.z) + d.w * d.w; }
-// PONO statistics from the 20 group partials (models/lmconv/layers.py:231-236: unbiased variance, eps 1e-5)
+// PONO statistics (models/lmconv/layers.py:231-236: unbiased variance, eps 1e-5)
 __device__ __forceinline__ float pono_mean(float total) { return total * (1.0f / (float)NF); }
 __device__ __forceinline__ float pono_inv(float ss_total) { return __builtin_amdgcn_rsqf(ss_total * (1.0f / (float)(NF - 1)) + 1e-5f); }
 
-// y = ((bias + NA) + C) + NB, element-wise on a group
-__device__ __forceinline__ f32x4 slot_sum4(const f32x4 &bias, const f32x4 &na, const f32x4 &c, const f32x4 &nb) { return ((bias + na) + c) + nb; }
+// y = ((bias + NA) + C) + NB
 __device__ __forceinline__ float slot_sum(float bias, float na, float c, float nb) { return ((bias + na) + c) + nb; }
 
 enum { POST_CONVIN = 0, POST_GATE = 1, POST_DIL = 2 };
 
-// n = PONO-normalised group.  KIND = POST_CONVIN: out = n [+ skip]              (layers.py:153-156)
+// n = PONO-normalised value.  KIND = POST_CONVIN: out = n [+ skip]              (layers.py:153-156)
 //                                   POST_GATE:   out = rin + n * sigmoid(g)      (layers.py:159-163)
 //                                   POST_DIL:    out = n                         (model.py:138-140,148-150)
 template <int KIND>
-__device__ __forceinline__ f32x4 post_finish(const f32x4 &n, const f32x4 &g, const f32x4 &skip, bool has_skip, const f32x4 &rin)
+__device__ __forceinline__ float post_finish(float n, float g, float skip, bool has_skip, float rin)
 {
     if (KIND == POST_CONVIN) return has_skip ? n + skip : n;
-    if (KIND == POST_GATE) return rin + n * sigmoid4(g);
+    if (KIND == POST_GATE) return rin + n * sigmoid1(g);
     return n;
 }
 
-// Sum of the 20 group partials of an item, in ONE association order everywhere: a balanced tree over the group
-// index (pairs, quads, octets, sixteen), groups 16..19 as their own tree, then row0 + row1.
-//   lanes form: lanes 0..19 of a wave hold the partials (lanes 20..31 are made 0); four DPP adds + two lane reads
-//   array form: the same tree written out (k_chain reads the partials of an item from LDS)
 template <int CTRL>
 __device__ __forceinline__ float dpp_xadd(float x)
 {
     const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, false);
     return x + __int_as_float(moved);
 }
-__device__ __forceinline__ float tree20_lanes(float part, bool own)
+__device__ __forceinline__ float lane_value(float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); }
+// sum over the 80 channels of an item; b MUST be 0 in lanes >= 16.  Every lane gets the same bits.
+__device__ __forceinline__ float pono_total(float a, float b)
 {
-    float x = own ? part : 0.0f;
+    float x = a + b;
     x = dpp_xadd<0xB1>(x);    // quad_perm [1,0,3,2]: pairs
     x = dpp_xadd<0x4E>(x);    // quad_perm [2,3,0,1]: quads
     x = dpp_xadd<0x141>(x);   // row_half_mirror: octets
-    x = dpp_xadd<0x140>(x);   // row_mirror: the 16 groups of a row
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 0)) +
-           __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 16));
-}
-__device__ __forceinline__ float tree20_array(const float *p)
-{
-    float a[10];
-#pragma unroll
-    for (int k = 0; k < 10; ++k) a[k] = p[2 * k] + p[2 * k + 1];
-    const float b0 = a[0] + a[1], b1 = a[2] + a[3], b2 = a[4] + a[5], b3 = a[6] + a[7], b4 = a[8] + a[9];
-    return ((b0 + b1) + (b2 + b3)) + b4;
+    x = dpp_xadd<0x140>(x);   // row_mirror: the 16 lanes of a row
+    return (lane_value(x, 0) + lane_value(x, 16)) + (lane_value(x, 32) + lane_value(x, 48));
 }
 
-// u_init on one-hot input as a gather, type-A mask (model.py:132), BEFORE norm_init, for channel group `grp`:
+// u_init on one-hot input as a gather, type-A mask (model.py:132), BEFORE norm_init:
 //   y[o] = b[o] + sum_t m_t * (W[t][512][o] + W[t][code(nbr_t)][o])
 // Only earlier order positions contribute (the centre of a type-A mask is 0), so in column mode this
-// belongs to the neighbour kernel, not to the chain.
-__device__ __forceinline__ f32x4 uinit_gather4(const int32_t *__restrict__ codes_f, const float *mA /*9 values*/,
-                                               const float *__restrict__ w, const float *__restrict__ bias, int q, int H,
-                                               int W, int grp)
+// belongs to the neighbour kernel, not to the chain.  V = float (channel c) or f32x4 (channels c .. c+3).
+template <typename V>
+__device__ __forceinline__ V uinit_gather(const int32_t *__restrict__ codes_f, const float *mA /*9 values*/,
+                                          const float *__restrict__ w, const float *__restrict__ bias, int q, int H, int W, int c)
 {
     const int r = q / W, c0 = q - r * W;
     int code[9];
@@ -270,24 +244,24 @@ __device__ __forceinline__ f32x4 uinit_gather4(const int32_t *__restrict__ codes
         mv[t] = in ? mA[t] : 0.0f;
         code[t] = (in && mv[t] != 0.0f) ? codes_f[rr * W + cc] : -1;
     }
-    f32x4 v = *(const f32x4 *)(bias + 4 * grp);
+    V v = *(const V *)(bias + c);
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         if (mv[t] == 0.0f) continue;
-        f32x4 x = *(const f32x4 *)(w + ((size_t)t * (NCLS + 1) + NCLS) * NF + 4 * grp);
-        if (code[t] >= 0) x = x + *(const f32x4 *)(w + ((size_t)t * (NCLS + 1) + code[t]) * NF + 4 * grp);
+        V x = *(const V *)(w + ((size_t)t * (NCLS + 1) + NCLS) * NF + c);
+        if (code[t] >= 0) x = x + *(const V *)(w + ((size_t)t * (NCLS + 1) + code[t]) * NF + c);
         v = v + x * mv[t];
     }
     return v;
 }
 
-__device__ __forceinline__ void store_raw_celu4(float *R, float *E, size_t loc, int grp, const f32x4 &u)
+__device__ __forceinline__ void store_raw_celu(float *R, float *E, size_t loc, int c, float u)
 {
-    f32x4 ep, en;
-    celu_pair4(u, ep, en);
-    *(f32x4 *)(R + loc * NF + 4 * grp) = u;
-    *(f32x4 *)(E + loc * (2 * NF) + 4 * grp) = ep;
-    *(f32x4 *)(E + loc * (2 * NF) + NF + 4 * grp) = en;
+    float ep, en;
+    celu_pair(u, ep, en);
+    R[loc * NF + c] = u;
+    E[loc * (2 * NF) + c] = ep;
+    E[loc * (2 * NF) + NF + c] = en;
 }
 
 struct PostArgs {
@@ -298,7 +272,7 @@ struct PostArgs {
     float *Rout, *Eout, *Xout;
 };
 
-// whole-grid post op: one wave per item (lanes 0..19 own the 20 channel groups), 4 items per 256-thread block
+// whole-grid post op: one wave per item, 4 items per 256-thread block
 template <int KIND>
 __global__ __launch_bounds__(256) void k_post_grid(PostArgs a)
 {
@@ -306,33 +280,36 @@ __global__ __launch_bounds__(256) void k_post_grid(PostArgs a)
     if (item >= a.nitems) return;  // whole waves leave together
     const size_t loc = item;       // item = f*L + q
     const size_t ss = (size_t)a.nitems * a.Co_pad;
-    const bool own = lane < NGRP;
-    const int c = 4 * (own ? lane : 0);
-    const float *P = a.partial + (size_t)item * a.Co_pad + c;
-    const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
-    f32x4 y = zero, g = zero, skip = zero, rin = zero;
-    if (own) {
-        y = slot_sum4(*(const f32x4 *)(a.bias + c), *(const f32x4 *)(P + SLOT_NA * ss), *(const f32x4 *)(P + SLOT_C * ss),
-                      *(const f32x4 *)(P + SLOT_NB * ss));
+    const float *P = a.partial + (size_t)item * a.Co_pad;
+    const bool hasB = lane < NB_LANES;
+    const int ch[2] = {lane, 64 + (lane & (NB_LANES - 1))};
+    float y[2], g[2] = {0.0f, 0.0f}, skip[2] = {0.0f, 0.0f}, rin[2] = {0.0f, 0.0f};
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int c = ch[k];
+        y[k] = slot_sum(a.bias[c], P[SLOT_NA * ss + c], P[SLOT_C * ss + c], P[SLOT_NB * ss + c]);
         if (KIND == POST_GATE) {
-            g = slot_sum4(*(const f32x4 *)(a.bias + c + NF), *(const f32x4 *)(P + SLOT_NA * ss + NF),
-                          *(const f32x4 *)(P + SLOT_C * ss + NF), *(const f32x4 *)(P + SLOT_NB * ss + NF));
-            rin = *(const f32x4 *)(a.Rin + loc * NF + c);
+            g[k] = slot_sum(a.bias[c + NF], P[SLOT_NA * ss + NF + c], P[SLOT_C * ss + NF + c], P[SLOT_NB * ss + NF + c]);
+            rin[k] = a.Rin[loc * NF + c];
         }
-        if (KIND == POST_CONVIN && a.has_skip) skip = *(const f32x4 *)(P + SLOT_SKIP * ss) + *(const f32x4 *)(a.bias2 + c);
+        if (KIND == POST_CONVIN && a.has_skip) skip[k] = P[SLOT_SKIP * ss + c] + a.bias2[c];
     }
-    const float mean = pono_mean(tree20_lanes(group_sum(y), own));
-    const f32x4 d = y - mean;
-    const float inv = pono_inv(tree20_lanes(group_sumsq(d), own));
-    if (!own) return;
-    const f32x4 out = post_finish<KIND>(d * inv, g, skip, a.has_skip != 0, rin);
-    if (KIND == POST_CONVIN) {
-        f32x4 ep, en;
-        celu_pair4(out, ep, en);
-        *(f32x4 *)(a.Xout + loc * (2 * NF) + c) = ep;
-        *(f32x4 *)(a.Xout + loc * (2 * NF) + NF + c) = en;
-    } else {
-        store_raw_celu4(a.Rout, a.Eout, loc, lane, out);
+    const float mean = pono_mean(pono_total(y[0], hasB ? y[1] : 0.0f));
+    const float d0 = y[0] - mean, d1 = y[1] - mean;
+    const float inv = pono_inv(pono_total(d0 * d0, hasB ? d1 * d1 : 0.0f));
+    const float dd[2] = {d0, d1};
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        if (k == 1 && !hasB) break;
+        const float out = post_finish<KIND>(dd[k] * inv, g[k], skip[k], a.has_skip != 0, rin[k]);
+        if (KIND == POST_CONVIN) {
+            float ep, en;
+            celu_pair(out, ep, en);
+            a.Xout[loc * (2 * NF) + ch[k]] = ep;
+            a.Xout[loc * (2 * NF) + NF + ch[k]] = en;
+        } else {
+            store_raw_celu(a.Rout, a.Eout, loc, ch[k], out);
+        }
     }
 }
 
@@ -350,16 +327,18 @@ __global__ __launch_bounds__(256) void k_uinit_grid(UinitArgs a)
     const int item = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (item >= a.nitems) return;
     const int f = item / a.L, q = item - f * a.L;
-    const bool own = lane < NGRP;
+    const bool hasB = lane < NB_LANES;
     float mA[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) mA[t] = a.mask[((size_t)f * 9 + t) * a.L + q];
-    f32x4 y = {0.0f, 0.0f, 0.0f, 0.0f};
-    if (own) y = uinit_gather4(a.codes + (size_t)f * a.L, mA, a.w, a.bias, q, a.H, a.W, lane);
-    const float mean = pono_mean(tree20_lanes(group_sum(y), own));   // norm_init
-    const f32x4 d = y - mean;
-    const float inv = pono_inv(tree20_lanes(group_sumsq(d), own));
-    if (own) store_raw_celu4(a.Rout, a.Eout, (size_t)item, lane, d * inv);
+    const int cB = 64 + (lane & (NB_LANES - 1));
+    const float yA = uinit_gather<float>(a.codes + (size_t)f * a.L, mA, a.w, a.bias, q, a.H, a.W, lane);
+    const float yB = uinit_gather<float>(a.codes + (size_t)f * a.L, mA, a.w, a.bias, q, a.H, a.W, cB);
+    const float mean = pono_mean(pono_total(yA, hasB ? yB : 0.0f));   // norm_init
+    const float dA = yA - mean, dB = yB - mean;
+    const float inv = pono_inv(pono_total(dA * dA, hasB ? dB * dB : 0.0f));
+    store_raw_celu(a.Rout, a.Eout, (size_t)item, lane, dA * inv);
+    if (hasB) store_raw_celu(a.Rout, a.Eout, (size_t)item, cB, dB * inv);
 }
 
 // logits = nin_out partial + bias; nchw: (F,512,H,W) like the reference, else (nitems,512)
@@ -415,9 +394,6 @@ enum { PRO_UINIT = 0, PRO_CONVIN = 1, PRO_GATE = 2, PRO_DIL = 3 };
 enum { IN_CELU = 0, IN_RAW = 1, IN_ELU = 2 };
 constexpr int NST = 33;       // 14 x (conv_input, conv_out) + 4 dilated convs + nin_out
 constexpr int NBR_LD = 2 * NF;
-constexpr int SIN_LD = 2 * NF + 4;
-constexpr int SL_LD = NCLS + 4;
-constexpr int CHAIN_WAVES = 16;  // one wave per frame of the 16-frame tile in the post ops; waves 0..9 own the MFMA tiles
 
 struct __attribute__((aligned(16))) StageDesc {
     // control words first, 16-byte aligned: k_chain fetches them with two ds_read_b128 per stage
@@ -494,7 +470,7 @@ __global__ __launch_bounds__(256) void k_nbr(NbrArgs a)
 #pragma unroll
         for (int t = 0; t < 9; ++t) mA[t] = a.ctx[f].m[0][t];
         *(f32x4 *)(a.upre + (size_t)f * NF + 4 * lane) =
-            uinit_gather4(a.codes + (size_t)f * a.L, mA, a.uinit_w, a.uinit_b, a.ctx[f].q, a.H, a.W, lane);
+            uinit_gather<f32x4>(a.codes + (size_t)f * a.L, mA, a.uinit_w, a.uinit_b, a.ctx[f].q, a.H, a.W, 4 * lane);
         return;
     }
     __shared__ __attribute__((aligned(16))) float sP[4][16][20];
@@ -568,234 +544,7 @@ __device__ __forceinline__ int draw_code(const float (&lg)[8], float temperature
 // against its two barriers per stage; the data exchanged between the waves here lives in LDS only.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// one centre-tap product: out[16 items][16 channels] = W (registers, loaded early) x LDS input rows
-template <int NG>
-__device__ __forceinline__ f32x4 center_tile(const f32x4 *av, const float (*sIn)[SIN_LD], int i, int kk)
-{
-    Acc5 acc = acc5_zero();
-#pragma unroll
-    for (int g0 = 0; g0 < NG; g0 += 5) {
-        f32x4 a5[5], b5[5];
-#pragma unroll
-        for (int j = 0; j < 5; ++j) {
-            a5[j] = av[g0 + j];
-            b5[j] = *(const f32x4 *)(&sIn[i][16 * (g0 + j) + 4 * kk]);
-        }
-        mfma_chunk5(a5, b5, acc);
-    }
-    return chunk_total(acc);
-}
-
-template <int NG>
-__device__ __forceinline__ void load_tile_weights(const float *__restrict__ w, int Co_pad, int o0, int i, int kk, f32x4 *av)
-{
-    const float *wbase = w + ((size_t)kk * Co_pad + o0 + i) * 4;
-#pragma unroll
-    for (int g = 0; g < NG; ++g) av[g] = *PS_GC(f32x4, wbase + (size_t)g * 16 * Co_pad);
-}
-
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
-
-constexpr int SG_LD = NF + 4;  // row stride (floats) of the 80-channel LDS arrays, keeps f32x4 rows 16-byte aligned
-
-// One workgroup (16 waves) per tile of 16 frames.  Lane (kk, i) of a wave owning output tile w holds, after the
-// MFMA, channels 16w + 4kk .. +3 of frame i -- the post op of the stage is applied right there:
-//   A  centre-tap products (waves < Co/16) and the nin_skip 1x1 (waves 10..14)
-//   B  y = ((bias + NA) + acc) + NB with 16-byte loads fetched before the MFMAs; the gate half (waves 5..9)
-//      and the nin_skip result pass through LDS; the 20 group partials of the PONO statistics are
-//      exchanged through LDS (two LDS-only barriers), then waves 0..4 finish: normalise, skip / gate /
-//      residual, concat-ELU, write the next stage's input (LDS) and the caches (global, 16-byte stores).
-// Weights of stage s+1 are requested at the start of B(s); nothing waits on global memory at a barrier.
-__global__ __launch_bounds__(CHAIN_WAVES * 64) void k_chain(ChainArgs a)
-{
-    __shared__ __attribute__((aligned(16))) float sIn[16][SIN_LD];     // input of the centre taps
-    __shared__ __attribute__((aligned(16))) float sSkip[16][SIN_LD];   // concat_elu(u_k) feeding nin_skip
-    __shared__ __attribute__((aligned(16))) float sS[16][SG_LD];       // nin_skip results
-    __shared__ __attribute__((aligned(16))) float sG[16][SG_LD];       // gate half of conv_out
-    __shared__ __attribute__((aligned(16))) float sU[8][16][SG_LD];    // u0..u7 of this location (skip connections)
-    __shared__ __attribute__((aligned(16))) float sRed[2][16][NGRP];   // PONO group partials: sums, squared deviations
-    __shared__ __attribute__((aligned(16))) float sL[16][SL_LD];       // nin_out results
-    __shared__ StageDesc sSt[NST];                                     // the chain description
-    const int tid = threadIdx.x, wave = uni(tid >> 6), lane = tid & 63, i = lane & 15, kk = lane >> 4;
-    const int f0 = blockIdx.x * 16;
-    const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
-    {
-        const int *src = (const int *)a.stages;
-        int *dst = (int *)sSt;
-        for (int k = tid; k < (int)(NST * sizeof(StageDesc) / 4); k += CHAIN_WAVES * 64) dst[k] = src[k];
-    }
-    // this lane's frame (column i of every MFMA tile) and its location
-    const int fi = f0 + i;
-    const bool vi = fi < a.F;
-    const int qi = vi ? a.cx.ctx[fi].q : 0;
-    const size_t off80 = ((size_t)fi * a.L + qi) * NF, off160 = 2 * off80;
-    const float *nbr_i = a.nbr + (size_t)fi * NBR_LD;
-    const size_t nbr_half = (size_t)a.F * NBR_LD, nbr_stage = 2 * nbr_half;
-    const bool pw = wave < 5;                 // waves 0..4 own the 80 channels the post ops produce
-    const int c4 = 16 * wave + 4 * kk;        // this lane's channel group (as a tile wave)
-    const int grp = 4 * wave + kk;
-    f32x4 ucur = zero;
-    if (!vi && wave < 10) {  // columns of absent frames feed zeros into the MFMA tiles
-        *(f32x4 *)(&sIn[i][c4]) = zero;
-        *(f32x4 *)(&sSkip[i][c4]) = zero;
-    }
-    __syncthreads();
-
-    // PONO over the 80 channels of every frame + the stage-specific finish + hand-off.  Called by ALL waves
-    // (it contains the barriers); only waves 0..4 carry data.  kind: PRO_* of the consumer stage `nx`.
-    auto post_and_emit = [&](const f32x4 &y, int kind, int nx) {
-        if (pw) sRed[0][i][grp] = group_sum(y);
-        lds_barrier();
-        f32x4 d = zero;
-        if (pw) {
-            d = y - pono_mean(tree20_array(&sRed[0][i][0]));
-            sRed[1][i][grp] = group_sumsq(d);
-        }
-        lds_barrier();
-        if (pw) {
-            const f32x4 n = d * pono_inv(tree20_array(&sRed[1][i][0]));
-            f32x4 out;
-            if (kind == PRO_CONVIN) {
-                const bool hs = uni(sSt[nx].p_has_skip) != 0;
-                f32x4 skip = zero;
-                if (hs) skip = *(const f32x4 *)(&sS[i][c4]) + *PS_GC(f32x4, sSt[nx].pbias2 + c4);
-                out = post_finish<POST_CONVIN>(n, zero, skip, hs, zero);
-            } else if (kind == PRO_GATE) {
-                out = post_finish<POST_GATE>(n, *(const f32x4 *)(&sG[i][c4]), zero, false, ucur);
-            } else {
-                out = n;  // PRO_DIL, PRO_UINIT (norm_init)
-            }
-            f32x4 ep, en;
-            celu_pair4(out, ep, en);
-            const int in_form = uni(sSt[nx].in_form);
-            if (vi) {
-                if (in_form == IN_CELU) { *(f32x4 *)(&sIn[i][c4]) = ep; *(f32x4 *)(&sIn[i][NF + c4]) = en; }
-                else if (in_form == IN_RAW) *(f32x4 *)(&sIn[i][c4]) = out;
-                else *(f32x4 *)(&sIn[i][c4]) = ep;
-                if (kind == PRO_CONVIN) {
-                    float *X = sSt[nx].outX;
-                    *PS_G(f32x4, X + off160 + c4) = ep;
-                    *PS_G(f32x4, X + off160 + NF + c4) = en;
-                } else {
-                    float *R = sSt[nx].outR, *E = sSt[nx].outE;
-                    *PS_G(f32x4, R + off80 + c4) = out;
-                    *PS_G(f32x4, E + off160 + c4) = ep;
-                    *PS_G(f32x4, E + off160 + NF + c4) = en;
-                }
-            }
-            if (kind != PRO_CONVIN) {
-                ucur = out;
-                const int save_slot = uni(sSt[nx].save_slot);
-                if (save_slot >= 0) *(f32x4 *)(&sU[save_slot][i][c4]) = out;
-            }
-        } else if (wave >= 10 && wave < 15) {
-            // idle nin_skip waves stage the input of stage nx's nin_skip: concat_elu(u_k), k from the up pass
-            const int k = uni(sSt[nx].skip_slot);
-            if (k >= 0 && vi) {
-                const int cs = 16 * (wave - 10) + 4 * kk;
-                f32x4 ep, en;
-                celu_pair4(*(const f32x4 *)(&sU[k][i][cs]), ep, en);
-                *(f32x4 *)(&sSkip[i][cs]) = ep;
-                *(f32x4 *)(&sSkip[i][NF + cs]) = en;
-            }
-        }
-        lds_barrier();
-    };
-
-    // weights of the first stage, then u0 = norm_init(u_init) from k_nbr's gather
-    f32x4 av[10];
-    auto fetch_weights = [&](int s2) {
-        const int NG = uni(sSt[s2].NG), Co_pad = uni(sSt[s2].Co_pad), center_tap = uni(sSt[s2].center_tap);
-        const float *w = sSt[s2].w, *w_skip = sSt[s2].w_skip;
-        const int ntile = Co_pad >> 4;
-        if (s2 == NST - 1) {  // nin_out: 32 tiles, two per wave (av[0..4], av[5..9])
-            load_tile_weights<5>(w, Co_pad, wave * 16, i, kk, av);
-            load_tile_weights<5>(w, Co_pad, (wave + CHAIN_WAVES) * 16, i, kk, av + 5);
-        } else if (wave < ntile) {
-            const float *wc = w + (size_t)center_tap * NG * 16 * Co_pad;
-            if (NG == 10) load_tile_weights<10>(wc, Co_pad, wave * 16, i, kk, av);
-            else load_tile_weights<5>(wc, Co_pad, wave * 16, i, kk, av);
-        } else if (w_skip != nullptr && wave >= 10 && wave < 15) {
-            load_tile_weights<10>(w_skip, NF, (wave - 10) * 16, i, kk, av);
-        }
-    };
-    fetch_weights(0);
-    {
-        f32x4 y = zero;
-        if (pw && vi) y = *PS_GC(f32x4, a.upre + (size_t)fi * NF + c4);
-        post_and_emit(y, PRO_UINIT, 0);
-    }
-
-#define PS_TRACE(slot) do { if (a.trace && blockIdx.x == 0 && tid == 0) a.trace[s * 10 + (slot)] = clock64(); } while (0)
-    for (int s = 0; s < NST - 1; ++s) {
-        const int NG = uni(sSt[s].NG), ntile = uni(sSt[s].Co_pad) >> 4;
-        const bool has_skip_w = sSt[s].w_skip != nullptr;
-        const bool tile_w = wave < ntile, skip_w = has_skip_w && wave >= 10 && wave < 15;
-        const int kind = uni(sSt[s + 1].pro);  // the post op that follows this stage
-        PS_TRACE(0);
-        // ---- operands of y = ((bias + NA) + acc) + NB for this lane's group: in flight under the MFMAs
-        f32x4 b4 = zero, na4 = zero, nb4 = zero;
-        if (tile_w && vi) {
-            b4 = *PS_GC(f32x4, sSt[s + 1].pbias + c4);
-            na4 = *PS_GC(f32x4, nbr_i + (size_t)s * nbr_stage + c4);
-            nb4 = *PS_GC(f32x4, nbr_i + (size_t)s * nbr_stage + nbr_half + c4);
-        }
-        PS_TRACE(5);
-        // ---- A: centre-tap products
-        f32x4 acc = zero;
-        if (tile_w) acc = NG == 10 ? center_tile<10>(av, sIn, i, kk) : center_tile<5>(av, sIn, i, kk);
-        else if (skip_w) *(f32x4 *)(&sS[i][16 * (wave - 10) + 4 * kk]) = center_tile<10>(av, sSkip, i, kk);
-        PS_TRACE(6);
-        // ---- weights of the next stage: requested now, consumed after three barriers
-        fetch_weights(s + 1);
-        // ---- B: post op on the accumulators
-        const f32x4 y = slot_sum4(b4, na4, acc, nb4);
-        if (kind == PRO_GATE && wave >= 5 && wave < 10) *(f32x4 *)(&sG[i][c4 - NF]) = y;
-        PS_TRACE(7);
-        post_and_emit(y, kind, s + 1);
-        PS_TRACE(4);
-    }
-#undef PS_TRACE
-
-    // ---- nin_out(elu(u)) (model.py:153): 32 tiles, two per wave; its input was emitted by the last gate
-    *(f32x4 *)(&sL[i][wave * 16 + kk * 4]) = center_tile<5>(av, sIn, i, kk);
-    *(f32x4 *)(&sL[i][(wave + CHAIN_WAVES) * 16 + kk * 4]) = center_tile<5>(av + 5, sIn, i, kk);
-    lds_barrier();
-
-    // ---- end of the order position: logits, categorical draw (sample.py:60-66), next context; wave = frame
-    const int pf = f0 + wave;
-    if (pf < a.F) {
-        const int f = pf, j = wave;
-        const int pq = uni(a.cx.ctx[f].q);
-        const size_t loc = (size_t)f * a.L + pq;
-        float lg[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) lg[k] = sL[j][lane * 8 + k] + a.out_b[lane * 8 + k];
-        if (a.out_logits) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) a.out_logits[loc * NCLS + lane * 8 + k] = lg[k];
-        }
-        if (a.step_logits) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) a.step_logits[(size_t)f * NCLS + lane * 8 + k] = lg[k];
-        }
-        if (a.codes && a.region[loc]) {
-            if (a.forced) {
-                if (lane == 0) a.codes[loc] = a.forced[loc];
-            } else {
-                const int code = draw_code(lg, a.temperature, a.uniforms[loc], lane);
-                if (lane == 0) a.codes[loc] = code;
-            }
-        }
-    }
-    if (a.advance) {
-        __syncthreads();  // every lane of the workgroup has read its ctx[fi].q by now (kernel start), and the draws are done
-        if (pf < a.F) {
-            const int step = a.cx.ctx[pf].step;
-            if (lane < 32) ctx_fill(a.cx, pf, step + 1, lane);
-        }
-    }
-}
 
 // ==========================================================================================
 // k_chain1: the same 33-stage chain on the vector ALU, one workgroup per FPW frames.
@@ -811,7 +560,7 @@ constexpr int C1_THREADS = 1024;
 constexpr int C1_MAXCHAIN = 800;   // 5 x 160, or 5 x 80 + 5 x 80 (conv_input + nin_skip)
 constexpr int SX_LD = 2 * NF;
 constexpr int C1_OUT_STEPS = 12;
-constexpr int VALU_CHAIN_MAX_FRAMES = 1024;  // above this the 16-frame MFMA tiles win (256 CUs x 4 rounds)   // nin_out: thread (o, part): part 0 = chains 0..2, part 1 = chains 3..4
+   // nin_out: thread (o, part): part 0 = chains 0..2, part 1 = chains 3..4
 
 template <int NGL, int FPW>
 __device__ __forceinline__ void valu_chain(const f32x4 *w /*4 * NGL steps*/, const float *xbase, int j, float (&acc)[FPW])
@@ -872,8 +621,8 @@ __device__ __forceinline__ T *ctl_p(const int *ctl, int rec, int field)
     return (T *)((CtlU64)ctl)[(rec * C1_CTL_DWORDS + field) >> 1];
 }
 struct ChainCtl { int Co, nchain, NG, nstep; const float *wv; };
-struct PostCtl { int Co, kind, has_skip, in_form, save_slot, skip_slot; const float *bias, *bias2; };
-struct StoreCtl { int kind; float *R, *E, *X; };
+struct PostCtl { int Co, kind, has_skip, in_form, save_slot; const float *bias, *bias2; };
+struct StoreCtl { int kind, skip_slot; float *R, *E, *X; };
 __device__ __forceinline__ ChainCtl load_chain_ctl(const int *ctl, int rec)
 {
     return ChainCtl{ctl_i(ctl, rec, CTL_CO), ctl_i(ctl, rec, CTL_NCHAIN), ctl_i(ctl, rec, CTL_NG), ctl_i(ctl, rec, CTL_NSTEP),
@@ -882,12 +631,12 @@ __device__ __forceinline__ ChainCtl load_chain_ctl(const int *ctl, int rec)
 __device__ __forceinline__ PostCtl load_post_ctl(const int *ctl, int rec)
 {
     return PostCtl{ctl_i(ctl, rec, CTL_CO), ctl_i(ctl, rec, CTL_KIND), ctl_i(ctl, rec, CTL_HAS_SKIP), ctl_i(ctl, rec, CTL_IN_FORM),
-                   ctl_i(ctl, rec, CTL_SAVE_SLOT), ctl_i(ctl, rec, CTL_SKIP_SLOT), ctl_p<const float>(ctl, rec, CTL_BIAS),
-                   ctl_p<const float>(ctl, rec, CTL_BIAS2)};
+                   ctl_i(ctl, rec, CTL_SAVE_SLOT), ctl_p<const float>(ctl, rec, CTL_BIAS), ctl_p<const float>(ctl, rec, CTL_BIAS2)};
 }
 __device__ __forceinline__ StoreCtl load_store_ctl(const int *ctl, int rec)
 {
-    return StoreCtl{ctl_i(ctl, rec, CTL_KIND), ctl_p<float>(ctl, rec, CTL_R), ctl_p<float>(ctl, rec, CTL_E), ctl_p<float>(ctl, rec, CTL_X)};
+    return StoreCtl{ctl_i(ctl, rec, CTL_KIND), ctl_i(ctl, rec, CTL_SKIP_SLOT), ctl_p<float>(ctl, rec, CTL_R),
+                    ctl_p<float>(ctl, rec, CTL_E), ctl_p<float>(ctl, rec, CTL_X)};
 }
 
 template <int FPW>
@@ -902,21 +651,15 @@ __global__ __launch_bounds__(C1_THREADS) void k_chain1(ChainArgs a)
     __shared__ __attribute__((aligned(16))) float sPL[FPW][5][NCLS];     // chain values of nin_out
     const int t = threadIdx.x, wave = uni(t >> 6), lane = t & 63;
     const int f0 = blockIdx.x * FPW;
-    const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
     // Roles, each in its own wave-uniform branch (so their registers do not add up):
     //   waves 0..12         one chain per thread and stage
-    //   wave 13             cache stores: lanes 20f..20f+19 carry frame f's finished values from LDS to R / E / X
-    //   waves 16-FPW..15    post op of one frame each, lanes 0..19 = its 20 channel groups
+    //   wave 13             cache stores (finished values LDS -> R / E / X) and the nin_skip inputs
+    //   waves 16-FPW..15    post op of one frame each, one channel per lane (see pono_total)
     constexpr int NW = C1_THREADS / 64, STORE_WAVE = 13;
     const int pf = wave - (NW - FPW);  // frame slot of a post wave, negative otherwise
     const bool pwave = pf >= 0, swave = wave == STORE_WAVE;
-    const int slot = pwave ? pf : lane / NGRP;  // frame slot this lane serves as post / store lane
-    const int grp = pwave ? lane : lane - slot * NGRP;
-    const int pfr = f0 + slot;
-    const bool own = (pwave ? lane < NGRP : (swave && slot < FPW)) && pfr < a.F;
-    const int c4 = own ? 4 * grp : 0;
-    const int pq = own ? a.cx.ctx[pfr].q : 0;
-    const size_t off80 = ((size_t)(own ? pfr : 0) * a.L + pq) * NF, off160 = 2 * off80;
+    const bool hasB = lane < NB_LANES;
+    const int cA = lane, cB = 64 + (lane & (NB_LANES - 1));
     // chain role: 80-output stages hold chains t = j * 80 + o (then the nin_skip chains), 160-output ones j * 160 + o
     const int q80 = t / NF, j160 = t / (2 * NF);
     const int j80 = q80 >= 5 ? q80 - 5 : q80;
@@ -939,7 +682,6 @@ __global__ __launch_bounds__(C1_THREADS) void k_chain1(ChainArgs a)
             for (int st = 8; st < C1_OUT_STEPS; ++st) wo[st] = *PS_GC(f32x4, wo_base + (size_t)st * C1_THREADS * 4);
         }
     };
-
     // nin_out(elu(u)) (model.py:153); called at the end of every role's branch, so wo never crosses a join
     auto nin_out_chains = [&]() {
         const int o = t & (NCLS - 1);
@@ -957,55 +699,63 @@ __global__ __launch_bounds__(C1_THREADS) void k_chain1(ChainArgs a)
 
     if (pwave) {
         // ================= post waves: one frame each, two barriers per stage =================
-        const float *nbr_f = a.nbr + (size_t)(own ? pfr : 0) * NBR_LD + c4;
+        const int pfr = f0 + pf;
+        const bool pvalid = pfr < a.F;
+        const float *nbr_f = a.nbr + (size_t)(pvalid ? pfr : 0) * NBR_LD;
         const size_t nbr_half = (size_t)a.F * NBR_LD, nbr_stage = 2 * nbr_half;
-        f32x4 ucur = zero;
-        // bias and neighbour-tap slots of a stage's post op: y = ((bias + NA) + centre) + NB; fetched one stage ahead
-        struct Ops { f32x4 b, na, nb, bg, nag, nbg, b2; };
-        // (always exactly seven loads from valid addresses, in every lane: static s_waitcnt counts -- see
-        // load_chain_weights; kinds without a gate half / skip re-read the main operands)
+        float ucur[2] = {0.0f, 0.0f};
+        // bias and neighbour-tap slots of a stage's post op: y = ((bias + NA) + centre) + NB; fetched one stage ahead.
+        // Always exactly fourteen loads from valid addresses, in every lane: static s_waitcnt counts (see
+        // load_chain_weights); kinds without a gate half / skip re-read the main operands.
+        struct Ops { float b[2], na[2], nb[2], bg[2], nag[2], nbg[2], b2[2]; };
         auto load_ops = [&](int s, const PostCtl &c, Ops &o) {
             const float *nb = nbr_f + (size_t)s * nbr_stage;
             const int gofs = c.kind == PRO_GATE ? NF : 0;
             const float *b2 = c.has_skip ? c.bias2 : c.bias;
-            o.b = *PS_GC(f32x4, c.bias + c4);
-            o.na = *PS_GC(f32x4, nb);
-            o.nb = *PS_GC(f32x4, nb + nbr_half);
-            o.bg = *PS_GC(f32x4, c.bias + gofs + c4);
-            o.nag = *PS_GC(f32x4, nb + gofs);
-            o.nbg = *PS_GC(f32x4, nb + nbr_half + gofs);
-            o.b2 = *PS_GC(f32x4, b2 + c4);
-        };
-        // PONO + finish + hand-off to the next stage; then the input of that stage's nin_skip, concat_elu(u_k) of a
-        // node this wave saved earlier
-        auto post_and_emit = [&](const f32x4 &y, const f32x4 &g, const f32x4 &skip, const PostCtl &c) {
-            const float mean = pono_mean(tree20_lanes(group_sum(y), own));
-            const f32x4 d = y - mean;
-            const float inv = pono_inv(tree20_lanes(group_sumsq(d), own));
-            if (!own) return;
-            const f32x4 n = d * inv;
-            f32x4 out;
-            if (c.kind == PRO_CONVIN) out = post_finish<POST_CONVIN>(n, zero, skip, c.has_skip != 0, zero);
-            else if (c.kind == PRO_GATE) out = post_finish<POST_GATE>(n, g, zero, false, ucur);
-            else out = n;  // PRO_DIL, PRO_UINIT (norm_init)
-            f32x4 ep, en;
-            celu_pair4(out, ep, en);
-            float *x = &sX[pf][c4];
-            if (c.in_form == IN_CELU) { *(f32x4 *)x = ep; *(f32x4 *)(x + NF) = en; }
-            else if (c.in_form == IN_RAW) *(f32x4 *)x = out;
-            else *(f32x4 *)x = ep;
-            *(f32x4 *)(&sOut[pf][1][c4]) = ep;
-            *(f32x4 *)(&sOut[pf][2][c4]) = en;
-            if (c.kind != PRO_CONVIN) {
-                *(f32x4 *)(&sOut[pf][0][c4]) = out;
-                ucur = out;
-                if (c.save_slot >= 0) *(f32x4 *)(&sU[c.save_slot][pf][c4]) = out;
+            const int ch[2] = {cA, cB};
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                o.b[k] = *PS_GC(float, c.bias + ch[k]);
+                o.na[k] = *PS_GC(float, nb + ch[k]);
+                o.nb[k] = *PS_GC(float, nb + nbr_half + ch[k]);
+                o.bg[k] = *PS_GC(float, c.bias + gofs + ch[k]);
+                o.nag[k] = *PS_GC(float, nb + gofs + ch[k]);
+                o.nbg[k] = *PS_GC(float, nb + nbr_half + gofs + ch[k]);
+                o.b2[k] = *PS_GC(float, b2 + ch[k]);
             }
-            if (c.skip_slot >= 0) {
-                f32x4 sp, sn;
-                celu_pair4(*(const f32x4 *)(&sU[c.skip_slot][pf][c4]), sp, sn);
-                *(f32x4 *)(&sSkip[pf][c4]) = sp;
-                *(f32x4 *)(&sSkip[pf][NF + c4]) = sn;
+        };
+        // PONO + finish + hand-off to the next stage
+        auto post_and_emit = [&](const float (&y)[2], const float (&g)[2], const float (&skip)[2], const PostCtl &c) {
+#ifdef PS_ABL_NOPOST
+            sX[pf][cA] = y[0] + g[0] + skip[0];
+            return;
+#endif
+            const float mean = pono_mean(pono_total(y[0], hasB ? y[1] : 0.0f));
+            const float d[2] = {y[0] - mean, y[1] - mean};
+            const float inv = pono_inv(pono_total(d[0] * d[0], hasB ? d[1] * d[1] : 0.0f));
+            if (!pvalid) return;
+            const int ch[2] = {cA, cB};
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                if (k == 1 && !hasB) break;
+                const float n = d[k] * inv;
+                float out;
+                if (c.kind == PRO_CONVIN) out = post_finish<POST_CONVIN>(n, 0.0f, skip[k], c.has_skip != 0, 0.0f);
+                else if (c.kind == PRO_GATE) out = post_finish<POST_GATE>(n, g[k], 0.0f, false, ucur[k]);
+                else out = n;  // PRO_DIL, PRO_UINIT (norm_init)
+                float ep, en;
+                celu_pair(out, ep, en);
+                float *x = &sX[pf][ch[k]];
+                if (c.in_form == IN_CELU) { x[0] = ep; x[NF] = en; }
+                else if (c.in_form == IN_RAW) x[0] = out;
+                else x[0] = ep;
+                sOut[pf][1][ch[k]] = ep;
+                sOut[pf][2][ch[k]] = en;
+                if (c.kind != PRO_CONVIN) {
+                    sOut[pf][0][ch[k]] = out;
+                    ucur[k] = out;
+                    if (c.save_slot >= 0) sU[c.save_slot][pf][ch[k]] = out;
+                }
             }
         };
         PostCtl cur = load_post_ctl(a.ctl1, 0), nxt = load_post_ctl(a.ctl1, 1), nn = load_post_ctl(a.ctl1, 2);
@@ -1021,34 +771,34 @@ __global__ __launch_bounds__(C1_THREADS) void k_chain1(ChainArgs a)
             lds_barrier();   // the chains of this stage are in sP
             PS_TRACE1(t == C1_THREADS - 64, 1);
             const int Co = cur.Co;
-            f32x4 y = zero, g = zero, skip = zero;
-            if (own) {
-                const float *P = &sP[pf][c4];
-                y = slot_sum4(ocur.b, ocur.na, chain_total(*(const f32x4 *)P, *(const f32x4 *)(P + Co), *(const f32x4 *)(P + 2 * Co),
-                                                           *(const f32x4 *)(P + 3 * Co), *(const f32x4 *)(P + 4 * Co)), ocur.nb);
+            const int ch[2] = {cA, cB};
+            float y[2], g[2] = {0.0f, 0.0f}, skip[2] = {0.0f, 0.0f};
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const float *P = &sP[pf][ch[k]];
+                y[k] = slot_sum(ocur.b[k], ocur.na[k], chain_total(P[0], P[Co], P[2 * Co], P[3 * Co], P[4 * Co]), ocur.nb[k]);
                 if (cur.kind == PRO_GATE) {
                     const float *G = P + NF;
-                    g = slot_sum4(ocur.bg, ocur.nag, chain_total(*(const f32x4 *)G, *(const f32x4 *)(G + Co), *(const f32x4 *)(G + 2 * Co),
-                                                                 *(const f32x4 *)(G + 3 * Co), *(const f32x4 *)(G + 4 * Co)), ocur.nbg);
+                    g[k] = slot_sum(ocur.bg[k], ocur.nag[k], chain_total(G[0], G[Co], G[2 * Co], G[3 * Co], G[4 * Co]), ocur.nbg[k]);
                 }
                 if (cur.has_skip) {
                     const float *S = P + 5 * Co;
-                    skip = chain_total(*(const f32x4 *)S, *(const f32x4 *)(S + NF), *(const f32x4 *)(S + 2 * NF),
-                                       *(const f32x4 *)(S + 3 * NF), *(const f32x4 *)(S + 4 * NF)) + ocur.b2;
+                    skip[k] = chain_total(S[0], S[NF], S[2 * NF], S[3 * NF], S[4 * NF]) + ocur.b2[k];
                 }
             }
-            PS_TRACE1(t == C1_THREADS - 64 && y.x != 12345.0f, 2);
+            PS_TRACE1(t == C1_THREADS - 64 && y[0] != 12345.0f, 2);
             post_and_emit(y, g, skip, cur);
             PS_TRACE1(t == C1_THREADS - 64, 3);
             lds_barrier();
             PS_TRACE1(t == C1_THREADS - 64, 4);
         };
-        Ops oA{zero, zero, zero, zero, zero, zero, zero}, oB = oA;
+        Ops oA, oB;
         load_ops(0, nxt, oA);
+        load_ops(0, nxt, oB);
         {   // u0 = norm_init(u_init) from k_nbr's gather
-            f32x4 y = zero;
-            if (own) y = *PS_GC(f32x4, a.upre + (size_t)pfr * NF + c4);
-            post_and_emit(y, zero, zero, cur);
+            const float *up = a.upre + (size_t)(pvalid ? pfr : 0) * NF;
+            const float y[2] = {*PS_GC(float, up + cA), *PS_GC(float, up + cB)}, z[2] = {0.0f, 0.0f};
+            post_and_emit(y, z, z, cur);
             lds_barrier();
         }
         for (int s = 0; s < NST - 3; s += 2) {
@@ -1059,43 +809,113 @@ __global__ __launch_bounds__(C1_THREADS) void k_chain1(ChainArgs a)
         load_out_weights();  // (peeled: keeps these 48 registers out of the loop)
         post_stage(NST - 2, oB, oA);
         nin_out_chains();
+
+        // ---- end of the order position: logits, categorical draw (sample.py:60-66)
+        if (pvalid) {
+            const int f = pfr;
+            const int fq = uni(a.cx.ctx[f].q);
+            const size_t loc = (size_t)f * a.L + fq;
+            float lg[8];
+            {
+                const float *Lp = &sPL[pf][0][lane * 8];
+                const f32x4 lo = chain_total(*(const f32x4 *)Lp, *(const f32x4 *)(Lp + NCLS), *(const f32x4 *)(Lp + 2 * NCLS),
+                                             *(const f32x4 *)(Lp + 3 * NCLS), *(const f32x4 *)(Lp + 4 * NCLS));
+                const f32x4 hi = chain_total(*(const f32x4 *)(Lp + 4), *(const f32x4 *)(Lp + NCLS + 4), *(const f32x4 *)(Lp + 2 * NCLS + 4),
+                                             *(const f32x4 *)(Lp + 3 * NCLS + 4), *(const f32x4 *)(Lp + 4 * NCLS + 4));
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { lg[k] = lo[k] + a.out_b[lane * 8 + k]; lg[4 + k] = hi[k] + a.out_b[lane * 8 + 4 + k]; }
+            }
+            if (a.out_logits) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) a.out_logits[loc * NCLS + lane * 8 + k] = lg[k];
+            }
+            if (a.step_logits) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) a.step_logits[(size_t)f * NCLS + lane * 8 + k] = lg[k];
+            }
+            if (a.codes && a.region[loc]) {
+                if (a.forced) {
+                    if (lane == 0) a.codes[loc] = a.forced[loc];
+                } else {
+                    const int code = draw_code(lg, a.temperature, a.uniforms[loc], lane);
+                    if (lane == 0) a.codes[loc] = code;
+                }
+            }
+        }
     } else if (swave) {
-        // ================= store wave: finished values LDS -> caches, off everybody's critical path =================
-        auto store_stage = [&](const StoreCtl &c) {  // what the post op of the record produced
-            if (!own) return;
-            const f32x4 ep = *(const f32x4 *)(&sOut[slot][1][c4]), en = *(const f32x4 *)(&sOut[slot][2][c4]);
-            if (c.kind == PRO_CONVIN) {
-                *PS_G(f32x4, c.X + off160 + c4) = ep;
-                *PS_G(f32x4, c.X + off160 + NF + c4) = en;
-            } else {
-                const f32x4 out = *(const f32x4 *)(&sOut[slot][0][c4]);
-                *PS_G(f32x4, c.R + off80 + c4) = out;
-                *PS_G(f32x4, c.E + off160 + c4) = ep;
-                *PS_G(f32x4, c.E + off160 + NF + c4) = en;
+        // ================= store wave: off everybody's critical path =================
+        size_t off80[FPW];
+        bool fvalid[FPW];
+#pragma unroll
+        for (int f = 0; f < FPW; ++f) {
+            fvalid[f] = f0 + f < a.F;
+            const int q = fvalid[f] ? a.cx.ctx[f0 + f].q : 0;
+            off80[f] = ((size_t)(fvalid[f] ? f0 + f : 0) * a.L + q) * NF;
+        }
+        const int ch[2] = {cA, cB};
+        auto store_outputs = [&](const StoreCtl &c) {  // what the post op of the record produced: LDS -> caches
+#pragma unroll
+            for (int f = 0; f < FPW; ++f) {
+                if (!fvalid[f]) continue;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    if (k == 1 && !hasB) break;
+                    const float ep = sOut[f][1][ch[k]], en = sOut[f][2][ch[k]];
+                    if (c.kind == PRO_CONVIN) {
+                        *PS_G(float, c.X + 2 * off80[f] + ch[k]) = ep;
+                        *PS_G(float, c.X + 2 * off80[f] + NF + ch[k]) = en;
+                    } else {
+                        *PS_G(float, c.R + off80[f] + ch[k]) = sOut[f][0][ch[k]];
+                        *PS_G(float, c.E + 2 * off80[f] + ch[k]) = ep;
+                        *PS_G(float, c.E + 2 * off80[f] + NF + ch[k]) = en;
+                    }
+                }
+            }
+        };
+        auto stage_skip_input = [&](const StoreCtl &c) {  // concat_elu(u_k) for the nin_skip of the stage the record feeds
+            if (c.skip_slot < 0) return;
+#pragma unroll
+            for (int f = 0; f < FPW; ++f) {
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    if (k == 1 && !hasB) break;
+                    float ep, en;
+                    celu_pair(sU[c.skip_slot][f][ch[k]], ep, en);
+                    sSkip[f][ch[k]] = ep;
+                    sSkip[f][NF + ch[k]] = en;
+                }
             }
         };
         StoreCtl sc = load_store_ctl(a.ctl1, 0);
         lds_barrier();
-        store_stage(sc);
+        store_outputs(sc);
         for (int s = 0; s < NST - 2; ++s) {
             sc = load_store_ctl(a.ctl1, 1 + s);
-            lds_barrier();   // (LDS reads of store_stage are complete: lds_barrier waits lgkmcnt(0) first)
+            lds_barrier();          // chains of stage s done: sSkip is free, the u_k were saved long ago
+            stage_skip_input(sc);   // for stage s + 1, whose chains start after the next barrier
             lds_barrier();
-            store_stage(sc);
+            store_outputs(sc);
         }
         sc = load_store_ctl(a.ctl1, NST - 1);
         load_out_weights();
         lds_barrier();
         lds_barrier();
-        store_stage(sc);
+        store_outputs(sc);
         nin_out_chains();
     } else {
         // ================= chain waves: one chain per thread and stage =================
-        f32x4 wA[8], wB[8];
-        ChainCtl cc = load_chain_ctl(a.ctl1, 1), cn = load_chain_ctl(a.ctl1, 2), cnn = cn;
-        auto chain_stage = [&](int s, const f32x4 (&wcur)[8], f32x4 (&wnxt)[8], auto last) {
+        // Three weight buffers: the fetch for stage s + 2 is issued between the barriers of stage s (under the post
+        // op), so it has a whole stage to land and the chain of stage s + 1 never waits for memory.
+        f32x4 wA[8], wB[8], wC[8];
+        ChainCtl cc = load_chain_ctl(a.ctl1, 1), cn = load_chain_ctl(a.ctl1, 2), cnn = load_chain_ctl(a.ctl1, 3), c3 = cnn;
+        auto chain_stage = [&](int s, const f32x4 (&wcur)[8], f32x4 (&wnn)[8], auto fetch, auto last) {
             PS_TRACE1(t == 0, 5);
+#ifdef PS_ABL_NOCHAIN
+            if (t < cc.nchain) sP[0][t] = wcur[0].x + wcur[7].w;
+            else if (false) {
+#else
             if (t < cc.nchain) {
+#endif
                 const bool main = cc.Co == 2 * NF || q80 < 5;
                 const int j = cc.Co == 2 * NF ? j160 : j80;
                 const float *xb = main ? &sX[0][0] : &sSkip[0][0];
@@ -1105,70 +925,46 @@ __global__ __launch_bounds__(C1_THREADS) void k_chain1(ChainArgs a)
 #pragma unroll
                 for (int f = 0; f < FPW; ++f) sP[f][t] = acc[f];
             }
-            if (last) load_out_weights();
             PS_TRACE1(t == 0 && sP[0][0] != 12345.0f, 6);
             lds_barrier();
             PS_TRACE1(t == 0, 7);
-            // the record two stages ahead: a scalar load shares lgkmcnt with the LDS reads of the chain and returns
-            // out of order, so it is issued here, where this wave only waits for the post op anyway
-            if (!last) cnn = load_chain_ctl(a.ctl1, 3 + s);  // (record NST at the end: rotated in, never used as a stage)
-            // Weights of the next stage.  The vector-memory queue is shallow: issuing these 13 x 8 KB takes the CU
-            // ~1700 cycles and blocks the issuing wave, so it happens here, under the post op, not ahead of the chain.
-            if (!last) load_chain_weights(cn.wv, cn.nchain, cn.nstep, t, wnxt);
+            // The vector-memory queue is shallow: issuing a stage's 13 x 8 KB takes the CU ~1700 cycles and blocks the
+            // issuing wave, so it happens here, where this wave only waits for the post op.  Same for the scalar load
+            // of the control record three stages ahead (it shares lgkmcnt with the LDS reads of the chain).
+#ifdef PS_ABL_NOFETCH
+            if (false) {
+#else
+            if (fetch) {
+#endif
+                c3 = load_chain_ctl(a.ctl1, 4 + s);  // (records past NST - 1 are rotated in but never used as stages)
+                load_chain_weights(cnn.wv, cnn.nchain, cnn.nstep, t, wnn);
+            }
+            if (last) load_out_weights();
             lds_barrier();
             PS_TRACE1(t == 0, 8);
             cc = cn;
             cn = cnn;
+            cnn = c3;
         };
         load_chain_weights(cc.wv, cc.nchain, cc.nstep, t, wA);
+        load_chain_weights(cn.wv, cn.nchain, cn.nstep, t, wB);
         lds_barrier();
-        for (int s = 0; s < NST - 3; s += 2) {
-            chain_stage(s, wA, wB, std::false_type{});
-            chain_stage(s + 1, wB, wA, std::false_type{});
+        const std::true_type yes{};
+        const std::false_type no{};
+        for (int s = 0; s < NST - 3; s += 3) {  // stages 0 .. 29
+            chain_stage(s, wA, wC, yes, no);
+            chain_stage(s + 1, wB, wA, yes, no);
+            chain_stage(s + 2, wC, wB, yes, no);
         }
-        chain_stage(NST - 3, wA, wB, std::false_type{});
-        chain_stage(NST - 2, wB, wA, std::true_type{});
+        chain_stage(NST - 3, wA, wC, no, no);   // stage 30 (its successor's weights were fetched during stage 29)
+        chain_stage(NST - 2, wB, wA, no, yes);  // stage 31, then the nin_out weights
         nin_out_chains();
     }
 #undef PS_TRACE1
 
-
-    // ---- end of the order position: logits, categorical draw (sample.py:60-66), next context
-    const bool pvalid = pwave && pfr < a.F;
-    if (pvalid) {
-        const int f = pfr;
-        const int fq = uni(a.cx.ctx[f].q);
-        const size_t loc = (size_t)f * a.L + fq;
-        float lg[8];
-        {
-            const float *Lp = &sPL[pf][0][lane * 8];
-            const f32x4 lo = chain_total(*(const f32x4 *)Lp, *(const f32x4 *)(Lp + NCLS), *(const f32x4 *)(Lp + 2 * NCLS),
-                                         *(const f32x4 *)(Lp + 3 * NCLS), *(const f32x4 *)(Lp + 4 * NCLS));
-            const f32x4 hi = chain_total(*(const f32x4 *)(Lp + 4), *(const f32x4 *)(Lp + NCLS + 4), *(const f32x4 *)(Lp + 2 * NCLS + 4),
-                                         *(const f32x4 *)(Lp + 3 * NCLS + 4), *(const f32x4 *)(Lp + 4 * NCLS + 4));
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { lg[k] = lo[k] + a.out_b[lane * 8 + k]; lg[4 + k] = hi[k] + a.out_b[lane * 8 + 4 + k]; }
-        }
-        if (a.out_logits) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) a.out_logits[loc * NCLS + lane * 8 + k] = lg[k];
-        }
-        if (a.step_logits) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) a.step_logits[(size_t)f * NCLS + lane * 8 + k] = lg[k];
-        }
-        if (a.codes && a.region[loc]) {
-            if (a.forced) {
-                if (lane == 0) a.codes[loc] = a.forced[loc];
-            } else {
-                const int code = draw_code(lg, a.temperature, a.uniforms[loc], lane);
-                if (lane == 0) a.codes[loc] = code;
-            }
-        }
-    }
     if (a.advance) {
-        __syncthreads();  // every wave read its ctx[f].q above / at kernel start; the draws are done
-        if (pvalid && lane < 32) ctx_fill(a.cx, pfr, a.cx.ctx[pfr].step + 1, lane);
+        __syncthreads();  // every wave read the ctx[f].q it needs above; the draws are done
+        if (pwave && f0 + pf < a.F && lane < 32) ctx_fill(a.cx, f0 + pf, a.cx.ctx[f0 + pf].step + 1, lane);
     }
 }
 
@@ -1307,7 +1103,6 @@ struct ps_pixelcnn {
     hipGraph_t graph = nullptr;          // step graph of the last ar_run (kept alive until replaced)
     hipGraphExec_t graph_exec = nullptr;
     bool use_graph = true;
-    int chain_kernel = 0;  // 0 = by frame count, 1 = k_chain1 (VALU, one CU per frame), 2 = k_chain (MFMA, 16 frames per CU); PS_CHAIN_KERNEL
     // bench.py profiling aid (ps_pixelcnn_time_column_step): event pair around every launch, by kernel tag
     struct ProfRec { int tag; hipEvent_t e0, e1; };
     std::vector<ProfRec> *prof = nullptr;
@@ -1537,11 +1332,7 @@ void run_column(ps_pixelcnn *h, int F, const int32_t *codes, ChainArgs ca, hipSt
     ca.stages = h->stages; ca.ctl1 = h->ctl1; ca.nbr = h->nbr; ca.upre = h->upre;
     ca.out_b = h->out_b;
     ca.H = h->H; ca.W = h->W; ca.L = h->L; ca.F = F;
-    // few frames: one CU per frame on the vector ALU; many: 16-frame MFMA tiles (same bits either way)
-    if (h->chain_kernel == 1 || (h->chain_kernel == 0 && F <= VALU_CHAIN_MAX_FRAMES))
-        timed(h, st, TAG_CHAIN, [&]() { hipLaunchKernelGGL(k_chain1<1>, dim3(F), dim3(C1_THREADS), 0, st, ca); });
-    else
-        timed(h, st, TAG_CHAIN, [&]() { hipLaunchKernelGGL(k_chain, dim3(tiles), dim3(CHAIN_WAVES * 64), 0, st, ca); });
+    timed(h, st, TAG_CHAIN, [&]() { hipLaunchKernelGGL(k_chain1<1>, dim3(F), dim3(C1_THREADS), 0, st, ca); });
 }
 
 CtxArgs make_ctx_args(ps_pixelcnn *h, const int32_t *order, const Masks &m, int F)
@@ -1577,7 +1368,6 @@ int ps_pixelcnn_create(const float *const *params, int n_params, int H, int W, i
     // caller's stream by default; PS_AR_GRAPH=1 replays it as a hipGraph on a stream owned by the handle instead.
     const char *env = getenv("PS_AR_GRAPH");
     h->use_graph = env && env[0] == '1';
-    if (const char *ck = getenv("PS_CHAIN_KERNEL")) h->chain_kernel = !strcmp(ck, "valu") ? 1 : !strcmp(ck, "mfma") ? 2 : 0;
     int rc = PS_OK;
     auto fail_out = [&](int code) { ps_pixelcnn_destroy(h); return code; };
 
