@@ -422,7 +422,21 @@ struct NbrArgs {
     const int32_t *codes;
     const float *uinit_w, *uinit_b;
     int nwork, H, W, L, F;
+    int chain_xcds;  // XCDs 0 .. chain_xcds-1 are left to k_chain1 (see xcd_slot); 0 = use every XCD
 };
+
+// XCD affinity, for speed only (nothing depends on it): workgroup b of a launch runs on XCD b % 8, each XCD with
+// its own 4 MB L2.  One order position streams ~3 MB of centre-tap weights per chain workgroup and ~9-18 MB of
+// neighbour-tap weights through k_nbr; sharing L2s, the two evict each other every position.  So the chain
+// workgroups are packed onto the first `chain_xcds` XCDs and k_nbr keeps to the others: both weight sets then
+// stay L2-resident from one position to the next.  Returns the compact index of this workgroup among those of
+// its kernel's XCDs, or -1 if it sits on the other kernel's XCDs (it exits at once).
+__device__ __forceinline__ int xcd_slot(int b, int lo, int hi /*use XCDs lo .. hi-1*/)
+{
+    const int x = b & 7;
+    if (x < lo || x >= hi) return -1;
+    return (b >> 3) * (hi - lo) + (x - lo);
+}
 
 // one neighbour tap of one conv for 16 frames x 16 output channels, from fresh accumulators
 template <int NG>
@@ -463,8 +477,12 @@ __device__ __forceinline__ f32x4 nbr_tap(const StageDesc &sd, const NbrArgs &a, 
 // the 4 taps of the slot and the partials are added in tap order (the order k_gemm uses)
 __global__ __launch_bounds__(256) void k_nbr(NbrArgs a)
 {
-    if ((int)blockIdx.x >= a.nwork) {  // last 4 work items: the u_init gather, one wave per frame, 20 groups of 4
-        const int f = blockIdx.y * 16 + ((int)blockIdx.x - a.nwork) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int slot = xcd_slot(blockIdx.x, a.chain_xcds, 8);
+    const int per_tile = a.nwork + 4;
+    if (slot < 0 || slot >= per_tile * ((a.F + 15) / 16)) return;
+    const int ftile = slot / per_tile, witem = slot - ftile * per_tile;
+    if (witem >= a.nwork) {  // last 4 work items: the u_init gather, one wave per frame, 20 groups of 4
+        const int f = ftile * 16 + (witem - a.nwork) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
         if (f >= a.F || lane >= NGRP) return;
         float mA[9];
 #pragma unroll
@@ -474,11 +492,11 @@ __global__ __launch_bounds__(256) void k_nbr(NbrArgs a)
         return;
     }
     __shared__ __attribute__((aligned(16))) float sP[4][16][20];
-    const NbrWork wk = a.work[blockIdx.x];
+    const NbrWork wk = a.work[witem];
     const StageDesc sd = a.stages[wk.stage];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, kk = lane >> 4;
     const int o0 = wk.cog * 16;
-    const int f = blockIdx.y * 16 + i;
+    const int f = ftile * 16 + i;
     const bool valid = f < a.F;
     const int t = wk.half * 5 + wave;  // taps 0..3 (NA) or 5..8 (NB)
     const f32x4 part = sd.NG == 10 ? nbr_tap<10>(sd, a, t, o0, f, valid, i, kk) : nbr_tap<5>(sd, a, t, o0, f, valid, i, kk);
@@ -510,6 +528,7 @@ struct ChainArgs {
     float *step_logits;       // (F,512) or null
     float temperature;
     int advance;              // 1: write the context of step+1
+    int chain_xcds;            // k_chain1 workgroups only work on XCDs 0 .. chain_xcds-1 (xcd_slot); 8 = all
     unsigned long long *trace; // optional [NST][10] shader-clock stamps of workgroup 0 (tuning aid)
     int ablate;                // tuning aid (PS_CHAIN_ABLATE): 1 no cache stores, 2 no slot prefetch, 4 no MFMA, 8 no post math
 };
@@ -650,7 +669,9 @@ __global__ __launch_bounds__(C1_THREADS) void k_chain1(ChainArgs a)
     __shared__ __attribute__((aligned(16))) float sOut[FPW][3][NF];      // (u, elu(u), elu(-u)) on their way to the caches
     __shared__ __attribute__((aligned(16))) float sPL[FPW][5][NCLS];     // chain values of nin_out
     const int t = threadIdx.x, wave = uni(t >> 6), lane = t & 63;
-    const int f0 = blockIdx.x * FPW;
+    const int wg = xcd_slot(blockIdx.x, 0, a.chain_xcds);
+    if (wg < 0 || wg * FPW >= a.F) return;
+    const int f0 = wg * FPW;
     // Roles, each in its own wave-uniform branch (so their registers do not add up):
     //   waves 0..12         one chain per thread and stage
     //   wave 13             cache stores (finished values LDS -> R / E / X) and the nin_skip inputs
@@ -667,7 +688,7 @@ __global__ __launch_bounds__(C1_THREADS) void k_chain1(ChainArgs a)
     __syncthreads();
 
 #ifdef PS_CHAIN_TRACE_BUILD  // tuning builds only: the stamps' stores perturb the waitcnt placement
-#define PS_TRACE1(who, slot) do { if (a.trace && blockIdx.x == 0 && (who)) a.trace[s * 10 + (slot)] = clock64(); } while (0)
+#define PS_TRACE1(who, slot) do { if (a.trace && wg == 0 && (who)) a.trace[s * 10 + (slot)] = clock64(); } while (0)
 #else
 #define PS_TRACE1(who, slot) do { } while (0)
 #endif
@@ -1103,6 +1124,7 @@ struct ps_pixelcnn {
     hipGraph_t graph = nullptr;          // step graph of the last ar_run (kept alive until replaced)
     hipGraphExec_t graph_exec = nullptr;
     bool use_graph = true;
+    bool xcd_pack = true;  // PS_XCD_PACK=0 turns the XCD split of the column kernels off
     // bench.py profiling aid (ps_pixelcnn_time_column_step): event pair around every launch, by kernel tag
     struct ProfRec { int tag; hipEvent_t e0, e1; };
     std::vector<ProfRec> *prof = nullptr;
@@ -1325,14 +1347,21 @@ int build_stage_table(ps_pixelcnn *h)
 // describe the current position.
 void run_column(ps_pixelcnn *h, int F, const int32_t *codes, ChainArgs ca, hipStream_t st)
 {
-    NbrArgs na{h->stages, h->work, h->ctx, h->nbr, h->upre, codes, h->uinit_w, h->uinit_b, h->nwork, h->H, h->W, h->L, F};
-    const int tiles = (F + 15) / 16;
-    if (!(h->prof && getenv("PS_PROF_SKIP_NBR")))  // tuning aid: time the chain alone (its weights then stay in L2)
-        timed(h, st, TAG_NBR, [&]() { hipLaunchKernelGGL(k_nbr, dim3(h->nwork + 4, tiles), dim3(256), 0, st, na); });
+    // XCD split (xcd_slot): up to 32 frames, the chain workgroups fill XCD 0 (32 CUs) and k_nbr takes XCDs 1..7
+    // (V=16: chain 47.5 -> 42.5 us); with more frames k_nbr needs the whole chip (V=64: the split costs it 9 us)
+    const int cx = (h->xcd_pack && F <= 32) ? 1 : 8;
+    NbrArgs na{h->stages, h->work, h->ctx, h->nbr, h->upre, codes, h->uinit_w, h->uinit_b, h->nwork, h->H, h->W, h->L, F,
+               cx == 8 ? 0 : cx};
+    const int tiles = (F + 15) / 16, nbr_wgs = (h->nwork + 4) * tiles, nbr_xcds = 8 - na.chain_xcds;
+    if (!(h->prof && getenv("PS_PROF_SKIP_NBR")))  // tuning aid: time the chain alone
+        timed(h, st, TAG_NBR, [&]() {
+            hipLaunchKernelGGL(k_nbr, dim3((nbr_wgs + nbr_xcds - 1) / nbr_xcds * 8), dim3(256), 0, st, na);
+        });
     ca.stages = h->stages; ca.ctl1 = h->ctl1; ca.nbr = h->nbr; ca.upre = h->upre;
     ca.out_b = h->out_b;
     ca.H = h->H; ca.W = h->W; ca.L = h->L; ca.F = F;
-    timed(h, st, TAG_CHAIN, [&]() { hipLaunchKernelGGL(k_chain1<1>, dim3(F), dim3(C1_THREADS), 0, st, ca); });
+    ca.chain_xcds = cx;
+    timed(h, st, TAG_CHAIN, [&]() { hipLaunchKernelGGL(k_chain1<1>, dim3((F + cx - 1) / cx * 8), dim3(C1_THREADS), 0, st, ca); });
 }
 
 CtxArgs make_ctx_args(ps_pixelcnn *h, const int32_t *order, const Masks &m, int F)
@@ -1368,6 +1397,7 @@ int ps_pixelcnn_create(const float *const *params, int n_params, int H, int W, i
     // caller's stream by default; PS_AR_GRAPH=1 replays it as a hipGraph on a stream owned by the handle instead.
     const char *env = getenv("PS_AR_GRAPH");
     h->use_graph = env && env[0] == '1';
+    if (const char *xp = getenv("PS_XCD_PACK")) h->xcd_pack = xp[0] != '0';
     int rc = PS_OK;
     auto fail_out = [&](int code) { ps_pixelcnn_destroy(h); return code; };
 
