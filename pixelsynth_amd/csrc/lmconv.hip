@@ -215,15 +215,20 @@ __device__ __forceinline__ float dpp_xadd(float x)
     return x + __int_as_float(moved);
 }
 __device__ __forceinline__ float lane_value(float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); }
-// sum over the 80 channels of an item; b MUST be 0 in lanes >= 16.  Every lane gets the same bits.
+// sum over the 80 channels of an item; b MUST be 0 in lanes >= 16.  The result is wave-uniform.
+//   v_l = a_l + b_l; butterfly over the 16 lanes of every row (pairs, quads, octets, row); then
+//   T = (R2 + R3) + (R0 + R1) with R_k the sum of row k.
 __device__ __forceinline__ float pono_total(float a, float b)
 {
     float x = a + b;
     x = dpp_xadd<0xB1>(x);    // quad_perm [1,0,3,2]: pairs
     x = dpp_xadd<0x4E>(x);    // quad_perm [2,3,0,1]: quads
     x = dpp_xadd<0x141>(x);   // row_half_mirror: octets
-    x = dpp_xadd<0x140>(x);   // row_mirror: the 16 lanes of a row
-    return (lane_value(x, 0) + lane_value(x, 16)) + (lane_value(x, 32) + lane_value(x, 48));
+    x = dpp_xadd<0x140>(x);   // row_mirror: every lane of row k now holds R_k
+    // row_bcast:15 into rows 1 and 3: R1 + R0, R3 + R2;  row_bcast:31 into rows 2, 3: row 3 = (R3 + R2) + (R1 + R0)
+    x = x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x142, 0xa, 0xf, false));
+    x = x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x143, 0xc, 0xf, false));
+    return lane_value(x, 63);
 }
 
 // u_init on one-hot input as a gather, type-A mask (model.py:132), BEFORE norm_init:
@@ -675,8 +680,9 @@ __global__ __launch_bounds__(C1_THREADS) void k_chain1(ChainArgs a)
     // Roles, each in its own wave-uniform branch (so their registers do not add up):
     //   waves 0..12         one chain per thread and stage
     //   wave 13             cache stores (finished values LDS -> R / E / X) and the nin_skip inputs
+    //   wave 14             touches the control records ahead of everybody (scalar-cache prefetch)
     //   waves 16-FPW..15    post op of one frame each, one channel per lane (see pono_total)
-    constexpr int NW = C1_THREADS / 64, STORE_WAVE = 13;
+    constexpr int NW = C1_THREADS / 64, STORE_WAVE = 13, CTL_WAVE = 14;
     const int pf = wave - (NW - FPW);  // frame slot of a post wave, negative otherwise
     const bool pwave = pf >= 0, swave = wave == STORE_WAVE;
     const bool hasB = lane < NB_LANES;
@@ -687,8 +693,9 @@ __global__ __launch_bounds__(C1_THREADS) void k_chain1(ChainArgs a)
     if (t < FPW * SX_LD) { (&sX[0][0])[t] = 0.0f; (&sSkip[0][0])[t] = 0.0f; }  // absent frames feed zeros
     __syncthreads();
 
-#ifdef PS_CHAIN_TRACE_BUILD  // tuning builds only: the stamps' stores perturb the waitcnt placement
-#define PS_TRACE1(who, slot) do { if (a.trace && wg == 0 && (who)) a.trace[s * 10 + (slot)] = clock64(); } while (0)
+#ifdef PS_CHAIN_TRACE_BUILD  // tuning builds only: shader-clock stamps of workgroup 0, collected in LDS, dumped at the end
+    __shared__ unsigned long long sTrace[NST][10];
+#define PS_TRACE1(who, slot) do { if (who) sTrace[s][slot] = clock64(); } while (0)
 #else
 #define PS_TRACE1(who, slot) do { } while (0)
 #endif
@@ -745,8 +752,12 @@ __global__ __launch_bounds__(C1_THREADS) void k_chain1(ChainArgs a)
                 o.b2[k] = *PS_GC(float, b2 + ch[k]);
             }
         };
-        // PONO + finish + hand-off to the next stage
-        auto post_and_emit = [&](const float (&y)[2], const float (&g)[2], const float (&skip)[2], const PostCtl &c) {
+        // PONO + finish + hand-off to the next stage.  Compiled once per (kind, skip, input form) combination that
+        // occurs in the network, so the body is straight-line code; only save_slot stays a run-time value.
+        auto post_and_emit = [&](const float (&y)[2], const float (&g)[2], const float (&skip)[2], auto KIND, auto SKIP,
+                                 auto INFORM, int save_slot) {
+            constexpr int kind = decltype(KIND)::value, in_form = decltype(INFORM)::value;
+            constexpr bool has_skip = decltype(SKIP)::value;
 #ifdef PS_ABL_NOPOST
             sX[pf][cA] = y[0] + g[0] + skip[0];
             return;
@@ -761,24 +772,47 @@ __global__ __launch_bounds__(C1_THREADS) void k_chain1(ChainArgs a)
                 if (k == 1 && !hasB) break;
                 const float n = d[k] * inv;
                 float out;
-                if (c.kind == PRO_CONVIN) out = post_finish<POST_CONVIN>(n, 0.0f, skip[k], c.has_skip != 0, 0.0f);
-                else if (c.kind == PRO_GATE) out = post_finish<POST_GATE>(n, g[k], 0.0f, false, ucur[k]);
+                if (kind == PRO_CONVIN) out = post_finish<POST_CONVIN>(n, 0.0f, skip[k], has_skip, 0.0f);
+                else if (kind == PRO_GATE) out = post_finish<POST_GATE>(n, g[k], 0.0f, false, ucur[k]);
                 else out = n;  // PRO_DIL, PRO_UINIT (norm_init)
                 float ep, en;
                 celu_pair(out, ep, en);
                 float *x = &sX[pf][ch[k]];
-                if (c.in_form == IN_CELU) { x[0] = ep; x[NF] = en; }
-                else if (c.in_form == IN_RAW) x[0] = out;
+                if (in_form == IN_CELU) { x[0] = ep; x[NF] = en; }
+                else if (in_form == IN_RAW) x[0] = out;
                 else x[0] = ep;
                 sOut[pf][1][ch[k]] = ep;
                 sOut[pf][2][ch[k]] = en;
-                if (c.kind != PRO_CONVIN) {
+                if (kind != PRO_CONVIN) {
                     sOut[pf][0][ch[k]] = out;
                     ucur[k] = out;
-                    if (c.save_slot >= 0) sU[c.save_slot][pf][ch[k]] = out;
+                    if (save_slot >= 0) sU[save_slot][pf][ch[k]] = out;
                 }
             }
         };
+        // y (+ gate half, + nin_skip) of this stage from the chain values and the prefetched operands, then the post op
+        auto post_body = [&](const Ops &o, auto KIND, auto SKIP, auto INFORM, int save_slot) {
+            constexpr int kind = decltype(KIND)::value;
+            constexpr bool has_skip = decltype(SKIP)::value;
+            constexpr int Co = kind == PRO_GATE ? 2 * NF : NF;
+            const int ch[2] = {cA, cB};
+            float y[2], g[2] = {0.0f, 0.0f}, skip[2] = {0.0f, 0.0f};
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const float *P = &sP[pf][ch[k]];
+                y[k] = slot_sum(o.b[k], o.na[k], chain_total(P[0], P[Co], P[2 * Co], P[3 * Co], P[4 * Co]), o.nb[k]);
+                if (kind == PRO_GATE) {
+                    const float *G = P + NF;
+                    g[k] = slot_sum(o.bg[k], o.nag[k], chain_total(G[0], G[Co], G[2 * Co], G[3 * Co], G[4 * Co]), o.nbg[k]);
+                }
+                if (has_skip) {
+                    const float *S = P + 5 * Co;
+                    skip[k] = chain_total(S[0], S[NF], S[2 * NF], S[3 * NF], S[4 * NF]) + o.b2[k];
+                }
+            }
+            post_and_emit(y, g, skip, KIND, SKIP, INFORM, save_slot);
+        };
+        using std::integral_constant;
         PostCtl cur = load_post_ctl(a.ctl1, 0), nxt = load_post_ctl(a.ctl1, 1), nn = load_post_ctl(a.ctl1, 2);
         auto post_stage = [&](int s, const Ops &ocur, Ops &onxt) {
             cur = nxt;                                              // record 1 + s
@@ -791,24 +825,19 @@ __global__ __launch_bounds__(C1_THREADS) void k_chain1(ChainArgs a)
             if (s + 1 < NST - 1) load_ops(s + 1, nxt, onxt);
             lds_barrier();   // the chains of this stage are in sP
             PS_TRACE1(t == C1_THREADS - 64, 1);
-            const int Co = cur.Co;
-            const int ch[2] = {cA, cB};
-            float y[2], g[2] = {0.0f, 0.0f}, skip[2] = {0.0f, 0.0f};
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const float *P = &sP[pf][ch[k]];
-                y[k] = slot_sum(ocur.b[k], ocur.na[k], chain_total(P[0], P[Co], P[2 * Co], P[3 * Co], P[4 * Co]), ocur.nb[k]);
-                if (cur.kind == PRO_GATE) {
-                    const float *G = P + NF;
-                    g[k] = slot_sum(ocur.bg[k], ocur.nag[k], chain_total(G[0], G[Co], G[2 * Co], G[3 * Co], G[4 * Co]), ocur.nbg[k]);
-                }
-                if (cur.has_skip) {
-                    const float *S = P + 5 * Co;
-                    skip[k] = chain_total(S[0], S[NF], S[2 * NF], S[3 * NF], S[4 * NF]) + ocur.b2[k];
-                }
+            const integral_constant<bool, true> yes{};
+            const integral_constant<bool, false> no{};
+            const integral_constant<int, IN_CELU> celu{};
+            if (cur.kind == PRO_CONVIN) {
+                if (cur.has_skip) post_body(ocur, integral_constant<int, PRO_CONVIN>{}, yes, celu, -1);
+                else post_body(ocur, integral_constant<int, PRO_CONVIN>{}, no, celu, -1);
+            } else if (cur.kind == PRO_GATE) {
+                if (cur.in_form == IN_CELU) post_body(ocur, integral_constant<int, PRO_GATE>{}, no, celu, cur.save_slot);
+                else if (cur.in_form == IN_RAW) post_body(ocur, integral_constant<int, PRO_GATE>{}, no, integral_constant<int, IN_RAW>{}, cur.save_slot);
+                else post_body(ocur, integral_constant<int, PRO_GATE>{}, no, integral_constant<int, IN_ELU>{}, cur.save_slot);
+            } else {
+                post_body(ocur, integral_constant<int, PRO_DIL>{}, no, celu, cur.save_slot);
             }
-            PS_TRACE1(t == C1_THREADS - 64 && y[0] != 12345.0f, 2);
-            post_and_emit(y, g, skip, cur);
             PS_TRACE1(t == C1_THREADS - 64, 3);
             lds_barrier();
             PS_TRACE1(t == C1_THREADS - 64, 4);
@@ -819,7 +848,8 @@ __global__ __launch_bounds__(C1_THREADS) void k_chain1(ChainArgs a)
         {   // u0 = norm_init(u_init) from k_nbr's gather
             const float *up = a.upre + (size_t)(pvalid ? pfr : 0) * NF;
             const float y[2] = {*PS_GC(float, up + cA), *PS_GC(float, up + cB)}, z[2] = {0.0f, 0.0f};
-            post_and_emit(y, z, z, cur);
+            post_and_emit(y, z, z, integral_constant<int, PRO_UINIT>{}, integral_constant<bool, false>{},
+                          integral_constant<int, IN_CELU>{}, cur.save_slot);
             lds_barrier();
         }
         for (int s = 0; s < NST - 3; s += 2) {
@@ -910,18 +940,41 @@ __global__ __launch_bounds__(C1_THREADS) void k_chain1(ChainArgs a)
         StoreCtl sc = load_store_ctl(a.ctl1, 0);
         lds_barrier();
         store_outputs(sc);
+        StoreCtl sn = load_store_ctl(a.ctl1, 1);
         for (int s = 0; s < NST - 2; ++s) {
-            sc = load_store_ctl(a.ctl1, 1 + s);
+            sc = sn;                // record 1 + s
             lds_barrier();          // chains of stage s done: sSkip is free, the u_k were saved long ago
             stage_skip_input(sc);   // for stage s + 1, whose chains start after the next barrier
+            sn = load_store_ctl(a.ctl1, 2 + s);  // waited for at the next barrier, under the post op
             lds_barrier();
             store_outputs(sc);
         }
-        sc = load_store_ctl(a.ctl1, NST - 1);
+        sc = sn;                    // record NST - 1
         load_out_weights();
         lds_barrier();
         lds_barrier();
         store_outputs(sc);
+        nin_out_chains();
+    } else if (wave == CTL_WAVE) {
+        // ================= control-record prefetch: keeps the scalar cache ahead of every other wave =================
+        // A record is first touched here, between the barriers of stage s (nobody waits for this wave then), three
+        // stages before the chain waves and two before the post / store waves ask for it: their s_loads hit.
+        int keep = 0;
+        auto touch = [&](int rec) {
+            rec = min(rec, NST);
+            keep ^= ctl_i(a.ctl1, rec, 0) ^ ctl_i(a.ctl1, rec, 16);  // both 64-byte lines of the 96-byte record
+        };
+        for (int r = 0; r < 6; ++r) touch(r);
+        lds_barrier();
+        for (int s = 0; s < NST - 2; ++s) {
+            lds_barrier();
+            touch(6 + s);
+            lds_barrier();
+        }
+        load_out_weights();
+        lds_barrier();
+        lds_barrier();
+        if (keep == 0x5eed1234) sP[0][0] = 0.0f;  // (keeps the loads alive)
         nin_out_chains();
     } else {
         // ================= chain waves: one chain per thread and stage =================
@@ -983,6 +1036,11 @@ __global__ __launch_bounds__(C1_THREADS) void k_chain1(ChainArgs a)
     }
 #undef PS_TRACE1
 
+#ifdef PS_CHAIN_TRACE_BUILD
+    __syncthreads();
+    if (a.trace && wg == 0)
+        for (int k = t; k < (NST - 1) * 10; k += C1_THREADS) a.trace[k] = (&sTrace[0][0])[k];
+#endif
     if (a.advance) {
         __syncthreads();  // every wave read the ctx[f].q it needs above; the draws are done
         if (pwave && f0 + pf < a.F && lane < 32) ctx_fill(a.cx, f0 + pf, a.cx.ctx[f0 + pf].step + 1, lane);
