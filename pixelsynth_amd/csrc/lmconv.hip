@@ -94,8 +94,23 @@ __device__ __forceinline__ f32x4 chunk_total(const Acc5 &a) { return chain_total
 // ==========================================================================================
 // whole-grid mode: items = (frame, location) pairs of the full grid
 // ==========================================================================================
+// Items of a whole-grid pass: every (frame, location) pair, or -- with a generation order -- only the first
+// `npre` locations of each frame in that order (the observed prefix an AR run starts from; later locations
+// are produced by the column steps, and no earlier location ever reads them).
+struct ItemMap {
+    const int32_t *order;  // (F, L) location by rank, or null = all L locations in raster order
+    int npre;              // locations per frame
+};
+__device__ __forceinline__ void item_loc(const ItemMap &m, int item, int L, int &f, int &q)
+{
+    f = item / m.npre;
+    const int r = item - f * m.npre;
+    q = m.order ? m.order[(size_t)f * L + r] : r;
+}
+
 struct GemmArgs {
     GemmTap tap[MAX_TAPS];
+    ItemMap items;
     int slot_first[5];  // slot s covers taps [slot_first[s], slot_first[s+1])
     int nslots, Cin, Co_pad, H, W, L, nitems, tiles_per_block;
     const float *mask;
@@ -117,8 +132,7 @@ __global__ __launch_bounds__(64) void k_gemm(GemmArgs a)
         const bool valid = item < a.nitems;
         int f = 0, r = 0, c = 0, q = 0;
         if (valid) {
-            f = item / a.L;
-            q = item - f * a.L;
+            item_loc(a.items, item, a.L, f, q);
             r = q / a.W;
             c = q - r * a.W;
         }
@@ -270,6 +284,7 @@ __device__ __forceinline__ void store_raw_celu(float *R, float *E, size_t loc, i
 }
 
 struct PostArgs {
+    ItemMap items;
     const float *partial;  // [slots][nitems][Co_pad]
     int nitems, Co_pad, L, has_skip;
     const float *bias, *bias2;
@@ -283,7 +298,9 @@ __global__ __launch_bounds__(256) void k_post_grid(PostArgs a)
 {
     const int item = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (item >= a.nitems) return;  // whole waves leave together
-    const size_t loc = item;       // item = f*L + q
+    int f, q;
+    item_loc(a.items, item, a.L, f, q);
+    const size_t loc = (size_t)f * a.L + q;
     const size_t ss = (size_t)a.nitems * a.Co_pad;
     const float *P = a.partial + (size_t)item * a.Co_pad;
     const bool hasB = lane < NB_LANES;
@@ -319,6 +336,7 @@ __global__ __launch_bounds__(256) void k_post_grid(PostArgs a)
 }
 
 struct UinitArgs {
+    ItemMap items;
     const int32_t *codes;  // (F,L), -1 = all-zero input
     const float *mask;     // mask_init (F,9,L)
     const float *w;        // [9][513][NF]
@@ -331,7 +349,9 @@ __global__ __launch_bounds__(256) void k_uinit_grid(UinitArgs a)
 {
     const int item = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (item >= a.nitems) return;
-    const int f = item / a.L, q = item - f * a.L;
+    int f, q;
+    item_loc(a.items, item, a.L, f, q);
+    const size_t loc = (size_t)f * a.L + q;
     const bool hasB = lane < NB_LANES;
     float mA[9];
 #pragma unroll
@@ -342,20 +362,21 @@ __global__ __launch_bounds__(256) void k_uinit_grid(UinitArgs a)
     const float mean = pono_mean(pono_total(yA, hasB ? yB : 0.0f));   // norm_init
     const float dA = yA - mean, dB = yB - mean;
     const float inv = pono_inv(pono_total(dA * dA, hasB ? dB * dB : 0.0f));
-    store_raw_celu(a.Rout, a.Eout, (size_t)item, lane, dA * inv);
-    if (hasB) store_raw_celu(a.Rout, a.Eout, (size_t)item, cB, dB * inv);
+    store_raw_celu(a.Rout, a.Eout, loc, lane, dA * inv);
+    if (hasB) store_raw_celu(a.Rout, a.Eout, loc, cB, dB * inv);
 }
 
 // logits = nin_out partial + bias; nchw: (F,512,H,W) like the reference, else (nitems,512)
-__global__ __launch_bounds__(256) void k_logits_grid(const float *partial, const float *bias, int nitems, int L,
+__global__ __launch_bounds__(256) void k_logits_grid(ItemMap items, const float *partial, const float *bias, int nitems, int L,
                                                      int nchw, float *logits)
 {
     const int item = blockIdx.x;
-    const int f = item / L, q = item - f * L;
+    int f, q;
+    item_loc(items, item, L, f, q);
     for (int o = threadIdx.x; o < NCLS; o += 256) {
         const float v = partial[(size_t)item * NCLS + o] + bias[o];
         if (nchw) logits[((size_t)f * NCLS + o) * L + q] = v;
-        else logits[(size_t)item * NCLS + o] = v;
+        else logits[((size_t)f * L + q) * NCLS + o] = v;
     }
 }
 
@@ -1252,18 +1273,22 @@ void conv_taps(GemmArgs &a, const float *in, int ld, const float *wp, int Cin, i
 // whole-grid evaluation (reference-faithful forward; cache build before the column steps)
 // logits: null (caches only), (F,512,H,W) when nchw, else (F*L,512) by location
 // ------------------------------------------------------------------------------------------
-void run_grid(ps_pixelcnn *h, int F, const int32_t *codes, const Masks &m, float *logits, bool nchw, hipStream_t st)
+void run_grid(ps_pixelcnn *h, int F, const int32_t *codes, const Masks &m, float *logits, bool nchw, hipStream_t st,
+              const int32_t *order = nullptr, int npre = -1)
 {
-    const int nitems = F * h->L;
+    const ItemMap items{order, order ? npre : h->L};
+    const int nitems = F * items.npre;
+    if (nitems <= 0) return;  // an AR run that starts at rank 0 has no prefix
     const int pblocks = (nitems + 3) / 4;
     auto gemm = [&](GemmArgs &a, const float *mask) {
+        a.items = items;
         a.H = h->H; a.W = h->W; a.L = h->L; a.nitems = nitems;
         a.mask = mask; a.mask_fstride = (size_t)9 * h->L; a.partial = h->partial; a.tiles_per_block = 8;
         const int tiles = (nitems + 15) / 16;
         hipLaunchKernelGGL(k_gemm, dim3(a.Co_pad / 16, a.nslots, (tiles + 7) / 8), dim3(64), 0, st, a);
     };
     {   // u_init + norm_init  (model.py:132)
-        UinitArgs u{codes, m.init, h->uinit_w, h->uinit_b, h->R[0], h->E[0], h->H, h->W, h->L, nitems};
+        UinitArgs u{items, codes, m.init, h->uinit_w, h->uinit_b, h->R[0], h->E[0], h->H, h->W, h->L, nitems};
         hipLaunchKernelGGL(k_uinit_grid, dim3(pblocks), dim3(256), 0, st, u);
     }
     auto gated = [&](int g) {
@@ -1276,12 +1301,12 @@ void run_grid(ps_pixelcnn *h, int F, const int32_t *codes, const Masks &m, float
             a.nslots = 4;
         }
         gemm(a, m.und);
-        PostArgs p{h->partial, nitems, NF, h->L, G.node_skip >= 0, G.b_in, G.b_skip, nullptr, nullptr, nullptr, h->X[g]};
+        PostArgs p{items, h->partial, nitems, NF, h->L, G.node_skip >= 0, G.b_in, G.b_skip, nullptr, nullptr, nullptr, h->X[g]};
         hipLaunchKernelGGL(k_post_grid<POST_CONVIN>, dim3(pblocks), dim3(256), 0, st, p);
         GemmArgs b{};
         conv_taps(b, h->X[g], 2 * NF, G.w_out, 2 * NF, 2 * NF, 1);                     // conv_out   (layers.py:159)
         gemm(b, m.und);
-        PostArgs q{h->partial, nitems, 2 * NF, h->L, 0, G.b_out, nullptr, h->R[G.node_in], h->R[G.node_out],
+        PostArgs q{items, h->partial, nitems, 2 * NF, h->L, 0, G.b_out, nullptr, h->R[G.node_in], h->R[G.node_out],
                    h->E[G.node_out], nullptr};
         hipLaunchKernelGGL(k_post_grid<POST_GATE>, dim3(pblocks), dim3(256), 0, st, q);   // gate + residual (:160-163)
     };
@@ -1290,7 +1315,7 @@ void run_grid(ps_pixelcnn *h, int F, const int32_t *codes, const Masks &m, float
         GemmArgs a{};
         conv_taps(a, h->R[D.node_in], NF, D.w, NF, NF, 2);                              // model.py:138,148
         gemm(a, m.dil);
-        PostArgs p{h->partial, nitems, NF, h->L, 0, D.b, nullptr, nullptr, h->R[D.node_out], h->E[D.node_out], nullptr};
+        PostArgs p{items, h->partial, nitems, NF, h->L, 0, D.b, nullptr, nullptr, h->R[D.node_out], h->E[D.node_out], nullptr};
         hipLaunchKernelGGL(k_post_grid<POST_DIL>, dim3(pblocks), dim3(256), 0, st, p);
     };
     gated(0); gated(1); dilated(0); gated(2); gated(3); dilated(1); gated(4); gated(5);     // up pass
@@ -1302,7 +1327,7 @@ void run_grid(ps_pixelcnn *h, int F, const int32_t *codes, const Masks &m, float
     a.slot_first[0] = 0; a.slot_first[1] = 1;
     a.tap[0] = GemmTap{h->E[NNODE - 1], h->out_w, 0, 0, -1, 2 * NF};
     gemm(a, nullptr);
-    hipLaunchKernelGGL(k_logits_grid, dim3(nitems), dim3(256), 0, st, h->partial, h->out_b, nitems, h->L, nchw ? 1 : 0,
+    hipLaunchKernelGGL(k_logits_grid, dim3(nitems), dim3(256), 0, st, items, h->partial, h->out_b, nitems, h->L, nchw ? 1 : 0,
                        logits);
 }
 
@@ -1562,7 +1587,7 @@ int ps_pixelcnn_ar_step(ps_pixelcnn *h, const int32_t *codes, const int32_t *ord
     PS_REQUIRE(step >= 0 && step < h->L && first_step >= 0 && first_step <= step, "pixelcnn_ar_step: bad step");
     hipStream_t st = (hipStream_t)stream;
     const Masks m{mask_init, mask_undilated, mask_dilated};
-    if (step == first_step) run_grid(h, F, codes, m, nullptr, false, st);
+    if (step == first_step) run_grid(h, F, codes, m, nullptr, false, st, order, first_step);
     ChainArgs ca{};
     ca.cx = make_ctx_args(h, order, m, F);
     hipLaunchKernelGGL(k_ctx_init, dim3(F), dim3(32), 0, st, ca.cx, step);
@@ -1595,7 +1620,7 @@ int ps_pixelcnn_ar_run(ps_pixelcnn *h, int32_t *codes, const int32_t *order, con
     hipLaunchKernelGGL(k_mask_codes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, codes, sample_region, n);
     // whole-grid pass: exact for every location that precedes the first sampled one; with out_logits it also
     // yields their logits, by location (the walked positions are overwritten by the column steps)
-    run_grid(h, F, codes, m, out_logits, false, st);
+    run_grid(h, F, codes, m, out_logits, false, st, order, first_step);
     ChainArgs ca{};
     ca.cx = make_ctx_args(h, order, m, F);
     ca.codes = codes; ca.region = sample_region; ca.forced = forced; ca.uniforms = uniforms;
@@ -1712,6 +1737,7 @@ int ps_lmconv_forward_f32(const float *x, const float *mask, size_t mask_batch_s
     hipLaunchKernelGGL(k_pack_conv, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, st, weight, Co, Ci, Cop, Cp, wp);
     GemmArgs a{};
     conv_taps(a, xcl, Cp, wp, Cp, Cop, dilation);
+    a.items = ItemMap{nullptr, L};
     a.H = H; a.W = W; a.L = L; a.nitems = B * L; a.mask = mask; a.mask_fstride = mask_batch_stride;
     a.partial = partial; a.tiles_per_block = 8;
     const int tiles = (a.nitems + 15) / 16;
