@@ -11,6 +11,7 @@
 #include <cstring>
 #include <queue>
 #include <tuple>
+#include <thread>
 #include <vector>
 
 #include "ps_common.h"
@@ -127,20 +128,38 @@ int ps_ar_plan(const uint8_t *bg, int B, int S, int G, int32_t *order_loc, uint8
     PS_REQUIRE(bg && order_loc && region && mask_init && mask_undilated && mask_dilated, "ar_plan: null pointer");
     PS_REQUIRE(B > 0 && S > 0 && G > 0 && S % G == 0, "ar_plan: bad sizes");
     const int L = G * G;
-    std::vector<int32_t> order((size_t)L * 2);
-    int first = L;
-    for (int b = 0; b < B; ++b) {
+    // frames are independent: one worker per frame (up to 16), each with its own scratch; the first failure wins
+    std::vector<int> first_b((size_t)B, L), rc_b((size_t)B, PS_OK);
+    auto one_frame = [&](int b) {
+        std::vector<int32_t> order((size_t)L * 2);
         uint8_t *reg = region + (size_t)b * L;
-        if (int rc = ps_generation_order(bg + (size_t)b * S * S, S, G, order.data(), reg, nullptr)) return rc;
+        if ((rc_b[b] = ps_generation_order(bg + (size_t)b * S * S, S, G, order.data(), reg, nullptr))) return;
         int32_t *ol = order_loc + (size_t)b * L;
+        int first = L;
         for (int i = 0; i < L; ++i) {
             ol[i] = order[2 * i] * G + order[2 * i + 1];
             if (reg[ol[i]] && i < first) first = i;
         }
+        first_b[b] = first;
         const size_t mo = (size_t)b * 9 * L;
-        if (int rc = ps_kernel_masks_f32(order.data(), L, G, G, 3, 1, 0, mask_init + mo)) return rc;
-        if (int rc = ps_kernel_masks_f32(order.data(), L, G, G, 3, 1, 1, mask_undilated + mo)) return rc;
-        if (int rc = ps_kernel_masks_f32(order.data(), L, G, G, 3, 2, 1, mask_dilated + mo)) return rc;
+        if ((rc_b[b] = ps_kernel_masks_f32(order.data(), L, G, G, 3, 1, 0, mask_init + mo))) return;
+        if ((rc_b[b] = ps_kernel_masks_f32(order.data(), L, G, G, 3, 1, 1, mask_undilated + mo))) return;
+        rc_b[b] = ps_kernel_masks_f32(order.data(), L, G, G, 3, 2, 1, mask_dilated + mo);
+    };
+    const int nthreads = std::min(B, 16);
+    if (nthreads <= 1) {
+        one_frame(0);
+    } else {
+        std::vector<std::thread> pool;
+        for (int w = 1; w < nthreads; ++w)
+            pool.emplace_back([&, w]() { for (int b = w; b < B; b += nthreads) one_frame(b); });
+        for (int b = 0; b < B; b += nthreads) one_frame(b);
+        for (auto &th : pool) th.join();
+    }
+    int first = L;
+    for (int b = 0; b < B; ++b) {
+        if (rc_b[b]) return rc_b[b];
+        first = std::min(first, first_b[b]);
     }
     if (first_step) *first_step = first;
     return PS_OK;

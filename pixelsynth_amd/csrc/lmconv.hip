@@ -437,7 +437,14 @@ struct __attribute__((aligned(16))) StageDesc {
     int nchain, nstep, pad0, pad1;
 };
 
-struct NbrWork { int stage, half, cog; };
+// a work item of k_nbr = (stage, slot NA|NB, 16 output channels), with everything it needs of the stage inline:
+// one dependent fetch instead of work item -> stage description -> data
+struct __attribute__((aligned(16))) NbrWork {
+    const float *w;   // packed weights of the conv [taps][NG*4][Co_pad][4]
+    const float *in;  // cache the taps gather from
+    int stage, half, cog, NG;
+    int Co_pad, in_ld, dil, mask_kind;
+};
 
 struct NbrArgs {
     const StageDesc *stages;
@@ -466,7 +473,7 @@ __device__ __forceinline__ int xcd_slot(int b, int lo, int hi /*use XCDs lo .. h
 
 // one neighbour tap of one conv for 16 frames x 16 output channels, from fresh accumulators
 template <int NG>
-__device__ __forceinline__ f32x4 nbr_tap(const StageDesc &sd, const NbrArgs &a, int t, int o0, int f, bool valid, int i, int kk)
+__device__ __forceinline__ f32x4 nbr_tap(const NbrWork &sd, const NbrArgs &a, int t, int o0, int f, bool valid, int i, int kk)
 {
     const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
     float mv = 0.0f;
@@ -519,13 +526,12 @@ __global__ __launch_bounds__(256) void k_nbr(NbrArgs a)
     }
     __shared__ __attribute__((aligned(16))) float sP[4][16][20];
     const NbrWork wk = a.work[witem];
-    const StageDesc sd = a.stages[wk.stage];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, kk = lane >> 4;
     const int o0 = wk.cog * 16;
     const int f = ftile * 16 + i;
     const bool valid = f < a.F;
     const int t = wk.half * 5 + wave;  // taps 0..3 (NA) or 5..8 (NB)
-    const f32x4 part = sd.NG == 10 ? nbr_tap<10>(sd, a, t, o0, f, valid, i, kk) : nbr_tap<5>(sd, a, t, o0, f, valid, i, kk);
+    const f32x4 part = wk.NG == 10 ? nbr_tap<10>(wk, a, t, o0, f, valid, i, kk) : nbr_tap<5>(wk, a, t, o0, f, valid, i, kk);
     *(f32x4 *)(&sP[wave][i][kk * 4]) = part;
     __syncthreads();
     if (wave == 0 && valid) {
@@ -1351,7 +1357,7 @@ int build_stage_table(ps_pixelcnn *h)
         const int s = (int)st.size();
         if (has_nbr)
             for (int half = 0; half < 2; ++half)
-                for (int cog = 0; cog < Co / 16; ++cog) work.push_back(NbrWork{s, half, cog});
+                for (int cog = 0; cog < Co / 16; ++cog) work.push_back(NbrWork{w, in, s, half, cog, NG, Co, in_ld, dil, mask_kind});
         // dense algorithmic work per frame of this stage (taps x 2*Co*Cin flops, fp32 weights once)
         const double taps_nbr = has_nbr ? 8.0 : 0.0, cin = NG * 16.0;
         h->flops_nbr += taps_nbr * 2.0 * Co * cin;

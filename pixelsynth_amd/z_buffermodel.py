@@ -26,11 +26,17 @@ from .projection.z_buffer_manipulator import PtsManipulator
 class ARPlan:
     """Device-resident, compact result of get_masks_for_batch for B images (see ps_ar_plan)."""
 
-    def __init__(self, order_loc, region, mask_init, mask_undilated, mask_dilated, first_step, gen_order):
+    def __init__(self, order_loc, region, mask_init, mask_undilated, mask_dilated, first_step, order_host, G):
         self.order_loc, self.region = order_loc, region
         self.mask_init, self.mask_undilated, self.mask_dilated = mask_init, mask_undilated, mask_dilated
         self.first_step = first_step
-        self.gen_order = gen_order  # list of (L,2) int arrays, the reference's gen_order
+        self._order_host, self._G = order_host, G
+
+    @property
+    def gen_order(self):
+        """list of (L,2) int arrays (row, col) by rank: the reference's gen_order (built on demand)."""
+        G = self._G
+        return [np.stack([o // G, o % G], 1).astype(np.int64) for o in self._order_host]
 
     @property
     def n_sampled(self):
@@ -54,8 +60,7 @@ def build_ar_plan(background_mask, G=32, device=None):
                                _lib.ptr(masks[1]), _lib.ptr(masks[2]), ctypes.cast(ctypes.byref(first), ctypes.c_void_p))
     _lib.check(rc, "ps_ar_plan")
     up = lambda a: torch.from_numpy(a).to(device, non_blocking=True)
-    plan = ARPlan(up(order_loc), up(region), up(masks[0]), up(masks[1]), up(masks[2]), int(first.value),
-                  [np.stack([o // G, o % G], 1).astype(np.int64) for o in order_loc])
+    plan = ARPlan(up(order_loc), up(region), up(masks[0]), up(masks[1]), up(masks[2]), int(first.value), order_loc, G)
     plan._n_sampled = region.sum(1).astype(int)
     return plan
 
