@@ -24,6 +24,7 @@
 //     NA/NB slots of all 32 convs at once (they only read finished columns of earlier positions); k_chain
 //     walks the 33 dependent stages inside one workgroup per 16 frames (centre-tap products on MFMA,
 //     post ops one wave per frame, LDS hand-off), draws the code and writes the next position's context.
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -455,7 +456,8 @@ struct NbrArgs {
     const int32_t *codes;
     const float *uinit_w, *uinit_b;
     int nwork, H, W, L, F;
-    int chain_xcds;  // XCDs 0 .. chain_xcds-1 are left to k_chain1 (see xcd_slot); 0 = use every XCD
+    int chain_xcds;  // XCDs 0 .. chain_xcds-1 are left to the chain workgroups (see k_column); 0 = no split
+    unsigned *cnt;   // [NST + 1] completion counters of this handle: work items done per stage ([NST]: u_init waves), ever
 };
 
 // XCD affinity, for speed only (nothing depends on it): workgroup b of a launch runs on XCD b % 8, each XCD with
@@ -506,40 +508,67 @@ __device__ __forceinline__ f32x4 nbr_tap(const NbrWork &sd, const NbrArgs &a, in
     return chunk_total(acc);
 }
 
-// grid (work items + 4, ceil(F/16)); a work item = (stage, slot NA|NB, 16 output channels); its 4 waves take
-// the 4 taps of the slot and the partials are added in tap order (the order k_gemm uses)
-__global__ __launch_bounds__(256) void k_nbr(NbrArgs a)
+// Results that another workgroup of the SAME launch consumes (k_column: neighbour slots -> chain) leave with
+// write-through stores (sc1: past this XCD's L2, which is not coherent with the consumer's); the consumer reads them
+// with device-scope loads after it has seen the completion counter.
+__device__ __forceinline__ void store_through(float *p, const f32x4 &v)
 {
-    const int slot = xcd_slot(blockIdx.x, a.chain_xcds, 8);
-    const int per_tile = a.nwork + 4;
-    if (slot < 0 || slot >= per_tile * ((a.F + 15) / 16)) return;
-    const int ftile = slot / per_tile, witem = slot - ftile * per_tile;
-    if (witem >= a.nwork) {  // last 4 work items: the u_init gather, one wave per frame, 20 groups of 4
-        const int f = ftile * 16 + (witem - a.nwork) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-        if (f >= a.F || lane >= NGRP) return;
-        float mA[9];
-#pragma unroll
-        for (int t = 0; t < 9; ++t) mA[t] = a.ctx[f].m[0][t];
-        *(f32x4 *)(a.upre + (size_t)f * NF + 4 * lane) =
-            uinit_gather<f32x4>(a.codes + (size_t)f * a.L, mA, a.uinit_w, a.uinit_b, a.ctx[f].q, a.H, a.W, 4 * lane);
-        return;
-    }
-    __shared__ __attribute__((aligned(16))) float sP[4][16][20];
-    const NbrWork wk = a.work[witem];
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(PS_G(f32x4, p)), "v"(v) : "memory");
+}
+__device__ __forceinline__ void signal_done(unsigned *counter, int lane)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through stores have left
+    if (lane == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Neighbour-tap role of k_column: a 1024-thread workgroup takes four work items, four waves each.  A work item =
+// (stage, slot NA|NB, 16 output channels) for a tile of 16 frames; its 4 waves take the 4 taps of the slot and
+// the partials are added in tap order (the order k_gemm uses).  The last 4 items of a tile are the u_init gather
+// (one wave per frame).  Every item bumps its stage's completion counter when its results are out.
+__device__ __forceinline__ void nbr_role(const NbrArgs &a, int nb)
+{
+    __shared__ __attribute__((aligned(16))) float sNP[4][4][16][20];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, kk = lane >> 4;
-    const int o0 = wk.cog * 16;
-    const int f = ftile * 16 + i;
-    const bool valid = f < a.F;
-    const int t = wk.half * 5 + wave;  // taps 0..3 (NA) or 5..8 (NB)
-    const f32x4 part = wk.NG == 10 ? nbr_tap<10>(wk, a, t, o0, f, valid, i, kk) : nbr_tap<5>(wk, a, t, o0, f, valid, i, kk);
-    *(f32x4 *)(&sP[wave][i][kk * 4]) = part;
-    __syncthreads();
-    if (wave == 0 && valid) {
-        const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
-        f32x4 tot = zero;
+    const int grp4 = wave >> 2, w4 = wave & 3;
+    const int per_tile = a.nwork + 4;
+    const int item = nb * 4 + grp4;
+    const bool active = item < per_tile * ((a.F + 15) / 16);
+    // item order within a tile: the u_init gather first (the chain needs it before anything else), then the conv
+    // work items in stage order
+    const int ftile = active ? item / per_tile : 0, witem = active ? item - ftile * per_tile - 4 : 0;
+    const bool conv = active && witem >= 0;
+    NbrWork wk{};
+    int f = 0;
+    bool valid = false;
+    if (conv) {
+        wk = a.work[witem];
+        f = ftile * 16 + i;
+        valid = f < a.F;
+        const int t = wk.half * 5 + w4;  // taps 0..3 (NA) or 5..8 (NB)
+        const f32x4 part = wk.NG == 10 ? nbr_tap<10>(wk, a, t, wk.cog * 16, f, valid, i, kk)
+                                       : nbr_tap<5>(wk, a, t, wk.cog * 16, f, valid, i, kk);
+        *(f32x4 *)(&sNP[grp4][w4][i][kk * 4]) = part;
+    } else if (active) {  // u_init gather: this wave's frame, 20 groups of 4 channels
+        const int fu = ftile * 16 + (witem + 4) * 4 + w4;
+        if (fu < a.F && lane < NGRP) {
+            float mA[9];
 #pragma unroll
-        for (int w = 0; w < 4; ++w) tot = tot + *(const f32x4 *)(&sP[w][i][kk * 4]);
-        *(f32x4 *)(a.nbr + (((size_t)wk.stage * 2 + wk.half) * a.F + f) * NBR_LD + o0 + kk * 4) = tot;
+            for (int t = 0; t < 9; ++t) mA[t] = a.ctx[fu].m[0][t];
+            store_through(a.upre + (size_t)fu * NF + 4 * lane,
+                          uinit_gather<f32x4>(a.codes + (size_t)fu * a.L, mA, a.uinit_w, a.uinit_b, a.ctx[fu].q, a.H, a.W, 4 * lane));
+        }
+        signal_done(a.cnt + NST, lane);
+    }
+    __syncthreads();
+    if (conv && w4 == 0) {
+        if (valid) {
+            const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+            f32x4 tot = zero;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) tot = tot + *(const f32x4 *)(&sNP[grp4][w][i][kk * 4]);
+            store_through(a.nbr + (((size_t)wk.stage * 2 + wk.half) * a.F + f) * NBR_LD + wk.cog * 16 + kk * 4, tot);
+        }
+        signal_done(a.cnt + wk.stage, lane);
     }
 }
 
@@ -560,7 +589,10 @@ struct ChainArgs {
     float *step_logits;       // (F,512) or null
     float temperature;
     int advance;              // 1: write the context of step+1
-    int chain_xcds;            // k_chain1 workgroups only work on XCDs 0 .. chain_xcds-1 (xcd_slot); 8 = all
+    const unsigned *cnt;       // completion counters of the neighbour role (NbrArgs::cnt)
+    unsigned epoch;            // column launches of this handle so far, this one included: counters are never reset
+    int tiles;                 // 16-frame tiles of the neighbour role
+    int *err;                  // set to 1 if a bounded wait ran out (ps_pixelcnn_status)
     unsigned long long *trace; // optional [NST][10] shader-clock stamps of workgroup 0 (tuning aid)
     int ablate;                // tuning aid (PS_CHAIN_ABLATE): 1 no cache stores, 2 no slot prefetch, 4 no MFMA, 8 no post math
 };
@@ -662,7 +694,7 @@ __device__ __forceinline__ void load_chain_weights(const float *wv, int nchain, 
 // Every role fetches its fields with scalar loads one stage ahead, so no wave ever waits on a descriptor.
 constexpr int C1_CTL_DWORDS = 24;
 enum { CTL_CO = 0, CTL_NCHAIN = 1, CTL_NG = 2, CTL_NSTEP = 3, CTL_WV = 4, CTL_BIAS = 6, CTL_KIND = 8, CTL_HAS_SKIP = 9,
-       CTL_IN_FORM = 10, CTL_SAVE_SLOT = 11, CTL_SKIP_SLOT = 12, CTL_BIAS2 = 14, CTL_R = 16, CTL_E = 18, CTL_X = 20 };
+       CTL_IN_FORM = 10, CTL_SAVE_SLOT = 11, CTL_SKIP_SLOT = 12, CTL_NBR_ITEMS = 13 /* of the stage, per tile */, CTL_BIAS2 = 14, CTL_R = 16, CTL_E = 18, CTL_X = 20 };
 typedef const __attribute__((address_space(4))) int *CtlInt;
 typedef const __attribute__((address_space(4))) unsigned long long *CtlU64;
 __device__ __forceinline__ int ctl_i(const int *ctl, int rec, int field) { return ((CtlInt)ctl)[rec * C1_CTL_DWORDS + field]; }
@@ -672,7 +704,7 @@ __device__ __forceinline__ T *ctl_p(const int *ctl, int rec, int field)
     return (T *)((CtlU64)ctl)[(rec * C1_CTL_DWORDS + field) >> 1];
 }
 struct ChainCtl { int Co, nchain, NG, nstep; const float *wv; };
-struct PostCtl { int Co, kind, has_skip, in_form, save_slot; const float *bias, *bias2; };
+struct PostCtl { int Co, kind, has_skip, in_form, save_slot, nbr_items; const float *bias, *bias2; };
 struct StoreCtl { int kind, skip_slot; float *R, *E, *X; };
 __device__ __forceinline__ ChainCtl load_chain_ctl(const int *ctl, int rec)
 {
@@ -682,7 +714,8 @@ __device__ __forceinline__ ChainCtl load_chain_ctl(const int *ctl, int rec)
 __device__ __forceinline__ PostCtl load_post_ctl(const int *ctl, int rec)
 {
     return PostCtl{ctl_i(ctl, rec, CTL_CO), ctl_i(ctl, rec, CTL_KIND), ctl_i(ctl, rec, CTL_HAS_SKIP), ctl_i(ctl, rec, CTL_IN_FORM),
-                   ctl_i(ctl, rec, CTL_SAVE_SLOT), ctl_p<const float>(ctl, rec, CTL_BIAS), ctl_p<const float>(ctl, rec, CTL_BIAS2)};
+                   ctl_i(ctl, rec, CTL_SAVE_SLOT), ctl_i(ctl, rec, CTL_NBR_ITEMS), ctl_p<const float>(ctl, rec, CTL_BIAS),
+                   ctl_p<const float>(ctl, rec, CTL_BIAS2)};
 }
 __device__ __forceinline__ StoreCtl load_store_ctl(const int *ctl, int rec)
 {
@@ -691,7 +724,7 @@ __device__ __forceinline__ StoreCtl load_store_ctl(const int *ctl, int rec)
 }
 
 template <int FPW>
-__global__ __launch_bounds__(C1_THREADS) void k_chain1(ChainArgs a)
+__device__ __forceinline__ void chain_role(const ChainArgs &a, int wg)
 {
     static_assert(FPW >= 1 && FPW <= 2, "waves 0..12 run the chains, wave 13 stores, the last FPW waves do the post ops");
     __shared__ __attribute__((aligned(16))) float sX[FPW][SX_LD];        // input of the centre taps
@@ -701,8 +734,6 @@ __global__ __launch_bounds__(C1_THREADS) void k_chain1(ChainArgs a)
     __shared__ __attribute__((aligned(16))) float sOut[FPW][3][NF];      // (u, elu(u), elu(-u)) on their way to the caches
     __shared__ __attribute__((aligned(16))) float sPL[FPW][5][NCLS];     // chain values of nin_out
     const int t = threadIdx.x, wave = uni(t >> 6), lane = t & 63;
-    const int wg = xcd_slot(blockIdx.x, 0, a.chain_xcds);
-    if (wg < 0 || wg * FPW >= a.F) return;
     const int f0 = wg * FPW;
     // Roles, each in its own wave-uniform branch (so their registers do not add up):
     //   waves 0..12         one chain per thread and stage
@@ -763,6 +794,9 @@ __global__ __launch_bounds__(C1_THREADS) void k_chain1(ChainArgs a)
         // Always exactly fourteen loads from valid addresses, in every lane: static s_waitcnt counts (see
         // load_chain_weights); kinds without a gate half / skip re-read the main operands.
         struct Ops { float b[2], na[2], nb[2], bg[2], nag[2], nbg[2], b2[2]; };
+        // The neighbour slots are produced by other workgroups of this launch (nbr_role, other XCDs): they are read
+        // with device-scope loads, and only once the stage's completion counter has reached this launch's target.
+        auto fresh = [](const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
         auto load_ops = [&](int s, const PostCtl &c, Ops &o) {
             const float *nb = nbr_f + (size_t)s * nbr_stage;
             const int gofs = c.kind == PRO_GATE ? NF : 0;
@@ -771,12 +805,24 @@ __global__ __launch_bounds__(C1_THREADS) void k_chain1(ChainArgs a)
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 o.b[k] = *PS_GC(float, c.bias + ch[k]);
-                o.na[k] = *PS_GC(float, nb + ch[k]);
-                o.nb[k] = *PS_GC(float, nb + nbr_half + ch[k]);
+                o.na[k] = fresh(nb + ch[k]);
+                o.nb[k] = fresh(nb + nbr_half + ch[k]);
                 o.bg[k] = *PS_GC(float, c.bias + gofs + ch[k]);
-                o.nag[k] = *PS_GC(float, nb + gofs + ch[k]);
-                o.nbg[k] = *PS_GC(float, nb + nbr_half + gofs + ch[k]);
+                o.nag[k] = fresh(nb + gofs + ch[k]);
+                o.nbg[k] = fresh(nb + nbr_half + gofs + ch[k]);
                 o.b2[k] = *PS_GC(float, b2 + ch[k]);
+            }
+        };
+        // completion counter of stage k (NST: the u_init gather); `have` is a value loaded earlier (normally already
+        // past the target, so this costs nothing); bounded, so a lost neighbour workgroup cannot hang the GPU
+        auto counter = [&](int k) { return __hip_atomic_load(a.cnt + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+        auto wait_counter = [&](unsigned have, int k, unsigned items_per_tile) {
+            const unsigned need = a.epoch * items_per_tile * (unsigned)a.tiles;
+            int spins = 0;
+            while ((int)(have - need) < 0) {
+                if (++spins > 20000) { if (lane == 0) *a.err = 1; break; }
+                __builtin_amdgcn_s_sleep(2);
+                have = counter(k);
             }
         };
         // PONO + finish + hand-off to the next stage.  Compiled once per (kind, skip, input form) combination that
@@ -840,6 +886,7 @@ __global__ __launch_bounds__(C1_THREADS) void k_chain1(ChainArgs a)
             post_and_emit(y, g, skip, KIND, SKIP, INFORM, save_slot);
         };
         using std::integral_constant;
+        unsigned cnt_nxt = 0;  // counter of the next stage, as loaded a stage earlier
         PostCtl cur = load_post_ctl(a.ctl1, 0), nxt = load_post_ctl(a.ctl1, 1), nn = load_post_ctl(a.ctl1, 2);
         auto post_stage = [&](int s, const Ops &ocur, Ops &onxt) {
             cur = nxt;                                              // record 1 + s
@@ -848,8 +895,13 @@ __global__ __launch_bounds__(C1_THREADS) void k_chain1(ChainArgs a)
             PS_TRACE1(t == C1_THREADS - 64, 0);
             // operands of the NEXT post op, issued while this wave waits for the chains: the vector-memory queue is
             // empty now, whereas after the barrier the chain waves fill it with the next stage's weights and any
-            // load issued behind them would stall this wave (the critical path) for the whole burst
-            if (s + 1 < NST - 1) load_ops(s + 1, nxt, onxt);
+            // load issued behind them would stall this wave (the critical path) for the whole burst.  The counter
+            // of the stage after that is requested now and looked at a stage later.
+            if (s + 1 < NST - 1) {
+                wait_counter(cnt_nxt, s + 1, (unsigned)nxt.nbr_items);
+                cnt_nxt = counter(min(s + 2, NST - 2));
+                load_ops(s + 1, nxt, onxt);
+            }
             lds_barrier();   // the chains of this stage are in sP
             PS_TRACE1(t == C1_THREADS - 64, 1);
             const integral_constant<bool, true> yes{};
@@ -870,11 +922,14 @@ __global__ __launch_bounds__(C1_THREADS) void k_chain1(ChainArgs a)
             PS_TRACE1(t == C1_THREADS - 64, 4);
         };
         Ops oA, oB;
-        load_ops(0, nxt, oA);
-        load_ops(0, nxt, oB);
-        {   // u0 = norm_init(u_init) from k_nbr's gather
+        {   // u0 = norm_init(u_init) from the neighbour role's gather
+            wait_counter(counter(NST), NST, 16u);
             const float *up = a.upre + (size_t)(pvalid ? pfr : 0) * NF;
-            const float y[2] = {*PS_GC(float, up + cA), *PS_GC(float, up + cB)}, z[2] = {0.0f, 0.0f};
+            const float y[2] = {fresh(up + cA), fresh(up + cB)}, z[2] = {0.0f, 0.0f};
+            wait_counter(counter(0), 0, (unsigned)nxt.nbr_items);
+            cnt_nxt = counter(1);
+            load_ops(0, nxt, oA);
+            load_ops(0, nxt, oB);
             post_and_emit(y, z, z, integral_constant<int, PRO_UINIT>{}, integral_constant<bool, false>{},
                           integral_constant<int, IN_CELU>{}, cur.save_slot);
             lds_barrier();
@@ -1074,6 +1129,32 @@ __global__ __launch_bounds__(C1_THREADS) void k_chain1(ChainArgs a)
     }
 }
 
+// ==========================================================================================
+// k_column: ONE launch per AR order position.  Workgroup b runs on XCD b % 8 (observed; used for speed only):
+//   chain role   frame f's 33-stage chain.  With the XCD split (<= 32 frames) these are the workgroups 8f, all on
+//                XCD 0, whose L2 then keeps the centre-tap weights from one position to the next.
+//   neighbour role   every other workgroup: four work items each (nbr_role), on XCDs 1..7.
+// Both start together: the chain only needs the neighbour slots of stage s when it reaches the post op of stage s,
+// and by then the neighbour role -- a few microseconds of parallel work -- is normally done; completion counters
+// per stage (device-scope atomics) and write-through stores carry the hand-off, every wait is bounded.
+// The neighbour workgroups never wait for anything, so the launch cannot deadlock whatever the dispatch order.
+// ==========================================================================================
+__global__ __launch_bounds__(C1_THREADS) void k_column(NbrArgs na, ChainArgs ca)
+{
+    const int b = blockIdx.x;
+    int chain_wg = -1, nb;
+    if (na.chain_xcds > 0) {  // XCD split: chain workgroups are the blocks 0, 8, 16, ...
+        const int ahead = min((b + 7) >> 3, ca.F);  // chain blocks with an index below b
+        if ((b & 7) == 0 && (b >> 3) < ca.F) chain_wg = b >> 3;
+        nb = b - ahead;
+    } else {
+        if (b < ca.F) chain_wg = b;
+        nb = b - ca.F;
+    }
+    if (chain_wg >= 0) chain_role<1>(ca, chain_wg);
+    else nbr_role(na, nb);
+}
+
 // repack the centre tap (+ nin_skip) of a stage for k_chain1: out[step][chain][4]
 __global__ void k_pack_valu(const float *wc, const float *wskip, int Co, int nchain, int nstep, float *out)
 {
@@ -1201,7 +1282,10 @@ struct ps_pixelcnn {
     float *col_logits = nullptr;
     StepCtx *ctx = nullptr;
     StageDesc *stages = nullptr;    // device copy of the 33-stage chain description
-    int *ctl1 = nullptr;            // the same for k_chain1 (scalar-load records)
+    int *ctl1 = nullptr;            // the same for the chain role (scalar-load records)
+    unsigned *cnt = nullptr;        // [NST + 1] completion counters of the neighbour role, never reset
+    int *err = nullptr;             // device flag: a bounded wait of the chain role ran out
+    unsigned epoch = 0;             // column launches so far
     NbrWork *work = nullptr;
     int nwork = 0;
     hipStream_t stream = nullptr;   // internal stream for graph capture/replay
@@ -1418,6 +1502,7 @@ int build_stage_table(ps_pixelcnn *h)
         for (int k = 0; k < NST; ++k) {
             int *c = &ctl[(size_t)(1 + k) * C1_CTL_DWORDS];
             c[CTL_CO] = st[k].Co_pad; c[CTL_NCHAIN] = st[k].nchain; c[CTL_NG] = st[k].NG; c[CTL_NSTEP] = st[k].nstep;
+            c[CTL_NBR_ITEMS] = st[k].has_nbr ? 2 * (st[k].Co_pad / 16) : 0;
             put_p(1 + k, CTL_WV, st[k].wv);
             if (k + 1 < NST) put_post(1 + k, st[k + 1]);
         }
@@ -1436,21 +1521,18 @@ int build_stage_table(ps_pixelcnn *h)
 // describe the current position.
 void run_column(ps_pixelcnn *h, int F, const int32_t *codes, ChainArgs ca, hipStream_t st)
 {
-    // XCD split (xcd_slot): up to 32 frames, the chain workgroups fill XCD 0 (32 CUs) and k_nbr takes XCDs 1..7
-    // (V=16: chain 47.5 -> 42.5 us); with more frames k_nbr needs the whole chip (V=64: the split costs it 9 us)
-    const int cx = (h->xcd_pack && F <= 32) ? 1 : 8;
+    // XCD split: up to 32 frames, the chain workgroups (blocks 0, 8, 16, ...) fill XCD 0 (32 CUs) and the neighbour
+    // role gets XCDs 1..7 (V=16: chain 47.5 -> 42.5 us); with more frames both use the whole chip
+    const bool split = h->xcd_pack && F <= 32;
+    const int tiles = (F + 15) / 16, nbr_wgs = ((h->nwork + 4) * tiles + 3) / 4;
     NbrArgs na{h->stages, h->work, h->ctx, h->nbr, h->upre, codes, h->uinit_w, h->uinit_b, h->nwork, h->H, h->W, h->L, F,
-               cx == 8 ? 0 : cx};
-    const int tiles = (F + 15) / 16, nbr_wgs = (h->nwork + 4) * tiles, nbr_xcds = 8 - na.chain_xcds;
-    if (!(h->prof && getenv("PS_PROF_SKIP_NBR")))  // tuning aid: time the chain alone
-        timed(h, st, TAG_NBR, [&]() {
-            hipLaunchKernelGGL(k_nbr, dim3((nbr_wgs + nbr_xcds - 1) / nbr_xcds * 8), dim3(256), 0, st, na);
-        });
+               split ? 1 : 0, h->cnt};
     ca.stages = h->stages; ca.ctl1 = h->ctl1; ca.nbr = h->nbr; ca.upre = h->upre;
     ca.out_b = h->out_b;
     ca.H = h->H; ca.W = h->W; ca.L = h->L; ca.F = F;
-    ca.chain_xcds = cx;
-    timed(h, st, TAG_CHAIN, [&]() { hipLaunchKernelGGL(k_chain1<1>, dim3((F + cx - 1) / cx * 8), dim3(C1_THREADS), 0, st, ca); });
+    ca.cnt = h->cnt; ca.epoch = ++h->epoch; ca.tiles = tiles; ca.err = h->err;
+    const int blocks = split ? std::max(nbr_wgs + F, 8 * (F - 1) + 1) : nbr_wgs + F;
+    timed(h, st, TAG_CHAIN, [&]() { hipLaunchKernelGGL(k_column, dim3(blocks), dim3(C1_THREADS), 0, st, na, ca); });
 }
 
 CtxArgs make_ctx_args(ps_pixelcnn *h, const int32_t *order, const Masks &m, int F)
@@ -1552,6 +1634,12 @@ int ps_pixelcnn_create(const float *const *params, int n_params, int H, int W, i
     if ((rc = dev_alloc(h, &h->nbr, (size_t)NST * 2 * max_frames * NBR_LD))) return fail_out(rc);
     if ((rc = dev_alloc(h, &h->upre, (size_t)max_frames * NF))) return fail_out(rc);
     if ((rc = dev_alloc(h, &h->ctx, (size_t)max_frames))) return fail_out(rc);
+    if ((rc = dev_alloc(h, &h->cnt, (size_t)NST + 1))) return fail_out(rc);
+    if ((rc = dev_alloc(h, &h->err, 1))) return fail_out(rc);
+    if (hipMemset(h->cnt, 0, (NST + 1) * sizeof(unsigned)) != hipSuccess || hipMemset(h->err, 0, sizeof(int)) != hipSuccess) {
+        ps::fail(PS_ERR_HIP, "pixelcnn_create: hipMemset failed");
+        return fail_out(PS_ERR_HIP);
+    }
     if ((rc = build_stage_table(h))) return fail_out(rc);
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming) != hipSuccess ||
