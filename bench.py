@@ -79,10 +79,12 @@ def run_step(model, d, world):
 
 
 def measure_roofline(model, d, out, V):
-    """Per-launch duration of the two kernels of an AR order position, measured with HIP events on the stream
-    they are launched on (ps_pixelcnn_time_column_step), against their dense algorithmic work.
-    The dominant one is k_chain: the sequential centre-tap chain (33 dependent 1x1 products + post ops +
-    draw), one workgroup (= one CU) per 16 frames, fp32 MFMA bound inside that CU."""
+    """Per-launch duration of the kernel of an AR order position (k_column), measured with HIP events on the stream
+    it is launched on (ps_pixelcnn_time_column_step), against its dense algorithmic fp32 work: the 33-stage
+    centre-tap chain of every frame (fp32 FMA chains on the vector ALU, one CU per frame) plus the neighbour-tap
+    partial sums of all 32 masked convs (fp32 MFMA, the rest of the chip, masked taps skipped).  Both share the
+    fp32 dense peak of gfx950 (157.3 TFLOP/s: packed-FMA VALU rate = fp32 MFMA rate).  The launch is bounded by the
+    LATENCY of the sequential chain, not by throughput -- DESIGN.md section 4 has the per-stage cycle budget."""
     plan = out["plan"]
     eng = model.outpaint2.engine(32, 32, V)
     c32 = out["codes"].reshape(V, 1024).to(torch.int32).contiguous()
@@ -98,23 +100,24 @@ def measure_roofline(model, d, out, V):
         ctypes.cast(total_ms, ctypes.c_void_p), ctypes.cast(flops, ctypes.c_void_p),
         ctypes.cast(wbytes, ctypes.c_void_p), _lib.current_stream())
     _lib.check(rc, "ps_pixelcnn_time_column_step")
-    us = [total_ms[i] * 1e3 / max(1, launches[i]) for i in range(2)]
-    active_cus = (V + 15) // 16
-    tf_chain = flops[1] / (us[1] * 1e-6) / 1e12
-    tf_nbr = flops[0] / (us[0] * 1e-6) / 1e12
-    gb_nbr = wbytes[0] / (us[0] * 1e-6) / 1e9
-    return {"bound": "mfma", "kernel": "k_chain (centre-tap chain of one AR order position, 1 workgroup per 16 frames)",
-            "achieved": round(tf_chain, 4), "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-            "frac": round(tf_chain / FP32_MFMA_PEAK_TF, 6), "traffic": None,
-            "algorithmic_flops_per_launch": round(flops[1]), "avg_launch_us": round(us[1], 3),
-            "active_cus": active_cus,
-            "frac_of_active_cus_peak": round(tf_chain / (FP32_MFMA_PEAK_TF * active_cus / 256.0), 4),
-            "k_nbr": {"what": "neighbour-tap partial sums of all 32 masked convs (whole chip, masked taps skipped)",
-                      "avg_launch_us": round(us[0], 3), "dense_flops_per_launch": round(flops[0]),
-                      "dense_tflops": round(tf_nbr, 4), "frac_mfma": round(tf_nbr / FP32_MFMA_PEAK_TF, 6),
-                      "weight_bytes_per_launch": round(wbytes[0]), "weight_stream_GBs": round(gb_nbr, 2),
-                      "frac_hbm": round(gb_nbr / HBM_PEAK_GBS, 5)},
-            "launches_per_ar_position": 2}
+    us = total_ms[1] * 1e3 / max(1, launches[1])
+    chain_cus = V
+    fl = flops[0] + flops[1]
+    tf = fl / (us * 1e-6) / 1e12
+    tf_chain = flops[1] / (us * 1e-6) / 1e12
+    chain_stream = wbytes[1] * V / (us * 1e-6) / 1e9
+    return {"bound": "mfma", "kernel": "k_column (one launch per AR order position: per-frame centre-tap chains + neighbour-tap slots of all 32 masked convs)",
+            "achieved": round(tf, 4), "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+            "frac": round(tf / FP32_MFMA_PEAK_TF, 6), "traffic": None,
+            "algorithmic_flops_per_launch": round(fl), "avg_launch_us": round(us, 3),
+            "chain": {"what": "33 dependent stages per frame, one CU per frame (latency-bound)", "cus": chain_cus,
+                      "flops_per_launch": round(flops[1]), "tflops": round(tf_chain, 4),
+                      "frac_of_its_cus_peak": round(tf_chain / (FP32_MFMA_PEAK_TF * chain_cus / 256.0), 4),
+                      "weight_bytes_streamed_per_frame": round(wbytes[1]),
+                      "L2_to_CU_stream_GBs_all_frames": round(chain_stream, 1)},
+            "neighbour_taps": {"what": "dense flops of the 8 neighbour taps x 32 convs (masked taps are skipped at run time)",
+                               "dense_flops_per_launch": round(flops[0]), "weight_bytes": round(wbytes[0])},
+            "launches_per_ar_position": 1}
 
 
 def extra_configs(device):

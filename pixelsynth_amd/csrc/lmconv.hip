@@ -186,7 +186,6 @@ __global__ __launch_bounds__(64) void k_gemm(GemmArgs a)
 // butterfly over the lanes of each row of 16 (DPP), then (row0 + row1) + (row2 + row3) -- so column steps and
 // whole-grid passes agree bit for bit.
 // ------------------------------------------------------------------------------------------
-constexpr int NGRP = NF / 4;  // 20 groups of 4 channels (u_init gather of k_nbr)
 constexpr int NB_LANES = NF - 64;  // 16 lanes carry a second channel
 
 // Elementwise math of the post ops.  These sit on the sequential critical path of every AR order position
@@ -452,12 +451,9 @@ struct NbrArgs {
     const NbrWork *work;
     const StepCtx *ctx;
     float *nbr;   // [NST][2][F][NBR_LD]
-    float *upre;  // [F][NF] u_init before norm_init
-    const int32_t *codes;
-    const float *uinit_w, *uinit_b;
     int nwork, H, W, L, F;
     int chain_xcds;  // XCDs 0 .. chain_xcds-1 are left to the chain workgroups (see k_column); 0 = no split
-    unsigned *cnt;   // [NST + 1] completion counters of this handle: work items done per stage ([NST]: u_init waves), ever
+    unsigned *cnt;   // [NST] completion counters of this handle: work items done per stage, ever
 };
 
 // XCD affinity, for speed only (nothing depends on it): workgroup b of a launch runs on XCD b % 8, each XCD with
@@ -523,24 +519,20 @@ __device__ __forceinline__ void signal_done(unsigned *counter, int lane)
 
 // Neighbour-tap role of k_column: a 1024-thread workgroup takes four work items, four waves each.  A work item =
 // (stage, slot NA|NB, 16 output channels) for a tile of 16 frames; its 4 waves take the 4 taps of the slot and
-// the partials are added in tap order (the order k_gemm uses).  The last 4 items of a tile are the u_init gather
-// (one wave per frame).  Every item bumps its stage's completion counter when its results are out.
+// the partials are added in tap order (the order k_gemm uses).  Every item bumps its stage's completion counter
+// once its results are out.
 __device__ __forceinline__ void nbr_role(const NbrArgs &a, int nb)
 {
     __shared__ __attribute__((aligned(16))) float sNP[4][4][16][20];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, kk = lane >> 4;
     const int grp4 = wave >> 2, w4 = wave & 3;
-    const int per_tile = a.nwork + 4;
     const int item = nb * 4 + grp4;
-    const bool active = item < per_tile * ((a.F + 15) / 16);
-    // item order within a tile: the u_init gather first (the chain needs it before anything else), then the conv
-    // work items in stage order
-    const int ftile = active ? item / per_tile : 0, witem = active ? item - ftile * per_tile - 4 : 0;
-    const bool conv = active && witem >= 0;
+    const bool active = item < a.nwork * ((a.F + 15) / 16);
+    const int ftile = active ? item / a.nwork : 0, witem = active ? item - ftile * a.nwork : 0;
     NbrWork wk{};
     int f = 0;
     bool valid = false;
-    if (conv) {
+    if (active) {
         wk = a.work[witem];
         f = ftile * 16 + i;
         valid = f < a.F;
@@ -548,19 +540,9 @@ __device__ __forceinline__ void nbr_role(const NbrArgs &a, int nb)
         const f32x4 part = wk.NG == 10 ? nbr_tap<10>(wk, a, t, wk.cog * 16, f, valid, i, kk)
                                        : nbr_tap<5>(wk, a, t, wk.cog * 16, f, valid, i, kk);
         *(f32x4 *)(&sNP[grp4][w4][i][kk * 4]) = part;
-    } else if (active) {  // u_init gather: this wave's frame, 20 groups of 4 channels
-        const int fu = ftile * 16 + (witem + 4) * 4 + w4;
-        if (fu < a.F && lane < NGRP) {
-            float mA[9];
-#pragma unroll
-            for (int t = 0; t < 9; ++t) mA[t] = a.ctx[fu].m[0][t];
-            store_through(a.upre + (size_t)fu * NF + 4 * lane,
-                          uinit_gather<f32x4>(a.codes + (size_t)fu * a.L, mA, a.uinit_w, a.uinit_b, a.ctx[fu].q, a.H, a.W, 4 * lane));
-        }
-        signal_done(a.cnt + NST, lane);
     }
     __syncthreads();
-    if (conv && w4 == 0) {
+    if (active && w4 == 0) {
         if (valid) {
             const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
             f32x4 tot = zero;
@@ -575,8 +557,9 @@ __device__ __forceinline__ void nbr_role(const NbrArgs &a, int nb)
 struct ChainArgs {
     const StageDesc *stages;
     const int *ctl1;          // k_chain1's per-stage control records (C1_CTL_DWORDS dwords each), read with scalar loads
-    const float *nbr;
-    const float *upre;        // [F][NF] from k_nbr
+    const float *nbr;         // neighbour slots of this launch, from the neighbour role
+    const float *uinit_w, *uinit_b;
+    const int32_t *codes_in;  // (F,L) current codes: the u_init gather reads earlier positions
     CtxArgs cx;
     const float *out_b;
     int H, W, L, F;
@@ -813,7 +796,7 @@ __device__ __forceinline__ void chain_role(const ChainArgs &a, int wg)
                 o.b2[k] = *PS_GC(float, b2 + ch[k]);
             }
         };
-        // completion counter of stage k (NST: the u_init gather); `have` is a value loaded earlier (normally already
+        // completion counter of stage k; `have` is a value loaded earlier (normally already
         // past the target, so this costs nothing); bounded, so a lost neighbour workgroup cannot hang the GPU
         auto counter = [&](int k) { return __hip_atomic_load(a.cnt + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
         auto wait_counter = [&](unsigned have, int k, unsigned items_per_tile) {
@@ -922,16 +905,22 @@ __device__ __forceinline__ void chain_role(const ChainArgs &a, int wg)
             PS_TRACE1(t == C1_THREADS - 64, 4);
         };
         Ops oA, oB;
-        {   // u0 = norm_init(u_init) from the neighbour role's gather
-            wait_counter(counter(NST), NST, 16u);
-            const float *up = a.upre + (size_t)(pvalid ? pfr : 0) * NF;
-            const float y[2] = {fresh(up + cA), fresh(up + cB)}, z[2] = {0.0f, 0.0f};
+        {   // u0 = norm_init(u_init): the gather over the (earlier) neighbours' codes, one channel per lane
+            const int fr = pvalid ? pfr : 0;
+            float mA[9];
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) mA[tp] = a.cx.ctx[fr].m[0][tp];
+            const int q0 = a.cx.ctx[fr].q;
+            const int32_t *cf = a.codes_in + (size_t)fr * a.L;
+            const float y[2] = {uinit_gather<float>(cf, mA, a.uinit_w, a.uinit_b, q0, a.H, a.W, cA),
+                                uinit_gather<float>(cf, mA, a.uinit_w, a.uinit_b, q0, a.H, a.W, cB)}, z[2] = {0.0f, 0.0f};
+            post_and_emit(y, z, z, integral_constant<int, PRO_UINIT>{}, integral_constant<bool, false>{},
+                          integral_constant<int, IN_CELU>{}, cur.save_slot);
+            // the neighbour slots of stage 0 are first needed after the chains of stage 0
             wait_counter(counter(0), 0, (unsigned)nxt.nbr_items);
             cnt_nxt = counter(1);
             load_ops(0, nxt, oA);
             load_ops(0, nxt, oB);
-            post_and_emit(y, z, z, integral_constant<int, PRO_UINIT>{}, integral_constant<bool, false>{},
-                          integral_constant<int, IN_CELU>{}, cur.save_slot);
             lds_barrier();
         }
         for (int s = 0; s < NST - 3; s += 2) {
@@ -1278,7 +1267,6 @@ struct ps_pixelcnn {
     float *R[NNODE], *E[NNODE], *X[NGATED];
     float *partial = nullptr;       // whole-grid slots [4][maxF*L][160]
     float *nbr = nullptr;           // column mode: neighbour slots [NST][2][maxF][160]
-    float *upre = nullptr;          // column mode: u_init before norm_init [maxF][80]
     float *col_logits = nullptr;
     StepCtx *ctx = nullptr;
     StageDesc *stages = nullptr;    // device copy of the 33-stage chain description
@@ -1524,10 +1512,10 @@ void run_column(ps_pixelcnn *h, int F, const int32_t *codes, ChainArgs ca, hipSt
     // XCD split: up to 32 frames, the chain workgroups (blocks 0, 8, 16, ...) fill XCD 0 (32 CUs) and the neighbour
     // role gets XCDs 1..7 (V=16: chain 47.5 -> 42.5 us); with more frames both use the whole chip
     const bool split = h->xcd_pack && F <= 32;
-    const int tiles = (F + 15) / 16, nbr_wgs = ((h->nwork + 4) * tiles + 3) / 4;
-    NbrArgs na{h->stages, h->work, h->ctx, h->nbr, h->upre, codes, h->uinit_w, h->uinit_b, h->nwork, h->H, h->W, h->L, F,
-               split ? 1 : 0, h->cnt};
-    ca.stages = h->stages; ca.ctl1 = h->ctl1; ca.nbr = h->nbr; ca.upre = h->upre;
+    const int tiles = (F + 15) / 16, nbr_wgs = (h->nwork * tiles + 3) / 4;
+    NbrArgs na{h->stages, h->work, h->ctx, h->nbr, h->nwork, h->H, h->W, h->L, F, split ? 1 : 0, h->cnt};
+    ca.stages = h->stages; ca.ctl1 = h->ctl1; ca.nbr = h->nbr;
+    ca.uinit_w = h->uinit_w; ca.uinit_b = h->uinit_b; ca.codes_in = codes;
     ca.out_b = h->out_b;
     ca.H = h->H; ca.W = h->W; ca.L = h->L; ca.F = F;
     ca.cnt = h->cnt; ca.epoch = ++h->epoch; ca.tiles = tiles; ca.err = h->err;
@@ -1632,7 +1620,6 @@ int ps_pixelcnn_create(const float *const *params, int n_params, int H, int W, i
     if ((rc = dev_alloc(h, &h->partial, pfloats))) return fail_out(rc);
     if ((rc = dev_alloc(h, &h->col_logits, (size_t)max_frames * NCLS))) return fail_out(rc);
     if ((rc = dev_alloc(h, &h->nbr, (size_t)NST * 2 * max_frames * NBR_LD))) return fail_out(rc);
-    if ((rc = dev_alloc(h, &h->upre, (size_t)max_frames * NF))) return fail_out(rc);
     if ((rc = dev_alloc(h, &h->ctx, (size_t)max_frames))) return fail_out(rc);
     if ((rc = dev_alloc(h, &h->cnt, (size_t)NST + 1))) return fail_out(rc);
     if ((rc = dev_alloc(h, &h->err, 1))) return fail_out(rc);
