@@ -119,15 +119,17 @@ struct GemmArgs {
     float *partial;  // [nslots][nitems][Co_pad]
 };
 
-// grid (Co_pad/16, nslots, item blocks), one wave per block
-__global__ __launch_bounds__(64) void k_gemm(GemmArgs a)
+// One wave = 16 items x (T x 16) output channels of one slot: the gathered input rows (B operand) are loaded once
+// per 80-channel chunk and reused by the T output tiles, so the kernel is bound by the MFMA pipe rather than by
+// the per-CU L1 fill rate (at T = 1 every 40 MFMAs needed 20 KB of operands).
+template <int T>
+__device__ __forceinline__ void gemm_tiles(const GemmArgs &a, int o0, int slot, int first_tile)
 {
     const int lane = threadIdx.x, i = lane & 15, kk = lane >> 4;
-    const int o0 = blockIdx.x * 16, slot = blockIdx.y;
     const int ngroups = a.Cin >> 4;
     const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
     for (int tt = 0; tt < a.tiles_per_block; ++tt) {
-        const int tile = blockIdx.z * a.tiles_per_block + tt;
+        const int tile = first_tile + tt;
         if (tile * 16 >= a.nitems) break;
         const int item = tile * 16 + i;
         const bool valid = item < a.nitems;
@@ -138,7 +140,9 @@ __global__ __launch_bounds__(64) void k_gemm(GemmArgs a)
             c = q - r * a.W;
         }
         // slot value = taps of the slot added in order, each tap from fresh accumulators: P_t = chunk_total(acc)
-        f32x4 tot = zero;
+        f32x4 tot[T];
+#pragma unroll
+        for (int u = 0; u < T; ++u) tot[u] = zero;
         for (int t = a.slot_first[slot]; t < a.slot_first[slot + 1]; ++t) {
             const GemmTap tp = a.tap[t];
             const float *src = nullptr;
@@ -150,33 +154,56 @@ __global__ __launch_bounds__(64) void k_gemm(GemmArgs a)
             }
             const bool live = mv != 0.0f;
             if (!__any(live)) continue;  // a masked tap is an exact zero: skipping it does not change the bits
-            Acc5 acc = acc5_zero();
+            Acc5 acc[T];
+#pragma unroll
+            for (int u = 0; u < T; ++u) acc[u] = acc5_zero();
             const float *wbase = tp.w + ((size_t)kk * a.Co_pad + o0 + i) * 4;
             int g = 0;
             for (; g + 5 <= ngroups; g += 5) {
-                f32x4 av[5], bv[5];
+                f32x4 bv[5];
 #pragma unroll
-                for (int j = 0; j < 5; ++j) {
-                    av[j] = *(const f32x4 *)(wbase + (size_t)(g + j) * 16 * a.Co_pad);
-                    bv[j] = live ? *(const f32x4 *)(src + 16 * (g + j)) * mv : zero;
+                for (int j = 0; j < 5; ++j) bv[j] = live ? *(const f32x4 *)(src + 16 * (g + j)) * mv : zero;
+#pragma unroll
+                for (int u = 0; u < T; ++u) {
+                    f32x4 av[5];
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) av[j] = *(const f32x4 *)(wbase + (size_t)(g + j) * 16 * a.Co_pad + 64 * u);
+                    mfma_chunk5(av, bv, acc[u]);
                 }
-                mfma_chunk5(av, bv, acc);
             }
             for (; g < ngroups; ++g) {  // ragged channel counts of the generic lmconv entry point only
-                const f32x4 av = *(const f32x4 *)(wbase + (size_t)g * 16 * a.Co_pad);
                 const f32x4 bv = live ? *(const f32x4 *)(src + 16 * g) * mv : zero;
-                f32x4 &a0 = acc.v[0];
-                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, a0, 0, 0, 0);
-                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, a0, 0, 0, 0);
-                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, a0, 0, 0, 0);
-                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, a0, 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < T; ++u) {
+                    const f32x4 av = *(const f32x4 *)(wbase + (size_t)g * 16 * a.Co_pad + 64 * u);
+                    f32x4 &a0 = acc[u].v[0];
+                    a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, a0, 0, 0, 0);
+                    a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, a0, 0, 0, 0);
+                    a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, a0, 0, 0, 0);
+                    a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, a0, 0, 0, 0);
+                }
             }
-            tot = tot + chunk_total(acc);
+#pragma unroll
+            for (int u = 0; u < T; ++u) tot[u] = tot[u] + chunk_total(acc[u]);
         }
         // D: row (output channel) = kk*4 + reg, col (item) = i
-        if (valid)
-            *(f32x4 *)(a.partial + ((size_t)slot * a.nitems + item) * a.Co_pad + o0 + kk * 4) = tot;
+        if (valid) {
+#pragma unroll
+            for (int u = 0; u < T; ++u)
+                *(f32x4 *)(a.partial + ((size_t)slot * a.nitems + item) * a.Co_pad + o0 + 16 * u + kk * 4) = tot[u];
+        }
     }
+}
+
+// grid (ceil(Co_pad / 64), nslots, item blocks), one wave per block
+__global__ __launch_bounds__(64) void k_gemm(GemmArgs a)
+{
+    const int o0 = blockIdx.x * 64, slot = blockIdx.y, first_tile = blockIdx.z * a.tiles_per_block;
+    const int T = min(4, (a.Co_pad - o0) >> 4);
+    if (T == 4) gemm_tiles<4>(a, o0, slot, first_tile);
+    else if (T == 3) gemm_tiles<3>(a, o0, slot, first_tile);
+    else if (T == 2) gemm_tiles<2>(a, o0, slot, first_tile);
+    else gemm_tiles<1>(a, o0, slot, first_tile);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1361,9 +1388,9 @@ void run_grid(ps_pixelcnn *h, int F, const int32_t *codes, const Masks &m, float
     auto gemm = [&](GemmArgs &a, const float *mask) {
         a.items = items;
         a.H = h->H; a.W = h->W; a.L = h->L; a.nitems = nitems;
-        a.mask = mask; a.mask_fstride = (size_t)9 * h->L; a.partial = h->partial; a.tiles_per_block = 8;
+        a.mask = mask; a.mask_fstride = (size_t)9 * h->L; a.partial = h->partial; a.tiles_per_block = 1;
         const int tiles = (nitems + 15) / 16;
-        hipLaunchKernelGGL(k_gemm, dim3(a.Co_pad / 16, a.nslots, (tiles + 7) / 8), dim3(64), 0, st, a);
+        hipLaunchKernelGGL(k_gemm, dim3((a.Co_pad + 63) / 64, a.nslots, tiles), dim3(64), 0, st, a);
     };
     {   // u_init + norm_init  (model.py:132)
         UinitArgs u{items, codes, m.init, h->uinit_w, h->uinit_b, h->R[0], h->E[0], h->H, h->W, h->L, nitems};
@@ -1820,9 +1847,9 @@ int ps_lmconv_forward_f32(const float *x, const float *mask, size_t mask_batch_s
     conv_taps(a, xcl, Cp, wp, Cp, Cop, dilation);
     a.items = ItemMap{nullptr, L};
     a.H = H; a.W = W; a.L = L; a.nitems = B * L; a.mask = mask; a.mask_fstride = mask_batch_stride;
-    a.partial = partial; a.tiles_per_block = 8;
+    a.partial = partial; a.tiles_per_block = 2;
     const int tiles = (a.nitems + 15) / 16;
-    hipLaunchKernelGGL(k_gemm, dim3(Cop / 16, a.nslots, (tiles + 7) / 8), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(k_gemm, dim3((Cop + 63) / 64, a.nslots, (tiles + 1) / 2), dim3(64), 0, st, a);
     hipLaunchKernelGGL(k_reduce_nchw, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, st, partial, bias, B, Co, Cop, L, y);
     PS_LAUNCH_CHECK();
     return PS_OK;
