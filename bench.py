@@ -106,9 +106,15 @@ def measure_roofline(model, d, out, V):
     tf = fl / (us * 1e-6) / 1e12
     tf_chain = flops[1] / (us * 1e-6) / 1e12
     chain_stream = wbytes[1] * V / (us * 1e-6) / 1e9
+    traffic, traffic_src = None, None
+    pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_d_k_column_pmc.json")
+    if V == 16 and os.path.exists(pmc):  # PMC passes cannot run inside the timed bench: committed summary of the same workload
+        with open(pmc) as fh:
+            rec = json.load(fh)
+        traffic, traffic_src = rec["traffic_bytes_per_launch"], rec["source"]
     return {"bound": "mfma", "kernel": "k_column (one launch per AR order position: per-frame centre-tap chains + neighbour-tap slots of all 32 masked convs)",
             "achieved": round(tf, 4), "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-            "frac": round(tf / FP32_MFMA_PEAK_TF, 6), "traffic": None,
+            "frac": round(tf / FP32_MFMA_PEAK_TF, 6), "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_flops_per_launch": round(fl), "avg_launch_us": round(us, 3),
             "chain": {"what": "33 dependent stages per frame, one CU per frame (latency-bound)", "cus": chain_cus,
                       "flops_per_launch": round(flops[1]), "tflops": round(tf_chain, 4),
