@@ -174,7 +174,7 @@ int ps_pixelcnn_forward_f32(ps_pixelcnn *h, const int32_t *codes, const float *m
  *   first_step: order positions < first_step are not walked one by one: they must all be observed
  *   (not in the sample region) in every image, and are covered by one whole-grid pass
  *   (0 is always valid; the caller knows the orders, it built them on the host).
- * Asynchronous on the caller's stream (two launches per order position).  With PS_AR_GRAPH=1 in the
+ * Asynchronous on the caller's stream (one launch per order position).  With PS_AR_GRAPH=1 in the
  * environment at handle creation the loop is replayed as a hipGraph on a stream owned by the handle,
  * fenced against the caller's stream with events on both sides. */
 int ps_pixelcnn_ar_run(ps_pixelcnn *h, int32_t *codes, const int32_t *order,
@@ -193,13 +193,21 @@ int ps_pixelcnn_ar_step(ps_pixelcnn *h, const int32_t *codes, const int32_t *ord
                         const float *mask_dilated, int F, int step, int first_step, float *logits,
                         void *stream);
 
+/* Inside a column launch the per-frame chains consume results of other workgroups of the same launch; every such
+ * wait is bounded, and one that runs out raises a flag in the handle instead of hanging the GPU.  This call
+ * synchronises `stream` and returns PS_OK, or an error if any launch since the handle's creation hit that
+ * limit (its results are then invalid).  Tests, smoke() and bench.py call it after their runs. */
+int ps_pixelcnn_status(ps_pixelcnn *h, void *stream);
+
 /* Measurement aid for bench.py (not part of the reference surface): evaluates `reps` order positions
  * eagerly on `stream` (at position `step`, without drawing) with a HIP event pair around every kernel
- * launch and returns, per kernel class, the number of launches and their summed duration in ms:
- *   [0] k_nbr   (neighbour-tap partial sums of all 32 masked convs, MFMA, whole chip)
- *   [1] k_chain (centre-tap chain + post ops + draw, one workgroup per 16 frames)
- * flops_per_launch / weight_bytes_per_launch [2]: dense algorithmic work of one launch of each class
- * (2*Co*Cin per tap and frame; fp32 weight bytes streamed once).  Synchronises the stream. */
+ * launch and returns the number of launches and their summed duration in ms:
+ *   [0] unused (0 launches; the neighbour taps had their own kernel before the single-launch column step)
+ *   [1] k_column (one launch per order position: neighbour-tap slots of all 32 masked convs on MFMA +
+ *       the per-frame centre-tap chains, post ops and draw)
+ * flops_per_launch / weight_bytes_per_launch [2]: dense algorithmic work of one launch, split as
+ *   [0] neighbour taps, [1] centre-tap chain (2*Co*Cin per tap and frame; fp32 weight bytes streamed once,
+ *   per frame for [1]).  Synchronises the stream. */
 #define PS_PROF_NTAGS 2
 int ps_pixelcnn_time_column_step(ps_pixelcnn *h, const int32_t *codes, const int32_t *order,
                                  const float *mask_init, const float *mask_undilated,

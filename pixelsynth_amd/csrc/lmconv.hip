@@ -1755,6 +1755,16 @@ int ps_pixelcnn_ar_run(ps_pixelcnn *h, int32_t *codes, const int32_t *order, con
     return PS_OK;
 }
 
+int ps_pixelcnn_status(ps_pixelcnn *h, void *stream)
+{
+    PS_REQUIRE(h, "pixelcnn_status: null handle");
+    PS_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    int flag = 0;
+    PS_HIP_CHECK(hipMemcpy(&flag, h->err, sizeof(int), hipMemcpyDeviceToHost));
+    if (flag) return ps::fail(PS_ERR_STATE, "pixelcnn: a bounded in-launch wait ran out (neighbour slots never arrived)");
+    return PS_OK;
+}
+
 int ps_pixelcnn_time_column_step(ps_pixelcnn *h, const int32_t *codes, const int32_t *order, const float *mask_init,
                                  const float *mask_undilated, const float *mask_dilated, int F, int step, int reps,
                                  int *launches, float *total_ms, double *flops_per_launch, double *weight_bytes_per_launch,

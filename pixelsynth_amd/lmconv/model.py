@@ -60,6 +60,10 @@ class PixelCNNEngine:
         rc = _lib.lib().ps_pixelcnn_create(ptrs, len(arrs), H, W, max_frames, ctypes.byref(self.handle))
         _lib.check(rc, "ps_pixelcnn_create")
 
+    def check(self):
+        """Synchronise and raise if any column launch of this engine gave up on an in-launch wait (ps_pixelcnn_status)."""
+        _lib.check(_lib.lib().ps_pixelcnn_status(self.handle, _lib.current_stream()), "ps_pixelcnn_status")
+
     def close(self):
         if getattr(self, "handle", None):
             _lib.lib().ps_pixelcnn_destroy(self.handle)

@@ -164,6 +164,7 @@ def test_ar_teacher_forced_vs_reference_sample_trace(golden_dir):
         c = tt(codes0.copy())
         out = eng.ar_run(c, tt(order_loc), tt(reg), mi, mu, md, temperature=0.7, forced=tt(final), first_step=fs,
                          want_logits=True)
+        eng.check()
         torch.cuda.synchronize()
         assert np.array_equal(c.cpu().numpy(), final)
         outs.append(out.cpu().numpy())
@@ -195,6 +196,7 @@ def test_ar_fused_sampling_inverse_cdf_and_determinism():
         c = tt(codes0.copy())
         out = eng.ar_run(c, tt(order_loc), tt(reg), *ms, temperature=0.7, uniforms=tt(u), first_step=first,
                          want_logits=True)
+        eng.check()
         torch.cuda.synchronize()
         runs.append((c.cpu().numpy(), out.cpu().numpy()))
     assert np.array_equal(runs[0][0], runs[1][0]) and np.array_equal(runs[0][1], runs[1][1])  # deterministic
@@ -217,6 +219,7 @@ def test_ar_fused_sampling_inverse_cdf_and_determinism():
     c = tt(codes0[1:2].copy())
     eng1.ar_run(c, tt(order_loc[1:2]), tt(reg[1:2]), *[m[1:2].contiguous() for m in ms], temperature=0.7,
                 uniforms=tt(u[1:2]), first_step=first)
+    eng1.check()
     assert np.array_equal(c.cpu().numpy()[0], codes[1])
     # the sampled grid is self-consistent: one whole-grid forward reproduces the logits it was drawn from
     full = eng.forward(tt(codes), *ms).reshape(F_, 512, 1024).permute(0, 2, 1).cpu().numpy()
