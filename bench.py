@@ -123,7 +123,12 @@ def measure_roofline(model, d, out, V):
                       "L2_to_CU_stream_GBs_all_frames": round(chain_stream, 1)},
             "neighbour_taps": {"what": "dense flops of the 8 neighbour taps x 32 convs (masked taps are skipped at run time)",
                                "dense_flops_per_launch": round(flops[0]), "weight_bytes": round(wbytes[0])},
-            "launches_per_ar_position": 1}
+            "launches_per_ar_position": 1,
+            "reference_definition": {
+                "what": "the same launch priced at what the reference schedules for it (SURVEY 8d): one whole-grid forward, "
+                        "11.43095 GFLOP, per frame and order position -- skipped redundant work is NOT utilisation, this is "
+                        "shown for comparison only",
+                "equivalent_tflops": round(11.43095e9 * V / (us * 1e-6) / 1e12, 1)}}
 
 
 def extra_configs(device):
@@ -159,6 +164,45 @@ def extra_configs(device):
     alg = 1900544.0 * 32  # algorithmic bytes per frame of the splat
     res["C2_splat_b32"] = {"frames_per_s": round(32 / dt, 1), "ms_per_batch": round(dt * 1e3, 3),
                            "algorithmic_GBs": round(alg / dt / 1e9, 2), "frac_hbm": round(alg / dt / 1e9 / HBM_PEAK_GBS, 5)}
+    # C2 in idx-emitting mode: the (B,S,S,K) idx / zbuf / dist tensors PyTorch3D materialises, B = 4
+    pts4 = pm.project_pts(d32["depth"][:4].reshape(4, 1, -1), d32["K"][:4], d32["Kinv"][:4], d32["P"][:4], d32["Pinv"][:4],
+                          d32["RT2"][:4], d32["RT2inv"][:4]).permute(0, 2, 1).contiguous()
+    src4 = d32["img"][:4].reshape(4, 3, -1).contiguous()
+    dbg = lambda: pm.splatter(pts4.clone(), src4, return_debug=True)
+    for _ in range(2):
+        dbg()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 5
+    for _ in range(n):
+        dbg()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    alg_dbg = (1900544.0 - 262144.0 + 786432.0 + 3 * 4 * 128 * 65536.0) * 4  # points in, + idx/zbuf/dist (S,S,K) out
+    res["C2_splat_idx_emitting_b4"] = {"frames_per_s": round(4 / dt, 1), "ms_per_batch": round(dt * 1e3, 3),
+                                       "algorithmic_GBs": round(alg_dbg / dt / 1e9, 2),
+                                       "frac_hbm": round(alg_dbg / dt / 1e9 / HBM_PEAK_GBS, 5)}
+    # C3 in reference-faithful mode (sample.py:54-57): one whole-grid forward per sampled code
+    eng = m1.outpaint2.engine(32, 32, 1)
+    plan = o1["plan"]
+    c1 = o1["codes"].reshape(1, 1024).to(torch.int32).contiguous()
+    fwd = lambda: eng.forward(c1, plan.mask_init, plan.mask_undilated, plan.mask_dilated)
+    for _ in range(2):
+        fwd()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 10
+    for _ in range(n):
+        fwd()
+    torch.cuda.synchronize()
+    t_fwd = (time.perf_counter() - t0) / n
+    n_s = int(plan.n_sampled[0])
+    res["C3_reference_faithful_mode"] = {
+        "ms_per_full_forward": round(t_fwd * 1e3, 3), "forward_tflops": round(11.43095e9 / t_fwd / 1e12, 3),
+        "frac_mfma_fp32": round(11.43095e9 / t_fwd / 1e12 / FP32_MFMA_PEAK_TF, 4),
+        "frames_per_s_extrapolated": round(1.0 / (n_s * t_fwd), 3),
+        "note": f"{n_s} sampled codes x one whole-grid forward each (what the reference schedules); the incremental "
+                "form above does the work of ONE such forward per frame"}
     return res
 
 
