@@ -203,6 +203,29 @@ def extra_configs(device):
         "frames_per_s_extrapolated": round(1.0 / (n_s * t_fwd), 3),
         "note": f"{n_s} sampled codes x one whole-grid forward each (what the reference schedules); the incremental "
                 "form above does the work of ONE such forward per frame"}
+    # SURVEY 8f row 1, reported separately (not part of the metric): VQ-VAE-2 top level either side of the AR loop for the
+    # 16 views of a step -- reprojected view -> top codes (convs through MIOpen, quantiser = ps_vq_nearest_f32) and
+    # sampled codes -> 256x256 image (ps_vq_embed_f32 + transposed convs), random-init weights
+    from pixelsynth_amd.vqvae2 import VQVAETop
+    vq = VQVAETop().eval()
+    vq.load_state_dict({k: torch.from_numpy(v) for k, v in syn.vqvae_state_dict(0).items()})
+    vq = vq.to(device)
+    d16, _ = make_inputs(2, 16, device)
+    gen16 = pm.forward_justpts(d16["img"], d16["depth"], d16["K"], d16["Kinv"], d16["P"], d16["Pinv"], d16["RT2"], d16["RT2inv"])[0]
+    timings = {}
+    for name, fn in (("encode_codes", lambda: vq.encode_codes(gen16)), ("decode_code", lambda: vq.decode_code(d16["codes"]))):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 10
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        timings[name] = (time.perf_counter() - t0) / n
+    res["VQVAE_top_16_views"] = {"encode_codes_ms": round(timings["encode_codes"] * 1e3, 3),
+                                 "decode_code_ms": round(timings["decode_code"] * 1e3, 3),
+                                 "note": "next-row component (SURVEY 8f.1), outside the headline metric"}
     return res
 
 

@@ -215,6 +215,23 @@ int ps_pixelcnn_time_column_step(ps_pixelcnn *h, const int32_t *codes, const int
                                  float *total_ms, double *flops_per_launch,
                                  double *weight_bytes_per_launch, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Vector quantisation around the AR loop (VQ-VAE-2 top level, models/vqvae2/vqvae.py) -- SURVEY 8f row 1
+ * ------------------------------------------------------------------------------------------- */
+
+/* Quantize.forward, inference part (models/vqvae2/vqvae.py:41-51): for every latent vector the index of the
+ * nearest codebook column.  z: layout 0 = (N,D) row-major (the reference's `flatten`), layout 1 = (B,D,HW) as the
+ * 1x1 conv in front of it leaves it (row n = b*HW + p; HW given, N = B*HW); embed (D,K) f32 (the reference's
+ * `embed` buffer); idx (N) int32; mindist (N) f32 or NULL.  D <= 64.
+ *   dist[n][k] = (|z_n|^2 - 2 z_n.e_k) + |e_k|^2, sums in ascending d (fused multiply-adds); ties -> smallest k. */
+int ps_vq_nearest_f32(const float *z, int layout, const float *embed, int N, int D, int K, int HW,
+                      int32_t *idx, float *mindist, void *stream);
+
+/* Quantize.embed_code + permute(0,3,1,2) (models/vqvae2/vqvae.py:77-78,306-307): idx (B,HW) int32 -> out (B,D,HW)
+ * f32, out[b][d][p] = embed[d][idx[b][p]] (zeros for an index outside [0,K)). */
+int ps_vq_embed_f32(const int32_t *idx, const float *embed, int B, int HW, int D, int K, float *out,
+                    void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -35,6 +35,8 @@ _PROTOS = {
     "ps_pixelcnn_forward_f32": (c_int, [c_void_p] * 5 + [c_int, c_void_p, c_void_p]),
     "ps_pixelcnn_ar_run": (c_int, [c_void_p] * 9 + [c_float, c_int, c_int, c_void_p, c_void_p]),
     "ps_pixelcnn_status": (c_int, [c_void_p, c_void_p]),
+    "ps_vq_nearest_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "ps_vq_embed_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ps_pixelcnn_time_column_step": (c_int, [c_void_p] * 6 + [c_int, c_int, c_int] + [c_void_p] * 5),
     "ps_pixelcnn_ar_step": (c_int, [c_void_p] * 6 + [c_int, c_int, c_int, c_void_p, c_void_p]),
 }

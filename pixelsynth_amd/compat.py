@@ -17,6 +17,7 @@ ALIASES = {
     "models.lmconv.masking": "pixelsynth_amd.lmconv.masking",
     "models.lmconv.sample": "pixelsynth_amd.lmconv.sample",
     "models.lmconv.utils": "pixelsynth_amd.lmconv.utils",
+    "models.vqvae2.vqvae": "pixelsynth_amd.vqvae2.vqvae",
 }
 
 

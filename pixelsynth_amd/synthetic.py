@@ -188,3 +188,59 @@ def background_masks(S=256):
     out["all"] = np.ones((S, S), bool)
     out["ragged"] = ((xx + (yy // 3) % 11) >= (S * 3) // 5)
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# VQ-VAE-2 top level (models/vqvae2/vqvae.py:VQVAETop with its default sizes): parameter / buffer names and shapes
+# in the reference's state_dict order; conv weights (Co,Ci,k,k), transposed convs (Ci,Co,k,k).
+# ------------------------------------------------------------------------------------------------
+def _vq_res(prefix, ch=128, rc=32):
+    return [(prefix + ".conv.1", (rc, ch, 3, 3), False), (prefix + ".conv.3", (ch, rc, 1, 1), False)]
+
+
+VQVAE_LAYERS = (
+    [("enc_b.blocks.0", (64, 3, 4, 4), False), ("enc_b.blocks.2", (128, 64, 4, 4), False), ("enc_b.blocks.4", (128, 128, 3, 3), False)]
+    + _vq_res("enc_b.blocks.5") + _vq_res("enc_b.blocks.6")
+    + [("enc_t.blocks.0", (64, 128, 4, 4), False), ("enc_t.blocks.2", (128, 64, 3, 3), False)]
+    + _vq_res("enc_t.blocks.3") + _vq_res("enc_t.blocks.4")
+    + [("quantize_conv_t", (64, 128, 1, 1), False), ("quantize_t", None, None), ("dec_t.blocks.0", (128, 64, 3, 3), False)]
+    + _vq_res("dec_t.blocks.1") + _vq_res("dec_t.blocks.2")
+    + [("dec_t.blocks.4", (128, 64, 4, 4), True), ("quantize_conv_b", (64, 192, 1, 1), False), ("quantize_b", None, None),
+       ("upsample_t", (64, 64, 4, 4), True), ("dec.blocks.0", (128, 64, 3, 3), False)]
+    + _vq_res("dec.blocks.1") + _vq_res("dec.blocks.2")
+    + [("dec.blocks.4", (128, 64, 4, 4), True), ("dec.blocks.6", (64, 3, 4, 4), True)])
+
+
+def vqvae_state_dict(seed=0, encoder_gain=2.0):
+    """Random VQVAETop weights with the reference's names / shapes and torch's default init ranges
+    (kaiming_uniform(a=sqrt5): bound 1/sqrt(fan_in)); codebooks ~ N(0,1) like the reference's buffers.
+    The encoder weights are scaled by `encoder_gain` per layer: at the default init the latent of a random image
+    is almost constant over the grid (spatial std 0.003 against a channel offset of 0.09) and every location would get
+    the same code.  Use codebook_from_latents for a codebook that matches the latent distribution."""
+    rs = np.random.RandomState(seed)
+    sd = {}
+    for name, shape, transposed in VQVAE_LAYERS:
+        if shape is None:
+            embed = rs.randn(64, 512).astype(np.float32)
+            sd[name + ".embed"] = embed
+            sd[name + ".cluster_size"] = np.zeros(512, np.float32)
+            sd[name + ".embed_avg"] = embed.copy()
+            continue
+        fan_in = (shape[0] if transposed else shape[1]) * shape[2] * shape[3]
+        bound = 1.0 / math.sqrt(fan_in)
+        gain = encoder_gain if name.startswith(("enc_", "quantize_conv_t")) else 1.0
+        sd[name + ".weight"] = ((rs.rand(*shape) * 2.0 - 1.0) * bound * gain).astype(np.float32)
+        nb = shape[1] if transposed else shape[0]
+        sd[name + ".bias"] = ((rs.rand(nb) * 2.0 - 1.0) * bound).astype(np.float32)
+    return sd
+
+
+def codebook_from_latents(lat, seed=0, n_embed=512, jitter=0.05):
+    """A synthetic codebook that matches a latent distribution (what training's EMA update converges to): n_embed
+    latent vectors of `lat` (B,D,H,W) picked at random, jittered by `jitter` x their spatial std -> (D, n_embed) f32."""
+    rs = np.random.RandomState(seed)
+    B, D, H, W = lat.shape
+    flat = np.ascontiguousarray(lat.transpose(0, 2, 3, 1).reshape(-1, D))
+    pick = flat[rs.randint(0, flat.shape[0], size=n_embed)]
+    spread = float((flat - flat.mean(0, keepdims=True)).std())
+    return np.ascontiguousarray((pick + rs.randn(n_embed, D) * jitter * spread).T.astype(np.float32))

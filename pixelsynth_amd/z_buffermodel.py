@@ -70,6 +70,9 @@ class ZbufferModelPts(nn.Module):
         super().__init__()
         self.opt = opt
         self.pts_regressor = pts_regressor
+        if vqvae is None and getattr(opt, "vqvae", False):  # z_buffermodel.py:81-82
+            from .vqvae2 import VQVAETop
+            vqvae = VQVAETop()
         self.vqvae = vqvae
         self.projector = projector
         C = 3 if getattr(opt, "use_rgb_features", True) else 64
@@ -163,6 +166,8 @@ class ZbufferModelPts(nn.Module):
         plan = build_ar_plan(background_mask, self.obs[1])
         V = fs.shape[0]
         L = self.obs[1] * self.obs[2]
+        if codes is None:  # z_buffermodel.py:345: the VQ-VAE top codes of the reprojected view
+            codes = self.vqvae.encode_codes(gen_fs)
         c32 = codes.reshape(V, L).to(torch.int32).contiguous().clone()
         eng = self.outpaint2.engine(self.obs[1], self.obs[2], V)
         if forced is None and uniforms is None:
@@ -193,7 +198,8 @@ class ZbufferModelPts(nn.Module):
         masks_init, masks_undilated, masks_dilated, gen_order = self.get_masks_for_batch(output_RT, input_RTinv,
                                                                                          background_mask)
         if self.vqvae is not None:
-            downsampled_fs = self.vqvae.encode(gen_fs)[3]
+            enc = getattr(self.vqvae, "encode_codes", None)      # our mirror: top codes only, int32, on the device
+            downsampled_fs = enc(gen_fs) if enc is not None else self.vqvae.encode(gen_fs)[3]
         else:
             downsampled_fs = batch["codes"].to(dev)
         autoreg_output, _ = sample(self.outpaint2, gen_order, masks_init, masks_undilated, masks_dilated,

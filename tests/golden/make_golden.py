@@ -299,10 +299,39 @@ def gen_ar_trace(R):
     print("ar_trace.npz", len(fx))
 
 
+def gen_vqvae(R):
+    """VQ-VAE-2 top level: the reference's own VQVAETop (models/vqvae2/vqvae.py:229-311) with the
+    synthetic weights of pixelsynth_amd.synthetic.vqvae_state_dict(0) and a codebook calibrated on image A
+    (codebook_from_latents); encode image B -> top codes, decode_code(codes) -> image.  Stored: the codebook, the
+    pre-quantisation latent of B, the codes, the two smallest distances per location (tie margin), the decoded
+    image on a 4x4-subsampled grid, and the state_dict key / shape list (strict load = name compatibility)."""
+    from models.vqvae2.vqvae import VQVAETop
+    sd = {k: t(v) for k, v in syn.vqvae_state_dict(0).items()}
+    ref = VQVAETop().eval()
+    assert list(ref.state_dict().keys()) == list(sd.keys())
+    ref.load_state_dict(sd, strict=True)
+    imgA, imgB = t(syn.image(11, 1, 3, 256)), t(syn.image(7, 1, 3, 256))
+    with torch.no_grad():
+        latA = ref.quantize_conv_t(ref.enc_t(ref.enc_b(imgA.clone())))
+        embed = syn.codebook_from_latents(latA.numpy(), 0)
+        ref.quantize_t.embed.copy_(t(embed))
+        latB = ref.quantize_conv_t(ref.enc_t(ref.enc_b(imgB.clone())))
+        _, _, _, id_t, _ = ref.encode(imgB.clone())
+        flat = latB.permute(0, 2, 3, 1).reshape(-1, 64)
+        dist = flat.pow(2).sum(1, keepdim=True) - 2 * flat @ ref.quantize_t.embed + ref.quantize_t.embed.pow(2).sum(0, keepdim=True)
+        two = dist.sort(1)[0][:, :2]
+        dec = ref.decode_code(id_t)
+    keys = np.array([f"{k}:{','.join(map(str, v.shape))}" for k, v in ref.state_dict().items()])
+    np.savez_compressed(os.path.join(HERE, "vqvae.npz"), embed=embed, latB=latB.numpy(), codes=id_t.numpy().astype(np.int32),
+                        two_smallest=two.numpy(), dec_sub=dec.numpy()[:, :, ::4, ::4], keys=keys,
+                        image_seeds=np.array([11, 7]))
+    print("vqvae: unique codes", int(id_t.unique().numel()), "min gap", float((two[:, 1] - two[:, 0]).min()))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     R = _import_reference()
-    which = sys.argv[1:] or ["projection", "orders", "layers", "blocks", "network", "ar"]
+    which = sys.argv[1:] or ["projection", "orders", "layers", "blocks", "network", "ar", "vqvae"]
     if "projection" in which:
         gen_projection(R)
     if "orders" in which:
@@ -315,3 +344,5 @@ if __name__ == "__main__":
         gen_network(R)
     if "ar" in which:
         gen_ar_trace(R)
+    if "vqvae" in which:
+        gen_vqvae(R)

@@ -1,0 +1,126 @@
+"""GPU: VQ kernels (ps_vq_nearest_f32 / ps_vq_embed_f32 through the C ABI) and the VQVAETop mirror against the
+oracle and the reference's golden outputs (tests/golden/vqvae.npz).
+
+Index parity: the nearest-code index is an arg-min over float32 distances whose summation order the reference
+leaves to its BLAS, so it is exact wherever the two smallest distances differ by more than the float noise
+(TIE = 1e-4 relative); at the few near-ties either candidate is accepted (and checked to be one of the two)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vqvae_oracle as vo
+from pixelsynth_amd import _lib, synthetic as syn
+
+pytestmark = pytest.mark.gpu
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "vqvae.npz"))
+TIE = 1e-4
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def nearest(z, layout, embed, hw=1, want_dist=False):
+    n = z.numel() // embed.shape[0]
+    idx = torch.empty(n, dtype=torch.int32, device="cuda")
+    md = torch.empty(n, dtype=torch.float32, device="cuda") if want_dist else None
+    rc = _lib.lib().ps_vq_nearest_f32(_lib.ptr(z), layout, _lib.ptr(embed), n, embed.shape[0], embed.shape[1], hw, _lib.ptr(idx),
+                                      _lib.ptr(md) if want_dist else None, _lib.current_stream())
+    _lib.check(rc, "ps_vq_nearest_f32")
+    return (idx, md) if want_dist else idx
+
+
+def check_indices(got, z, embed):
+    """got (N,) vs the float64 distances of the same inputs: exact except at near-ties."""
+    d = ((z.astype(np.float64)[:, :, None] - embed.astype(np.float64)[None]) ** 2).sum(1)
+    order = np.argsort(d, 1, kind="stable")
+    best, second = order[:, 0], order[:, 1]
+    rows = np.arange(len(d))
+    gap = (d[rows, second] - d[rows, best]) / np.maximum(d[rows, best], 1e-12)
+    ok = got == best
+    assert np.all(ok | (gap < TIE)), f"{(~ok & (gap >= TIE)).sum()} wrong indices away from ties"
+    near = ~ok
+    assert np.all(d[rows[near], got[near]] <= d[rows[near], best[near]] * (1 + TIE) + 1e-12)
+    return int(near.sum())
+
+
+@pytest.mark.parametrize("N,D,K", [(1, 64, 512), (16, 64, 512), (1000, 64, 512), (37, 8, 5), (300, 33, 700)])
+def test_nearest_random(N, D, K):
+    rs = np.random.RandomState(N + D + K)
+    z, emb = rs.randn(N, D).astype(np.float32), rs.randn(D, K).astype(np.float32)
+    idx, md = nearest(dev(z), 0, dev(emb), want_dist=True)
+    got = idx.cpu().numpy()
+    assert got.min() >= 0 and got.max() < K
+    check_indices(got, z, emb)
+    d = ((z.astype(np.float64)[:, :, None] - emb.astype(np.float64)[None]) ** 2).sum(1)
+    np.testing.assert_allclose(md.cpu().numpy(), d[np.arange(N), got], rtol=1e-4, atol=1e-4)
+
+
+def test_nearest_exact_ties_take_the_smallest_index():
+    z = np.zeros((4, 8), np.float32)
+    emb = np.ones((8, 6), np.float32)
+    emb[:, 3] = 0.5
+    emb[:, 5] = 0.5            # columns 3 and 5 are identical minimisers
+    assert nearest(dev(z), 0, dev(emb)).cpu().tolist() == [3, 3, 3, 3]
+
+
+def test_nearest_nchw_layout_equals_flat_layout():
+    lat = G["latB"]                                              # (1,64,32,32)
+    emb = dev(G["embed"])
+    flat = np.ascontiguousarray(lat.transpose(0, 2, 3, 1).reshape(-1, 64))
+    a = nearest(dev(flat), 0, emb).cpu().numpy()
+    b = nearest(dev(lat), 1, emb, hw=1024).cpu().numpy()
+    assert np.array_equal(a, b)
+    near = check_indices(a, flat, G["embed"])
+    ref = G["codes"].reshape(-1)
+    two = G["two_smallest"]
+    gap = (two[:, 1] - two[:, 0]) / np.maximum(np.abs(two[:, 0]), 1e-12)
+    assert np.all((a == ref) | (gap < TIE)) and near <= 8          # the reference's codes, up to its own near-ties
+
+
+def test_embed_gather():
+    emb = G["embed"]
+    codes = G["codes"].copy()
+    codes[0, 0, 0], codes[0, 0, 1] = -1, 512                      # out of range -> zeros
+    out = torch.empty(1, 64, 32, 32, device="cuda")
+    d_codes, d_emb = dev(codes), dev(emb)                          # (kept alive across the asynchronous launch)
+    rc = _lib.lib().ps_vq_embed_f32(_lib.ptr(d_codes), _lib.ptr(d_emb), 1, 1024, 64, 512, _lib.ptr(out), _lib.current_stream())
+    _lib.check(rc, "ps_vq_embed_f32")
+    want = emb[:, np.clip(codes.reshape(-1), 0, 511)].reshape(64, 32, 32)
+    want[:, 0, 0] = 0
+    want[:, 0, 1] = 0
+    assert np.array_equal(out.cpu().numpy()[0], want)
+
+
+def test_errors():
+    L = _lib.lib()
+    z = dev(np.zeros((4, 65), np.float32))
+    assert L.ps_vq_nearest_f32(_lib.ptr(z), 0, _lib.ptr(z), 4, 65, 4, 1, _lib.ptr(z), None, None) < 0   # D > 64
+    assert L.ps_vq_nearest_f32(None, 0, _lib.ptr(z), 4, 8, 4, 1, _lib.ptr(z), None, None) < 0
+
+
+def test_module_encode_decode_against_reference_outputs():
+    from pixelsynth_amd.vqvae2 import VQVAETop
+    sd = {k: torch.from_numpy(v) for k, v in syn.vqvae_state_dict(0).items()}
+    sd["quantize_t.embed"] = torch.from_numpy(G["embed"])
+    m = VQVAETop().eval()
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda()
+    img = dev(syn.image(int(G["image_seeds"][1]), 1, 3, 256))
+    codes = m.encode_codes(img)
+    assert codes.dtype == torch.int32 and codes.is_cuda and tuple(codes.shape) == (1, 32, 32)
+    got, ref = codes.cpu().numpy().reshape(-1), G["codes"].reshape(-1)
+    two = G["two_smallest"]
+    gap = (two[:, 1] - two[:, 0]) / np.maximum(np.abs(two[:, 0]), 1e-12)
+    assert np.all((got == ref) | (gap < TIE)) and (got != ref).sum() <= 8
+    with torch.no_grad():
+        full = m.encode(img)                                       # the reference-shaped surface agrees with the fast path
+    assert torch.equal(full[3].to(torch.int32), codes)
+    dec = m.decode_code(dev(G["codes"]))                           # the reference's codes -> the reference's image
+    np.testing.assert_allclose(dec.cpu().numpy()[:, :, ::4, ::4], G["dec_sub"], rtol=1e-4, atol=1e-5)
+    sd_cpu = {k: v for k, v in sd.items()}
+    with torch.no_grad():
+        want = vo.decode_code(sd_cpu, torch.from_numpy(G["codes"]).long())
+    np.testing.assert_allclose(dec.cpu().numpy(), want.numpy(), rtol=1e-4, atol=1e-5)

@@ -117,3 +117,36 @@ def test_forward_image_reference_shaped_outputs():
     keep = fg32.cpu().numpy()
     assert np.array_equal(outputs["PredCodes"][0].cpu().numpy()[keep], syn.codes(6, 1)[0][keep])
     assert 0.2 < 1 - keep.mean() < 0.9   # a 0.6 rad yaw leaves a large region to outpaint
+
+
+def test_views_with_the_vqvae_in_the_loop():
+    """reprojected view -> VQ-VAE top codes (device int32) -> AR outpainting -> decode_code.
+    The observed part of the code grid must come through untouched, the sampled part must be valid codes, and the
+    decoded image must equal the oracle's decode of the same codes."""
+    from oracle import vqvae_oracle as vo
+    m = make_model(vqvae=True)
+    sd = {k: torch.from_numpy(v) for k, v in syn.vqvae_state_dict(0).items()}
+    m.vqvae.load_state_dict(sd, strict=True)
+    m = m.to(DEV).eval()
+    V = 2
+    cam = syn.demo_cameras(V)
+    img = tt(syn.image(21, V, 3, 256))
+    depth = tt(syn.depth_smooth(22, V, 256, 1.0, 100.0))
+    rts = [syn.yaw_pose(cam["P"][v:v + 1], y) for v, y in enumerate((0.3, -0.45))]
+    RT2 = tt(np.concatenate([r[1] for r in rts]))
+    RT2inv = tt(np.concatenate([r[0] for r in rts]))
+    uni = tt(np.random.RandomState(5).rand(V, 1024).astype(np.float32))
+    out = m.outpaint_views(img, depth, tt(cam["K"]), tt(cam["Kinv"]), tt(cam["P"]), tt(cam["Pinv"]), RT2, RT2inv, None,
+                           temperature=0.7, uniforms=uni)
+    m.outpaint2.engine(32, 32, V).check()
+    codes = out["codes"].cpu().numpy()
+    enc = m.vqvae.encode_codes(out["gen_fs"]).cpu().numpy()
+    region = out["plan"].region.cpu().numpy().astype(bool).reshape(V, 32, 32)
+    assert region.any() and (~region).any()
+    assert np.array_equal(codes[~region], enc[~region])
+    assert codes.min() >= 0 and codes.max() < 512
+    dec = m.vqvae.decode_code(out["codes"])
+    assert tuple(dec.shape) == (V, 3, 256, 256)
+    with torch.no_grad():
+        want = vo.decode_code(sd, torch.from_numpy(codes).long())
+    np.testing.assert_allclose(dec.cpu().numpy(), want.numpy(), rtol=1e-4, atol=1e-5)
