@@ -481,6 +481,7 @@ struct NbrArgs {
     int nwork, H, W, L, F;
     int chain_xcds;  // XCDs 0 .. chain_xcds-1 are left to the chain workgroups (see k_column); 0 = no split
     unsigned *cnt;   // [NST] completion counters of this handle: work items done per stage, ever
+    int nbr_wgs;     // neighbour-role workgroups of the launch
 };
 
 // XCD affinity, for speed only (nothing depends on it): workgroup b of a launch runs on XCD b % 8, each XCD with
@@ -1153,7 +1154,8 @@ __device__ __forceinline__ void chain_role(const ChainArgs &a, int wg)
 // Both start together: the chain only needs the neighbour slots of stage s when it reaches the post op of stage s,
 // and by then the neighbour role -- a few microseconds of parallel work -- is normally done; completion counters
 // per stage (device-scope atomics) and write-through stores carry the hand-off, every wait is bounded.
-// The neighbour workgroups never wait for anything, so the launch cannot deadlock whatever the dispatch order.
+// The neighbour workgroups never wait for anything and are never kept off the chip by waiting chain workgroups (at
+// most 32 chain workgroups in the split layout, neighbour workgroups first in the other), so the launch cannot deadlock.
 // ==========================================================================================
 __global__ __launch_bounds__(C1_THREADS) void k_column(NbrArgs na, ChainArgs ca)
 {
@@ -1163,9 +1165,11 @@ __global__ __launch_bounds__(C1_THREADS) void k_column(NbrArgs na, ChainArgs ca)
         const int ahead = min((b + 7) >> 3, ca.F);  // chain blocks with an index below b
         if ((b & 7) == 0 && (b >> 3) < ca.F) chain_wg = b >> 3;
         nb = b - ahead;
-    } else {
-        if (b < ca.F) chain_wg = b;
-        nb = b - ca.F;
+    } else {  // no split: the neighbour workgroups come FIRST, so that they are dispatched before any chain
+        // workgroup can occupy a CU -- with F >= the number of CUs the chains would otherwise fill the chip and
+        // wait (bounded, but in vain) for neighbour workgroups that cannot start
+        nb = b;
+        if (b >= na.nbr_wgs) chain_wg = b - na.nbr_wgs;
     }
     if (chain_wg >= 0) chain_role<1>(ca, chain_wg);
     else nbr_role(na, nb);
@@ -1540,7 +1544,7 @@ void run_column(ps_pixelcnn *h, int F, const int32_t *codes, ChainArgs ca, hipSt
     // role gets XCDs 1..7 (V=16: chain 47.5 -> 42.5 us); with more frames both use the whole chip
     const bool split = h->xcd_pack && F <= 32;
     const int tiles = (F + 15) / 16, nbr_wgs = (h->nwork * tiles + 3) / 4;
-    NbrArgs na{h->stages, h->work, h->ctx, h->nbr, h->nwork, h->H, h->W, h->L, F, split ? 1 : 0, h->cnt};
+    NbrArgs na{h->stages, h->work, h->ctx, h->nbr, h->nwork, h->H, h->W, h->L, F, split ? 1 : 0, h->cnt, nbr_wgs};
     ca.stages = h->stages; ca.ctl1 = h->ctl1; ca.nbr = h->nbr;
     ca.uinit_w = h->uinit_w; ca.uinit_b = h->uinit_b; ca.codes_in = codes;
     ca.out_b = h->out_b;

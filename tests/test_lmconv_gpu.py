@@ -253,3 +253,39 @@ def test_sample_dropin_modes_agree():
         assert np.array_equal(res[mode][0][keep], syn.codes(31, 1)[0][keep])  # observed codes are never touched
     assert np.array_equal(res["reference"], res["multinomial"])
     assert (res["fused"][0][~keep] != syn.codes(31, 1)[0][~keep]).mean() > 0.9  # really resampled
+
+
+@pytest.mark.parametrize("F_", [17, 40, 300])
+def test_ar_many_frames_layouts(F_):
+    """More frames than one 16-frame tile / than the XCD-split layout takes (32) / than the chip has CUs (256):
+    the column launches must stay exact (sampled grid reproduced bit for bit by one whole-grid forward) and no
+    in-launch wait may run out.  Short walk (last 24 order positions) to keep the test quick."""
+    net = make_net(3)
+    eng = net.engine(32, 32, F_)
+    bgs = syn.background_masks(256)
+    names = ["right_half", "half_plus_island", "ragged"]
+    infos = [c_oracle.masks_for_background(bgs[names[b % 3]], 32) for b in range(F_)]
+    order_loc = np.stack([(i["order"][:, 0] * 32 + i["order"][:, 1]) for i in infos]).astype(np.int32)
+    first = 1000
+    reg = np.zeros((F_, 1024), np.uint8)
+    for b in range(F_):
+        reg[b, order_loc[b][first:]] = 1                      # sample the last 24 positions of every order
+    ms = [tt(np.concatenate([i[k] for i in infos])) for k in ("mask_init", "mask_undilated", "mask_dilated")]
+    codes0 = syn.codes(11, F_).reshape(F_, 1024).astype(np.int32)
+    u = np.random.RandomState(6).rand(F_, 1024).astype(np.float32)
+    c = tt(codes0.copy())
+    out = eng.ar_run(c, tt(order_loc), tt(reg), *ms, temperature=0.7, uniforms=tt(u), first_step=first, want_logits=True)
+    eng.check()
+    codes, logits = c.cpu().numpy(), out.cpu().numpy()
+    assert np.array_equal(codes[reg == 0], codes0[reg == 0]) and (codes[reg == 1] >= 0).all() and (codes[reg == 1] < 512).all()
+    full = eng.forward(tt(codes), *ms).reshape(F_, 512, 1024).permute(0, 2, 1).cpu().numpy()
+    for b in range(F_):
+        walked = order_loc[b][first:]
+        assert np.array_equal(full[b][walked], logits[b][walked]), b
+    # frame independence across layouts: frame 3 of this batch = the same frame run alone
+    eng1 = make_net(3).engine(32, 32, 1)
+    c1 = tt(codes0[3:4].copy())
+    eng1.ar_run(c1, tt(order_loc[3:4]), tt(reg[3:4]), *[m[3:4].contiguous() for m in ms], temperature=0.7,
+                uniforms=tt(u[3:4]), first_step=first)
+    eng1.check()
+    assert np.array_equal(c1.cpu().numpy()[0], codes[3])
