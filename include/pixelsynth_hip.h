@@ -174,9 +174,7 @@ int ps_pixelcnn_forward_f32(ps_pixelcnn *h, const int32_t *codes, const float *m
  *   first_step: order positions < first_step are not walked one by one: they must all be observed
  *   (not in the sample region) in every image, and are covered by one whole-grid pass
  *   (0 is always valid; the caller knows the orders, it built them on the host).
- * Asynchronous on the caller's stream (one launch per order position).  With PS_AR_GRAPH=1 in the
- * environment at handle creation the loop is replayed as a hipGraph on a stream owned by the handle,
- * fenced against the caller's stream with events on both sides. */
+ * Asynchronous on the caller's stream (one launch per order position, enqueued eagerly). */
 int ps_pixelcnn_ar_run(ps_pixelcnn *h, int32_t *codes, const int32_t *order,
                        const uint8_t *sample_region, const float *mask_init,
                        const float *mask_undilated, const float *mask_dilated, const int32_t *forced,

@@ -1307,11 +1307,6 @@ struct ps_pixelcnn {
     unsigned epoch = 0;             // column launches so far
     NbrWork *work = nullptr;
     int nwork = 0;
-    hipStream_t stream = nullptr;   // internal stream for graph capture/replay
-    hipEvent_t ev_in = nullptr, ev_out = nullptr;
-    hipGraph_t graph = nullptr;          // step graph of the last ar_run (kept alive until replaced)
-    hipGraphExec_t graph_exec = nullptr;
-    bool use_graph = true;
     bool xcd_pack = true;  // PS_XCD_PACK=0 turns the XCD split of the column kernels off
     // bench.py profiling aid (ps_pixelcnn_time_column_step): event pair around every launch, by kernel tag
     struct ProfRec { int tag; hipEvent_t e0, e1; };
@@ -1336,17 +1331,6 @@ int upload(ps_pixelcnn *h, float **p, const float *src, size_t count)
     if (int rc = dev_alloc(h, p, count)) return rc;
     PS_HIP_CHECK(hipMemcpy(*p, src, count * sizeof(float), hipMemcpyHostToDevice));
     return PS_OK;
-}
-
-// the executable graph must outlive its launches: drain the internal stream before dropping it
-void release_graph(ps_pixelcnn *h)
-{
-    if (!h->graph_exec && !h->graph) return;
-    (void)hipStreamSynchronize(h->stream);
-    if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
-    if (h->graph) (void)hipGraphDestroy(h->graph);
-    h->graph_exec = nullptr;
-    h->graph = nullptr;
 }
 
 struct Masks { const float *init, *und, *dil; };
@@ -1583,10 +1567,6 @@ int ps_pixelcnn_create(const float *const *params, int n_params, int H, int W, i
     for (int i = 0; i < n_params; ++i) PS_REQUIRE(params[i], "pixelcnn_create: tensor %d is null", i);
     ps_pixelcnn *h = new ps_pixelcnn();
     h->H = H; h->W = W; h->L = H * W; h->maxF = max_frames;
-    // Two launches per order position keep the host far ahead of the GPU, so the loop is launched eagerly on the
-    // caller's stream by default; PS_AR_GRAPH=1 replays it as a hipGraph on a stream owned by the handle instead.
-    const char *env = getenv("PS_AR_GRAPH");
-    h->use_graph = env && env[0] == '1';
     if (const char *xp = getenv("PS_XCD_PACK")) h->xcd_pack = xp[0] != '0';
     int rc = PS_OK;
     auto fail_out = [&](int code) { ps_pixelcnn_destroy(h); return code; };
@@ -1659,12 +1639,6 @@ int ps_pixelcnn_create(const float *const *params, int n_params, int H, int W, i
         return fail_out(PS_ERR_HIP);
     }
     if ((rc = build_stage_table(h))) return fail_out(rc);
-    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_out, hipEventDisableTiming) != hipSuccess) {
-        ps::fail(PS_ERR_HIP, "pixelcnn_create: stream/event creation failed");
-        return fail_out(PS_ERR_HIP);
-    }
     *out = h;
     return PS_OK;
 }
@@ -1672,11 +1646,7 @@ int ps_pixelcnn_create(const float *const *params, int n_params, int H, int W, i
 void ps_pixelcnn_destroy(ps_pixelcnn *h)
 {
     if (!h) return;
-    if (h->stream) release_graph(h);
     for (void *p : h->allocs) (void)hipFree(p);
-    if (h->ev_in) (void)hipEventDestroy(h->ev_in);
-    if (h->ev_out) (void)hipEventDestroy(h->ev_out);
-    if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
 
@@ -1720,13 +1690,7 @@ int ps_pixelcnn_ar_run(ps_pixelcnn *h, int32_t *codes, const int32_t *order, con
     PS_REQUIRE((forced != nullptr) != (uniforms != nullptr), "pixelcnn_ar_run: give exactly one of forced / uniforms");
     PS_REQUIRE(first_step >= 0 && first_step <= h->L, "pixelcnn_ar_run: first_step out of range");
     PS_REQUIRE(temperature > 0.0f, "pixelcnn_ar_run: temperature must be > 0");
-    hipStream_t caller = (hipStream_t)stream;
-    hipStream_t st = h->use_graph ? h->stream : caller;
-    if (h->use_graph) {  // hand over from the caller's stream to the internal (capturable) one
-        release_graph(h);
-        PS_HIP_CHECK(hipEventRecord(h->ev_in, caller));
-        PS_HIP_CHECK(hipStreamWaitEvent(st, h->ev_in, 0));
-    }
+    hipStream_t st = (hipStream_t)stream;
     const Masks m{mask_init, mask_undilated, mask_dilated};
     const size_t n = (size_t)F * h->L;
     hipLaunchKernelGGL(k_mask_codes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, codes, sample_region, n);
@@ -1740,22 +1704,10 @@ int ps_pixelcnn_ar_run(ps_pixelcnn *h, int32_t *codes, const int32_t *order, con
     hipLaunchKernelGGL(k_ctx_init, dim3(F), dim3(32), 0, st, ca.cx, first_step);
     PS_LAUNCH_CHECK();
     const int nsteps = h->L - first_step;
-    if (nsteps > 0) {
-        if (h->use_graph) {
-            PS_HIP_CHECK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-            run_column(h, F, codes, ca, st);
-            PS_HIP_CHECK(hipStreamEndCapture(st, &h->graph));
-            PS_HIP_CHECK(hipGraphInstantiate(&h->graph_exec, h->graph, nullptr, nullptr, 0));
-            for (int sidx = 0; sidx < nsteps; ++sidx) PS_HIP_CHECK(hipGraphLaunch(h->graph_exec, st));
-        } else {
-            for (int sidx = 0; sidx < nsteps; ++sidx) run_column(h, F, codes, ca, st);
-        }
-    }
+    // one launch per order position, enqueued eagerly: the host stays far ahead of the GPU (a hipGraph replay was
+    // measured slower, and the launch tag / completion-counter target changes with every launch anyway)
+    for (int sidx = 0; sidx < nsteps; ++sidx) run_column(h, F, codes, ca, st);
     PS_LAUNCH_CHECK();
-    if (h->use_graph) {
-        PS_HIP_CHECK(hipEventRecord(h->ev_out, st));
-        PS_HIP_CHECK(hipStreamWaitEvent(caller, h->ev_out, 0));
-    }
     return PS_OK;
 }
 
