@@ -107,7 +107,7 @@ def measure_roofline(model, d, out, V):
     tf_chain = flops[1] / (us * 1e-6) / 1e12
     chain_stream = wbytes[1] * V / (us * 1e-6) / 1e9
     traffic, traffic_src = None, None
-    pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_d_k_column_pmc.json")
+    pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_e_k_column_pmc.json")
     if V == 16 and os.path.exists(pmc):  # PMC passes cannot run inside the timed bench: committed summary of the same workload
         with open(pmc) as fh:
             rec = json.load(fh)

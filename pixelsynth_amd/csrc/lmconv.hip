@@ -545,16 +545,22 @@ __device__ __forceinline__ void signal_done(unsigned *counter, int lane)
     if (lane == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Neighbour-tap role of k_column: a 1024-thread workgroup takes four work items, four waves each.  A work item =
+// A neighbour workgroup runs NBR_ITEMS_PER_WG work items, four waves each: with all sixteen waves at work every SIMD
+// would interleave four MFMA chains (4 x 40 x 32 cycles = 2.2 us before the first result of a launch); two items put
+// two waves on each SIMD.
+constexpr int NBR_ITEMS_PER_WG = 2;
+
+// Neighbour-tap role of k_column: a 1024-thread workgroup takes NBR_ITEMS_PER_WG work items, four waves each.  A work item =
 // (stage, slot NA|NB, 16 output channels) for a tile of 16 frames; its 4 waves take the 4 taps of the slot and
 // the partials are added in tap order (the order k_gemm uses).  Every item bumps its stage's completion counter
 // once its results are out.
 __device__ __forceinline__ void nbr_role(const NbrArgs &a, int nb)
 {
-    __shared__ __attribute__((aligned(16))) float sNP[4][4][16][20];
+    __shared__ __attribute__((aligned(16))) float sNP[NBR_ITEMS_PER_WG][4][16][20];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, kk = lane >> 4;
     const int grp4 = wave >> 2, w4 = wave & 3;
-    const int item = nb * 4 + grp4;
+    if (grp4 >= NBR_ITEMS_PER_WG) return;  // (these waves leave before the barrier: it only counts live waves)
+    const int item = nb * NBR_ITEMS_PER_WG + grp4;
     const bool active = item < a.nwork * ((a.F + 15) / 16);
     const int ftile = active ? item / a.nwork : 0, witem = active ? item - ftile * a.nwork : 0;
     NbrWork wk{};
@@ -1527,7 +1533,7 @@ void run_column(ps_pixelcnn *h, int F, const int32_t *codes, ChainArgs ca, hipSt
     // XCD split: up to 32 frames, the chain workgroups (blocks 0, 8, 16, ...) fill XCD 0 (32 CUs) and the neighbour
     // role gets XCDs 1..7 (V=16: chain 47.5 -> 42.5 us); with more frames both use the whole chip
     const bool split = h->xcd_pack && F <= 32;
-    const int tiles = (F + 15) / 16, nbr_wgs = (h->nwork * tiles + 3) / 4;
+    const int tiles = (F + 15) / 16, nbr_wgs = (h->nwork * tiles + NBR_ITEMS_PER_WG - 1) / NBR_ITEMS_PER_WG;
     NbrArgs na{h->stages, h->work, h->ctx, h->nbr, h->nwork, h->H, h->W, h->L, F, split ? 1 : 0, h->cnt, nbr_wgs};
     ca.stages = h->stages; ca.ctl1 = h->ctl1; ca.nbr = h->nbr;
     ca.uinit_w = h->uinit_w; ca.uinit_b = h->uinit_b; ca.codes_in = codes;
