@@ -18,12 +18,16 @@
 //   * The taps are grouped in split-K slots NA (taps 0..3), C (the location itself), NB (taps 5..8) and SKIP
 //     (nin_skip); every consumer adds them as ((bias + NA) + C) + NB, and every kernel walks taps and
 //     80-channel chunks in the same order -- so the two evaluation modes below agree bit for bit.
-//   * Whole-grid mode (k_gemm + k_post_grid, items = F*L): the reference-faithful OurPixelCNN.forward and the
-//     cache build for the prefix of observed locations.
-//   * Column mode (the incremental AR step, items = F): two launches per order position.  k_nbr computes the
-//     NA/NB slots of all 32 convs at once (they only read finished columns of earlier positions); k_chain
-//     walks the 33 dependent stages inside one workgroup per 16 frames (centre-tap products on MFMA,
-//     post ops one wave per frame, LDS hand-off), draws the code and writes the next position's context.
+//   * fp32 MFMA is a chain of fused multiply-adds in ascending k, so MFMA tiles and v_fma_f32 loops that walk one
+//     canonical order (five accumulation chains per tap, mfma_chunk5) produce identical bits.
+//   * Whole-grid mode (k_gemm + k_post_grid, items = F*L or the observed prefix of every order): the
+//     reference-faithful OurPixelCNN.forward and the cache build an AR run starts from.
+//   * Column mode (the incremental AR step, items = F): ONE launch per order position, k_column, with two
+//     workgroup roles that start together -- nbr_role computes the NA/NB slots of all 32 convs (MFMA; they only
+//     read finished columns of earlier positions), chain_role walks the 33 dependent stages of one frame on one
+//     CU (centre taps as per-thread FMA chains on weights held in registers, post op by a dedicated wave, LDS
+//     hand-off), draws the code and writes the next position's context.  Completion counters per stage carry the
+//     neighbour slots across; every wait is bounded.
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -37,7 +41,7 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// Pointers that reach a kernel through a descriptor in memory (StageDesc) are "generic" to the compiler,
+// Pointers that reach a kernel through a descriptor in memory (NbrWork, control records) are "generic" to the compiler,
 // which then emits FLAT loads/stores.  FLAT ops also count on lgkmcnt, so an LDS-only barrier
 // (s_waitcnt lgkmcnt(0)) would drain every weight / slot prefetch in flight.  All descriptor pointers
 // are device-global memory: say so, and get global_load / global_store.
@@ -216,7 +220,7 @@ __global__ __launch_bounds__(64) void k_gemm(GemmArgs a)
 constexpr int NB_LANES = NF - 64;  // 16 lanes carry a second channel
 
 // Elementwise math of the post ops.  These sit on the sequential critical path of every AR order position
-// (k_chain1), so they use the hardware transcendental units directly (v_exp_f32 / v_rcp_f32 / v_rsq_f32,
+// (the chain role), so they use the hardware transcendental units directly (v_exp_f32 / v_rcp_f32 / v_rsq_f32,
 // ~1 ulp) instead of the libm-exact sequences; the result stays ~1e-7 relative to the exact value,
 // far inside the 1e-4 logit tolerance, and both evaluation modes share these functions bit for bit.
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
@@ -408,15 +412,14 @@ __global__ __launch_bounds__(256) void k_logits_grid(ItemMap items, const float 
 }
 
 // ==========================================================================================
-// column mode: one location per frame per order position (the incremental AR step).
-// Two launches per order position:
-//   k_nbr    every NEIGHBOUR-tap partial sum (slots NA, NB) of all 32 masked convs at once.  They only
-//            read finished columns of earlier order positions, so they do not depend on this
-//            position's chain and run fully parallel (one wave = one stage x slot x 16 channels).
-//   k_chain  one workgroup per 16 frames walks the 33 stages in order.  Only the centre taps
-//            (1x1 products on the fresh activation) and the post ops are sequential; activations go
-//            stage to stage through LDS, weights stream from L2.  Ends with the categorical draw and
-//            the context of the next order position.
+// column mode: one location per frame per order position (the incremental AR step) -- k_column below.
+//   neighbour role   every NEIGHBOUR-tap partial sum (slots NA, NB) of all 32 masked convs at once.  They only
+//                    read finished columns of earlier order positions, so they do not depend on this
+//                    position's chain and run fully parallel (one wave = one tap of one stage x slot x 16 channels).
+//   chain role       one workgroup per frame walks the 33 stages in order.  Only the centre taps (1x1 products on
+//                    the fresh activation) and the post ops are sequential; activations go stage to stage through
+//                    LDS, weights stream from L2 into registers.  Ends with the categorical draw and the context of
+//                    the next order position.
 // ==========================================================================================
 struct StepCtx {
     int step, q;
@@ -448,8 +451,9 @@ enum { IN_CELU = 0, IN_RAW = 1, IN_ELU = 2 };
 constexpr int NST = 33;       // 14 x (conv_input, conv_out) + 4 dilated convs + nin_out
 constexpr int NBR_LD = 2 * NF;
 
-struct __attribute__((aligned(16))) StageDesc {
-    // control words first, 16-byte aligned: k_chain fetches them with two ds_read_b128 per stage
+// Host-side description of one of the 33 stages (build_stage_table); the kernels read the tables derived from it:
+// NbrWork records (neighbour role) and the control records of the chain role.
+struct StageDesc {
     int pro, in_form, save_slot /* keep this u in LDS, -1 */, p_has_skip;
     int NG, Co_pad, center_tap, skip_slot /* saved u_k feeding w_skip, -1 */;
     const float *w;       // packed weights [taps][NG*4][Co_pad][4]
@@ -459,9 +463,9 @@ struct __attribute__((aligned(16))) StageDesc {
     // prologue of this stage = post op of the previous stage
     const float *pbias, *pbias2;
     float *outR, *outE, *outX;  // caches the prologue writes at the current location
-    // the centre-tap (+ nin_skip) weights again, laid out for k_chain1: [nstep][nchain][4]
+    // the centre-tap (+ nin_skip) weights again, laid out for the chain role: [nstep][nchain][4]
     const float *wv;
-    int nchain, nstep, pad0, pad1;
+    int nchain, nstep;
 };
 
 // a work item of k_nbr = (stage, slot NA|NB, 16 output channels), with everything it needs of the stage inline:
@@ -474,7 +478,6 @@ struct __attribute__((aligned(16))) NbrWork {
 };
 
 struct NbrArgs {
-    const StageDesc *stages;
     const NbrWork *work;
     const StepCtx *ctx;
     float *nbr;   // [NST][2][F][NBR_LD]
@@ -589,8 +592,7 @@ __device__ __forceinline__ void nbr_role(const NbrArgs &a, int nb)
 }
 
 struct ChainArgs {
-    const StageDesc *stages;
-    const int *ctl1;          // k_chain1's per-stage control records (C1_CTL_DWORDS dwords each), read with scalar loads
+    const int *ctl1;          // the chain role's per-stage control records (C1_CTL_DWORDS dwords each), read with scalar loads
     const float *nbr;         // neighbour slots of this launch, from the neighbour role
     const float *uinit_w, *uinit_b;
     const int32_t *codes_in;  // (F,L) current codes: the u_init gather reads earlier positions
@@ -611,7 +613,6 @@ struct ChainArgs {
     int tiles;                 // 16-frame tiles of the neighbour role
     int *err;                  // set to 1 if a bounded wait ran out (ps_pixelcnn_status)
     unsigned long long *trace; // optional [NST][10] shader-clock stamps of workgroup 0 (tuning aid)
-    int ablate;                // tuning aid (PS_CHAIN_ABLATE): 1 no cache stores, 2 no slot prefetch, 4 no MFMA, 8 no post math
 };
 
 // categorical draw from logits / T by inverse CDF with one uniform (sample.py:60-66); lane l holds classes 8l..8l+7
@@ -647,20 +648,19 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // ==========================================================================================
-// k_chain1: the same 33-stage chain on the vector ALU, one workgroup per FPW frames.
-// With few frames per GPU the MFMA chain fills 1/16 of one tile per frame and one CU per 16 frames; here
-// every frame gets its own CU (fp32 FMA on the VALU has the same peak as fp32 MFMA on gfx950) and nothing
-// is padded.  Thread t of a stage owns ONE chain (output o, accumulator j) of mfma_chunk5's order --
-// 16 or 32 dependent v_fma_f32 -- with its weights in registers (layout [step][chain][4], one coalesced
-// 16-byte load per step, fetched a full stage ahead) and the input read from LDS as broadcasts.  The five
-// chain values per output meet in LDS; the frame's post op (PONO, gate / skip / residual, concat-ELU) is
-// done by ONE wave with DPP-free lane reads, exactly like k_post_grid.  Two LDS-only barriers per stage.
+// chain role: the 33-stage chain of one frame on the vector ALU, one workgroup (= one CU) per frame.
+// A 16-frame MFMA tile per CU would leave 15/16 of the chip idle at PixelSynth's frame counts; fp32 FMA on the
+// VALU has the same peak as fp32 MFMA on gfx950, so every frame gets its own CU and nothing is padded.
+// Thread t of a stage owns ONE chain (output o, accumulator j) of mfma_chunk5's order -- 16 or 32 dependent
+// v_fma_f32 -- with its weights in registers (layout [step][chain][4], one coalesced 16-byte load per step, three
+// buffers: fetched two stages ahead) and the input read from LDS as broadcasts.  The five chain values per output
+// meet in LDS; the frame's post op (PONO, gate / skip / residual, concat-ELU) is done by ONE wave, one channel per
+// lane with DPP reductions, exactly like k_post_grid.  Two LDS-only barriers per stage.
 // ==========================================================================================
 constexpr int C1_THREADS = 1024;
 constexpr int C1_MAXCHAIN = 800;   // 5 x 160, or 5 x 80 + 5 x 80 (conv_input + nin_skip)
 constexpr int SX_LD = 2 * NF;
-constexpr int C1_OUT_STEPS = 12;
-   // nin_out: thread (o, part): part 0 = chains 0..2, part 1 = chains 3..4
+constexpr int C1_OUT_STEPS = 12;   // nin_out: thread (o, part): part 0 = chains 0..2, part 1 = chains 3..4
 
 template <int NGL, int FPW>
 __device__ __forceinline__ void valu_chain(const f32x4 *w /*4 * NGL steps*/, const float *xbase, int j, float (&acc)[FPW])
@@ -686,11 +686,7 @@ __device__ __forceinline__ void valu_chain(const f32x4 *w /*4 * NGL steps*/, con
     }
 }
 
-#ifdef PS_WEIGHTS_NT
-#define PS_WLOAD(p) __builtin_nontemporal_load(PS_GC(f32x4, p))
-#else
-#define PS_WLOAD(p) (*PS_GC(f32x4, p))
-#endif
+#define PS_WLOAD(p) (*PS_GC(f32x4, p))  // (nontemporal loads were measured 40 % slower: they lose the L2 residency)
 // Always EXACTLY eight loads, whatever the stage and thread: s_waitcnt counts are static, so a path that issued
 // fewer loads than another would force the compiler to wait for everything (vmcnt(0)) before the chain that
 // consumes the PREVIOUS fetch -- i.e. to wait for the prefetch it has just issued.  Four-step stages and threads
@@ -706,7 +702,7 @@ __device__ __forceinline__ void load_chain_weights(const float *wv, int nchain, 
     for (int st = 0; st < 4; ++st) w[4 + st] = PS_WLOAD(hi + st * stride);
 }
 
-// Control record of one stage for k_chain1, C1_CTL_DWORDS dwords in constant memory: record 0 describes the u0
+// Control record of one stage for the chain role, C1_CTL_DWORDS dwords in constant memory: record 0 describes the u0
 // post op (norm_init), record 1 + s stage s and the post op that follows it, record NST the nin_out chains.
 // Every role fetches its fields with scalar loads one stage ahead, so no wave ever waits on a descriptor.
 constexpr int C1_CTL_DWORDS = 24;
@@ -848,10 +844,6 @@ __device__ __forceinline__ void chain_role(const ChainArgs &a, int wg)
                                  auto INFORM, int save_slot) {
             constexpr int kind = decltype(KIND)::value, in_form = decltype(INFORM)::value;
             constexpr bool has_skip = decltype(SKIP)::value;
-#ifdef PS_ABL_NOPOST
-            sX[pf][cA] = y[0] + g[0] + skip[0];
-            return;
-#endif
             const float mean = pono_mean(pono_total(y[0], hasB ? y[1] : 0.0f));
             const float d[2] = {y[0] - mean, y[1] - mean};
             const float inv = pono_inv(pono_total(d[0] * d[0], hasB ? d[1] * d[1] : 0.0f));
@@ -1089,12 +1081,7 @@ __device__ __forceinline__ void chain_role(const ChainArgs &a, int wg)
         ChainCtl cc = load_chain_ctl(a.ctl1, 1), cn = load_chain_ctl(a.ctl1, 2), cnn = load_chain_ctl(a.ctl1, 3), c3 = cnn;
         auto chain_stage = [&](int s, const f32x4 (&wcur)[8], f32x4 (&wnn)[8], auto fetch, auto last) {
             PS_TRACE1(t == 0, 5);
-#ifdef PS_ABL_NOCHAIN
-            if (t < cc.nchain) sP[0][t] = wcur[0].x + wcur[7].w;
-            else if (false) {
-#else
             if (t < cc.nchain) {
-#endif
                 const bool main = cc.Co == 2 * NF || q80 < 5;
                 const int j = cc.Co == 2 * NF ? j160 : j80;
                 const float *xb = main ? &sX[0][0] : &sSkip[0][0];
@@ -1110,11 +1097,7 @@ __device__ __forceinline__ void chain_role(const ChainArgs &a, int wg)
             // The vector-memory queue is shallow: issuing a stage's 13 x 8 KB takes the CU ~1700 cycles and blocks the
             // issuing wave, so it happens here, where this wave only waits for the post op.  Same for the scalar load
             // of the control record three stages ahead (it shares lgkmcnt with the LDS reads of the chain).
-#ifdef PS_ABL_NOFETCH
-            if (false) {
-#else
             if (fetch) {
-#endif
                 c3 = load_chain_ctl(a.ctl1, 4 + s);  // (records past NST - 1 are rotated in but never used as stages)
                 load_chain_weights(cnn.wv, cnn.nchain, cnn.nstep, t, wnn);
             }
@@ -1181,7 +1164,7 @@ __global__ __launch_bounds__(C1_THREADS) void k_column(NbrArgs na, ChainArgs ca)
     else nbr_role(na, nb);
 }
 
-// repack the centre tap (+ nin_skip) of a stage for k_chain1: out[step][chain][4]
+// repack the centre tap (+ nin_skip) of a stage for the chain role: out[step][chain][4]
 __global__ void k_pack_valu(const float *wc, const float *wskip, int Co, int nchain, int nstep, float *out)
 {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1196,7 +1179,7 @@ __global__ void k_pack_valu(const float *wc, const float *wskip, int Co, int nch
     out[idx] = w[((size_t)(ch >> 2) * n + o) * 4 + (ch & 3)];
 }
 
-// nin_out for k_chain1: out[step 0..11][thread 0..1023][4]; thread (o = t & 511, part = t >> 9)
+// nin_out for the chain role: out[step 0..11][thread 0..1023][4]; thread (o = t & 511, part = t >> 9)
 __global__ void k_pack_valu_out(const float *wo /*[20][512][4]*/, float *out)
 {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1306,7 +1289,6 @@ struct ps_pixelcnn {
     float *nbr = nullptr;           // column mode: neighbour slots [NST][2][maxF][160]
     float *col_logits = nullptr;
     StepCtx *ctx = nullptr;
-    StageDesc *stages = nullptr;    // device copy of the 33-stage chain description
     int *ctl1 = nullptr;            // the same for the chain role (scalar-load records)
     unsigned *cnt = nullptr;        // [NST + 1] completion counters of the neighbour role, never reset
     int *err = nullptr;             // device flag: a bounded wait of the chain role ran out
@@ -1431,7 +1413,7 @@ void run_grid(ps_pixelcnn *h, int F, const int32_t *codes, const Masks &m, float
 }
 
 // ------------------------------------------------------------------------------------------
-// the 33-stage chain description consumed by k_nbr / k_chain (built once per handle)
+// the 33-stage description and the tables the two roles of k_column read (built once per handle)
 // ------------------------------------------------------------------------------------------
 int build_stage_table(ps_pixelcnn *h)
 {
@@ -1478,7 +1460,7 @@ int build_stage_table(ps_pixelcnn *h)
     gated(11); gated(12); gated(13);
     push(h->out_w, nullptr, nullptr, 0, 5, NCLS, 1, 1, 0, 0, IN_ELU, -1);  // nin_out(elu(u)), prologue = last gate
     if ((int)st.size() != NST) return ps::fail(PS_ERR_STATE, "stage table has %d entries, expected %d", (int)st.size(), NST);
-    for (int k = 0; k < NST; ++k) {  // the centre taps again in k_chain1's [step][chain][4] layout
+    for (int k = 0; k < NST; ++k) {  // the centre taps again in the chain role's [step][chain][4] layout
         StageDesc &d = st[k];
         float *wv = nullptr;
         if (k == NST - 1) {
@@ -1497,7 +1479,7 @@ int build_stage_table(ps_pixelcnn *h)
         d.wv = wv;
     }
     PS_HIP_CHECK(hipDeviceSynchronize());
-    {   // k_chain1's control records
+    {   // the chain role's control records
         std::vector<int> ctl((size_t)(NST + 1) * C1_CTL_DWORDS, 0);
         auto put_p = [&](int rec, int field, const void *ptr) { memcpy(&ctl[(size_t)rec * C1_CTL_DWORDS + field], &ptr, 8); };
         auto put_post = [&](int rec, const StageDesc &nx) {  // the post op feeding stage `nx`
@@ -1518,8 +1500,6 @@ int build_stage_table(ps_pixelcnn *h)
         if (int rc = dev_alloc(h, &h->ctl1, ctl.size())) return rc;
         PS_HIP_CHECK(hipMemcpy(h->ctl1, ctl.data(), ctl.size() * sizeof(int), hipMemcpyHostToDevice));
     }
-    if (int rc = dev_alloc(h, &h->stages, st.size())) return rc;
-    PS_HIP_CHECK(hipMemcpy(h->stages, st.data(), st.size() * sizeof(StageDesc), hipMemcpyHostToDevice));
     if (int rc = dev_alloc(h, &h->work, work.size())) return rc;
     PS_HIP_CHECK(hipMemcpy(h->work, work.data(), work.size() * sizeof(NbrWork), hipMemcpyHostToDevice));
     h->nwork = (int)work.size();
@@ -1534,8 +1514,8 @@ void run_column(ps_pixelcnn *h, int F, const int32_t *codes, ChainArgs ca, hipSt
     // role gets XCDs 1..7 (V=16: chain 47.5 -> 42.5 us); with more frames both use the whole chip
     const bool split = h->xcd_pack && F <= 32;
     const int tiles = (F + 15) / 16, nbr_wgs = (h->nwork * tiles + NBR_ITEMS_PER_WG - 1) / NBR_ITEMS_PER_WG;
-    NbrArgs na{h->stages, h->work, h->ctx, h->nbr, h->nwork, h->H, h->W, h->L, F, split ? 1 : 0, h->cnt, nbr_wgs};
-    ca.stages = h->stages; ca.ctl1 = h->ctl1; ca.nbr = h->nbr;
+    NbrArgs na{h->work, h->ctx, h->nbr, h->nwork, h->H, h->W, h->L, F, split ? 1 : 0, h->cnt, nbr_wgs};
+    ca.ctl1 = h->ctl1; ca.nbr = h->nbr;
     ca.uinit_w = h->uinit_w; ca.uinit_b = h->uinit_b; ca.codes_in = codes;
     ca.out_b = h->out_b;
     ca.H = h->H; ca.W = h->W; ca.L = h->L; ca.F = F;
@@ -1742,7 +1722,6 @@ int ps_pixelcnn_time_column_step(ps_pixelcnn *h, const int32_t *codes, const int
     ca.cx = make_ctx_args(h, order, Masks{mask_init, mask_undilated, mask_dilated}, F);
     ca.step_logits = h->col_logits;
     ca.temperature = 1.0f;
-    if (const char *ab = getenv("PS_CHAIN_ABLATE")) ca.ablate = atoi(ab);
     hipLaunchKernelGGL(k_ctx_init, dim3(F), dim3(32), 0, st, ca.cx, step);
     run_column(h, F, codes, ca, st);  // untimed warm-up
     if (const char *tp = getenv("PS_CHAIN_TRACE")) {  // tuning aid: per-stage shader-clock stamps of workgroup 0

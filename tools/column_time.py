@@ -1,5 +1,5 @@
 """Tuning aid: per-launch time of the two kernels of one AR order position (ps_pixelcnn_time_column_step).
-usage: python tools/column_time.py [views] [reps]      env: PS_CHAIN_KERNEL=valu|mfma, PS_PROF_SKIP_NBR=1, PS_CHAIN_TRACE=file"""
+usage: python tools/column_time.py [views] [reps]      env: PS_XCD_PACK=0|1, PS_CHAIN_TRACE=file (needs a -DPS_CHAIN_TRACE_BUILD build)"""
 import ctypes
 import os
 import sys
