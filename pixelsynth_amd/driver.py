@@ -1,0 +1,139 @@
+"""Driver of the novel-view path (SURVEY 8b "what calls it"): the counterpart of the reference's demo.py:181-270 /
+create_vid.py for what this repository builds.
+
+    python -m pixelsynth_amd.driver --trajectory circle --frames 64 --out results/      (one GPU)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+           -m pixelsynth_amd.driver --trajectory circle --frames 64 --out results/         (C4: views sharded over 8 GPUs)
+
+One source image (a PNG, or the synthetic RealEstate10K-shaped sample), the demo cameras of process_demo_data
+(demo.py:36-96), target poses from ZbufferModelPts.get_rt_from_rot (directions 'R','L','U','D',... in `--frames`
+equal steps, or the 'C' circle of z_buffermodel.py:217-225).  Every view is rendered independently FROM THE SOURCE
+(the reference's demo chains frames on one GPU): reproject + splat, VQ-VAE top codes, AR outpainting,
+decode, get_combined.  Ranks take views round-robin, finished frames are all-gathered (RCCL), rank 0 writes
+<out>/video/%d.png in trajectory order -- the layout create_vid.py's ffmpeg call expects (demo.py:125-164).
+
+The depth regressor, the refinement decoder and trained weights are not part of this repository: depth
+is synthetic unless --depth-npy is given, weights are random-init unless --pixelcnn / --vqvae state dicts are given,
+and the saved image is the un-refined composite (reprojected features where visible, decoded sample elsewhere).
+"""
+import argparse
+import os
+import types
+
+import numpy as np
+import torch
+
+from . import distributed as D, synthetic as syn
+
+
+def make_opts(**kw):
+    o = dict(W=256, use_rgb_features=True, splatter="xyblending", learn_default_feature=True, radius=4, pp_pixel=128,
+             tau=1.0, rad_pow=2, accumulation="alphacomposite", background_smoothing_kernel_size=13, min_z=1.0, max_z=100.0,
+             rotation=0.6, direction="R", temperature=0.7, model_setting="gen_scene", seed=0, homography=False, vqvae=True)
+    o.update(kw)
+    return types.SimpleNamespace(**o)
+
+
+def build_model(device, pixelcnn_sd=None, vqvae_sd=None):
+    from .z_buffermodel import ZbufferModelPts
+    model = ZbufferModelPts(make_opts()).eval()
+    load = lambda path, fallback: torch.load(path, map_location="cpu") if path else {k: torch.from_numpy(v) for k, v in fallback.items()}
+    model.outpaint2.load_state_dict(load(pixelcnn_sd, syn.pixelcnn_state_dict(0)))
+    model.vqvae.load_state_dict(load(vqvae_sd, syn.vqvae_state_dict(0)))
+    return model.to(device)
+
+
+def trajectory(model, input_RT, kind, n):
+    """-> list of (label, RTinv (1,4,4), RT (1,4,4)) target poses, in playback order."""
+    poses = []
+    for i in range(n):
+        if kind == "circle":
+            inv, rt = model.get_rt_from_rot("C", input_RT, i, n)
+            poses.append((f"C_{i}", inv, rt))
+        else:
+            inv, rt = model.get_rt_from_rot(kind, input_RT, i + 1, n)
+            poses.append((f"{kind}_{i + 1}", inv, rt))
+    return poses
+
+
+@torch.no_grad()
+def render_views(model, img, depth, cam, poses, temperature=0.7, seed=0):
+    """img (1,3,S,S) in [-1,1], depth (1,1,S,S), cam dict of (1,4,4) tensors, poses as from trajectory()
+    -> dict(frames (V,3,S,S), features, background_mask, codes): the views of `poses`, batched through outpaint_views."""
+    V = len(poses)
+    rep = lambda t: t.expand(V, *t.shape[1:]).contiguous()
+    RT2 = torch.cat([p[2] for p in poses]).contiguous()
+    RT2inv = torch.cat([p[1] for p in poses]).contiguous()
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    uniforms = torch.rand(V, 1024, generator=g).to(img.device)
+    out = model.outpaint_views(rep(img), rep(depth), rep(cam["K"]), rep(cam["Kinv"]), rep(cam["P"]), rep(cam["Pinv"]), RT2, RT2inv,
+                               None, temperature=temperature, uniforms=uniforms)
+    model.outpaint2.engine(32, 32, V).check()
+    sample = model.vqvae.decode_code(out["codes"])
+    frames = model.get_combined(out["gen_fs"], sample, out["background_mask"])
+    return dict(frames=frames, features=out["gen_fs"], background_mask=out["background_mask"], codes=out["codes"])
+
+
+def save_png(path, chw):
+    from PIL import Image
+    a = ((chw.clamp(-1, 1) * 0.5 + 0.5) * 255.0 + 0.5).to(torch.uint8).permute(1, 2, 0).cpu().numpy()
+    Image.fromarray(a).save(path)
+
+
+def load_image(path, S=256):
+    from PIL import Image
+    im = Image.open(path).convert("RGB").resize((S, S), Image.BICUBIC)
+    return torch.from_numpy(np.asarray(im).astype(np.float32) / 127.5 - 1.0).permute(2, 0, 1)[None]
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
+    ap.add_argument("--image", help="source PNG/JPEG (default: the synthetic sample)")
+    ap.add_argument("--depth-npy", help="(S,S) float32 depth in [min_z, max_z] (default: synthetic smooth depth)")
+    ap.add_argument("--trajectory", default="circle", help="circle | R | L | U | D | UL | UR | DL | DR")
+    ap.add_argument("--frames", type=int, default=64)
+    ap.add_argument("--batch", type=int, default=16, help="views rendered together per rank")
+    ap.add_argument("--out", default="results")
+    ap.add_argument("--pixelcnn", help="state_dict of the reference's OurPixelCNN (torch.save)")
+    ap.add_argument("--vqvae", help="state_dict of the reference's VQVAETop (torch.save)")
+    args = ap.parse_args(argv)
+
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.distributed.init_process_group("nccl", device_id=device)
+    model = build_model(device, args.pixelcnn, args.vqvae)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    img = (load_image(args.image) if args.image else torch.from_numpy(syn.image(1000, 1, 3, 256))).to(device)
+    depth = t(np.load(args.depth_npy)[None, None].astype(np.float32)) if args.depth_npy else t(syn.depth_smooth(2000, 1, 256, 1.0, 100.0))
+    cam = {k: t(v) for k, v in syn.demo_cameras(1).items()}
+    kind = "circle" if args.trajectory == "circle" else args.trajectory
+    poses = trajectory(model, cam["P"], kind, args.frames)
+    mine = D.shard_views(len(poses), rank, world)
+    frames = []
+    for s in range(0, len(mine), args.batch):
+        chunk = [poses[i] for i in mine[s:s + args.batch]]
+        frames.append(render_views(model, img, depth, cam, chunk, seed=rank * 1000 + s)["frames"])
+    local_frames = torch.cat(frames) if frames else torch.empty(0, 3, 256, 256, device=device)
+    per_rank = (len(poses) + world - 1) // world                         # gather_frames wants equal shards: pad the last round
+    if local_frames.shape[0] < per_rank:
+        pad = torch.zeros(per_rank - local_frames.shape[0], 3, 256, 256, device=device)
+        local_frames = torch.cat([local_frames, pad])
+    all_frames = D.gather_frames(local_frames, len(poses))
+    if rank == 0:
+        vid = os.path.join(args.out, "video")
+        os.makedirs(vid, exist_ok=True)
+        save_png(os.path.join(vid, "0.png"), img[0])                      # frame 0 = the source (demo.py:133-137)
+        for i in range(len(poses)):
+            save_png(os.path.join(vid, f"{i + 1}.png"), all_frames[i])
+        print(f"wrote {len(poses) + 1} frames to {vid}/%d.png  (ffmpeg -i {vid}/%d.png ... as create_vid.py does)")
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,5 +1,6 @@
 """GPU tests of the orchestration mirror (pixelsynth_amd/z_buffermodel.py): poses, masks for batch in the
 reference's layout, the batched view path against its pieces, and the reference-shaped forward_image."""
+import os
 import types
 
 import numpy as np
@@ -150,3 +151,26 @@ def test_views_with_the_vqvae_in_the_loop():
     with torch.no_grad():
         want = vo.decode_code(sd, torch.from_numpy(codes).long())
     np.testing.assert_allclose(dec.cpu().numpy(), want.numpy(), rtol=1e-4, atol=1e-5)
+
+
+def test_driver_renders_a_trajectory_and_writes_the_video_layout(tmp_path):
+    """the driver (counterpart of demo.py / create_vid.py): poses of the 'C' circle and of a direction sweep,
+    views rendered from the source, PNGs under <out>/video/%d.png starting with the source frame."""
+    from PIL import Image
+    from pixelsynth_amd import driver
+    driver.main(["--trajectory", "circle", "--frames", "5", "--batch", "3", "--out", str(tmp_path)])
+    names = sorted(os.listdir(tmp_path / "video"), key=lambda n: int(n.split(".")[0]))
+    assert names == [f"{i}.png" for i in range(6)]
+    frames = [np.asarray(Image.open(tmp_path / "video" / n)) for n in names]
+    assert all(f.shape == (256, 256, 3) and f.dtype == np.uint8 for f in frames)
+    src = ((np.clip(syn.image(1000, 1, 3, 256)[0], -1, 1) * 0.5 + 0.5) * 255.0 + 0.5).astype(np.uint8).transpose(1, 2, 0)
+    assert np.array_equal(frames[0], src)
+    assert not np.array_equal(frames[1], frames[3])                       # different poses give different views
+    m = driver.build_model(torch.device(DEV))
+    P = tt(syn.demo_cameras(1)["P"])
+    poses = driver.trajectory(m, P, "circle", 8)
+    assert [p[0] for p in poses] == [f"C_{i}" for i in range(8)]
+    inv_ref, rt_ref = syn.circle_pose(syn.demo_cameras(1)["P"], 3, 8)
+    np.testing.assert_allclose(poses[3][2].cpu().numpy(), rt_ref, rtol=1e-6, atol=1e-6)
+    sweep = driver.trajectory(m, P, "R", 4)
+    np.testing.assert_allclose(sweep[-1][2].cpu().numpy(), syn.yaw_pose(syn.demo_cameras(1)["P"], 0.6)[1], rtol=1e-6, atol=1e-6)
