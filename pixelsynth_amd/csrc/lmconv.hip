@@ -212,12 +212,14 @@ __global__ __launch_bounds__(64) void k_gemm(GemmArgs a)
 
 // ------------------------------------------------------------------------------------------
 // per-item post ops, shared by the whole-grid kernels and the column chain.
-// One wave per item, one channel per lane: lane l owns channel l ("A") and, for l < 16, channel 64 + l ("B").
-// The statistics of PONO are reduced in ONE association order everywhere (pono_total): v_l = A_l + B_l, a
-// butterfly over the lanes of each row of 16 (DPP), then (row0 + row1) + (row2 + row3) -- so column steps and
-// whole-grid passes agree bit for bit.
+// One wave per item, TWO adjacent channels per lane: lane l < 40 owns channels 2l and 2l + 1 (8-byte accesses, packed
+// fp32 add / mul / fma for everything but the transcendentals); lanes 40..63 carry zeros.
+// The statistics of PONO are reduced in ONE association order everywhere (pono_total): s_l = y[2l] + y[2l+1], a
+// butterfly over the lanes of each row of 16 (DPP), then R2 + (R1 + R0) -- so column steps and whole-grid passes
+// agree bit for bit.
 // ------------------------------------------------------------------------------------------
-constexpr int NB_LANES = NF - 64;  // 16 lanes carry a second channel
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr int PONO_LANES = NF / 2;  // 40 lanes carry data
 
 // Elementwise math of the post ops.  These sit on the sequential critical path of every AR order position
 // (the chain role), so they use the hardware transcendental units directly (v_exp_f32 / v_rcp_f32 / v_rsq_f32,
@@ -245,11 +247,23 @@ enum { POST_CONVIN = 0, POST_GATE = 1, POST_DIL = 2 };
 // n = PONO-normalised value.  KIND = POST_CONVIN: out = n [+ skip]              (layers.py:153-156)
 //                                   POST_GATE:   out = rin + n * sigmoid(g)      (layers.py:159-163)
 //                                   POST_DIL:    out = n                         (model.py:138-140,148-150)
+__device__ __forceinline__ f32x2 sigmoid2(const f32x2 &x) { return f32x2{sigmoid1(x.x), sigmoid1(x.y)}; }
+__device__ __forceinline__ void celu_pair2(const f32x2 &x, f32x2 &ep, f32x2 &en)
+{
+    float p0, p1, n0, n1;
+    celu_pair(x.x, p0, n0);
+    celu_pair(x.y, p1, n1);
+    ep = f32x2{p0, p1};
+    en = f32x2{n0, n1};
+}
+// y = ((bias + NA) + C) + NB on a channel pair
+__device__ __forceinline__ f32x2 slot_sum2(const f32x2 &bias, const f32x2 &na, const f32x2 &c, const f32x2 &nb) { return ((bias + na) + c) + nb; }
+
 template <int KIND>
-__device__ __forceinline__ float post_finish(float n, float g, float skip, bool has_skip, float rin)
+__device__ __forceinline__ f32x2 post_finish(const f32x2 &n, const f32x2 &g, const f32x2 &skip, bool has_skip, const f32x2 &rin)
 {
     if (KIND == POST_CONVIN) return has_skip ? n + skip : n;
-    if (KIND == POST_GATE) return rin + n * sigmoid1(g);
+    if (KIND == POST_GATE) return rin + n * sigmoid2(g);
     return n;
 }
 
@@ -260,20 +274,20 @@ __device__ __forceinline__ float dpp_xadd(float x)
     return x + __int_as_float(moved);
 }
 __device__ __forceinline__ float lane_value(float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); }
-// sum over the 80 channels of an item; b MUST be 0 in lanes >= 16.  The result is wave-uniform.
-//   v_l = a_l + b_l; butterfly over the 16 lanes of every row (pairs, quads, octets, row); then
-//   T = (R2 + R3) + (R0 + R1) with R_k the sum of row k.
-__device__ __forceinline__ float pono_total(float a, float b)
+// sum over the 80 channels of an item, two per lane; `own` = this lane is one of the 40 data lanes (others count 0).
+// The result is wave-uniform.  s_l = v.x + v.y; butterfly over the 16 lanes of every row (pairs, quads, octets, row);
+// then T = R2 + (R1 + R0) with R_k the sum of row k (row 2 = lanes 32..39 + zeros).
+__device__ __forceinline__ float pono_total(const f32x2 &v, bool own)
 {
-    float x = a + b;
+    float x = own ? v.x + v.y : 0.0f;
     x = dpp_xadd<0xB1>(x);    // quad_perm [1,0,3,2]: pairs
     x = dpp_xadd<0x4E>(x);    // quad_perm [2,3,0,1]: quads
     x = dpp_xadd<0x141>(x);   // row_half_mirror: octets
     x = dpp_xadd<0x140>(x);   // row_mirror: every lane of row k now holds R_k
-    // row_bcast:15 into rows 1 and 3: R1 + R0, R3 + R2;  row_bcast:31 into rows 2, 3: row 3 = (R3 + R2) + (R1 + R0)
+    // row_bcast:15 into rows 1 (and 3): R1 + R0;  row_bcast:31 into rows 2 (and 3): R2 + (R1 + R0)
     x = x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x142, 0xa, 0xf, false));
     x = x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x143, 0xc, 0xf, false));
-    return lane_value(x, 63);
+    return lane_value(x, 47);
 }
 
 // u_init on one-hot input as a gather, type-A mask (model.py:132), BEFORE norm_init:
@@ -305,13 +319,13 @@ __device__ __forceinline__ V uinit_gather(const int32_t *__restrict__ codes_f, c
     return v;
 }
 
-__device__ __forceinline__ void store_raw_celu(float *R, float *E, size_t loc, int c, float u)
+__device__ __forceinline__ void store_raw_celu2(float *R, float *E, size_t loc, int c, const f32x2 &u)
 {
-    float ep, en;
-    celu_pair(u, ep, en);
-    R[loc * NF + c] = u;
-    E[loc * (2 * NF) + c] = ep;
-    E[loc * (2 * NF) + NF + c] = en;
+    f32x2 ep, en;
+    celu_pair2(u, ep, en);
+    *(f32x2 *)(R + loc * NF + c) = u;
+    *(f32x2 *)(E + loc * (2 * NF) + c) = ep;
+    *(f32x2 *)(E + loc * (2 * NF) + NF + c) = en;
 }
 
 struct PostArgs {
@@ -333,36 +347,30 @@ __global__ __launch_bounds__(256) void k_post_grid(PostArgs a)
     item_loc(a.items, item, a.L, f, q);
     const size_t loc = (size_t)f * a.L + q;
     const size_t ss = (size_t)a.nitems * a.Co_pad;
-    const float *P = a.partial + (size_t)item * a.Co_pad;
-    const bool hasB = lane < NB_LANES;
-    const int ch[2] = {lane, 64 + (lane & (NB_LANES - 1))};
-    float y[2], g[2] = {0.0f, 0.0f}, skip[2] = {0.0f, 0.0f}, rin[2] = {0.0f, 0.0f};
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int c = ch[k];
-        y[k] = slot_sum(a.bias[c], P[SLOT_NA * ss + c], P[SLOT_C * ss + c], P[SLOT_NB * ss + c]);
-        if (KIND == POST_GATE) {
-            g[k] = slot_sum(a.bias[c + NF], P[SLOT_NA * ss + NF + c], P[SLOT_C * ss + NF + c], P[SLOT_NB * ss + NF + c]);
-            rin[k] = a.Rin[loc * NF + c];
-        }
-        if (KIND == POST_CONVIN && a.has_skip) skip[k] = P[SLOT_SKIP * ss + c] + a.bias2[c];
+    const bool own = lane < PONO_LANES;
+    const int c = own ? 2 * lane : 0;
+    const float *P = a.partial + (size_t)item * a.Co_pad + c;
+    const f32x2 zero = {0.0f, 0.0f};
+    auto ld = [](const float *p) { return *(const f32x2 *)p; };
+    f32x2 g = zero, skip = zero, rin = zero;
+    const f32x2 y = slot_sum2(ld(a.bias + c), ld(P + SLOT_NA * ss), ld(P + SLOT_C * ss), ld(P + SLOT_NB * ss));
+    if (KIND == POST_GATE) {
+        g = slot_sum2(ld(a.bias + NF + c), ld(P + SLOT_NA * ss + NF), ld(P + SLOT_C * ss + NF), ld(P + SLOT_NB * ss + NF));
+        rin = ld(a.Rin + loc * NF + c);
     }
-    const float mean = pono_mean(pono_total(y[0], hasB ? y[1] : 0.0f));
-    const float d0 = y[0] - mean, d1 = y[1] - mean;
-    const float inv = pono_inv(pono_total(d0 * d0, hasB ? d1 * d1 : 0.0f));
-    const float dd[2] = {d0, d1};
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        if (k == 1 && !hasB) break;
-        const float out = post_finish<KIND>(dd[k] * inv, g[k], skip[k], a.has_skip != 0, rin[k]);
-        if (KIND == POST_CONVIN) {
-            float ep, en;
-            celu_pair(out, ep, en);
-            a.Xout[loc * (2 * NF) + ch[k]] = ep;
-            a.Xout[loc * (2 * NF) + NF + ch[k]] = en;
-        } else {
-            store_raw_celu(a.Rout, a.Eout, loc, ch[k], out);
-        }
+    if (KIND == POST_CONVIN && a.has_skip) skip = ld(P + SLOT_SKIP * ss) + ld(a.bias2 + c);
+    const float mean = pono_mean(pono_total(y, own));
+    const f32x2 d = y - mean;
+    const float inv = pono_inv(pono_total(d * d, own));
+    if (!own) return;
+    const f32x2 out = post_finish<KIND>(d * inv, g, skip, a.has_skip != 0, rin);
+    if (KIND == POST_CONVIN) {
+        f32x2 ep, en;
+        celu_pair2(out, ep, en);
+        *(f32x2 *)(a.Xout + loc * (2 * NF) + c) = ep;
+        *(f32x2 *)(a.Xout + loc * (2 * NF) + NF + c) = en;
+    } else {
+        store_raw_celu2(a.Rout, a.Eout, loc, c, out);
     }
 }
 
@@ -383,18 +391,16 @@ __global__ __launch_bounds__(256) void k_uinit_grid(UinitArgs a)
     int f, q;
     item_loc(a.items, item, a.L, f, q);
     const size_t loc = (size_t)f * a.L + q;
-    const bool hasB = lane < NB_LANES;
+    const bool own = lane < PONO_LANES;
+    const int c = own ? 2 * lane : 0;
     float mA[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) mA[t] = a.mask[((size_t)f * 9 + t) * a.L + q];
-    const int cB = 64 + (lane & (NB_LANES - 1));
-    const float yA = uinit_gather<float>(a.codes + (size_t)f * a.L, mA, a.w, a.bias, q, a.H, a.W, lane);
-    const float yB = uinit_gather<float>(a.codes + (size_t)f * a.L, mA, a.w, a.bias, q, a.H, a.W, cB);
-    const float mean = pono_mean(pono_total(yA, hasB ? yB : 0.0f));   // norm_init
-    const float dA = yA - mean, dB = yB - mean;
-    const float inv = pono_inv(pono_total(dA * dA, hasB ? dB * dB : 0.0f));
-    store_raw_celu(a.Rout, a.Eout, loc, lane, dA * inv);
-    if (hasB) store_raw_celu(a.Rout, a.Eout, loc, cB, dB * inv);
+    const f32x2 y = uinit_gather<f32x2>(a.codes + (size_t)f * a.L, mA, a.w, a.bias, q, a.H, a.W, c);
+    const float mean = pono_mean(pono_total(y, own));   // norm_init
+    const f32x2 d = y - mean;
+    const float inv = pono_inv(pono_total(d * d, own));
+    if (own) store_raw_celu2(a.Rout, a.Eout, loc, c, d * inv);
 }
 
 // logits = nin_out partial + bias; nchw: (F,512,H,W) like the reference, else (nitems,512)
@@ -752,12 +758,13 @@ __device__ __forceinline__ void chain_role(const ChainArgs &a, int wg)
     //   waves 0..12         one chain per thread and stage
     //   wave 13             cache stores (finished values LDS -> R / E / X) and the nin_skip inputs
     //   wave 14             touches the control records ahead of everybody (scalar-cache prefetch)
-    //   waves 16-FPW..15    post op of one frame each, one channel per lane (see pono_total)
+    //   waves 16-FPW..15    post op of one frame each, two channels per lane (see pono_total)
     constexpr int NW = C1_THREADS / 64, STORE_WAVE = 13, CTL_WAVE = 14;
     const int pf = wave - (NW - FPW);  // frame slot of a post wave, negative otherwise
     const bool pwave = pf >= 0, swave = wave == STORE_WAVE;
-    const bool hasB = lane < NB_LANES;
-    const int cA = lane, cB = 64 + (lane & (NB_LANES - 1));
+    // store wave: one channel per lane, lane l also takes channel 64 + l for l < 16
+    const bool hasB = lane < NF - 64;
+    const int cA = lane, cB = 64 + (lane & (NF - 64 - 1));
     // chain role: 80-output stages hold chains t = j * 80 + o (then the nin_skip chains), 160-output ones j * 160 + o
     const int q80 = t / NF, j160 = t / (2 * NF);
     const int j80 = q80 >= 5 ? q80 - 5 : q80;
@@ -800,31 +807,34 @@ __device__ __forceinline__ void chain_role(const ChainArgs &a, int wg)
         // ================= post waves: one frame each, two barriers per stage =================
         const int pfr = f0 + pf;
         const bool pvalid = pfr < a.F;
-        const float *nbr_f = a.nbr + (size_t)(pvalid ? pfr : 0) * NBR_LD;
+        const bool own = lane < PONO_LANES;          // two channels per lane: 2 * lane, 2 * lane + 1 (see pono_total)
+        const int c2 = own ? 2 * lane : 0;
+        const float *nbr_f = a.nbr + (size_t)(pvalid ? pfr : 0) * NBR_LD + c2;
         const size_t nbr_half = (size_t)a.F * NBR_LD, nbr_stage = 2 * nbr_half;
-        float ucur[2] = {0.0f, 0.0f};
+        const f32x2 zero2 = {0.0f, 0.0f};
+        f32x2 ucur = zero2;
         // bias and neighbour-tap slots of a stage's post op: y = ((bias + NA) + centre) + NB; fetched one stage ahead.
-        // Always exactly fourteen loads from valid addresses, in every lane: static s_waitcnt counts (see
+        // Always exactly seven 8-byte loads from valid addresses, in every lane: static s_waitcnt counts (see
         // load_chain_weights); kinds without a gate half / skip re-read the main operands.
-        struct Ops { float b[2], na[2], nb[2], bg[2], nag[2], nbg[2], b2[2]; };
+        struct Ops { f32x2 b, na, nb, bg, nag, nbg, b2; };
         // The neighbour slots are produced by other workgroups of this launch (nbr_role, other XCDs): they are read
         // with device-scope loads, and only once the stage's completion counter has reached this launch's target.
-        auto fresh = [](const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+        auto fresh = [](const float *p) {
+            const unsigned long long raw = __hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return f32x2{__uint_as_float((unsigned)raw), __uint_as_float((unsigned)(raw >> 32))};
+        };
+        auto plain = [](const float *p) { return *PS_GC(f32x2, p); };
         auto load_ops = [&](int s, const PostCtl &c, Ops &o) {
             const float *nb = nbr_f + (size_t)s * nbr_stage;
             const int gofs = c.kind == PRO_GATE ? NF : 0;
             const float *b2 = c.has_skip ? c.bias2 : c.bias;
-            const int ch[2] = {cA, cB};
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                o.b[k] = *PS_GC(float, c.bias + ch[k]);
-                o.na[k] = fresh(nb + ch[k]);
-                o.nb[k] = fresh(nb + nbr_half + ch[k]);
-                o.bg[k] = *PS_GC(float, c.bias + gofs + ch[k]);
-                o.nag[k] = fresh(nb + gofs + ch[k]);
-                o.nbg[k] = fresh(nb + nbr_half + gofs + ch[k]);
-                o.b2[k] = *PS_GC(float, b2 + ch[k]);
-            }
+            o.b = plain(c.bias + c2);
+            o.na = fresh(nb);
+            o.nb = fresh(nb + nbr_half);
+            o.bg = plain(c.bias + gofs + c2);
+            o.nag = fresh(nb + gofs);
+            o.nbg = fresh(nb + nbr_half + gofs);
+            o.b2 = plain(b2 + c2);
         };
         // completion counter of stage k; `have` is a value loaded earlier (normally already
         // past the target, so this costs nothing); bounded, so a lost neighbour workgroup cannot hang the GPU
@@ -840,36 +850,30 @@ __device__ __forceinline__ void chain_role(const ChainArgs &a, int wg)
         };
         // PONO + finish + hand-off to the next stage.  Compiled once per (kind, skip, input form) combination that
         // occurs in the network, so the body is straight-line code; only save_slot stays a run-time value.
-        auto post_and_emit = [&](const float (&y)[2], const float (&g)[2], const float (&skip)[2], auto KIND, auto SKIP,
-                                 auto INFORM, int save_slot) {
+        auto post_and_emit = [&](const f32x2 &y, const f32x2 &g, const f32x2 &skip, auto KIND, auto SKIP, auto INFORM, int save_slot) {
             constexpr int kind = decltype(KIND)::value, in_form = decltype(INFORM)::value;
             constexpr bool has_skip = decltype(SKIP)::value;
-            const float mean = pono_mean(pono_total(y[0], hasB ? y[1] : 0.0f));
-            const float d[2] = {y[0] - mean, y[1] - mean};
-            const float inv = pono_inv(pono_total(d[0] * d[0], hasB ? d[1] * d[1] : 0.0f));
-            if (!pvalid) return;
-            const int ch[2] = {cA, cB};
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                if (k == 1 && !hasB) break;
-                const float n = d[k] * inv;
-                float out;
-                if (kind == PRO_CONVIN) out = post_finish<POST_CONVIN>(n, 0.0f, skip[k], has_skip, 0.0f);
-                else if (kind == PRO_GATE) out = post_finish<POST_GATE>(n, g[k], 0.0f, false, ucur[k]);
-                else out = n;  // PRO_DIL, PRO_UINIT (norm_init)
-                float ep, en;
-                celu_pair(out, ep, en);
-                float *x = &sX[pf][ch[k]];
-                if (in_form == IN_CELU) { x[0] = ep; x[NF] = en; }
-                else if (in_form == IN_RAW) x[0] = out;
-                else x[0] = ep;
-                sOut[pf][1][ch[k]] = ep;
-                sOut[pf][2][ch[k]] = en;
-                if (kind != PRO_CONVIN) {
-                    sOut[pf][0][ch[k]] = out;
-                    ucur[k] = out;
-                    if (save_slot >= 0) sU[save_slot][pf][ch[k]] = out;
-                }
+            const float mean = pono_mean(pono_total(y, own));
+            const f32x2 d = y - mean;
+            const float inv = pono_inv(pono_total(d * d, own));
+            if (!pvalid || !own) return;
+            const f32x2 n = d * inv;
+            f32x2 out;
+            if (kind == PRO_CONVIN) out = post_finish<POST_CONVIN>(n, zero2, skip, has_skip, zero2);
+            else if (kind == PRO_GATE) out = post_finish<POST_GATE>(n, g, zero2, false, ucur);
+            else out = n;  // PRO_DIL, PRO_UINIT (norm_init)
+            f32x2 ep, en;
+            celu_pair2(out, ep, en);
+            float *x = &sX[pf][c2];
+            if (in_form == IN_CELU) { *(f32x2 *)x = ep; *(f32x2 *)(x + NF) = en; }
+            else if (in_form == IN_RAW) *(f32x2 *)x = out;
+            else *(f32x2 *)x = ep;
+            *(f32x2 *)(&sOut[pf][1][c2]) = ep;
+            *(f32x2 *)(&sOut[pf][2][c2]) = en;
+            if (kind != PRO_CONVIN) {
+                *(f32x2 *)(&sOut[pf][0][c2]) = out;
+                ucur = out;
+                if (save_slot >= 0) *(f32x2 *)(&sU[save_slot][pf][c2]) = out;
             }
         };
         // y (+ gate half, + nin_skip) of this stage from the chain values and the prefetched operands, then the post op
@@ -877,21 +881,15 @@ __device__ __forceinline__ void chain_role(const ChainArgs &a, int wg)
             constexpr int kind = decltype(KIND)::value;
             constexpr bool has_skip = decltype(SKIP)::value;
             constexpr int Co = kind == PRO_GATE ? 2 * NF : NF;
-            const int ch[2] = {cA, cB};
-            float y[2], g[2] = {0.0f, 0.0f}, skip[2] = {0.0f, 0.0f};
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const float *P = &sP[pf][ch[k]];
-                y[k] = slot_sum(o.b[k], o.na[k], chain_total(P[0], P[Co], P[2 * Co], P[3 * Co], P[4 * Co]), o.nb[k]);
-                if (kind == PRO_GATE) {
-                    const float *G = P + NF;
-                    g[k] = slot_sum(o.bg[k], o.nag[k], chain_total(G[0], G[Co], G[2 * Co], G[3 * Co], G[4 * Co]), o.nbg[k]);
-                }
-                if (has_skip) {
-                    const float *S = P + 5 * Co;
-                    skip[k] = chain_total(S[0], S[NF], S[2 * NF], S[3 * NF], S[4 * NF]) + o.b2[k];
-                }
-            }
+            auto five = [](const float *p, int stride) {
+                return chain_total(*(const f32x2 *)p, *(const f32x2 *)(p + stride), *(const f32x2 *)(p + 2 * stride),
+                                   *(const f32x2 *)(p + 3 * stride), *(const f32x2 *)(p + 4 * stride));
+            };
+            const float *P = &sP[pf][c2];
+            const f32x2 y = slot_sum2(o.b, o.na, five(P, Co), o.nb);
+            f32x2 g = zero2, skip = zero2;
+            if (kind == PRO_GATE) g = slot_sum2(o.bg, o.nag, five(P + NF, Co), o.nbg);
+            if (has_skip) skip = five(P + 5 * Co, NF) + o.b2;
             post_and_emit(y, g, skip, KIND, SKIP, INFORM, save_slot);
         };
         using std::integral_constant;
@@ -931,16 +929,14 @@ __device__ __forceinline__ void chain_role(const ChainArgs &a, int wg)
             PS_TRACE1(t == C1_THREADS - 64, 4);
         };
         Ops oA, oB;
-        {   // u0 = norm_init(u_init): the gather over the (earlier) neighbours' codes, one channel per lane
+        {   // u0 = norm_init(u_init): the gather over the (earlier) neighbours' codes
             const int fr = pvalid ? pfr : 0;
             float mA[9];
 #pragma unroll
             for (int tp = 0; tp < 9; ++tp) mA[tp] = a.cx.ctx[fr].m[0][tp];
             const int q0 = a.cx.ctx[fr].q;
-            const int32_t *cf = a.codes_in + (size_t)fr * a.L;
-            const float y[2] = {uinit_gather<float>(cf, mA, a.uinit_w, a.uinit_b, q0, a.H, a.W, cA),
-                                uinit_gather<float>(cf, mA, a.uinit_w, a.uinit_b, q0, a.H, a.W, cB)}, z[2] = {0.0f, 0.0f};
-            post_and_emit(y, z, z, integral_constant<int, PRO_UINIT>{}, integral_constant<bool, false>{},
+            const f32x2 y = uinit_gather<f32x2>(a.codes_in + (size_t)fr * a.L, mA, a.uinit_w, a.uinit_b, q0, a.H, a.W, c2);
+            post_and_emit(y, zero2, zero2, integral_constant<int, PRO_UINIT>{}, integral_constant<bool, false>{},
                           integral_constant<int, IN_CELU>{}, cur.save_slot);
             // the neighbour slots of stage 0 are first needed after the chains of stage 0
             wait_counter(counter(0), 0, (unsigned)nxt.nbr_items);
