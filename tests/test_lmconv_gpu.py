@@ -289,3 +289,38 @@ def test_ar_many_frames_layouts(F_):
                 uniforms=tt(u[3:4]), first_step=first)
     eng1.check()
     assert np.array_equal(c1.cpu().numpy()[0], codes[3])
+
+
+@pytest.mark.parametrize("H,W", [(16, 16), (8, 12)])
+def test_other_grid_sizes(H, W):
+    """The engine is not tied to PixelSynth's 32x32 code grid: whole-grid logits against the torch-fp32 oracle and
+    incremental == whole-grid (bit for bit) on a square and a non-square grid, random generation order."""
+    net = make_net(5)
+    F_, L = 2, H * W
+    eng = net.engine(H, W, F_)
+    rs = np.random.RandomState(H * 100 + W)
+    orders = [np.stack(np.unravel_index(rs.permutation(L), (H, W)), 1).astype(np.int32) for _ in range(F_)]
+    masks = [np.concatenate([c_oracle.unfolded_masks(o, H, W, 3, dil, typ) for o in orders]) for dil, typ in ((1, "A"), (1, "B"), (2, "B"))]
+    ms = [tt(m) for m in masks]
+    codes0 = rs.randint(0, 512, size=(F_, L)).astype(np.int32)
+    logits = eng.forward(tt(codes0), *ms).cpu().numpy()
+    sd = {k: torch.from_numpy(v) for k, v in syn.pixelcnn_state_dict(5).items()}
+    x = torch.nn.functional.one_hot(torch.from_numpy(codes0.astype(np.int64)).view(F_, H, W), 512).permute(0, 3, 1, 2).float()
+    with torch.no_grad():
+        want = lo.pixelcnn_forward(sd, x, *[torch.from_numpy(m) for m in masks]).numpy()
+    np.testing.assert_allclose(logits, want, rtol=1e-4, atol=1e-4)
+    order_loc = np.stack([o[:, 0] * W + o[:, 1] for o in orders]).astype(np.int32)
+    first = L // 2
+    reg = np.zeros((F_, L), np.uint8)
+    for b in range(F_):
+        reg[b, order_loc[b][first:]] = 1
+    u = rs.rand(F_, L).astype(np.float32)
+    c = tt(codes0.copy())
+    out = eng.ar_run(c, tt(order_loc), tt(reg), *ms, temperature=0.7, uniforms=tt(u), first_step=first, want_logits=True)
+    eng.check()
+    codes = c.cpu().numpy()
+    full = eng.forward(tt(codes), *ms).reshape(F_, 512, L).permute(0, 2, 1).cpu().numpy()
+    got = out.cpu().numpy()
+    for b in range(F_):
+        walked = order_loc[b][first:]
+        assert np.array_equal(full[b][walked], got[b][walked])
