@@ -51,6 +51,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int NF = 80;        // nr_filters          (models/z_buffermodel.py:63)
 constexpr int NCLS = 512;     // input_channels / classes
 constexpr int NNODE = 19;     // u0..u8 (up pass) + d0..d9 (down pass)
+constexpr int R_LD = 96;      // row stride of the raw-u caches R[node]: 80 channels padded to three 128-byte lines, so that a
+                              // cache line never spans two locations (E / X rows are 160 floats = five lines)
 constexpr int NGATED = 14;
 constexpr int MAX_TAPS = 10;  // 9 conv taps + 1 nin_skip slot
 
@@ -323,7 +325,7 @@ __device__ __forceinline__ void store_raw_celu2(float *R, float *E, size_t loc, 
 {
     f32x2 ep, en;
     celu_pair2(u, ep, en);
-    *(f32x2 *)(R + loc * NF + c) = u;
+    *(f32x2 *)(R + loc * R_LD + c) = u;
     *(f32x2 *)(E + loc * (2 * NF) + c) = ep;
     *(f32x2 *)(E + loc * (2 * NF) + NF + c) = en;
 }
@@ -356,7 +358,7 @@ __global__ __launch_bounds__(256) void k_post_grid(PostArgs a)
     const f32x2 y = slot_sum2(ld(a.bias + c), ld(P + SLOT_NA * ss), ld(P + SLOT_C * ss), ld(P + SLOT_NB * ss));
     if (KIND == POST_GATE) {
         g = slot_sum2(ld(a.bias + NF + c), ld(P + SLOT_NA * ss + NF), ld(P + SLOT_C * ss + NF), ld(P + SLOT_NB * ss + NF));
-        rin = ld(a.Rin + loc * NF + c);
+        rin = ld(a.Rin + loc * R_LD + c);
     }
     if (KIND == POST_CONVIN && a.has_skip) skip = ld(P + SLOT_SKIP * ss) + ld(a.bias2 + c);
     const float mean = pono_mean(pono_total(y, own));
@@ -988,13 +990,14 @@ __device__ __forceinline__ void chain_role(const ChainArgs &a, int wg)
         }
     } else if (swave) {
         // ================= store wave: off everybody's critical path =================
-        size_t off80[FPW];
+        size_t off80[FPW], offR[FPW];
         bool fvalid[FPW];
 #pragma unroll
         for (int f = 0; f < FPW; ++f) {
             fvalid[f] = f0 + f < a.F;
             const int q = fvalid[f] ? a.cx.ctx[f0 + f].q : 0;
             off80[f] = ((size_t)(fvalid[f] ? f0 + f : 0) * a.L + q) * NF;
+            offR[f] = ((size_t)(fvalid[f] ? f0 + f : 0) * a.L + q) * R_LD;
         }
         const int ch[2] = {cA, cB};
         auto store_outputs = [&](const StoreCtl &c) {  // what the post op of the record produced: LDS -> caches
@@ -1009,7 +1012,7 @@ __device__ __forceinline__ void chain_role(const ChainArgs &a, int wg)
                         *PS_G(float, c.X + 2 * off80[f] + ch[k]) = ep;
                         *PS_G(float, c.X + 2 * off80[f] + NF + ch[k]) = en;
                     } else {
-                        *PS_G(float, c.R + off80[f] + ch[k]) = sOut[f][0][ch[k]];
+                        *PS_G(float, c.R + offR[f] + ch[k]) = sOut[f][0][ch[k]];
                         *PS_G(float, c.E + 2 * off80[f] + ch[k]) = ep;
                         *PS_G(float, c.E + 2 * off80[f] + NF + ch[k]) = en;
                     }
@@ -1390,7 +1393,7 @@ void run_grid(ps_pixelcnn *h, int F, const int32_t *codes, const Masks &m, float
     auto dilated = [&](int d) {
         const ps_pixelcnn::Dil &D = h->dil[d];
         GemmArgs a{};
-        conv_taps(a, h->R[D.node_in], NF, D.w, NF, NF, 2);                              // model.py:138,148
+        conv_taps(a, h->R[D.node_in], R_LD, D.w, NF, NF, 2);                            // model.py:138,148
         gemm(a, m.dil);
         PostArgs p{items, h->partial, nitems, NF, h->L, 0, D.b, nullptr, nullptr, h->R[D.node_out], h->E[D.node_out], nullptr};
         hipLaunchKernelGGL(k_post_grid<POST_DIL>, dim3(pblocks), dim3(256), 0, st, p);
@@ -1447,7 +1450,7 @@ int build_stage_table(ps_pixelcnn *h)
     };
     auto dilated = [&](int d) {
         const ps_pixelcnn::Dil &D = h->dil[d];
-        push(D.w, nullptr, h->R[D.node_in], NF, 5, NF, 2, 2, 4, 1, IN_RAW, -1);
+        push(D.w, nullptr, h->R[D.node_in], R_LD, 5, NF, 2, 2, 4, 1, IN_RAW, -1);
         prev = Prev{PRO_DIL, D.b, nullptr, 0, h->R[D.node_out], h->E[D.node_out], nullptr, -1};
         prev.save = (D.node_out >= 1 && D.node_out <= 7) ? D.node_out : -1;
     };
@@ -1603,7 +1606,7 @@ int ps_pixelcnn_create(const float *const *params, int n_params, int H, int W, i
     }
     const size_t locs = (size_t)max_frames * h->L;
     for (int n = 0; n < NNODE; ++n) {
-        if ((rc = dev_alloc(h, &h->R[n], locs * NF))) return fail_out(rc);
+        if ((rc = dev_alloc(h, &h->R[n], locs * R_LD))) return fail_out(rc);
         if ((rc = dev_alloc(h, &h->E[n], locs * 2 * NF))) return fail_out(rc);
     }
     for (int g = 0; g < NGATED; ++g)
