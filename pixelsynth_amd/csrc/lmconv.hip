@@ -296,29 +296,35 @@ __device__ __forceinline__ float pono_total(const f32x2 &v, bool own)
 //   y[o] = b[o] + sum_t m_t * (W[t][512][o] + W[t][code(nbr_t)][o])
 // Only earlier order positions contribute (the centre of a type-A mask is 0), so in column mode this
 // belongs to the neighbour kernel, not to the chain.  V = float (channel c) or f32x4 (channels c .. c+3).
+// `code[t]`: the neighbour's class, -1 = all-zero input (not sampled yet), UINIT_CLOSED = tap closed / outside the grid
+constexpr int UINIT_CLOSED = -2;
+template <typename V>
+__device__ __forceinline__ V uinit_from_codes(const int *code /*9*/, const float *mA /*9 values*/, const float *__restrict__ w,
+                                              const float *__restrict__ bias, int c)
+{
+    V v = *(const V *)(bias + c);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        if (code[t] == UINIT_CLOSED) continue;
+        V x = *(const V *)(w + ((size_t)t * (NCLS + 1) + NCLS) * NF + c);
+        if (code[t] >= 0) x = x + *(const V *)(w + ((size_t)t * (NCLS + 1) + code[t]) * NF + c);
+        v = v + x * mA[t];
+    }
+    return v;
+}
 template <typename V>
 __device__ __forceinline__ V uinit_gather(const int32_t *__restrict__ codes_f, const float *mA /*9 values*/,
                                           const float *__restrict__ w, const float *__restrict__ bias, int q, int H, int W, int c)
 {
     const int r = q / W, c0 = q - r * W;
     int code[9];
-    float mv[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         const int rr = r + t / 3 - 1, cc = c0 + t % 3 - 1;
         const bool in = rr >= 0 && rr < H && cc >= 0 && cc < W;
-        mv[t] = in ? mA[t] : 0.0f;
-        code[t] = (in && mv[t] != 0.0f) ? codes_f[rr * W + cc] : -1;
+        code[t] = (in && mA[t] != 0.0f) ? codes_f[rr * W + cc] : UINIT_CLOSED;
     }
-    V v = *(const V *)(bias + c);
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        if (mv[t] == 0.0f) continue;
-        V x = *(const V *)(w + ((size_t)t * (NCLS + 1) + NCLS) * NF + c);
-        if (code[t] >= 0) x = x + *(const V *)(w + ((size_t)t * (NCLS + 1) + code[t]) * NF + c);
-        v = v + x * mv[t];
-    }
-    return v;
+    return uinit_from_codes<V>(code, mA, w, bias, c);
 }
 
 __device__ __forceinline__ void store_raw_celu2(float *R, float *E, size_t loc, int c, const f32x2 &u)
@@ -429,30 +435,47 @@ __global__ __launch_bounds__(256) void k_logits_grid(ItemMap items, const float 
 //                    LDS, weights stream from L2 into registers.  Ends with the categorical draw and the context of
 //                    the next order position.
 // ==========================================================================================
+// Context of one order position of one frame: everything the launch needs that does not depend on this position's
+// own chain, gathered in one 160-byte record so that it costs one memory round trip.  Two records per frame, indexed
+// by the parity of the position: the launch of position p reads record p & 1 and prepares record (p + 1) & 1.
 struct StepCtx {
-    int step, q;
-    float m[3][9];  // mask values of location q: [0] type A dil 1, [1] type B dil 1, [2] type B dil 2
+    int q;            // location
+    int late_tap;     // type-A tap whose neighbour is the location of position p - 1 (its code is patched in last), -1
+    float m[3][9];    // mask values of location q: [0] type A dil 1, [1] type B dil 1, [2] type B dil 2
+    int ncode[9];     // code of the type-A neighbour of every tap (u_init gather), UINIT_CLOSED where the tap is closed
+    int pad;
 };
 
 struct CtxArgs {
-    StepCtx *ctx;
+    StepCtx *ctx;     // [2][F]
     const int32_t *order;
     const float *mask[3];
     int F, L;
 };
+__device__ __forceinline__ StepCtx *ctx_of(const CtxArgs &a, int f, int step) { return a.ctx + (size_t)(step & 1) * a.F + f; }
 
-__device__ __forceinline__ void ctx_fill(const CtxArgs &a, int f, int step, int t /*thread 0..31*/)
+// neighbour code of type-A tap t of location q (-1: closed tap or outside the grid)
+__device__ __forceinline__ int ctx_nbr_loc(int q, int t, int H, int W)
 {
-    if (step >= a.L) {
-        if (t == 0) a.ctx[f].step = step;
-        return;
-    }
-    const int q = a.order[(size_t)f * a.L + step];
-    if (t < 27) a.ctx[f].m[t / 9][t % 9] = a.mask[t / 9][((size_t)f * 9 + t % 9) * a.L + q];
-    if (t == 27) { a.ctx[f].step = step; a.ctx[f].q = q; }
+    const int r = q / W, c = q - r * W, rr = r + t / 3 - 1, cc = c + t % 3 - 1;
+    return (rr >= 0 && rr < H && cc >= 0 && cc < W) ? rr * W + cc : -1;
 }
 
-__global__ __launch_bounds__(32) void k_ctx_init(CtxArgs a, int step) { ctx_fill(a, blockIdx.x, step, threadIdx.x); }
+// complete record of position `step` from the current codes (first position of a run / single-step API)
+__global__ __launch_bounds__(32) void k_ctx_init(CtxArgs a, const int32_t *codes, int H, int W, int step)
+{
+    const int f = blockIdx.x, t = threadIdx.x;
+    if (step >= a.L) return;
+    StepCtx *c = ctx_of(a, f, step);
+    const int q = a.order[(size_t)f * a.L + step];
+    if (t < 27) c->m[t / 9][t % 9] = a.mask[t / 9][((size_t)f * 9 + t % 9) * a.L + q];
+    if (t == 27) { c->q = q; c->late_tap = -1; }
+    if (t < 9) {
+        const int loc = ctx_nbr_loc(q, t, H, W);
+        const float mA = a.mask[0][((size_t)f * 9 + t) * a.L + q];
+        c->ncode[t] = (loc >= 0 && mA != 0.0f) ? codes[(size_t)f * a.L + loc] : UINIT_CLOSED;
+    }
+}
 
 enum { PRO_UINIT = 0, PRO_CONVIN = 1, PRO_GATE = 2, PRO_DIL = 3 };
 enum { IN_CELU = 0, IN_RAW = 1, IN_ELU = 2 };
@@ -493,6 +516,7 @@ struct NbrArgs {
     int chain_xcds;  // XCDs 0 .. chain_xcds-1 are left to the chain workgroups (see k_column); 0 = no split
     unsigned *cnt;   // [NST] completion counters of this handle: work items done per stage, ever
     int nbr_wgs;     // neighbour-role workgroups of the launch
+    int step;        // order position of this launch (selects the context record, see StepCtx)
 };
 
 // XCD affinity, for speed only (nothing depends on it): workgroup b of a launch runs on XCD b % 8, each XCD with
@@ -516,11 +540,12 @@ __device__ __forceinline__ f32x4 nbr_tap(const NbrWork &sd, const NbrArgs &a, in
     float mv = 0.0f;
     const float *src = nullptr;
     if (valid) {
-        const int q = a.ctx[f].q;
+        const StepCtx &cx = a.ctx[(size_t)(a.step & 1) * a.F + f];
+        const int q = cx.q;
         const int r = q / a.W, c = q - r * a.W;
         const int rr = r + (t / 3 - 1) * sd.dil, cc = c + (t % 3 - 1) * sd.dil;
         if (rr >= 0 && rr < a.H && cc >= 0 && cc < a.W) {
-            mv = a.ctx[f].m[sd.mask_kind][t];
+            mv = cx.m[sd.mask_kind][t];
             src = sd.in + ((size_t)f * a.L + rr * a.W + cc) * sd.in_ld + 4 * kk;
         }
     }
@@ -620,6 +645,7 @@ struct ChainArgs {
     unsigned epoch;            // column launches of this handle so far, this one included: counters are never reset
     int tiles;                 // 16-frame tiles of the neighbour role
     int *err;                  // set to 1 if a bounded wait ran out (ps_pixelcnn_status)
+    int step;                  // order position of this launch
     unsigned long long *trace; // optional [NST][10] shader-clock stamps of workgroup 0 (tuning aid)
 };
 
@@ -754,6 +780,7 @@ __device__ __forceinline__ void chain_role(const ChainArgs &a, int wg)
     __shared__ __attribute__((aligned(16))) float sU[8][FPW][NF];        // u0..u7 of this location
     __shared__ __attribute__((aligned(16))) float sOut[FPW][3][NF];      // (u, elu(u), elu(-u)) on their way to the caches
     __shared__ __attribute__((aligned(16))) float sPL[FPW][5][NCLS];     // chain values of nin_out
+    __shared__ int sLate[FPW];                                           // next record: tap that waits for this position's code
     const int t = threadIdx.x, wave = uni(t >> 6), lane = t & 63;
     const int f0 = wg * FPW;
     // Roles, each in its own wave-uniform branch (so their registers do not add up):
@@ -931,13 +958,14 @@ __device__ __forceinline__ void chain_role(const ChainArgs &a, int wg)
             PS_TRACE1(t == C1_THREADS - 64, 4);
         };
         Ops oA, oB;
-        {   // u0 = norm_init(u_init): the gather over the (earlier) neighbours' codes
-            const int fr = pvalid ? pfr : 0;
+        const StepCtx *ctxp = ctx_of(a.cx, pvalid ? pfr : 0, a.step);
+        const int q0 = ctxp->q;
+        {   // u0 = norm_init(u_init): the gather over the (earlier) neighbours' codes, which the context record carries
             float mA[9];
+            int ncode[9];
 #pragma unroll
-            for (int tp = 0; tp < 9; ++tp) mA[tp] = a.cx.ctx[fr].m[0][tp];
-            const int q0 = a.cx.ctx[fr].q;
-            const f32x2 y = uinit_gather<f32x2>(a.codes_in + (size_t)fr * a.L, mA, a.uinit_w, a.uinit_b, q0, a.H, a.W, c2);
+            for (int tp = 0; tp < 9; ++tp) { mA[tp] = ctxp->m[0][tp]; ncode[tp] = ctxp->ncode[tp]; }
+            const f32x2 y = uinit_from_codes<f32x2>(ncode, mA, a.uinit_w, a.uinit_b, c2);
             post_and_emit(y, zero2, zero2, integral_constant<int, PRO_UINIT>{}, integral_constant<bool, false>{},
                           integral_constant<int, IN_CELU>{}, cur.save_slot);
             // the neighbour slots of stage 0 are first needed after the chains of stage 0
@@ -959,7 +987,7 @@ __device__ __forceinline__ void chain_role(const ChainArgs &a, int wg)
         // ---- end of the order position: logits, categorical draw (sample.py:60-66)
         if (pvalid) {
             const int f = pfr;
-            const int fq = uni(a.cx.ctx[f].q);
+            const int fq = uni(q0);
             const size_t loc = (size_t)f * a.L + fq;
             float lg[8];
             {
@@ -979,13 +1007,16 @@ __device__ __forceinline__ void chain_role(const ChainArgs &a, int wg)
 #pragma unroll
                 for (int k = 0; k < 8; ++k) a.step_logits[(size_t)f * NCLS + lane * 8 + k] = lg[k];
             }
+            int final_code = UINIT_CLOSED;  // (unknown yet)
             if (a.codes && a.region[loc]) {
-                if (a.forced) {
-                    if (lane == 0) a.codes[loc] = a.forced[loc];
-                } else {
-                    const int code = draw_code(lg, a.temperature, a.uniforms[loc], lane);
-                    if (lane == 0) a.codes[loc] = code;
-                }
+                final_code = a.forced ? a.forced[loc] : draw_code(lg, a.temperature, a.uniforms[loc], lane);
+                if (lane == 0) a.codes[loc] = final_code;
+            }
+            // the next position's record was prepared by the control wave, except the code of this very location
+            const int lt = sLate[pf];
+            if (a.advance && lt >= 0 && lane == 0) {
+                if (final_code == UINIT_CLOSED) final_code = a.codes_in[loc];  // observed location: its code stays
+                ctx_of(a.cx, f, a.step + 1)->ncode[lt] = final_code;
             }
         }
     } else if (swave) {
@@ -995,7 +1026,7 @@ __device__ __forceinline__ void chain_role(const ChainArgs &a, int wg)
 #pragma unroll
         for (int f = 0; f < FPW; ++f) {
             fvalid[f] = f0 + f < a.F;
-            const int q = fvalid[f] ? a.cx.ctx[f0 + f].q : 0;
+            const int q = fvalid[f] ? ctx_of(a.cx, f0 + f, a.step)->q : 0;
             off80[f] = ((size_t)(fvalid[f] ? f0 + f : 0) * a.L + q) * NF;
             offR[f] = ((size_t)(fvalid[f] ? f0 + f : 0) * a.L + q) * R_LD;
         }
@@ -1060,11 +1091,49 @@ __device__ __forceinline__ void chain_role(const ChainArgs &a, int wg)
             rec = min(rec, NST);
             keep ^= ctl_i(a.ctl1, rec, 0) ^ ctl_i(a.ctl1, rec, 16);  // both 64-byte lines of the 96-byte record
         };
+        // The context record of the NEXT position is built here, its dependent fetches (location from the order; mask
+        // values; the neighbours' codes) spread over the windows of stages 0, 4, 8 and written in that of stage 12 --
+        // this wave never holds up a barrier, and nothing is left for the end of the launch but the one code that is
+        // not known before (the tap whose neighbour is this very location: late_tap, patched by the post wave).
+        const bool build = a.advance && a.step + 1 < a.L;
+        int nq[FPW], ncode[FPW], qcur[FPW];
+        float nm[FPW];
+        bool late[FPW];
+#pragma unroll
+        for (int f = 0; f < FPW; ++f) {
+            nq[f] = 0; ncode[f] = UINIT_CLOSED; nm[f] = 0.0f; late[f] = false;
+            qcur[f] = build ? ctx_of(a.cx, f0 + f < a.F ? f0 + f : 0, a.step)->q : 0;
+            if (lane == 0) sLate[f] = -1;
+        }
         for (int r = 0; r < 6; ++r) touch(r);
         lds_barrier();
         for (int s = 0; s < NST - 2; ++s) {
             lds_barrier();
             touch(6 + s);
+            if (build) {
+#pragma unroll
+                for (int f = 0; f < FPW; ++f) {
+                    const int fr = f0 + f < a.F ? f0 + f : 0;
+                    if (s == 0) nq[f] = a.cx.order[(size_t)fr * a.L + a.step + 1];
+                    if (s == 4 && lane < 27) nm[f] = a.cx.mask[lane / 9][((size_t)fr * 9 + lane % 9) * a.L + nq[f]];
+                    if (s == 8 && lane < 9) {
+                        const int loc = ctx_nbr_loc(nq[f], lane, a.H, a.W);
+                        if (loc >= 0 && nm[f] != 0.0f) {
+                            late[f] = loc == qcur[f];
+                            ncode[f] = late[f] ? -1 : a.codes_in[(size_t)fr * a.L + loc];
+                        }
+                    }
+                    if (s == 12 && f0 + f < a.F) {
+                        StepCtx *nx = ctx_of(a.cx, fr, a.step + 1);
+                        const unsigned long long lb = __ballot(late[f]);
+                        const int lt = lb ? __builtin_ctzll(lb) : -1;
+                        if (lane < 27) nx->m[lane / 9][lane % 9] = nm[f];
+                        if (lane < 9) nx->ncode[lane] = ncode[f];
+                        if (lane == 27) { nx->q = nq[f]; nx->late_tap = lt; }
+                        if (lane == 0) sLate[f] = lt;
+                    }
+                }
+            }
             lds_barrier();
         }
         load_out_weights();
@@ -1128,10 +1197,6 @@ __device__ __forceinline__ void chain_role(const ChainArgs &a, int wg)
     if (a.trace && wg == 0)
         for (int k = t; k < (NST - 1) * 10; k += C1_THREADS) a.trace[k] = (&sTrace[0][0])[k];
 #endif
-    if (a.advance) {
-        __syncthreads();  // every wave read the ctx[f].q it needs above; the draws are done
-        if (pwave && f0 + pf < a.F && lane < 32) ctx_fill(a.cx, f0 + pf, a.cx.ctx[f0 + pf].step + 1, lane);
-    }
 }
 
 // ==========================================================================================
@@ -1505,15 +1570,17 @@ int build_stage_table(ps_pixelcnn *h)
     return PS_OK;
 }
 
-// one order position: neighbour taps of every conv, then the centre-tap chain + draw.  h->ctx must
+// one order position: neighbour taps of every conv and the centre-tap chains + draw, one launch.  The context
+// record of `step` (h->ctx, parity step & 1) must
 // describe the current position.
-void run_column(ps_pixelcnn *h, int F, const int32_t *codes, ChainArgs ca, hipStream_t st)
+void run_column(ps_pixelcnn *h, int F, const int32_t *codes, ChainArgs ca, int step, hipStream_t st)
 {
     // XCD split: up to 32 frames, the chain workgroups (blocks 0, 8, 16, ...) fill XCD 0 (32 CUs) and the neighbour
     // role gets XCDs 1..7 (V=16: chain 47.5 -> 42.5 us); with more frames both use the whole chip
     const bool split = h->xcd_pack && F <= 32;
     const int tiles = (F + 15) / 16, nbr_wgs = (h->nwork * tiles + NBR_ITEMS_PER_WG - 1) / NBR_ITEMS_PER_WG;
-    NbrArgs na{h->work, h->ctx, h->nbr, h->nwork, h->H, h->W, h->L, F, split ? 1 : 0, h->cnt, nbr_wgs};
+    NbrArgs na{h->work, h->ctx, h->nbr, h->nwork, h->H, h->W, h->L, F, split ? 1 : 0, h->cnt, nbr_wgs, step};
+    ca.step = step;
     ca.ctl1 = h->ctl1; ca.nbr = h->nbr;
     ca.uinit_w = h->uinit_w; ca.uinit_b = h->uinit_b; ca.codes_in = codes;
     ca.out_b = h->out_b;
@@ -1616,7 +1683,7 @@ int ps_pixelcnn_create(const float *const *params, int n_params, int H, int W, i
     if ((rc = dev_alloc(h, &h->partial, pfloats))) return fail_out(rc);
     if ((rc = dev_alloc(h, &h->col_logits, (size_t)max_frames * NCLS))) return fail_out(rc);
     if ((rc = dev_alloc(h, &h->nbr, (size_t)NST * 2 * max_frames * NBR_LD))) return fail_out(rc);
-    if ((rc = dev_alloc(h, &h->ctx, (size_t)max_frames))) return fail_out(rc);
+    if ((rc = dev_alloc(h, &h->ctx, (size_t)2 * max_frames))) return fail_out(rc);
     if ((rc = dev_alloc(h, &h->cnt, (size_t)NST + 1))) return fail_out(rc);
     if ((rc = dev_alloc(h, &h->err, 1))) return fail_out(rc);
     if (hipMemset(h->cnt, 0, (NST + 1) * sizeof(unsigned)) != hipSuccess || hipMemset(h->err, 0, sizeof(int)) != hipSuccess) {
@@ -1657,10 +1724,10 @@ int ps_pixelcnn_ar_step(ps_pixelcnn *h, const int32_t *codes, const int32_t *ord
     if (step == first_step) run_grid(h, F, codes, m, nullptr, false, st, order, first_step);
     ChainArgs ca{};
     ca.cx = make_ctx_args(h, order, m, F);
-    hipLaunchKernelGGL(k_ctx_init, dim3(F), dim3(32), 0, st, ca.cx, step);
+    hipLaunchKernelGGL(k_ctx_init, dim3(F), dim3(32), 0, st, ca.cx, codes, h->H, h->W, step);
     ca.step_logits = logits;
     ca.temperature = 1.0f;
-    run_column(h, F, codes, ca, st);
+    run_column(h, F, codes, ca, step, st);
     PS_LAUNCH_CHECK();
     return PS_OK;
 }
@@ -1686,12 +1753,12 @@ int ps_pixelcnn_ar_run(ps_pixelcnn *h, int32_t *codes, const int32_t *order, con
     ca.cx = make_ctx_args(h, order, m, F);
     ca.codes = codes; ca.region = sample_region; ca.forced = forced; ca.uniforms = uniforms;
     ca.out_logits = out_logits; ca.temperature = temperature; ca.advance = 1;
-    hipLaunchKernelGGL(k_ctx_init, dim3(F), dim3(32), 0, st, ca.cx, first_step);
+    hipLaunchKernelGGL(k_ctx_init, dim3(F), dim3(32), 0, st, ca.cx, codes, h->H, h->W, first_step);
     PS_LAUNCH_CHECK();
     const int nsteps = h->L - first_step;
     // one launch per order position, enqueued eagerly: the host stays far ahead of the GPU (a hipGraph replay was
     // measured slower, and the launch tag / completion-counter target changes with every launch anyway)
-    for (int sidx = 0; sidx < nsteps; ++sidx) run_column(h, F, codes, ca, st);
+    for (int sidx = 0; sidx < nsteps; ++sidx) run_column(h, F, codes, ca, first_step + sidx, st);
     PS_LAUNCH_CHECK();
     return PS_OK;
 }
@@ -1721,15 +1788,15 @@ int ps_pixelcnn_time_column_step(ps_pixelcnn *h, const int32_t *codes, const int
     ca.cx = make_ctx_args(h, order, Masks{mask_init, mask_undilated, mask_dilated}, F);
     ca.step_logits = h->col_logits;
     ca.temperature = 1.0f;
-    hipLaunchKernelGGL(k_ctx_init, dim3(F), dim3(32), 0, st, ca.cx, step);
-    run_column(h, F, codes, ca, st);  // untimed warm-up
+    hipLaunchKernelGGL(k_ctx_init, dim3(F), dim3(32), 0, st, ca.cx, codes, h->H, h->W, step);
+    run_column(h, F, codes, ca, step, st);  // untimed warm-up
     if (const char *tp = getenv("PS_CHAIN_TRACE")) {  // tuning aid: per-stage shader-clock stamps of workgroup 0
         unsigned long long *d = nullptr;
         if (hipMalloc(&d, NST * 10 * 8) == hipSuccess) {
             (void)hipMemsetAsync(d, 0, NST * 10 * 8, st);
             ChainArgs ct = ca;
             ct.trace = d;
-            run_column(h, F, codes, ct, st);
+            run_column(h, F, codes, ct, step, st);
             std::vector<unsigned long long> hst(NST * 10);
             (void)hipStreamSynchronize(st);
             (void)hipMemcpy(hst.data(), d, NST * 10 * 8, hipMemcpyDeviceToHost);
@@ -1744,7 +1811,7 @@ int ps_pixelcnn_time_column_step(ps_pixelcnn *h, const int32_t *codes, const int
         }
     }
     h->prof = &recs;
-    for (int r = 0; r < reps; ++r) run_column(h, F, codes, ca, st);
+    for (int r = 0; r < reps; ++r) run_column(h, F, codes, ca, step, st);
     h->prof = nullptr;
     PS_HIP_CHECK(hipStreamSynchronize(st));
     for (int t = 0; t < PS_PROF_NTAGS; ++t) { launches[t] = 0; total_ms[t] = 0.0f; }
