@@ -48,33 +48,28 @@ class RasterizePointsXYsBlending(nn.Module):
 
     def __init__(self, C=64, learn_feature=True, radius=1.5, size=256, points_per_pixel=8, opts=None):
         super().__init__()
+        # `default_feature` is never used by forward (in the reference neither) but checkpoints carry it:
+        # a (1,C,1) parameter when learnt, a zero buffer otherwise
         if learn_feature:
-            # never used by forward in the reference either (:74-75) but must exist for checkpoints
-            default_feature = nn.Parameter(torch.randn(1, C, 1))
-            self.register_parameter("default_feature", default_feature)
+            self.default_feature = nn.Parameter(torch.randn(1, C, 1))
         else:
-            default_feature = torch.zeros(1, C, 1)
-            self.register_buffer("default_feature", default_feature)
-        self.radius = radius
-        self.size = size
-        self.points_per_pixel = points_per_pixel
-        self.opts = opts
+            self.register_buffer("default_feature", torch.zeros(1, C, 1))
+        self.radius, self.size, self.points_per_pixel, self.opts = radius, size, points_per_pixel, opts
 
     def _opt(self, name, default):
         return getattr(self.opts, name, default) if self.opts is not None else default
 
     def forward(self, pts3D, src, return_debug=False):
-        bs = src.size(0)
-        if len(src.size()) > 3:
-            bs, c, w, _ = src.size()
+        if src.dim() > 3:    # image-shaped input: (B,C,w,w) features with a (B,3,N) cloud, one row of points per w
+            bs, c, w = src.shape[:3]
             image_size = w
             pts3D = pts3D.permute(0, 2, 1)
-            src = src.unsqueeze(2).repeat(1, 1, w, 1, 1).view(bs, c, -1)
+            src = src.unsqueeze(2).expand(bs, c, w, *src.shape[2:]).reshape(bs, c, -1)
         else:
-            image_size = self.size
-        # Make sure these have been arranged in the same way (reference asserts, :68-69)
-        assert pts3D.size(2) == 3
-        assert pts3D.size(1) == src.size(2)
+            bs, image_size = src.size(0), self.size
+        # cloud and features must be arranged alike: (B,N,3) against (B,C,N)
+        if pts3D.size(2) != 3 or pts3D.size(1) != src.size(2):
+            raise AssertionError(f"splat: points {tuple(pts3D.shape)} do not match features {tuple(src.shape)}")
         _lib.require_cuda(pts3D, src)
         os.environ.get("DEBUG")  # the reference reads os.environ["DEBUG"] (KeyError if unset); tolerated here
 

@@ -38,10 +38,12 @@ def compact_mask(mask, B, C_in):
 
 def lmconv_forward(x, mask, weight, bias=None, dilation=1):
     """y[b,o,l] = bias[o] + sum_{c,t} W[o,c,t] * mask[b,t,l] * xpad[b,c,l+dil*off(t)]  (reference :25-49)."""
-    assert len(x.shape) == 4, "Unfold/fold only support 4D batched image-like tensors"
+    if x.dim() != 4:
+        raise AssertionError("lmconv expects a 4D (B, C, H, W) input")
     out_channels, in_channels, k1, k2 = weight.shape
-    assert x.size(1) == in_channels
-    assert mask.size(1) == k1 * k2
+    if x.size(1) != in_channels or mask.size(1) != k1 * k2:
+        raise AssertionError(f"lmconv: input has {x.size(1)} channels / mask {mask.size(1)} taps, "
+                             f"weight wants {in_channels} / {k1 * k2}")
     if (k1, k2) != (3, 3):
         raise NotImplementedError("the HIP lmconv kernel implements the 3x3 kernels PixelSynth uses")
     _lib.require_cuda(x, mask, weight, bias)
@@ -74,28 +76,27 @@ class _locally_masked_conv2d:
 
 
 class locally_masked_conv2d(nn.Module):
+    """Module form: parameters `weight (Co,Ci,k,k)`, optional `mask_weight (Co,k,k)` and `bias (Co)` under the
+    reference's names, default-initialised like a torch conv (uniform with bound 1/sqrt(fan_in))."""
+
     def __init__(self, in_channels, out_channels, kernel_size=(3, 3), dilation=1, bias=True, mask_weight=False):
         super(locally_masked_conv2d, self).__init__()
-        self.in_channels = in_channels
-        self.out_channels = out_channels
-        self.dilation = dilation
-        pad0 = (dilation * (kernel_size[0] - 1)) // 2
-        pad1 = (dilation * (kernel_size[1] - 1)) // 2
-        self.padding = (pad0, pad1)
-        self.weight = Parameter(torch.Tensor(out_channels, in_channels, *kernel_size))
-        self.mask_weight = Parameter(torch.Tensor(out_channels, *kernel_size)) if mask_weight else None
-        self.bias = Parameter(torch.Tensor(out_channels)) if bias else None
+        kh, kw = kernel_size
+        self.in_channels, self.out_channels, self.dilation = in_channels, out_channels, dilation
+        self.padding = tuple(dilation * (k - 1) // 2 for k in (kh, kw))
+        self.weight = Parameter(torch.empty(out_channels, in_channels, kh, kw))
+        self.mask_weight = Parameter(torch.empty(out_channels, kh, kw)) if mask_weight else None
+        self.bias = Parameter(torch.empty(out_channels)) if bias else None
         self.reset_parameters()
 
     def reset_parameters(self):
-        # same default init as the reference (:128-136)
-        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
-        if self.mask_weight is not None:
-            nn.init.kaiming_uniform_(self.mask_weight, a=math.sqrt(5))
-        if self.bias is not None:
-            fan_in, _ = nn.init._calculate_fan_in_and_fan_out(self.weight)
-            bound = 1 / math.sqrt(fan_in)
-            nn.init.uniform_(self.bias, -bound, bound)
+        bound = 1.0 / math.sqrt(self.in_channels * self.weight.shape[2] * self.weight.shape[3])
+        with torch.no_grad():
+            for p_ in (self.weight, self.mask_weight):
+                if p_ is not None:
+                    nn.init.kaiming_uniform_(p_, a=math.sqrt(5))      # = U(-1/sqrt(fan_in), +1/sqrt(fan_in))
+            if self.bias is not None:
+                self.bias.uniform_(-bound, bound)
 
     def forward(self, x, mask=None):
         return _locally_masked_conv2d.apply(x, mask, self.weight, self.mask_weight, self.bias, self.dilation,

@@ -113,36 +113,40 @@ class PixelCNNEngine:
         return logits
 
 
+def _resnet_stack(n, nr_filters, nonlinearity, conv_op, feature_norm_op, skip, dropout_prob):
+    return nn.ModuleList([gated_resnet(nr_filters, conv_op, feature_norm_op, nonlinearity, skip_connection=skip,
+                                       dropout_prob=dropout_prob) for _ in range(n)])
+
+
 class OurPixelCNNLayer_up(nn.Module):
+    """nr_resnet gated blocks in sequence; returns every intermediate u (the skip sources of the down pass)."""
+
     def __init__(self, nr_resnet, nr_filters, resnet_nonlinearity, conv_op, feature_norm_op=None,
                  kernel_size=(5, 5), weight_norm=True, dropout_prob=0.5, rematerialize=False):
         super(OurPixelCNNLayer_up, self).__init__()
         self.nr_resnet = nr_resnet
-        self.u_stream = nn.ModuleList([gated_resnet(nr_filters, conv_op, feature_norm_op, resnet_nonlinearity,
-                                                    skip_connection=0, dropout_prob=dropout_prob)
-                                       for _ in range(nr_resnet)])
+        self.u_stream = _resnet_stack(nr_resnet, nr_filters, resnet_nonlinearity, conv_op, feature_norm_op, 0, dropout_prob)
 
     def forward(self, u, mask=None):
-        u_list = []
-        for i in range(self.nr_resnet):
-            u = self.u_stream[i](u, mask=mask)
-            u_list += [u]
-        return u_list
+        outs = []
+        for block in self.u_stream:
+            u = block(u, mask=mask)
+            outs.append(u)
+        return outs
 
 
 class OurPixelCNNLayer_down(nn.Module):
+    """nr_resnet gated blocks, each taking the most recent unused u of the up pass as its skip input."""
+
     def __init__(self, nr_resnet, nr_filters, resnet_nonlinearity, conv_op, feature_norm_op=None,
                  kernel_size=(5, 5), weight_norm=True, dropout_prob=0.5, rematerialize=False):
         super(OurPixelCNNLayer_down, self).__init__()
         self.nr_resnet = nr_resnet
-        self.u_stream = nn.ModuleList([gated_resnet(nr_filters, conv_op, feature_norm_op, resnet_nonlinearity,
-                                                    skip_connection=1, dropout_prob=dropout_prob)
-                                       for _ in range(nr_resnet)])
+        self.u_stream = _resnet_stack(nr_resnet, nr_filters, resnet_nonlinearity, conv_op, feature_norm_op, 1, dropout_prob)
 
     def forward(self, u, u_list, mask=None):
-        for i in range(self.nr_resnet):
-            a = u_list.pop()
-            u = self.u_stream[i](u, a=a, mask=mask)
+        for block in self.u_stream:
+            u = block(u, a=u_list.pop(), mask=mask)
         return u
 
 
@@ -230,22 +234,21 @@ class OurPixelCNN(nn.Module):
         return self._forward_layers(x, sample, mask_init, mask_undilated, mask_dilated)
 
     def _forward_layers(self, x, sample, mask_init, mask_undilated, mask_dilated):
-        """The reference's layer-by-layer forward (model.py:118-155); every lmconv is the HIP kernel."""
-        xs = [int(y) for y in x.size()]
-        padding = torch.ones(xs[0], 1, xs[2], xs[3], device=x.device, dtype=x.dtype)
-        x = torch.cat((x, padding), 1)
-        u_list = [self.norm_init(self.u_init(x, mask=mask_init), mask=mask_undilated)]
-        for i in range(2):
-            u_list += self.up_layers[i](u_list[-1], mask=mask_undilated)
-            u_list += [self.downsize_u_stream[i](u_list[-1], mask=mask_dilated)]
-            if self.norm_ds:
-                u_list[-1] = self.norm_ds[i](u_list[-1], mask=mask_dilated)
-        u_list += self.up_layers[2](u_list[-1], mask=mask_undilated)
-        u = u_list.pop()
-        for i in range(2):
-            u = self.down_layers[i](u, u_list, mask=mask_undilated)
-            u = self.upsize_u_stream[i](u, mask=mask_dilated)
-            if self.norm_us:
-                u = self.norm_us[i](u, mask=mask_dilated)
-        u = self.down_layers[2](u, u_list, mask=mask_undilated)
+        """Layer-by-layer forward with the reference's dataflow (model.py:118-155); every lmconv is the HIP kernel.
+        Up pass: u0 = norm(u_init([x, 1])), three groups of gated blocks separated by dilated convs, every u kept;
+        down pass: the same in reverse, each gated block consuming the latest unused u as its skip input."""
+        ones = x.new_ones(x.size(0), 1, x.size(2), x.size(3))
+        stack = [self.norm_init(self.u_init(torch.cat((x, ones), 1), mask=mask_init), mask=mask_undilated)]
+        for g in range(3):
+            stack.extend(self.up_layers[g](stack[-1], mask=mask_undilated))
+            if g < 2:
+                d = self.downsize_u_stream[g](stack[-1], mask=mask_dilated)
+                stack.append(self.norm_ds[g](d, mask=mask_dilated) if self.norm_ds else d)
+        u = stack.pop()
+        for g in range(3):
+            u = self.down_layers[g](u, stack, mask=mask_undilated)
+            if g < 2:
+                u = self.upsize_u_stream[g](u, mask=mask_dilated)
+                if self.norm_us:
+                    u = self.norm_us[g](u, mask=mask_dilated)
         return self.nin_out(F.elu(u))

@@ -32,13 +32,13 @@ class PtsManipulator(nn.Module):
         self.opt = opt
         self.W = W
         self.splatter = get_splatter(opt.splatter, None, opt, size=W, C=C, points_per_pixel=opt.pp_pixel)
-        # same buffer as the reference (:38-48) so state_dicts line up; the kernels regenerate it on the fly
-        xs = torch.linspace(0, W - 1, W) / float(W - 1) * 2 - 1
-        ys = torch.linspace(0, W - 1, W) / float(W - 1) * 2 - 1
-        xs = xs.view(1, 1, 1, W).repeat(1, 1, W, 1)
-        ys = ys.view(1, 1, W, 1).repeat(1, 1, 1, W)
-        xyzs = torch.cat((xs, -ys, -torch.ones(xs.size()), torch.ones(xs.size())), 1).view(1, 4, -1)
-        self.register_buffer("xyzs", xyzs)
+        # the reference's `xyzs` buffer (:38-48) is kept so that state_dicts line up -- rows (x, -y, -1, 1) of the
+        # align-corners NDC grid, row-major; the kernels regenerate these values on the fly
+        axis = torch.arange(W, dtype=torch.float32) / float(W - 1) * 2 - 1
+        gx = axis.view(1, W).expand(W, W).reshape(-1)
+        gy = axis.view(W, 1).expand(W, W).reshape(-1)
+        one = torch.ones(W * W)
+        self.register_buffer("xyzs", torch.stack((gx, -gy, -one, one)).unsqueeze(0))
 
     # ------------------------------------------------------------------ a2
     def project_pts(self, pts3D, K, K_inv, RT_cam1, RTinv_cam1, RT_cam2, RTinv_cam2):
@@ -86,20 +86,18 @@ class PtsManipulator(nn.Module):
     def forward_justpts_cumulative(self, src1, pred_pts, K, K_inv, RT_cam1, RTinv_cam1, RT_cam2, RTinv_cam2,
                                    prior_point_cloud, src2, last_background_mask, RTinv_cam3):
         """Reference :184-219 -> (features, background_mask, new_point_cloud, src)."""
-        bs, c, w, h = src1.size()
-        if last_background_mask is not None:
-            last_background_mask = last_background_mask.view(bs, 1, -1)
+        bs, c = src1.shape[:2]
+        mask_flat = None if last_background_mask is None else last_background_mask.view(bs, 1, -1)
         src = src1
-        if len(pred_pts.size()) > 3:
-            pred_pts = pred_pts.view(bs, 1, -1)
-            src1 = src1.view(bs, c, -1)
+        if pred_pts.dim() > 3:
+            pred_pts = pred_pts.reshape(bs, 1, -1)
+            src = src1.reshape(bs, c, -1)
             if src2 is not None:
-                pred_pts = pred_pts[last_background_mask == True].view(bs, 1, -1)  # noqa: E712
-                src1 = src1[last_background_mask.repeat(1, c, 1) == True].view(bs, c, -1)  # noqa: E712
-                src2 = src2.view(bs, c, -1)
-                src = torch.cat([src1, src2], axis=2)
-            else:
-                src = src1
+                # only the points that fell on background last time are new; boolean gathers keep row-major order
+                keep = mask_flat.bool()
+                pred_pts = pred_pts[keep].view(bs, 1, -1)
+                src = torch.cat([src[keep.expand(bs, c, -1)].view(bs, c, -1), src2.reshape(bs, c, -1)], dim=2)
+        last_background_mask = mask_flat
         pts3D, new_point_cloud = self.project_pts_cumulative(
             pred_pts, K, K_inv, RT_cam1, RTinv_cam1, RT_cam2, RTinv_cam2, prior_point_cloud,
             last_background_mask, RTinv_cam3)

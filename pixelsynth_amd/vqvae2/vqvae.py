@@ -140,19 +140,22 @@ class VQVAETop(nn.Module):
         return self.decode(self.quantize_t.embed_grid(code_t))
 
     # ---------------------------------------------------------------- reference-shaped surface
+    def _quantise(self, quantizer, features):
+        """(B,C,H,W) features -> (quantised (B,C,H,W), diff (1,), codes (B,H,W)) through a Quantize module."""
+        q, diff, ids = quantizer(features.movedim(1, -1))
+        return q.movedim(-1, 1), diff.reshape(1), ids
+
+    def encode(self, input):
+        """-> (quant_t, quant_b, diff, id_t, id_b) like the reference; only id_t matters to the novel-view path."""
+        bottom = self.enc_b(input)
+        quant_t, diff_t, id_t = self._quantise(self.quantize_t, self.quantize_conv_t(self.enc_t(bottom)))
+        fused = torch.cat([self.dec_t(quant_t), bottom], dim=1)
+        quant_b, diff_b, id_b = self._quantise(self.quantize_b, self.quantize_conv_b(fused))
+        return quant_t, quant_b, diff_t + diff_b, id_t, id_b
+
     def forward(self, input):
         quant_t, _, diff, _, _ = self.encode(input)
         return self.decode(quant_t), diff
-
-    def encode(self, input):
-        enc_b = self.enc_b(input)
-        enc_t = self.enc_t(enc_b)
-        quant_t, diff_t, id_t = self.quantize_t(self.quantize_conv_t(enc_t).permute(0, 2, 3, 1))
-        quant_t = quant_t.permute(0, 3, 1, 2)
-        dec_t = self.dec_t(quant_t)
-        quant_b, diff_b, id_b = self.quantize_b(self.quantize_conv_b(torch.cat([dec_t, enc_b], 1)).permute(0, 2, 3, 1))
-        quant_b = quant_b.permute(0, 3, 1, 2)
-        return quant_t, quant_b, diff_t.unsqueeze(0) + diff_b.unsqueeze(0), id_t, id_b
 
     def decode(self, quant_t):
         return self.dec(self.upsample_t(quant_t))
