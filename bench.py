@@ -73,7 +73,7 @@ def run_step(model, d, world):
     out = model.outpaint_views(d["img"], d["depth"], d["K"], d["Kinv"], d["P"], d["Pinv"], d["RT2"], d["RT2inv"],
                                d["codes"], temperature=0.7, uniforms=d["uniforms"])
     if world > 1:  # finished frames of every rank: the path's only collective, RCCL all_gather over xGMI
-        out["all_gen_fs"] = D.gather_frames(out["gen_fs"])
+        out["all_frames_u8"] = D.gather_frames(D.to_image_u8(out["gen_fs"]))
         out["all_codes"] = D.gather_frames(out["codes"].contiguous())
     return out
 
@@ -336,7 +336,7 @@ def main():
                        "views_per_gpu": V, "image": "256x256", "code_grid": "32x32", "num_classes": 512,
                        "ar_steps_walked": 1024 - plan.first_step,
                        "sampled_codes_per_view_mean": round(float(np.mean(plan.n_sampled)), 1),
-                       "parallelism": f"views sharded over {world} GPU(s), RCCL all_gather of finished frames"},
+                       "parallelism": f"views sharded over {world} GPU(s), RCCL all_gather of the finished 8-bit frames + codes"},
         }
         if world == 1:
             try:

@@ -41,6 +41,12 @@ def gather_frames(local, n_views=None):
     return out if n_views is None else out[:n_views]
 
 
+def to_image_u8(frames):
+    """Finished frames in [-1, 1] -> 8-bit images (what the reference's demo writes to disk, demo.py:100-178): a quarter
+    of the bytes on the wire for the gather (786 KB -> 197 KB per 256x256 frame)."""
+    return ((frames.clamp(-1.0, 1.0) * 0.5 + 0.5) * 255.0 + 0.5).to(torch.uint8)
+
+
 def max_over_ranks(seconds, device=None):
     """Slowest rank's wall time (bench.py contract: take the MAX over ranks)."""
     rank, w = world()

@@ -75,9 +75,11 @@ def render_views(model, img, depth, cam, poses, temperature=0.7, seed=0):
 
 
 def save_png(path, chw):
+    """chw: (3,S,S) uint8 image, or float in [-1, 1]."""
     from PIL import Image
-    a = ((chw.clamp(-1, 1) * 0.5 + 0.5) * 255.0 + 0.5).to(torch.uint8).permute(1, 2, 0).cpu().numpy()
-    Image.fromarray(a).save(path)
+    if chw.dtype != torch.uint8:
+        chw = D.to_image_u8(chw)
+    Image.fromarray(chw.permute(1, 2, 0).cpu().numpy()).save(path)
 
 
 def load_image(path, S=256):
@@ -118,10 +120,10 @@ def main(argv=None):
     for s in range(0, len(mine), args.batch):
         chunk = [poses[i] for i in mine[s:s + args.batch]]
         frames.append(render_views(model, img, depth, cam, chunk, seed=rank * 1000 + s)["frames"])
-    local_frames = torch.cat(frames) if frames else torch.empty(0, 3, 256, 256, device=device)
+    local_frames = D.to_image_u8(torch.cat(frames)) if frames else torch.empty(0, 3, 256, 256, dtype=torch.uint8, device=device)
     per_rank = (len(poses) + world - 1) // world                         # gather_frames wants equal shards: pad the last round
     if local_frames.shape[0] < per_rank:
-        pad = torch.zeros(per_rank - local_frames.shape[0], 3, 256, 256, device=device)
+        pad = torch.zeros(per_rank - local_frames.shape[0], 3, 256, 256, dtype=torch.uint8, device=device)
         local_frames = torch.cat([local_frames, pad])
     all_frames = D.gather_frames(local_frames, len(poses))
     if rank == 0:
