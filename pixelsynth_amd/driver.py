@@ -4,6 +4,7 @@ create_vid.py for what this repository builds.
     python -m pixelsynth_amd.driver --trajectory circle --frames 64 --out results/      (one GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
            -m pixelsynth_amd.driver --trajectory circle --frames 64 --out results/         (C4: views sharded over 8 GPUs)
+    python -m pixelsynth_amd.driver --scene R L --num-split 4 --out results/             (chained, as the reference's gen_scene)
 
 One source image (a PNG, or the synthetic RealEstate10K-shaped sample), the demo cameras of process_demo_data
 (demo.py:36-96), target poses from ZbufferModelPts.get_rt_from_rot (directions 'R','L','U','D',... in `--frames`
@@ -11,6 +12,11 @@ equal steps, or the 'C' circle of z_buffermodel.py:217-225).  Every view is rend
 (the reference's demo chains frames on one GPU): reproject + splat, VQ-VAE top codes, AR outpainting,
 decode, get_combined.  Ranks take views round-robin, finished frames are all-gathered (RCCL), rank 0 writes
 <out>/video/%d.png in trajectory order -- the layout create_vid.py's ffmpeg call expects (demo.py:125-164).
+
+--scene runs ZbufferModelPts.forward_scene instead (z_buffermodel.py:420-584): frames chained on ONE GPU, each rendered
+from the previous generated frame on top of the accumulated point cloud; images go to <out>/scene/ and <out>/video/ in
+the reference's save_scene / save_video layout (demo.py:100-164).  A chain does not shard: with several ranks, rank r
+renders its own chain for direction list r (replicas).
 
 The depth regressor, the refinement decoder and trained weights are not part of this repository: depth
 is synthetic unless --depth-npy is given, weights are random-init unless --pixelcnn / --vqvae state dicts are given,
@@ -74,6 +80,32 @@ def render_views(model, img, depth, cam, poses, temperature=0.7, seed=0):
     return dict(frames=frames, features=out["gen_fs"], background_mask=out["background_mask"], codes=out["codes"])
 
 
+def scene_outputs_to_disk(outputs, directions, num_split, out_dir):
+    """PredImg_<dir>_<i> of forward_scene -> scene/output_image_<dir>_%04d.png (demo.py:100-123) and video/%d.png in
+    playback order: out along each direction, and back again for the rotational ones (demo.py:125-164).
+    -> number of video frames written."""
+    def splits(d):
+        return num_split * 2 if d in ("S", "C") else max(num_split // 2, 1) if d in ("U", "D", "UL", "UR", "DR", "DL") else num_split
+    scene, vid = os.path.join(out_dir, "scene"), os.path.join(out_dir, "video")
+    os.makedirs(scene, exist_ok=True)
+    os.makedirs(vid, exist_ok=True)
+    for d in directions:
+        if d in ("S", "C"):
+            continue
+        for i in range(1, splits(d) + 1):
+            save_png(os.path.join(scene, "output_image_%s_%04d.png" % (d, i)), outputs[f"PredImg_{d}_{i}"][0])
+    save_png(os.path.join(vid, "0.png"), outputs[f"PredImg_{directions[0]}_0"][0])
+    n = 1
+    for d in directions:
+        order = list(range(1, splits(d)))
+        if d not in ("S", "C"):
+            order += list(range(splits(d) - 1, -1, -1))
+        for i in order:
+            save_png(os.path.join(vid, f"{n}.png"), outputs[f"PredImg_{d}_{i}"][0])
+            n += 1
+    return n
+
+
 def save_png(path, chw):
     """chw: (3,S,S) uint8 image, or float in [-1, 1]."""
     from PIL import Image
@@ -93,6 +125,9 @@ def main(argv=None):
     ap.add_argument("--image", help="source PNG/JPEG (default: the synthetic sample)")
     ap.add_argument("--depth-npy", help="(S,S) float32 depth in [min_z, max_z] (default: synthetic smooth depth)")
     ap.add_argument("--trajectory", default="circle", help="circle | R | L | U | D | UL | UR | DL | DR")
+    ap.add_argument("--scene", nargs="+", metavar="DIR", help="chained mode: directions of forward_scene, e.g. R L C")
+    ap.add_argument("--num-split", type=int, default=4, help="--scene: views per direction (num_split)")
+    ap.add_argument("--sequential", action="store_true", help="--scene: sequential_outpainting")
     ap.add_argument("--frames", type=int, default=64)
     ap.add_argument("--batch", type=int, default=16, help="views rendered together per rank")
     ap.add_argument("--out", default="results")
@@ -113,6 +148,17 @@ def main(argv=None):
     img = (load_image(args.image) if args.image else torch.from_numpy(syn.image(1000, 1, 3, 256))).to(device)
     depth = t(np.load(args.depth_npy)[None, None].astype(np.float32)) if args.depth_npy else t(syn.depth_smooth(2000, 1, 256, 1.0, 100.0))
     cam = {k: t(v) for k, v in syn.demo_cameras(1).items()}
+    if args.scene:
+        model.opt.directions, model.opt.num_split = list(args.scene), args.num_split
+        model.opt.sequential_outpainting, model.opt.num_samples = args.sequential, 1
+        batch = {"images": [img], "cameras": [cam], "depth_fn": syn.depth_from_image}
+        _, outputs = model(batch)
+        model.outpaint2.engine(32, 32, 1).check()
+        n = scene_outputs_to_disk(outputs, model.opt.directions, args.num_split, os.path.join(args.out, f"rank{rank}") if world > 1 else args.out)
+        print(f"rank {rank}: chained scene {' '.join(args.scene)}: {n} video frames")
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
     kind = "circle" if args.trajectory == "circle" else args.trajectory
     poses = trajectory(model, cam["P"], kind, args.frames)
     mine = D.shard_views(len(poses), rank, world)

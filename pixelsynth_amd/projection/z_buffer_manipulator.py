@@ -94,9 +94,13 @@ class PtsManipulator(nn.Module):
             src = src1.reshape(bs, c, -1)
             if src2 is not None:
                 # only the points that fell on background last time are new; boolean gathers keep row-major order
+                # (sized explicitly: a frame with no background at all contributes zero new points, where the
+                # reference's view(bs, 1, -1) cannot infer a size)
                 keep = mask_flat.bool()
-                pred_pts = pred_pts[keep].view(bs, 1, -1)
-                src = torch.cat([src[keep.expand(bs, c, -1)].view(bs, c, -1), src2.reshape(bs, c, -1)], dim=2)
+                new_pts = pred_pts[keep]
+                n_keep = new_pts.numel() // bs
+                pred_pts = new_pts.view(bs, 1, n_keep)
+                src = torch.cat([src[keep.expand(bs, c, -1)].view(bs, c, n_keep), src2.reshape(bs, c, -1)], dim=2)
         last_background_mask = mask_flat
         pts3D, new_point_cloud = self.project_pts_cumulative(
             pred_pts, K, K_inv, RT_cam1, RTinv_cam1, RT_cam2, RTinv_cam2, prior_point_cloud,
@@ -111,14 +115,13 @@ class PtsManipulator(nn.Module):
         """Reference :221-266 -> (sampler (B,3,NT), xy_proj (B,4,NT))."""
         _lib.require_cuda(pts3D, K, K_inv, RTinv_cam1, RT_cam2)
         B = pts3D.size(0)
-        depth = _f32c(pts3D).view(B, -1)
+        depth = _f32c(pts3D).view(B, pts3D.numel() // B)
         n_new = depth.size(1)
         new_index = None
         if last_background_mask is not None:
             m = last_background_mask.view(B, -1)
             # boolean-mask gather keeps row-major order (:226-228); equal counts per image as in the reference
-            new_index = torch.nonzero(m, as_tuple=False)[:, 1].view(B, -1).to(torch.int32).contiguous()
-            assert new_index.size(1) == n_new
+            new_index = torch.nonzero(m, as_tuple=False)[:, 1].view(B, n_new).to(torch.int32).contiguous()
         n_prior = 0 if prior_point_cloud is None else prior_point_cloud.size(2)
         NT = n_new + n_prior
         sampler = torch.empty(B, 3, NT, dtype=torch.float32, device=depth.device)

@@ -38,6 +38,15 @@ def depth_smooth(seed, B=1, S=256, lo=1.0, hi=100.0):
     return out
 
 
+def depth_from_image(img, lo=1.0, hi=100.0):
+    """Deterministic stand-in for the depth Unet in chained (forward_scene) runs: a smooth depth in [lo, hi] computed
+    from the frame itself (luminance, 16x16 box filter), torch in -> torch out, (B,3,S,S) -> (B,1,S,S)."""
+    import torch.nn.functional as F
+    lum = img.float().mean(1, keepdim=True)
+    smooth = F.interpolate(F.avg_pool2d(lum, 16), size=img.shape[-2:], mode="bilinear", align_corners=False)
+    return lo + (hi - lo) * (0.15 + 0.7 * (0.5 + 0.5 * smooth.clamp(-1, 1)))
+
+
 def demo_cameras(B=1, ratio=1.0):
     """process_demo_data cameras (demo.py:36-96): dict of (B,4,4) f32 arrays P, Pinv, K, Kinv."""
     offset = np.array([[2, 0, -1], [0, -2, 1], [0, 0, -1]], dtype=np.float32)

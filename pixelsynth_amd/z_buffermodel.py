@@ -65,11 +65,38 @@ def build_ar_plan(background_mask, G=32, device=None):
     return plan
 
 
+def rank_samples(discrim_scores, entropy_scores):
+    """Index of the sample get_best_sample keeps (z_buffermodel.py:266-276): samples are ranked by discriminator score
+    (ascending) and by classifier entropy (ascending); total = .5*(n-1-entropy_rank) + .5*discrim_rank; the first
+    arg-max wins.  Ranks come from numpy's default argsort, as there."""
+    n = len(discrim_scores)
+    by_disc, by_entr = np.argsort(np.asarray(discrim_scores)), np.argsort(np.asarray(entropy_scores))
+    disc_rank, entr_rank = np.empty(n, np.int64), np.empty(n, np.int64)
+    disc_rank[by_disc] = np.arange(n)
+    entr_rank[by_entr] = np.arange(n)
+    return int(np.argmax(.5 * (n - 1 - entr_rank) + .5 * disc_rank))
+
+
+class _SceneState:
+    """What forward_scene carries from one rendered frame to the next (z_buffermodel.py:436-443)."""
+
+    def __init__(self, img):
+        self.img = img                # the frame the next one is rendered from
+        self.cloud = None             # (1,4,N) every point so far, in the camera of the last rendered frame
+        self.feats = None             # (1,C,N) their features
+        self.background = None        # (1,S,S) background mask of the last rendered frame
+        self.out_RTinv = None         # inverse pose of the last rendered frame
+        self.numerator = None
+        self.direction = None
+
+
 class ZbufferModelPts(nn.Module):
-    def __init__(self, opt, pts_regressor=None, vqvae=None, projector=None):
+    def __init__(self, opt, pts_regressor=None, vqvae=None, projector=None, encoder=None, classifier=None):
         super().__init__()
         self.opt = opt
         self.pts_regressor = pts_regressor
+        self.encoder = encoder        # feature encoder when use_rgb_features is off (SURVEY 8f.2, injected)
+        self.classifier = classifier  # Places365 ResNet-18 of get_best_sample (SURVEY 8f.3, injected)
         if vqvae is None and getattr(opt, "vqvae", False):  # z_buffermodel.py:81-82
             from .vqvae2 import VQVAETop
             vqvae = VQVAETop()
@@ -213,3 +240,149 @@ class ZbufferModelPts(nn.Module):
             ar_sample = self.vqvae.decode_code(codes.to(torch.int64))
             outputs["PredImg"] = self.projector(self.get_combined(gen_fs, ar_sample, background_mask), background_mask)
         return None, outputs
+
+    # ---------------------------------------------------------------- sample ranking (8f.3, host logic)
+    def _entropy_score(self, gen_img):
+        """Entropy of the scene classifier on the candidate, including the reference's reinterpretation of the
+        (3,256,256) tensor as (256,256,3) (z_buffermodel.py:256-262) and its 224x224 ImageNet-normalised input."""
+        from PIL import Image
+        raw = ((gen_img[0].reshape([256, 256, 3]).cpu().numpy() * .5 + .5) * 255).astype(np.uint8)
+        im = np.asarray(Image.fromarray(raw).resize((224, 224), Image.BILINEAR), np.float32) / 255.0
+        im = (im - np.array([0.485, 0.456, 0.406], np.float32)) / np.array([0.229, 0.224, 0.225], np.float32)
+        x = torch.from_numpy(im).permute(2, 0, 1)[None].to(gen_img.device)
+        probs = torch.softmax(self.classifier(x).float().cpu(), 1).squeeze().numpy()
+        probs = np.sort(probs)[::-1]
+        return float(-np.sum(probs * np.log(probs)))
+
+    def _decode_candidate(self, gen_fs, background_mask, codes):
+        """codes (B,32,32) -> image: decode, blend with the reprojected features (a14), refine if a projector exists."""
+        combined = self.get_combined(gen_fs, self.vqvae.decode_code(codes), background_mask)
+        return combined if self.projector is None else self.projector(combined, background_mask)
+
+    @torch.no_grad()
+    def get_best_sample(self, plan, codes, background_mask, gen_fs, netD, input_img, uniforms=None):
+        """z_buffermodel.py:244-276 on the fused sampler: num_samples outpaintings of the same view, the best by
+        discriminator + entropy rank is kept.  `plan` is the ARPlan of background_mask, `codes` (B,32,32) the VQ-VAE
+        codes of gen_fs.  One sample needs no scorers; more need `netD` and `self.classifier`.
+        uniforms: optional (num_samples,B,L) draws (otherwise torch.Generator seeded i, as sample() reseeds with i)."""
+        n = max(int(getattr(self.opt, "num_samples", 1)), 1)
+        if n > 1 and (netD is None or self.classifier is None):
+            raise RuntimeError("num_samples > 1 ranks candidates with the discriminator (netD) and the scene classifier; "
+                               "neither is part of this library -- pass both or use num_samples=1")
+        B, G = codes.shape[0], self.obs[1]
+        L = G * self.obs[2]
+        eng = self.outpaint2.engine(G, self.obs[2], B)
+        imgs, disc, entr = [], [], []
+        for i in range(n):
+            if uniforms is not None:
+                u = uniforms[i]
+            else:
+                u = torch.rand(B, L, generator=torch.Generator(device="cpu").manual_seed(i)).to(codes.device)
+            c = codes.reshape(B, L).to(torch.int32).contiguous().clone()
+            eng.ar_run(c, plan.order_loc, plan.region, plan.mask_init, plan.mask_undilated, plan.mask_dilated,
+                       temperature=self.opt.temperature, uniforms=u.contiguous(), first_step=plan.first_step)
+            img = self._decode_candidate(gen_fs, background_mask, c.view(B, G, self.obs[2]))
+            imgs.append(img)
+            if n > 1:
+                disc.append(float(netD.run_discriminator_one_step(img, input_img)["D_Fake"].mean().cpu()))
+                entr.append(self._entropy_score(img))
+        return imgs[rank_samples(disc, entr)] if n > 1 else imgs[0]
+
+    # ---------------------------------------------------------------- chained trajectories (8f.4)
+    def _scene_depth(self, img, batch):
+        if self.pts_regressor is not None:  # :476-480
+            return torch.sigmoid(self.pts_regressor(img)) * (self.opt.max_z - self.opt.min_z) + self.opt.min_z
+        fn = batch.get("depth_fn")  # synthetic runs: a callable img -> depth stands in for the Unet
+        if fn is None:
+            raise RuntimeError("forward_scene regresses depth from every generated frame: give the model a "
+                               "pts_regressor or the batch a 'depth_fn' callable")
+        return fn(img)
+
+    def _scene_frame(self, st, batch, K, K_inv, in_RT, in_RTinv, out_RT, out_RTinv, netD, input_img):
+        """One frame of a chained trajectory: depth of the current frame, cumulative reprojection (only the points
+        that were background last time are new, a5), outpainting, state hand-over (:476-522 / :540-582)."""
+        depth = self._scene_depth(st.img, batch)
+        fs = st.img if getattr(self.opt, "use_rgb_features", True) else self.encoder(st.img)
+        gen_fs, background_mask, cloud, feats = self.pts_transformer.forward_justpts_cumulative(
+            fs, depth, K, K_inv, in_RT, in_RTinv, out_RT, out_RTinv, st.cloud, st.feats, st.background, st.out_RTinv)
+        if not getattr(self.opt, "no_outpainting", False):
+            plan = build_ar_plan(background_mask, self.obs[1])
+            gen_img = self.get_best_sample(plan, self.vqvae.encode_codes(gen_fs), background_mask, gen_fs, netD, input_img)
+        else:
+            gen_img = gen_fs if self.projector is None else self.projector(gen_fs)
+        st.img, st.cloud, st.feats, st.background, st.out_RTinv = gen_img, cloud, feats, background_mask, out_RTinv
+        return gen_img, gen_fs, depth, background_mask
+
+    @torch.no_grad()
+    def forward_scene(self, batch, netD=None):
+        """z_buffermodel.py:420-584 (model_setting gen_scene / gen_two_imgs): per direction, first the far end of the
+        sweep (unless sequential_outpainting), then the views in between, every frame rendered from the previous
+        one on top of the accumulated point cloud.  B = 1, as in the reference (a5 needs equal counts per image).
+        -> (None, outputs) with the reference's keys PredImg_<dir>_<i>, FeaturesImg_..., PredDepthImg_..., ForegroundImg_..."""
+        dev = torch.device("cuda", torch.cuda.current_device())
+        input_img = batch["images"][0].to(dev)
+        cam = {k: v.to(dev) for k, v in batch["cameras"][0].items() if torch.is_tensor(v)}
+        K, K_inv, input_RT, input_RTinv = cam["K"], cam["Kinv"], cam["P"], cam["Pinv"]
+        two = self.opt.model_setting == 'gen_two_imgs'
+        directions = [self.mapping[int(batch["direction"])]] if two else list(self.opt.directions)
+        sequential = bool(getattr(self.opt, "sequential_outpainting", False))
+        outputs = {"InputImg": input_img}
+        st = _SceneState(input_img)
+
+        def pose_of(direction, numerator, denom):
+            return self.get_rt_from_rot(direction, input_RT, numerator, denom)
+
+        def summary(direction, tag, gen_fs, depth, background_mask):
+            outputs[f"FeaturesImg_{direction}_{tag}"] = gen_fs
+            outputs[f"PredDepthImg_{direction}_{tag}"] = depth
+            outputs[f"ForegroundImg_{direction}_{tag}"] = (~background_mask).repeat(input_img.shape[0], 1, 1, 1).float()
+
+        for direction in directions:
+            base = int(self.opt.num_split)
+            if two:
+                num_split = 2
+            elif direction in ('S', 'C'):
+                num_split = base * 2
+            elif direction in ('U', 'D', 'UL', 'UR', 'DR', 'DL'):
+                num_split = max(base // 2, 1)
+            else:
+                num_split = base
+
+            def source_pose():  # where the frame we render FROM was taken
+                if st.numerator is None:
+                    return input_RTinv, input_RT
+                return pose_of(st.direction, st.numerator, num_split)
+
+            if not sequential:
+                # the large completion first (:470-522)
+                in_RTinv, in_RT = source_pose()
+                out_RTinv, out_RT = pose_of(direction, num_split, num_split)
+                gen_img, gen_fs, depth, bgm = self._scene_frame(st, batch, K, K_inv, in_RT, in_RTinv, out_RT, out_RTinv,
+                                                                netD, input_img)
+                st.numerator, st.direction = num_split, direction
+                outputs[f"PredImg_{direction}_{num_split}"] = gen_img
+                summary(direction, num_split, gen_fs, depth, bgm)
+                todo = range(num_split - 1, -1, -1)
+            else:
+                todo = range(num_split + 1)
+            for i in todo:
+                if sequential and i == 0:
+                    in_RTinv, in_RT = source_pose()
+                else:
+                    in_RTinv, in_RT = pose_of(direction, st.numerator, num_split)
+                out_RTinv, out_RT = pose_of(direction, i, num_split)
+                gen_img, gen_fs, depth, bgm = self._scene_frame(st, batch, K, K_inv, in_RT, in_RTinv, out_RT, out_RTinv,
+                                                                netD, input_img)
+                outputs[f"PredImg_{direction}_{i}"] = gen_img
+                outputs[f"FeaturesImg_{direction}_{i}"] = gen_fs
+                if sequential and i == num_split:
+                    summary(direction, num_split, gen_fs, depth, bgm)
+                    st.direction = direction
+                st.numerator = i
+        return None, outputs
+
+    def forward(self, batch, netD=None):
+        """z_buffermodel.py:278-290."""
+        if self.opt.model_setting in ('gen_scene', 'gen_two_imgs'):
+            return self.forward_scene(batch, netD)
+        return self.forward_image(batch, netD)

@@ -79,3 +79,19 @@ def test_masking_mirror_matches_oracle():
     unf = masking.get_unfolded_masks(order, 32, 32, 3, 2, "B")
     assert np.array_equal(unf.numpy(), c_oracle.unfolded_masks(ref, 32, 32, 3, 2, "B"))
     assert np.array_equal(km.reshape(1024, 9).T.astype(np.float32), unf[0].numpy())
+
+
+def test_rank_samples_follows_the_reference_rule():
+    """z_buffermodel.py:266-276, restated with its own loops: rank of sample i in each sorted list (np.where), total =
+    .5*(n-1-entropy_rank) + .5*discriminator_rank, arg-max."""
+    from pixelsynth_amd.z_buffermodel import rank_samples
+    rs = np.random.RandomState(3)
+    for n in (1, 2, 3, 5, 8):
+        for _ in range(20):
+            disc, entr = rs.rand(n).tolist(), rs.rand(n).tolist()
+            sorted_disc, sorted_entr = np.array(disc).argsort(), np.array(entr).argsort()
+            disc_ranks = [np.where(sorted_disc == i)[0][0] for i in range(n)]
+            entr_ranks = [np.where(sorted_entr == i)[0][0] for i in range(n)]
+            total = .5 * (n - 1 - np.array(entr_ranks)) + .5 * np.array(disc_ranks)
+            assert rank_samples(disc, entr) == int(np.argmax(total))
+    assert rank_samples([0.1, 0.9], [2.0, 1.0]) == 1     # highest discriminator score and lowest entropy wins

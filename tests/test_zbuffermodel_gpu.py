@@ -153,6 +153,129 @@ def test_views_with_the_vqvae_in_the_loop():
     np.testing.assert_allclose(dec.cpu().numpy(), want.numpy(), rtol=1e-4, atol=1e-5)
 
 
+def _scene_model(**kw):
+    o = dict(vqvae=True, model_setting="gen_scene", num_split=2, directions=["R", "L"], num_samples=1,
+             sequential_outpainting=False)
+    o.update(kw)
+    m = make_model(**o)
+    m.vqvae.load_state_dict({k: torch.from_numpy(v) for k, v in syn.vqvae_state_dict(0).items()}, strict=True)
+    return m.to(DEV).eval()
+
+
+def _scene_batch():
+    cam = {k: torch.from_numpy(v) for k, v in syn.demo_cameras(1).items()}
+    return {"images": [torch.from_numpy(syn.image(31, 1, 3, 256))], "cameras": [cam], "depth_fn": syn.depth_from_image}
+
+
+def _record_scene(m, batch):
+    """Run forward_scene with every cumulative reprojection call recorded (arguments and results)."""
+    calls, inner = [], m.pts_transformer.forward_justpts_cumulative
+
+    def spy(*a):
+        r = inner(*a)
+        calls.append((a, r))
+        return r
+    m.pts_transformer.forward_justpts_cumulative = spy
+    try:
+        _, out = m(batch)
+    finally:
+        m.pts_transformer.forward_justpts_cumulative = inner
+    return calls, out
+
+
+@pytest.mark.parametrize("sequential", [False, True])
+def test_forward_scene_pose_schedule_and_state_chain(sequential):
+    """SURVEY 8f row 4, z_buffermodel.py:420-584: the chained trajectory.  The schedule of (source pose, target pose)
+    pairs is restated here from the reference's loop and compared with what the model hands to the cumulative
+    reprojection; every frame must be rendered from the previous generated frame, on top of the previous frame's
+    cloud, features and background mask; the output keys are the reference's."""
+    m = _scene_model(sequential_outpainting=sequential)
+    batch = _scene_batch()
+    calls, out = _record_scene(m, batch)
+    P = tt(syn.demo_cameras(1)["P"])
+    pose = lambda d, n: m.get_rt_from_rot(d, P, n, 2)[1].cpu().numpy()
+    src = P.cpu().numpy()
+    if not sequential:   # far end first, then back towards the source view; the next direction starts from R_0
+        want = [(src, pose("R", 2), "R_2"), (pose("R", 2), pose("R", 1), "R_1"), (pose("R", 1), pose("R", 0), "R_0"),
+                (pose("R", 0), pose("L", 2), "L_2"), (pose("L", 2), pose("L", 1), "L_1"), (pose("L", 1), pose("L", 0), "L_0")]
+    else:                # 0, 1, 2 in order; the next direction starts from the last rendered view R_2
+        want = [(src, pose("R", 0), "R_0"), (pose("R", 0), pose("R", 1), "R_1"), (pose("R", 1), pose("R", 2), "R_2"),
+                (pose("R", 2), pose("L", 0), "L_0"), (pose("L", 0), pose("L", 1), "L_1"), (pose("L", 1), pose("L", 2), "L_2")]
+    assert len(calls) == len(want)
+    prev_img = batch["images"][0].to(DEV)
+    prev = None
+    for (a, r), (rt_in, rt_out, tag) in zip(calls, want):
+        src1, depth, K, Kinv, RT1, RT1inv, RT2, RT2inv, prior, src2, last_bg, RT3inv = a
+        np.testing.assert_allclose(RT1.cpu().numpy(), rt_in, rtol=0, atol=1e-6)
+        np.testing.assert_allclose(RT2.cpu().numpy(), rt_out, rtol=0, atol=1e-6)
+        np.testing.assert_allclose(RT1inv.cpu().numpy(), np.linalg.inv(rt_in), rtol=0, atol=1e-5)
+        assert torch.equal(src1, prev_img)                                   # rendered from the previous generated frame
+        assert torch.equal(depth, syn.depth_from_image(prev_img))
+        if prev is None:
+            assert prior is None and src2 is None and last_bg is None and RT3inv is None
+        else:
+            (pa, pr) = prev
+            assert prior is pr[2] and src2 is pr[3] and last_bg is pr[1] and torch.equal(RT3inv, pa[7])
+            n_new = int(pr[1].sum())
+            assert r[2].shape[2] == n_new + pr[2].shape[2]                     # only last frame's background is new
+        assert torch.equal(out[f"FeaturesImg_{tag}"], r[0])
+        prev_img, prev = out[f"PredImg_{tag}"], (a, r)
+        assert tuple(prev_img.shape) == (1, 3, 256, 256) and torch.isfinite(prev_img).all()
+    for d in ("R", "L"):
+        assert tuple(out[f"PredDepthImg_{d}_2"].shape) == (1, 1, 256, 256)
+        assert tuple(out[f"ForegroundImg_{d}_2"].shape) == (1, 1, 256, 256)
+    m.outpaint2.engine(32, 32, 1).check()
+    # an outpainted frame = reprojected features where visible, decoded sample elsewhere (no refinement net here)
+    a, r = calls[0]
+    fg = ~r[1][:, None].expand(1, 3, 256, 256)
+    assert torch.equal(out["PredImg_" + want[0][2]][fg], r[0][fg])
+
+
+def test_forward_scene_first_frame_equals_the_single_view_path():
+    """No prior cloud yet: the first chained frame is forward_justpts of the source, and its outpainting is what
+    outpaint_views produces for the same draws."""
+    m = _scene_model()
+    batch = _scene_batch()
+    calls, out = _record_scene(m, batch)
+    a, r = calls[0]
+    img, cam = batch["images"][0].to(DEV), {k: v.to(DEV) for k, v in batch["cameras"][0].items()}
+    RTinv, RT = m.get_rt_from_rot("R", cam["P"], 2, 2)
+    u = torch.rand(1, 1024, generator=torch.Generator(device="cpu").manual_seed(0)).to(DEV)
+    ref = m.outpaint_views(img, syn.depth_from_image(img), cam["K"], cam["Kinv"], cam["P"], cam["Pinv"], RT, RTinv, None,
+                           temperature=0.7, uniforms=u)
+    assert torch.equal(r[0], ref["gen_fs"]) and torch.equal(r[1], ref["background_mask"])
+    want = m.get_combined(ref["gen_fs"], m.vqvae.decode_code(ref["codes"]), ref["background_mask"])
+    assert torch.equal(out["PredImg_R_2"], want)
+
+
+def test_get_best_sample_ranks_candidates():
+    """num_samples > 1: every candidate is scored by the (injected) discriminator and scene classifier and the
+    reference's rank rule picks one (z_buffermodel.py:244-276); without scorers the call refuses."""
+    from pixelsynth_amd.z_buffermodel import build_ar_plan, rank_samples
+    m = _scene_model(num_samples=3)
+    img = tt(syn.image(31, 1, 3, 256))
+    cam = {k: tt(v) for k, v in syn.demo_cameras(1).items()}
+    RTinv, RT = m.get_rt_from_rot("R", cam["P"], 2, 2)
+    gen_fs, bg = m.pts_transformer.forward_justpts(img, syn.depth_from_image(img), cam["K"], cam["Kinv"], cam["P"],
+                                                   cam["Pinv"], RT, RTinv)
+    plan = build_ar_plan(bg, 32)
+    codes = m.vqvae.encode_codes(gen_fs)
+    with pytest.raises(RuntimeError, match="num_samples"):
+        m.get_best_sample(plan, codes, bg, gen_fs, None, img)
+    seen = []
+
+    class D:   # scores a candidate by its mean (any deterministic function will do)
+        def run_discriminator_one_step(self, fake, real):
+            seen.append(fake)
+            return {"D_Fake": fake.mean().reshape(1)}
+    m.classifier = lambda x: torch.cat([x.mean().reshape(1, 1) * k for k in range(1, 11)], 1)
+    best = m.get_best_sample(plan, codes, bg, gen_fs, D(), img)
+    assert len(seen) == 3 and not torch.equal(seen[0], seen[1])
+    disc = [float(s.mean()) for s in seen]
+    entr = [m._entropy_score(s) for s in seen]
+    assert torch.equal(best, seen[rank_samples(disc, entr)])
+
+
 def test_driver_renders_a_trajectory_and_writes_the_video_layout(tmp_path):
     """the driver (counterpart of demo.py / create_vid.py): poses of the 'C' circle and of a direction sweep,
     views rendered from the source, PNGs under <out>/video/%d.png starting with the source frame."""
@@ -174,3 +297,12 @@ def test_driver_renders_a_trajectory_and_writes_the_video_layout(tmp_path):
     np.testing.assert_allclose(poses[3][2].cpu().numpy(), rt_ref, rtol=1e-6, atol=1e-6)
     sweep = driver.trajectory(m, P, "R", 4)
     np.testing.assert_allclose(sweep[-1][2].cpu().numpy(), syn.yaw_pose(syn.demo_cameras(1)["P"], 0.6)[1], rtol=1e-6, atol=1e-6)
+
+
+def test_driver_chained_scene_writes_scene_and_video_layout(tmp_path):
+    """--scene: forward_scene on one GPU, files in the reference's save_scene / save_video layout (demo.py:100-164)."""
+    from pixelsynth_amd import driver
+    driver.main(["--scene", "R", "U", "--num-split", "2", "--out", str(tmp_path)])
+    assert sorted(os.listdir(tmp_path / "scene")) == ["output_image_R_0001.png", "output_image_R_0002.png", "output_image_U_0001.png"]
+    # R: 1, then back 1, 0; U (num_split 1): back 0  -> 1 + 3 + 1 frames
+    assert sorted(os.listdir(tmp_path / "video"), key=lambda n: int(n.split(".")[0])) == [f"{i}.png" for i in range(5)]
