@@ -226,6 +226,30 @@ def extra_configs(device):
     res["VQVAE_top_16_views"] = {"encode_codes_ms": round(timings["encode_codes"] * 1e3, 3),
                                  "decode_code_ms": round(timings["decode_code"] * 1e3, 3),
                                  "note": "next-row component (SURVEY 8f.1), outside the headline metric"}
+    # the reference's own way of rendering a trajectory -- forward_scene, frames chained on one GPU
+    # (every frame rendered from the previous one over the accumulated cloud, VQ-VAE in the loop, no sharding possible)
+    import types
+    from pixelsynth_amd.z_buffermodel import ZbufferModelPts
+    o = vars(make_opts()).copy()
+    o.update(model_setting="gen_scene", directions=["R", "L"], num_split=4, num_samples=1, sequential_outpainting=False,
+             vqvae=True)
+    ms = ZbufferModelPts(types.SimpleNamespace(**o)).eval()
+    ms.outpaint2.load_state_dict(m1.outpaint2.state_dict())
+    ms.vqvae.load_state_dict(vq.state_dict())
+    ms = ms.to(device)
+    batch = {"images": [d1["img"]], "cameras": [{"K": d1["K"], "Kinv": d1["Kinv"], "P": d1["P"], "Pinv": d1["Pinv"]}],
+             "depth_fn": syn.depth_from_image}
+    ms(batch)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    _, outs = ms(batch)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    nfr = sum(1 for k in outs if k.startswith("PredImg_"))
+    ms.outpaint2.engine(32, 32, 1).check()
+    res["chained_scene_R_L_split4"] = {"frames": nfr, "frames_per_s": round(nfr / dt, 3), "ms_per_frame": round(dt / nfr * 1e3, 3),
+                                       "note": "forward_scene (z_buffermodel.py:420-584) on one GPU: a state chain, "
+                                               "replicas only across GPUs (SURVEY 8e)"}
     return res
 
 
