@@ -226,6 +226,30 @@ def extra_configs(device):
     res["VQVAE_top_16_views"] = {"encode_codes_ms": round(timings["encode_codes"] * 1e3, 3),
                                  "decode_code_ms": round(timings["decode_code"] * 1e3, 3),
                                  "note": "next-row component (SURVEY 8f.1), outside the headline metric"}
+    # SURVEY 8f row 2, also outside the metric: depth Unet on the 16 source images and refinement decoder on the 16 blended
+    # views (torch / MIOpen convolutions, fused noise-affine normalisation), synthetic weights
+    from pixelsynth_amd.networks import Unet, get_decoder
+    nets = {}
+    for name, mod in (("unet", Unet(channels_in=3, channels_out=1, opt=syn.network_opts())), ("decoder", get_decoder(syn.network_opts()))):
+        shapes = {k: tuple(v.shape) for k, v in mod.state_dict().items()}
+        mod.load_state_dict({k: torch.from_numpy(v) for k, v in syn.fill_state_dict(shapes, 5).items()})
+        nets[name] = mod.to(device).eval()
+    bg16 = torch.zeros(16, 256, 256, dtype=torch.bool, device=device)
+    bg16[:, :, 160:] = True
+    with torch.no_grad():
+        for name, fn in (("depth_unet", lambda: nets["unet"](d16["img"])), ("refine_decoder", lambda: nets["decoder"](gen16, bg16))):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n = 10
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            timings[name] = (time.perf_counter() - t0) / n
+    res["depth_and_refinement_16_views"] = {"depth_unet_ms": round(timings["depth_unet"] * 1e3, 3),
+                                            "refine_decoder_ms": round(timings["refine_decoder"] * 1e3, 3),
+                                            "note": "next-row components (SURVEY 8f.2), outside the headline metric"}
     # the reference's own way of rendering a trajectory -- forward_scene, frames chained on one GPU
     # (every frame rendered from the previous one over the accumulated cloud, VQ-VAE in the loop, no sharding possible)
     import types

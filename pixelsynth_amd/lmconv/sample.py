@@ -107,7 +107,7 @@ def sample(model, generation_idx, mask_init, mask_undilated, mask_dilated, batch
             raise ValueError(f"unknown AR mode {mode!r}")
         data = F.one_hot(c32.view(B, H, W).to(torch.int64), num_classes).permute(0, 3, 1, 2).to(torch.float32)
 
-    loss_score = nn.CrossEntropyLoss()(data, batch_to_complete_full.to(dev))
+    loss_score = nn.CrossEntropyLoss()(data, batch_to_complete_full.to(dev).to(torch.int64))
     # revert seeding for dataloader (sample.py:70-71)
     torch.manual_seed(args.dataloader_seed)
     np.random.seed(args.dataloader_seed)

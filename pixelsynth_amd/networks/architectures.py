@@ -1,0 +1,239 @@
+"""The dense networks either side of the hot path: the depth regressor `Unet`
+(models/networks/architectures.py:174-279) and the refinement `ResNetDecoder` (:126-167) with its blocks
+(models/layers/blocks.py:34-73) and noise-conditioned normalisation (models/layers/normalization.py:21-47, :97-200).
+
+Same constructor arguments, attribute / parameter names and shapes as the reference, so its checkpoints load with
+`load_state_dict(strict=True)`; the bodies are written for inference on one MI355X:
+
+  * the convolutions run through torch (MIOpen) for now -- "Torch/MIOpen first" in SURVEY 8f -- in NHWC
+    (channels_last) on the GPU: measured on 16 views, 3.3 ms instead of 12.6 ms for the Unet and 27 ms instead of
+    31 ms for the decoder (MIOpen's NHWC implicit-GEMM / CK kernels, no layout shuffles between layers); inputs are
+    converted on entry, results handed back NCHW-contiguous because the HIP kernels downstream take raw NCHW pointers;
+  * `LinearNoiseLayer` + stored-statistics batch norm + ReLU is ONE per-(sample, channel) affine and a clamp
+    (`_noise_affine`), not four elementwise passes;
+  * `ResNetDecoder.forward(..., noise=)` takes the noise draws explicitly (a list of (B,20) tensors, two per block) so
+    a run is reproducible and comparable with the reference; without it the draws come from torch.randn as there.
+
+Training-mode batch statistics are supported for the plain BatchNorm2d layers (torch's own); the noise-conditioned
+layers implement the stored-statistics (eval) form only -- this repository does not train.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+NOISE_SZ = 20
+
+# decoder tables of get_resnet_arch (models/networks/configs.py): first width, then (width, resample) per block.
+_DEC_WIDTHS = lambda g: [g, 2 * g, 4 * g, 4 * g, 2 * g, 2 * g, 2 * g, 3]
+_DEC_RESAMPLE = [None, "Down", "Down", None, "Up", "Up", None, None]
+_DEC_FIRST = {"256W8UpDown": lambda c: 128, "256W8UpDown64": lambda c: 64, "256W8UpDownDV": lambda c: 64,
+              "256W8UpDownRGB": lambda c: 3, "256W8UpDown3": lambda c: c, "256W8UpDown3SuperRes": lambda c: c}
+
+
+def _spectral(opt):
+    return "spectral" in opt.norm_G
+
+
+def _conv(opt, cin, cout, k, stride, pad):
+    conv = nn.Conv2d(cin, cout, kernel_size=k, stride=stride, padding=pad)
+    return nn.utils.spectral_norm(conv) if _spectral(opt) else conv
+
+
+def _norm_layer(opt):
+    kind = opt.norm_G.split(":")[1]
+    if kind in ("batch", "spectral_batch"):
+        return nn.BatchNorm2d
+    if kind == "spectral_instance":
+        return nn.InstanceNorm2d
+    if kind == "spectral_batchstanding":
+        return BatchNorm_StandingStats
+    raise ValueError("unknown norm_G %r" % opt.norm_G)
+
+
+class bn(nn.Module):
+    """Stored statistics of the BigGAN-style batch norm (normalization.py:117-166); buffers only."""
+
+    def __init__(self, num_channels, eps=1e-5, momentum=0.1):
+        super().__init__()
+        self.eps, self.momentum, self.accumulate_standing = eps, momentum, False
+        self.register_buffer("stored_mean", torch.zeros(num_channels))
+        self.register_buffer("stored_var", torch.ones(num_channels))
+        self.register_buffer("accumulation_counter", torch.zeros(1))
+
+    def scale_shift(self, gain, bias):
+        """y = x * scale - shift with gain/bias (B or 1, C, 1, 1) folded in (fused_bn, normalization.py:170-184)."""
+        if self.training:
+            raise RuntimeError("noise-conditioned batch norm: only the stored-statistics (eval) form is built here")
+        mean, var = self.stored_mean.view(1, -1, 1, 1), self.stored_var.view(1, -1, 1, 1)
+        if self.accumulate_standing:
+            mean, var = mean / self.accumulation_counter, var / self.accumulation_counter
+        scale = torch.rsqrt(var + self.eps) * gain
+        return scale, mean * scale - bias
+
+    def forward(self, x, gain, bias):
+        scale, shift = self.scale_shift(gain, bias)
+        return x * scale - shift
+
+
+class BatchNorm_StandingStats(nn.Module):
+    def __init__(self, output_size, eps=1e-5, momentum=0.1):
+        super().__init__()
+        self.output_size, self.eps, self.momentum = output_size, eps, momentum
+        self.gain = nn.Parameter(torch.ones(output_size))
+        self.bias = nn.Parameter(torch.zeros(output_size))
+        self.bn = bn(output_size, eps, momentum)
+
+    def forward(self, x, y=None):
+        return self.bn(x, self.gain.view(1, -1, 1, 1), self.bias.view(1, -1, 1, 1))
+
+
+class LinearNoiseLayer(nn.Module):
+    """Gain and bias of a batch norm predicted from a noise vector (normalization.py:21-47)."""
+
+    def __init__(self, opt, noise_sz=NOISE_SZ, output_sz=32):
+        super().__init__()
+        self.noise_sz = noise_sz
+        lin = lambda: nn.Linear(noise_sz, output_sz, bias=False)
+        self.gain = nn.utils.spectral_norm(lin()) if _spectral(opt) else lin()
+        self.bias = nn.utils.spectral_norm(lin()) if _spectral(opt) else lin()
+        self.bn = bn(output_sz)
+
+    def affine(self, x, noise=None):
+        if noise is None:
+            noise = torch.randn(x.size(0), self.noise_sz).to(x.device)
+        B = noise.size(0)
+        return self.bn.scale_shift((1 + self.gain(noise)).view(B, -1, 1, 1), self.bias(noise).view(B, -1, 1, 1))
+
+    def forward(self, x, noise=None):
+        scale, shift = self.affine(x, noise)
+        return x * scale - shift
+
+
+class _Slots(nn.Module):
+    """Sub-modules registered under the indices the reference's nn.Sequential gave them (checkpoint key names)."""
+
+    def __init__(self, **at):
+        super().__init__()
+        for idx, mod in at.items():
+            self.add_module(idx.lstrip("_"), mod)
+
+    def __getitem__(self, idx):
+        return self._modules[str(idx)]
+
+
+def _nhwc(module, x):
+    """On the GPU: weights (once) and input to channels_last."""
+    if not x.is_cuda:
+        return x
+    if not getattr(module, "_nhwc_ready", False):
+        module.to(memory_format=torch.channels_last)
+        module._nhwc_ready = True
+    return x.contiguous(memory_format=torch.channels_last)
+
+
+def _resample(kind, x):
+    if kind == "Up":
+        return F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)
+    if kind:            # "Down" or True
+        return F.avg_pool2d(x, kernel_size=3, stride=2, padding=1)
+    return x
+
+
+class ResNet_Block(nn.Module):
+    """(norm, relu, 3x3) x 2 (+ resample) on one branch, 1x1 (+ resample) or identity on the other (blocks.py:34-73)."""
+
+    def __init__(self, in_c, in_o, opt, downsample=None):
+        super().__init__()
+        self.resample = downsample
+        self.ch_a = _Slots(_0=LinearNoiseLayer(opt, output_sz=in_c), _2=_conv(opt, in_c, in_o, 3, 1, 1),
+                           _3=LinearNoiseLayer(opt, output_sz=in_o), _5=_conv(opt, in_o, in_o, 3, 1, 1))
+        self.projected = bool(downsample) or in_c != in_o
+        if self.projected:
+            self.ch_b = _Slots(_0=_conv(opt, in_c, in_o, 1, 1, 0))
+
+    @staticmethod
+    def _noise_affine(layer, x, noise):
+        scale, shift = layer.affine(x, noise)
+        return torch.clamp_min(torch.addcmul(-shift, x, scale), 0)     # norm + ReLU in one pass
+
+    def forward(self, x, noise=(None, None)):
+        a = self.ch_a[2](self._noise_affine(self.ch_a[0], x, noise[0]))
+        a = self.ch_a[5](self._noise_affine(self.ch_a[3], a, noise[1]))
+        b = self.ch_b[0](x) if self.projected else x
+        return _resample(self.resample, a) + (_resample(self.resample, b) if self.projected else b)
+
+
+class ResNetDecoder(nn.Module):
+    """The refinement network (architectures.py:126-167): eight blocks, tanh, optional residual around them."""
+
+    def __init__(self, opt, channels_in=64, channels_out=3, use_tanh=True):
+        super().__init__()
+        self.opt = opt
+        setup = opt.refine_model_type.split("_")[1]
+        if setup not in _DEC_FIRST:
+            raise ValueError("refine_model_type %r: decoder table not built" % opt.refine_model_type)
+        widths = [_DEC_FIRST[setup](channels_in)] + _DEC_WIDTHS(opt.ngf)
+        self.eblocks = nn.ModuleList([ResNet_Block(widths[i], widths[i + 1], opt, _DEC_RESAMPLE[i]) for i in range(8)])
+        if use_tanh:
+            self.norm = nn.Tanh()
+
+    def n_noise(self):
+        return 2 * len(self.eblocks)
+
+    def forward(self, x, background_mask=None, noise=None):
+        h = x if background_mask is None else torch.cat((x, (~background_mask).unsqueeze(1).float()), 1)
+        h = _nhwc(self, h)
+        for i, blk in enumerate(self.eblocks):
+            h = blk(h, (None, None) if noise is None else (noise[2 * i], noise[2 * i + 1]))
+        if getattr(self.opt, "predict_residual", False):
+            if background_mask is not None and getattr(self.opt, "normalize_before_residual", False):
+                return (self.norm(h) + x).contiguous()
+            return self.norm(h + x).contiguous()
+        return self.norm(h).contiguous()
+
+
+class Unet(nn.Module):
+    """Depth regressor (architectures.py:174-279): 8 stride-2 4x4 convolutions down to 1x1, 8 x (bilinear x2, 3x3)
+    back up with skip concatenations; leaky ReLU on the way down, ReLU on the way up, no norm on conv1 / conv8 / dconv8."""
+
+    _ENC_NORM = [None, "batch_norm2_0", "batch_norm4_0", "batch_norm8_0", "batch_norm8_1", "batch_norm8_2", "batch_norm8_3", None]
+    _DEC_NORM = ["batch_norm8_4", "batch_norm8_5", "batch_norm8_6", "batch_norm8_7", "batch_norm4_1", "batch_norm2_1", "batch_norm", None]
+
+    def __init__(self, num_filters=32, channels_in=3, channels_out=3, use_tanh=False, use_3D=False, opt=None):
+        super().__init__()
+        if use_3D:
+            raise NotImplementedError("3-D Unet is not part of the novel-view path")
+        f = num_filters
+        enc = [channels_in, f, 2 * f, 4 * f, 8 * f, 8 * f, 8 * f, 8 * f, 8 * f]
+        dec_out = [8 * f, 8 * f, 8 * f, 8 * f, 4 * f, 2 * f, f, channels_out]
+        norm = _norm_layer(opt)
+        for i in range(8):
+            setattr(self, f"conv{i + 1}", _conv(opt, enc[i], enc[i + 1], 4, 2, 1))
+            if self._ENC_NORM[i]:
+                setattr(self, self._ENC_NORM[i], norm(enc[i + 1]))
+        for i in range(8):
+            cin = enc[8] if i == 0 else dec_out[i - 1] + enc[8 - i]          # previous output ++ the mirrored encoder level
+            setattr(self, f"dconv{i + 1}", _conv(opt, cin, dec_out[i], 3, 1, 1))
+            if self._DEC_NORM[i]:
+                setattr(self, self._DEC_NORM[i], norm(dec_out[i]))
+
+    def forward(self, input):
+        skips, h = [], _nhwc(self, input)
+        for i in range(8):
+            h = getattr(self, f"conv{i + 1}")(h if i == 0 else F.leaky_relu(h, 0.2))
+            if self._ENC_NORM[i]:
+                h = getattr(self, self._ENC_NORM[i])(h)
+            skips.append(h)
+        for i in range(8):
+            h = F.interpolate(F.relu(h), scale_factor=2, mode="bilinear", align_corners=False)
+            h = getattr(self, f"dconv{i + 1}")(h)
+            if self._DEC_NORM[i]:
+                h = torch.cat((getattr(self, self._DEC_NORM[i])(h), skips[6 - i]), 1)
+        return h.contiguous()
+
+
+def get_decoder(opt):
+    """models/networks/utilities.py:26-36 for the resnet decoders (the mask channel is there unless no_outpainting)."""
+    if "resnet" not in opt.refine_model_type:
+        raise ValueError("refine_model_type %r: only the resnet decoders are built" % opt.refine_model_type)
+    return ResNetDecoder(opt, channels_in=3 + (0 if getattr(opt, "no_outpainting", False) else 1), channels_out=3)

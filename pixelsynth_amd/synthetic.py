@@ -253,3 +253,60 @@ def codebook_from_latents(lat, seed=0, n_embed=512, jitter=0.05):
     pick = flat[rs.randint(0, flat.shape[0], size=n_embed)]
     spread = float((flat - flat.mean(0, keepdims=True)).std())
     return np.ascontiguousarray((pick + rs.randn(n_embed, D) * jitter * spread).T.astype(np.float32))
+
+
+# ------------------------------------------------------------------------------------------------
+# Dense networks of SURVEY 8f row 2 (depth Unet, refinement decoder): synthetic weights for ANY module, by key name.
+# ------------------------------------------------------------------------------------------------
+def fill_state_dict(shapes, seed=0):
+    """{key: shape} (a module's state_dict layout) -> {key: array}: deterministic per (seed, key), independent of key
+    order, so the reference's module and its mirror get identical values from their own key lists.
+    Weights ~ U(+-1/sqrt(fan_in)); spectral-norm vectors u, v = the leading singular pair of weight_orig (three power
+    iterations), so the stored sigma is what training would have left there; normalisation statistics away from 0 / 1."""
+    import zlib
+    out = {}
+    rs_of = lambda key: np.random.RandomState((zlib.crc32(key.encode()) ^ (seed * 2654435761)) & 0x7FFFFFFF)
+    for key, shape in shapes.items():
+        rs, leaf = rs_of(key), key.rsplit(".", 1)[-1]
+        shape = tuple(shape)
+        if leaf in ("weight_orig", "weight") and len(shape) >= 2:
+            fan_in = int(np.prod(shape[1:]))
+            out[key] = ((rs.rand(*shape) * 2 - 1) / math.sqrt(fan_in)).astype(np.float32)
+        elif leaf in ("weight", "gain") and len(shape) == 1:
+            out[key] = (0.8 + 0.4 * rs.rand(*shape)).astype(np.float32)
+        elif leaf == "bias":
+            out[key] = ((rs.rand(*shape) * 2 - 1) * 0.1).astype(np.float32)
+        elif leaf in ("running_mean", "stored_mean"):
+            out[key] = (rs.randn(*shape) * 0.1).astype(np.float32)
+        elif leaf in ("running_var", "stored_var"):
+            out[key] = (0.5 + rs.rand(*shape)).astype(np.float32)
+        elif leaf == "num_batches_tracked":
+            out[key] = np.zeros(shape, np.int64)
+        elif leaf == "accumulation_counter":
+            out[key] = np.zeros(shape, np.float32)
+        elif leaf in ("weight_u", "weight_v"):
+            continue
+        else:
+            raise KeyError("fill_state_dict: no rule for %r" % key)
+    for key in shapes:
+        if key.endswith(".weight_u"):
+            base = key[:-len("weight_u")]
+            W = out[base + "weight_orig"].reshape(shapes[base + "weight_orig"][0], -1).astype(np.float64)
+            u = rs_of(key).randn(W.shape[0])
+            for _ in range(3):
+                v = W.T @ u
+                v /= np.linalg.norm(v) + 1e-12
+                u = W @ v
+                u /= np.linalg.norm(u) + 1e-12
+            out[key], out[base + "weight_v"] = u.astype(np.float32), v.astype(np.float32)
+    return out
+
+
+def network_opts(**kw):
+    """The generator options PixelSynth trains with (scripts/train_dpr_realestate.sh); an argparse.Namespace, which
+    the reference tests with `"name" in opt`."""
+    import argparse
+    o = dict(norm_G="sync:spectral_batch", refine_model_type="resnet_256W8UpDown3", ngf=64, predict_residual=True,
+             normalize_before_residual=False)
+    o.update(kw)
+    return argparse.Namespace(**o)

@@ -4,10 +4,12 @@ models/z_buffermodel.py:ZbufferModelPts for the rows of SURVEY.md 8(a): target p
 (get_masks_for_batch :641-701), autoregressive outpainting (get_best_sample -> sample()) and the
 foreground/background blend (get_combined :703-708).
 
-The dense networks the reference runs around that path (depth Unet, VQ-VAE-2 encode/decode, refinement
-decoder, discriminator / Places365 ranking) are SURVEY 8(f) "next" rows, not built here: they are
-injected as callables (`pts_regressor`, `vqvae`, `projector`); when absent, the batch must carry the
-tensors they would have produced (`depths`, `codes`) -- that is how the synthetic benchmark drives it.
+The dense networks the reference runs around that path are SURVEY 8(f) "next" rows: the VQ-VAE-2 top level
+(pixelsynth_amd/vqvae2), the depth Unet and the refinement decoder (pixelsynth_amd/networks) are built when the
+options name them (`vqvae`, `norm_G` + `refine_model_type`) or can be injected (`pts_regressor`, `vqvae`,
+`projector`); the discriminator / Places365 classifier of the sample ranking are injected only.  When a network is
+absent the batch must carry the tensors it would have produced (`depths`, `codes`) -- that is how the synthetic
+benchmark drives the hot path on its own.
 """
 import math
 import types
@@ -94,6 +96,13 @@ class ZbufferModelPts(nn.Module):
     def __init__(self, opt, pts_regressor=None, vqvae=None, projector=None, encoder=None, classifier=None):
         super().__init__()
         self.opt = opt
+        if pts_regressor is None and hasattr(opt, "norm_G"):  # z_buffermodel.py:41-44
+            from .networks import Unet
+            extra = {"num_filters": opt.Unet_num_filters} if hasattr(opt, "Unet_num_filters") else {}
+            pts_regressor = Unet(channels_in=3, channels_out=1, opt=opt, **extra)
+        if projector is None and "resnet" in getattr(opt, "refine_model_type", "") and hasattr(opt, "norm_G"):  # :90
+            from .networks import get_decoder
+            projector = get_decoder(opt)
         self.pts_regressor = pts_regressor
         self.encoder = encoder        # feature encoder when use_rgb_features is off (injected)
         self.classifier = classifier  # Places365 ResNet-18 of get_best_sample (injected)
@@ -236,9 +245,8 @@ class ZbufferModelPts(nn.Module):
         outputs = {"InputImg": input_img, "PredDepthImg": regressed_pts / 5 - 1,
                    "ForegroundImg": (~background_mask).repeat(input_img.shape[0], 1, 1, 1).float(),
                    "FeaturesImg": gen_fs, "PredCodes": codes}
-        if self.vqvae is not None and self.projector is not None:
-            ar_sample = self.vqvae.decode_code(codes.to(torch.int64))
-            outputs["PredImg"] = self.projector(self.get_combined(gen_fs, ar_sample, background_mask), background_mask)
+        if self.vqvae is not None:  # :250-252 (without a refinement net the blend itself is the prediction)
+            outputs["PredImg"] = self._decode_candidate(gen_fs, background_mask, codes.to(torch.int64))
         return None, outputs
 
     # ---------------------------------------------------------------- sample ranking (8f.3, host logic)

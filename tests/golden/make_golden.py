@@ -38,6 +38,7 @@ def _import_reference():
     sys.modules["models.lmconv.get_custom_order"] = gco
     for name in ["pytorch3d", "pytorch3d.structures", "pytorch3d.renderer", "pytorch3d.renderer.points"]:
         sys.modules[name] = types.ModuleType(name)
+    sys.modules["torchvision"] = types.ModuleType("torchvision")     # architectures.py only touches it inside VGG19
     sys.modules["pytorch3d.structures"].Pointclouds = object
     sys.modules["pytorch3d.renderer"].compositing = object
     sys.modules["pytorch3d.renderer.points"].rasterize_points = object
@@ -328,10 +329,48 @@ def gen_vqvae(R):
     print("vqvae: unique codes", int(id_t.unique().numel()), "min gap", float((two[:, 1] - two[:, 0]).min()))
 
 
+def gen_networks(R):
+    """Depth Unet and refinement ResNetDecoder: the reference's own modules
+    (models/networks/architectures.py:126-279, built by models/networks/utilities.py:get_decoder) with the options
+    PixelSynth trains with, in eval mode, filled by pixelsynth_amd.synthetic.fill_state_dict from their own key lists.
+    The decoder's noise draws (torch.randn inside LinearNoiseLayer, normalization.py:39) are replaced for the run by a
+    recorded sequence.  Stored: outputs on a 2x2 / 4x4 subsampled grid, the noise, key/shape lists."""
+    from models.networks.architectures import Unet
+    from models.networks.utilities import get_decoder
+    opt = syn.network_opts()
+    unet = Unet(channels_in=3, channels_out=1, opt=opt).eval()
+    dec = get_decoder(opt).eval()
+    out = {}
+    for name, mod in (("unet", unet), ("decoder", dec)):
+        shapes = {k: tuple(v.shape) for k, v in mod.state_dict().items()}
+        mod.load_state_dict({k: t(v) for k, v in syn.fill_state_dict(shapes, 5).items()}, strict=True)
+        out[name + "_keys"] = np.array([f"{k}:{','.join(map(str, v))}" for k, v in shapes.items()])
+    img = t(syn.image(41, 1, 3, 256))
+    x = t(syn.image(42, 1, 3, 256))
+    bgm = torch.from_numpy(syn.background_masks(256)["ragged"])[None]
+    noise = np.random.RandomState(43).randn(16, 1, 20).astype(np.float32)
+    draws = iter(noise)
+    real_randn = torch.randn
+    torch.randn = lambda *a, **k: t(next(draws))
+    try:
+        with torch.no_grad():
+            depth = unet(img)
+            refined = dec(x, bgm)
+            opt.predict_residual = False
+            draws = iter(noise)
+            plain = dec(x, bgm)
+    finally:
+        torch.randn = real_randn
+    np.savez_compressed(os.path.join(HERE, "networks.npz"), unet_out_sub=depth.numpy()[:, :, ::2, ::2],
+                        decoder_out_sub=refined.numpy()[:, :, ::4, ::4], decoder_plain_sub=plain.numpy()[:, :, ::4, ::4],
+                        noise=noise, image_seeds=np.array([41, 42]), weight_seed=np.array(5), **out)
+    print("networks: unet out", float(depth.mean()), float(depth.std()), "decoder out", float(refined.mean()), float(refined.std()))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     R = _import_reference()
-    which = sys.argv[1:] or ["projection", "orders", "layers", "blocks", "network", "ar", "vqvae"]
+    which = sys.argv[1:] or ["projection", "orders", "layers", "blocks", "network", "ar", "vqvae", "networks"]
     if "projection" in which:
         gen_projection(R)
     if "orders" in which:
@@ -346,3 +385,5 @@ if __name__ == "__main__":
         gen_ar_trace(R)
     if "vqvae" in which:
         gen_vqvae(R)
+    if "networks" in which:
+        gen_networks(R)

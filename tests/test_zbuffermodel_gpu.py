@@ -306,3 +306,26 @@ def test_driver_chained_scene_writes_scene_and_video_layout(tmp_path):
     assert sorted(os.listdir(tmp_path / "scene")) == ["output_image_R_0001.png", "output_image_R_0002.png", "output_image_U_0001.png"]
     # R: 1, then back 1, 0; U (num_split 1): back 0  -> 1 + 3 + 1 frames
     assert sorted(os.listdir(tmp_path / "video"), key=lambda n: int(n.split(".")[0])) == [f"{i}.png" for i in range(5)]
+
+
+def test_forward_image_with_every_network_in_the_loop():
+    """SURVEY 8f rows 1-2 around the path: depth Unet -> reproject/splat -> VQ-VAE codes -> AR -> decode -> blend ->
+    refinement decoder, all on the device; the output dict is the reference's (z_buffermodel.py:385-417)."""
+    o = vars(syn.network_opts())
+    m = make_model(vqvae=True, **o)
+    for mod, seed in ((m.pts_regressor, 5), (m.projector, 5)):
+        shapes = {k: tuple(v.shape) for k, v in mod.state_dict().items()}
+        mod.load_state_dict({k: torch.from_numpy(v) for k, v in syn.fill_state_dict(shapes, seed).items()}, strict=True)
+    m.vqvae.load_state_dict({k: torch.from_numpy(v) for k, v in syn.vqvae_state_dict(0).items()}, strict=True)
+    m = m.to(DEV).eval()
+    cam = {k: torch.from_numpy(v) for k, v in syn.demo_cameras(1).items()}
+    img = torch.from_numpy(syn.image(4, 1, 3, 256))
+    torch.manual_seed(3)
+    _, out = m.forward_image({"images": [img], "cameras": [cam]})
+    m.outpaint2.engine(32, 32, 1).check()
+    depth = torch.sigmoid(m.pts_regressor(img.to(DEV))) * 99.0 + 1.0
+    assert torch.allclose(out["PredDepthImg"], depth / 5 - 1, atol=1e-5)
+    assert tuple(out["PredImg"].shape) == (1, 3, 256, 256) and torch.isfinite(out["PredImg"]).all()
+    assert float(out["PredImg"].abs().max()) <= 1.0          # tanh
+    bg = out["ForegroundImg"][0, 0] == 0
+    assert 0.2 < float(bg.float().mean()) < 0.9
