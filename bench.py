@@ -69,66 +69,94 @@ def make_inputs(rank, V, device, smooth=True):
     return dev, host
 
 
-def run_step(model, d, world):
-    out = model.outpaint_views(d["img"], d["depth"], d["K"], d["Kinv"], d["P"], d["Pinv"], d["RT2"], d["RT2inv"],
-                               d["codes"], temperature=0.7, uniforms=d["uniforms"])
-    if world > 1:  # finished frames of every rank: the path's only collective, RCCL all_gather over xGMI
+def front(model, d):
+    """First half of a step: reproject + splat, background masks to the host, orders / masks / wavefront schedule built
+    and uploaded (ends synchronised with the stream it ran on)."""
+    return model.plan_views(d["img"], d["depth"], d["K"], d["Kinv"], d["P"], d["Pinv"], d["RT2"], d["RT2inv"])
+
+
+def back(model, d, planned, world):
+    """Second half: the AR run (asynchronous), then the path's only collective."""
+    out = model.outpaint_planned(planned, d["codes"], temperature=0.7, uniforms=d["uniforms"])
+    if world > 1:  # finished frames of every rank: RCCL all_gather over xGMI
         out["all_frames_u8"] = D.gather_frames(D.to_image_u8(out["gen_fs"]))
         out["all_codes"] = D.gather_frames(out["codes"].contiguous())
     return out
 
 
+def run_step(model, d, world):
+    return back(model, d, front(model, d), world)
+
+
+def run_steps(model, d, world, n, side):
+    """n steps, software-pipelined: while the device runs the AR loop of step i (main stream), the host half of step
+    i + 1 -- splat on the side stream, masks back, planning, uploads -- is already under way.  Same work per step, the
+    steps are independent; results identical to n x run_step."""
+    main = torch.cuda.current_stream()
+    planned, out = None, None
+    for i in range(n):
+        if planned is None:
+            planned = front(model, d)
+        out = back(model, d, planned, world)
+        planned = None
+        if i + 1 < n:
+            with torch.cuda.stream(side):
+                planned = front(model, d)
+            for v in (planned["gen_fs"], planned["background_mask"], planned["plan"].order_loc, planned["plan"].region,
+                      planned["plan"].mask_init, planned["plan"].mask_undilated, planned["plan"].mask_dilated,
+                      planned["plan"].waves[0]):
+                v.record_stream(main)
+            main.wait_stream(side)
+    return out
+
+
 def measure_roofline(model, d, out, V):
-    """Per-launch duration of the kernel of an AR order position (k_column), measured with HIP events on the stream
-    it is launched on (ps_pixelcnn_time_column_step), against its dense algorithmic fp32 work: the 33-stage
-    centre-tap chain of every frame (fp32 FMA chains on the vector ALU, one CU per frame) plus the neighbour-tap
-    partial sums of all 32 masked convs (fp32 MFMA, the rest of the chip, masked taps skipped).  Both share the
-    fp32 dense peak of gfx950 (157.3 TFLOP/s: packed-FMA VALU rate = fp32 MFMA rate).  The launch is bounded by the
-    LATENCY of the sequential chain, not by throughput -- DESIGN.md section 4 has the per-stage cycle budget."""
+    """Average launch of k_column -- the dominant kernel: one launch per WAVEFRONT of independent columns (one column =
+    one order position of one frame) -- over a whole AR run of this step's views, measured with HIP events on the stream
+    the launches go to (ps_pixelcnn_time_ar_run_waves), against the dense algorithmic fp32 work of its columns:
+    11.163 MFLOP per column = the 33-stage centre-tap chain (fp32 FMA chains on the vector ALU, one CU per column)
+    plus the neighbour-tap partial sums of all 32 masked convs (fp32 MFMA on the other XCDs, masked taps skipped).
+    Both share the fp32 dense peak of gfx950 (157.3 TFLOP/s: packed-FMA VALU rate = fp32 MFMA rate).  A launch is
+    bounded by the LATENCY of the 33 dependent stages, not by throughput -- DESIGN.md section 4 has the cycle budget."""
     plan = out["plan"]
     eng = model.outpaint2.engine(32, 32, V)
-    c32 = out["codes"].reshape(V, 1024).to(torch.int32).contiguous()
-    step = min(1023, plan.first_step + (1024 - plan.first_step) // 2)
-    launches = (ctypes.c_int * 2)()
-    total_ms = (ctypes.c_float * 2)()
-    flops = (ctypes.c_double * 2)()
-    wbytes = (ctypes.c_double * 2)()
-    reps = 50
-    rc = _lib.lib().ps_pixelcnn_time_column_step(
-        eng.handle, _lib.ptr(c32), _lib.ptr(plan.order_loc), _lib.ptr(plan.mask_init), _lib.ptr(plan.mask_undilated),
-        _lib.ptr(plan.mask_dilated), V, step, reps, ctypes.cast(launches, ctypes.c_void_p),
-        ctypes.cast(total_ms, ctypes.c_void_p), ctypes.cast(flops, ctypes.c_void_p),
-        ctypes.cast(wbytes, ctypes.c_void_p), _lib.current_stream())
-    _lib.check(rc, "ps_pixelcnn_time_column_step")
-    us = total_ms[1] * 1e3 / max(1, launches[1])
-    chain_cus = V
-    fl = flops[0] + flops[1]
+    cols, wave_start = plan.waves
+    ncols = int(cols.shape[0])
+    launches, total_ms, fpc = ctypes.c_int(0), ctypes.c_float(0.0), ctypes.c_double(0.0)
+    us_list = []
+    for _ in range(3):
+        c32 = d["codes"].reshape(V, 1024).to(torch.int32).contiguous().clone()
+        rc = _lib.lib().ps_pixelcnn_time_ar_run_waves(
+            eng.handle, _lib.ptr(c32), _lib.ptr(plan.order_loc), _lib.ptr(plan.region), _lib.ptr(plan.mask_init),
+            _lib.ptr(plan.mask_undilated), _lib.ptr(plan.mask_dilated), _lib.ptr(d["uniforms"]), 0.7, V, plan.first_step,
+            _lib.ptr(cols), _lib.ptr(wave_start), len(wave_start) - 1, ctypes.cast(ctypes.byref(launches), ctypes.c_void_p),
+            ctypes.cast(ctypes.byref(total_ms), ctypes.c_void_p), ctypes.cast(ctypes.byref(fpc), ctypes.c_void_p),
+            _lib.current_stream())
+        _lib.check(rc, "ps_pixelcnn_time_ar_run_waves")
+        us_list.append(total_ms.value * 1e3 / max(1, launches.value))
+    us = sorted(us_list)[1]
+    cols_per_launch = ncols / max(1, launches.value)
+    fl = fpc.value * cols_per_launch
     tf = fl / (us * 1e-6) / 1e12
-    tf_chain = flops[1] / (us * 1e-6) / 1e12
-    chain_stream = wbytes[1] * V / (us * 1e-6) / 1e9
     traffic, traffic_src = None, None
-    pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_e_k_column_pmc.json")
+    pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_f_k_column_pmc.json")
     if V == 16 and os.path.exists(pmc):  # PMC passes cannot run inside the timed bench: committed summary of the same workload
         with open(pmc) as fh:
             rec = json.load(fh)
         traffic, traffic_src = rec["traffic_bytes_per_launch"], rec["source"]
-    return {"bound": "mfma", "kernel": "k_column (one launch per AR order position: per-frame centre-tap chains + neighbour-tap slots of all 32 masked convs)",
+    return {"bound": "mfma", "kernel": "k_column (one launch per wavefront of independent AR columns: per-column centre-tap chains + "
+                                       "neighbour-tap slots of all 32 masked convs)",
             "achieved": round(tf, 4), "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
             "frac": round(tf / FP32_MFMA_PEAK_TF, 6), "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_flops_per_launch": round(fl), "avg_launch_us": round(us, 3),
-            "chain": {"what": "33 dependent stages per frame, one CU per frame (latency-bound)", "cus": chain_cus,
-                      "flops_per_launch": round(flops[1]), "tflops": round(tf_chain, 4),
-                      "frac_of_its_cus_peak": round(tf_chain / (FP32_MFMA_PEAK_TF * chain_cus / 256.0), 4),
-                      "weight_bytes_streamed_per_frame": round(wbytes[1]),
-                      "L2_to_CU_stream_GBs_all_frames": round(chain_stream, 1)},
-            "neighbour_taps": {"what": "dense flops of the 8 neighbour taps x 32 convs (masked taps are skipped at run time)",
-                               "dense_flops_per_launch": round(flops[0]), "weight_bytes": round(wbytes[0])},
-            "launches_per_ar_position": 1,
+            "flops_per_column": round(fpc.value), "columns_per_launch": round(cols_per_launch, 2),
+            "launches_per_ar_run": launches.value, "wavefronts": len(wave_start) - 1, "columns": ncols,
+            "walk_positions_without_wavefronts": 1024 - plan.first_step,
             "reference_definition": {
-                "what": "the same launch priced at what the reference schedules for it (SURVEY 8d): one whole-grid forward, "
-                        "11.43095 GFLOP, per frame and order position -- skipped redundant work is NOT utilisation, this is "
-                        "shown for comparison only",
-                "equivalent_tflops": round(11.43095e9 * V / (us * 1e-6) / 1e12, 1)}}
+                "what": "the same launch priced at what the reference schedules for its columns (SURVEY 8d): one whole-grid "
+                        "forward, 11.43095 GFLOP, per frame and order position -- skipped redundant work is NOT utilisation, "
+                        "this is shown for comparison only",
+                "equivalent_tflops": round(11.43095e9 * cols_per_launch / (us * 1e-6) / 1e12, 1)}}
 
 
 def extra_configs(device):
@@ -357,13 +385,11 @@ def main():
         D.barrier()
         torch.cuda.synchronize()
 
-    out = None
-    for _ in range(args.warmup):
-        out = run_step(model, d, world)
+    side = torch.cuda.Stream()
+    out = run_steps(model, d, world, args.warmup, side) if args.warmup > 0 else None
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = run_step(model, d, world)
+    out = run_steps(model, d, world, args.steps, side)
     barrier()
     dt = time.perf_counter() - t0
     model.outpaint2.engine(32, 32, V).check()  # (outside the timed region) no column launch gave up on an in-launch wait

@@ -114,6 +114,18 @@ int ps_kernel_masks_f32(const int32_t *order, int L, int nrows, int ncols, int k
 int ps_ar_plan(const uint8_t *bg, int B, int S, int G, int32_t *order_loc, uint8_t *region,
                float *mask_init, float *mask_undilated, float *mask_dilated, int32_t *first_step);
 
+/* Wavefront schedule of an AR run (host).  In the exact incremental form of sample() (models/lmconv/sample.py:24-66)
+ * the column of order position i of a frame reads only the finished columns of locations that are a 3x3 tap neighbour
+ * (dilation 1 or 2) of its own location AND earlier in the order -- the open taps of the three kernel masks
+ * (masking.py:287-370).  The columns of a frame therefore form a DAG; all columns of one DAG level ("wave") can be
+ * evaluated and sampled together, with results identical to the position-by-position walk.
+ *   order_loc (B,L) int32 as from ps_ar_plan, L = H*W; first_step as from ps_ar_plan (columns before it are done by
+ *   the whole-grid pass);
+ *   cols (B*(L-first_step), 2) int32 OUT: (frame, order position) of every walked column, wave by wave;
+ *   wave_start (L-first_step+1) int32 OUT: wave w = cols[wave_start[w] .. wave_start[w+1]);  *n_waves OUT. */
+int ps_ar_wavefronts(const int32_t *order_loc, int B, int H, int W, int first_step, int32_t *cols,
+                     int32_t *wave_start, int32_t *n_waves);
+
 /* ------------------------------------------------------------------------------------------
  * Locally masked convolution / PixelCNN (models/lmconv)
  * ---------------------------------------------------------------------------------------- */
@@ -174,12 +186,34 @@ int ps_pixelcnn_forward_f32(ps_pixelcnn *h, const int32_t *codes, const float *m
  *   first_step: order positions < first_step are not walked one by one: they must all be observed
  *   (not in the sample region) in every image, and are covered by one whole-grid pass
  *   (0 is always valid; the caller knows the orders, it built them on the host).
- * Asynchronous on the caller's stream (one launch per order position, enqueued eagerly). */
+ * Asynchronous on the caller's stream (one launch per order position, enqueued eagerly; see
+ * ps_pixelcnn_ar_run_waves for the schedule that needs far fewer dependent launches). */
 int ps_pixelcnn_ar_run(ps_pixelcnn *h, int32_t *codes, const int32_t *order,
                        const uint8_t *sample_region, const float *mask_init,
                        const float *mask_undilated, const float *mask_dilated, const int32_t *forced,
                        const float *uniforms, float temperature, int F, int first_step,
                        float *out_logits, void *stream);
+
+/* The same run, wavefront by wavefront: wave_cols (ncols,2) int32 on the DEVICE and wave_start (n_waves+1) int32 on
+ * the HOST are the schedule of ps_ar_wavefronts for these orders and this first_step (ncols = F * (L - first_step)).
+ * One launch per wave (waves of more than 128 columns are split) instead of one per order position -- 60-110
+ * dependent launches instead of 400-700 for PixelSynth's orders -- and bit-identical codes and logits. */
+int ps_pixelcnn_ar_run_waves(ps_pixelcnn *h, int32_t *codes, const int32_t *order,
+                             const uint8_t *sample_region, const float *mask_init,
+                             const float *mask_undilated, const float *mask_dilated,
+                             const int32_t *forced, const float *uniforms, float temperature, int F,
+                             int first_step, const int32_t *wave_cols, const int32_t *wave_start,
+                             int n_waves, float *out_logits, void *stream);
+
+/* bench.py aid: ps_pixelcnn_ar_run_waves (uniforms, no logits) with a HIP event pair around every column launch on
+ * the caller's stream; synchronises.  launches / total_ms: the k_column launches of the run and their summed
+ * duration; flops_per_column: dense flops of one column (11.163 MFLOP). */
+int ps_pixelcnn_time_ar_run_waves(ps_pixelcnn *h, int32_t *codes, const int32_t *order,
+                                  const uint8_t *sample_region, const float *mask_init,
+                                  const float *mask_undilated, const float *mask_dilated,
+                                  const float *uniforms, float temperature, int F, int first_step,
+                                  const int32_t *wave_cols, const int32_t *wave_start, int n_waves,
+                                  int *launches, float *total_ms, double *flops_per_column, void *stream);
 
 /* One order position of the loop above for callers that draw the sample themselves (the drop-in
  * sample() keeps torch.multinomial): evaluates the column of location order[f][step] for every

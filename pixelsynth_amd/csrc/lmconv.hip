@@ -435,24 +435,34 @@ __global__ __launch_bounds__(256) void k_logits_grid(ItemMap items, const float 
 //                    LDS, weights stream from L2 into registers.  Ends with the categorical draw and the context of
 //                    the next order position.
 // ==========================================================================================
-// Context of one order position of one frame: everything the launch needs that does not depend on this position's
-// own chain, gathered in one 160-byte record so that it costs one memory round trip.  Two records per frame, indexed
-// by the parity of the position: the launch of position p reads record p & 1 and prepares record (p + 1) & 1.
+// A COLUMN = one order position of one frame.  Everything a launch needs about a column that does not depend on the
+// run so far sits in one 160-byte record, so that it costs one memory round trip: frame, location, the mask values of
+// the location and where the u_init gather finds the codes of its (earlier) neighbours.  The records of a whole run
+// are written once (k_ctx_build), in schedule order: a launch works on a contiguous slice of them.
+//
+// Wavefronts.  Column (f, i) reads the finished columns of the locations that are BOTH a tap neighbour (3x3, dilation 1
+// or 2) of its location and earlier in the frame's order -- nothing else; in particular not the column of position
+// i - 1 unless that one happens to be such a neighbour.  So the columns of a frame form a DAG whose depth (60-110 for
+// PixelSynth's orders over 400-700 walked positions: the order sweeps a frontier, and along a frontier only every
+// other cell or so depends on the previous one) is the number of dependent launches, not the number of positions:
+// all columns of one DAG level (a "wavefront", host: ps_ar_wavefronts) go into ONE launch, each with its own chain
+// workgroup.  Every column is computed exactly as in the position-by-position walk (which is the special case of one
+// column per frame and launch), so the results are bit-identical.
 struct StepCtx {
     int q;            // location
-    int late_tap;     // type-A tap whose neighbour is the location of position p - 1 (its code is patched in last), -1
+    int f;            // frame
     float m[3][9];    // mask values of location q: [0] type A dil 1, [1] type B dil 1, [2] type B dil 2
-    int ncode[9];     // code of the type-A neighbour of every tap (u_init gather), UINIT_CLOSED where the tap is closed
-    int pad;
+    int nloc[9];      // location of the type-A neighbour of every tap (u_init gather), -1 where the tap is closed
+    int pad[2];
 };
+static_assert(sizeof(StepCtx) == 160, "one record = 160 bytes");
 
 struct CtxArgs {
-    StepCtx *ctx;     // [2][F]
+    StepCtx *ctx;     // [columns of the run]
     const int32_t *order;
     const float *mask[3];
     int F, L;
 };
-__device__ __forceinline__ StepCtx *ctx_of(const CtxArgs &a, int f, int step) { return a.ctx + (size_t)(step & 1) * a.F + f; }
 
 // neighbour code of type-A tap t of location q (-1: closed tap or outside the grid)
 __device__ __forceinline__ int ctx_nbr_loc(int q, int t, int H, int W)
@@ -461,19 +471,21 @@ __device__ __forceinline__ int ctx_nbr_loc(int q, int t, int H, int W)
     return (rr >= 0 && rr < H && cc >= 0 && cc < W) ? rr * W + cc : -1;
 }
 
-// complete record of position `step` from the current codes (first position of a run / single-step API)
-__global__ __launch_bounds__(32) void k_ctx_init(CtxArgs a, const int32_t *codes, int H, int W, int step)
+// records of `ncols` columns: cols = (frame, order position) pairs in schedule order, or null for the plain walk
+// (column k = frame k % F at position first + k / F)
+__global__ __launch_bounds__(32) void k_ctx_build(CtxArgs a, const int32_t *cols, int ncols, int first, int H, int W)
 {
-    const int f = blockIdx.x, t = threadIdx.x;
-    if (step >= a.L) return;
-    StepCtx *c = ctx_of(a, f, step);
-    const int q = a.order[(size_t)f * a.L + step];
+    const int k = blockIdx.x, t = threadIdx.x;
+    if (k >= ncols) return;
+    const int f = cols ? cols[2 * k] : k % a.F, i = cols ? cols[2 * k + 1] : first + k / a.F;
+    StepCtx *c = a.ctx + k;
+    const int q = a.order[(size_t)f * a.L + i];
     if (t < 27) c->m[t / 9][t % 9] = a.mask[t / 9][((size_t)f * 9 + t % 9) * a.L + q];
-    if (t == 27) { c->q = q; c->late_tap = -1; }
+    if (t == 27) { c->q = q; c->f = f; }
     if (t < 9) {
         const int loc = ctx_nbr_loc(q, t, H, W);
         const float mA = a.mask[0][((size_t)f * 9 + t) * a.L + q];
-        c->ncode[t] = (loc >= 0 && mA != 0.0f) ? codes[(size_t)f * a.L + loc] : UINIT_CLOSED;
+        c->nloc[t] = (loc >= 0 && mA != 0.0f) ? loc : -1;
     }
 }
 
@@ -508,15 +520,26 @@ struct __attribute__((aligned(16))) NbrWork {
     int Co_pad, in_ld, dil, mask_kind;
 };
 
+// Completion counters of the neighbour role: one per (stage, 16-column tile of the launch), each on its own 128-byte
+// line -- several thousand items finish per launch, and atomics on one line are served one after the other by the
+// memory side (counters packed in two lines made the neighbour role atomics-bound and every chain's polls queue behind
+// them: 128 columns 84 -> see DESIGN).  A chain only watches the counters of its own tile.
+constexpr int COL_CAP = 128;  // columns per launch: 4 chain XCDs x 32 CUs (larger wavefronts are split)
+constexpr int MAX_TILES = COL_CAP / 16, CNT_PAD = 32 /* dwords */;
+__device__ __host__ __forceinline__ size_t cnt_index(int stage, int tile) { return ((size_t)stage * MAX_TILES + tile) * CNT_PAD; }
+
 struct NbrArgs {
     const NbrWork *work;
-    const StepCtx *ctx;
-    float *nbr;   // [NST][2][F][NBR_LD]
-    int nwork, H, W, L, F;
-    int chain_xcds;  // XCDs 0 .. chain_xcds-1 are left to the chain workgroups (see k_column); 0 = no split
-    unsigned *cnt;   // [NST] completion counters of this handle: work items done per stage, ever
-    int nbr_wgs;     // neighbour-role workgroups of the launch
-    int step;        // order position of this launch (selects the context record, see StepCtx)
+    const StepCtx *ctx;   // records of this launch's columns
+    float *nbr;           // [NST][2][col_stride][NBR_LD]
+    int nwork, H, W, L;
+    int ncols;            // columns of this launch
+    int col_stride;       // column capacity of the nbr buffer
+    int tiles;            // 16-column tiles = ceil(ncols / 16)
+    int chain_xcds;       // the chain workgroups are the blocks on XCDs 0 .. chain_xcds-1 (see k_column)
+    unsigned *cnt;        // [NST][MAX_TILES] padded completion counters of this handle: work items done, ever (cnt_index)
+    int nbr_wgs, groups;  // neighbour-role workgroups of the launch; work items each of them runs at a time (2 or 4)
+    int debug;            // tuning only
 };
 
 // XCD affinity, for speed only (nothing depends on it): workgroup b of a launch runs on XCD b % 8, each XCD with
@@ -532,16 +555,16 @@ __device__ __forceinline__ int xcd_slot(int b, int lo, int hi /*use XCDs lo .. h
     return (b >> 3) * (hi - lo) + (x - lo);
 }
 
-// one neighbour tap of one conv for 16 frames x 16 output channels, from fresh accumulators
+// one neighbour tap of one conv for 16 columns x 16 output channels, from fresh accumulators
 template <int NG>
-__device__ __forceinline__ f32x4 nbr_tap(const NbrWork &sd, const NbrArgs &a, int t, int o0, int f, bool valid, int i, int kk)
+__device__ __forceinline__ f32x4 nbr_tap(const NbrWork &sd, const NbrArgs &a, int t, int o0, int col, bool valid, int i, int kk)
 {
     const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
     float mv = 0.0f;
     const float *src = nullptr;
     if (valid) {
-        const StepCtx &cx = a.ctx[(size_t)(a.step & 1) * a.F + f];
-        const int q = cx.q;
+        const StepCtx &cx = a.ctx[col];
+        const int q = cx.q, f = cx.f;
         const int r = q / a.W, c = q - r * a.W;
         const int rr = r + (t / 3 - 1) * sd.dil, cc = c + (t % 3 - 1) * sd.dil;
         if (rr >= 0 && rr < a.H && cc >= 0 && cc < a.W) {
@@ -552,7 +575,9 @@ __device__ __forceinline__ f32x4 nbr_tap(const NbrWork &sd, const NbrArgs &a, in
     const bool live = mv != 0.0f;
     if (!__any(live)) return zero;
     Acc5 acc = acc5_zero();
-    const float *wbase = sd.w + (size_t)t * NG * 16 * sd.Co_pad + ((size_t)kk * sd.Co_pad + o0 + i) * 4;
+    const float *wbase = (a.debug & 4) ? sd.w + ((size_t)kk * sd.Co_pad + i) * 4
+                                        : sd.w + (size_t)t * NG * 16 * sd.Co_pad + ((size_t)kk * sd.Co_pad + o0 + i) * 4;
+    if (a.debug & 8) src = sd.in + 4 * kk;
     f32x4 av[NG], bv[NG];
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
@@ -581,47 +606,58 @@ __device__ __forceinline__ void signal_done(unsigned *counter, int lane)
     if (lane == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// A neighbour workgroup runs NBR_ITEMS_PER_WG work items, four waves each: with all sixteen waves at work every SIMD
-// would interleave four MFMA chains (4 x 40 x 32 cycles = 2.2 us before the first result of a launch); two items put
-// two waves on each SIMD.
-constexpr int NBR_ITEMS_PER_WG = 2;
+// Neighbour-tap role of k_column.  A work item = (stage, slot NA|NB, 16 output channels) for a tile of 16 columns: its
+// 4 waves take the 4 taps of the slot and the partials are added in tap order through LDS (the order k_gemm uses).
+// A workgroup runs `groups` items at a time, four waves each (2 for small launches: with all sixteen waves at work every
+// SIMD interleaves four MFMA chains, 4 x 40 x 32 cycles = 2.2 us before the first result; 4 when there are more items
+// than CUs x 2), and walks the item list round by round: item (round * workgroups + nb) * groups + group -- stage-major
+// over the tiles, so the first stages of every tile come first.  An item's completion is published (its stage's
+// counter) once its write-through stores have left; that wait is folded into the NEXT round's wait for its operands
+// (vmcnt is in order), only the last round drains on its own.  The workgroups of a launch are all resident (at most
+// one per CU), so nothing here ever waits for another workgroup.
+constexpr int NBR_MAX_GROUPS = 4;
 
-// Neighbour-tap role of k_column: a 1024-thread workgroup takes NBR_ITEMS_PER_WG work items, four waves each.  A work item =
-// (stage, slot NA|NB, 16 output channels) for a tile of 16 frames; its 4 waves take the 4 taps of the slot and
-// the partials are added in tap order (the order k_gemm uses).  Every item bumps its stage's completion counter
-// once its results are out.
 __device__ __forceinline__ void nbr_role(const NbrArgs &a, int nb)
 {
-    __shared__ __attribute__((aligned(16))) float sNP[NBR_ITEMS_PER_WG][4][16][20];
+    __shared__ __attribute__((aligned(16))) float sNP[2][NBR_MAX_GROUPS][4][16][20];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, kk = lane >> 4;
     const int grp4 = wave >> 2, w4 = wave & 3;
-    if (grp4 >= NBR_ITEMS_PER_WG) return;  // (these waves leave before the barrier: it only counts live waves)
-    const int item = nb * NBR_ITEMS_PER_WG + grp4;
-    const bool active = item < a.nwork * ((a.F + 15) / 16);
-    const int ftile = active ? item / a.nwork : 0, witem = active ? item - ftile * a.nwork : 0;
-    NbrWork wk{};
-    int f = 0;
-    bool valid = false;
-    if (active) {
-        wk = a.work[witem];
-        f = ftile * 16 + i;
-        valid = f < a.F;
-        const int t = wk.half * 5 + w4;  // taps 0..3 (NA) or 5..8 (NB)
-        const f32x4 part = wk.NG == 10 ? nbr_tap<10>(wk, a, t, wk.cog * 16, f, valid, i, kk)
-                                       : nbr_tap<5>(wk, a, t, wk.cog * 16, f, valid, i, kk);
-        *(f32x4 *)(&sNP[grp4][w4][i][kk * 4]) = part;
-    }
-    __syncthreads();
-    if (active && w4 == 0) {
-        if (valid) {
-            const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
-            f32x4 tot = zero;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) tot = tot + *(const f32x4 *)(&sNP[grp4][w][i][kk * 4]);
-            store_through(a.nbr + (((size_t)wk.stage * 2 + wk.half) * a.F + f) * NBR_LD + wk.cog * 16 + kk * 4, tot);
+    if (nb >= a.nbr_wgs || grp4 >= a.groups) return;  // (leave before any barrier: it only counts live waves)
+    const int nitems = a.nwork * a.tiles, per_round = a.nbr_wgs * a.groups;
+    unsigned *pending = nullptr;  // counter of the item this group finished in the previous round, not yet published
+    for (int base = 0; base < nitems; base += per_round) {
+        const int item = base + nb * a.groups + grp4, par = (base / per_round) & 1;
+        const bool active = item < nitems;
+        const int witem = active ? item / a.tiles : 0, ctile = active ? item - witem * a.tiles : 0;
+        NbrWork wk{};
+        int col = 0;
+        bool valid = false;
+        if (active) {
+            wk = a.work[witem];
+            col = ctile * 16 + i;
+            valid = col < a.ncols;
+            const int t = wk.half * 5 + w4;  // taps 0..3 (NA) or 5..8 (NB)
+            const f32x4 part = wk.NG == 10 ? nbr_tap<10>(wk, a, t, wk.cog * 16, col, valid, i, kk)
+                                           : nbr_tap<5>(wk, a, t, wk.cog * 16, col, valid, i, kk);
+            *(f32x4 *)(&sNP[par][grp4][w4][i][kk * 4]) = part;
         }
-        signal_done(a.cnt + wk.stage, lane);
+        if (w4 == 0 && pending) {  // the operands of this round have arrived, so the older stores have left too
+            signal_done(pending, lane);
+            pending = nullptr;
+        }
+        __syncthreads();
+        if (active && w4 == 0) {
+            if (valid) {
+                const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+                f32x4 tot = zero;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) tot = tot + *(const f32x4 *)(&sNP[par][grp4][w][i][kk * 4]);
+                store_through(a.nbr + (((size_t)wk.stage * 2 + wk.half) * a.col_stride + col) * NBR_LD + wk.cog * 16 + kk * 4, tot);
+            }
+            pending = a.cnt + cnt_index(wk.stage, ctile);
+        }
     }
+    if (w4 == 0 && pending) signal_done(pending, lane);
 }
 
 struct ChainArgs {
@@ -629,24 +665,25 @@ struct ChainArgs {
     const float *nbr;         // neighbour slots of this launch, from the neighbour role
     const float *uinit_w, *uinit_b;
     const int32_t *codes_in;  // (F,L) current codes: the u_init gather reads earlier positions
-    CtxArgs cx;
+    const StepCtx *ctx;       // records of this launch's columns (workgroup k of the chain role takes column k)
     const float *out_b;
-    int H, W, L, F;
-    // end of the order position
+    int H, W, L;
+    int ncols, col_stride;    // columns of this launch / column capacity of the nbr buffer
+    // end of the column
     int32_t *codes;           // (F,L) written for sampled locations, or null (logits only)
     const uint8_t *region;    // (F,L) by location
     const int32_t *forced;    // (F,L) by location or null
     const float *uniforms;    // (F,L) by location or null
     float *out_logits;        // (F,L,512) by location or null
-    float *step_logits;       // (F,512) or null
+    float *step_logits;       // (F,512) by frame or null
     float temperature;
-    int advance;              // 1: write the context of step+1
     const unsigned *cnt;       // completion counters of the neighbour role (NbrArgs::cnt)
-    unsigned epoch;            // column launches of this handle so far, this one included: counters are never reset
-    int tiles;                 // 16-frame tiles of the neighbour role
+    unsigned tile_uses[MAX_TILES];  // launches of this handle so far that had a tile t, this one included: the counters are
+                               // never reset, counter (k, t) stands at tile_uses[t] x (items of stage k per tile) when done
     int *err;                  // set to 1 if a bounded wait ran out (ps_pixelcnn_status)
-    int step;                  // order position of this launch
     unsigned long long *trace; // optional [NST][10] shader-clock stamps of workgroup 0 (tuning aid)
+    int debug;                 // tuning only (PS_COLUMN_DEBUG): 1 = chains do not wait for the neighbour slots, 2 = no chains,
+                               // 3 = no neighbour role and no waiting
 };
 
 // categorical draw from logits / T by inverse CDF with one uniform (sample.py:60-66); lane l holds classes 8l..8l+7
@@ -780,9 +817,8 @@ __device__ __forceinline__ void chain_role(const ChainArgs &a, int wg)
     __shared__ __attribute__((aligned(16))) float sU[8][FPW][NF];        // u0..u7 of this location
     __shared__ __attribute__((aligned(16))) float sOut[FPW][3][NF];      // (u, elu(u), elu(-u)) on their way to the caches
     __shared__ __attribute__((aligned(16))) float sPL[FPW][5][NCLS];     // chain values of nin_out
-    __shared__ int sLate[FPW];                                           // next record: tap that waits for this position's code
     const int t = threadIdx.x, wave = uni(t >> 6), lane = t & 63;
-    const int f0 = wg * FPW;
+    const int f0 = wg * FPW;  // first column of this workgroup (index into the launch's records)
     // Roles, each in its own wave-uniform branch (so their registers do not add up):
     //   waves 0..12         one chain per thread and stage
     //   wave 13             cache stores (finished values LDS -> R / E / X) and the nin_skip inputs
@@ -834,12 +870,12 @@ __device__ __forceinline__ void chain_role(const ChainArgs &a, int wg)
 
     if (pwave) {
         // ================= post waves: one frame each, two barriers per stage =================
-        const int pfr = f0 + pf;
-        const bool pvalid = pfr < a.F;
+        const int pfr = f0 + pf;   // column
+        const bool pvalid = pfr < a.ncols;
         const bool own = lane < PONO_LANES;          // two channels per lane: 2 * lane, 2 * lane + 1 (see pono_total)
         const int c2 = own ? 2 * lane : 0;
         const float *nbr_f = a.nbr + (size_t)(pvalid ? pfr : 0) * NBR_LD + c2;
-        const size_t nbr_half = (size_t)a.F * NBR_LD, nbr_stage = 2 * nbr_half;
+        const size_t nbr_half = (size_t)a.col_stride * NBR_LD, nbr_stage = 2 * nbr_half;
         const f32x2 zero2 = {0.0f, 0.0f};
         f32x2 ucur = zero2;
         // bias and neighbour-tap slots of a stage's post op: y = ((bias + NA) + centre) + NB; fetched one stage ahead.
@@ -867,9 +903,12 @@ __device__ __forceinline__ void chain_role(const ChainArgs &a, int wg)
         };
         // completion counter of stage k; `have` is a value loaded earlier (normally already
         // past the target, so this costs nothing); bounded, so a lost neighbour workgroup cannot hang the GPU
-        auto counter = [&](int k) { return __hip_atomic_load(a.cnt + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+        const int my_tile = (pvalid ? pfr : 0) >> 4;
+        const unsigned my_uses = a.tile_uses[my_tile];
+        auto counter = [&](int k) { return __hip_atomic_load(a.cnt + cnt_index(k, my_tile), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
         auto wait_counter = [&](unsigned have, int k, unsigned items_per_tile) {
-            const unsigned need = a.epoch * items_per_tile * (unsigned)a.tiles;
+            const unsigned need = my_uses * items_per_tile;
+            if (a.debug & 1) return;
             int spins = 0;
             while ((int)(have - need) < 0) {
                 if (++spins > 20000) { if (lane == 0) *a.err = 1; break; }
@@ -958,13 +997,18 @@ __device__ __forceinline__ void chain_role(const ChainArgs &a, int wg)
             PS_TRACE1(t == C1_THREADS - 64, 4);
         };
         Ops oA, oB;
-        const StepCtx *ctxp = ctx_of(a.cx, pvalid ? pfr : 0, a.step);
-        const int q0 = ctxp->q;
-        {   // u0 = norm_init(u_init): the gather over the (earlier) neighbours' codes, which the context record carries
+        const StepCtx *ctxp = a.ctx + (pvalid ? pfr : 0);
+        const int q0 = ctxp->q, fr0 = ctxp->f;
+        {   // u0 = norm_init(u_init): the gather over the (earlier) neighbours' codes; the record says where they are,
+            // the codes themselves were written by earlier launches (sampled) or are the caller's (observed)
             float mA[9];
             int ncode[9];
 #pragma unroll
-            for (int tp = 0; tp < 9; ++tp) { mA[tp] = ctxp->m[0][tp]; ncode[tp] = ctxp->ncode[tp]; }
+            for (int tp = 0; tp < 9; ++tp) {
+                mA[tp] = ctxp->m[0][tp];
+                const int nl = ctxp->nloc[tp];
+                ncode[tp] = nl >= 0 ? a.codes_in[(size_t)fr0 * a.L + nl] : UINIT_CLOSED;
+            }
             const f32x2 y = uinit_from_codes<f32x2>(ncode, mA, a.uinit_w, a.uinit_b, c2);
             post_and_emit(y, zero2, zero2, integral_constant<int, PRO_UINIT>{}, integral_constant<bool, false>{},
                           integral_constant<int, IN_CELU>{}, cur.save_slot);
@@ -984,9 +1028,9 @@ __device__ __forceinline__ void chain_role(const ChainArgs &a, int wg)
         post_stage(NST - 2, oB, oA);
         nin_out_chains();
 
-        // ---- end of the order position: logits, categorical draw (sample.py:60-66)
+        // ---- end of the column: logits, categorical draw (sample.py:60-66)
         if (pvalid) {
-            const int f = pfr;
+            const int f = uni(fr0);
             const int fq = uni(q0);
             const size_t loc = (size_t)f * a.L + fq;
             float lg[8];
@@ -1007,16 +1051,9 @@ __device__ __forceinline__ void chain_role(const ChainArgs &a, int wg)
 #pragma unroll
                 for (int k = 0; k < 8; ++k) a.step_logits[(size_t)f * NCLS + lane * 8 + k] = lg[k];
             }
-            int final_code = UINIT_CLOSED;  // (unknown yet)
             if (a.codes && a.region[loc]) {
-                final_code = a.forced ? a.forced[loc] : draw_code(lg, a.temperature, a.uniforms[loc], lane);
-                if (lane == 0) a.codes[loc] = final_code;
-            }
-            // the next position's record was prepared by the control wave, except the code of this very location
-            const int lt = sLate[pf];
-            if (a.advance && lt >= 0 && lane == 0) {
-                if (final_code == UINIT_CLOSED) final_code = a.codes_in[loc];  // observed location: its code stays
-                ctx_of(a.cx, f, a.step + 1)->ncode[lt] = final_code;
+                const int code = a.forced ? a.forced[loc] : draw_code(lg, a.temperature, a.uniforms[loc], lane);
+                if (lane == 0) a.codes[loc] = code;
             }
         }
     } else if (swave) {
@@ -1025,10 +1062,11 @@ __device__ __forceinline__ void chain_role(const ChainArgs &a, int wg)
         bool fvalid[FPW];
 #pragma unroll
         for (int f = 0; f < FPW; ++f) {
-            fvalid[f] = f0 + f < a.F;
-            const int q = fvalid[f] ? ctx_of(a.cx, f0 + f, a.step)->q : 0;
-            off80[f] = ((size_t)(fvalid[f] ? f0 + f : 0) * a.L + q) * NF;
-            offR[f] = ((size_t)(fvalid[f] ? f0 + f : 0) * a.L + q) * R_LD;
+            fvalid[f] = f0 + f < a.ncols;
+            const StepCtx *rec = a.ctx + (fvalid[f] ? f0 + f : 0);
+            const size_t at = (size_t)rec->f * a.L + rec->q;
+            off80[f] = at * NF;
+            offR[f] = at * R_LD;
         }
         const int ch[2] = {cA, cB};
         auto store_outputs = [&](const StoreCtl &c) {  // what the post op of the record produced: LDS -> caches
@@ -1091,49 +1129,11 @@ __device__ __forceinline__ void chain_role(const ChainArgs &a, int wg)
             rec = min(rec, NST);
             keep ^= ctl_i(a.ctl1, rec, 0) ^ ctl_i(a.ctl1, rec, 16);  // both 64-byte lines of the 96-byte record
         };
-        // The context record of the NEXT position is built here, its dependent fetches (location from the order; mask
-        // values; the neighbours' codes) spread over the windows of stages 0, 4, 8 and written in that of stage 12 --
-        // this wave never holds up a barrier, and nothing is left for the end of the launch but the one code that is
-        // not known before (the tap whose neighbour is this very location: late_tap, patched by the post wave).
-        const bool build = a.advance && a.step + 1 < a.L;
-        int nq[FPW], ncode[FPW], qcur[FPW];
-        float nm[FPW];
-        bool late[FPW];
-#pragma unroll
-        for (int f = 0; f < FPW; ++f) {
-            nq[f] = 0; ncode[f] = UINIT_CLOSED; nm[f] = 0.0f; late[f] = false;
-            qcur[f] = build ? ctx_of(a.cx, f0 + f < a.F ? f0 + f : 0, a.step)->q : 0;
-            if (lane == 0) sLate[f] = -1;
-        }
         for (int r = 0; r < 6; ++r) touch(r);
         lds_barrier();
         for (int s = 0; s < NST - 2; ++s) {
             lds_barrier();
             touch(6 + s);
-            if (build) {
-#pragma unroll
-                for (int f = 0; f < FPW; ++f) {
-                    const int fr = f0 + f < a.F ? f0 + f : 0;
-                    if (s == 0) nq[f] = a.cx.order[(size_t)fr * a.L + a.step + 1];
-                    if (s == 4 && lane < 27) nm[f] = a.cx.mask[lane / 9][((size_t)fr * 9 + lane % 9) * a.L + nq[f]];
-                    if (s == 8 && lane < 9) {
-                        const int loc = ctx_nbr_loc(nq[f], lane, a.H, a.W);
-                        if (loc >= 0 && nm[f] != 0.0f) {
-                            late[f] = loc == qcur[f];
-                            ncode[f] = late[f] ? -1 : a.codes_in[(size_t)fr * a.L + loc];
-                        }
-                    }
-                    if (s == 12 && f0 + f < a.F) {
-                        StepCtx *nx = ctx_of(a.cx, fr, a.step + 1);
-                        const unsigned long long lb = __ballot(late[f]);
-                        const int lt = lb ? __builtin_ctzll(lb) : -1;
-                        if (lane < 27) nx->m[lane / 9][lane % 9] = nm[f];
-                        if (lane < 9) nx->ncode[lane] = ncode[f];
-                        if (lane == 27) { nx->q = nq[f]; nx->late_tap = lt; }
-                        if (lane == 0) sLate[f] = lt;
-                    }
-                }
-            }
             lds_barrier();
         }
         load_out_weights();
@@ -1200,32 +1200,32 @@ __device__ __forceinline__ void chain_role(const ChainArgs &a, int wg)
 }
 
 // ==========================================================================================
-// k_column: ONE launch per AR order position.  Workgroup b runs on XCD b % 8 (observed; used for speed only):
-//   chain role   frame f's 33-stage chain.  With the XCD split (<= 32 frames) these are the workgroups 8f, all on
-//                XCD 0, whose L2 then keeps the centre-tap weights from one position to the next.
-//   neighbour role   every other workgroup: four work items each (nbr_role), on XCDs 1..7.
+// k_column: ONE launch per wavefront of columns (or per order position: one column per frame).  Workgroup b runs on
+// XCD b % 8 (observed; used for speed only):
+//   chain role       workgroup = one column's 33-stage chain, on XCDs 0 .. chain_xcds-1 (32 CUs each, one 1024-thread
+//                    workgroup per CU): their L2s keep the centre-tap weights from one launch to the next.
+//   neighbour role   one workgroup per CU of the other XCDs (at most), walking the item list (nbr_role).
 // Both start together: the chain only needs the neighbour slots of stage s when it reaches the post op of stage s,
-// and by then the neighbour role -- a few microseconds of parallel work -- is normally done; completion counters
+// and by then the neighbour role is normally past that stage (its items are ordered by stage); completion counters
 // per stage (device-scope atomics) and write-through stores carry the hand-off, every wait is bounded.
-// The neighbour workgroups never wait for anything and are never kept off the chip by waiting chain workgroups (at
-// most 32 chain workgroups in the split layout, neighbour workgroups first in the other), so the launch cannot deadlock.
+// The neighbour workgroups never wait for anything and never share an XCD with the chain workgroups (the other
+// blocks of the chain XCDs exit at once), and a launch holds at most 32 chain workgroups per chain XCD, so waiting
+// chains cannot keep the neighbour role off the chip: the launch cannot deadlock.
 // ==========================================================================================
 __global__ __launch_bounds__(C1_THREADS) void k_column(NbrArgs na, ChainArgs ca)
 {
-    const int b = blockIdx.x;
-    int chain_wg = -1, nb;
-    if (na.chain_xcds > 0) {  // XCD split: chain workgroups are the blocks 0, 8, 16, ...
-        const int ahead = min((b + 7) >> 3, ca.F);  // chain blocks with an index below b
-        if ((b & 7) == 0 && (b >> 3) < ca.F) chain_wg = b >> 3;
-        nb = b - ahead;
-    } else {  // no split: the neighbour workgroups come FIRST, so that they are dispatched before any chain
-        // workgroup can occupy a CU -- with F >= the number of CUs the chains would otherwise fill the chip and
-        // wait (bounded, but in vain) for neighbour workgroups that cannot start
-        nb = b;
-        if (b >= na.nbr_wgs) chain_wg = b - na.nbr_wgs;
+    const int b = blockIdx.x, cx = na.chain_xcds, x = b & 7, row = b >> 3;
+    const int chain_rows = (ca.ncols + cx - 1) / cx;  // rows of 8 blocks (one per XCD) that hold chain workgroups
+    if (row < chain_rows) {
+        if (x < cx) {
+            const int col = row * cx + x;
+            if (col < ca.ncols && (ca.debug & 3) != 2) chain_role<1>(ca, col);
+        } else if ((ca.debug & 3) != 3) {
+            nbr_role(na, row * (8 - cx) + (x - cx));
+        }
+    } else if ((ca.debug & 3) != 3) {
+        nbr_role(na, chain_rows * (8 - cx) + (row - chain_rows) * 8 + x);
     }
-    if (chain_wg >= 0) chain_role<1>(ca, chain_wg);
-    else nbr_role(na, nb);
 }
 
 // repack the centre tap (+ nin_skip) of a stage for the chain role: out[step][chain][4]
@@ -1350,16 +1350,17 @@ struct ps_pixelcnn {
     float *uinit_w = nullptr, *uinit_b = nullptr, *out_w = nullptr, *out_b = nullptr;
     float *R[NNODE], *E[NNODE], *X[NGATED];
     float *partial = nullptr;       // whole-grid slots [4][maxF*L][160]
-    float *nbr = nullptr;           // column mode: neighbour slots [NST][2][maxF][160]
+    float *nbr = nullptr;           // column mode: neighbour slots [NST][2][COL_CAP][160]
     float *col_logits = nullptr;
-    StepCtx *ctx = nullptr;
+    StepCtx *ctx = nullptr;         // column records of a run, [maxF * L]
     int *ctl1 = nullptr;            // the same for the chain role (scalar-load records)
-    unsigned *cnt = nullptr;        // [NST + 1] completion counters of the neighbour role, never reset
+    unsigned *cnt = nullptr;        // [NST][MAX_TILES] padded completion counters of the neighbour role, never reset
     int *err = nullptr;             // device flag: a bounded wait of the chain role ran out
-    unsigned epoch = 0;             // column launches so far
+    unsigned tile_uses[MAX_TILES] = {};  // column launches so far that had tile t (target of the counters)
     NbrWork *work = nullptr;
     int nwork = 0;
-    bool xcd_pack = true;  // PS_XCD_PACK=0 turns the XCD split of the column kernels off
+    int col_cap = COL_CAP;          // columns per launch (PS_COL_CAP: tuning)
+    int chain_xcds = 0;             // PS_CHAIN_XCDS: tuning (0 = automatic)
     // bench.py profiling aid (ps_pixelcnn_time_column_step): event pair around every launch, by kernel tag
     struct ProfRec { int tag; hipEvent_t e0, e1; };
     std::vector<ProfRec> *prof = nullptr;
@@ -1570,24 +1571,34 @@ int build_stage_table(ps_pixelcnn *h)
     return PS_OK;
 }
 
-// one order position: neighbour taps of every conv and the centre-tap chains + draw, one launch.  The context
-// record of `step` (h->ctx, parity step & 1) must
-// describe the current position.
-void run_column(ps_pixelcnn *h, int F, const int32_t *codes, ChainArgs ca, int step, hipStream_t st)
+// `ncols` independent columns (records rec[0..ncols)): neighbour taps of every conv and the centre-tap chains + draw,
+// in launches of at most col_cap columns.
+void run_columns(ps_pixelcnn *h, const StepCtx *rec, int ncols, const int32_t *codes, ChainArgs ca, hipStream_t st)
 {
-    // XCD split: up to 32 frames, the chain workgroups (blocks 0, 8, 16, ...) fill XCD 0 (32 CUs) and the neighbour
-    // role gets XCDs 1..7 (V=16: chain 47.5 -> 42.5 us); with more frames both use the whole chip
-    const bool split = h->xcd_pack && F <= 32;
-    const int tiles = (F + 15) / 16, nbr_wgs = (h->nwork * tiles + NBR_ITEMS_PER_WG - 1) / NBR_ITEMS_PER_WG;
-    NbrArgs na{h->work, h->ctx, h->nbr, h->nwork, h->H, h->W, h->L, F, split ? 1 : 0, h->cnt, nbr_wgs, step};
-    ca.step = step;
     ca.ctl1 = h->ctl1; ca.nbr = h->nbr;
     ca.uinit_w = h->uinit_w; ca.uinit_b = h->uinit_b; ca.codes_in = codes;
     ca.out_b = h->out_b;
-    ca.H = h->H; ca.W = h->W; ca.L = h->L; ca.F = F;
-    ca.cnt = h->cnt; ca.epoch = ++h->epoch; ca.tiles = tiles; ca.err = h->err;
-    const int blocks = split ? std::max(nbr_wgs + F, 8 * (F - 1) + 1) : nbr_wgs + F;
-    timed(h, st, TAG_CHAIN, [&]() { hipLaunchKernelGGL(k_column, dim3(blocks), dim3(C1_THREADS), 0, st, na, ca); });
+    ca.H = h->H; ca.W = h->W; ca.L = h->L; ca.col_stride = COL_CAP;
+    ca.cnt = h->cnt; ca.err = h->err;
+    if (const char *dbg = getenv("PS_COLUMN_DEBUG")) ca.debug = atoi(dbg);
+    for (int done = 0; done < ncols; done += h->col_cap) {
+        const int n = std::min(h->col_cap, ncols - done);
+        const int tiles = (n + 15) / 16, nitems = h->nwork * tiles;
+        // chain workgroups on XCDs 0 .. cx-1 of the first rows of 8 blocks, neighbour workgroups everywhere else, 256
+        // blocks at most (one per CU, all resident)
+        const int cx = h->chain_xcds > 0 ? std::min(8, std::max(h->chain_xcds, (n + 31) / 32)) : std::min(4, (n + 31) / 32);
+        const int chain_rows = (n + cx - 1) / cx;
+        const int nbr_cus = chain_rows * (8 - cx) + (32 - chain_rows) * 8;
+        const int groups = nitems > 2 * nbr_cus ? 4 : 2;
+        const int nbr_wgs = std::min(nbr_cus, (nitems + groups - 1) / groups);
+        NbrArgs na{h->work, rec + done, h->nbr, h->nwork, h->H, h->W, h->L, n, COL_CAP, tiles, cx, h->cnt, nbr_wgs, groups, ca.debug};
+        ca.ctx = rec + done; ca.ncols = n;
+        for (int t = 0; t < tiles; ++t) h->tile_uses[t] += 1;
+        for (int t = 0; t < MAX_TILES; ++t) ca.tile_uses[t] = h->tile_uses[t];
+        const int in_chain_rows = chain_rows * (8 - cx);
+        const int rows = nbr_wgs <= in_chain_rows ? chain_rows : chain_rows + (nbr_wgs - in_chain_rows + 7) / 8;
+        timed(h, st, TAG_CHAIN, [&]() { hipLaunchKernelGGL(k_column, dim3(rows * 8), dim3(C1_THREADS), 0, st, na, ca); });
+    }
 }
 
 CtxArgs make_ctx_args(ps_pixelcnn *h, const int32_t *order, const Masks &m, int F)
@@ -1619,7 +1630,8 @@ int ps_pixelcnn_create(const float *const *params, int n_params, int H, int W, i
     for (int i = 0; i < n_params; ++i) PS_REQUIRE(params[i], "pixelcnn_create: tensor %d is null", i);
     ps_pixelcnn *h = new ps_pixelcnn();
     h->H = H; h->W = W; h->L = H * W; h->maxF = max_frames;
-    if (const char *xp = getenv("PS_XCD_PACK")) h->xcd_pack = xp[0] != '0';
+    if (const char *cc = getenv("PS_COL_CAP")) h->col_cap = std::max(1, std::min(COL_CAP, atoi(cc)));
+    if (const char *cc = getenv("PS_CHAIN_XCDS")) h->chain_xcds = std::max(0, std::min(8, atoi(cc)));
     int rc = PS_OK;
     auto fail_out = [&](int code) { ps_pixelcnn_destroy(h); return code; };
 
@@ -1682,11 +1694,11 @@ int ps_pixelcnn_create(const float *const *params, int n_params, int H, int W, i
     if (locs * NCLS > pfloats) pfloats = locs * NCLS;
     if ((rc = dev_alloc(h, &h->partial, pfloats))) return fail_out(rc);
     if ((rc = dev_alloc(h, &h->col_logits, (size_t)max_frames * NCLS))) return fail_out(rc);
-    if ((rc = dev_alloc(h, &h->nbr, (size_t)NST * 2 * max_frames * NBR_LD))) return fail_out(rc);
-    if ((rc = dev_alloc(h, &h->ctx, (size_t)2 * max_frames))) return fail_out(rc);
-    if ((rc = dev_alloc(h, &h->cnt, (size_t)NST + 1))) return fail_out(rc);
+    if ((rc = dev_alloc(h, &h->nbr, (size_t)NST * 2 * COL_CAP * NBR_LD))) return fail_out(rc);
+    if ((rc = dev_alloc(h, &h->ctx, locs))) return fail_out(rc);
+    if ((rc = dev_alloc(h, &h->cnt, cnt_index(NST, 0)))) return fail_out(rc);
     if ((rc = dev_alloc(h, &h->err, 1))) return fail_out(rc);
-    if (hipMemset(h->cnt, 0, (NST + 1) * sizeof(unsigned)) != hipSuccess || hipMemset(h->err, 0, sizeof(int)) != hipSuccess) {
+    if (hipMemset(h->cnt, 0, cnt_index(NST, 0) * sizeof(unsigned)) != hipSuccess || hipMemset(h->err, 0, sizeof(int)) != hipSuccess) {
         ps::fail(PS_ERR_HIP, "pixelcnn_create: hipMemset failed");
         return fail_out(PS_ERR_HIP);
     }
@@ -1723,11 +1735,59 @@ int ps_pixelcnn_ar_step(ps_pixelcnn *h, const int32_t *codes, const int32_t *ord
     const Masks m{mask_init, mask_undilated, mask_dilated};
     if (step == first_step) run_grid(h, F, codes, m, nullptr, false, st, order, first_step);
     ChainArgs ca{};
-    ca.cx = make_ctx_args(h, order, m, F);
-    hipLaunchKernelGGL(k_ctx_init, dim3(F), dim3(32), 0, st, ca.cx, codes, h->H, h->W, step);
+    hipLaunchKernelGGL(k_ctx_build, dim3(F), dim3(32), 0, st, make_ctx_args(h, order, m, F), (const int32_t *)nullptr, F, step,
+                       h->H, h->W);
     ca.step_logits = logits;
     ca.temperature = 1.0f;
-    run_column(h, F, codes, ca, step, st);
+    run_columns(h, h->ctx, F, codes, ca, st);
+    PS_LAUNCH_CHECK();
+    return PS_OK;
+}
+
+// The AR run: whole-grid pass over the observed prefix, then the remaining columns -- wavefront by wavefront when the
+// caller brings a schedule (ps_ar_wavefronts), else position by position (one column per frame and launch).
+static int ar_run_impl(ps_pixelcnn *h, int32_t *codes, const int32_t *order, const uint8_t *sample_region,
+                       const float *mask_init, const float *mask_undilated, const float *mask_dilated,
+                       const int32_t *forced, const float *uniforms, float temperature, int F, int first_step,
+                       const int32_t *wave_cols, const int32_t *wave_start, int n_waves, float *out_logits, void *stream)
+{
+    if (int rc = check_handle(h, F)) return rc;
+    PS_REQUIRE(codes && order && sample_region && mask_init && mask_undilated && mask_dilated, "pixelcnn_ar_run: null pointer");
+    PS_REQUIRE((forced != nullptr) != (uniforms != nullptr), "pixelcnn_ar_run: give exactly one of forced / uniforms");
+    PS_REQUIRE(first_step >= 0 && first_step <= h->L, "pixelcnn_ar_run: first_step out of range");
+    PS_REQUIRE(temperature > 0.0f, "pixelcnn_ar_run: temperature must be > 0");
+    const int nsteps = h->L - first_step;
+    if (wave_cols) {
+        PS_REQUIRE(wave_start && n_waves >= 0 && wave_start[0] == 0, "pixelcnn_ar_run_waves: bad schedule");
+        for (int w = 0; w < n_waves; ++w)
+            PS_REQUIRE(wave_start[w + 1] >= wave_start[w], "pixelcnn_ar_run_waves: wave_start must not decrease");
+        PS_REQUIRE(wave_start[n_waves] == F * nsteps, "pixelcnn_ar_run_waves: the schedule holds %d columns, the run has %d",
+                   wave_start[n_waves], F * nsteps);
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const Masks m{mask_init, mask_undilated, mask_dilated};
+    const size_t n = (size_t)F * h->L;
+    hipLaunchKernelGGL(k_mask_codes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, codes, sample_region, n);
+    // whole-grid pass: exact for every location that precedes the first sampled one; with out_logits it also
+    // yields their logits, by location (the walked positions are overwritten by the column steps)
+    run_grid(h, F, codes, m, out_logits, false, st, order, first_step);
+    ChainArgs ca{};
+    ca.codes = codes; ca.region = sample_region; ca.forced = forced; ca.uniforms = uniforms;
+    ca.out_logits = out_logits; ca.temperature = temperature;
+    const int total = F * nsteps;
+    if (total > 0)
+        hipLaunchKernelGGL(k_ctx_build, dim3(total), dim3(32), 0, st, make_ctx_args(h, order, m, F), wave_cols, total, first_step,
+                           h->H, h->W);
+    PS_LAUNCH_CHECK();
+    // launches are enqueued eagerly: the host stays far ahead of the GPU (a hipGraph replay was measured slower, and
+    // the completion-counter target changes with every launch anyway)
+    if (wave_cols) {
+        for (int w = 0; w < n_waves; ++w)
+            if (wave_start[w + 1] > wave_start[w])
+                run_columns(h, h->ctx + wave_start[w], wave_start[w + 1] - wave_start[w], codes, ca, st);
+    } else {
+        for (int sidx = 0; sidx < nsteps; ++sidx) run_columns(h, h->ctx + (size_t)sidx * F, F, codes, ca, st);
+    }
     PS_LAUNCH_CHECK();
     return PS_OK;
 }
@@ -1737,30 +1797,45 @@ int ps_pixelcnn_ar_run(ps_pixelcnn *h, int32_t *codes, const int32_t *order, con
                        const int32_t *forced, const float *uniforms, float temperature, int F, int first_step,
                        float *out_logits, void *stream)
 {
-    if (int rc = check_handle(h, F)) return rc;
-    PS_REQUIRE(codes && order && sample_region && mask_init && mask_undilated && mask_dilated, "pixelcnn_ar_run: null pointer");
-    PS_REQUIRE((forced != nullptr) != (uniforms != nullptr), "pixelcnn_ar_run: give exactly one of forced / uniforms");
-    PS_REQUIRE(first_step >= 0 && first_step <= h->L, "pixelcnn_ar_run: first_step out of range");
-    PS_REQUIRE(temperature > 0.0f, "pixelcnn_ar_run: temperature must be > 0");
-    hipStream_t st = (hipStream_t)stream;
-    const Masks m{mask_init, mask_undilated, mask_dilated};
-    const size_t n = (size_t)F * h->L;
-    hipLaunchKernelGGL(k_mask_codes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, codes, sample_region, n);
-    // whole-grid pass: exact for every location that precedes the first sampled one; with out_logits it also
-    // yields their logits, by location (the walked positions are overwritten by the column steps)
-    run_grid(h, F, codes, m, out_logits, false, st, order, first_step);
-    ChainArgs ca{};
-    ca.cx = make_ctx_args(h, order, m, F);
-    ca.codes = codes; ca.region = sample_region; ca.forced = forced; ca.uniforms = uniforms;
-    ca.out_logits = out_logits; ca.temperature = temperature; ca.advance = 1;
-    hipLaunchKernelGGL(k_ctx_init, dim3(F), dim3(32), 0, st, ca.cx, codes, h->H, h->W, first_step);
-    PS_LAUNCH_CHECK();
-    const int nsteps = h->L - first_step;
-    // one launch per order position, enqueued eagerly: the host stays far ahead of the GPU (a hipGraph replay was
-    // measured slower, and the launch tag / completion-counter target changes with every launch anyway)
-    for (int sidx = 0; sidx < nsteps; ++sidx) run_column(h, F, codes, ca, first_step + sidx, st);
-    PS_LAUNCH_CHECK();
-    return PS_OK;
+    return ar_run_impl(h, codes, order, sample_region, mask_init, mask_undilated, mask_dilated, forced, uniforms, temperature, F,
+                       first_step, nullptr, nullptr, 0, out_logits, stream);
+}
+
+int ps_pixelcnn_ar_run_waves(ps_pixelcnn *h, int32_t *codes, const int32_t *order, const uint8_t *sample_region,
+                             const float *mask_init, const float *mask_undilated, const float *mask_dilated,
+                             const int32_t *forced, const float *uniforms, float temperature, int F, int first_step,
+                             const int32_t *wave_cols, const int32_t *wave_start, int n_waves, float *out_logits,
+                             void *stream)
+{
+    PS_REQUIRE(wave_cols && wave_start, "pixelcnn_ar_run_waves: null schedule");
+    return ar_run_impl(h, codes, order, sample_region, mask_init, mask_undilated, mask_dilated, forced, uniforms, temperature, F,
+                       first_step, wave_cols, wave_start, n_waves, out_logits, stream);
+}
+
+int ps_pixelcnn_time_ar_run_waves(ps_pixelcnn *h, int32_t *codes, const int32_t *order, const uint8_t *sample_region,
+                                  const float *mask_init, const float *mask_undilated, const float *mask_dilated,
+                                  const float *uniforms, float temperature, int F, int first_step, const int32_t *wave_cols,
+                                  const int32_t *wave_start, int n_waves, int *launches, float *total_ms,
+                                  double *flops_per_column, void *stream)
+{
+    PS_REQUIRE(h && launches && total_ms, "pixelcnn_time_ar_run_waves: null pointer");
+    std::vector<ps_pixelcnn::ProfRec> recs;
+    h->prof = &recs;
+    const int rc = ar_run_impl(h, codes, order, sample_region, mask_init, mask_undilated, mask_dilated, nullptr, uniforms,
+                               temperature, F, first_step, wave_cols, wave_start, n_waves, nullptr, stream);
+    h->prof = nullptr;
+    (void)hipStreamSynchronize((hipStream_t)stream);
+    *launches = 0;
+    *total_ms = 0.0f;
+    for (auto &r : recs) {
+        float ms = 0.0f;
+        (void)hipEventElapsedTime(&ms, r.e0, r.e1);
+        if (r.tag == TAG_CHAIN) { *launches += 1; *total_ms += ms; }
+        (void)hipEventDestroy(r.e0);
+        (void)hipEventDestroy(r.e1);
+    }
+    if (flops_per_column) *flops_per_column = h->flops_nbr + h->flops_chain;
+    return rc;
 }
 
 int ps_pixelcnn_status(ps_pixelcnn *h, void *stream)
@@ -1785,18 +1860,18 @@ int ps_pixelcnn_time_column_step(ps_pixelcnn *h, const int32_t *codes, const int
     hipStream_t st = (hipStream_t)stream;
     std::vector<ps_pixelcnn::ProfRec> recs;
     ChainArgs ca{};
-    ca.cx = make_ctx_args(h, order, Masks{mask_init, mask_undilated, mask_dilated}, F);
     ca.step_logits = h->col_logits;
     ca.temperature = 1.0f;
-    hipLaunchKernelGGL(k_ctx_init, dim3(F), dim3(32), 0, st, ca.cx, codes, h->H, h->W, step);
-    run_column(h, F, codes, ca, step, st);  // untimed warm-up
+    hipLaunchKernelGGL(k_ctx_build, dim3(F), dim3(32), 0, st, make_ctx_args(h, order, Masks{mask_init, mask_undilated, mask_dilated}, F),
+                       (const int32_t *)nullptr, F, step, h->H, h->W);
+    run_columns(h, h->ctx, F, codes, ca, st);  // untimed warm-up
     if (const char *tp = getenv("PS_CHAIN_TRACE")) {  // tuning aid: per-stage shader-clock stamps of workgroup 0
         unsigned long long *d = nullptr;
         if (hipMalloc(&d, NST * 10 * 8) == hipSuccess) {
             (void)hipMemsetAsync(d, 0, NST * 10 * 8, st);
             ChainArgs ct = ca;
             ct.trace = d;
-            run_column(h, F, codes, ct, step, st);
+            run_columns(h, h->ctx, F, codes, ct, st);
             std::vector<unsigned long long> hst(NST * 10);
             (void)hipStreamSynchronize(st);
             (void)hipMemcpy(hst.data(), d, NST * 10 * 8, hipMemcpyDeviceToHost);
@@ -1811,7 +1886,7 @@ int ps_pixelcnn_time_column_step(ps_pixelcnn *h, const int32_t *codes, const int
         }
     }
     h->prof = &recs;
-    for (int r = 0; r < reps; ++r) run_column(h, F, codes, ca, step, st);
+    for (int r = 0; r < reps; ++r) run_columns(h, h->ctx, F, codes, ca, st);
     h->prof = nullptr;
     PS_HIP_CHECK(hipStreamSynchronize(st));
     for (int t = 0; t < PS_PROF_NTAGS; ++t) { launches[t] = 0; total_ms[t] = 0.0f; }

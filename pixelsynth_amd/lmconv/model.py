@@ -89,18 +89,28 @@ class PixelCNNEngine:
         return logits
 
     def ar_run(self, codes, order, region, mask_init, mask_undilated, mask_dilated, temperature=1.0, forced=None,
-               uniforms=None, first_step=0, want_logits=False):
+               uniforms=None, first_step=0, want_logits=False, waves=None):
         """In-place AR completion of codes (F,L) int32.  order (F,L) int32 location per order position,
-        region (F,L) uint8 by location.  Returns out_logits (F,L,512) or None."""
+        region (F,L) uint8 by location.  waves: optional wavefront schedule for these orders and this first_step,
+        (cols device int32 (n,2), wave_start host int32 array) as from wavefronts() -- same results, far fewer
+        dependent launches.  Returns out_logits (F,L,512) or None."""
         F_ = codes.shape[0]
         _lib.require_cuda(codes, order, region, mask_init, mask_undilated, mask_dilated)
         assert codes.dtype == torch.int32 and codes.is_contiguous()
         out = torch.empty(F_, self.L, 512, dtype=torch.float32, device=codes.device) if want_logits else None
-        rc = _lib.lib().ps_pixelcnn_ar_run(
-            self.handle, _lib.ptr(codes), _lib.ptr(order), _lib.ptr(region), _lib.ptr(mask_init),
-            _lib.ptr(mask_undilated), _lib.ptr(mask_dilated), _lib.ptr(forced), _lib.ptr(uniforms),
-            float(temperature), F_, int(first_step), _lib.ptr(out), _lib.current_stream())
-        _lib.check(rc, "ps_pixelcnn_ar_run")
+        head = (self.handle, _lib.ptr(codes), _lib.ptr(order), _lib.ptr(region), _lib.ptr(mask_init),
+                _lib.ptr(mask_undilated), _lib.ptr(mask_dilated), _lib.ptr(forced), _lib.ptr(uniforms),
+                float(temperature), F_, int(first_step))
+        if waves is None or waves[0].shape[0] == 0:  # (nothing to walk: only the whole-grid pass runs)
+            rc = _lib.lib().ps_pixelcnn_ar_run(*head, _lib.ptr(out), _lib.current_stream())
+            _lib.check(rc, "ps_pixelcnn_ar_run")
+        else:
+            cols, wave_start = waves
+            _lib.require_cuda(cols)
+            assert cols.dtype == torch.int32 and wave_start.dtype == np.int32
+            rc = _lib.lib().ps_pixelcnn_ar_run_waves(*head, _lib.ptr(cols), _lib.ptr(wave_start), len(wave_start) - 1,
+                                                     _lib.ptr(out), _lib.current_stream())
+            _lib.check(rc, "ps_pixelcnn_ar_run_waves")
         return out
 
     def ar_step(self, codes, order, mask_init, mask_undilated, mask_dilated, step, first_step):
@@ -252,3 +262,22 @@ class OurPixelCNN(nn.Module):
                 if self.norm_us:
                     u = self.norm_us[g](u, mask=mask_dilated)
         return self.nin_out(F.elu(u))
+
+
+def wavefronts(order_host, H, W, first_step, device=None):
+    """Wavefront schedule of an AR run (ps_ar_wavefronts): order_host (F,L) int32 numpy array ->
+    (cols int32 (n,2) tensor on `device`, wave_start int32 numpy array of n_waves + 1 entries)."""
+    import ctypes
+    order_host = np.ascontiguousarray(order_host, np.int32)
+    F_, L = order_host.shape
+    n = F_ * (L - first_step)
+    cols = np.empty((max(n, 1), 2), np.int32)
+    wave_start = np.zeros(L - first_step + 1, np.int32)
+    nw = ctypes.c_int32(0)
+    rc = _lib.lib().ps_ar_wavefronts(_lib.ptr(order_host), F_, H, W, int(first_step), _lib.ptr(cols), _lib.ptr(wave_start),
+                                     ctypes.cast(ctypes.byref(nw), ctypes.c_void_p))
+    _lib.check(rc, "ps_ar_wavefronts")
+    cols_t = torch.from_numpy(cols[:n] if n else cols[:0])
+    if device is not None:
+        cols_t = cols_t.to(device, non_blocking=True)
+    return cols_t, np.ascontiguousarray(wave_start[:nw.value + 1])

@@ -64,6 +64,8 @@ def build_ar_plan(background_mask, G=32, device=None):
     up = lambda a: torch.from_numpy(a).to(device, non_blocking=True)
     plan = ARPlan(up(order_loc), up(region), up(masks[0]), up(masks[1]), up(masks[2]), int(first.value), order_loc, G)
     plan._n_sampled = region.sum(1).astype(int)
+    from .lmconv.model import wavefronts
+    plan.waves = wavefronts(order_loc, G, G, plan.first_step, device)   # (cols on the device, wave_start on the host)
     return plan
 
 
@@ -191,27 +193,43 @@ class ZbufferModelPts(nn.Module):
 
     # ---------------------------------------------------------------- batched hot path (C3/C4/C5)
     @torch.no_grad()
-    def outpaint_views(self, fs, depth, K, K_inv, input_RT, input_RTinv, output_RT, output_RTinv, codes,
-                       temperature=0.7, uniforms=None, forced=None):
-        """V independent novel views in one pass: reproject + splat (a2-a6), order + masks (a7-a9),
-        AR outpainting of the 32x32 code grid (a13, fused device loop).
-        fs (V,C,S,S), depth (V,1,S,S), cameras (V,4,4), codes (V,32,32) int (the VQ-VAE codes of the
-        reprojected view; synthetic in the benchmark).  Returns dict(gen_fs, background_mask, codes, plan)."""
+    def plan_views(self, fs, depth, K, K_inv, input_RT, input_RTinv, output_RT, output_RTinv):
+        """First half of outpaint_views: reproject + splat (a2-a6) on the current stream, then the host part -- the
+        background masks come back, generation orders, kernel masks and the wavefront schedule are built (a7-a9) and
+        uploaded.  Ends with everything the AR run needs resident on the device.
+        -> dict(gen_fs, background_mask, plan)."""
         gen_fs, background_mask = self.pts_transformer.forward_justpts(fs, depth, K, K_inv, input_RT, input_RTinv,
                                                                       output_RT, output_RTinv)
-        plan = build_ar_plan(background_mask, self.obs[1])
-        V = fs.shape[0]
+        return dict(gen_fs=gen_fs, background_mask=background_mask, plan=build_ar_plan(background_mask, self.obs[1]))
+
+    @torch.no_grad()
+    def outpaint_planned(self, planned, codes, temperature=0.7, uniforms=None, forced=None):
+        """Second half: AR outpainting of the 32x32 code grids (a13) of the views prepared by plan_views; asynchronous
+        on the current stream.  Adds `codes` (V,32,32) int32 to the dict and returns it."""
+        gen_fs, plan = planned["gen_fs"], planned["plan"]
+        V = gen_fs.shape[0]
         L = self.obs[1] * self.obs[2]
         if codes is None:  # z_buffermodel.py:345: the VQ-VAE top codes of the reprojected view
             codes = self.vqvae.encode_codes(gen_fs)
         c32 = codes.reshape(V, L).to(torch.int32).contiguous().clone()
         eng = self.outpaint2.engine(self.obs[1], self.obs[2], V)
         if forced is None and uniforms is None:
-            uniforms = torch.rand(V, L, device=fs.device, dtype=torch.float32)
+            uniforms = torch.rand(V, L, device=gen_fs.device, dtype=torch.float32)
         eng.ar_run(c32, plan.order_loc, plan.region, plan.mask_init, plan.mask_undilated, plan.mask_dilated,
-                   temperature=temperature, uniforms=uniforms, forced=forced, first_step=plan.first_step)
-        return dict(gen_fs=gen_fs, background_mask=background_mask, codes=c32.view(V, self.obs[1], self.obs[2]),
-                    plan=plan)
+                   temperature=temperature, uniforms=uniforms, forced=forced, first_step=plan.first_step, waves=plan.waves)
+        planned["codes"] = c32.view(V, self.obs[1], self.obs[2])
+        return planned
+
+    def outpaint_views(self, fs, depth, K, K_inv, input_RT, input_RTinv, output_RT, output_RTinv, codes,
+                       temperature=0.7, uniforms=None, forced=None):
+        """V independent novel views in one pass: reproject + splat (a2-a6), order + masks (a7-a9),
+        AR outpainting of the 32x32 code grid (a13, fused device loop).
+        fs (V,C,S,S), depth (V,1,S,S), cameras (V,4,4), codes (V,32,32) int (the VQ-VAE codes of the
+        reprojected view; synthetic in the benchmark).  Returns dict(gen_fs, background_mask, codes, plan).
+        Callers with several batches can overlap the host part of the next batch with the AR run of this one:
+        plan_views on a side stream while outpaint_planned runs (bench.py, driver.py do)."""
+        planned = self.plan_views(fs, depth, K, K_inv, input_RT, input_RTinv, output_RT, output_RTinv)
+        return self.outpaint_planned(planned, codes, temperature, uniforms, forced)
 
     # ---------------------------------------------------------------- reference-shaped single image path
     @torch.no_grad()
@@ -288,7 +306,7 @@ class ZbufferModelPts(nn.Module):
                 u = torch.rand(B, L, generator=torch.Generator(device="cpu").manual_seed(i)).to(codes.device)
             c = codes.reshape(B, L).to(torch.int32).contiguous().clone()
             eng.ar_run(c, plan.order_loc, plan.region, plan.mask_init, plan.mask_undilated, plan.mask_dilated,
-                       temperature=self.opt.temperature, uniforms=u.contiguous(), first_step=plan.first_step)
+                       temperature=self.opt.temperature, uniforms=u.contiguous(), first_step=plan.first_step, waves=plan.waves)
             img = self._decode_candidate(gen_fs, background_mask, c.view(B, G, self.obs[2]))
             imgs.append(img)
             if n > 1:

@@ -324,3 +324,39 @@ def test_other_grid_sizes(H, W):
     for b in range(F_):
         walked = order_loc[b][first:]
         assert np.array_equal(full[b][walked], got[b][walked])
+
+
+@pytest.mark.parametrize("F_,first", [(1, 512), (5, 320), (20, 600), (40, 900)])
+def test_ar_wavefront_schedule_is_bit_identical_to_the_walk(F_, first):
+    """The wavefront schedule (ps_ar_wavefronts + ps_pixelcnn_ar_run_waves: all columns of one dependency level in one
+    launch) must reproduce the position-by-position walk bit for bit -- sampled codes AND the logits each location was
+    decided from -- for frames with different orders, wave counts and first positions; waves larger than a launch's
+    column capacity (40 frames) are split."""
+    from pixelsynth_amd.lmconv.model import wavefronts
+    net = make_net(3)
+    eng = net.engine(32, 32, F_)
+    bgs = syn.background_masks(256)
+    names = ["right_half", "half_plus_island", "ragged", "all", "top_band"]
+    infos = [c_oracle.masks_for_background(bgs[names[b % 5]], 32) for b in range(F_)]
+    order_loc = np.stack([(i["order"][:, 0] * 32 + i["order"][:, 1]) for i in infos]).astype(np.int32)
+    reg = np.zeros((F_, 1024), np.uint8)
+    rs = np.random.RandomState(F_)
+    for b in range(F_):
+        walked = order_loc[b][first:]
+        reg[b, walked[rs.rand(walked.size) < 0.8]] = 1        # some walked positions stay observed, as in real views
+        reg[b, order_loc[b][first]] = 1
+    ms = [tt(np.concatenate([i[k] for i in infos])) for k in ("mask_init", "mask_undilated", "mask_dilated")]
+    codes0 = syn.codes(13, F_).reshape(F_, 1024).astype(np.int32)
+    u = tt(np.random.RandomState(8).rand(F_, 1024).astype(np.float32))
+    c_walk, c_wave = tt(codes0.copy()), tt(codes0.copy())
+    l_walk = eng.ar_run(c_walk, tt(order_loc), tt(reg), *ms, temperature=0.7, uniforms=u, first_step=first, want_logits=True)
+    eng.check()
+    waves = wavefronts(order_loc, 32, 32, first, DEV)
+    n_waves = len(waves[1]) - 1
+    assert waves[0].shape[0] == F_ * (1024 - first) and n_waves < (1024 - first) // 3
+    l_wave = eng.ar_run(c_wave, tt(order_loc), tt(reg), *ms, temperature=0.7, uniforms=u, first_step=first, want_logits=True,
+                        waves=waves)
+    eng.check()
+    assert torch.equal(c_walk, c_wave)
+    assert torch.equal(l_walk, l_wave)
+    assert (c_wave.cpu().numpy()[reg == 1] != codes0[reg == 1]).any()

@@ -201,3 +201,45 @@ def test_ar_sample_vs_reference_sample(golden_dir):
                                                  seed=int(fx["seed"]), max_steps=24)
     ref_codes = np.array([fx["final_codes"][i, j] for i, j in region[:24]])
     assert np.array_equal(chosen, ref_codes)
+
+
+def test_wavefront_schedule_respects_every_dependency():
+    """ps_ar_wavefronts (host): every walked column appears once; a column's wave is exactly one more than the latest
+    wave among the columns it reads (3x3 neighbours at dilation 1 and 2 that are earlier in the order, i.e. the open
+    taps of the three kernel masks), restated here with plain loops; and the schedule is far shallower than the walk."""
+    from pixelsynth_amd.lmconv.model import wavefronts
+    bgs = syn.background_masks(256)
+    names = ["right_half", "half_plus_island", "ragged", "all", "top_band"]
+    infos = [c_oracle.masks_for_background(bgs[n], 32) for n in names]
+    order_loc = np.stack([(i["order"][:, 0] * 32 + i["order"][:, 1]) for i in infos]).astype(np.int32)
+    G, L = 32, 1024
+    for first in (0, 320, 1000, 1024):
+        cols, wave_start = wavefronts(order_loc, G, G, first)
+        cols = cols.numpy()
+        assert cols.shape == (len(names) * (L - first), 2) and wave_start[0] == 0 and wave_start[-1] == cols.shape[0]
+        wave_of = {}
+        for w in range(len(wave_start) - 1):
+            for f, i in cols[wave_start[w]:wave_start[w + 1]]:
+                assert (f, i) not in wave_of
+                wave_of[(int(f), int(i))] = w
+        assert len(wave_of) == cols.shape[0]
+        for f in range(len(names)):
+            rank = np.empty(L, int)
+            rank[order_loc[f]] = np.arange(L)
+            masks = [infos[f][k].reshape(9, L) for k in ("mask_init", "mask_undilated", "mask_dilated")]
+            for i in range(first, L):
+                q = int(order_loc[f][i])
+                r, c = divmod(q, G)
+                dep = -1
+                for dil, mk in ((1, masks[0]), (1, masks[1]), (2, masks[2])):
+                    for t in range(9):
+                        rr, cc = r + (t // 3 - 1) * dil, c + (t % 3 - 1) * dil
+                        if t == 4 or not (0 <= rr < G and 0 <= cc < G):
+                            continue
+                        p = rr * G + cc
+                        assert (mk[t, q] != 0) == (rank[p] < i)          # open tap <=> earlier in the order
+                        if rank[p] < i and rank[p] >= first:
+                            dep = max(dep, wave_of[(f, int(rank[p]))])
+                assert wave_of[(f, i)] == dep + 1
+        if first == 320:
+            assert len(wave_start) - 1 < (L - first) // 4

@@ -29,10 +29,11 @@ for _ in range(N):
     c32 = d["codes"].reshape(V, 1024).to(torch.int32).contiguous().clone()
     eng = model.outpaint2.engine(32, 32, V)
     eng.ar_run(c32, plan.order_loc, plan.region, plan.mask_init, plan.mask_undilated, plan.mask_dilated,
-               temperature=0.7, uniforms=d["uniforms"], forced=None, first_step=plan.first_step)
+               temperature=0.7, uniforms=d["uniforms"], forced=None, first_step=plan.first_step,
+               waves=None if os.environ.get("PS_NO_WAVES") else plan.waves)
     torch.cuda.synchronize()
     t3 = time.perf_counter()
     acc[0] += t1 - t0
     acc[1] += t2 - t1
     acc[2] += t3 - t2
-print(f"V={V}: splat {acc[0] / N * 1e3:.3f} ms, plan {acc[1] / N * 1e3:.3f} ms, ar_run {acc[2] / N * 1e3:.3f} ms, first_step {plan.first_step}")
+print(f"V={V}: splat {acc[0] / N * 1e3:.3f} ms, plan {acc[1] / N * 1e3:.3f} ms, ar_run {acc[2] / N * 1e3:.3f} ms, first_step {plan.first_step}, waves {len(plan.waves[1]) - 1}, columns {plan.waves[0].shape[0]}")
