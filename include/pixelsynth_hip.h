@@ -235,7 +235,7 @@ int ps_pixelcnn_status(ps_pixelcnn *h, void *stream);
  * eagerly on `stream` (at position `step`, without drawing) with a HIP event pair around every kernel
  * launch and returns the number of launches and their summed duration in ms:
  *   [0] unused (0 launches; the neighbour taps had their own kernel before the single-launch column step)
- *   [1] k_column (one launch per order position: neighbour-tap slots of all 32 masked convs on MFMA +
+ *   [1] k_column (one launch per order position here: neighbour-tap slots of all 32 masked convs on MFMA +
  *       the per-frame centre-tap chains, post ops and draw)
  * flops_per_launch / weight_bytes_per_launch [2]: dense algorithmic work of one launch, split as
  *   [0] neighbour taps, [1] centre-tap chain (2*Co*Cin per tap and frame; fp32 weight bytes streamed once,
