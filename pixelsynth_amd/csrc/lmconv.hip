@@ -131,7 +131,7 @@ struct GemmArgs {
 template <int T>
 __device__ __forceinline__ void gemm_tiles(const GemmArgs &a, int o0, int slot, int first_tile)
 {
-    const int lane = threadIdx.x, i = lane & 15, kk = lane >> 4;
+    const int lane = threadIdx.x & 63, i = lane & 15, kk = lane >> 4;
     const int ngroups = a.Cin >> 4;
     const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
     for (int tt = 0; tt < a.tiles_per_block; ++tt) {
@@ -201,10 +201,14 @@ __device__ __forceinline__ void gemm_tiles(const GemmArgs &a, int o0, int slot, 
     }
 }
 
-// grid (ceil(Co_pad / 64), nslots, item blocks), one wave per block
+// grid (ceil(Co_pad / 64), item blocks, nslots), one wave per block.  Blocks are dispatched x fastest, z slowest, and a
+// wave of the four-tap slots NA / NB lives four times as long as one of the single-tap slots C / SKIP: the slot is the
+// slowest dimension, long slots first, so that the kernel's tail is made of short waves.
 __global__ __launch_bounds__(64) void k_gemm(GemmArgs a)
 {
-    const int o0 = blockIdx.x * 64, slot = blockIdx.y, first_tile = blockIdx.z * a.tiles_per_block;
+    const int z = blockIdx.z;
+    const int slot = z == 0 ? SLOT_NA : z == 1 && a.nslots > 2 ? SLOT_NB : z == 2 ? SLOT_C : z;  // (NA, NB, C, SKIP)
+    const int o0 = blockIdx.x * 64, first_tile = blockIdx.y * a.tiles_per_block;
     const int T = min(4, (a.Co_pad - o0) >> 4);
     if (T == 4) gemm_tiles<4>(a, o0, slot, first_tile);
     else if (T == 3) gemm_tiles<3>(a, o0, slot, first_tile);
@@ -557,13 +561,14 @@ __device__ __forceinline__ int xcd_slot(int b, int lo, int hi /*use XCDs lo .. h
 
 // one neighbour tap of one conv for 16 columns x 16 output channels, from fresh accumulators
 template <int NG>
-__device__ __forceinline__ f32x4 nbr_tap(const NbrWork &sd, const NbrArgs &a, int t, int o0, int col, bool valid, int i, int kk)
+__device__ __forceinline__ f32x4 nbr_tap(const NbrWork &sd, const NbrArgs &a, const StepCtx *recs, int t, int o0, int col, bool valid,
+                                         int i, int kk)
 {
     const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
     float mv = 0.0f;
     const float *src = nullptr;
     if (valid) {
-        const StepCtx &cx = a.ctx[col];
+        const StepCtx &cx = recs[col];
         const int q = cx.q, f = cx.f;
         const int r = q / a.W, c = q - r * a.W;
         const int rr = r + (t / 3 - 1) * sd.dil, cc = c + (t % 3 - 1) * sd.dil;
@@ -615,14 +620,31 @@ __device__ __forceinline__ void signal_done(unsigned *counter, int lane)
 // counter) once its write-through stores have left; that wait is folded into the NEXT round's wait for its operands
 // (vmcnt is in order), only the last round drains on its own.  The workgroups of a launch are all resident (at most
 // one per CU), so nothing here ever waits for another workgroup.
+// (Tried and dropped, each slower because the 128-register budget of a 1024-thread workgroup spills: fetching the next
+// round's records a round ahead; one wave per item with its four taps in sequence and no barrier; items of two column
+// tiles that keep the tap's weights in registers.)
 constexpr int NBR_MAX_GROUPS = 4;
+constexpr int NWORK_MAX = 512;  // work-table entries the neighbour role can stage (this network: 460)
 
 __device__ __forceinline__ void nbr_role(const NbrArgs &a, int nb)
 {
     __shared__ __attribute__((aligned(16))) float sNP[2][NBR_MAX_GROUPS][4][16][20];
+    // the launch's column records and the work table, staged once: a round then starts with two LDS reads instead of
+    // two dependent trips to memory (work record -> column record) before its operands can even be requested
+    __shared__ __attribute__((aligned(16))) StepCtx sCtx[COL_CAP];
+    __shared__ __attribute__((aligned(16))) NbrWork sWork[NWORK_MAX];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, kk = lane >> 4;
     const int grp4 = wave >> 2, w4 = wave & 3;
-    if (nb >= a.nbr_wgs || grp4 >= a.groups) return;  // (leave before any barrier: it only counts live waves)
+    if (nb >= a.nbr_wgs) return;
+    {
+        const int nc = a.ncols * (int)(sizeof(StepCtx) / 16), nw = a.nwork * (int)(sizeof(NbrWork) / 16);
+        for (int k = threadIdx.x; k < nc + nw; k += (int)blockDim.x) {
+            if (k < nc) ((uint4 *)sCtx)[k] = ((const uint4 *)a.ctx)[k];
+            else ((uint4 *)sWork)[k - nc] = ((const uint4 *)a.work)[k - nc];
+        }
+        __syncthreads();
+    }
+    if (grp4 >= a.groups) return;  // (leave before the next barrier: it only counts live waves)
     const int nitems = a.nwork * a.tiles, per_round = a.nbr_wgs * a.groups;
     unsigned *pending = nullptr;  // counter of the item this group finished in the previous round, not yet published
     for (int base = 0; base < nitems; base += per_round) {
@@ -633,12 +655,12 @@ __device__ __forceinline__ void nbr_role(const NbrArgs &a, int nb)
         int col = 0;
         bool valid = false;
         if (active) {
-            wk = a.work[witem];
+            wk = sWork[witem];
             col = ctile * 16 + i;
             valid = col < a.ncols;
             const int t = wk.half * 5 + w4;  // taps 0..3 (NA) or 5..8 (NB)
-            const f32x4 part = wk.NG == 10 ? nbr_tap<10>(wk, a, t, wk.cog * 16, col, valid, i, kk)
-                                           : nbr_tap<5>(wk, a, t, wk.cog * 16, col, valid, i, kk);
+            const f32x4 part = wk.NG == 10 ? nbr_tap<10>(wk, a, sCtx, t, wk.cog * 16, col, valid, i, kk)
+                                           : nbr_tap<5>(wk, a, sCtx, t, wk.cog * 16, col, valid, i, kk);
             *(f32x4 *)(&sNP[par][grp4][w4][i][kk * 4]) = part;
         }
         if (w4 == 0 && pending) {  // the operands of this round have arrived, so the older stores have left too
@@ -1431,7 +1453,7 @@ void run_grid(ps_pixelcnn *h, int F, const int32_t *codes, const Masks &m, float
         a.H = h->H; a.W = h->W; a.L = h->L; a.nitems = nitems;
         a.mask = mask; a.mask_fstride = (size_t)9 * h->L; a.partial = h->partial; a.tiles_per_block = 1;
         const int tiles = (nitems + 15) / 16;
-        hipLaunchKernelGGL(k_gemm, dim3((a.Co_pad + 63) / 64, a.nslots, tiles), dim3(64), 0, st, a);
+        hipLaunchKernelGGL(k_gemm, dim3((a.Co_pad + 63) / 64, tiles, a.nslots), dim3(64), 0, st, a);
     };
     {   // u_init + norm_init  (model.py:132)
         UinitArgs u{items, codes, m.init, h->uinit_w, h->uinit_b, h->R[0], h->E[0], h->H, h->W, h->L, nitems};
@@ -1568,6 +1590,7 @@ int build_stage_table(ps_pixelcnn *h)
     if (int rc = dev_alloc(h, &h->work, work.size())) return rc;
     PS_HIP_CHECK(hipMemcpy(h->work, work.data(), work.size() * sizeof(NbrWork), hipMemcpyHostToDevice));
     h->nwork = (int)work.size();
+    PS_REQUIRE(h->nwork <= NWORK_MAX, "pixelcnn: %d neighbour work entries exceed the staging table", h->nwork);
     return PS_OK;
 }
 
@@ -1941,7 +1964,7 @@ int ps_lmconv_forward_f32(const float *x, const float *mask, size_t mask_batch_s
     a.H = H; a.W = W; a.L = L; a.nitems = B * L; a.mask = mask; a.mask_fstride = mask_batch_stride;
     a.partial = partial; a.tiles_per_block = 2;
     const int tiles = (a.nitems + 15) / 16;
-    hipLaunchKernelGGL(k_gemm, dim3((Cop + 63) / 64, a.nslots, (tiles + 1) / 2), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(k_gemm, dim3((Cop + 63) / 64, (tiles + 1) / 2, a.nslots), dim3(64), 0, st, a);
     hipLaunchKernelGGL(k_reduce_nchw, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, st, partial, bias, B, Co, Cop, L, y);
     PS_LAUNCH_CHECK();
     return PS_OK;
