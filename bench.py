@@ -102,10 +102,7 @@ def run_steps(model, d, world, n, side):
         if i + 1 < n:
             with torch.cuda.stream(side):
                 planned = front(model, d)
-            for v in (planned["gen_fs"], planned["background_mask"], planned["plan"].order_loc, planned["plan"].region,
-                      planned["plan"].mask_init, planned["plan"].mask_undilated, planned["plan"].mask_dilated,
-                      planned["plan"].waves[0]):
-                v.record_stream(main)
+            model.adopt_planned(planned, main)
             main.wait_stream(side)
     return out
 

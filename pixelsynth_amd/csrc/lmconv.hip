@@ -204,15 +204,22 @@ __device__ __forceinline__ void gemm_tiles(const GemmArgs &a, int o0, int slot, 
 // grid (ceil(Co_pad / 64), item blocks, nslots), one wave per block.  Blocks are dispatched x fastest, z slowest, and a
 // wave of the four-tap slots NA / NB lives four times as long as one of the single-tap slots C / SKIP: the slot is the
 // slowest dimension, long slots first, so that the kernel's tail is made of short waves.
+// 16-channel output tiles per wave: 2 (with four waves per SIMD) measured best -- 4: 55.7 us, 2: 51.1, 2 at four waves per
+// SIMD: 49.3, 1: 60.2 us per launch at 16 frames
+#ifndef PS_GEMM_T
+#define PS_GEMM_T 2
+#endif
+constexpr int GEMM_T = PS_GEMM_T;
+__attribute__((amdgpu_waves_per_eu(4, 4)))
 __global__ __launch_bounds__(64) void k_gemm(GemmArgs a)
 {
     const int z = blockIdx.z;
     const int slot = z == 0 ? SLOT_NA : z == 1 && a.nslots > 2 ? SLOT_NB : z == 2 ? SLOT_C : z;  // (NA, NB, C, SKIP)
-    const int o0 = blockIdx.x * 64, first_tile = blockIdx.y * a.tiles_per_block;
-    const int T = min(4, (a.Co_pad - o0) >> 4);
-    if (T == 4) gemm_tiles<4>(a, o0, slot, first_tile);
-    else if (T == 3) gemm_tiles<3>(a, o0, slot, first_tile);
-    else if (T == 2) gemm_tiles<2>(a, o0, slot, first_tile);
+    const int o0 = blockIdx.x * 16 * GEMM_T, first_tile = blockIdx.y * a.tiles_per_block;
+    const int T = min(GEMM_T, (a.Co_pad - o0) >> 4);
+    if (GEMM_T >= 4 && T == 4) gemm_tiles<4>(a, o0, slot, first_tile);
+    else if (GEMM_T >= 3 && T == 3) gemm_tiles<3>(a, o0, slot, first_tile);
+    else if (GEMM_T >= 2 && T == 2) gemm_tiles<2>(a, o0, slot, first_tile);
     else gemm_tiles<1>(a, o0, slot, first_tile);
 }
 
@@ -1453,7 +1460,7 @@ void run_grid(ps_pixelcnn *h, int F, const int32_t *codes, const Masks &m, float
         a.H = h->H; a.W = h->W; a.L = h->L; a.nitems = nitems;
         a.mask = mask; a.mask_fstride = (size_t)9 * h->L; a.partial = h->partial; a.tiles_per_block = 1;
         const int tiles = (nitems + 15) / 16;
-        hipLaunchKernelGGL(k_gemm, dim3((a.Co_pad + 63) / 64, tiles, a.nslots), dim3(64), 0, st, a);
+        hipLaunchKernelGGL(k_gemm, dim3((a.Co_pad + 16 * GEMM_T - 1) / (16 * GEMM_T), tiles, a.nslots), dim3(64), 0, st, a);
     };
     {   // u_init + norm_init  (model.py:132)
         UinitArgs u{items, codes, m.init, h->uinit_w, h->uinit_b, h->R[0], h->E[0], h->H, h->W, h->L, nitems};
@@ -1964,7 +1971,7 @@ int ps_lmconv_forward_f32(const float *x, const float *mask, size_t mask_batch_s
     a.H = H; a.W = W; a.L = L; a.nitems = B * L; a.mask = mask; a.mask_fstride = mask_batch_stride;
     a.partial = partial; a.tiles_per_block = 2;
     const int tiles = (a.nitems + 15) / 16;
-    hipLaunchKernelGGL(k_gemm, dim3((Cop + 63) / 64, (tiles + 1) / 2, a.nslots), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(k_gemm, dim3((Cop + 16 * GEMM_T - 1) / (16 * GEMM_T), (tiles + 1) / 2, a.nslots), dim3(64), 0, st, a);
     hipLaunchKernelGGL(k_reduce_nchw, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, st, partial, bias, B, Co, Cop, L, y);
     PS_LAUNCH_CHECK();
     return PS_OK;

@@ -106,6 +106,40 @@ def scene_outputs_to_disk(outputs, directions, num_split, out_dir):
     return n
 
 
+@torch.no_grad()
+def render_pipelined(model, img, depth, cam, chunks, seeds, temperature=0.7):
+    """render_views for several batches of poses, with the host half of batch i + 1 (splat on a side stream, masks back,
+    orders / masks / wavefront schedule, uploads) overlapped with the AR run of batch i.  -> list of frames (V_i,3,S,S)."""
+    main, side = torch.cuda.current_stream(), torch.cuda.Stream()
+
+    def inputs(chunk):
+        V = len(chunk)
+        rep = lambda t: t.expand(V, *t.shape[1:]).contiguous()
+        return (rep(img), rep(depth), rep(cam["K"]), rep(cam["Kinv"]), rep(cam["P"]), rep(cam["Pinv"]),
+                torch.cat([p[2] for p in chunk]).contiguous(), torch.cat([p[1] for p in chunk]).contiguous())
+
+    frames, planned = [], None
+    for k, chunk in enumerate(chunks):
+        if planned is None:
+            planned = model.plan_views(*inputs(chunk))
+        V = len(chunk)
+        uniforms = torch.rand(V, 1024, generator=torch.Generator(device="cpu").manual_seed(seeds[k])).to(img.device)
+        out = model.outpaint_planned(planned, None, temperature=temperature, uniforms=uniforms)
+        planned = None
+        if k + 1 < len(chunks):
+            if k == 0:
+                side.wait_stream(main)      # (the shared inputs were produced on the main stream)
+            with torch.cuda.stream(side):
+                planned = model.plan_views(*inputs(chunks[k + 1]))
+            model.adopt_planned(planned, main)
+            main.wait_stream(side)
+        sample = model.vqvae.decode_code(out["codes"])
+        frames.append(model.get_combined(out["gen_fs"], sample, out["background_mask"]))
+    if chunks:
+        model.outpaint2.engine(32, 32, len(chunks[-1])).check()
+    return frames
+
+
 def save_png(path, chw):
     """chw: (3,S,S) uint8 image, or float in [-1, 1]."""
     from PIL import Image
@@ -162,10 +196,8 @@ def main(argv=None):
     kind = "circle" if args.trajectory == "circle" else args.trajectory
     poses = trajectory(model, cam["P"], kind, args.frames)
     mine = D.shard_views(len(poses), rank, world)
-    frames = []
-    for s in range(0, len(mine), args.batch):
-        chunk = [poses[i] for i in mine[s:s + args.batch]]
-        frames.append(render_views(model, img, depth, cam, chunk, seed=rank * 1000 + s)["frames"])
+    frames = render_pipelined(model, img, depth, cam, [[poses[i] for i in mine[s:s + args.batch]] for s in range(0, len(mine), args.batch)],
+                              seeds=[rank * 1000 + s for s in range(0, len(mine), args.batch)])
     local_frames = D.to_image_u8(torch.cat(frames)) if frames else torch.empty(0, 3, 256, 256, dtype=torch.uint8, device=device)
     per_rank = (len(poses) + world - 1) // world                         # gather_frames wants equal shards: pad the last round
     if local_frames.shape[0] < per_rank:

@@ -202,6 +202,16 @@ class ZbufferModelPts(nn.Module):
                                                                       output_RT, output_RTinv)
         return dict(gen_fs=gen_fs, background_mask=background_mask, plan=build_ar_plan(background_mask, self.obs[1]))
 
+    @staticmethod
+    def adopt_planned(planned, stream):
+        """A plan made on a side stream is about to be consumed on `stream`: tell the caching allocator, so that the
+        plan's buffers are not recycled on the side stream while work queued on `stream` still reads them."""
+        plan = planned["plan"]
+        for t in (planned["gen_fs"], planned["background_mask"], plan.order_loc, plan.region, plan.mask_init,
+                  plan.mask_undilated, plan.mask_dilated, plan.waves[0]):
+            if t.numel():
+                t.record_stream(stream)
+
     @torch.no_grad()
     def outpaint_planned(self, planned, codes, temperature=0.7, uniforms=None, forced=None):
         """Second half: AR outpainting of the 32x32 code grids (a13) of the views prepared by plan_views; asynchronous

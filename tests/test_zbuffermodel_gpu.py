@@ -329,3 +329,28 @@ def test_forward_image_with_every_network_in_the_loop():
     assert float(out["PredImg"].abs().max()) <= 1.0          # tanh
     bg = out["ForegroundImg"][0, 0] == 0
     assert 0.2 < float(bg.float().mean()) < 0.9
+
+
+def test_plan_views_then_outpaint_planned_equals_outpaint_views_also_across_streams():
+    """The two halves of outpaint_views (host planning / device AR run) are what bench.py and the driver overlap across
+    batches: planning on a side stream while another AR run is in flight must give the same views."""
+    m = make_model()
+    V = 3
+    cam = syn.demo_cameras(V)
+    img, depth = tt(syn.image(51, V, 3, 256)), tt(syn.depth_smooth(52, V, 256, 1.0, 100.0))
+    rts = [syn.yaw_pose(cam["P"][v:v + 1], y) for v, y in enumerate((0.6, -0.3, 0.45))]
+    RT2, RT2inv = tt(np.concatenate([r[1] for r in rts])), tt(np.concatenate([r[0] for r in rts]))
+    codes, uni = tt(syn.codes(53, V)), tt(np.random.RandomState(54).rand(V, 1024).astype(np.float32))
+    args = (img, depth, tt(cam["K"]), tt(cam["Kinv"]), tt(cam["P"]), tt(cam["Pinv"]), RT2, RT2inv)
+    ref = m.outpaint_views(*args, codes, temperature=0.7, uniforms=uni)
+    ref_codes = ref["codes"].clone()
+    side, main = torch.cuda.Stream(), torch.cuda.current_stream()
+    busy = m.outpaint_planned(m.plan_views(*args), codes, temperature=0.7, uniforms=uni)      # an AR run in flight ...
+    with torch.cuda.stream(side):
+        planned = m.plan_views(*args)                                                        # ... while the next is planned
+    main.wait_stream(side)
+    out = m.outpaint_planned(planned, codes, temperature=0.7, uniforms=uni)
+    torch.cuda.synchronize()
+    m.outpaint2.engine(32, 32, V).check()
+    assert torch.equal(out["codes"], ref_codes) and torch.equal(busy["codes"], ref_codes)
+    assert torch.equal(out["gen_fs"], ref["gen_fs"]) and torch.equal(out["background_mask"], ref["background_mask"])
