@@ -786,6 +786,9 @@ __device__ __forceinline__ void valu_chain(const f32x4 *w /*4 * NGL steps*/, con
     }
 }
 
+#ifndef PS_WSPLIT
+#define PS_WSPLIT 3
+#endif
 #define PS_WLOAD(p) (*PS_GC(f32x4, p))  // (nontemporal loads were measured 40 % slower: they lose the L2 residency)
 // Always EXACTLY eight loads, whatever the stage and thread: s_waitcnt counts are static, so a path that issued
 // fewer loads than another would force the compiler to wait for everything (vmcnt(0)) before the chain that
@@ -800,6 +803,16 @@ __device__ __forceinline__ void load_chain_weights(const float *wv, int nchain, 
     for (int st = 0; st < 4; ++st) w[st] = PS_WLOAD(base + st * stride);
 #pragma unroll
     for (int st = 0; st < 4; ++st) w[4 + st] = PS_WLOAD(hi + st * stride);
+}
+// the same fetch in two instalments, loads [LO, HI) of the eight (see chain_stage)
+template <int LO, int HI>
+__device__ __forceinline__ void load_chain_weights_part(const float *wv, int nchain, int nstep, int t, f32x4 (&w)[8])
+{
+    const float *base = wv + (size_t)min(t, nchain - 1) * 4;
+    const size_t stride = (size_t)nchain * 4;
+    const float *hi = nstep == 8 ? base + 4 * stride : base;
+#pragma unroll
+    for (int st = LO; st < HI; ++st) w[st] = PS_WLOAD((st < 4 ? base : hi) + (st & 3) * stride);
 }
 
 // Control record of one stage for the chain role, C1_CTL_DWORDS dwords in constant memory: record 0 describes the u0
@@ -1175,9 +1188,13 @@ __device__ __forceinline__ void chain_role(const ChainArgs &a, int wg)
         // Three weight buffers: the fetch for stage s + 2 is issued between the barriers of stage s (under the post
         // op), so it has a whole stage to land and the chain of stage s + 1 never waits for memory.
         f32x4 wA[8], wB[8], wC[8];
+        constexpr int WSPLIT = PS_WSPLIT;  // loads of a stage's eight that are issued ahead of the chains
         ChainCtl cc = load_chain_ctl(a.ctl1, 1), cn = load_chain_ctl(a.ctl1, 2), cnn = load_chain_ctl(a.ctl1, 3), c3 = cnn;
         auto chain_stage = [&](int s, const f32x4 (&wcur)[8], f32x4 (&wnn)[8], auto fetch, auto last) {
             PS_TRACE1(t == 0, 5);
+            // first instalment of the fetch for stage s + 2: the queue is empty now (the second instalment of the
+            // previous stage went out under its post op), so these issue while the chains below run
+            if (fetch) load_chain_weights_part<0, WSPLIT>(cnn.wv, cnn.nchain, cnn.nstep, t, wnn);
             if (t < cc.nchain) {
                 const bool main = cc.Co == 2 * NF || q80 < 5;
                 const int j = cc.Co == 2 * NF ? j160 : j80;
@@ -1196,7 +1213,7 @@ __device__ __forceinline__ void chain_role(const ChainArgs &a, int wg)
             // of the control record three stages ahead (it shares lgkmcnt with the LDS reads of the chain).
             if (fetch) {
                 c3 = load_chain_ctl(a.ctl1, 4 + s);  // (records past NST - 1 are rotated in but never used as stages)
-                load_chain_weights(cnn.wv, cnn.nchain, cnn.nstep, t, wnn);
+                load_chain_weights_part<WSPLIT, 8>(cnn.wv, cnn.nchain, cnn.nstep, t, wnn);
             }
             if (last) load_out_weights();
             lds_barrier();
