@@ -551,6 +551,7 @@ struct NbrArgs {
     unsigned *cnt;        // [NST][MAX_TILES] padded completion counters of this handle: work items done, ever (cnt_index)
     int nbr_wgs, groups;  // neighbour-role workgroups of the launch; work items each of them runs at a time (2 or 4)
     int debug;            // tuning only
+    int *err;             // set to 1 if a bounded wait ran out (ps_pixelcnn_status)
 };
 
 // XCD affinity, for speed only (nothing depends on it): workgroup b of a launch runs on XCD b % 8, each XCD with
@@ -640,10 +641,12 @@ __device__ __forceinline__ void nbr_role(const NbrArgs &a, int nb)
     // two dependent trips to memory (work record -> column record) before its operands can even be requested
     __shared__ __attribute__((aligned(16))) StepCtx sCtx[COL_CAP];
     __shared__ __attribute__((aligned(16))) NbrWork sWork[NWORK_MAX];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, kk = lane >> 4;
+    __shared__ unsigned sArr[2][NBR_MAX_GROUPS], sRd[NBR_MAX_GROUPS];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, i = lane & 15, kk = lane >> 4;
     const int grp4 = wave >> 2, w4 = wave & 3;
     if (nb >= a.nbr_wgs) return;
     {
+        if (threadIdx.x < NBR_MAX_GROUPS) { sArr[0][threadIdx.x] = 0; sArr[1][threadIdx.x] = 0; sRd[threadIdx.x] = 0; }
         const int nc = a.ncols * (int)(sizeof(StepCtx) / 16), nw = a.nwork * (int)(sizeof(NbrWork) / 16);
         for (int k = threadIdx.x; k < nc + nw; k += (int)blockDim.x) {
             if (k < nc) ((uint4 *)sCtx)[k] = ((const uint4 *)a.ctx)[k];
@@ -651,40 +654,57 @@ __device__ __forceinline__ void nbr_role(const NbrArgs &a, int nb)
         }
         __syncthreads();
     }
-    if (grp4 >= a.groups) return;  // (leave before the next barrier: it only counts live waves)
+    if (grp4 >= a.groups) return;
+    // From here on the four waves of a group only synchronise with each other, through two monotone LDS counters (no
+    // workgroup barrier: the groups drift apart, so one group's MFMAs run under another group's operand fetches instead
+    // of all sixteen waves fetching, multiplying and exchanging in lock-step):
+    //   sArr[r & 1][g]  partials the tap waves 1..3 have written in rounds of that parity (3 per round; per parity,
+    //            because a tap wave may be one round ahead of wave 0); wave 0 adds up round r once it reads 3 (r / 2 + 1);
+    //   sRd[g]   rounds wave 0 has consumed; a tap wave reuses exchange buffer r & 1 once rounds <= r - 2 are consumed.
+    // Every wait is bounded (a lost wave sets the handle's error flag instead of hanging the GPU).
     const int nitems = a.nwork * a.tiles, per_round = a.nbr_wgs * a.groups;
     unsigned *pending = nullptr;  // counter of the item this group finished in the previous round, not yet published
+    auto spin_until = [&](const unsigned *flag, unsigned want) {
+        int spins = 0;
+        while ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - want) < 0) {
+            if (++spins > (1 << 22)) { if (lane == 0) *a.err = 1; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    };
+    unsigned r = 0;  // rounds this group has worked on
     for (int base = 0; base < nitems; base += per_round) {
-        const int item = base + nb * a.groups + grp4, par = (base / per_round) & 1;
-        const bool active = item < nitems;
-        const int witem = active ? item / a.tiles : 0, ctile = active ? item - witem * a.tiles : 0;
-        NbrWork wk{};
-        int col = 0;
-        bool valid = false;
-        if (active) {
-            wk = sWork[witem];
-            col = ctile * 16 + i;
-            valid = col < a.ncols;
-            const int t = wk.half * 5 + w4;  // taps 0..3 (NA) or 5..8 (NB)
-            const f32x4 part = wk.NG == 10 ? nbr_tap<10>(wk, a, sCtx, t, wk.cog * 16, col, valid, i, kk)
-                                           : nbr_tap<5>(wk, a, sCtx, t, wk.cog * 16, col, valid, i, kk);
+        const int item = base + nb * a.groups + grp4;
+        if (item >= nitems) break;  // (the four waves of a group agree)
+        const int witem = item / a.tiles, ctile = item - witem * a.tiles, par = r & 1;
+        const NbrWork wk = sWork[witem];
+        const int col = ctile * 16 + i;
+        const bool valid = col < a.ncols;
+        const int t = wk.half * 5 + w4;  // taps 0..3 (NA) or 5..8 (NB)
+        const f32x4 part = wk.NG == 10 ? nbr_tap<10>(wk, a, sCtx, t, wk.cog * 16, col, valid, i, kk)
+                                       : nbr_tap<5>(wk, a, sCtx, t, wk.cog * 16, col, valid, i, kk);
+        if (w4 != 0) {
+            if (r >= 2) spin_until(&sRd[grp4], r - 1);
             *(f32x4 *)(&sNP[par][grp4][w4][i][kk * 4]) = part;
-        }
-        if (w4 == 0 && pending) {  // the operands of this round have arrived, so the older stores have left too
-            signal_done(pending, lane);
-            pending = nullptr;
-        }
-        __syncthreads();
-        if (active && w4 == 0) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_fetch_add(&sArr[par][grp4], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+            if (pending) {  // the operands of this round have arrived, so the older stores have left too
+                signal_done(pending, lane);
+                pending = nullptr;
+            }
+            spin_until(&sArr[par][grp4], 3 * (r / 2 + 1));
             if (valid) {
                 const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
-                f32x4 tot = zero;
+                f32x4 tot = zero + part;
 #pragma unroll
-                for (int w = 0; w < 4; ++w) tot = tot + *(const f32x4 *)(&sNP[par][grp4][w][i][kk * 4]);
+                for (int w = 1; w < 4; ++w) tot = tot + *(const f32x4 *)(&sNP[par][grp4][w][i][kk * 4]);
                 store_through(a.nbr + (((size_t)wk.stage * 2 + wk.half) * a.col_stride + col) * NBR_LD + wk.cog * 16 + kk * 4, tot);
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_store(&sRd[grp4], r + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             pending = a.cnt + cnt_index(wk.stage, ctile);
         }
+        ++r;
     }
     if (w4 == 0 && pending) signal_done(pending, lane);
 }
@@ -1638,7 +1658,7 @@ void run_columns(ps_pixelcnn *h, const StepCtx *rec, int ncols, const int32_t *c
         const int nbr_cus = chain_rows * (8 - cx) + (32 - chain_rows) * 8;
         const int groups = nitems > 2 * nbr_cus ? 4 : 2;
         const int nbr_wgs = std::min(nbr_cus, (nitems + groups - 1) / groups);
-        NbrArgs na{h->work, rec + done, h->nbr, h->nwork, h->H, h->W, h->L, n, COL_CAP, tiles, cx, h->cnt, nbr_wgs, groups, ca.debug};
+        NbrArgs na{h->work, rec + done, h->nbr, h->nwork, h->H, h->W, h->L, n, COL_CAP, tiles, cx, h->cnt, nbr_wgs, groups, ca.debug, h->err};
         ca.ctx = rec + done; ca.ncols = n;
         for (int t = 0; t < tiles; ++t) h->tile_uses[t] += 1;
         for (int t = 0; t < MAX_TILES; ++t) ca.tile_uses[t] = h->tile_uses[t];
