@@ -484,11 +484,16 @@ __device__ __forceinline__ int ctx_nbr_loc(int q, int t, int H, int W)
 
 // records of `ncols` columns: cols = (frame, order position) pairs in schedule order, or null for the plain walk
 // (column k = frame k % F at position first + k / F)
-__global__ __launch_bounds__(32) void k_ctx_build(CtxArgs a, const int32_t *cols, int ncols, int first, int H, int W)
+__global__ __launch_bounds__(32) void k_ctx_build(CtxArgs a, const int32_t *cols, int ncols, int first, int H, int W, int *err)
 {
     const int k = blockIdx.x, t = threadIdx.x;
     if (k >= ncols) return;
-    const int f = cols ? cols[2 * k] : k % a.F, i = cols ? cols[2 * k + 1] : first + k / a.F;
+    int f = cols ? cols[2 * k] : k % a.F, i = cols ? cols[2 * k + 1] : first + k / a.F;
+    if (f < 0 || f >= a.F || i < first || i >= a.L) {  // a schedule that does not belong to this run: flag it, stay in bounds
+        if (t == 0) *err = 2;
+        f = 0;
+        i = first;
+    }
     StepCtx *c = a.ctx + k;
     const int q = a.order[(size_t)f * a.L + i];
     if (t < 27) c->m[t / 9][t % 9] = a.mask[t / 9][((size_t)f * 9 + t % 9) * a.L + q];
@@ -1427,6 +1432,7 @@ struct ps_pixelcnn {
     int nwork = 0;
     int col_cap = COL_CAP;          // columns per launch (PS_COL_CAP: tuning)
     int chain_xcds = 0;             // PS_CHAIN_XCDS: tuning (0 = automatic)
+    int force_groups = 0;           // PS_NBR_GROUPS: tuning (0 = automatic)
     // bench.py profiling aid (ps_pixelcnn_time_column_step): event pair around every launch, by kernel tag
     struct ProfRec { int tag; hipEvent_t e0, e1; };
     std::vector<ProfRec> *prof = nullptr;
@@ -1656,7 +1662,7 @@ void run_columns(ps_pixelcnn *h, const StepCtx *rec, int ncols, const int32_t *c
         const int cx = h->chain_xcds > 0 ? std::min(8, std::max(h->chain_xcds, (n + 31) / 32)) : std::min(4, (n + 31) / 32);
         const int chain_rows = (n + cx - 1) / cx;
         const int nbr_cus = chain_rows * (8 - cx) + (32 - chain_rows) * 8;
-        const int groups = nitems > 2 * nbr_cus ? 4 : 2;
+        const int groups = h->force_groups ? h->force_groups : (nitems > 2 * nbr_cus ? 4 : 2);
         const int nbr_wgs = std::min(nbr_cus, (nitems + groups - 1) / groups);
         NbrArgs na{h->work, rec + done, h->nbr, h->nwork, h->H, h->W, h->L, n, COL_CAP, tiles, cx, h->cnt, nbr_wgs, groups, ca.debug, h->err};
         ca.ctx = rec + done; ca.ncols = n;
@@ -1699,6 +1705,7 @@ int ps_pixelcnn_create(const float *const *params, int n_params, int H, int W, i
     h->H = H; h->W = W; h->L = H * W; h->maxF = max_frames;
     if (const char *cc = getenv("PS_COL_CAP")) h->col_cap = std::max(1, std::min(COL_CAP, atoi(cc)));
     if (const char *cc = getenv("PS_CHAIN_XCDS")) h->chain_xcds = std::max(0, std::min(8, atoi(cc)));
+    if (const char *cc = getenv("PS_NBR_GROUPS")) h->force_groups = std::max(0, std::min(NBR_MAX_GROUPS, atoi(cc)));
     int rc = PS_OK;
     auto fail_out = [&](int code) { ps_pixelcnn_destroy(h); return code; };
 
@@ -1803,7 +1810,7 @@ int ps_pixelcnn_ar_step(ps_pixelcnn *h, const int32_t *codes, const int32_t *ord
     if (step == first_step) run_grid(h, F, codes, m, nullptr, false, st, order, first_step);
     ChainArgs ca{};
     hipLaunchKernelGGL(k_ctx_build, dim3(F), dim3(32), 0, st, make_ctx_args(h, order, m, F), (const int32_t *)nullptr, F, step,
-                       h->H, h->W);
+                       h->H, h->W, h->err);
     ca.step_logits = logits;
     ca.temperature = 1.0f;
     run_columns(h, h->ctx, F, codes, ca, st);
@@ -1844,7 +1851,7 @@ static int ar_run_impl(ps_pixelcnn *h, int32_t *codes, const int32_t *order, con
     const int total = F * nsteps;
     if (total > 0)
         hipLaunchKernelGGL(k_ctx_build, dim3(total), dim3(32), 0, st, make_ctx_args(h, order, m, F), wave_cols, total, first_step,
-                           h->H, h->W);
+                           h->H, h->W, h->err);
     PS_LAUNCH_CHECK();
     // launches are enqueued eagerly: the host stays far ahead of the GPU (a hipGraph replay was measured slower, and
     // the completion-counter target changes with every launch anyway)
@@ -1911,6 +1918,8 @@ int ps_pixelcnn_status(ps_pixelcnn *h, void *stream)
     PS_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
     int flag = 0;
     PS_HIP_CHECK(hipMemcpy(&flag, h->err, sizeof(int), hipMemcpyDeviceToHost));
+    if (flag) PS_HIP_CHECK(hipMemset(h->err, 0, sizeof(int)));  // reported once; the handle stays usable
+    if (flag == 2) return ps::fail(PS_ERR_STATE, "pixelcnn: the wavefront schedule names columns outside this run");
     if (flag) return ps::fail(PS_ERR_STATE, "pixelcnn: a bounded in-launch wait ran out (neighbour slots never arrived)");
     return PS_OK;
 }
@@ -1930,7 +1939,7 @@ int ps_pixelcnn_time_column_step(ps_pixelcnn *h, const int32_t *codes, const int
     ca.step_logits = h->col_logits;
     ca.temperature = 1.0f;
     hipLaunchKernelGGL(k_ctx_build, dim3(F), dim3(32), 0, st, make_ctx_args(h, order, Masks{mask_init, mask_undilated, mask_dilated}, F),
-                       (const int32_t *)nullptr, F, step, h->H, h->W);
+                       (const int32_t *)nullptr, F, step, h->H, h->W, h->err);
     run_columns(h, h->ctx, F, codes, ca, st);  // untimed warm-up
     if (const char *tp = getenv("PS_CHAIN_TRACE")) {  // tuning aid: per-stage shader-clock stamps of workgroup 0
         unsigned long long *d = nullptr;

@@ -360,3 +360,28 @@ def test_ar_wavefront_schedule_is_bit_identical_to_the_walk(F_, first):
     assert torch.equal(c_walk, c_wave)
     assert torch.equal(l_walk, l_wave)
     assert (c_wave.cpu().numpy()[reg == 1] != codes0[reg == 1]).any()
+
+
+def test_ar_run_waves_rejects_a_schedule_of_another_run():
+    """The host checks the schedule's shape (column count, monotone wave_start); entries that name frames / positions
+    outside the run are caught on the device and reported by check(), without touching memory out of bounds."""
+    from pixelsynth_amd.lmconv.model import wavefronts
+    net = make_net(3)
+    F_, first = 2, 1000
+    eng = net.engine(32, 32, F_)
+    info = c_oracle.masks_for_background(syn.background_masks(256)["right_half"], 32)
+    order_loc = np.stack([(info["order"][:, 0] * 32 + info["order"][:, 1])] * F_).astype(np.int32)
+    reg = np.zeros((F_, 1024), np.uint8)
+    reg[:, order_loc[0][first:]] = 1
+    ms = [tt(np.concatenate([info[k]] * F_)) for k in ("mask_init", "mask_undilated", "mask_dilated")]
+    u = tt(np.random.RandomState(1).rand(F_, 1024).astype(np.float32))
+    cols, wave_start = wavefronts(order_loc, 32, 32, first, DEV)
+    with pytest.raises(RuntimeError, match="schedule holds"):
+        eng.ar_run(tt(syn.codes(1, F_).reshape(F_, 1024).astype(np.int32)), tt(order_loc), tt(reg), *ms, temperature=0.7,
+                   uniforms=u, first_step=first, waves=(cols, np.ascontiguousarray(wave_start[:-1])))   # a wave short
+    bad = cols.clone()
+    bad[0, 0] = 7                                                       # a frame this run does not have
+    eng.ar_run(tt(syn.codes(1, F_).reshape(F_, 1024).astype(np.int32)), tt(order_loc), tt(reg), *ms, temperature=0.7,
+               uniforms=u, first_step=first, waves=(bad, wave_start))
+    with pytest.raises(RuntimeError, match="outside this run"):
+        eng.check()
