@@ -136,7 +136,7 @@ def measure_roofline(model, d, out, V):
     fl = fpc.value * cols_per_launch
     tf = fl / (us * 1e-6) / 1e12
     traffic, traffic_src = None, None
-    pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_f_k_column_pmc.json")
+    pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_g_k_column_pmc.json")
     if V == 16 and os.path.exists(pmc):  # PMC passes cannot run inside the timed bench: committed summary of the same workload
         with open(pmc) as fh:
             rec = json.load(fh)
