@@ -151,7 +151,10 @@ __device__ __forceinline__ void gemm_tiles(const GemmArgs &a, int o0, int slot, 
         for (int u = 0; u < T; ++u) tot[u] = zero;
         for (int t = a.slot_first[slot]; t < a.slot_first[slot + 1]; ++t) {
             const GemmTap tp = a.tap[t];
-            const float *src = nullptr;
+            // Lanes without a live input row still LOAD (row 0 of the cache, a valid address) and discard: a load under a
+            // lane condition compiles to branch / load / s_waitcnt vmcnt(0) per load, i.e. the five input loads of a
+            // chunk one round trip after the other (k_gemm: 48.8 -> 43.6 us per launch).
+            const float *src = tp.in + 4 * kk;
             float mv = 0.0f;
             const int rr = r + tp.dr, cc = c + tp.dc;
             if (valid && rr >= 0 && rr < a.H && cc >= 0 && cc < a.W) {
@@ -168,7 +171,9 @@ __device__ __forceinline__ void gemm_tiles(const GemmArgs &a, int o0, int slot, 
             for (; g + 5 <= ngroups; g += 5) {
                 f32x4 bv[5];
 #pragma unroll
-                for (int j = 0; j < 5; ++j) bv[j] = live ? *(const f32x4 *)(src + 16 * (g + j)) * mv : zero;
+                for (int j = 0; j < 5; ++j) bv[j] = *(const f32x4 *)(src + 16 * (g + j));
+#pragma unroll
+                for (int j = 0; j < 5; ++j) bv[j] = live ? bv[j] * mv : zero;
 #pragma unroll
                 for (int u = 0; u < T; ++u) {
                     f32x4 av[5];
@@ -178,7 +183,8 @@ __device__ __forceinline__ void gemm_tiles(const GemmArgs &a, int o0, int slot, 
                 }
             }
             for (; g < ngroups; ++g) {  // ragged channel counts of the generic lmconv entry point only
-                const f32x4 bv = live ? *(const f32x4 *)(src + 16 * g) * mv : zero;
+                const f32x4 raw = *(const f32x4 *)(src + 16 * g);
+                const f32x4 bv = live ? raw * mv : zero;
 #pragma unroll
                 for (int u = 0; u < T; ++u) {
                     const f32x4 av = *(const f32x4 *)(wbase + (size_t)g * 16 * a.Co_pad + 64 * u);
@@ -593,10 +599,11 @@ __device__ __forceinline__ f32x4 nbr_tap(const NbrWork &sd, const NbrArgs &a, co
     const bool live = mv != 0.0f;
     if (!__any(live)) return zero;
     Acc5 acc = acc5_zero();
-    const float *wbase = (a.debug & 4) ? sd.w + ((size_t)kk * sd.Co_pad + i) * 4
-                                        : sd.w + (size_t)t * NG * 16 * sd.Co_pad + ((size_t)kk * sd.Co_pad + o0 + i) * 4;
-    if (a.debug & 8) src = sd.in + 4 * kk;
+    const float *wbase = sd.w + (size_t)t * NG * 16 * sd.Co_pad + ((size_t)kk * sd.Co_pad + o0 + i) * 4;
     f32x4 av[NG], bv[NG];
+    // (the input rows are loaded under the lane condition, which the compiler turns into one round trip per load -- unlike
+    // k_gemm, here that is the faster form: with all ten loads in flight at once the neighbour role alone gets 13 %
+    // faster, but the launch as a whole 6 % slower -- the chains on the other XCDs wait longer for their own operands)
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
         av[g] = *PS_GC(f32x4, wbase + (size_t)g * 16 * sd.Co_pad);
