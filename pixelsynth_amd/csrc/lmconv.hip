@@ -320,11 +320,20 @@ __device__ __forceinline__ V uinit_from_codes(const int *code /*9*/, const float
                                               const float *__restrict__ bias, int c)
 {
     V v = *(const V *)(bias + c);
+    // all eighteen rows are requested before any is used (closed taps re-read the ones row and drop it): fetched under
+    // the tap's condition they come one round trip after the other, up to nine of them at the start of every launch
+    V ones[9], rows[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const float *wt = w + (size_t)t * (NCLS + 1) * NF + c;
+        ones[t] = *(const V *)(wt + (size_t)NCLS * NF);
+        rows[t] = *(const V *)(wt + (size_t)(code[t] >= 0 ? code[t] : NCLS) * NF);
+    }
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         if (code[t] == UINIT_CLOSED) continue;
-        V x = *(const V *)(w + ((size_t)t * (NCLS + 1) + NCLS) * NF + c);
-        if (code[t] >= 0) x = x + *(const V *)(w + ((size_t)t * (NCLS + 1) + code[t]) * NF + c);
+        V x = ones[t];
+        if (code[t] >= 0) x = x + rows[t];
         v = v + x * mA[t];
     }
     return v;
@@ -579,13 +588,13 @@ __device__ __forceinline__ int xcd_slot(int b, int lo, int hi /*use XCDs lo .. h
 }
 
 // one neighbour tap of one conv for 16 columns x 16 output channels, from fresh accumulators
-template <int NG>
+template <int NG, bool EAGER>
 __device__ __forceinline__ f32x4 nbr_tap(const NbrWork &sd, const NbrArgs &a, const StepCtx *recs, int t, int o0, int col, bool valid,
                                          int i, int kk)
 {
     const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
     float mv = 0.0f;
-    const float *src = nullptr;
+    const float *src = EAGER ? sd.in + 4 * kk : nullptr;  // (EAGER: lanes without a live input row load row 0 and drop it)
     if (valid) {
         const StepCtx &cx = recs[col];
         const int q = cx.q, f = cx.f;
@@ -601,13 +610,19 @@ __device__ __forceinline__ f32x4 nbr_tap(const NbrWork &sd, const NbrArgs &a, co
     Acc5 acc = acc5_zero();
     const float *wbase = sd.w + (size_t)t * NG * 16 * sd.Co_pad + ((size_t)kk * sd.Co_pad + o0 + i) * 4;
     f32x4 av[NG], bv[NG];
-    // (the input rows are loaded under the lane condition, which the compiler turns into one round trip per load -- unlike
-    // k_gemm, here that is the faster form: with all ten loads in flight at once the neighbour role alone gets 13 %
-    // faster, but the launch as a whole 6 % slower -- the chains on the other XCDs wait longer for their own operands)
+    // The input rows are loaded under the lane condition, which the compiler turns into one round trip per load.  Unlike in
+    // k_gemm that is the faster form here: with all ten loads in flight at once the neighbour role alone gets 13 % faster,
+    // but the launch as a whole 6 % slower (the chains on the other XCDs wait longer for their own operands).  Only the
+    // FIRST round of a launch is eager: its items are the stages the chains are already waiting for.
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
         av[g] = *PS_GC(f32x4, wbase + (size_t)g * 16 * sd.Co_pad);
-        bv[g] = live ? *PS_GC(f32x4, src + 16 * g) * mv : zero;
+        if (EAGER) bv[g] = *PS_GC(f32x4, src + 16 * g);
+        else bv[g] = live ? *PS_GC(f32x4, src + 16 * g) * mv : zero;
+    }
+    if (EAGER) {
+#pragma unroll
+        for (int g = 0; g < NG; ++g) bv[g] = live ? bv[g] * mv : zero;
     }
 #pragma unroll
     for (int g0 = 0; g0 < NG; g0 += 5) {
@@ -692,8 +707,11 @@ __device__ __forceinline__ void nbr_role(const NbrArgs &a, int nb)
         const int col = ctile * 16 + i;
         const bool valid = col < a.ncols;
         const int t = wk.half * 5 + w4;  // taps 0..3 (NA) or 5..8 (NB)
-        const f32x4 part = wk.NG == 10 ? nbr_tap<10>(wk, a, sCtx, t, wk.cog * 16, col, valid, i, kk)
-                                       : nbr_tap<5>(wk, a, sCtx, t, wk.cog * 16, col, valid, i, kk);
+        f32x4 part;
+        if (r == 0) part = wk.NG == 10 ? nbr_tap<10, true>(wk, a, sCtx, t, wk.cog * 16, col, valid, i, kk)
+                                       : nbr_tap<5, true>(wk, a, sCtx, t, wk.cog * 16, col, valid, i, kk);
+        else part = wk.NG == 10 ? nbr_tap<10, false>(wk, a, sCtx, t, wk.cog * 16, col, valid, i, kk)
+                                : nbr_tap<5, false>(wk, a, sCtx, t, wk.cog * 16, col, valid, i, kk);
         if (w4 != 0) {
             if (r >= 2) spin_until(&sRd[grp4], r - 1);
             *(f32x4 *)(&sNP[par][grp4][w4][i][kk * 4]) = part;
@@ -913,8 +931,10 @@ __device__ __forceinline__ void chain_role(const ChainArgs &a, int wg)
 #ifdef PS_CHAIN_TRACE_BUILD  // tuning builds only: shader-clock stamps of workgroup 0, collected in LDS, dumped at the end
     __shared__ unsigned long long sTrace[NST][10];
 #define PS_TRACE1(who, slot) do { if (who) sTrace[s][slot] = clock64(); } while (0)
+#define PS_TRACE_MARK(who, k) do { if (who) sTrace[k][9] = clock64(); } while (0)  // [k][9]: 0 role start, 1 u0 done, 2 stages done, 3 draw done
 #else
 #define PS_TRACE1(who, slot) do { } while (0)
+#define PS_TRACE_MARK(who, k) do { } while (0)
 #endif
     f32x4 wo[C1_OUT_STEPS];
     const int opart = t >> 9;  // nin_out role: thread (o = t & 511, part): part 0 = chains 0..2, part 1 = chains 3..4
@@ -1070,6 +1090,7 @@ __device__ __forceinline__ void chain_role(const ChainArgs &a, int wg)
             lds_barrier();
             PS_TRACE1(t == C1_THREADS - 64, 4);
         };
+        PS_TRACE_MARK(lane == 0, 0);
         Ops oA, oB;
         const StepCtx *ctxp = a.ctx + (pvalid ? pfr : 0);
         const int q0 = ctxp->q, fr0 = ctxp->f;
@@ -1093,6 +1114,7 @@ __device__ __forceinline__ void chain_role(const ChainArgs &a, int wg)
             load_ops(0, nxt, oB);
             lds_barrier();
         }
+        PS_TRACE_MARK(lane == 0, 1);
         for (int s = 0; s < NST - 3; s += 2) {
             post_stage(s, oA, oB);
             post_stage(s + 1, oB, oA);
@@ -1100,6 +1122,7 @@ __device__ __forceinline__ void chain_role(const ChainArgs &a, int wg)
         post_stage(NST - 3, oA, oB);
         load_out_weights();  // (peeled: keeps these 48 registers out of the loop)
         post_stage(NST - 2, oB, oA);
+        PS_TRACE_MARK(lane == 0, 2);
         nin_out_chains();
 
         // ---- end of the column: logits, categorical draw (sample.py:60-66)
@@ -1130,6 +1153,7 @@ __device__ __forceinline__ void chain_role(const ChainArgs &a, int wg)
                 if (lane == 0) a.codes[loc] = code;
             }
         }
+        PS_TRACE_MARK(lane == 0, 3);
     } else if (swave) {
         // ================= store wave: off everybody's critical path =================
         size_t off80[FPW], offR[FPW];
@@ -1269,6 +1293,7 @@ __device__ __forceinline__ void chain_role(const ChainArgs &a, int wg)
         nin_out_chains();
     }
 #undef PS_TRACE1
+#undef PS_TRACE_MARK
 
 #ifdef PS_CHAIN_TRACE_BUILD
     __syncthreads();
@@ -1963,6 +1988,7 @@ int ps_pixelcnn_time_column_step(ps_pixelcnn *h, const int32_t *codes, const int
                     fprintf(fp, "%d %llu %llu %llu %llu %llu %llu %llu %llu %llu\n", s2, hst[s2 * 10], hst[s2 * 10 + 5],
                             hst[s2 * 10 + 6], hst[s2 * 10 + 7], hst[s2 * 10 + 8], hst[s2 * 10 + 1], hst[s2 * 10 + 2],
                             hst[s2 * 10 + 3], hst[s2 * 10 + 4]);
+                fprintf(fp, "# marks (role start, u0 done, stages done, draw done): %llu %llu %llu %llu\n", hst[9], hst[19], hst[29], hst[39]);
                 fclose(fp);
             }
             (void)hipFree(d);
