@@ -348,7 +348,8 @@ __device__ __forceinline__ V uinit_gather(const int32_t *__restrict__ codes_f, c
     for (int t = 0; t < 9; ++t) {
         const int rr = r + t / 3 - 1, cc = c0 + t % 3 - 1;
         const bool in = rr >= 0 && rr < H && cc >= 0 && cc < W;
-        code[t] = (in && mA[t] != 0.0f) ? codes_f[rr * W + cc] : UINIT_CLOSED;
+        const int raw = codes_f[in ? rr * W + cc : q];  // (loaded unconditionally: see uinit_from_codes)
+        code[t] = (in && mA[t] != 0.0f) ? raw : UINIT_CLOSED;
     }
     return uinit_from_codes<V>(code, mA, w, bias, c);
 }
@@ -1097,13 +1098,16 @@ __device__ __forceinline__ void chain_role(const ChainArgs &a, int wg)
         {   // u0 = norm_init(u_init): the gather over the (earlier) neighbours' codes; the record says where they are,
             // the codes themselves were written by earlier launches (sampled) or are the caller's (observed)
             float mA[9];
-            int ncode[9];
+            int ncode[9], nl[9];
 #pragma unroll
             for (int tp = 0; tp < 9; ++tp) {
                 mA[tp] = ctxp->m[0][tp];
-                const int nl = ctxp->nloc[tp];
-                ncode[tp] = nl >= 0 ? a.codes_in[(size_t)fr0 * a.L + nl] : UINIT_CLOSED;
+                nl[tp] = ctxp->nloc[tp];
             }
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) ncode[tp] = a.codes_in[(size_t)fr0 * a.L + max(nl[tp], 0)];  // all nine in flight
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) ncode[tp] = nl[tp] >= 0 ? ncode[tp] : UINIT_CLOSED;
             const f32x2 y = uinit_from_codes<f32x2>(ncode, mA, a.uinit_w, a.uinit_b, c2);
             post_and_emit(y, zero2, zero2, integral_constant<int, PRO_UINIT>{}, integral_constant<bool, false>{},
                           integral_constant<int, IN_CELU>{}, cur.save_slot);
