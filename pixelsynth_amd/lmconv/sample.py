@@ -85,9 +85,10 @@ def sample(model, generation_idx, mask_init, mask_undilated, mask_dilated, batch
         region = torch.from_numpy(region_np).to(dev)
         c32 = codes.view(B, L).to(torch.int32).contiguous()
         if mode == "fused":
+            from .model import wavefronts
             uniforms = torch.rand(B, L, device=dev, dtype=torch.float32)
             eng.ar_run(c32, order, region, m_i, m_u, m_d, temperature=temperature, uniforms=uniforms,
-                       first_step=first)
+                       first_step=first, waves=wavefronts(order_np, H, W, first, dev))
         elif mode == "multinomial":
             c32[region.bool()] = -1
             flat_region = region.bool()
