@@ -2,7 +2,7 @@
 import sys
 import numpy as np
 
-a = np.loadtxt(sys.argv[1], dtype=np.int64)
+a = np.loadtxt(sys.argv[1], dtype=np.int64, comments='#')
 # file columns: s, slot0, slot5, slot6, slot7, slot8, slot1, slot2, slot3, slot4
 slot = {0: 1, 5: 2, 6: 3, 7: 4, 8: 5, 1: 6, 2: 7, 3: 8, 4: 9}
 g = lambda k: a[:, slot[k]]
@@ -14,3 +14,8 @@ for k in range(len(a)):
     tot += np.array(row)
     print(k, *row)
 print("sum", *tot)
+
+for line in open(sys.argv[1]):
+    if line.startswith("# marks"):
+        v = [int(x) for x in line.split(":")[1].split()]
+        print("post wave of workgroup 0, cycles: u0", v[1] - v[0], "| stage loop", v[2] - v[1], "| nin_out + draw", v[3] - v[2])

@@ -1,5 +1,8 @@
-"""Tuning aid: per-launch time of the two kernels of one AR order position (ps_pixelcnn_time_column_step).
-usage: python tools/column_time.py [views] [reps]      env: PS_XCD_PACK=0|1, PS_CHAIN_TRACE=file (needs a -DPS_CHAIN_TRACE_BUILD build)"""
+"""Tuning aid: time of one k_column launch with `views` columns (one order position of every view:
+ps_pixelcnn_time_column_step).
+usage: python tools/column_time.py [views] [reps]
+env: PS_CHAIN_TRACE=file (needs a -DPS_CHAIN_TRACE_BUILD build; read with tools/chain_trace.py),
+     PS_COLUMN_DEBUG=1|2|3 (chains do not wait / no chains / no neighbour role), PS_COL_CAP, PS_CHAIN_XCDS, PS_NBR_GROUPS"""
 import ctypes
 import os
 import sys
