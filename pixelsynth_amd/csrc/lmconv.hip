@@ -163,6 +163,7 @@ __device__ __forceinline__ void gemm_tiles(const GemmArgs &a, int o0, int slot, 
             }
             const bool live = mv != 0.0f;
             if (!__any(live)) continue;  // a masked tap is an exact zero: skipping it does not change the bits
+            if (!live) src = tp.in + 4 * kk;  // (a masked row is not fetched either)
             Acc5 acc[T];
 #pragma unroll
             for (int u = 0; u < T; ++u) acc[u] = acc5_zero();
@@ -595,7 +596,7 @@ __device__ __forceinline__ f32x4 nbr_tap(const NbrWork &sd, const NbrArgs &a, co
 {
     const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
     float mv = 0.0f;
-    const float *src = EAGER ? sd.in + 4 * kk : nullptr;  // (EAGER: lanes without a live input row load row 0 and drop it)
+    const float *src = sd.in + 4 * kk;  // lanes without an input row load row 0 and drop it
     if (valid) {
         const StepCtx &cx = recs[col];
         const int q = cx.q, f = cx.f;
@@ -608,28 +609,33 @@ __device__ __forceinline__ f32x4 nbr_tap(const NbrWork &sd, const NbrArgs &a, co
     }
     const bool live = mv != 0.0f;
     if (!__any(live)) return zero;
+    if (!live) src = sd.in + 4 * kk;  // a masked row is not fetched either (one shared line instead of sixteen different ones)
     Acc5 acc = acc5_zero();
     const float *wbase = sd.w + (size_t)t * NG * 16 * sd.Co_pad + ((size_t)kk * sd.Co_pad + o0 + i) * 4;
     f32x4 av[NG], bv[NG];
-    // The input rows are loaded under the lane condition, which the compiler turns into one round trip per load.  Unlike in
-    // k_gemm that is the faster form here: with all ten loads in flight at once the neighbour role alone gets 13 % faster,
-    // but the launch as a whole 6 % slower (the chains on the other XCDs wait longer for their own operands).  Only the
-    // FIRST round of a launch is eager: its items are the stages the chains are already waiting for.
+    // How many input-row loads a wave keeps in flight matters beyond this role: with all ten at once (EAGER) the neighbour
+    // role alone is 13 % faster, but a large launch as a whole 6 % slower -- the chains on the other XCDs wait longer for
+    // their own operands.  So only the FIRST round of a launch is eager (its items are the stages the chains are already
+    // waiting for); later rounds fetch one 80-channel chunk of rows at a time, multiply it, then fetch the next.  (Loading
+    // under the lane condition `live ? *p : 0` -- one round trip per load, see k_gemm -- was within 1 % of that.)
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        av[g] = *PS_GC(f32x4, wbase + (size_t)g * 16 * sd.Co_pad);
-        if (EAGER) bv[g] = *PS_GC(f32x4, src + 16 * g);
-        else bv[g] = live ? *PS_GC(f32x4, src + 16 * g) * mv : zero;
-    }
+    for (int g = 0; g < NG; ++g) av[g] = *PS_GC(f32x4, wbase + (size_t)g * 16 * sd.Co_pad);
     if (EAGER) {
 #pragma unroll
-        for (int g = 0; g < NG; ++g) bv[g] = live ? bv[g] * mv : zero;
+        for (int g = 0; g < NG; ++g) bv[g] = *PS_GC(f32x4, src + 16 * g);
     }
 #pragma unroll
     for (int g0 = 0; g0 < NG; g0 += 5) {
+        if (!EAGER) {
+#pragma unroll
+            for (int g = g0; g < g0 + 5; ++g) bv[g] = *PS_GC(f32x4, src + 16 * g);
+        }
+#pragma unroll
+        for (int g = g0; g < g0 + 5; ++g) bv[g] = live ? bv[g] * mv : zero;
         const f32x4 (&a5)[5] = *reinterpret_cast<const f32x4 (*)[5]>(&av[g0]);
         const f32x4 (&b5)[5] = *reinterpret_cast<const f32x4 (*)[5]>(&bv[g0]);
         mfma_chunk5(a5, b5, acc);
+        if (!EAGER) asm volatile("" ::: "memory");  // keeps the next chunk's loads behind this chunk's MFMAs
     }
     return chunk_total(acc);
 }
