@@ -22,12 +22,13 @@
 //     canonical order (five accumulation chains per tap, mfma_chunk5) produce identical bits.
 //   * Whole-grid mode (k_gemm + k_post_grid, items = F*L or the observed prefix of every order): the
 //     reference-faithful OurPixelCNN.forward and the cache build an AR run starts from.
-//   * Column mode (the incremental AR step, items = F): ONE launch per order position, k_column, with two
-//     workgroup roles that start together -- nbr_role computes the NA/NB slots of all 32 convs (MFMA; they only
-//     read finished columns of earlier positions), chain_role walks the 33 dependent stages of one frame on one
+//   * Column mode (the incremental AR evaluation; a column = one order position of one frame): k_column, ONE launch per
+//     WAVEFRONT of columns that do not depend on each other (the walk position by position is the special case of one
+//     column per frame), with two workgroup roles that start together -- nbr_role computes the NA/NB slots of all
+//     32 convs (MFMA; they only read finished columns), chain_role walks the 33 dependent stages of one column on one
 //     CU (centre taps as per-thread FMA chains on weights held in registers, post op by a dedicated wave, LDS
-//     hand-off), draws the code and writes the next position's context.  Completion counters per stage carry the
-//     neighbour slots across; every wait is bounded.
+//     hand-off) and draws the code.  Completion counters per (stage, column tile) carry the neighbour slots across;
+//     every wait is bounded.
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -544,7 +545,7 @@ struct StageDesc {
     int nchain, nstep;
 };
 
-// a work item of k_nbr = (stage, slot NA|NB, 16 output channels), with everything it needs of the stage inline:
+// a work item of the neighbour role = (stage, slot NA|NB, 16 output channels), with everything it needs of the stage inline:
 // one dependent fetch instead of work item -> stage description -> data
 struct __attribute__((aligned(16))) NbrWork {
     const float *w;   // packed weights of the conv [taps][NG*4][Co_pad][4]
@@ -575,19 +576,6 @@ struct NbrArgs {
     int debug;            // tuning only
     int *err;             // set to 1 if a bounded wait ran out (ps_pixelcnn_status)
 };
-
-// XCD affinity, for speed only (nothing depends on it): workgroup b of a launch runs on XCD b % 8, each XCD with
-// its own 4 MB L2.  One order position streams ~3 MB of centre-tap weights per chain workgroup and ~9-18 MB of
-// neighbour-tap weights through k_nbr; sharing L2s, the two evict each other every position.  So the chain
-// workgroups are packed onto the first `chain_xcds` XCDs and k_nbr keeps to the others: both weight sets then
-// stay L2-resident from one position to the next.  Returns the compact index of this workgroup among those of
-// its kernel's XCDs, or -1 if it sits on the other kernel's XCDs (it exits at once).
-__device__ __forceinline__ int xcd_slot(int b, int lo, int hi /*use XCDs lo .. hi-1*/)
-{
-    const int x = b & 7;
-    if (x < lo || x >= hi) return -1;
-    return (b >> 3) * (hi - lo) + (x - lo);
-}
 
 // one neighbour tap of one conv for 16 columns x 16 output channels, from fresh accumulators
 template <int NG, bool EAGER>
