@@ -926,9 +926,11 @@ __device__ __forceinline__ void chain_role(const ChainArgs &a, int wg)
 #ifdef PS_CHAIN_TRACE_BUILD  // tuning builds only: shader-clock stamps of workgroup 0, collected in LDS, dumped at the end
     __shared__ unsigned long long sTrace[NST][10];
 #define PS_TRACE1(who, slot) do { if (who) sTrace[s][slot] = clock64(); } while (0)
+#define PS_TRACE2(who, slot) do { if (who) sTrace[cur_stage][slot] = clock64(); } while (0)
 #define PS_TRACE_MARK(who, k) do { if (who) sTrace[k][9] = clock64(); } while (0)  // [k][9]: 0 role start, 1 u0 done, 2 stages done, 3 draw done
 #else
 #define PS_TRACE1(who, slot) do { } while (0)
+#define PS_TRACE2(who, slot) do { } while (0)
 #define PS_TRACE_MARK(who, k) do { } while (0)
 #endif
     f32x4 wo[C1_OUT_STEPS];
@@ -967,6 +969,7 @@ __device__ __forceinline__ void chain_role(const ChainArgs &a, int wg)
         const size_t nbr_half = (size_t)a.col_stride * NBR_LD, nbr_stage = 2 * nbr_half;
         const f32x2 zero2 = {0.0f, 0.0f};
         f32x2 ucur = zero2;
+        int cur_stage = 0;  // (tuning builds: the stage the trace stamps of post_body belong to)
         // bias and neighbour-tap slots of a stage's post op: y = ((bias + NA) + centre) + NB; fetched one stage ahead.
         // Always exactly seven 8-byte loads from valid addresses, in every lane: static s_waitcnt counts (see
         // load_chain_weights); kinds without a gate half / skip re-read the main operands.
@@ -1047,12 +1050,14 @@ __device__ __forceinline__ void chain_role(const ChainArgs &a, int wg)
             f32x2 g = zero2, skip = zero2;
             if (kind == PRO_GATE) g = slot_sum2(o.bg, o.nag, five(P + NF, Co), o.nbg);
             if (has_skip) skip = five(P + 5 * Co, NF) + o.b2;
+            PS_TRACE2(t == C1_THREADS - 64 && y.x != 12345.0f, 2);
             post_and_emit(y, g, skip, KIND, SKIP, INFORM, save_slot);
         };
         using std::integral_constant;
         unsigned cnt_nxt = 0;  // counter of the next stage, as loaded a stage earlier
         PostCtl cur = load_post_ctl(a.ctl1, 0), nxt = load_post_ctl(a.ctl1, 1), nn = load_post_ctl(a.ctl1, 2);
         auto post_stage = [&](int s, const Ops &ocur, Ops &onxt) {
+            cur_stage = s;
             cur = nxt;                                              // record 1 + s
             nxt = nn;                                               // record 2 + s, requested a stage ago
             if (s + 2 < NST - 1) nn = load_post_ctl(a.ctl1, 3 + s);
@@ -1292,6 +1297,7 @@ __device__ __forceinline__ void chain_role(const ChainArgs &a, int wg)
     }
 #undef PS_TRACE1
 #undef PS_TRACE_MARK
+#undef PS_TRACE2
 
 #ifdef PS_CHAIN_TRACE_BUILD
     __syncthreads();
