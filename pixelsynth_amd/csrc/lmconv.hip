@@ -969,7 +969,7 @@ __device__ __forceinline__ void chain_role(const ChainArgs &a, int wg)
         const size_t nbr_half = (size_t)a.col_stride * NBR_LD, nbr_stage = 2 * nbr_half;
         const f32x2 zero2 = {0.0f, 0.0f};
         f32x2 ucur = zero2;
-        int cur_stage = 0;  // (tuning builds: the stage the trace stamps of post_body belong to)
+        [[maybe_unused]] int cur_stage = 0;  // (tuning builds: the stage the trace stamps of post_body belong to)
         // bias and neighbour-tap slots of a stage's post op: y = ((bias + NA) + centre) + NB; fetched one stage ahead.
         // Always exactly seven 8-byte loads from valid addresses, in every lane: static s_waitcnt counts (see
         // load_chain_weights); kinds without a gate half / skip re-read the main operands.
