@@ -126,6 +126,13 @@ int ps_ar_plan(const uint8_t *bg, int B, int S, int G, int32_t *order_loc, uint8
 int ps_ar_wavefronts(const int32_t *order_loc, int B, int H, int W, int first_step, int32_t *cols,
                      int32_t *wave_start, int32_t *n_waves);
 
+/* The same with at most max_cols columns per wave (what one launch of ps_pixelcnn_ar_run_waves takes: 128): list
+ * scheduling over the ready columns, longest chain of dependants first, so that what does not fit in a wave shares the
+ * next one with the columns that have become ready meanwhile instead of costing a launch of its own.  max_cols = 0:
+ * the pure levels of ps_ar_wavefronts.  wave_start needs (L-first_step) + ceil(B*(L-first_step)/max_cols) + 1 entries. */
+int ps_ar_wavefronts_capped(const int32_t *order_loc, int B, int H, int W, int first_step, int max_cols,
+                            int32_t *cols, int32_t *wave_start, int32_t *n_waves);
+
 /* ------------------------------------------------------------------------------------------
  * Locally masked convolution / PixelCNN (models/lmconv)
  * ---------------------------------------------------------------------------------------- */

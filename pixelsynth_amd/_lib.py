@@ -37,6 +37,7 @@ _PROTOS = {
     "ps_pixelcnn_ar_run_waves": (c_int, [c_void_p] * 9 + [c_float, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "ps_pixelcnn_time_ar_run_waves": (c_int, [c_void_p] * 8 + [c_float, c_int, c_int, c_void_p, c_void_p, c_int] + [c_void_p] * 4),
     "ps_ar_wavefronts": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "ps_ar_wavefronts_capped": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "ps_pixelcnn_status": (c_int, [c_void_p, c_void_p]),
     "ps_vq_nearest_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "ps_vq_embed_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),

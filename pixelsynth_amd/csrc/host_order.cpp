@@ -165,57 +165,120 @@ int ps_ar_plan(const uint8_t *bg, int B, int S, int G, int32_t *order_loc, uint8
     return PS_OK;
 }
 
-int ps_ar_wavefronts(const int32_t *order_loc, int B, int H, int W, int first_step, int32_t *cols, int32_t *wave_start,
-                     int32_t *n_waves)
+int ps_ar_wavefronts_capped(const int32_t *order_loc, int B, int H, int W, int first_step, int max_cols, int32_t *cols,
+                            int32_t *wave_start, int32_t *n_waves)
 {
     PS_REQUIRE(order_loc && cols && wave_start && n_waves, "ar_wavefronts: null pointer");
-    PS_REQUIRE(B > 0 && H > 0 && W > 0, "ar_wavefronts: bad sizes");
+    PS_REQUIRE(B > 0 && H > 0 && W > 0 && max_cols >= 0, "ar_wavefronts: bad sizes");
     const int L = H * W;
     PS_REQUIRE(first_step >= 0 && first_step <= L, "ar_wavefronts: first_step out of range");
     const int nsteps = L - first_step;
-    // wave of a column = 1 + the latest wave among the columns it reads: the locations that are a 3x3 tap neighbour at
-    // dilation 1 or 2 AND earlier in the order (exactly the open taps of the three kernel masks); columns before
-    // first_step are wave 0 (the whole-grid pass).  Filled in order, so every dependency is known when it is needed.
-    std::vector<int32_t> wave((size_t)B * nsteps);
-    std::vector<int32_t> rank((size_t)L), lvl((size_t)L);
-    int deepest = 0;
+    // A column reads the columns of the locations that are a 3x3 tap neighbour at dilation 1 or 2 AND earlier in the
+    // order (exactly the open taps of the three kernel masks); columns before first_step are done by the whole-grid pass.
+    std::vector<int32_t> rank((size_t)B * L);
     for (int b = 0; b < B; ++b) {
         const int32_t *ol = order_loc + (size_t)b * L;
-        std::fill(rank.begin(), rank.end(), -1);
+        int32_t *rk = rank.data() + (size_t)b * L;
+        std::fill(rk, rk + L, -1);
         for (int i = 0; i < L; ++i) {
-            PS_REQUIRE(ol[i] >= 0 && ol[i] < L && rank[ol[i]] < 0, "ar_wavefronts: frame %d: order is not a permutation", b);
-            rank[ol[i]] = i;
-        }
-        std::fill(lvl.begin(), lvl.end(), 0);
-        for (int i = first_step; i < L; ++i) {
-            const int q = ol[i], r = q / W, c = q - r * W;
-            int dep = 0;
-            for (int dil = 1; dil <= 2; ++dil)
-                for (int t = 0; t < 9; ++t) {
-                    if (t == 4) continue;
-                    const int rr = r + (t / 3 - 1) * dil, cc = c + (t % 3 - 1) * dil;
-                    if (rr < 0 || rr >= H || cc < 0 || cc >= W) continue;
-                    const int p = rr * W + cc;
-                    if (rank[p] < i) dep = std::max(dep, lvl[p]);
-                }
-            lvl[q] = dep + 1;
-            wave[(size_t)b * nsteps + (i - first_step)] = dep;  // 0-based wave index
-            deepest = std::max(deepest, dep + 1);
+            PS_REQUIRE(ol[i] >= 0 && ol[i] < L && rk[ol[i]] < 0, "ar_wavefronts: frame %d: order is not a permutation", b);
+            rk[ol[i]] = i;
         }
     }
-    // counting sort by wave; within a wave by frame, then by position
-    std::vector<int32_t> count((size_t)deepest + 1, 0);
-    for (int32_t w : wave) count[(size_t)w + 1] += 1;
-    for (int w = 0; w < deepest; ++w) count[(size_t)w + 1] += count[w];
-    for (int w = 0; w <= deepest; ++w) wave_start[w] = count[w];
-    for (int b = 0; b < B; ++b)
-        for (int k = 0; k < nsteps; ++k) {
-            const int32_t at = count[wave[(size_t)b * nsteps + k]]++;
-            cols[2 * (size_t)at] = b;
-            cols[2 * (size_t)at + 1] = first_step + k;
+    auto for_neighbours = [&](int q, auto &&fn) {
+        const int r = q / W, c = q - r * W;
+        for (int dil = 1; dil <= 2; ++dil)
+            for (int t = 0; t < 9; ++t) {
+                if (t == 4) continue;
+                const int rr = r + (t / 3 - 1) * dil, cc = c + (t % 3 - 1) * dil;
+                if (rr >= 0 && rr < H && cc >= 0 && cc < W) fn(rr * W + cc);
+            }
+    };
+    if (max_cols == 0) {
+        // pure dependency levels: wave of a column = 1 + the latest wave among the columns it reads
+        std::vector<int32_t> wave((size_t)B * nsteps), lvl((size_t)L);
+        int deepest = 0;
+        for (int b = 0; b < B; ++b) {
+            const int32_t *ol = order_loc + (size_t)b * L, *rk = rank.data() + (size_t)b * L;
+            std::fill(lvl.begin(), lvl.end(), 0);
+            for (int i = first_step; i < L; ++i) {
+                int dep = 0;
+                for_neighbours(ol[i], [&](int p) { if (rk[p] < i) dep = std::max(dep, lvl[p]); });
+                lvl[ol[i]] = dep + 1;
+                wave[(size_t)b * nsteps + (i - first_step)] = dep;  // 0-based wave index
+                deepest = std::max(deepest, dep + 1);
+            }
         }
-    *n_waves = deepest;
+        // counting sort by wave; within a wave by frame, then by position
+        std::vector<int32_t> count((size_t)deepest + 1, 0);
+        for (int32_t w : wave) count[(size_t)w + 1] += 1;
+        for (int w = 0; w < deepest; ++w) count[(size_t)w + 1] += count[w];
+        for (int w = 0; w <= deepest; ++w) wave_start[w] = count[w];
+        for (int b = 0; b < B; ++b)
+            for (int k = 0; k < nsteps; ++k) {
+                const int32_t at = count[wave[(size_t)b * nsteps + k]]++;
+                cols[2 * (size_t)at] = b;
+                cols[2 * (size_t)at + 1] = first_step + k;
+            }
+        *n_waves = deepest;
+        return PS_OK;
+    }
+    // Waves of at most max_cols columns (what one launch takes): list scheduling over the ready columns, those with the
+    // longest chain of dependants first.  A level that does not fit is not cut in two launches of its own: what is
+    // left over shares the next wave with the columns that have become ready meanwhile.
+    std::vector<int32_t> height((size_t)B * L, 0), indeg((size_t)B * L, 0);
+    typedef std::tuple<int32_t, int32_t, int32_t> Key;  // (height, -frame, -position): deterministic
+    std::priority_queue<Key> ready;
+    for (int b = 0; b < B; ++b) {
+        const int32_t *ol = order_loc + (size_t)b * L, *rk = rank.data() + (size_t)b * L;
+        int32_t *hb = height.data() + (size_t)b * L, *db = indeg.data() + (size_t)b * L;
+        for (int i = L - 1; i >= first_step; --i) {
+            int h = 0, d = 0;
+            for_neighbours(ol[i], [&](int p) {
+                if (rk[p] > i) h = std::max(h, (int)hb[p]);
+                else if (rk[p] >= first_step) ++d;
+            });
+            hb[ol[i]] = h + 1;
+            db[ol[i]] = d;
+        }
+        for (int i = first_step; i < L; ++i)
+            if (db[ol[i]] == 0) ready.emplace(hb[ol[i]], -b, -i);
+    }
+    size_t at = 0;
+    int nw = 0;
+    std::vector<Key> taken;
+    wave_start[0] = 0;
+    while (!ready.empty()) {
+        taken.clear();
+        while (!ready.empty() && (int)taken.size() < max_cols) {
+            taken.push_back(ready.top());
+            ready.pop();
+        }
+        for (const Key &k : taken) {
+            const int b = -std::get<1>(k), i = -std::get<2>(k);
+            cols[2 * at] = b;
+            cols[2 * at + 1] = i;
+            ++at;
+        }
+        for (const Key &k : taken) {  // their dependants may run from the NEXT wave on
+            const int b = -std::get<1>(k), i = -std::get<2>(k);
+            const int32_t *ol = order_loc + (size_t)b * L, *rk = rank.data() + (size_t)b * L;
+            int32_t *hb = height.data() + (size_t)b * L, *db = indeg.data() + (size_t)b * L;
+            for_neighbours(ol[i], [&](int p) {
+                if (rk[p] > i && --db[p] == 0) ready.emplace(hb[p], -b, -rk[p]);
+            });
+        }
+        wave_start[++nw] = (int32_t)at;
+    }
+    PS_REQUIRE(at == (size_t)B * nsteps, "ar_wavefronts: internal error, %zu of %zu columns scheduled", at, (size_t)B * nsteps);
+    *n_waves = nw;
     return PS_OK;
+}
+
+int ps_ar_wavefronts(const int32_t *order_loc, int B, int H, int W, int first_step, int32_t *cols, int32_t *wave_start,
+                     int32_t *n_waves)
+{
+    return ps_ar_wavefronts_capped(order_loc, B, H, W, first_step, 0, cols, wave_start, n_waves);
 }
 
 int ps_kernel_masks_f32(const int32_t *order, int L, int nrows, int ncols, int k, int dilation, int mask_type_b,

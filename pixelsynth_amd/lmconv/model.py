@@ -264,19 +264,24 @@ class OurPixelCNN(nn.Module):
         return self.nin_out(F.elu(u))
 
 
-def wavefronts(order_host, H, W, first_step, device=None):
-    """Wavefront schedule of an AR run (ps_ar_wavefronts): order_host (F,L) int32 numpy array ->
-    (cols int32 (n,2) tensor on `device`, wave_start int32 numpy array of n_waves + 1 entries)."""
+COLUMNS_PER_LAUNCH = 128   # what one k_column launch takes (csrc/lmconv.hip: COL_CAP)
+
+
+def wavefronts(order_host, H, W, first_step, device=None, max_cols=COLUMNS_PER_LAUNCH):
+    """Wavefront schedule of an AR run (ps_ar_wavefronts_capped): order_host (F,L) int32 numpy array ->
+    (cols int32 (n,2) tensor on `device`, wave_start int32 numpy array of n_waves + 1 entries).
+    max_cols: columns per wave (0 = the pure dependency levels)."""
     import ctypes
     order_host = np.ascontiguousarray(order_host, np.int32)
     F_, L = order_host.shape
-    n = F_ * (L - first_step)
+    nsteps = L - first_step
+    n = F_ * nsteps
     cols = np.empty((max(n, 1), 2), np.int32)
-    wave_start = np.zeros(L - first_step + 1, np.int32)
+    wave_start = np.zeros(nsteps + (n + max_cols - 1) // max_cols + 2 if max_cols else nsteps + 1, np.int32)
     nw = ctypes.c_int32(0)
-    rc = _lib.lib().ps_ar_wavefronts(_lib.ptr(order_host), F_, H, W, int(first_step), _lib.ptr(cols), _lib.ptr(wave_start),
-                                     ctypes.cast(ctypes.byref(nw), ctypes.c_void_p))
-    _lib.check(rc, "ps_ar_wavefronts")
+    rc = _lib.lib().ps_ar_wavefronts_capped(_lib.ptr(order_host), F_, H, W, int(first_step), int(max_cols), _lib.ptr(cols),
+                                            _lib.ptr(wave_start), ctypes.cast(ctypes.byref(nw), ctypes.c_void_p))
+    _lib.check(rc, "ps_ar_wavefronts_capped")
     cols_t = torch.from_numpy(cols[:n] if n else cols[:0])
     if device is not None:
         cols_t = cols_t.to(device, non_blocking=True)

@@ -353,7 +353,8 @@ def test_ar_wavefront_schedule_is_bit_identical_to_the_walk(F_, first):
     eng.check()
     waves = wavefronts(order_loc, 32, 32, first, DEV)
     n_waves = len(waves[1]) - 1
-    assert waves[0].shape[0] == F_ * (1024 - first) and n_waves < (1024 - first) // 3
+    ncols = F_ * (1024 - first)
+    assert waves[0].shape[0] == ncols and n_waves < max((1024 - first) // 3, -(-ncols // 128) + 8)   # depth- or capacity-bound
     l_wave = eng.ar_run(c_wave, tt(order_loc), tt(reg), *ms, temperature=0.7, uniforms=u, first_step=first, want_logits=True,
                         waves=waves)
     eng.check()

@@ -204,42 +204,54 @@ def test_ar_sample_vs_reference_sample(golden_dir):
 
 
 def test_wavefront_schedule_respects_every_dependency():
-    """ps_ar_wavefronts (host): every walked column appears once; a column's wave is exactly one more than the latest
-    wave among the columns it reads (3x3 neighbours at dilation 1 and 2 that are earlier in the order, i.e. the open
-    taps of the three kernel masks), restated here with plain loops; and the schedule is far shallower than the walk."""
+    """ps_ar_wavefronts_capped (host): every walked column appears once and every column it reads -- the 3x3 neighbours at
+    dilation 1 and 2 that are earlier in the order, i.e. the open taps of the three kernel masks, restated here with
+    plain loops -- sits in an EARLIER wave.  Without a capacity a column's wave is exactly one more than the latest
+    wave among those; with the capacity of a launch (128) no wave is larger, and the list scheduler still needs no
+    more waves than the dependency depth or the column count force.  Far shallower than the walk either way."""
     from pixelsynth_amd.lmconv.model import wavefronts
     bgs = syn.background_masks(256)
     names = ["right_half", "half_plus_island", "ragged", "all", "top_band"]
-    infos = [c_oracle.masks_for_background(bgs[n], 32) for n in names]
+    infos = [c_oracle.masks_for_background(bgs[n], 32) for n in names] * 3          # 15 frames: waves above the capacity
+    F_ = len(infos)
     order_loc = np.stack([(i["order"][:, 0] * 32 + i["order"][:, 1]) for i in infos]).astype(np.int32)
     G, L = 32, 1024
     for first in (0, 320, 1000, 1024):
-        cols, wave_start = wavefronts(order_loc, G, G, first)
-        cols = cols.numpy()
-        assert cols.shape == (len(names) * (L - first), 2) and wave_start[0] == 0 and wave_start[-1] == cols.shape[0]
-        wave_of = {}
-        for w in range(len(wave_start) - 1):
-            for f, i in cols[wave_start[w]:wave_start[w + 1]]:
-                assert (f, i) not in wave_of
-                wave_of[(int(f), int(i))] = w
-        assert len(wave_of) == cols.shape[0]
-        for f in range(len(names)):
-            rank = np.empty(L, int)
-            rank[order_loc[f]] = np.arange(L)
-            masks = [infos[f][k].reshape(9, L) for k in ("mask_init", "mask_undilated", "mask_dilated")]
-            for i in range(first, L):
-                q = int(order_loc[f][i])
-                r, c = divmod(q, G)
-                dep = -1
-                for dil, mk in ((1, masks[0]), (1, masks[1]), (2, masks[2])):
-                    for t in range(9):
-                        rr, cc = r + (t // 3 - 1) * dil, c + (t % 3 - 1) * dil
-                        if t == 4 or not (0 <= rr < G and 0 <= cc < G):
-                            continue
-                        p = rr * G + cc
-                        assert (mk[t, q] != 0) == (rank[p] < i)          # open tap <=> earlier in the order
-                        if rank[p] < i and rank[p] >= first:
-                            dep = max(dep, wave_of[(f, int(rank[p]))])
-                assert wave_of[(f, i)] == dep + 1
+        depth = None
+        for cap in (0, 128):
+            cols, wave_start = wavefronts(order_loc, G, G, first, max_cols=cap)
+            cols = cols.numpy()
+            assert cols.shape == (F_ * (L - first), 2) and wave_start[0] == 0 and wave_start[-1] == cols.shape[0]
+            sizes = np.diff(wave_start)
+            assert (sizes > 0).all() and (cap == 0 or sizes.size == 0 or sizes.max() <= cap)
+            wave_of = {}
+            for w in range(len(wave_start) - 1):
+                for f, i in cols[wave_start[w]:wave_start[w + 1]]:
+                    assert (f, i) not in wave_of
+                    wave_of[(int(f), int(i))] = w
+            assert len(wave_of) == cols.shape[0]
+            for f in range(F_):
+                rank = np.empty(L, int)
+                rank[order_loc[f]] = np.arange(L)
+                masks = [infos[f][k].reshape(9, L) for k in ("mask_init", "mask_undilated", "mask_dilated")]
+                for i in range(first, L):
+                    q = int(order_loc[f][i])
+                    r, c = divmod(q, G)
+                    dep = -1
+                    for dil, mk in ((1, masks[0]), (1, masks[1]), (2, masks[2])):
+                        for t in range(9):
+                            rr, cc = r + (t // 3 - 1) * dil, c + (t % 3 - 1) * dil
+                            if t == 4 or not (0 <= rr < G and 0 <= cc < G):
+                                continue
+                            p = rr * G + cc
+                            assert (mk[t, q] != 0) == (rank[p] < i)          # open tap <=> earlier in the order
+                            if rank[p] < i and rank[p] >= first:
+                                dep = max(dep, wave_of[(f, int(rank[p]))])
+                    assert wave_of[(f, i)] == dep + 1 if cap == 0 else wave_of[(f, i)] > dep
+            n_waves = len(wave_start) - 1
+            if cap == 0:
+                depth = n_waves
+            else:
+                assert n_waves <= max(depth, -(-cols.shape[0] // cap)) + depth // 8   # close to the lower bound
         if first == 320:
-            assert len(wave_start) - 1 < (L - first) // 4
+            assert depth < (L - first) // 4
