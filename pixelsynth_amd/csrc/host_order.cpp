@@ -11,6 +11,7 @@
 #include <cstring>
 #include <queue>
 #include <tuple>
+#include <utility>
 #include <thread>
 #include <vector>
 
@@ -227,9 +228,16 @@ int ps_ar_wavefronts_capped(const int32_t *order_loc, int B, int H, int W, int f
     // longest chain of dependants first.  A level that does not fit is not cut in two launches of its own: what is
     // left over shares the next wave with the columns that have become ready meanwhile.
     std::vector<int32_t> height((size_t)B * L, 0), indeg((size_t)B * L, 0);
-    typedef std::tuple<int32_t, int32_t, int32_t> Key;  // (height, -frame, -position): deterministic
-    std::priority_queue<Key> ready;
-    for (int b = 0; b < B; ++b) {
+    // ready columns by height (a bucket queue: heights are at most L); within a height, first come first served
+    std::vector<std::vector<std::pair<int32_t, int32_t>>> bucket((size_t)L + 2);
+    int top = 0;
+    size_t nready = 0;
+    auto push = [&](int h, int b, int i) {
+        bucket[(size_t)h].emplace_back(b, i);
+        top = std::max(top, h);
+        ++nready;
+    };
+    auto frame_graph = [&](int b) {  // heights (longest chain of dependants) and in-degrees of one frame's columns
         const int32_t *ol = order_loc + (size_t)b * L, *rk = rank.data() + (size_t)b * L;
         int32_t *hb = height.data() + (size_t)b * L, *db = indeg.data() + (size_t)b * L;
         for (int i = L - 1; i >= first_step; --i) {
@@ -241,31 +249,37 @@ int ps_ar_wavefronts_capped(const int32_t *order_loc, int B, int H, int W, int f
             hb[ol[i]] = h + 1;
             db[ol[i]] = d;
         }
+    };
+    for (int b = 0; b < B; ++b) frame_graph(b);  // (threads were tried: their start-up costs more than the 0.3 ms they share out)
+    for (int b = 0; b < B; ++b) {
+        const int32_t *ol = order_loc + (size_t)b * L;
+        const int32_t *hb = height.data() + (size_t)b * L, *db = indeg.data() + (size_t)b * L;
         for (int i = first_step; i < L; ++i)
-            if (db[ol[i]] == 0) ready.emplace(hb[ol[i]], -b, -i);
+            if (db[ol[i]] == 0) push(hb[ol[i]], b, i);
     }
     size_t at = 0;
     int nw = 0;
-    std::vector<Key> taken;
+    std::vector<std::pair<int32_t, int32_t>> taken;
     wave_start[0] = 0;
-    while (!ready.empty()) {
+    while (nready > 0) {
         taken.clear();
-        while (!ready.empty() && (int)taken.size() < max_cols) {
-            taken.push_back(ready.top());
-            ready.pop();
+        while (nready > 0 && (int)taken.size() < max_cols) {
+            while (bucket[(size_t)top].empty()) --top;
+            taken.push_back(bucket[(size_t)top].back());
+            bucket[(size_t)top].pop_back();
+            --nready;
         }
-        for (const Key &k : taken) {
-            const int b = -std::get<1>(k), i = -std::get<2>(k);
-            cols[2 * at] = b;
-            cols[2 * at + 1] = i;
+        for (const auto &k : taken) {
+            cols[2 * at] = k.first;
+            cols[2 * at + 1] = k.second;
             ++at;
         }
-        for (const Key &k : taken) {  // their dependants may run from the NEXT wave on
-            const int b = -std::get<1>(k), i = -std::get<2>(k);
+        for (const auto &k : taken) {  // their dependants may run from the NEXT wave on
+            const int b = k.first, i = k.second;
             const int32_t *ol = order_loc + (size_t)b * L, *rk = rank.data() + (size_t)b * L;
             int32_t *hb = height.data() + (size_t)b * L, *db = indeg.data() + (size_t)b * L;
             for_neighbours(ol[i], [&](int p) {
-                if (rk[p] > i && --db[p] == 0) ready.emplace(hb[p], -b, -rk[p]);
+                if (rk[p] > i && --db[p] == 0) push(hb[p], b, rk[p]);
             });
         }
         wave_start[++nw] = (int32_t)at;
