@@ -264,7 +264,9 @@ class OurPixelCNN(nn.Module):
         return self.nin_out(F.elu(u))
 
 
-COLUMNS_PER_LAUNCH = 128   # what one k_column launch takes (csrc/lmconv.hip: COL_CAP)
+import os
+
+COLUMNS_PER_LAUNCH = int(os.environ.get("PS_WAVE_COLS", "128"))   # what one k_column launch takes (csrc/lmconv.hip: COL_CAP = 128 at most)
 
 
 def wavefronts(order_host, H, W, first_step, device=None, max_cols=COLUMNS_PER_LAUNCH):
