@@ -326,12 +326,13 @@ def test_other_grid_sizes(H, W):
         assert np.array_equal(full[b][walked], got[b][walked])
 
 
-@pytest.mark.parametrize("F_,first", [(1, 512), (5, 320), (20, 600), (40, 900)])
-def test_ar_wavefront_schedule_is_bit_identical_to_the_walk(F_, first):
-    """The wavefront schedule (ps_ar_wavefronts + ps_pixelcnn_ar_run_waves: all columns of one dependency level in one
-    launch) must reproduce the position-by-position walk bit for bit -- sampled codes AND the logits each location was
-    decided from -- for frames with different orders, wave counts and first positions; waves larger than a launch's
-    column capacity (40 frames) are split."""
+@pytest.mark.parametrize("F_,first,cap", [(1, 512, 128), (5, 320, 128), (20, 600, 128), (40, 900, 128), (40, 900, 0), (3, 700, 16)])
+def test_ar_wavefront_schedule_is_bit_identical_to_the_walk(F_, first, cap):
+    """The wavefront schedule (ps_ar_wavefronts_capped + ps_pixelcnn_ar_run_waves: columns that do not depend on each
+    other in one launch) must reproduce the position-by-position walk bit for bit -- sampled codes AND the logits each
+    location was decided from -- for frames with different orders, wave counts and first positions: list-scheduled waves
+    of a launch's capacity (128), of a smaller one, and the pure dependency levels (cap 0), whose oversized waves the
+    launcher splits."""
     from pixelsynth_amd.lmconv.model import wavefronts
     net = make_net(3)
     eng = net.engine(32, 32, F_)
@@ -351,10 +352,10 @@ def test_ar_wavefront_schedule_is_bit_identical_to_the_walk(F_, first):
     c_walk, c_wave = tt(codes0.copy()), tt(codes0.copy())
     l_walk = eng.ar_run(c_walk, tt(order_loc), tt(reg), *ms, temperature=0.7, uniforms=u, first_step=first, want_logits=True)
     eng.check()
-    waves = wavefronts(order_loc, 32, 32, first, DEV)
+    waves = wavefronts(order_loc, 32, 32, first, DEV, max_cols=cap)   # cap 0: pure levels, oversized ones split by the launcher
     n_waves = len(waves[1]) - 1
     ncols = F_ * (1024 - first)
-    assert waves[0].shape[0] == ncols and n_waves < max((1024 - first) // 3, -(-ncols // 128) + 8)   # depth- or capacity-bound
+    assert waves[0].shape[0] == ncols and n_waves < max((1024 - first) // 3, -(-ncols // max(cap, 1)) + 8)   # depth- or capacity-bound
     l_wave = eng.ar_run(c_wave, tt(order_loc), tt(reg), *ms, temperature=0.7, uniforms=u, first_step=first, want_logits=True,
                         waves=waves)
     eng.check()
