@@ -127,6 +127,7 @@ class ZbufferModelPts(nn.Module):
                         'D': np.array([.3, 0, 0]), 'UR': np.array([-.15, .3, 0]), 'UL': np.array([-.15, -.3, 0]),
                         'DR': np.array([.15, .3, 0]), 'DL': np.array([.15, -.3, 0])}  # :113-114
         self.mapping = ['R', 'L', 'U', 'D', 'UL', 'UR', 'DR', 'DL']
+        self.sample_batch = 32        # frames (candidates x views) a get_best_sample engine run takes at most
 
     # ---------------------------------------------------------------- a15
     def eulerAnglesToRotationMatrix(self, theta):
@@ -307,21 +308,33 @@ class ZbufferModelPts(nn.Module):
                                "neither is part of this library -- pass both or use num_samples=1")
         B, G = codes.shape[0], self.obs[1]
         L = G * self.obs[2]
-        eng = self.outpaint2.engine(G, self.obs[2], B)
+        dev = codes.device
+        if uniforms is None:
+            uniforms = torch.stack([torch.rand(B, L, generator=torch.Generator(device="cpu").manual_seed(i)) for i in range(n)]).to(dev)
+        # The candidates are independent AR runs of the same view(s): they go through the sampler TOGETHER, as n * B frames
+        # (sample-major) that share the view's order and masks and differ in their draws -- one wavefront schedule, the
+        # launches of one run instead of n runs one after the other (the num_samples candidates are one of
+        # the path's natural parallel axes).
+        per = max(1, min(n, self.sample_batch // max(B, 1)))          # candidates per engine run
         imgs, disc, entr = [], [], []
-        for i in range(n):
-            if uniforms is not None:
-                u = uniforms[i]
-            else:
-                u = torch.rand(B, L, generator=torch.Generator(device="cpu").manual_seed(i)).to(codes.device)
-            c = codes.reshape(B, L).to(torch.int32).contiguous().clone()
-            eng.ar_run(c, plan.order_loc, plan.region, plan.mask_init, plan.mask_undilated, plan.mask_dilated,
-                       temperature=self.opt.temperature, uniforms=u.contiguous(), first_step=plan.first_step, waves=plan.waves)
-            img = self._decode_candidate(gen_fs, background_mask, c.view(B, G, self.obs[2]))
-            imgs.append(img)
-            if n > 1:
-                disc.append(float(netD.run_discriminator_one_step(img, input_img)["D_Fake"].mean().cpu()))
-                entr.append(self._entropy_score(img))
+        for s0 in range(0, n, per):
+            k = min(per, n - s0)
+            rep = lambda t: t.repeat((k,) + (1,) * (t.dim() - 1)).contiguous()
+            waves = plan.waves
+            if k > 1:
+                from .lmconv.model import wavefronts
+                waves = wavefronts(np.tile(plan._order_host, (k, 1)), G, self.obs[2], plan.first_step, dev)
+            c = rep(codes.reshape(B, L).to(torch.int32))
+            eng = self.outpaint2.engine(G, self.obs[2], k * B)
+            eng.ar_run(c, rep(plan.order_loc), rep(plan.region), rep(plan.mask_init), rep(plan.mask_undilated),
+                       rep(plan.mask_dilated), temperature=self.opt.temperature,
+                       uniforms=uniforms[s0:s0 + k].reshape(k * B, L).contiguous(), first_step=plan.first_step, waves=waves)
+            for j in range(k):
+                img = self._decode_candidate(gen_fs, background_mask, c[j * B:(j + 1) * B].view(B, G, self.obs[2]))
+                imgs.append(img)
+                if n > 1:
+                    disc.append(float(netD.run_discriminator_one_step(img, input_img)["D_Fake"].mean().cpu()))
+                    entr.append(self._entropy_score(img))
         return imgs[rank_samples(disc, entr)] if n > 1 else imgs[0]
 
     # ---------------------------------------------------------------- chained trajectories (8f.4)

@@ -354,3 +354,35 @@ def test_plan_views_then_outpaint_planned_equals_outpaint_views_also_across_stre
     m.outpaint2.engine(32, 32, V).check()
     assert torch.equal(out["codes"], ref_codes) and torch.equal(busy["codes"], ref_codes)
     assert torch.equal(out["gen_fs"], ref["gen_fs"]) and torch.equal(out["background_mask"], ref["background_mask"])
+
+
+def test_get_best_sample_batches_the_candidates_without_changing_them():
+    """The num_samples candidates of a view run through the sampler together (sample-parallel frames); every candidate
+    must be exactly what a run of its own produces."""
+    from pixelsynth_amd.z_buffermodel import build_ar_plan
+    m = _scene_model(num_samples=5)
+    img = tt(syn.image(31, 1, 3, 256))
+    cam = {k: tt(v) for k, v in syn.demo_cameras(1).items()}
+    RTinv, RT = m.get_rt_from_rot("R", cam["P"], 2, 2)
+    gen_fs, bg = m.pts_transformer.forward_justpts(img, syn.depth_from_image(img), cam["K"], cam["Kinv"], cam["P"],
+                                                   cam["Pinv"], RT, RTinv)
+    plan = build_ar_plan(bg, 32)
+    codes = m.vqvae.encode_codes(gen_fs)
+    uni = torch.rand(5, 1, 1024, generator=torch.Generator(device="cpu").manual_seed(9)).to(DEV)
+    seen = []
+
+    class D:
+        def run_discriminator_one_step(self, fake, real):
+            seen.append(fake)
+            return {"D_Fake": fake.mean().reshape(1)}
+    m.classifier = lambda x: torch.cat([x.mean().reshape(1, 1) * k for k in range(1, 11)], 1)
+    m.sample_batch = 3                      # 5 candidates -> engine runs of 3 and 2 frames
+    m.get_best_sample(plan, codes, bg, gen_fs, D(), img, uniforms=uni)
+    batched = [s.clone() for s in seen]
+    seen.clear()
+    m.sample_batch = 1                      # one candidate per run
+    m.get_best_sample(plan, codes, bg, gen_fs, D(), img, uniforms=uni)
+    assert len(batched) == len(seen) == 5
+    for a, b in zip(batched, seen):
+        assert torch.equal(a, b)
+    assert not torch.equal(batched[0], batched[1])
