@@ -368,7 +368,7 @@ class ZbufferModelPts(nn.Module):
         sweep (unless sequential_outpainting), then the views in between, every frame rendered from the previous
         one on top of the accumulated point cloud.  B = 1, as in the reference (a5 needs equal counts per image).
         -> (None, outputs) with the reference's keys PredImg_<dir>_<i>, FeaturesImg_..., PredDepthImg_..., ForegroundImg_..."""
-        dev = torch.device("cuda", torch.cuda.current_device())
+        dev = next(self.parameters()).device   # (the renderer itself refuses anything but the GPU)
         input_img = batch["images"][0].to(dev)
         cam = {k: v.to(dev) for k, v in batch["cameras"][0].items() if torch.is_tensor(v)}
         K, K_inv, input_RT, input_RTinv = cam["K"], cam["Kinv"], cam["P"], cam["Pinv"]

@@ -367,10 +367,152 @@ def gen_networks(R):
     print("networks: unet out", float(depth.mean()), float(depth.std()), "decoder out", float(refined.mean()), float(refined.std()))
 
 
+def _import_reference_model():
+    """models/z_buffermodel.py itself (SURVEY 8c lists it as not importable: torchvision, cv2, mock are absent).  With
+    attribute-only stand-ins for those three -- none of their code is ever reached by what is called below -- the
+    reference's ZbufferModelPts constructs on CPU, so get_rt_from_rot, get_combined and the frame loop of forward_scene
+    run as written."""
+    tv = sys.modules["torchvision"]
+    tr = types.ModuleType("torchvision.transforms")
+
+    class _T:
+        def __init__(self, *a, **k):
+            pass
+    for n in ("Compose", "Resize", "CenterCrop", "ToTensor", "Normalize"):
+        setattr(tr, n, _T)
+    tv.transforms = tr
+    sys.modules["torchvision.transforms"] = tr
+    tm = types.ModuleType("torchvision.models")
+    tm.__dict__["resnet18"] = lambda num_classes: torch.nn.Identity()
+    tv.models = tm
+    sys.modules["torchvision.models"] = tm
+    mock = types.ModuleType("mock")
+    mock.Mock = type("Mock", (), {})
+    sys.modules["mock"] = mock
+    sys.modules["cv2"] = types.ModuleType("cv2")
+    import models.z_buffermodel as zb
+    return zb
+
+
+def _reference_model(zb, **kw):
+    opt = syn.network_opts()
+    o = dict(W=256, use_rgb_features=True, depth_predictor_type="unet", seed=0, max_z=100.0, min_z=1.0, voxel_size=64,
+             model_setting="gen_img", rotation=0.6, homography=False, losses=["1.0_l1"], discriminator_losses=None,
+             splatter="xyblending", learn_default_feature=True, radius=4, pp_pixel=128, tau=1.0, rad_pow=2,
+             accumulation="alphacomposite")
+    o.update(kw)
+    for k, v in o.items():
+        setattr(opt, k, v)
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        return zb.ZbufferModelPts(opt).eval()
+
+
+def pose_inputs():
+    """Source poses the a15 fixture is generated for: the demo camera, a Matterport-style camera, a generic rigid pose."""
+    rs = np.random.RandomState(77)
+    A = rs.randn(3, 3)
+    Q, _ = np.linalg.qr(A)
+    G = np.eye(4, dtype=np.float32)
+    G[:3, :3] = Q.astype(np.float32)
+    G[:3, 3] = rs.randn(3).astype(np.float32)
+    return [("demo", syn.demo_cameras(1)["P"]), ("mp3d", syn.mp3d_cameras(1)["P"]), ("rigid", G[None])]
+
+
+POSE_CASES = (  # (model_setting, homography, rotation, direction, num, denom)
+    [("gen_img", h, rot, d, None, None) for h in (False, True) for rot in (0.6, 0.25)
+     for d in ("R", "L", "U", "D", "UR", "UL", "DR", "DL")]
+    + [("gen_scene", h, 0.6, d, n, dn) for h in (False, True) for d in ("R", "L", "U", "D", "UL", "DR")
+       for (n, dn) in ((0, 4), (1, 4), (3, 4), (4, 4), (2, 2))]
+    + [("gen_scene", False, 0.6, d, n, dn) for d in ("C", "S") for (n, dn) in ((0, 64), (5, 64), (16, 64), (37, 64), (3, 8))]
+    + [("gen_two_imgs", False, 0.6, d, n, 2) for d in ("R", "DL", "C", "S") for n in (0, 1, 2)])
+
+
+def gen_poses(R):
+    """a15: the reference's own get_rt_from_rot / eulerAnglesToRotationMatrix (models/z_buffermodel.py:186-242) for every
+    branch -- gen_img directions at opt.rotation, num/denom sweeps, the 'C' rotation circle, the 'S' translation circle,
+    homography -- plus get_combined (:703-708) and the (source pose, target pose, output key) schedule of forward_scene
+    (:420-584) in both outpainting orders, recorded from the reference's own loop with the point-cloud renderer, the depth
+    net and the decoder replaced by recorders (no_outpainting: the AR part is not what this fixture pins)."""
+    zb = _import_reference_model()
+    fx = {}
+    m = _reference_model(zb)
+    for pname, P in pose_inputs():
+        fx[f"P_{pname}"] = P
+    rows = []
+    for ci, (setting, hom, rot, d, n, dn) in enumerate(POSE_CASES):
+        m.opt.model_setting, m.opt.homography, m.opt.rotation = setting, hom, rot
+        for pname, P in pose_inputs():
+            with torch.no_grad():
+                RTinv, RT = m.get_rt_from_rot(d, t(P), n, dn)
+            fx[f"pose{ci}_{pname}_RT"] = RT.numpy()
+            fx[f"pose{ci}_{pname}_RTinv"] = RTinv.numpy()
+        rows.append(f"{setting}|{int(hom)}|{rot}|{d}|{'' if n is None else n}|{'' if dn is None else dn}")
+    fx["pose_cases"] = np.array(rows)
+    fx["euler_theta"] = np.array([[0.1, -0.7, 0.3], [0.0, 0.6, 0.0], [-1.2, 0.4, 2.0]])
+    fx["euler_R"] = np.stack([m.eulerAnglesToRotationMatrix(th) for th in fx["euler_theta"]])
+    # get_combined
+    rs = np.random.RandomState(5)
+    g, a = rs.randn(2, 3, 16, 16).astype(np.float32), rs.randn(2, 3, 16, 16).astype(np.float32)
+    bgm = rs.rand(2, 16, 16) > 0.5
+    fx.update(comb_gen=g, comb_ar=a, comb_bg=bgm, comb_out=m.get_combined(t(g), t(a), t(bgm)).numpy())
+    # forward_scene schedule
+    for tag, seq, dirs, split, setting in (("far_first", False, ["R", "L"], 2, "gen_scene"), ("sequential", True, ["R", "L"], 2, "gen_scene"),
+                                           ("far_first_UC", False, ["U", "C", "DL"], 3, "gen_scene"), ("sequential_UC", True, ["U", "C", "DL"], 3, "gen_scene"),
+                                           ("two_imgs", False, None, 4, "gen_two_imgs")):
+        mm = _reference_model(zb, model_setting=setting, directions=dirs, num_split=split, sequential_outpainting=seq,
+                              no_outpainting=True, num_samples=1)
+        calls = []
+
+        def fake_cumulative(fs, pts, K, K_inv, RT1, RT1inv, RT2, RT2inv, prior, fs_old, last_bg, RT3inv):
+            k = len(calls)
+            calls.append(dict(RT1=RT1.numpy().copy(), RT1inv=RT1inv.numpy().copy(), RT2=RT2.numpy().copy(),
+                              RT2inv=RT2inv.numpy().copy(), RT3inv=None if RT3inv is None else RT3inv.numpy().copy(),
+                              src_tag=float(fs.flatten()[0]), prior_tag=None if prior is None else float(prior.flatten()[0])))
+            gen = torch.full((1, 3, 8, 8), float(k + 1))           # frame k is recognisable by its value
+            return gen, torch.zeros(1, 8, 8, dtype=torch.bool), torch.full((1, 4, 5), float(k + 1)), torch.full((1, 3, 5), float(k + 1))
+        mm.pts_transformer.forward_justpts_cumulative = fake_cumulative
+        class _Fn(torch.nn.Module):
+            def __init__(self, fn):
+                super().__init__()
+                self.fn = fn
+
+            def forward(self, x):
+                return self.fn(x)
+        mm.pts_regressor = _Fn(lambda img: torch.zeros(1, 1, 8, 8))
+        mm.projector = _Fn(lambda x: x)
+        del mm._modules['loss_function']
+        mm.__dict__['loss_function'] = lambda a, b: {}     # 'loss not used' (:591); its modules only exist on a GPU
+        cam = {k: t(v) for k, v in syn.demo_cameras(1).items()}
+        batch = {"images": [torch.zeros(1, 3, 8, 8)], "cameras": [cam]}
+        if setting == "gen_two_imgs":
+            batch["direction"] = torch.tensor(5)     # mapping[5] = 'UR'
+        import contextlib
+        import io
+        with contextlib.redirect_stdout(io.StringIO()), torch.no_grad():
+            out = mm.forward_scene(batch)
+        if isinstance(out, tuple):
+            out = out[-1]
+        fx[f"scene_{tag}_n"] = np.array(len(calls))
+        for k, c in enumerate(calls):
+            for key in ("RT1", "RT1inv", "RT2", "RT2inv"):
+                fx[f"scene_{tag}_{k}_{key}"] = c[key]
+            fx[f"scene_{tag}_{k}_RT3inv"] = np.zeros((0,)) if c["RT3inv"] is None else c["RT3inv"]
+            fx[f"scene_{tag}_{k}_src"] = np.array(c["src_tag"])       # 0 = the input image, k = output of call k-1
+        keys = sorted(k for k in out if k.startswith("PredImg_"))
+        fx[f"scene_{tag}_pred_keys"] = np.array(keys)
+        fx[f"scene_{tag}_pred_frame"] = np.array([float(out[k].flatten()[0]) for k in keys])   # which call produced the key
+        fx[f"scene_{tag}_all_keys"] = np.array(sorted(out.keys()))
+        fx[f"scene_{tag}_opts"] = np.array([str(seq), ",".join(dirs or ["UR(two)"]), str(split), setting])
+    np.savez_compressed(os.path.join(HERE, "poses.npz"), **fx)
+    print("poses.npz", len(fx))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     R = _import_reference()
-    which = sys.argv[1:] or ["projection", "orders", "layers", "blocks", "network", "ar", "vqvae", "networks"]
+    which = sys.argv[1:] or ["projection", "orders", "layers", "blocks", "network", "ar", "vqvae", "networks", "poses"]
     if "projection" in which:
         gen_projection(R)
     if "orders" in which:
@@ -387,3 +529,5 @@ if __name__ == "__main__":
         gen_vqvae(R)
     if "networks" in which:
         gen_networks(R)
+    if "poses" in which:
+        gen_poses(R)

@@ -29,23 +29,21 @@ def make_model(S=256, K=128, **kw):
     return m.to(DEV)
 
 
-def test_get_rt_from_rot_matches_restated_poses():
+def test_get_rt_from_rot_on_the_device_matches_the_reference_fixture():
+    """a15 on device tensors against poses.npz, recorded from the reference's own get_rt_from_rot
+    (tests/golden/make_golden.py:gen_poses); every branch: directions at opt.rotation, num/denom sweeps, the 'C' and 'S'
+    circles, homography.  (tests/test_poses_cpu.py runs the same fixture on the host.)  Tolerance: torch.inverse on the
+    GPU is another LU than on the CPU, 1e-5."""
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "poses.npz"))
     m = make_model()
-    P = tt(syn.demo_cameras(1)["P"])
-    for direction, yaw in (("R", 0.6), ("L", -0.6)):
-        m.opt.direction = direction
-        RTinv, RT = m.get_rt_from_rot(direction, P)
-        inv_ref, rt_ref = syn.yaw_pose(syn.demo_cameras(1)["P"], yaw)
-        np.testing.assert_allclose(RT.cpu().numpy(), rt_ref, rtol=1e-6, atol=1e-6)
-        np.testing.assert_allclose(RTinv.cpu().numpy(), inv_ref, rtol=1e-5, atol=1e-5)
-    m.opt.model_setting = "gen_scene"
-    RTinv, RT = m.get_rt_from_rot("C", P, 5, 64)      # circle trajectory, z_buffermodel.py:217-225
-    inv_ref, rt_ref = syn.circle_pose(syn.demo_cameras(1)["P"], 5, 64)
-    np.testing.assert_allclose(RT.cpu().numpy(), rt_ref, rtol=1e-6, atol=1e-6)
-    RTinv, RT = m.get_rt_from_rot("U", P, 3, 8)       # rotvec * num / denom
-    rt_ref = syn.yaw_pose(syn.demo_cameras(1)["P"], 0.0, pitch=-0.3 * 3 / 8)[1]
-    np.testing.assert_allclose(RT.cpu().numpy(), rt_ref, rtol=1e-6, atol=1e-6)
-    np.testing.assert_allclose((RT @ RTinv).cpu().numpy()[0], np.eye(4), atol=1e-5)
+    for ci, row in enumerate(fx["pose_cases"]):
+        setting, hom, rot, d, n, dn = str(row).split("|")
+        m.opt.model_setting, m.opt.homography, m.opt.rotation = setting, bool(int(hom)), float(rot)
+        for pname in ("demo", "mp3d", "rigid"):
+            RTinv, RT = m.get_rt_from_rot(d, tt(fx[f"P_{pname}"]), int(n) if n else None, int(dn) if dn else None)
+            assert RT.is_cuda and RTinv.is_cuda
+            np.testing.assert_allclose(RT.cpu().numpy(), fx[f"pose{ci}_{pname}_RT"], rtol=0, atol=1e-6)
+            np.testing.assert_allclose(RTinv.cpu().numpy(), fx[f"pose{ci}_{pname}_RTinv"], rtol=1e-5, atol=1e-5)
 
 
 def test_get_masks_for_batch_reference_layout_and_compact():
