@@ -5,6 +5,7 @@ path without source edits:
     import pixelsynth_amd.compat; pixelsynth_amd.compat.install_reference_aliases()
 """
 import importlib
+import importlib.util
 import sys
 import types
 
@@ -21,9 +22,31 @@ ALIASES = {
 }
 
 
+def _parent_package(pkg):
+    """The reference's own package when its tree is importable (demo.py run from a checkout: everything that is NOT
+    aliased -- models.networks, models.base_model, ... -- must keep resolving through the real package's __path__);
+    an empty namespace module only when there is nothing to import."""
+    if pkg in sys.modules:
+        return sys.modules[pkg]
+    try:
+        return importlib.import_module(pkg)
+    except Exception:   # ImportError, or a package __init__ that needs what this machine lacks
+        sys.modules.pop(pkg, None)
+    m = types.ModuleType(pkg)
+    m.__path__ = []
+    spec = None
+    try:
+        spec = importlib.util.find_spec(pkg)
+    except Exception:
+        pass
+    if spec is not None and spec.submodule_search_locations:
+        m.__path__ = list(spec.submodule_search_locations)   # the real directory: non-aliased submodules still resolve
+    sys.modules[pkg] = m
+    return m
+
+
 def install_reference_aliases(force=False):
-    """Register the mirrors under the reference's module names.  Parent packages that are not importable
-    (the reference tree absent) are created as empty namespace modules."""
+    """Register the mirrors under the reference's module names."""
     installed = []
     for ref, ours in ALIASES.items():
         if ref in sys.modules and not force:
@@ -31,10 +54,9 @@ def install_reference_aliases(force=False):
         parts = ref.split(".")
         for i in range(1, len(parts)):
             pkg = ".".join(parts[:i])
-            if pkg not in sys.modules:
-                m = types.ModuleType(pkg)
-                m.__path__ = []
-                sys.modules[pkg] = m
+            parent = _parent_package(pkg)
+            if i > 1:
+                setattr(sys.modules[".".join(parts[:i - 1])], parts[i - 1], parent)
         mod = importlib.import_module(ours)
         sys.modules[ref] = mod
         setattr(sys.modules[".".join(parts[:-1])], parts[-1], mod)

@@ -12,6 +12,7 @@
 #include <queue>
 #include <tuple>
 #include <utility>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -131,7 +132,8 @@ int ps_ar_plan(const uint8_t *bg, int B, int S, int G, int32_t *order_loc, uint8
     const int L = G * G;
     // frames are independent: one worker per frame (up to 16), each with its own scratch; the first failure wins
     std::vector<int> first_b((size_t)B, L), rc_b((size_t)B, PS_OK);
-    auto one_frame = [&](int b) {
+    std::vector<std::string> msg_b((size_t)B);   // the error channel is thread-local: a worker's message is carried over by hand
+    auto one_frame_impl = [&](int b) {
         std::vector<int32_t> order((size_t)L * 2);
         uint8_t *reg = region + (size_t)b * L;
         if ((rc_b[b] = ps_generation_order(bg + (size_t)b * S * S, S, G, order.data(), reg, nullptr))) return;
@@ -147,6 +149,10 @@ int ps_ar_plan(const uint8_t *bg, int B, int S, int G, int32_t *order_loc, uint8
         if ((rc_b[b] = ps_kernel_masks_f32(order.data(), L, G, G, 3, 1, 1, mask_undilated + mo))) return;
         rc_b[b] = ps_kernel_masks_f32(order.data(), L, G, G, 3, 2, 1, mask_dilated + mo);
     };
+    auto one_frame = [&](int b) {
+        one_frame_impl(b);
+        if (rc_b[b]) msg_b[b] = ps::last_error_ref();
+    };
     const int nthreads = std::min(B, 16);
     if (nthreads <= 1) {
         one_frame(0);
@@ -159,7 +165,7 @@ int ps_ar_plan(const uint8_t *bg, int B, int S, int G, int32_t *order_loc, uint8
     }
     int first = L;
     for (int b = 0; b < B; ++b) {
-        if (rc_b[b]) return rc_b[b];
+        if (rc_b[b]) return ps::fail(rc_b[b], "ar_plan: frame %d: %s", b, msg_b[b].c_str());
         first = std::min(first, first_b[b]);
     }
     if (first_step) *first_step = first;

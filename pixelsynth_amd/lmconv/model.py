@@ -75,12 +75,31 @@ class PixelCNNEngine:
         except Exception:
             pass
 
-    # masks: (F,9,L) f32 contiguous device tensors
+    def _frame_masks(self, F_, *masks):
+        """The kernels index the three masks per frame, (F,9,L) f32 contiguous: a (1,9,L) mask -- the reference's broadcast
+        form, what get_masks() returns -- is expanded here; anything else is refused before a kernel reads past it."""
+        out = []
+        for m in masks:
+            if m.dim() != 3 or m.shape[1] != 9 or m.shape[2] != self.L or m.shape[0] not in (1, F_):
+                raise ValueError(f"mask of shape {tuple(m.shape)}: expected ({F_}|1, 9, {self.L})")
+            if m.shape[0] != F_:
+                m = m.expand(F_, -1, -1)
+            out.append(m.to(torch.float32).contiguous())
+        return out
+
+    def _frame_arg(self, F_, name, t, dtype):
+        if t is not None and (tuple(t.shape) != (F_, self.L) or t.dtype != dtype or not t.is_contiguous()):
+            raise ValueError(f"{name}: expected a contiguous ({F_}, {self.L}) {dtype} tensor, got {tuple(t.shape)} {t.dtype}")
+
+    # masks: (F,9,L) or (1,9,L) f32 device tensors
     def forward(self, codes, mask_init, mask_undilated, mask_dilated):
         """codes (F,L) or (F,H,W) int32 (-1 = zero input) -> logits (F,512,H,W)."""
         F_ = codes.shape[0]
+        if F_ > self.max_frames:
+            raise ValueError(f"{F_} frames on an engine built for {self.max_frames}")
         codes = codes.reshape(F_, self.L).to(torch.int32).contiguous()
         _lib.require_cuda(codes, mask_init, mask_undilated, mask_dilated)
+        mask_init, mask_undilated, mask_dilated = self._frame_masks(F_, mask_init, mask_undilated, mask_dilated)
         logits = torch.empty(F_, 512, self.H, self.W, dtype=torch.float32, device=codes.device)
         rc = _lib.lib().ps_pixelcnn_forward_f32(self.handle, _lib.ptr(codes), _lib.ptr(mask_init),
                                                 _lib.ptr(mask_undilated), _lib.ptr(mask_dilated), F_,
@@ -95,8 +114,11 @@ class PixelCNNEngine:
         (cols device int32 (n,2), wave_start host int32 array) as from wavefronts() -- same results, far fewer
         dependent launches.  Returns out_logits (F,L,512) or None."""
         F_ = codes.shape[0]
-        _lib.require_cuda(codes, order, region, mask_init, mask_undilated, mask_dilated)
-        assert codes.dtype == torch.int32 and codes.is_contiguous()
+        _lib.require_cuda(codes, order, region, mask_init, mask_undilated, mask_dilated, forced, uniforms)
+        mask_init, mask_undilated, mask_dilated = self._frame_masks(F_, mask_init, mask_undilated, mask_dilated)
+        for name, t, dt in (("codes", codes, torch.int32), ("order", order, torch.int32), ("region", region, torch.uint8),
+                            ("forced", forced, torch.int32), ("uniforms", uniforms, torch.float32)):
+            self._frame_arg(F_, name, t, dt)
         out = torch.empty(F_, self.L, 512, dtype=torch.float32, device=codes.device) if want_logits else None
         head = (self.handle, _lib.ptr(codes), _lib.ptr(order), _lib.ptr(region), _lib.ptr(mask_init),
                 _lib.ptr(mask_undilated), _lib.ptr(mask_dilated), _lib.ptr(forced), _lib.ptr(uniforms),
@@ -115,6 +137,9 @@ class PixelCNNEngine:
 
     def ar_step(self, codes, order, mask_init, mask_undilated, mask_dilated, step, first_step):
         F_ = codes.shape[0]
+        mask_init, mask_undilated, mask_dilated = self._frame_masks(F_, mask_init, mask_undilated, mask_dilated)
+        self._frame_arg(F_, "codes", codes, torch.int32)
+        self._frame_arg(F_, "order", order, torch.int32)
         logits = torch.empty(F_, 512, dtype=torch.float32, device=codes.device)
         rc = _lib.lib().ps_pixelcnn_ar_step(self.handle, _lib.ptr(codes), _lib.ptr(order), _lib.ptr(mask_init),
                                             _lib.ptr(mask_undilated), _lib.ptr(mask_dilated), F_, int(step),

@@ -3,8 +3,8 @@ models/lmconv/sample.py:sample() (same signature, same return value).
 
 Three evaluation modes (args.ar_mode or env PS_AR_MODE):
   "fused"       (default) the whole loop runs on the device through ps_pixelcnn_ar_run: exact
-                incremental evaluation (one network COLUMN per order position against cached
-                activations, replayed as a hipGraph) and an inverse-CDF categorical draw from
+                incremental evaluation (one network COLUMN per location against cached activations,
+                all columns of a dependency level in one launch) and an inverse-CDF categorical draw from
                 softmax(logits/T) with uniforms taken from torch's generator after the reference's
                 seeding rule.  Same distribution as the reference, different RNG stream.
   "multinomial" the incremental evaluation, but every draw is torch.multinomial called exactly as
@@ -89,6 +89,7 @@ def sample(model, generation_idx, mask_init, mask_undilated, mask_dilated, batch
             uniforms = torch.rand(B, L, device=dev, dtype=torch.float32)
             eng.ar_run(c32, order, region, m_i, m_u, m_d, temperature=temperature, uniforms=uniforms,
                        first_step=first, waves=wavefronts(order_np, H, W, first, dev))
+            eng.check()   # a column launch that gave up on an in-launch wait raises here instead of returning wrong codes
         elif mode == "multinomial":
             c32[region.bool()] = -1
             flat_region = region.bool()
@@ -104,6 +105,7 @@ def sample(model, generation_idx, mask_init, mask_undilated, mask_dilated, batch
                         new_samples = torch.multinomial(prob, 1).squeeze(-1)
                     c32[b, q] = new_samples[b].to(torch.int32)
             del flat_region
+            eng.check()
         else:
             raise ValueError(f"unknown AR mode {mode!r}")
         data = F.one_hot(c32.view(B, H, W).to(torch.int64), num_classes).permute(0, 3, 1, 2).to(torch.float32)

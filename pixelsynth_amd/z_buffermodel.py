@@ -232,7 +232,7 @@ class ZbufferModelPts(nn.Module):
         return planned
 
     def outpaint_views(self, fs, depth, K, K_inv, input_RT, input_RTinv, output_RT, output_RTinv, codes,
-                       temperature=0.7, uniforms=None, forced=None):
+                       temperature=0.7, uniforms=None, forced=None, check=True):
         """V independent novel views in one pass: reproject + splat (a2-a6), order + masks (a7-a9),
         AR outpainting of the 32x32 code grid (a13, fused device loop).
         fs (V,C,S,S), depth (V,1,S,S), cameras (V,4,4), codes (V,32,32) int (the VQ-VAE codes of the
@@ -240,7 +240,10 @@ class ZbufferModelPts(nn.Module):
         Callers with several batches can overlap the host part of the next batch with the AR run of this one:
         plan_views on a side stream while outpaint_planned runs (bench.py, driver.py do)."""
         planned = self.plan_views(fs, depth, K, K_inv, input_RT, input_RTinv, output_RT, output_RTinv)
-        return self.outpaint_planned(planned, codes, temperature, uniforms, forced)
+        out = self.outpaint_planned(planned, codes, temperature, uniforms, forced)
+        if check:   # synchronises; pipelined callers (plan_views / outpaint_planned) pass check=False and ask the engine once
+            self.outpaint2.engine(self.obs[1], self.obs[2], fs.shape[0]).check()
+        return out
 
     # ---------------------------------------------------------------- reference-shaped single image path
     @torch.no_grad()
@@ -248,32 +251,46 @@ class ZbufferModelPts(nn.Module):
         """Hot-path part of forward_image (z_buffermodel.py:291-419) for model_setting gen_img / gen_paired_img.
         batch: {"images": [(B,3,S,S)], "cameras": [{"P","Pinv","K","Kinv"}], optional "depths": [(B,1,S,S)],
         optional "codes": (B,32,32)} -> (None, outputs dict with the reference's keys)."""
-        dev = torch.device("cuda", torch.cuda.current_device())
+        dev = next(self.parameters()).device   # (the renderer itself refuses anything but the GPU)
         input_img = batch["images"][0].to(dev)
         cam = {k: v.to(dev) for k, v in batch["cameras"][0].items() if torch.is_tensor(v)}
         K, K_inv, input_RT, input_RTinv = cam["K"], cam["Kinv"], cam["P"], cam["Pinv"]
-        output_RTinv, output_RT = self.get_rt_from_rot(self.opt.direction, input_RT)
+        paired = getattr(self.opt, "model_setting", "gen_img") == "gen_paired_img"
+        if paired:   # :294-295 (process_batch :127-130): the target view comes with the batch
+            output_img = batch["images"][-1].to(dev)
+            output_RT, output_RTinv = batch["cameras"][-1]["P"].to(dev), batch["cameras"][-1]["Pinv"].to(dev)
+        else:
+            output_RTinv, output_RT = self.get_rt_from_rot(self.opt.direction, input_RT)
         if self.pts_regressor is not None:
             regressed_pts = torch.sigmoid(self.pts_regressor(input_img)) * (self.opt.max_z - self.opt.min_z) + self.opt.min_z
         else:
             regressed_pts = batch["depths"][0].to(dev)
-        fs = input_img
+        fs = input_img if getattr(self.opt, "use_rgb_features", True) else self.encoder(input_img)
         gen_fs, background_mask = self.pts_transformer.forward_justpts(fs, regressed_pts, K, K_inv, input_RT,
                                                                       input_RTinv, output_RT, output_RTinv)
-        masks_init, masks_undilated, masks_dilated, gen_order = self.get_masks_for_batch(output_RT, input_RTinv,
-                                                                                         background_mask)
+        outputs = {"InputImg": input_img, "PredDepthImg": regressed_pts / 5 - 1,
+                   "ForegroundImg": (~background_mask).repeat(input_img.shape[0], 1, 1, 1).float(), "FeaturesImg": gen_fs}
+        if paired:
+            outputs["OutputImg"] = output_img
+        if getattr(self.opt, "no_outpainting", False):   # :383-384
+            outputs["PredImg"] = gen_fs if self.projector is None else self.projector(gen_fs)
+            return None, outputs
         if self.vqvae is not None:
             enc = getattr(self.vqvae, "encode_codes", None)      # our mirror: top codes only, int32, on the device
             downsampled_fs = enc(gen_fs) if enc is not None else self.vqvae.encode(gen_fs)[3]
         else:
             downsampled_fs = batch["codes"].to(dev)
+        if max(int(getattr(self.opt, "num_samples", 1)), 1) > 1:   # :349 -> get_best_sample with opt.num_samples candidates
+            plan = self.get_masks_for_batch(output_RT, input_RTinv, background_mask, compact=True)
+            outputs["PredImg"] = self.get_best_sample(plan, downsampled_fs, background_mask, gen_fs, netD, input_img)
+            return None, outputs
+        masks_init, masks_undilated, masks_dilated, gen_order = self.get_masks_for_batch(output_RT, input_RTinv,
+                                                                                         background_mask)
         autoreg_output, _ = sample(self.outpaint2, gen_order, masks_init, masks_undilated, masks_dilated,
                                    downsampled_fs, self.obs, self.args, 0, self.opt.temperature,
                                    self.downsample(background_mask.float()))
         codes = torch.argmax(autoreg_output, dim=1)
-        outputs = {"InputImg": input_img, "PredDepthImg": regressed_pts / 5 - 1,
-                   "ForegroundImg": (~background_mask).repeat(input_img.shape[0], 1, 1, 1).float(),
-                   "FeaturesImg": gen_fs, "PredCodes": codes}
+        outputs["PredCodes"] = codes
         if self.vqvae is not None:  # :250-252 (without a refinement net the blend itself is the prediction)
             outputs["PredImg"] = self._decode_candidate(gen_fs, background_mask, codes.to(torch.int64))
         return None, outputs
@@ -329,6 +346,7 @@ class ZbufferModelPts(nn.Module):
             eng.ar_run(c, rep(plan.order_loc), rep(plan.region), rep(plan.mask_init), rep(plan.mask_undilated),
                        rep(plan.mask_dilated), temperature=self.opt.temperature,
                        uniforms=uniforms[s0:s0 + k].reshape(k * B, L).contiguous(), first_step=plan.first_step, waves=waves)
+            eng.check()
             for j in range(k):
                 img = self._decode_candidate(gen_fs, background_mask, c[j * B:(j + 1) * B].view(B, G, self.obs[2]))
                 imgs.append(img)

@@ -29,6 +29,28 @@ def test_aliases_resolve_in_a_fresh_interpreter():
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
 
 
+@pytest.mark.skipif(not os.path.isdir("/root/reference/models"), reason="needs the reference checkout (build container only)")
+def test_aliases_keep_the_reference_tree_importable():
+    """INTEGRATION.md option A: demo.py run from a reference checkout.  With the reference on sys.path the aliased modules
+    resolve to the mirrors AND everything that is not aliased (models.networks.configs, ...) still imports from the
+    reference's own packages -- a synthesised empty parent package would hide them."""
+    code = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, '/root/reference')\n"
+        "import pixelsynth_amd.compat as c; c.install_reference_aliases()\n"
+        "import models.networks.configs as cfg\n"
+        "assert cfg.__file__.startswith('/root/reference/'), cfg.__file__\n"
+        "from models.lmconv.model import OurPixelCNN\n"
+        "assert OurPixelCNN.__module__ == 'pixelsynth_amd.lmconv.model'\n"
+        "import models.lmconv.masking as m\n"
+        "assert m.__name__ == 'pixelsynth_amd.lmconv.masking'\n"
+        "import models.vqvae2.vqvae as v\n"
+        "assert v.__name__ == 'pixelsynth_amd.vqvae2.vqvae'\n"
+        "import models.lmconv.average_checkpoints\n"       # a non-aliased sibling of aliased modules
+        "print('ok')\n" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+
+
 def test_state_dict_keys_match_reference_order():
     from pixelsynth_amd.lmconv.layers import PONO
     from pixelsynth_amd.lmconv.model import PARAM_KEYS, OurPixelCNN

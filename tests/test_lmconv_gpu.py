@@ -178,6 +178,31 @@ def test_ar_teacher_forced_vs_reference_sample_trace(golden_dir):
     assert np.array_equal(outs[1][0], full)
 
 
+@pytest.mark.parametrize("cap", [128, 0, 1024])
+def test_ar_wavefront_run_teacher_forced_vs_reference_sample_trace(golden_dir, cap):
+    """The product path itself (ps_pixelcnn_ar_run_waves, what sample() / outpaint_views run) teacher-forced with the codes the
+    REFERENCE's own sample() drew: the logits every sampled position was decided from against the logits the reference's
+    loop saw at that step (1e-4), directly -- not through the position-by-position walk."""
+    from pixelsynth_amd.lmconv.model import wavefronts
+    fx = np.load(os.path.join(golden_dir, "ar_trace.npz"))
+    net = make_net(int(fx["wseed"]))
+    eng = net.engine(32, 32, 1)
+    order, region, order_loc, reg, first = _ar_setup(fx)
+    mi, mu, md = masks_for(order)
+    codes0 = syn.codes(int(fx["codes_seed"]), 1).reshape(1, 1024).astype(np.int32)
+    final = fx["final_codes"].astype(np.int32).reshape(1, 1024)
+    c = tt(codes0.copy())
+    waves = wavefronts(order_loc, 32, 32, first, DEV, max_cols=cap)
+    out = eng.ar_run(c, tt(order_loc), tt(reg), mi, mu, md, temperature=0.7, forced=tt(final), first_step=first,
+                     want_logits=True, waves=waves)
+    eng.check()
+    torch.cuda.synchronize()
+    assert np.array_equal(c.cpu().numpy(), final)
+    got = np.stack([out.cpu().numpy()[0, i * 32 + j] for i, j in region])[::4]
+    np.testing.assert_allclose(got, fx["step_logits"], rtol=1e-4, atol=1e-4)
+    assert len(waves[1]) - 1 < len(region)      # fewer launches than sampled positions: the schedule is a real wavefront one
+
+
 def test_ar_fused_sampling_inverse_cdf_and_determinism():
     net = make_net(3)
     F_ = 3

@@ -134,21 +134,56 @@ def tt(a):
     return torch.from_numpy(np.ascontiguousarray(a)).to(dev())
 
 
+def _fixture_camera(name):
+    """camera set and depth range a projection fixture was generated with (tests/golden/make_golden.py:poses)"""
+    return (syn.mp3d_cameras(1), 0.5, 10.0) if name.startswith("mp3d") else (syn.demo_cameras(1), 1.0, 100.0)
+
+
 def test_project_pts_vs_oracle_and_golden(golden_dir):
+    """Every pose of the fixture, the demo cameras (K = I) and the Matterport-shaped ones
+    (K = diag(1/tan(hfov/2), .., 1, 1), depth 0.5-10: config C5) alike."""
     fx = np.load(os.path.join(golden_dir, "projection.npz"))
-    cam = syn.demo_cameras(1)
-    for name in ("demo_L", "demo_R", "demo_circle5"):
+    names = [str(n) for n in fx["pose_names"]]
+    assert {"demo_L", "demo_R", "demo_circle5", "mp3d_yaw", "mp3d_back"} <= set(names)
+    for name in names:
+        cam, lo, hi = _fixture_camera(name)
         RT2 = fx[f"pose_{name}_RT2"]
         for W, stride in ((16, 1), (256, 61)):
             pm = _manip(W)
-            d = syn.depth_uniform(7, 2, W, 1.0, 100.0)
+            d = syn.depth_uniform(7, 2, W, lo, hi)
             rep = lambda m: tt(np.repeat(m, 2, 0))
             s = pm.project_pts(tt(d).view(2, 1, -1), rep(cam["K"]), rep(cam["Kinv"]), rep(cam["P"]), rep(cam["Pinv"]),
                                rep(RT2), rep(fx[f"pose_{name}_RT2inv"])).cpu().numpy()
-            np.testing.assert_allclose(s[:, :, ::stride], fx[f"proj_{name}_W{W}"], rtol=2e-5, atol=2e-5)
+            np.testing.assert_allclose(s[:, :, ::stride], fx[f"proj_{name}_W{W}"], rtol=2e-5, atol=2e-5, err_msg=f"{name} W{W}")
             ref = c_oracle.project_pts(d, np.repeat(cam["K"], 2, 0), np.repeat(cam["Kinv"], 2, 0),
                                        np.repeat(cam["Pinv"], 2, 0), np.repeat(RT2, 2, 0), W)
             assert np.array_equal(s, ref), f"{name} W{W}: {np.abs(s - ref).max()}"
+
+
+def test_forward_justpts_matterport_shaped_vs_oracle(golden_dir):
+    """C5's inputs through the fused kernel: K != I (hfov 90 deg), depth 0.5-10, a yaw + pitch target pose and a view that
+    looks backwards (most points behind the camera / outside the frame): mask bit-exact, features 1e-6, idx / dist
+    bit-exact through the unfused route."""
+    fx = np.load(os.path.join(golden_dir, "projection.npz"))
+    S, B = 256, 2
+    cam = syn.mp3d_cameras(1)
+    img = syn.image(21, B, 3, S)
+    depth = np.concatenate([syn.depth_smooth(22, 1, S, 0.5, 10.0), syn.depth_uniform(23, 1, S, 0.5, 10.0)])
+    rep = lambda m: np.repeat(m, B, 0)
+    pm = _manip(S)
+    for name in ("mp3d_yaw", "mp3d_back"):
+        RT2, RT2inv = fx[f"pose_{name}_RT2"], fx[f"pose_{name}_RT2inv"]
+        args = [tt(rep(cam[k])) for k in ("K", "Kinv", "P", "Pinv")] + [tt(rep(RT2)), tt(rep(RT2inv))]
+        feat, bg = pm.forward_justpts(tt(img), tt(depth), *args)
+        sampler = c_oracle.project_pts(depth, rep(cam["K"]), rep(cam["Kinv"]), rep(cam["Pinv"]), rep(RT2), S)
+        ref = c_oracle.splat_forward(np.ascontiguousarray(sampler.transpose(0, 2, 1)), img.reshape(B, 3, -1), S)
+        assert np.array_equal(bg.cpu().numpy(), ref["bg"]), name
+        np.testing.assert_allclose(feat.cpu().numpy(), ref["feat"], rtol=0, atol=1e-6, err_msg=name)
+        s = pm.project_pts(tt(depth).view(B, 1, -1), *args)
+        f2, bg2, idx, zbuf, dist = pm.splatter(s.permute(0, 2, 1).contiguous(), tt(img).view(B, 3, -1), return_debug=True)
+        assert torch.equal(f2, feat) and torch.equal(bg2, bg)
+        assert np.array_equal(idx.cpu().numpy(), ref["idx"]) and np.array_equal(dist.cpu().numpy(), ref["dist"])
+    assert 0.02 < ref["bg"].mean()
 
 
 def test_project_pts_cumulative_vs_golden(golden_dir):
