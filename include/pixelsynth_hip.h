@@ -238,6 +238,11 @@ int ps_pixelcnn_ar_step(ps_pixelcnn *h, const int32_t *codes, const int32_t *ord
  * limit (its results are then invalid).  Tests, smoke() and bench.py call it after their runs. */
 int ps_pixelcnn_status(ps_pixelcnn *h, void *stream);
 
+/* Debugging aid (tools/tp_debug.py; not part of the reference surface): device address of one of the handle's
+ * activation caches -- what 0: raw u of node idx (19 nodes, row stride 96 floats), 1: concat_elu(u) of node idx (160),
+ * 2: the activation inside gated resnet idx (14 blocks, 160); rows are frame * L + location.  NULL if out of range. */
+void *ps_pixelcnn_debug_cache(ps_pixelcnn *h, int what, int idx);
+
 /* Measurement aid for bench.py (not part of the reference surface): evaluates `reps` order positions
  * eagerly on `stream` (at position `step`, without drawing) with a HIP event pair around every kernel
  * launch and returns the number of launches and their summed duration in ms:

@@ -486,8 +486,14 @@ struct StepCtx {
 };
 static_assert(sizeof(StepCtx) == 160, "one record = 160 bytes");
 
+// cache rows (frame * L + location) of the eight neighbour taps of a column for the two mask kinds the convs use
+// (type B dilation 1, type B dilation 2), -1 = tap closed or outside the grid; taps 0..3 = slot NA, 4..7 = slot NB
+struct ColTaps { int row[2][8]; };
+static_assert(sizeof(ColTaps) == 64, "one record = 64 bytes");
+
 struct CtxArgs {
     StepCtx *ctx;     // [columns of the run]
+    ColTaps *taps;    // [columns of the run] neighbour rows for the throughput form (k_column_tp)
     const int32_t *order;
     const float *mask[3];
     int F, L;
@@ -520,6 +526,13 @@ __global__ __launch_bounds__(32) void k_ctx_build(CtxArgs a, const int32_t *cols
         const int loc = ctx_nbr_loc(q, t, H, W);
         const float mA = a.mask[0][((size_t)f * 9 + t) * a.L + q];
         c->nloc[t] = (loc >= 0 && mA != 0.0f) ? loc : -1;
+    }
+    if (t < 16) {  // neighbour rows for k_column_tp: kind 0 = type B dilation 1, kind 1 = type B dilation 2; the masks are 0 / 1
+        const int kind = t >> 3, tq = t & 7, tap = tq < 4 ? tq : tq + 1, dil = kind + 1;
+        const int r = q / W, cc = q - r * W, rr = r + (tap / 3 - 1) * dil, c2 = cc + (tap % 3 - 1) * dil;
+        const bool in = rr >= 0 && rr < H && c2 >= 0 && c2 < W;
+        const float mv = a.mask[1 + kind][((size_t)f * 9 + tap) * a.L + q];
+        a.taps[k].row[kind][tq] = (in && mv != 0.0f) ? f * a.L + rr * W + c2 : -1;
     }
 }
 
@@ -631,9 +644,13 @@ __device__ __forceinline__ f32x4 nbr_tap(const NbrWork &sd, const NbrArgs &a, co
 // Results that another workgroup of the SAME launch consumes (k_column: neighbour slots -> chain) leave with
 // write-through stores (sc1: past this XCD's L2, which is not coherent with the consumer's); the consumer reads them
 // with device-scope loads after it has seen the completion counter.
+// (hipcc pads no hazard wait states around an asm statement: a store of more than 64 bits still reads its data registers
+// when the next instruction issues, and the compiler is free to overwrite them there -- two of these back to back, the
+// second address computed into the first one's data registers, stored address bits for a quarter of the lanes.  The
+// s_nop covers the VMEM-store-data hazard.)
 __device__ __forceinline__ void store_through(float *p, const f32x4 &v)
 {
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(PS_G(f32x4, p)), "v"(v) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 3" : : "v"(PS_G(f32x4, p)), "v"(v) : "memory");
 }
 __device__ __forceinline__ void signal_done(unsigned *counter, int lane)
 {
@@ -863,9 +880,11 @@ __device__ __forceinline__ void load_chain_weights_part(const float *wv, int nch
 // Control record of one stage for the chain role, C1_CTL_DWORDS dwords in constant memory: record 0 describes the u0
 // post op (norm_init), record 1 + s stage s and the post op that follows it, record NST the nin_out chains.
 // Every role fetches its fields with scalar loads one stage ahead, so no wave ever waits on a descriptor.
-constexpr int C1_CTL_DWORDS = 24;
+constexpr int C1_CTL_DWORDS = 32;
 enum { CTL_CO = 0, CTL_NCHAIN = 1, CTL_NG = 2, CTL_NSTEP = 3, CTL_WV = 4, CTL_BIAS = 6, CTL_KIND = 8, CTL_HAS_SKIP = 9,
-       CTL_IN_FORM = 10, CTL_SAVE_SLOT = 11, CTL_SKIP_SLOT = 12, CTL_NBR_ITEMS = 13 /* of the stage, per tile */, CTL_BIAS2 = 14, CTL_R = 16, CTL_E = 18, CTL_X = 20 };
+       CTL_IN_FORM = 10, CTL_SAVE_SLOT = 11, CTL_SKIP_SLOT = 12, CTL_NBR_ITEMS = 13 /* of the stage, per tile */, CTL_BIAS2 = 14, CTL_R = 16, CTL_E = 18, CTL_X = 20,
+       // throughput mode (k_column_tp): the centre tap / nin_skip in the MFMA layout [c/4][o][4], work items of the stage per tile
+       CTL_WC = 22, CTL_WS = 24, CTL_TP_ITEMS = 26 };
 typedef const __attribute__((address_space(4))) int *CtlInt;
 typedef const __attribute__((address_space(4))) unsigned long long *CtlU64;
 __device__ __forceinline__ int ctl_i(const int *ctl, int rec, int field) { return ((CtlInt)ctl)[rec * C1_CTL_DWORDS + field]; }
@@ -1228,7 +1247,7 @@ __device__ __forceinline__ void chain_role(const ChainArgs &a, int wg)
         int keep = 0;
         auto touch = [&](int rec) {
             rec = min(rec, NST);
-            keep ^= ctl_i(a.ctl1, rec, 0) ^ ctl_i(a.ctl1, rec, 16);  // both 64-byte lines of the 96-byte record
+            keep ^= ctl_i(a.ctl1, rec, 0) ^ ctl_i(a.ctl1, rec, 16);  // both 64-byte lines of the 128-byte record
         };
         for (int r = 0; r < 6; ++r) touch(r);
         lds_barrier();
@@ -1333,6 +1352,430 @@ __global__ __launch_bounds__(C1_THREADS) void k_column(NbrArgs na, ChainArgs ca)
     } else if ((ca.debug & 3) != 3) {
         nbr_role(na, chain_rows * (8 - cx) + (row - chain_rows) * 8 + x);
     }
+}
+
+// ==========================================================================================
+// k_column_tp: the column launch in THROUGHPUT form, for wavefronts of more columns than k_column takes (views x samples
+// in the hundreds).  Same arithmetic, same canonical accumulation order, bit-identical results; what changes is how the
+// work is laid on the chip:
+//   chain role      one 512-thread workgroup (one CU) per TILE OF 16 COLUMNS.  The centre taps are MFMA work now -- 16
+//                   columns are the N of v_mfma_f32_16x16x4_f32 -- so a stage's 104 KB of centre-tap weights are fetched once
+//                   per 16 columns instead of once per column, and a launch takes 64 tiles = 1024 columns.  A stage = MFMA
+//                   phase (units of (16 output channels, accumulation chain j) = 8 dependent MFMAs, dealt round-robin to
+//                   the 8 waves; operand B = the tile's input vectors in LDS, laid out [channel / 4][column][4] so that a
+//                   wave reads a contiguous KB; operand A = weights from L2 into registers, fetched right after the previous
+//                   MFMA phase) -> LDS barrier -> post phase (wave w does the post ops of columns w and w + 8, the very code
+//                   of the latency form: PONO, gate / skip / residual, concat-ELU, cache stores) -> LDS barrier.
+//   neighbour role  every other CU: one WAVE per work item (stage, slot NA|NB, 32 output channels) x 16-column tile, its
+//                   four taps in sequence on two MFMA output tiles that share the gathered input rows (the registers for
+//                   that are there at 8 waves per CU; the 1024-thread latency form has 128 per thread and splits the taps
+//                   over four waves instead).  Items are walked stage-major, so that all CUs work on one stage's weights
+//                   at a time; results leave write-through, a per-(stage, tile) counter publishes them.
+// The hand-off (write-through stores -> device-scope counter -> device-scope loads, bounded waits) is the one of k_column.
+// ==========================================================================================
+constexpr int TP_THREADS = 512, TP_WAVES = TP_THREADS / 64, TP_COLS = 16;
+constexpr int TP_MAX_TILES = 64, TP_COL_CAP = TP_MAX_TILES * TP_COLS;   // 1024 columns per launch
+constexpr int TP_MAXU = 7;            // units per wave and stage: ceil(50 / 8)
+constexpr int XB_LD = 68;             // B-operand layout: dwords per 4-channel group (16 columns x 4 + 4 pad: conflict-free
+constexpr int XB_SIZE = 40 * XB_LD;   //   for the post op's 8-byte writes and for the waves' 16-byte reads)
+constexpr int SP_LD = 5 * 2 * NF + 4; // chain values of one column [j][o] (+ [j][80] of nin_skip): 800 + 4 pad
+constexpr int SLOG_LD = NCLS + 4;     // logits of one column (aliases the chain values)
+static_assert(TP_COLS * SLOG_LD <= TP_COLS * SP_LD, "logits alias the chain-value buffer");
+__device__ __host__ __forceinline__ size_t tp_cnt_index(int stage, int tile) { return ((size_t)stage * TP_MAX_TILES + tile) * CNT_PAD; }
+__device__ __forceinline__ int xb_index(int ch, int col) { return (ch >> 2) * XB_LD + col * 4 + (ch & 3); }
+
+// a work item of the throughput neighbour role = (stage, slot NA|NB, T x 16 output channels from o0)
+struct __attribute__((aligned(16))) NbrWorkTp {
+    const float *w;   // packed weights of the conv [taps][NG*4][Co_pad][4]
+    const float *in;  // cache the taps gather from
+    int stage, half, o0, T;
+    int NG, Co_pad, in_ld, kind /* 0 = und, 1 = dil */;
+};
+static_assert(sizeof(NbrWorkTp) == 48, "three 16-byte loads");
+
+struct TpArgs {
+    // neighbour role
+    const NbrWorkTp *work;
+    const ColTaps *taps;      // records of this launch's columns
+    float *nbr;               // [NST][2][TP_COL_CAP][NBR_LD]
+    unsigned *cnt;            // [NST][TP_MAX_TILES] padded completion counters (tp_cnt_index), never reset
+    int nwork, tiles, nbr_wgs;
+    // chain role (fields as in ChainArgs)
+    const int *ctl1;
+    const float *uinit_w, *uinit_b;
+    const int32_t *codes_in;
+    const StepCtx *ctx;
+    const float *out_w, *out_b;
+    int L, ncols;
+    int32_t *codes;
+    const uint8_t *region;
+    const int32_t *forced;
+    const float *uniforms;
+    float *out_logits, *step_logits;
+    float temperature;
+    unsigned tile_uses[TP_MAX_TILES];
+    int *err;
+    int debug;
+};
+
+template <int T, int NG>
+__device__ __forceinline__ void nbr_item_tp(const NbrWorkTp &wk, const TpArgs &a, int ctile, int lane)
+{
+    const int i = lane & 15, kk = lane >> 4;
+    const int col = ctile * TP_COLS + i;
+    const bool valid = col < a.ncols;
+    const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    i32x4 rows = {-1, -1, -1, -1};
+    if (valid) rows = *PS_GC(i32x4, &a.taps[col].row[wk.kind][wk.half * 4]);
+    f32x4 tot[T];
+#pragma unroll
+    for (int u = 0; u < T; ++u) tot[u] = zero;
+    const size_t gstride = (size_t)16 * wk.Co_pad;   // floats between channel groups of the packed weights
+#pragma unroll
+    for (int tq = 0; tq < 4; ++tq) {
+        const int row = rows[tq];
+        const bool live = row >= 0;
+        if (!__any(live)) continue;   // (a closed tap is an exact zero)
+        const int t = wk.half * 5 + tq;
+        const float *src = wk.in + (size_t)(live ? row : 0) * wk.in_ld + 4 * kk;
+        const float *wbase = wk.w + (size_t)t * NG * gstride + ((size_t)kk * wk.Co_pad + wk.o0 + i) * 4;
+        Acc5 acc[T];
+#pragma unroll
+        for (int u = 0; u < T; ++u) acc[u] = acc5_zero();
+#pragma unroll
+        for (int g0 = 0; g0 < NG; g0 += 5) {
+            f32x4 bv[5];
+#pragma unroll
+            for (int g = 0; g < 5; ++g) bv[g] = *PS_GC(f32x4, src + 16 * (g0 + g));
+#pragma unroll
+            for (int g = 0; g < 5; ++g) bv[g] = live ? bv[g] : zero;   // (mask values are 0 / 1: no multiply needed)
+#pragma unroll
+            for (int u = 0; u < T; ++u) {
+                f32x4 av[5];
+#pragma unroll
+                for (int g = 0; g < 5; ++g) av[g] = *PS_GC(f32x4, wbase + (size_t)(g0 + g) * gstride + 64 * u);
+                mfma_chunk5(av, bv, acc[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < T; ++u) tot[u] = tot[u] + chunk_total(acc[u]);
+    }
+    if (valid) {
+        float *dst = a.nbr + (((size_t)wk.stage * 2 + wk.half) * TP_COL_CAP + col) * NBR_LD + wk.o0 + kk * 4;
+#pragma unroll
+        for (int u = 0; u < T; ++u) store_through(dst + 16 * u, tot[u]);
+    }
+}
+
+__device__ __forceinline__ void nbr_role_tp(const TpArgs &a, int nb)
+{
+    const int wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int gw = nb * TP_WAVES + wave, nw = a.nbr_wgs * TP_WAVES;
+    const int nitems = a.nwork * a.tiles;
+    for (int item = gw; item < nitems; item += nw) {
+        const int witem = item / a.tiles, ctile = item - witem * a.tiles;
+        NbrWorkTp wk;
+        {   // wave-uniform record: scalar loads
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            typedef const __attribute__((address_space(4))) u32x4 *CU4;
+            const CU4 p = (CU4)(a.work + witem);
+            u32x4 r[3];
+            r[0] = p[0]; r[1] = p[1]; r[2] = p[2];
+            __builtin_memcpy(&wk, r, sizeof(wk));
+        }
+        if (wk.T == 2) {
+            if (wk.NG == 10) nbr_item_tp<2, 10>(wk, a, ctile, lane); else nbr_item_tp<2, 5>(wk, a, ctile, lane);
+        } else {
+            if (wk.NG == 10) nbr_item_tp<1, 10>(wk, a, ctile, lane); else nbr_item_tp<1, 5>(wk, a, ctile, lane);
+        }
+        signal_done(a.cnt + tp_cnt_index(wk.stage, ctile), lane);
+    }
+}
+
+__device__ __forceinline__ void chain_role_tp(const TpArgs &a, int tile)
+{
+    __shared__ __attribute__((aligned(16))) float sXb[XB_SIZE];            // input of the centre taps, B-operand layout
+    __shared__ __attribute__((aligned(16))) float sSb[XB_SIZE];            // concat_elu(u_k) feeding nin_skip, same layout
+    __shared__ __attribute__((aligned(16))) float sP[TP_COLS * SP_LD];     // chain values of the stage [col][j][o]; logits at the end
+    __shared__ __attribute__((aligned(16))) float sU[8][TP_COLS][NF];      // u0..u7 of the tile's columns
+    __shared__ __attribute__((aligned(16))) StepCtx sC[TP_COLS];
+    const int t = threadIdx.x, wave = uni(t >> 6), lane = t & 63, i = lane & 15, kk = lane >> 4;
+    const int col0 = tile * TP_COLS;
+    const int ncl = min(TP_COLS, a.ncols - col0);   // columns of this tile (>= 1)
+    {
+        const int nq = (int)(sizeof(StepCtx) / 16);
+        for (int k = t; k < TP_COLS * nq; k += TP_THREADS) {
+            const int c = min(k / nq, ncl - 1);     // absent columns repeat the last one (their results are dropped)
+            ((uint4 *)sC)[k] = ((const uint4 *)(a.ctx + col0 + c))[k % nq];
+        }
+        for (int k = t; k < XB_SIZE; k += TP_THREADS) { sXb[k] = 0.0f; sSb[k] = 0.0f; }
+    }
+    __syncthreads();
+    // ---- post-op side: wave w owns columns w and w + 8, two channels per lane (see pono_total)
+    const bool own = lane < PONO_LANES;
+    const int c2 = own ? 2 * lane : 0;
+    const f32x2 zero2 = {0.0f, 0.0f};
+    bool pvalid[2];
+    int pcol[2], pq[2], pfr[2];
+    size_t ploc[2];
+    f32x2 ucur[2] = {zero2, zero2};
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        pcol[k] = wave + 8 * k;
+        pvalid[k] = pcol[k] < ncl;
+        pq[k] = uni(sC[pcol[k]].q);
+        pfr[k] = uni(sC[pcol[k]].f);
+        ploc[k] = (size_t)pfr[k] * a.L + pq[k];
+    }
+    const size_t nbr_half = (size_t)TP_COL_CAP * NBR_LD, nbr_stage = 2 * nbr_half;
+    const unsigned my_uses = a.tile_uses[tile];
+    auto counter = [&](int k) { return __hip_atomic_load(a.cnt + tp_cnt_index(k, tile), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto wait_counter = [&](int k, unsigned items_per_tile) {
+        if (a.debug & 1) return;
+        const unsigned need = my_uses * items_per_tile;
+        int spins = 0;
+        while ((int)(counter(k) - need) < 0) {
+            if (++spins > 40000) { if (lane == 0) *a.err = 1; break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+    };
+    struct Ops { f32x2 b, na, nb, bg, nag, nbg, b2; };
+    auto fresh = [](const float *p) {
+        const unsigned long long raw = __hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return f32x2{__uint_as_float((unsigned)raw), __uint_as_float((unsigned)(raw >> 32))};
+    };
+    auto plain = [](const float *p) { return *PS_GC(f32x2, p); };
+    // bias and neighbour slots of the post op after stage s (always seven loads from valid addresses, see k_column)
+    auto load_ops = [&](int s, const PostCtl &c, int k, Ops &o) {
+        const float *nb = a.nbr + (size_t)s * nbr_stage + (size_t)(col0 + (pvalid[k] ? pcol[k] : 0)) * NBR_LD + c2;
+        const int gofs = c.kind == PRO_GATE ? NF : 0;
+        const float *b2 = c.has_skip ? c.bias2 : c.bias;
+        o.b = plain(c.bias + c2);
+        o.na = fresh(nb);
+        o.nb = fresh(nb + nbr_half);
+        o.bg = plain(c.bias + gofs + c2);
+        o.nag = fresh(nb + gofs);
+        o.nbg = fresh(nb + nbr_half + gofs);
+        o.b2 = plain(b2 + c2);
+    };
+    // PONO + finish + hand-off: next stage's input into the B-operand layout, values to the caches
+    auto emit = [&](int k, const f32x2 &y, const f32x2 &g, const f32x2 &skip, int kind, bool has_skip, int in_form, int save_slot,
+                    const StoreCtl &sc) {
+        const float mean = pono_mean(pono_total(y, own));
+        const f32x2 d = y - mean;
+        const float inv = pono_inv(pono_total(d * d, own));
+        if (!pvalid[k] || !own) return;
+        const f32x2 n = d * inv;
+        f32x2 out;
+        if (kind == PRO_CONVIN) out = post_finish<POST_CONVIN>(n, zero2, skip, has_skip, zero2);
+        else if (kind == PRO_GATE) out = post_finish<POST_GATE>(n, g, zero2, false, ucur[k]);
+        else out = n;  // PRO_DIL, PRO_UINIT (norm_init)
+        f32x2 ep, en;
+        celu_pair2(out, ep, en);
+        const int col = pcol[k];
+        if (in_form == IN_CELU) { *(f32x2 *)&sXb[xb_index(c2, col)] = ep; *(f32x2 *)&sXb[xb_index(NF + c2, col)] = en; }
+        else if (in_form == IN_RAW) *(f32x2 *)&sXb[xb_index(c2, col)] = out;
+        else *(f32x2 *)&sXb[xb_index(c2, col)] = ep;
+        if (kind == PRO_CONVIN) {
+            *PS_G(f32x2, sc.X + ploc[k] * (2 * NF) + c2) = ep;
+            *PS_G(f32x2, sc.X + ploc[k] * (2 * NF) + NF + c2) = en;
+        } else {
+            *PS_G(f32x2, sc.R + ploc[k] * R_LD + c2) = out;
+            *PS_G(f32x2, sc.E + ploc[k] * (2 * NF) + c2) = ep;
+            *PS_G(f32x2, sc.E + ploc[k] * (2 * NF) + NF + c2) = en;
+            ucur[k] = out;
+            if (save_slot >= 0) *(f32x2 *)(&sU[save_slot][col][c2]) = out;
+        }
+    };
+    // concat_elu(u_k) of the saved u the NEXT stage's nin_skip reads
+    auto stage_skip_input = [&](int k, int skip_slot) {
+        if (skip_slot < 0 || !own) return;
+        const int col = pcol[k];
+        f32x2 ep, en;
+        celu_pair2(*(const f32x2 *)(&sU[skip_slot][col][c2]), ep, en);
+        *(f32x2 *)&sSb[xb_index(c2, col)] = ep;
+        *(f32x2 *)&sSb[xb_index(NF + c2, col)] = en;
+    };
+
+    // ---- MFMA side: unit n of a stage = (16 output channels ot, chain j), n = w, w + 8, ...; main units first, then nin_skip's
+    struct UnitW { f32x4 a0, a1; };
+    UnitW W[TP_MAXU];
+    auto unit_of = [&](int n, int Co, int &ot, int &j, bool &skip) {
+        const int um = 5 * (Co >> 4);
+        skip = n >= um;
+        const int m = skip ? n - um : n;
+        ot = m / 5;
+        j = m - ot * 5;
+    };
+    // weights of this wave's units of the stage described by record `rec` (NG groups: one or two 16-byte loads per unit)
+    auto load_unit_weights = [&](int rec) {
+        const int Co = ctl_i(a.ctl1, rec, CTL_CO), NG = ctl_i(a.ctl1, rec, CTL_NG);
+        const float *wc = ctl_p<const float>(a.ctl1, rec, CTL_WC), *ws = ctl_p<const float>(a.ctl1, rec, CTL_WS);
+        const int total = 5 * (Co >> 4) + (ws ? 5 * (NF >> 4) : 0);
+#pragma unroll
+        for (int u = 0; u < TP_MAXU; ++u) {
+            const int n = min(wave + TP_WAVES * u, total - 1);   // (waves without a u-th unit re-read a valid one: static load counts)
+            int ot, j; bool skip;
+            unit_of(n, Co, ot, j, skip);
+            const float *w = skip ? ws : wc;
+            const int cw = skip ? NF : Co;
+            const float *p0 = w + ((size_t)(4 * j + kk) * cw + ot * 16 + i) * 4;
+            const float *p1 = NG == 10 ? w + ((size_t)(4 * (j + 5) + kk) * cw + ot * 16 + i) * 4 : p0;
+            W[u].a0 = *PS_GC(f32x4, p0);
+            W[u].a1 = *PS_GC(f32x4, p1);
+        }
+    };
+    // NU = units a wave has at most in this stage (7 of 50, 4 of 25): units 0 .. NU-2 exist for every wave, the last one for the
+    // first waves only -- one wave-uniform branch, everything else straight-line
+    auto mfma_units = [&](auto NUc, int rec) {
+        constexpr int NU = decltype(NUc)::value;
+        const int Co = ctl_i(a.ctl1, rec, CTL_CO), NG = ctl_i(a.ctl1, rec, CTL_NG);
+        const bool has_ws = ctl_p<const float>(a.ctl1, rec, CTL_WS) != nullptr;
+        const int um = 5 * (Co >> 4), total = um + (has_ws ? 5 * (NF >> 4) : 0);
+        const bool last = wave + TP_WAVES * (NU - 1) < total;
+        f32x4 b0[NU], b1[NU], acc[NU];
+        int dst[NU];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int n = min(wave + TP_WAVES * u, total - 1);
+            int ot, j; bool skip;
+            unit_of(n, Co, ot, j, skip);
+            const float *src = skip ? sSb : sXb;
+            b0[u] = *(const f32x4 *)&src[(4 * j + kk) * XB_LD + i * 4];
+            b1[u] = *(const f32x4 *)&src[(4 * (NG == 10 ? j + 5 : j) + kk) * XB_LD + i * 4];
+            dst[u] = i * SP_LD + (skip ? 5 * Co + j * NF : j * Co) + ot * 16 + kk * 4;
+            acc[u] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+        // canonical order of a chain: group j (c = 0..3), then group j + 5; the units are independent accumulators
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int u = 0; u < NU - 1; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(W[u].a0[c], b0[u][c], acc[u], 0, 0, 0);
+            if (last) acc[NU - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(W[NU - 1].a0[c], b0[NU - 1][c], acc[NU - 1], 0, 0, 0);
+        }
+        if (NG == 10) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+#pragma unroll
+                for (int u = 0; u < NU - 1; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(W[u].a1[c], b1[u][c], acc[u], 0, 0, 0);
+                if (last) acc[NU - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(W[NU - 1].a1[c], b1[NU - 1][c], acc[NU - 1], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NU - 1; ++u) *(f32x4 *)&sP[dst[u]] = acc[u];
+        if (last) *(f32x4 *)&sP[dst[NU - 1]] = acc[NU - 1];
+    };
+    auto mfma_phase = [&](int rec) {
+        const int Co = ctl_i(a.ctl1, rec, CTL_CO);
+        const bool has_ws = ctl_p<const float>(a.ctl1, rec, CTL_WS) != nullptr;
+        const int total = 5 * (Co >> 4) + (has_ws ? 5 * (NF >> 4) : 0);
+        if (total > 4 * TP_WAVES) mfma_units(std::integral_constant<int, TP_MAXU>{}, rec);
+        else mfma_units(std::integral_constant<int, 4>{}, rec);
+    };
+
+    // ================= u0 = norm_init(u_init): gather over the (earlier) neighbours' codes =================
+    PostCtl pc = load_post_ctl(a.ctl1, 0);
+    StoreCtl sc = load_store_ctl(a.ctl1, 0);
+    load_unit_weights(1);   // stage 0
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const StepCtx &cx = sC[pcol[k]];
+        float mA[9];
+        int ncode[9], nl[9];
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) { mA[tp] = cx.m[0][tp]; nl[tp] = cx.nloc[tp]; }
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) ncode[tp] = a.codes_in[(size_t)pfr[k] * a.L + max(nl[tp], 0)];
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) ncode[tp] = nl[tp] >= 0 ? ncode[tp] : UINIT_CLOSED;
+        const f32x2 y = uinit_from_codes<f32x2>(ncode, mA, a.uinit_w, a.uinit_b, c2);
+        emit(k, y, zero2, zero2, PRO_UINIT, false, pc.in_form, pc.save_slot, sc);
+        stage_skip_input(k, sc.skip_slot);
+    }
+    lds_barrier();
+
+    // ================= the 32 conv stages =================
+    for (int s = 0; s < NST - 1; ++s) {
+        pc = load_post_ctl(a.ctl1, 1 + s);     // stage s and the post op that follows it
+        sc = load_store_ctl(a.ctl1, 1 + s);
+        const int tp_items = ctl_i(a.ctl1, 1 + s, CTL_TP_ITEMS);
+        // operands of this stage's post op: issued now, they land under the MFMA phase
+        Ops ops[2];
+        wait_counter(s, (unsigned)tp_items);
+        load_ops(s, pc, 0, ops[0]);
+        load_ops(s, pc, 1, ops[1]);
+        mfma_phase(1 + s);
+        load_unit_weights(2 + s);   // next stage's (record NST = nin_out: its own loop below, these are dropped); lands under the post op
+        lds_barrier();
+        const int Co = pc.Co;
+#pragma unroll
+        for (int kq = 0; kq < 2; ++kq) {
+            const int k = (a.debug & 4) ? 1 - kq : kq;
+            if ((a.debug & 8) && kq == 1) lds_barrier();
+            auto five = [](const float *p, int stride) {
+                return chain_total(*(const f32x2 *)p, *(const f32x2 *)(p + stride), *(const f32x2 *)(p + 2 * stride),
+                                   *(const f32x2 *)(p + 3 * stride), *(const f32x2 *)(p + 4 * stride));
+            };
+            const float *P = &sP[pcol[k] * SP_LD + c2];
+            const f32x2 y = slot_sum2(ops[k].b, ops[k].na, five(P, Co), ops[k].nb);
+            f32x2 g = zero2, skip = zero2;
+            if (pc.kind == PRO_GATE) g = slot_sum2(ops[k].bg, ops[k].nag, five(P + NF, Co), ops[k].nbg);
+            if (pc.has_skip) skip = five(P + 5 * Co, NF) + ops[k].b2;
+            emit(k, y, g, skip, pc.kind, pc.has_skip != 0, pc.in_form, pc.save_slot, sc);
+            stage_skip_input(k, sc.skip_slot);
+        }
+        lds_barrier();
+    }
+
+    // ================= nin_out(elu(u)) (model.py:153): 32 output tiles x 5 chains of 4 MFMAs, logits, draw =================
+    {
+        const int g_ = 0; (void)g_;
+        f32x4 bx[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) bx[j] = *(const f32x4 *)&sXb[(4 * j + kk) * XB_LD + i * 4];
+#pragma unroll
+        for (int q = 0; q < NCLS / 16 / TP_WAVES; ++q) {
+            const int ot = wave + TP_WAVES * q;
+            f32x4 av[5];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) av[j] = *PS_GC(f32x4, a.out_w + ((size_t)(4 * j + kk) * NCLS + ot * 16 + i) * 4);
+            Acc5 acc = acc5_zero();
+            mfma_chunk5(av, bx, acc);
+            *(f32x4 *)&sP[i * SLOG_LD + ot * 16 + kk * 4] = chunk_total(acc);
+        }
+    }
+    lds_barrier();
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        if (!pvalid[k]) continue;
+        float lg[8];
+        const float *Lp = &sP[pcol[k] * SLOG_LD + lane * 8];
+        const f32x4 lo = *(const f32x4 *)Lp, hi = *(const f32x4 *)(Lp + 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { lg[q] = lo[q] + a.out_b[lane * 8 + q]; lg[4 + q] = hi[q] + a.out_b[lane * 8 + 4 + q]; }
+        const size_t loc = ploc[k];
+        if (a.out_logits) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) a.out_logits[loc * NCLS + lane * 8 + q] = lg[q];
+        }
+        if (a.step_logits) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) a.step_logits[(size_t)pfr[k] * NCLS + lane * 8 + q] = lg[q];
+        }
+        if (a.codes && a.region[loc]) {
+            const int code = a.forced ? a.forced[loc] : draw_code(lg, a.temperature, a.uniforms[loc], lane);
+            if (lane == 0) a.codes[loc] = code;
+        }
+    }
+}
+
+// blocks [0, nbr_wgs): neighbour role (they never wait for anything); blocks after them: one chain tile each
+__global__ __launch_bounds__(TP_THREADS) void k_column_tp(TpArgs a)
+{
+    const int b = blockIdx.x;
+    if (b < a.nbr_wgs) { if ((a.debug & 3) != 3) nbr_role_tp(a, b); }
+    else if ((a.debug & 3) != 2) chain_role_tp(a, b - a.nbr_wgs);
 }
 
 // repack the centre tap (+ nin_skip) of a stage for the chain role: out[step][chain][4]
@@ -1466,6 +1909,15 @@ struct ps_pixelcnn {
     unsigned tile_uses[MAX_TILES] = {};  // column launches so far that had tile t (target of the counters)
     NbrWork *work = nullptr;
     int nwork = 0;
+    // throughput form (k_column_tp): launches of more than tp_min_cols columns
+    NbrWorkTp *work_tp = nullptr;
+    int nwork_tp = 0;
+    float *nbr_tp = nullptr;        // neighbour slots [NST][2][TP_COL_CAP][160]
+    unsigned *cnt_tp = nullptr;     // [NST][TP_MAX_TILES] padded completion counters, never reset
+    unsigned tile_uses_tp[TP_MAX_TILES] = {};
+    ColTaps *taps = nullptr;        // neighbour rows of the columns of a run, [maxF * L]
+    int n_cus = 256;                // compute units of the device: workgroups of a column launch that are resident together
+    int tp_min_cols = COL_CAP + 1;  // PS_TP_MIN_COLS: tuning
     int col_cap = COL_CAP;          // columns per launch (PS_COL_CAP: tuning)
     int chain_xcds = 0;             // PS_CHAIN_XCDS: tuning (0 = automatic)
     int force_groups = 0;           // PS_NBR_GROUPS: tuning (0 = automatic)
@@ -1592,6 +2044,7 @@ int build_stage_table(ps_pixelcnn *h)
 {
     std::vector<StageDesc> st;
     std::vector<NbrWork> work;
+    std::vector<NbrWorkTp> work_tp;
     struct Prev { int pro; const float *bias, *bias2; int has_skip; float *R, *E, *X; int save; } prev;
     prev = Prev{PRO_UINIT, nullptr, nullptr, 0, h->R[0], h->E[0], nullptr, 0};  // u0 is saved in LDS slot 0
     auto push = [&](const float *w, const float *w_skip, const float *in, int in_ld, int NG, int Co, int dil,
@@ -1606,6 +2059,9 @@ int build_stage_table(ps_pixelcnn *h)
         if (has_nbr)
             for (int half = 0; half < 2; ++half)
                 for (int cog = 0; cog < Co / 16; ++cog) work.push_back(NbrWork{w, in, s, half, cog, NG, Co, in_ld, dil, mask_kind});
+        if (has_nbr)   // throughput form: two output tiles per item where the stage has them
+            for (int half = 0; half < 2; ++half)
+                for (int o0 = 0; o0 < Co; o0 += 32) work_tp.push_back(NbrWorkTp{w, in, s, half, o0, o0 + 32 <= Co ? 2 : 1, NG, Co, in_ld, mask_kind - 1});
         // dense algorithmic work per frame of this stage (taps x 2*Co*Cin flops, fp32 weights once)
         const double taps_nbr = has_nbr ? 8.0 : 0.0, cin = NG * 16.0;
         h->flops_nbr += taps_nbr * 2.0 * Co * cin;
@@ -1667,7 +2123,11 @@ int build_stage_table(ps_pixelcnn *h)
             int *c = &ctl[(size_t)(1 + k) * C1_CTL_DWORDS];
             c[CTL_CO] = st[k].Co_pad; c[CTL_NCHAIN] = st[k].nchain; c[CTL_NG] = st[k].NG; c[CTL_NSTEP] = st[k].nstep;
             c[CTL_NBR_ITEMS] = st[k].has_nbr ? 2 * (st[k].Co_pad / 16) : 0;
+            c[CTL_TP_ITEMS] = st[k].has_nbr ? 2 * ((st[k].Co_pad + 31) / 32) : 0;
             put_p(1 + k, CTL_WV, st[k].wv);
+            // the centre tap (and nin_skip) in the MFMA layout [c/4][o][4]; nin_out's weights are that layout already
+            put_p(1 + k, CTL_WC, k == NST - 1 ? st[k].w : st[k].w + (size_t)st[k].center_tap * st[k].NG * 16 * st[k].Co_pad);
+            put_p(1 + k, CTL_WS, st[k].w_skip);
             if (k + 1 < NST) put_post(1 + k, st[k + 1]);
         }
         if (int rc = dev_alloc(h, &h->ctl1, ctl.size())) return rc;
@@ -1677,6 +2137,9 @@ int build_stage_table(ps_pixelcnn *h)
     PS_HIP_CHECK(hipMemcpy(h->work, work.data(), work.size() * sizeof(NbrWork), hipMemcpyHostToDevice));
     h->nwork = (int)work.size();
     PS_REQUIRE(h->nwork <= NWORK_MAX, "pixelcnn: %d neighbour work entries exceed the staging table", h->nwork);
+    if (int rc = dev_alloc(h, &h->work_tp, work_tp.size())) return rc;
+    PS_HIP_CHECK(hipMemcpy(h->work_tp, work_tp.data(), work_tp.size() * sizeof(NbrWorkTp), hipMemcpyHostToDevice));
+    h->nwork_tp = (int)work_tp.size();
     return PS_OK;
 }
 
@@ -1690,6 +2153,27 @@ void run_columns(ps_pixelcnn *h, const StepCtx *rec, int ncols, const int32_t *c
     ca.H = h->H; ca.W = h->W; ca.L = h->L; ca.col_stride = COL_CAP;
     ca.cnt = h->cnt; ca.err = h->err;
     if (const char *dbg = getenv("PS_COLUMN_DEBUG")) ca.debug = atoi(dbg);
+    if (ncols >= h->tp_min_cols) {   // throughput form: 16-column chain tiles, up to TP_COL_CAP columns per launch
+        TpArgs ta{};
+        ta.work = h->work_tp; ta.nbr = h->nbr_tp; ta.cnt = h->cnt_tp; ta.nwork = h->nwork_tp;
+        ta.ctl1 = h->ctl1; ta.uinit_w = h->uinit_w; ta.uinit_b = h->uinit_b; ta.codes_in = codes;
+        ta.out_w = h->out_w; ta.out_b = h->out_b; ta.L = h->L;
+        ta.codes = ca.codes; ta.region = ca.region; ta.forced = ca.forced; ta.uniforms = ca.uniforms;
+        ta.out_logits = ca.out_logits; ta.step_logits = ca.step_logits; ta.temperature = ca.temperature;
+        ta.err = h->err; ta.debug = ca.debug;
+        const int cap = std::min(TP_COL_CAP, std::max(TP_COLS, (h->n_cus / 2) * TP_COLS));   // at least half of the CUs to the neighbour role
+        const ColTaps *taps = h->taps + (rec - h->ctx);
+        for (int done = 0; done < ncols; done += cap) {
+            const int n = std::min(cap, ncols - done);
+            const int tiles = (n + TP_COLS - 1) / TP_COLS;
+            ta.taps = taps + done; ta.ctx = rec + done; ta.ncols = n; ta.tiles = tiles;
+            ta.nbr_wgs = std::max(1, std::min(h->n_cus - tiles, (h->nwork_tp * tiles + TP_WAVES - 1) / TP_WAVES));
+            for (int t = 0; t < tiles; ++t) h->tile_uses_tp[t] += 1;
+            for (int t = 0; t < TP_MAX_TILES; ++t) ta.tile_uses[t] = h->tile_uses_tp[t];
+            timed(h, st, TAG_CHAIN, [&]() { hipLaunchKernelGGL(k_column_tp, dim3(ta.nbr_wgs + tiles), dim3(TP_THREADS), 0, st, ta); });
+        }
+        return;
+    }
     for (int done = 0; done < ncols; done += h->col_cap) {
         const int n = std::min(h->col_cap, ncols - done);
         const int tiles = (n + 15) / 16, nitems = h->nwork * tiles;
@@ -1713,7 +2197,7 @@ void run_columns(ps_pixelcnn *h, const StepCtx *rec, int ncols, const int32_t *c
 CtxArgs make_ctx_args(ps_pixelcnn *h, const int32_t *order, const Masks &m, int F)
 {
     CtxArgs cx{};
-    cx.ctx = h->ctx; cx.order = order;
+    cx.ctx = h->ctx; cx.taps = h->taps; cx.order = order;
     cx.mask[0] = m.init; cx.mask[1] = m.und; cx.mask[2] = m.dil;
     cx.F = F; cx.L = h->L;
     return cx;
@@ -1742,6 +2226,12 @@ int ps_pixelcnn_create(const float *const *params, int n_params, int H, int W, i
     if (const char *cc = getenv("PS_COL_CAP")) h->col_cap = std::max(1, std::min(COL_CAP, atoi(cc)));
     if (const char *cc = getenv("PS_CHAIN_XCDS")) h->chain_xcds = std::max(0, std::min(8, atoi(cc)));
     if (const char *cc = getenv("PS_NBR_GROUPS")) h->force_groups = std::max(0, std::min(NBR_MAX_GROUPS, atoi(cc)));
+    if (const char *cc = getenv("PS_TP_MIN_COLS")) h->tp_min_cols = std::max(1, atoi(cc));
+    {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+            h->n_cus = cus;
+    }
     int rc = PS_OK;
     auto fail_out = [&](int code) { ps_pixelcnn_destroy(h); return code; };
 
@@ -1806,6 +2296,13 @@ int ps_pixelcnn_create(const float *const *params, int n_params, int H, int W, i
     if ((rc = dev_alloc(h, &h->col_logits, (size_t)max_frames * NCLS))) return fail_out(rc);
     if ((rc = dev_alloc(h, &h->nbr, (size_t)NST * 2 * COL_CAP * NBR_LD))) return fail_out(rc);
     if ((rc = dev_alloc(h, &h->ctx, locs))) return fail_out(rc);
+    if ((rc = dev_alloc(h, &h->taps, locs))) return fail_out(rc);
+    if ((rc = dev_alloc(h, &h->nbr_tp, (size_t)NST * 2 * TP_COL_CAP * NBR_LD))) return fail_out(rc);
+    if ((rc = dev_alloc(h, &h->cnt_tp, tp_cnt_index(NST, 0)))) return fail_out(rc);
+    if (hipMemset(h->cnt_tp, 0, tp_cnt_index(NST, 0) * sizeof(unsigned)) != hipSuccess) {
+        ps::fail(PS_ERR_HIP, "pixelcnn_create: hipMemset failed");
+        return fail_out(PS_ERR_HIP);
+    }
     if ((rc = dev_alloc(h, &h->cnt, cnt_index(NST, 0)))) return fail_out(rc);
     if ((rc = dev_alloc(h, &h->err, 1))) return fail_out(rc);
     if (hipMemset(h->cnt, 0, cnt_index(NST, 0) * sizeof(unsigned)) != hipSuccess || hipMemset(h->err, 0, sizeof(int)) != hipSuccess) {
@@ -1946,6 +2443,18 @@ int ps_pixelcnn_time_ar_run_waves(ps_pixelcnn *h, int32_t *codes, const int32_t 
     }
     if (flops_per_column) *flops_per_column = h->flops_nbr + h->flops_chain;
     return rc;
+}
+
+// tuning / debugging aid (tools/tp_debug.py): device address of an activation cache -- what 0: R[idx] (raw u of node idx,
+// row stride 96), 1: E[idx] (concat_elu(u), 160), 2: X[idx] (inside gated resnet idx, 160); rows are (frame * L + location)
+void *ps_pixelcnn_debug_cache(ps_pixelcnn *h, int what, int idx)
+{
+    if (!h) return nullptr;
+    if (what == 0 && idx >= 0 && idx < NNODE) return h->R[idx];
+    if (what == 1 && idx >= 0 && idx < NNODE) return h->E[idx];
+    if (what == 2 && idx >= 0 && idx < NGATED) return h->X[idx];
+    if (what == 3) return h->nbr_tp;   // neighbour slots of the last throughput launch [NST][2][1024][160]
+    return nullptr;
 }
 
 int ps_pixelcnn_status(ps_pixelcnn *h, void *stream)

@@ -291,16 +291,27 @@ class OurPixelCNN(nn.Module):
 
 import os
 
-COLUMNS_PER_LAUNCH = int(os.environ.get("PS_WAVE_COLS", "128"))   # what one k_column launch takes (csrc/lmconv.hip: COL_CAP = 128 at most)
+# Columns one launch takes (csrc/lmconv.hip): k_column, the latency form -- one CU per column -- takes COL_CAP = 128; waves with
+# more columns run as k_column_tp, the throughput form -- 16-column MFMA chain tiles -- which takes TP_COL_CAP = 1024.  Few
+# frames never fill more than the latency form holds, so their schedule is capped at its capacity.
+COLUMNS_PER_LAUNCH = int(os.environ.get("PS_WAVE_COLS", "128"))
+COLUMNS_PER_LAUNCH_TP = int(os.environ.get("PS_WAVE_COLS_TP", "1024"))
+TP_MIN_FRAMES = int(os.environ.get("PS_TP_MIN_FRAMES", "24"))
 
 
-def wavefronts(order_host, H, W, first_step, device=None, max_cols=COLUMNS_PER_LAUNCH):
+def launch_capacity(frames):
+    return COLUMNS_PER_LAUNCH_TP if frames >= TP_MIN_FRAMES else COLUMNS_PER_LAUNCH
+
+
+def wavefronts(order_host, H, W, first_step, device=None, max_cols=None):
     """Wavefront schedule of an AR run (ps_ar_wavefronts_capped): order_host (F,L) int32 numpy array ->
     (cols int32 (n,2) tensor on `device`, wave_start int32 numpy array of n_waves + 1 entries).
-    max_cols: columns per wave (0 = the pure dependency levels)."""
+    max_cols: columns per wave (0 = the pure dependency levels; None = what a launch takes for this many frames)."""
     import ctypes
     order_host = np.ascontiguousarray(order_host, np.int32)
     F_, L = order_host.shape
+    if max_cols is None:
+        max_cols = launch_capacity(F_)
     nsteps = L - first_step
     n = F_ * nsteps
     cols = np.empty((max(n, 1), 2), np.int32)
