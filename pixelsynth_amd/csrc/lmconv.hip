@@ -884,7 +884,8 @@ constexpr int C1_CTL_DWORDS = 32;
 enum { CTL_CO = 0, CTL_NCHAIN = 1, CTL_NG = 2, CTL_NSTEP = 3, CTL_WV = 4, CTL_BIAS = 6, CTL_KIND = 8, CTL_HAS_SKIP = 9,
        CTL_IN_FORM = 10, CTL_SAVE_SLOT = 11, CTL_SKIP_SLOT = 12, CTL_NBR_ITEMS = 13 /* of the stage, per tile */, CTL_BIAS2 = 14, CTL_R = 16, CTL_E = 18, CTL_X = 20,
        // throughput mode (k_column_tp): the centre tap / nin_skip in the MFMA layout [c/4][o][4], work items of the stage per tile
-       CTL_WC = 22, CTL_WS = 24, CTL_TP_ITEMS = 26 };
+       CTL_WC = 22, CTL_WS = 24, CTL_TP_ITEMS = 26,
+       CTL_TP_TYPE = 27, CTL_WTP = 28 /* the stage's weights in the chain role's own order [wave][unit][half][lane][4] */ };
 typedef const __attribute__((address_space(4))) int *CtlInt;
 typedef const __attribute__((address_space(4))) unsigned long long *CtlU64;
 __device__ __forceinline__ int ctl_i(const int *ctl, int rec, int field) { return ((CtlInt)ctl)[rec * C1_CTL_DWORDS + field]; }
@@ -1393,13 +1394,25 @@ struct __attribute__((aligned(16))) NbrWorkTp {
 };
 static_assert(sizeof(NbrWorkTp) == 48, "three 16-byte loads");
 
+// Stage types of the chain role (what fixes a stage's unit list): conv_input, conv_input + nin_skip, conv_out, dilated conv
+enum { TPT_CONVIN = 0, TPT_CONVIN_SKIP = 1, TPT_CONVOUT = 2, TPT_DIL = 3 };
+__device__ __host__ constexpr int tpt_units(int type) { return type == TPT_CONVIN || type == TPT_DIL ? 25 : 50; }   // (tile, chain) units
+__device__ __host__ constexpr int tpt_nu(int type) { return type == TPT_CONVIN || type == TPT_DIL ? 4 : TP_MAXU; } // per wave, at most
+__device__ __host__ constexpr int tpt_nh(int type) { return type == TPT_DIL ? 1 : 2; }                              // 16-byte weight loads per unit
+// Unit u of wave w in a stage of a given type, everything that does not depend on the lane: where its B operands sit in the
+// B-operand buffers (floats from sXb; nin_skip's units read sSb = sXb + XB_SIZE), where its chain values go in a column's
+// row of sP.  Built on the host (build_stage_table), staged in LDS.
+struct __attribute__((aligned(16))) TpUnit { int b0, b1, dst, pad; };
+
 struct TpArgs {
+    const TpUnit *units;      // [4 types][TP_WAVES][TP_MAXU]
     // neighbour role
     const NbrWorkTp *work;
     const ColTaps *taps;      // records of this launch's columns
     float *nbr;               // [NST][2][TP_COL_CAP][NBR_LD]
     unsigned *cnt;            // [NST][TP_MAX_TILES] padded completion counters (tp_cnt_index), never reset
     int nwork, tiles, nbr_wgs;
+    int chain_xcds, fill_nbr;   // placement (k_column_tp): XCDs that hold the chain tiles; first neighbour index of their spare CUs or -1
     // chain role (fields as in ChainArgs)
     const int *ctl1;
     const float *uinit_w, *uinit_b;
@@ -1416,6 +1429,7 @@ struct TpArgs {
     unsigned tile_uses[TP_MAX_TILES];
     int *err;
     int debug;
+    unsigned long long *trace;   // tuning builds (-DPS_TP_TRACE_BUILD): [NST][8] shader-clock stamps of tile 0, wave 0
 };
 
 template <int T, int NG>
@@ -1495,11 +1509,14 @@ __device__ __forceinline__ void nbr_role_tp(const TpArgs &a, int nb)
 
 __device__ __forceinline__ void chain_role_tp(const TpArgs &a, int tile)
 {
-    __shared__ __attribute__((aligned(16))) float sXb[XB_SIZE];            // input of the centre taps, B-operand layout
-    __shared__ __attribute__((aligned(16))) float sSb[XB_SIZE];            // concat_elu(u_k) feeding nin_skip, same layout
+    __shared__ __attribute__((aligned(16))) float sXS[2 * XB_SIZE];        // B-operand layout: input of the centre taps, and behind
+    float *const sXb = sXS, *const sSb = sXS + XB_SIZE;                    //   it concat_elu(u_k) feeding nin_skip
+    __shared__ __attribute__((aligned(16))) TpUnit sUnit[4 * TP_WAVES * TP_MAXU];   // the unit tables of the four stage types
     __shared__ __attribute__((aligned(16))) float sP[TP_COLS * SP_LD];     // chain values of the stage [col][j][o]; logits at the end
     __shared__ __attribute__((aligned(16))) float sU[8][TP_COLS][NF];      // u0..u7 of the tile's columns
     __shared__ __attribute__((aligned(16))) StepCtx sC[TP_COLS];
+    __shared__ __attribute__((aligned(16))) int sCtl[(NST + 1) * C1_CTL_DWORDS];   // the control records (a scalar load from memory at
+                                                                                  // every stage start cost ~1000 cycles of its ~8000)
     const int t = threadIdx.x, wave = uni(t >> 6), lane = t & 63, i = lane & 15, kk = lane >> 4;
     const int col0 = tile * TP_COLS;
     const int ncl = min(TP_COLS, a.ncols - col0);   // columns of this tile (>= 1)
@@ -1510,223 +1527,267 @@ __device__ __forceinline__ void chain_role_tp(const TpArgs &a, int tile)
             ((uint4 *)sC)[k] = ((const uint4 *)(a.ctx + col0 + c))[k % nq];
         }
         for (int k = t; k < XB_SIZE; k += TP_THREADS) { sXb[k] = 0.0f; sSb[k] = 0.0f; }
+        for (int k = t; k < (NST + 1) * C1_CTL_DWORDS / 4; k += TP_THREADS) ((uint4 *)sCtl)[k] = ((const uint4 *)a.ctl1)[k];
+        for (int k = t; k < 4 * TP_WAVES * TP_MAXU; k += TP_THREADS) ((uint4 *)sUnit)[k] = ((const uint4 *)a.units)[k];
     }
     __syncthreads();
+    auto li = [&](int rec, int field) { return uni(sCtl[rec * C1_CTL_DWORDS + field]); };
+    auto lpf = [&](int rec, int field) {
+        const unsigned lo = (unsigned)li(rec, field), hi = (unsigned)li(rec, field + 1);
+        return (float *)(((unsigned long long)hi << 32) | lo);
+    };
+    auto post_ctl = [&](int rec) {
+        return PostCtl{li(rec, CTL_CO), li(rec, CTL_KIND), li(rec, CTL_HAS_SKIP), li(rec, CTL_IN_FORM), li(rec, CTL_SAVE_SLOT),
+                       li(rec, CTL_NBR_ITEMS), lpf(rec, CTL_BIAS), lpf(rec, CTL_BIAS2)};
+    };
+    auto store_ctl = [&](int rec) { return StoreCtl{li(rec, CTL_KIND), li(rec, CTL_SKIP_SLOT), lpf(rec, CTL_R), lpf(rec, CTL_E), lpf(rec, CTL_X)}; };
     // ---- post-op side: wave w owns columns w and w + 8, two channels per lane (see pono_total)
     const bool own = lane < PONO_LANES;
     const int c2 = own ? 2 * lane : 0;
     const f32x2 zero2 = {0.0f, 0.0f};
     bool pvalid[2];
-    int pcol[2], pq[2], pfr[2];
+    int pcol[2], pfr[2];
     size_t ploc[2];
     f32x2 ucur[2] = {zero2, zero2};
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         pcol[k] = wave + 8 * k;
         pvalid[k] = pcol[k] < ncl;
-        pq[k] = uni(sC[pcol[k]].q);
         pfr[k] = uni(sC[pcol[k]].f);
-        ploc[k] = (size_t)pfr[k] * a.L + pq[k];
+        ploc[k] = (size_t)pfr[k] * a.L + uni(sC[pcol[k]].q);
     }
     const size_t nbr_half = (size_t)TP_COL_CAP * NBR_LD, nbr_stage = 2 * nbr_half;
     const unsigned my_uses = a.tile_uses[tile];
     auto counter = [&](int k) { return __hip_atomic_load(a.cnt + tp_cnt_index(k, tile), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-    auto wait_counter = [&](int k, unsigned items_per_tile) {
+    // `have`: the counter as requested a stage earlier (normally past the target already); bounded
+    auto wait_counter = [&](unsigned have, int k, unsigned items_per_tile) {
         if (a.debug & 1) return;
         const unsigned need = my_uses * items_per_tile;
         int spins = 0;
-        while ((int)(counter(k) - need) < 0) {
+        while ((int)(have - need) < 0) {
             if (++spins > 40000) { if (lane == 0) *a.err = 1; break; }
             __builtin_amdgcn_s_sleep(2);
+            have = counter(k);
         }
+        asm volatile("" ::: "memory");
     };
-    struct Ops { f32x2 b, na, nb, bg, nag, nbg, b2; };
     auto fresh = [](const float *p) {
         const unsigned long long raw = __hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return f32x2{__uint_as_float((unsigned)raw), __uint_as_float((unsigned)(raw >> 32))};
     };
     auto plain = [](const float *p) { return *PS_GC(f32x2, p); };
-    // bias and neighbour slots of the post op after stage s (always seven loads from valid addresses, see k_column)
-    auto load_ops = [&](int s, const PostCtl &c, int k, Ops &o) {
-        const float *nb = a.nbr + (size_t)s * nbr_stage + (size_t)(col0 + (pvalid[k] ? pcol[k] : 0)) * NBR_LD + c2;
-        const int gofs = c.kind == PRO_GATE ? NF : 0;
-        const float *b2 = c.has_skip ? c.bias2 : c.bias;
-        o.b = plain(c.bias + c2);
-        o.na = fresh(nb);
-        o.nb = fresh(nb + nbr_half);
-        o.bg = plain(c.bias + gofs + c2);
-        o.nag = fresh(nb + gofs);
-        o.nbg = fresh(nb + nbr_half + gofs);
-        o.b2 = plain(b2 + c2);
-    };
-    // PONO + finish + hand-off: next stage's input into the B-operand layout, values to the caches
-    auto emit = [&](int k, const f32x2 &y, const f32x2 &g, const f32x2 &skip, int kind, bool has_skip, int in_form, int save_slot,
-                    const StoreCtl &sc) {
-        const float mean = pono_mean(pono_total(y, own));
-        const f32x2 d = y - mean;
-        const float inv = pono_inv(pono_total(d * d, own));
-        if (!pvalid[k] || !own) return;
-        const f32x2 n = d * inv;
-        f32x2 out;
-        if (kind == PRO_CONVIN) out = post_finish<POST_CONVIN>(n, zero2, skip, has_skip, zero2);
-        else if (kind == PRO_GATE) out = post_finish<POST_GATE>(n, g, zero2, false, ucur[k]);
-        else out = n;  // PRO_DIL, PRO_UINIT (norm_init)
-        f32x2 ep, en;
-        celu_pair2(out, ep, en);
-        const int col = pcol[k];
-        if (in_form == IN_CELU) { *(f32x2 *)&sXb[xb_index(c2, col)] = ep; *(f32x2 *)&sXb[xb_index(NF + c2, col)] = en; }
-        else if (in_form == IN_RAW) *(f32x2 *)&sXb[xb_index(c2, col)] = out;
-        else *(f32x2 *)&sXb[xb_index(c2, col)] = ep;
-        if (kind == PRO_CONVIN) {
-            *PS_G(f32x2, sc.X + ploc[k] * (2 * NF) + c2) = ep;
-            *PS_G(f32x2, sc.X + ploc[k] * (2 * NF) + NF + c2) = en;
-        } else {
-            *PS_G(f32x2, sc.R + ploc[k] * R_LD + c2) = out;
-            *PS_G(f32x2, sc.E + ploc[k] * (2 * NF) + c2) = ep;
-            *PS_G(f32x2, sc.E + ploc[k] * (2 * NF) + NF + c2) = en;
-            ucur[k] = out;
-            if (save_slot >= 0) *(f32x2 *)(&sU[save_slot][col][c2]) = out;
+    // PONO + finish of BOTH columns of this wave (independent instruction streams, interleaved by the compiler) and the
+    // hand-off: next stage's input into the B-operand layout, values to the caches.  KIND / HAS_SKIP are compile-time.
+    auto emit2 = [&](const f32x2 (&y)[2], const f32x2 (&g)[2], const f32x2 (&skip)[2], auto KINDc, auto SKIPc, int in_form, int save_slot,
+                     const StoreCtl &sc) {
+        constexpr int kind = decltype(KINDc)::value;
+        constexpr bool has_skip = decltype(SKIPc)::value;
+        float mean[2], inv[2];
+        f32x2 d[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) mean[k] = pono_mean(pono_total(y[k], own));
+#pragma unroll
+        for (int k = 0; k < 2; ++k) d[k] = y[k] - mean[k];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) inv[k] = pono_inv(pono_total(d[k] * d[k], own));
+        if (!own) return;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const f32x2 n = d[k] * inv[k];
+            f32x2 out;
+            if (kind == PRO_CONVIN) out = post_finish<POST_CONVIN>(n, zero2, skip[k], has_skip, zero2);
+            else if (kind == PRO_GATE) out = post_finish<POST_GATE>(n, g[k], zero2, false, ucur[k]);
+            else out = n;  // PRO_DIL, PRO_UINIT (norm_init)
+            f32x2 ep, en;
+            celu_pair2(out, ep, en);
+            const int col = pcol[k];
+            if (!pvalid[k]) continue;
+            if (in_form == IN_CELU) { *(f32x2 *)&sXb[xb_index(c2, col)] = ep; *(f32x2 *)&sXb[xb_index(NF + c2, col)] = en; }
+            else if (in_form == IN_RAW) *(f32x2 *)&sXb[xb_index(c2, col)] = out;
+            else *(f32x2 *)&sXb[xb_index(c2, col)] = ep;
+            if (kind == PRO_CONVIN) {
+                *PS_G(f32x2, sc.X + ploc[k] * (2 * NF) + c2) = ep;
+                *PS_G(f32x2, sc.X + ploc[k] * (2 * NF) + NF + c2) = en;
+            } else {
+                *PS_G(f32x2, sc.R + ploc[k] * R_LD + c2) = out;
+                *PS_G(f32x2, sc.E + ploc[k] * (2 * NF) + c2) = ep;
+                *PS_G(f32x2, sc.E + ploc[k] * (2 * NF) + NF + c2) = en;
+                ucur[k] = out;
+                if (save_slot >= 0) *(f32x2 *)(&sU[save_slot][col][c2]) = out;
+            }
         }
     };
     // concat_elu(u_k) of the saved u the NEXT stage's nin_skip reads
-    auto stage_skip_input = [&](int k, int skip_slot) {
+    auto stage_skip_input = [&](int skip_slot) {
         if (skip_slot < 0 || !own) return;
-        const int col = pcol[k];
-        f32x2 ep, en;
-        celu_pair2(*(const f32x2 *)(&sU[skip_slot][col][c2]), ep, en);
-        *(f32x2 *)&sSb[xb_index(c2, col)] = ep;
-        *(f32x2 *)&sSb[xb_index(NF + c2, col)] = en;
-    };
-
-    // ---- MFMA side: unit n of a stage = (16 output channels ot, chain j), n = w, w + 8, ...; main units first, then nin_skip's
-    struct UnitW { f32x4 a0, a1; };
-    UnitW W[TP_MAXU];
-    auto unit_of = [&](int n, int Co, int &ot, int &j, bool &skip) {
-        const int um = 5 * (Co >> 4);
-        skip = n >= um;
-        const int m = skip ? n - um : n;
-        ot = m / 5;
-        j = m - ot * 5;
-    };
-    // weights of this wave's units of the stage described by record `rec` (NG groups: one or two 16-byte loads per unit)
-    auto load_unit_weights = [&](int rec) {
-        const int Co = ctl_i(a.ctl1, rec, CTL_CO), NG = ctl_i(a.ctl1, rec, CTL_NG);
-        const float *wc = ctl_p<const float>(a.ctl1, rec, CTL_WC), *ws = ctl_p<const float>(a.ctl1, rec, CTL_WS);
-        const int total = 5 * (Co >> 4) + (ws ? 5 * (NF >> 4) : 0);
 #pragma unroll
-        for (int u = 0; u < TP_MAXU; ++u) {
-            const int n = min(wave + TP_WAVES * u, total - 1);   // (waves without a u-th unit re-read a valid one: static load counts)
-            int ot, j; bool skip;
-            unit_of(n, Co, ot, j, skip);
-            const float *w = skip ? ws : wc;
-            const int cw = skip ? NF : Co;
-            const float *p0 = w + ((size_t)(4 * j + kk) * cw + ot * 16 + i) * 4;
-            const float *p1 = NG == 10 ? w + ((size_t)(4 * (j + 5) + kk) * cw + ot * 16 + i) * 4 : p0;
-            W[u].a0 = *PS_GC(f32x4, p0);
-            W[u].a1 = *PS_GC(f32x4, p1);
+        for (int k = 0; k < 2; ++k) {
+            const int col = pcol[k];
+            f32x2 ep, en;
+            celu_pair2(*(const f32x2 *)(&sU[skip_slot][col][c2]), ep, en);
+            *(f32x2 *)&sSb[xb_index(c2, col)] = ep;
+            *(f32x2 *)&sSb[xb_index(NF + c2, col)] = en;
         }
     };
-    // NU = units a wave has at most in this stage (7 of 50, 4 of 25): units 0 .. NU-2 exist for every wave, the last one for the
-    // first waves only -- one wave-uniform branch, everything else straight-line
-    auto mfma_units = [&](auto NUc, int rec) {
-        constexpr int NU = decltype(NUc)::value;
-        const int Co = ctl_i(a.ctl1, rec, CTL_CO), NG = ctl_i(a.ctl1, rec, CTL_NG);
-        const bool has_ws = ctl_p<const float>(a.ctl1, rec, CTL_WS) != nullptr;
-        const int um = 5 * (Co >> 4), total = um + (has_ws ? 5 * (NF >> 4) : 0);
-        const bool last = wave + TP_WAVES * (NU - 1) < total;
+
+    // ---- MFMA side.  Unit n of a stage = (16 output channels ot, accumulation chain j), n = w, w + 8, ... for wave w; main units
+    // first, then nin_skip's.  Nothing about a unit is computed here: its B-operand and chain-value offsets come from the unit
+    // table of the stage's type, its weights from the stage's copy in this role's own order [wave][unit][half][lane][4] -- one
+    // base register, the rest immediates.
+    struct UnitW { f32x4 a0, a1; };
+    const int lane_b = kk * XB_LD + i * 4, lane_d = i * SP_LD + kk * 4;
+    // weights of this wave's units of the stage of record `rec` (type ty): NU x 2 16-byte loads from consecutive KBs
+    auto weights_base = [&](int rec, int ty) {
+        return lpf(rec, CTL_WTP) + ((size_t)wave * tpt_nu(ty) * 2 * 64 + lane) * 4;
+    };
+    // MFMA phase of a stage of type TY on the weights in Wc; the weights of the NEXT stage (type nty, base nbase) are requested
+    // into Wn between the MFMAs of the first half -- they have the rest of the stage to arrive, and no wave waits at an issue
+    // queue with nothing to do.  Units 0 .. NU-2 exist for every wave, unit NU-1 for the first waves only (`last`).
+    auto mfma_units = [&](auto TYc, const UnitW (&Wc)[TP_MAXU], int nty, const float *nbase, UnitW (&Wn)[TP_MAXU]) {
+        constexpr int TY = decltype(TYc)::value, NU = tpt_nu(TY), NH = tpt_nh(TY);
+        const bool last = wave + TP_WAVES * (NU - 1) < tpt_units(TY);
+        const TpUnit *ut = sUnit + (TY * TP_WAVES + wave) * TP_MAXU;
         f32x4 b0[NU], b1[NU], acc[NU];
         int dst[NU];
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
-            const int n = min(wave + TP_WAVES * u, total - 1);
-            int ot, j; bool skip;
-            unit_of(n, Co, ot, j, skip);
-            const float *src = skip ? sSb : sXb;
-            b0[u] = *(const f32x4 *)&src[(4 * j + kk) * XB_LD + i * 4];
-            b1[u] = *(const f32x4 *)&src[(4 * (NG == 10 ? j + 5 : j) + kk) * XB_LD + i * 4];
-            dst[u] = i * SP_LD + (skip ? 5 * Co + j * NF : j * Co) + ot * 16 + kk * 4;
+            const TpUnit e = ut[u];
+            b0[u] = *(const f32x4 *)&sXS[e.b0 + lane_b];
+            if (NH == 2) b1[u] = *(const f32x4 *)&sXS[e.b1 + lane_b];
+            dst[u] = e.dst + lane_d;
             acc[u] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         }
+        const int nn = 2 * tpt_nu(nty);   // 16-byte loads of the next stage per wave: 8 or 14 (every unit has two KBs in the copy)
+        auto next_load = [&](int q) {     // q-th KB of the next stage's weights of this wave; q is a compile-time constant at every call
+            if (q >= nn) return;
+            const f32x4 v = *PS_GC(f32x4, nbase + (size_t)q * 256);
+            if (q & 1) Wn[q >> 1].a1 = v; else Wn[q >> 1].a0 = v;
+        };
         // canonical order of a chain: group j (c = 0..3), then group j + 5; the units are independent accumulators
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
 #pragma unroll
-            for (int u = 0; u < NU - 1; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(W[u].a0[c], b0[u][c], acc[u], 0, 0, 0);
-            if (last) acc[NU - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(W[NU - 1].a0[c], b0[NU - 1][c], acc[NU - 1], 0, 0, 0);
+            for (int u = 0; u < NU - 1; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wc[u].a0[c], b0[u][c], acc[u], 0, 0, 0);
+            if (last) acc[NU - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wc[NU - 1].a0[c], b0[NU - 1][c], acc[NU - 1], 0, 0, 0);
+#pragma unroll
+            for (int q = 4 * c; q < 4 * c + 4; ++q) if (q < 2 * TP_MAXU) next_load(q);
         }
-        if (NG == 10) {
+        if (NH == 2) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
 #pragma unroll
-                for (int u = 0; u < NU - 1; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(W[u].a1[c], b1[u][c], acc[u], 0, 0, 0);
-                if (last) acc[NU - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(W[NU - 1].a1[c], b1[NU - 1][c], acc[NU - 1], 0, 0, 0);
+                for (int u = 0; u < NU - 1; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wc[u].a1[c], b1[u][c], acc[u], 0, 0, 0);
+                if (last) acc[NU - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wc[NU - 1].a1[c], b1[NU - 1][c], acc[NU - 1], 0, 0, 0);
             }
         }
 #pragma unroll
         for (int u = 0; u < NU - 1; ++u) *(f32x4 *)&sP[dst[u]] = acc[u];
         if (last) *(f32x4 *)&sP[dst[NU - 1]] = acc[NU - 1];
     };
-    auto mfma_phase = [&](int rec) {
-        const int Co = ctl_i(a.ctl1, rec, CTL_CO);
-        const bool has_ws = ctl_p<const float>(a.ctl1, rec, CTL_WS) != nullptr;
-        const int total = 5 * (Co >> 4) + (has_ws ? 5 * (NF >> 4) : 0);
-        if (total > 4 * TP_WAVES) mfma_units(std::integral_constant<int, TP_MAXU>{}, rec);
-        else mfma_units(std::integral_constant<int, 4>{}, rec);
+
+#ifdef PS_TP_TRACE_BUILD
+#define TP_STAMP(slot) do { if (a.trace && tile == 0 && t == 0) a.trace[s * 8 + (slot)] = clock64(); } while (0)
+#else
+#define TP_STAMP(slot) do { } while (0)
+#endif
+    // One stage: operands of its post op requested, MFMA phase (next stage's weights requested underneath), barrier, post op of
+    // this wave's two columns, barrier.  The stage's type fixes Co, NG, the unit list and the post op that follows it
+    // (conv_input -> CONVIN with or without nin_skip, conv_out -> GATE, dilated conv -> DIL).
+    unsigned cnt_have = 0;
+    auto run_stage = [&](int s, auto TYc, const UnitW (&Wc)[TP_MAXU], UnitW (&Wn)[TP_MAXU]) {
+        constexpr int TY = decltype(TYc)::value;
+        constexpr int kind = TY == TPT_CONVOUT ? PRO_GATE : TY == TPT_DIL ? PRO_DIL : PRO_CONVIN;
+        constexpr bool has_skip = TY == TPT_CONVIN_SKIP;
+        constexpr int Co = kind == PRO_GATE ? 2 * NF : NF;
+        using std::integral_constant;
+        TP_STAMP(0);
+        const PostCtl pc = post_ctl(1 + s);     // stage s and the post op that follows it
+        const StoreCtl sc = store_ctl(1 + s);
+        const int nty = li(2 + s, CTL_TP_TYPE);
+        const float *nbase = weights_base(2 + s, nty);
+        wait_counter(cnt_have, s, (unsigned)li(1 + s, CTL_TP_ITEMS));
+        cnt_have = counter(min(s + 1, NST - 2));             // looked at a stage later
+        TP_STAMP(1);
+        // operands of this stage's post op: y = ((bias + NA) + centre) + NB (+ gate half, + nin_skip bias); they land under the MFMAs
+        f32x2 ob = plain(pc.bias + c2), obg = zero2, ob2 = zero2, ona[2], onb[2], onag[2], onbg[2];
+        if (kind == PRO_GATE) obg = plain(pc.bias + NF + c2);
+        if (has_skip) ob2 = plain(pc.bias2 + c2);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const float *nb = a.nbr + (size_t)s * nbr_stage + (size_t)(col0 + (pvalid[k] ? pcol[k] : 0)) * NBR_LD + c2;
+            ona[k] = fresh(nb);
+            onb[k] = fresh(nb + nbr_half);
+            if (kind == PRO_GATE) { onag[k] = fresh(nb + NF); onbg[k] = fresh(nb + nbr_half + NF); }
+        }
+        TP_STAMP(2);
+        mfma_units(TYc, Wc, nty, nbase, Wn);
+        TP_STAMP(3);
+        lds_barrier();
+        TP_STAMP(4);
+        auto five = [](const float *p, int stride) {
+            return chain_total(*(const f32x2 *)p, *(const f32x2 *)(p + stride), *(const f32x2 *)(p + 2 * stride),
+                               *(const f32x2 *)(p + 3 * stride), *(const f32x2 *)(p + 4 * stride));
+        };
+        f32x2 y[2], g[2] = {zero2, zero2}, skip[2] = {zero2, zero2};
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const float *P = &sP[pcol[k] * SP_LD + c2];
+            y[k] = slot_sum2(ob, ona[k], five(P, Co), onb[k]);
+            if (kind == PRO_GATE) g[k] = slot_sum2(obg, onag[k], five(P + NF, Co), onbg[k]);
+            if (has_skip) skip[k] = five(P + 5 * Co, NF) + ob2;
+        }
+        emit2(y, g, skip, integral_constant<int, kind>{}, integral_constant<bool, has_skip>{}, pc.in_form, pc.save_slot, sc);
+        stage_skip_input(sc.skip_slot);
+        TP_STAMP(5);
+        lds_barrier();
+        TP_STAMP(6);
+    };
+    auto dispatch_stage = [&](int s, const UnitW (&Wc)[TP_MAXU], UnitW (&Wn)[TP_MAXU]) {
+        using std::integral_constant;
+        const int ty = li(1 + s, CTL_TP_TYPE);
+        if (ty == TPT_CONVOUT) run_stage(s, integral_constant<int, TPT_CONVOUT>{}, Wc, Wn);
+        else if (ty == TPT_CONVIN_SKIP) run_stage(s, integral_constant<int, TPT_CONVIN_SKIP>{}, Wc, Wn);
+        else if (ty == TPT_CONVIN) run_stage(s, integral_constant<int, TPT_CONVIN>{}, Wc, Wn);
+        else run_stage(s, integral_constant<int, TPT_DIL>{}, Wc, Wn);
     };
 
     // ================= u0 = norm_init(u_init): gather over the (earlier) neighbours' codes =================
-    PostCtl pc = load_post_ctl(a.ctl1, 0);
-    StoreCtl sc = load_store_ctl(a.ctl1, 0);
-    load_unit_weights(1);   // stage 0
+    UnitW WA[TP_MAXU], WB[TP_MAXU];
+    {
+        const PostCtl pc = post_ctl(0);
+        const StoreCtl sc = store_ctl(0);
+        {   // stage 0's weights (conv_input without nin_skip: 4 units x 2 halves)
+            const float *b0p = weights_base(1, li(1, CTL_TP_TYPE));
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const StepCtx &cx = sC[pcol[k]];
-        float mA[9];
-        int ncode[9], nl[9];
+            for (int u = 0; u < 4; ++u) { WA[u].a0 = *PS_GC(f32x4, b0p + (size_t)(2 * u) * 256); WA[u].a1 = *PS_GC(f32x4, b0p + (size_t)(2 * u + 1) * 256); }
+        }
+        cnt_have = counter(0);
+        f32x2 y[2];
 #pragma unroll
-        for (int tp = 0; tp < 9; ++tp) { mA[tp] = cx.m[0][tp]; nl[tp] = cx.nloc[tp]; }
+        for (int k = 0; k < 2; ++k) {
+            const StepCtx &cx = sC[pcol[k]];
+            float mA[9];
+            int ncode[9], nl[9];
 #pragma unroll
-        for (int tp = 0; tp < 9; ++tp) ncode[tp] = a.codes_in[(size_t)pfr[k] * a.L + max(nl[tp], 0)];
+            for (int tp = 0; tp < 9; ++tp) { mA[tp] = cx.m[0][tp]; nl[tp] = cx.nloc[tp]; }
 #pragma unroll
-        for (int tp = 0; tp < 9; ++tp) ncode[tp] = nl[tp] >= 0 ? ncode[tp] : UINIT_CLOSED;
-        const f32x2 y = uinit_from_codes<f32x2>(ncode, mA, a.uinit_w, a.uinit_b, c2);
-        emit(k, y, zero2, zero2, PRO_UINIT, false, pc.in_form, pc.save_slot, sc);
-        stage_skip_input(k, sc.skip_slot);
+            for (int tp = 0; tp < 9; ++tp) ncode[tp] = a.codes_in[(size_t)pfr[k] * a.L + max(nl[tp], 0)];
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) ncode[tp] = nl[tp] >= 0 ? ncode[tp] : UINIT_CLOSED;
+            y[k] = uinit_from_codes<f32x2>(ncode, mA, a.uinit_w, a.uinit_b, c2);
+        }
+        const f32x2 z2[2] = {zero2, zero2};
+        emit2(y, z2, z2, std::integral_constant<int, PRO_UINIT>{}, std::integral_constant<bool, false>{}, pc.in_form, pc.save_slot, sc);
+        stage_skip_input(sc.skip_slot);
     }
     lds_barrier();
 
-    // ================= the 32 conv stages =================
-    for (int s = 0; s < NST - 1; ++s) {
-        pc = load_post_ctl(a.ctl1, 1 + s);     // stage s and the post op that follows it
-        sc = load_store_ctl(a.ctl1, 1 + s);
-        const int tp_items = ctl_i(a.ctl1, 1 + s, CTL_TP_ITEMS);
-        // operands of this stage's post op: issued now, they land under the MFMA phase
-        Ops ops[2];
-        wait_counter(s, (unsigned)tp_items);
-        load_ops(s, pc, 0, ops[0]);
-        load_ops(s, pc, 1, ops[1]);
-        mfma_phase(1 + s);
-        load_unit_weights(2 + s);   // next stage's (record NST = nin_out: its own loop below, these are dropped); lands under the post op
-        lds_barrier();
-        const int Co = pc.Co;
-#pragma unroll
-        for (int kq = 0; kq < 2; ++kq) {
-            const int k = (a.debug & 4) ? 1 - kq : kq;
-            if ((a.debug & 8) && kq == 1) lds_barrier();
-            auto five = [](const float *p, int stride) {
-                return chain_total(*(const f32x2 *)p, *(const f32x2 *)(p + stride), *(const f32x2 *)(p + 2 * stride),
-                                   *(const f32x2 *)(p + 3 * stride), *(const f32x2 *)(p + 4 * stride));
-            };
-            const float *P = &sP[pcol[k] * SP_LD + c2];
-            const f32x2 y = slot_sum2(ops[k].b, ops[k].na, five(P, Co), ops[k].nb);
-            f32x2 g = zero2, skip = zero2;
-            if (pc.kind == PRO_GATE) g = slot_sum2(ops[k].bg, ops[k].nag, five(P + NF, Co), ops[k].nbg);
-            if (pc.has_skip) skip = five(P + 5 * Co, NF) + ops[k].b2;
-            emit(k, y, g, skip, pc.kind, pc.has_skip != 0, pc.in_form, pc.save_slot, sc);
-            stage_skip_input(k, sc.skip_slot);
-        }
-        lds_barrier();
+    // ================= the 32 conv stages (weights double-buffered: WA / WB alternate) =================
+    for (int s = 0; s < NST - 1; s += 2) {
+        dispatch_stage(s, WA, WB);
+        dispatch_stage(s + 1, WB, WA);   // (the last call requests nin_out's record: a dilated-type dummy, dropped)
     }
+#undef TP_STAMP
 
     // ================= nin_out(elu(u)) (model.py:153): 32 output tiles x 5 chains of 4 MFMAs, logits, draw =================
     {
@@ -1770,12 +1831,56 @@ __device__ __forceinline__ void chain_role_tp(const TpArgs &a, int tile)
     }
 }
 
-// blocks [0, nbr_wgs): neighbour role (they never wait for anything); blocks after them: one chain tile each
+// chain_xcds = 0: blocks [0, nbr_wgs) neighbour role (they never wait for anything), the blocks after them one chain tile each.
+// chain_xcds = cx > 0 (speed only; block b runs on XCD b % 8): the chain tiles are the blocks on XCDs 0 .. cx-1, whose L2s then
+// hold the 2.8 MB of centre-tap weights instead of sharing their bandwidth with the neighbour role's operand stream; every
+// other block is a neighbour workgroup (the spare CUs of the chain XCDs too when fill is set).
 __global__ __launch_bounds__(TP_THREADS) void k_column_tp(TpArgs a)
 {
-    const int b = blockIdx.x;
-    if (b < a.nbr_wgs) { if ((a.debug & 3) != 3) nbr_role_tp(a, b); }
-    else if ((a.debug & 3) != 2) chain_role_tp(a, b - a.nbr_wgs);
+    const int b = blockIdx.x, cx = a.chain_xcds;
+    if (cx == 0) {
+        if (b < a.nbr_wgs) { if ((a.debug & 3) != 3) nbr_role_tp(a, b); }
+        else if ((a.debug & 3) != 2) chain_role_tp(a, b - a.nbr_wgs);
+        return;
+    }
+    const int x = b & 7, slot = b >> 3;
+    if (x < cx) {
+        const int tile = slot * cx + x;
+        if (tile < a.tiles) { if ((a.debug & 3) != 2) chain_role_tp(a, tile); }
+        else if (a.fill_nbr >= 0 && (a.debug & 3) != 3) nbr_role_tp(a, a.fill_nbr + (tile - a.tiles));
+    } else if ((a.debug & 3) != 3) {
+        nbr_role_tp(a, slot * (8 - cx) + (x - cx));
+    }
+}
+
+// (ot, j, nin_skip?) of unit n of a stage with Co output channels: main units tile-major, then nin_skip's
+__device__ __host__ __forceinline__ void tp_unit_of(int n, int Co, int &ot, int &j, bool &skip)
+{
+    const int um = 5 * (Co >> 4);
+    skip = n >= um;
+    const int m = skip ? n - um : n;
+    ot = m / 5;
+    j = m - ot * 5;
+}
+
+// the centre tap (+ nin_skip) of a stage in the throughput chain role's own order: out[wave][unit][half][lane][4] =
+// W[o = ot*16 + i][channels 16*(j + 5*half) + 4*kk .. +3] for lane (kk, i) -- what load h of unit u of wave w wants, KB by KB
+__global__ void k_pack_tp(const float *wc, const float *ws, int Co, int NG, int type, float *out)
+{
+    const int NU = tpt_nu(type), total = tpt_units(type);
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= TP_WAVES * NU * 2 * 64) return;
+    const int lane = idx & 63, h = (idx >> 6) & 1, u = ((idx >> 7) % NU), w = (idx >> 7) / NU;
+    const int n = w + TP_WAVES * u, i = lane & 15, kk = lane >> 4;
+    f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (n < total && (h == 0 || NG == 10)) {
+        int ot, j; bool skip;
+        tp_unit_of(n, Co, ot, j, skip);
+        const float *wp = skip ? ws : wc;
+        const int cw = skip ? NF : Co;
+        v = *(const f32x4 *)(wp + ((size_t)(4 * (j + 5 * h) + kk) * cw + ot * 16 + i) * 4);
+    }
+    *(f32x4 *)(out + (size_t)idx * 4) = v;
 }
 
 // repack the centre tap (+ nin_skip) of a stage for the chain role: out[step][chain][4]
@@ -1912,12 +2017,16 @@ struct ps_pixelcnn {
     // throughput form (k_column_tp): launches of more than tp_min_cols columns
     NbrWorkTp *work_tp = nullptr;
     int nwork_tp = 0;
+    TpUnit *units_tp = nullptr;     // unit tables of the four stage types [4][TP_WAVES][TP_MAXU]
     float *nbr_tp = nullptr;        // neighbour slots [NST][2][TP_COL_CAP][160]
     unsigned *cnt_tp = nullptr;     // [NST][TP_MAX_TILES] padded completion counters, never reset
     unsigned tile_uses_tp[TP_MAX_TILES] = {};
     ColTaps *taps = nullptr;        // neighbour rows of the columns of a run, [maxF * L]
+    unsigned long long *tp_trace = nullptr;   // tuning builds: stamps of the last k_column_tp launch (ps_pixelcnn_debug_cache what 4)
     int n_cus = 256;                // compute units of the device: workgroups of a column launch that are resident together
     int tp_min_cols = COL_CAP + 1;  // PS_TP_MIN_COLS: tuning
+    int tp_xcds = -1;               // PS_TP_XCDS: 0 = chain tiles anywhere, -1 = on as few XCDs as hold them, n = on at least n XCDs
+    int tp_fill = 1;                // PS_TP_FILL: neighbour workgroups on the spare CUs of the chain XCDs
     int col_cap = COL_CAP;          // columns per launch (PS_COL_CAP: tuning)
     int chain_xcds = 0;             // PS_CHAIN_XCDS: tuning (0 = automatic)
     int force_groups = 0;           // PS_NBR_GROUPS: tuning (0 = automatic)
@@ -2107,6 +2216,37 @@ int build_stage_table(ps_pixelcnn *h)
         }
         d.wv = wv;
     }
+    // throughput form: the stages' weights in that chain role's own order, and the unit tables of the four stage types
+    std::vector<float *> wtp(NST, nullptr);
+    std::vector<int> tptype(NST, TPT_DIL);
+    for (int k = 0; k < NST - 1; ++k) {
+        const StageDesc &d = st[k];
+        const int type = d.NG == 5 ? TPT_DIL : d.Co_pad == 2 * NF ? TPT_CONVOUT : d.w_skip ? TPT_CONVIN_SKIP : TPT_CONVIN;
+        tptype[k] = type;
+        const int n = TP_WAVES * tpt_nu(type) * 2 * 64;
+        if (int rc = dev_alloc(h, &wtp[k], (size_t)n * 4)) return rc;
+        hipLaunchKernelGGL(k_pack_tp, dim3((n + 255) / 256), dim3(256), 0, 0, d.w + (size_t)d.center_tap * d.NG * 16 * d.Co_pad, d.w_skip,
+                           d.Co_pad, d.NG, type, wtp[k]);
+    }
+    wtp[NST - 1] = wtp[NST - 2];   // nin_out has its own loop: the record only has to name loadable memory (requested, dropped)
+    {
+        std::vector<TpUnit> units((size_t)4 * TP_WAVES * TP_MAXU, TpUnit{0, 0, 0, 0});
+        for (int type = 0; type < 4; ++type) {
+            const int Co = type == TPT_CONVOUT ? 2 * NF : NF, total = tpt_units(type);
+            for (int w = 0; w < TP_WAVES; ++w)
+                for (int u = 0; u < TP_MAXU; ++u) {
+                    const int n = std::min(w + TP_WAVES * u, total - 1);   // absent units name a valid one (never stored)
+                    int ot, j; bool skip;
+                    tp_unit_of(n, Co, ot, j, skip);
+                    TpUnit &e = units[((size_t)type * TP_WAVES + w) * TP_MAXU + u];
+                    e.b0 = (skip ? XB_SIZE : 0) + 4 * j * XB_LD;
+                    e.b1 = e.b0 + (type == TPT_DIL ? 0 : 20 * XB_LD);
+                    e.dst = (skip ? 5 * Co + j * NF : j * Co) + ot * 16;
+                }
+        }
+        if (int rc = dev_alloc(h, &h->units_tp, units.size())) return rc;
+        PS_HIP_CHECK(hipMemcpy(h->units_tp, units.data(), units.size() * sizeof(TpUnit), hipMemcpyHostToDevice));
+    }
     PS_HIP_CHECK(hipDeviceSynchronize());
     {   // the chain role's control records
         std::vector<int> ctl((size_t)(NST + 1) * C1_CTL_DWORDS, 0);
@@ -2128,6 +2268,8 @@ int build_stage_table(ps_pixelcnn *h)
             // the centre tap (and nin_skip) in the MFMA layout [c/4][o][4]; nin_out's weights are that layout already
             put_p(1 + k, CTL_WC, k == NST - 1 ? st[k].w : st[k].w + (size_t)st[k].center_tap * st[k].NG * 16 * st[k].Co_pad);
             put_p(1 + k, CTL_WS, st[k].w_skip);
+            c[CTL_TP_TYPE] = tptype[k];
+            put_p(1 + k, CTL_WTP, wtp[k]);
             if (k + 1 < NST) put_post(1 + k, st[k + 1]);
         }
         if (int rc = dev_alloc(h, &h->ctl1, ctl.size())) return rc;
@@ -2155,22 +2297,38 @@ void run_columns(ps_pixelcnn *h, const StepCtx *rec, int ncols, const int32_t *c
     if (const char *dbg = getenv("PS_COLUMN_DEBUG")) ca.debug = atoi(dbg);
     if (ncols >= h->tp_min_cols) {   // throughput form: 16-column chain tiles, up to TP_COL_CAP columns per launch
         TpArgs ta{};
+        ta.units = h->units_tp;
         ta.work = h->work_tp; ta.nbr = h->nbr_tp; ta.cnt = h->cnt_tp; ta.nwork = h->nwork_tp;
         ta.ctl1 = h->ctl1; ta.uinit_w = h->uinit_w; ta.uinit_b = h->uinit_b; ta.codes_in = codes;
         ta.out_w = h->out_w; ta.out_b = h->out_b; ta.L = h->L;
         ta.codes = ca.codes; ta.region = ca.region; ta.forced = ca.forced; ta.uniforms = ca.uniforms;
         ta.out_logits = ca.out_logits; ta.step_logits = ca.step_logits; ta.temperature = ca.temperature;
         ta.err = h->err; ta.debug = ca.debug;
+        ta.trace = h->tp_trace;
         const int cap = std::min(TP_COL_CAP, std::max(TP_COLS, (h->n_cus / 2) * TP_COLS));   // at least half of the CUs to the neighbour role
         const ColTaps *taps = h->taps + (rec - h->ctx);
         for (int done = 0; done < ncols; done += cap) {
             const int n = std::min(cap, ncols - done);
             const int tiles = (n + TP_COLS - 1) / TP_COLS;
             ta.taps = taps + done; ta.ctx = rec + done; ta.ncols = n; ta.tiles = tiles;
-            ta.nbr_wgs = std::max(1, std::min(h->n_cus - tiles, (h->nwork_tp * tiles + TP_WAVES - 1) / TP_WAVES));
             for (int t = 0; t < tiles; ++t) h->tile_uses_tp[t] += 1;
             for (int t = 0; t < TP_MAX_TILES; ++t) ta.tile_uses[t] = h->tile_uses_tp[t];
-            timed(h, st, TAG_CHAIN, [&]() { hipLaunchKernelGGL(k_column_tp, dim3(ta.nbr_wgs + tiles), dim3(TP_THREADS), 0, st, ta); });
+            int grid;
+            const int rows = h->n_cus / 8;   // CUs per XCD
+            if (h->tp_xcds != 0 && h->n_cus % 8 == 0 && rows > 0 && tiles <= 4 * rows) {
+                const int cx = h->tp_xcds > 0 ? std::max(h->tp_xcds, (tiles + rows - 1) / rows) : (tiles + rows - 1) / rows;
+                ta.chain_xcds = std::min(cx, 7);
+                const int spare = ta.chain_xcds * rows - tiles;
+                ta.nbr_wgs = (8 - ta.chain_xcds) * rows;
+                ta.fill_nbr = -1;
+                if (h->tp_fill && spare > 0) { ta.fill_nbr = ta.nbr_wgs; ta.nbr_wgs += spare; }
+                grid = h->n_cus;
+            } else {
+                ta.chain_xcds = 0; ta.fill_nbr = -1;
+                ta.nbr_wgs = std::max(1, std::min(h->n_cus - tiles, (h->nwork_tp * tiles + TP_WAVES - 1) / TP_WAVES));
+                grid = ta.nbr_wgs + tiles;
+            }
+            timed(h, st, TAG_CHAIN, [&]() { hipLaunchKernelGGL(k_column_tp, dim3(grid), dim3(TP_THREADS), 0, st, ta); });
         }
         return;
     }
@@ -2227,6 +2385,8 @@ int ps_pixelcnn_create(const float *const *params, int n_params, int H, int W, i
     if (const char *cc = getenv("PS_CHAIN_XCDS")) h->chain_xcds = std::max(0, std::min(8, atoi(cc)));
     if (const char *cc = getenv("PS_NBR_GROUPS")) h->force_groups = std::max(0, std::min(NBR_MAX_GROUPS, atoi(cc)));
     if (const char *cc = getenv("PS_TP_MIN_COLS")) h->tp_min_cols = std::max(1, atoi(cc));
+    if (const char *cc = getenv("PS_TP_XCDS")) h->tp_xcds = atoi(cc);
+    if (const char *cc = getenv("PS_TP_FILL")) h->tp_fill = atoi(cc);
     {
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
@@ -2454,6 +2614,10 @@ void *ps_pixelcnn_debug_cache(ps_pixelcnn *h, int what, int idx)
     if (what == 1 && idx >= 0 && idx < NNODE) return h->E[idx];
     if (what == 2 && idx >= 0 && idx < NGATED) return h->X[idx];
     if (what == 3) return h->nbr_tp;   // neighbour slots of the last throughput launch [NST][2][1024][160]
+    if (what == 4) {                   // tuning builds: allocate / return the stamp buffer [NST][8] of 64-bit clocks
+        if (!h->tp_trace && dev_alloc(h, &h->tp_trace, (size_t)NST * 8) == PS_OK) (void)hipMemset(h->tp_trace, 0, NST * 8 * 8);
+        return h->tp_trace;
+    }
     return nullptr;
 }
 

@@ -1,0 +1,37 @@
+"""Tuning aid (needs a build with PS_EXTRA_HIPCC_FLAGS=-DPS_TP_TRACE_BUILD): shader-clock stamps of the chain role of
+k_column_tp, tile 0 / wave 0, per stage: wait for the neighbour counter, operand issue, MFMA phase, barrier, post op, barrier."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from pixelsynth_amd import _lib  # noqa: E402
+
+V = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+device = torch.device("cuda", 0)
+model = bench.build_model(device)
+d, _ = bench.make_inputs(0, V, device)
+out = bench.run_step(model, d, 1)
+eng = model.outpaint2.engine(32, 32, V)
+p = _lib.lib().ps_pixelcnn_debug_cache(eng.handle, 4, 0)
+out = bench.run_step(model, d, 1)
+torch.cuda.synchronize()
+
+
+class _Raw:
+    def __init__(self, ptr, shape):
+        self.__cuda_array_interface__ = {"shape": shape, "typestr": "<i8", "data": (ptr, False), "version": 2}
+
+
+st = torch.as_tensor(_Raw(p, (33, 8)), device=device).cpu().numpy()
+names = ["ctl+wait", "ops issue", "mfma", "wload+barrier", "post", "barrier"]
+tot = np.zeros(6)
+print("stage  " + "  ".join(f"{n:>13s}" for n in names) + "   total (cycles of the 100 MHz? shader clock)")
+for s in range(32):
+    dl = [st[s, k + 1] - st[s, k] for k in range(6)]
+    tot += dl
+    print(f"{s:5d}  " + "  ".join(f"{v:13d}" for v in dl) + f"   {st[s, 6] - st[s, 0]}")
+print("sum    " + "  ".join(f"{int(v):13d}" for v in tot) + f"   {int(tot.sum())}   span {st[31, 6] - st[0, 0]}")
