@@ -1509,10 +1509,15 @@ __device__ __forceinline__ void nbr_role_tp(const TpArgs &a, int nb)
 
 __device__ __forceinline__ void chain_role_tp(const TpArgs &a, int tile)
 {
-    __shared__ __attribute__((aligned(16))) float sXS[2 * XB_SIZE];        // B-operand layout: input of the centre taps, and behind
-    float *const sXb = sXS, *const sSb = sXS + XB_SIZE;                    //   it concat_elu(u_k) feeding nin_skip
+    // (Both 16-byte-accessed buffers are DECLARED as 16-byte elements: behind a float array and a run-time index hipcc cannot
+    // prove the alignment and splits every ds_read_b128 / ds_write_b128 into two ds_read2_b32 -- which, at a lane stride of
+    // four dwords, is an 8-way bank conflict on every operand read: the MFMA phase took 2-3x its MFMA time.)
+    __shared__ f32x4 sXS4[2 * XB_SIZE / 4];                                // B-operand layout: input of the centre taps, and behind
+    float *const sXS = (float *)sXS4;                                      //   it concat_elu(u_k) feeding nin_skip
+    float *const sXb = sXS, *const sSb = sXS + XB_SIZE;
     __shared__ __attribute__((aligned(16))) TpUnit sUnit[4 * TP_WAVES * TP_MAXU];   // the unit tables of the four stage types
-    __shared__ __attribute__((aligned(16))) float sP[TP_COLS * SP_LD];     // chain values of the stage [col][j][o]; logits at the end
+    __shared__ f32x4 sP4[TP_COLS * SP_LD / 4];                             // chain values of the stage [col][j][o]; logits at the end
+    float *const sP = (float *)sP4;
     __shared__ __attribute__((aligned(16))) float sU[8][TP_COLS][NF];      // u0..u7 of the tile's columns
     __shared__ __attribute__((aligned(16))) StepCtx sC[TP_COLS];
     __shared__ __attribute__((aligned(16))) int sCtl[(NST + 1) * C1_CTL_DWORDS];   // the control records (a scalar load from memory at
@@ -1634,67 +1639,86 @@ __device__ __forceinline__ void chain_role_tp(const TpArgs &a, int tile)
     // first, then nin_skip's.  Nothing about a unit is computed here: its B-operand and chain-value offsets come from the unit
     // table of the stage's type, its weights from the stage's copy in this role's own order [wave][unit][half][lane][4] -- one
     // base register, the rest immediates.
+#ifndef PS_TP_EXP
+#define PS_TP_EXP 0
+#endif
+#ifdef PS_TP_TRACE_BUILD
+    int trace_s = 0;
+    const int trace_wave = a.debug >> 8;   // PS_COLUMN_DEBUG = 256 * wave (+ mode): the wave whose stamps are kept
+#define TP_STAMP(slot) do { if (a.trace && tile == 0 && t == 64 * trace_wave) a.trace[s * 8 + (slot)] = clock64(); } while (0)
+#define TP_STAMP2(slot, dep) do { if (a.trace && tile == 0 && t == 64 * trace_wave && (dep)) a.trace[trace_s * 8 + (slot)] = clock64(); } while (0)
+#else
+#define TP_STAMP(slot) do { } while (0)
+#define TP_STAMP2(slot, dep) do { } while (0)
+#endif
     struct UnitW { f32x4 a0, a1; };
     const int lane_b = kk * XB_LD + i * 4, lane_d = i * SP_LD + kk * 4;
     // weights of this wave's units of the stage of record `rec` (type ty): NU x 2 16-byte loads from consecutive KBs
     auto weights_base = [&](int rec, int ty) {
         return lpf(rec, CTL_WTP) + ((size_t)wave * tpt_nu(ty) * 2 * 64 + lane) * 4;
     };
-    // MFMA phase of a stage of type TY on the weights in Wc; the weights of the NEXT stage (type nty, base nbase) are requested
-    // into Wn between the MFMAs of the first half -- they have the rest of the stage to arrive, and no wave waits at an issue
-    // queue with nothing to do.  Units 0 .. NU-2 exist for every wave, unit NU-1 for the first waves only (`last`).
-    auto mfma_units = [&](auto TYc, const UnitW (&Wc)[TP_MAXU], int nty, const float *nbase, UnitW (&Wn)[TP_MAXU]) {
+    // MFMA phase of a stage of type TY.  One weight buffer, refilled in place: a unit's first-half weights (a0: channel group j)
+    // are dead once the first half has been issued, so the NEXT stage's a0 (type nty, base nbase) are requested into the same
+    // registers between the MFMAs of the second half, and its a1 right after the second half -- each has more than half a stage
+    // to arrive, and the requests go out while the matrix pipe works through MFMAs already issued.  The B operands of the
+    // second half (group j + 5) take the registers of the first half's.  Units 0 .. NU-2 exist for every wave, unit NU-1 for
+    // the first waves only (`last`).
+    auto mfma_units = [&](auto TYc, UnitW (&W)[TP_MAXU], int nty, const float *nbase) {
         constexpr int TY = decltype(TYc)::value, NU = tpt_nu(TY), NH = tpt_nh(TY);
         const bool last = wave + TP_WAVES * (NU - 1) < tpt_units(TY);
         const TpUnit *ut = sUnit + (TY * TP_WAVES + wave) * TP_MAXU;
-        f32x4 b0[NU], b1[NU], acc[NU];
-        int dst[NU];
+        f32x4 b[NU], acc[NU];
+        int b1i[NU], dst[NU];
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
-            const TpUnit e = ut[u];
-            b0[u] = *(const f32x4 *)&sXS[e.b0 + lane_b];
-            if (NH == 2) b1[u] = *(const f32x4 *)&sXS[e.b1 + lane_b];
-            dst[u] = e.dst + lane_d;
+            const uint4 raw = ((const uint4 *)ut)[u];   // {b0, b1, dst, -}
+            b[u] = sXS4[((int)raw.x + lane_b) >> 2];
+            b1i[u] = ((int)raw.y + lane_b) >> 2;
+            dst[u] = ((int)raw.z + lane_d) >> 2;
             acc[u] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         }
-        const int nn = 2 * tpt_nu(nty);   // 16-byte loads of the next stage per wave: 8 or 14 (every unit has two KBs in the copy)
-        auto next_load = [&](int q) {     // q-th KB of the next stage's weights of this wave; q is a compile-time constant at every call
-            if (q >= nn) return;
-            const f32x4 v = *PS_GC(f32x4, nbase + (size_t)q * 256);
-            if (q & 1) Wn[q >> 1].a1 = v; else Wn[q >> 1].a0 = v;
-        };
+        const int nnu = tpt_nu(nty);   // units per wave of the next stage: 4 or 7 (every unit has two KBs in the stage's copy)
+        TP_STAMP2(3, b[0][0] != 12345.0f);
         // canonical order of a chain: group j (c = 0..3), then group j + 5; the units are independent accumulators
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
 #pragma unroll
-            for (int u = 0; u < NU - 1; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wc[u].a0[c], b0[u][c], acc[u], 0, 0, 0);
-            if (last) acc[NU - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wc[NU - 1].a0[c], b0[NU - 1][c], acc[NU - 1], 0, 0, 0);
-#pragma unroll
-            for (int q = 4 * c; q < 4 * c + 4; ++q) if (q < 2 * TP_MAXU) next_load(q);
+            for (int u = 0; u < NU - 1; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(W[u].a0[c], b[u][c], acc[u], 0, 0, 0);
+            if (last) acc[NU - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(W[NU - 1].a0[c], b[NU - 1][c], acc[NU - 1], 0, 0, 0);
         }
+        TP_STAMP2(4, true);
         if (NH == 2) {
+#pragma unroll
+            for (int u = 0; u < NU; ++u) b[u] = sXS4[b1i[u]];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
 #pragma unroll
-                for (int u = 0; u < NU - 1; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wc[u].a1[c], b1[u][c], acc[u], 0, 0, 0);
-                if (last) acc[NU - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wc[NU - 1].a1[c], b1[NU - 1][c], acc[NU - 1], 0, 0, 0);
-            }
-        }
+                for (int u = 0; u < NU - 1; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(W[u].a1[c], b[u][c], acc[u], 0, 0, 0);
+                if (last) acc[NU - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(W[NU - 1].a1[c], b[NU - 1][c], acc[NU - 1], 0, 0, 0);
 #pragma unroll
-        for (int u = 0; u < NU - 1; ++u) *(f32x4 *)&sP[dst[u]] = acc[u];
-        if (last) *(f32x4 *)&sP[dst[NU - 1]] = acc[NU - 1];
+                for (int u = 2 * c; u < 2 * c + 2; ++u)
+                    if (u < TP_MAXU && u < nnu) W[u].a0 = *PS_GC(f32x4, nbase + (size_t)(2 * u) * 256);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < TP_MAXU; ++u)
+                if (u < nnu) W[u].a0 = *PS_GC(f32x4, nbase + (size_t)(2 * u) * 256);
+        }
+        TP_STAMP2(5, true);
+#pragma unroll
+        for (int u = 0; u < TP_MAXU; ++u)
+            if (u < nnu) W[u].a1 = *PS_GC(f32x4, nbase + (size_t)(2 * u + 1) * 256);
+#pragma unroll
+        for (int u = 0; u < NU - 1; ++u) sP4[dst[u]] = acc[u];
+        if (last) sP4[dst[NU - 1]] = acc[NU - 1];
+        TP_STAMP2(6, acc[0][0] != 12345.0f);
     };
 
-#ifdef PS_TP_TRACE_BUILD
-#define TP_STAMP(slot) do { if (a.trace && tile == 0 && t == 0) a.trace[s * 8 + (slot)] = clock64(); } while (0)
-#else
-#define TP_STAMP(slot) do { } while (0)
-#endif
     // One stage: operands of its post op requested, MFMA phase (next stage's weights requested underneath), barrier, post op of
     // this wave's two columns, barrier.  The stage's type fixes Co, NG, the unit list and the post op that follows it
     // (conv_input -> CONVIN with or without nin_skip, conv_out -> GATE, dilated conv -> DIL).
     unsigned cnt_have = 0;
-    auto run_stage = [&](int s, auto TYc, const UnitW (&Wc)[TP_MAXU], UnitW (&Wn)[TP_MAXU]) {
+    auto run_stage = [&](int s, auto TYc, UnitW (&W)[TP_MAXU]) {
         constexpr int TY = decltype(TYc)::value;
         constexpr int kind = TY == TPT_CONVOUT ? PRO_GATE : TY == TPT_DIL ? PRO_DIL : PRO_CONVIN;
         constexpr bool has_skip = TY == TPT_CONVIN_SKIP;
@@ -1715,15 +1739,25 @@ __device__ __forceinline__ void chain_role_tp(const TpArgs &a, int tile)
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const float *nb = a.nbr + (size_t)s * nbr_stage + (size_t)(col0 + (pvalid[k] ? pcol[k] : 0)) * NBR_LD + c2;
+#if PS_TP_EXP == 1
+            ona[k] = plain(nb);
+            onb[k] = plain(nb + nbr_half);
+            if (kind == PRO_GATE) { onag[k] = plain(nb + NF); onbg[k] = plain(nb + nbr_half + NF); }
+#elif PS_TP_EXP == 2
+            ona[k] = onb[k] = onag[k] = onbg[k] = zero2; (void)nb;
+#else
             ona[k] = fresh(nb);
             onb[k] = fresh(nb + nbr_half);
             if (kind == PRO_GATE) { onag[k] = fresh(nb + NF); onbg[k] = fresh(nb + nbr_half + NF); }
+#endif
         }
         TP_STAMP(2);
-        mfma_units(TYc, Wc, nty, nbase, Wn);
-        TP_STAMP(3);
+#ifdef PS_TP_TRACE_BUILD
+        trace_s = s;
+#endif
+        mfma_units(TYc, W, nty, nbase);
         lds_barrier();
-        TP_STAMP(4);
+        TP_STAMP(7);
         auto five = [](const float *p, int stride) {
             return chain_total(*(const f32x2 *)p, *(const f32x2 *)(p + stride), *(const f32x2 *)(p + 2 * stride),
                                *(const f32x2 *)(p + 3 * stride), *(const f32x2 *)(p + 4 * stride));
@@ -1738,21 +1772,19 @@ __device__ __forceinline__ void chain_role_tp(const TpArgs &a, int tile)
         }
         emit2(y, g, skip, integral_constant<int, kind>{}, integral_constant<bool, has_skip>{}, pc.in_form, pc.save_slot, sc);
         stage_skip_input(sc.skip_slot);
-        TP_STAMP(5);
         lds_barrier();
-        TP_STAMP(6);
     };
-    auto dispatch_stage = [&](int s, const UnitW (&Wc)[TP_MAXU], UnitW (&Wn)[TP_MAXU]) {
+    auto dispatch_stage = [&](int s, UnitW (&W)[TP_MAXU]) {
         using std::integral_constant;
         const int ty = li(1 + s, CTL_TP_TYPE);
-        if (ty == TPT_CONVOUT) run_stage(s, integral_constant<int, TPT_CONVOUT>{}, Wc, Wn);
-        else if (ty == TPT_CONVIN_SKIP) run_stage(s, integral_constant<int, TPT_CONVIN_SKIP>{}, Wc, Wn);
-        else if (ty == TPT_CONVIN) run_stage(s, integral_constant<int, TPT_CONVIN>{}, Wc, Wn);
-        else run_stage(s, integral_constant<int, TPT_DIL>{}, Wc, Wn);
+        if (ty == TPT_CONVOUT) run_stage(s, integral_constant<int, TPT_CONVOUT>{}, W);
+        else if (ty == TPT_CONVIN_SKIP) run_stage(s, integral_constant<int, TPT_CONVIN_SKIP>{}, W);
+        else if (ty == TPT_CONVIN) run_stage(s, integral_constant<int, TPT_CONVIN>{}, W);
+        else run_stage(s, integral_constant<int, TPT_DIL>{}, W);
     };
 
     // ================= u0 = norm_init(u_init): gather over the (earlier) neighbours' codes =================
-    UnitW WA[TP_MAXU], WB[TP_MAXU];
+    UnitW WA[TP_MAXU];
     {
         const PostCtl pc = post_ctl(0);
         const StoreCtl sc = store_ctl(0);
@@ -1782,19 +1814,17 @@ __device__ __forceinline__ void chain_role_tp(const TpArgs &a, int tile)
     }
     lds_barrier();
 
-    // ================= the 32 conv stages (weights double-buffered: WA / WB alternate) =================
-    for (int s = 0; s < NST - 1; s += 2) {
-        dispatch_stage(s, WA, WB);
-        dispatch_stage(s + 1, WB, WA);   // (the last call requests nin_out's record: a dilated-type dummy, dropped)
-    }
+    // ================= the 32 conv stages =================
+    for (int s = 0; s < NST - 1; ++s) dispatch_stage(s, WA);   // (the last one requests nin_out's record: a dummy, dropped)
 #undef TP_STAMP
+#undef TP_STAMP2
 
     // ================= nin_out(elu(u)) (model.py:153): 32 output tiles x 5 chains of 4 MFMAs, logits, draw =================
     {
         const int g_ = 0; (void)g_;
         f32x4 bx[5];
 #pragma unroll
-        for (int j = 0; j < 5; ++j) bx[j] = *(const f32x4 *)&sXb[(4 * j + kk) * XB_LD + i * 4];
+        for (int j = 0; j < 5; ++j) bx[j] = sXS4[((4 * j + kk) * XB_LD + i * 4) >> 2];
 #pragma unroll
         for (int q = 0; q < NCLS / 16 / TP_WAVES; ++q) {
             const int ot = wave + TP_WAVES * q;
@@ -1803,7 +1833,7 @@ __device__ __forceinline__ void chain_role_tp(const TpArgs &a, int tile)
             for (int j = 0; j < 5; ++j) av[j] = *PS_GC(f32x4, a.out_w + ((size_t)(4 * j + kk) * NCLS + ot * 16 + i) * 4);
             Acc5 acc = acc5_zero();
             mfma_chunk5(av, bx, acc);
-            *(f32x4 *)&sP[i * SLOG_LD + ot * 16 + kk * 4] = chunk_total(acc);
+            sP4[(i * SLOG_LD + ot * 16 + kk * 4) >> 2] = chunk_total(acc);
         }
     }
     lds_barrier();
@@ -1812,7 +1842,8 @@ __device__ __forceinline__ void chain_role_tp(const TpArgs &a, int tile)
         if (!pvalid[k]) continue;
         float lg[8];
         const float *Lp = &sP[pcol[k] * SLOG_LD + lane * 8];
-        const f32x4 lo = *(const f32x4 *)Lp, hi = *(const f32x4 *)(Lp + 4);
+        const f32x4 lo = sP4[(pcol[k] * SLOG_LD + lane * 8) >> 2], hi = sP4[((pcol[k] * SLOG_LD + lane * 8) >> 2) + 1];
+        (void)Lp;
 #pragma unroll
         for (int q = 0; q < 4; ++q) { lg[q] = lo[q] + a.out_b[lane * 8 + q]; lg[4 + q] = hi[q] + a.out_b[lane * 8 + 4 + q]; }
         const size_t loc = ploc[k];
@@ -2269,7 +2300,7 @@ int build_stage_table(ps_pixelcnn *h)
             put_p(1 + k, CTL_WC, k == NST - 1 ? st[k].w : st[k].w + (size_t)st[k].center_tap * st[k].NG * 16 * st[k].Co_pad);
             put_p(1 + k, CTL_WS, st[k].w_skip);
             c[CTL_TP_TYPE] = tptype[k];
-            put_p(1 + k, CTL_WTP, wtp[k]);
+            put_p(1 + k, CTL_WTP, getenv("PS_TP_EXP_HOTW") ? wtp[1] : wtp[k]);   // (timing experiment: every stage streams the same 112 KB)
             if (k + 1 < NST) put_post(1 + k, st[k + 1]);
         }
         if (int rc = dev_alloc(h, &h->ctl1, ctl.size())) return rc;

@@ -27,11 +27,12 @@ class _Raw:
 
 
 st = torch.as_tensor(_Raw(p, (33, 8)), device=device).cpu().numpy()
-names = ["ctl+wait", "ops issue", "mfma", "wload+barrier", "post", "barrier"]
-tot = np.zeros(6)
+names = ["ctl+wait", "ops issue", "B reads", "half 1", "half 2", "acc->LDS", "barrier"]
+tot = np.zeros(7)
 print("stage  " + "  ".join(f"{n:>13s}" for n in names) + "   total (cycles of the 100 MHz? shader clock)")
 for s in range(32):
-    dl = [st[s, k + 1] - st[s, k] for k in range(6)]
+    dl = [st[s, k + 1] - st[s, k] for k in range(7)]
     tot += dl
-    print(f"{s:5d}  " + "  ".join(f"{v:13d}" for v in dl) + f"   {st[s, 6] - st[s, 0]}")
-print("sum    " + "  ".join(f"{int(v):13d}" for v in tot) + f"   {int(tot.sum())}   span {st[31, 6] - st[0, 0]}")
+    nxt = (st[s + 1, 0] - st[s, 7]) if s < 31 else 0
+    print(f"{s:5d}  " + "  ".join(f"{v:13d}" for v in dl) + f"   post+barrier {nxt:6d}   total {st[s, 7] - st[s, 0] + nxt}")
+print("sum    " + "  ".join(f"{int(v):13d}" for v in tot) + f"   {int(tot.sum())}   span {st[31, 7] - st[0, 0]}")
