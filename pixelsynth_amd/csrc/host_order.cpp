@@ -266,6 +266,7 @@ int ps_ar_wavefronts_capped(const int32_t *order_loc, int B, int H, int W, int f
     size_t at = 0;
     int nw = 0;
     std::vector<std::pair<int32_t, int32_t>> taken;
+    std::vector<std::pair<uint32_t, std::pair<int32_t, int32_t>>> keyed;
     wave_start[0] = 0;
     while (nready > 0) {
         taken.clear();
@@ -274,6 +275,27 @@ int ps_ar_wavefronts_capped(const int32_t *order_loc, int B, int H, int W, int f
             taken.push_back(bucket[(size_t)top].back());
             bucket[(size_t)top].pop_back();
             --nready;
+        }
+        // Within a wave the order of the columns is free.  A launch works on them in tiles of 16, and a neighbour tap that is
+        // closed for every column of a tile is skipped for the whole tile: columns with the same set of open taps (the same
+        // sixteen bits: 8 neighbours at dilation 1, 8 at dilation 2) are put next to each other.
+        if (taken.size() > 16) {
+            keyed.clear();
+            for (const auto &k : taken) {
+                const int b = k.first, i = k.second;
+                const int32_t *ol = order_loc + (size_t)b * L, *rk = rank.data() + (size_t)b * L;
+                const int q = ol[i], r = q / W, c = q - r * W;
+                uint32_t sig = 0;
+                for (int dil = 1; dil <= 2; ++dil)
+                    for (int t = 0; t < 9; ++t) {
+                        if (t == 4) continue;
+                        const int rr = r + (t / 3 - 1) * dil, cc = c + (t % 3 - 1) * dil;
+                        sig = (sig << 1) | ((rr >= 0 && rr < H && cc >= 0 && cc < W && rk[rr * W + cc] < i) ? 1u : 0u);
+                    }
+                keyed.emplace_back(sig, k);
+            }
+            std::stable_sort(keyed.begin(), keyed.end(), [](const auto &x, const auto &y) { return x.first < y.first; });
+            for (size_t k = 0; k < keyed.size(); ++k) taken[k] = keyed[k].second;
         }
         for (const auto &k : taken) {
             cols[2 * at] = k.first;
