@@ -3,14 +3,14 @@
 
     python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
 
-One STEP = one pass of the hot path over one batch of V independent novel views of a source image
-(BASELINE.json config C5's per-GPU shard: 1 source x 16 views; at --gpus 8 the job is exactly C5 =
-8 sources x 16 views): reprojection + soft z-buffer splat, generation order + masks
-(a7-a9), autoregressive outpainting of the 32x32 VQ code grid (a13).  Inputs are synthetic and
-already resident in HBM when the timed region starts; weights are random-init with the reference's
-shapes.  The VQ-VAE / depth / refinement networks around the path are out of scope, so the
-codes of the reprojected view are synthetic.  Weak scaling: every rank renders its own V views; the only
-collective is the RCCL all_gather of the finished frames (no data-path exchange).
+One STEP = one pass of the hot path over one batch of V independent novel views per GPU.  Default V = 128 = BASELINE.json's
+config C5 -- Matterport-shaped 256x256 inputs, 8 source images x 16 novel views each -- which fits one GPU, so at N = 1
+the step IS C5; under `torch.distributed.run` every rank renders its own 8 x 16 views (weak scaling).  A view =
+reprojection + soft z-buffer splat, generation order + masks (a7-a9), autoregressive outpainting of
+the 32x32 VQ code grid (a13).  Inputs are synthetic and already resident in HBM when the timed region starts; weights
+are random-init with the reference's shapes.  The VQ-VAE / depth / refinement networks around the path are next-row
+components, timed separately under `other_single_gpu_configs`; the codes of the reprojected view are
+synthetic.  The only collective is the RCCL all_gather of the finished frames (no data-path exchange).
 
 Prints ONE JSON line (rank 0) with the contract fields plus `roofline` and `cpu_baseline`.
 """
@@ -49,12 +49,28 @@ def build_model(device):
     return model.to(device)
 
 
-def make_inputs(rank, V, device, smooth=True):
+VIEWS_PER_SOURCE = 16   # config C5: 8 source images x 16 novel views each
+
+
+def make_inputs(rank, V, device, smooth=True, cameras="mp3d"):
+    """V independent (source, target view) pairs: ceil(V / 16) source images, 16 target views each (a yaw sweep of +-0.6 rad,
+    the reference's full angle, models/z_buffermodel.py:113).  cameras "mp3d": Matterport/Habitat-shaped (config C5:
+    K = diag(1/tan(hfov/2), ., 1, 1) at hfov 90 deg, depth 0.5 .. 10, data/create_rgb_dataset.py:204-216); "demo": the demo /
+    RealEstate10K-shaped cameras of demo.py:36-96 (K = I, P = diag(2,-2,-1,1)), depth 1 .. 100."""
     S = 256
-    img = np.repeat(syn.image(1000 + rank, 1, 3, S), V, 0)
-    depth = np.repeat((syn.depth_smooth if smooth else syn.depth_uniform)(2000 + rank, 1, S, 1.0, 100.0), V, 0)
-    cam = syn.demo_cameras(V)
-    yaws = np.linspace(-0.6, 0.6, V) if V > 1 else np.array([0.6])
+    n_src = max(1, -(-V // VIEWS_PER_SOURCE))
+    per = -(-V // n_src)
+    lo, hi = (0.5, 10.0) if cameras == "mp3d" else (1.0, 100.0)
+    cam = (syn.mp3d_cameras if cameras == "mp3d" else syn.demo_cameras)(V)
+    img = np.empty((V, 3, S, S), np.float32)
+    depth = np.empty((V, 1, S, S), np.float32)
+    yaws = np.empty(V, np.float64)
+    for s_ in range(n_src):
+        sl = slice(s_ * per, min(V, (s_ + 1) * per))
+        n = sl.stop - sl.start
+        img[sl] = syn.image(1000 + 64 * rank + s_, 1, 3, S)
+        depth[sl] = (syn.depth_smooth if smooth else syn.depth_uniform)(2000 + 64 * rank + s_, 1, S, lo, hi)
+        yaws[sl] = np.linspace(-0.6, 0.6, n) if n > 1 else np.array([0.6])
     RT2 = np.empty((V, 4, 4), np.float32)
     RT2inv = np.empty((V, 4, 4), np.float32)
     for v in range(V):
@@ -65,7 +81,7 @@ def make_inputs(rank, V, device, smooth=True):
     dev = dict(img=t(img), depth=t(depth), K=t(cam["K"]), Kinv=t(cam["Kinv"]), P=t(cam["P"]), Pinv=t(cam["Pinv"]),
                RT2=t(RT2), RT2inv=t(RT2inv), codes=t(codes),
                uniforms=t(np.random.RandomState(4000 + rank).rand(V, 1024).astype(np.float32)))
-    host = dict(img=img, depth=depth, cam=cam, RT2=RT2, RT2inv=RT2inv, codes=codes, yaws=yaws)
+    host = dict(img=img, depth=depth, cam=cam, RT2=RT2, RT2inv=RT2inv, codes=codes, yaws=yaws, n_src=n_src, cameras=cameras)
     return dev, host
 
 
@@ -135,16 +151,18 @@ def measure_roofline(model, d, out, V):
     cols_per_launch = ncols / max(1, launches.value)
     fl = fpc.value * cols_per_launch
     tf = fl / (us * 1e-6) / 1e12
-    traffic, traffic_src = None, None
-    pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_g_k_column_pmc.json")
-    if V == 16 and os.path.exists(pmc):  # PMC passes cannot run inside the timed bench: committed summary of the same workload
-        with open(pmc) as fh:
-            rec = json.load(fh)
-        traffic, traffic_src = rec["traffic_bytes_per_launch"], rec["source"]
-    return {"bound": "mfma", "kernel": "k_column (one launch per wavefront of independent AR columns: per-column centre-tap chains + "
-                                       "neighbour-tap slots of all 32 masked convs)",
+    traffic, traffic_src, mfma_util = None, None, None
+    pmc = latest_pmc_record(V)   # PMC passes cannot run inside the timed bench: committed summary of the same workload
+    if pmc:
+        traffic, traffic_src, mfma_util = pmc.get("traffic_bytes_per_launch"), pmc.get("source"), pmc.get("mfma")
+    tp = cols_per_launch > 128
+    kernel = ("k_column_tp (throughput form of the column launch, one launch per wavefront of up to 1024 independent AR columns: "
+              "16-column MFMA chain tiles + one wave per neighbour item)" if tp else
+              "k_column (one launch per wavefront of independent AR columns: per-column centre-tap chains + "
+              "neighbour-tap slots of all 32 masked convs)")
+    return {"bound": "mfma", "kernel": kernel,
             "achieved": round(tf, 4), "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-            "frac": round(tf / FP32_MFMA_PEAK_TF, 6), "traffic": traffic, "traffic_source": traffic_src,
+            "frac": round(tf / FP32_MFMA_PEAK_TF, 6), "traffic": traffic, "traffic_source": traffic_src, "mfma_counters": mfma_util,
             "algorithmic_flops_per_launch": round(fl), "avg_launch_us": round(us, 3),
             "flops_per_column": round(fpc.value), "columns_per_launch": round(cols_per_launch, 2),
             "launches_per_ar_run": launches.value, "wavefronts": len(wave_start) - 1, "columns": ncols,
@@ -156,13 +174,54 @@ def measure_roofline(model, d, out, V):
                 "equivalent_tflops": round(11.43095e9 * cols_per_launch / (us * 1e-6) / 1e12, 1)}}
 
 
+def latest_pmc_record(V):
+    """The newest `*_k_column_pmc.json` under profiles/ that profiles/README.md lists for this number of views (the README's
+    last matching line wins), or None -- so that the record follows the kernel instead of naming a file here."""
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    try:
+        with open(os.path.join(root, "README.md")) as fh:
+            names = [w.strip("`*,;()") for line in fh for w in line.split() if w.strip("`*,;()").endswith("_pmc.json")]
+    except OSError:
+        return None
+    for name in reversed(names):
+        path = os.path.join(root, name)
+        if os.path.exists(path):
+            with open(path) as fh:
+                rec = json.load(fh)
+            if rec.get("views") == V:
+                return rec
+    return None
+
+
+def small_batch_config(device, V, cameras, steps=5):
+    """frames/s and the column launch's roofline numbers of a smaller batch (pipelined steps like the headline)."""
+    model = build_model(device)
+    d, _ = make_inputs(0, V, device, cameras=cameras)
+    side = torch.cuda.Stream()
+    out = run_steps(model, d, 1, 2, side)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = run_steps(model, d, 1, steps, side)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    model.outpaint2.engine(32, 32, V).check()
+    r = measure_roofline(model, d, out, V)
+    return {"frames_per_s": round(V / dt, 1), "ms_per_step": round(dt * 1e3, 3), "views": V, "cameras": cameras,
+            "sampled_codes_per_view_mean": round(float(np.mean(out["plan"].n_sampled)), 1),
+            "column_launch": {k: r[k] for k in ("achieved", "frac", "avg_launch_us", "columns_per_launch", "launches_per_ar_run")}}
+
+
 def extra_configs(device):
     """The other single-GPU configurations BASELINE.json names, measured the same way (inputs resident, barrier-free
     single stream, wall clock around synchronised steps): C3 = ONE view end to end (latency-bound: the AR chain
     uses one CU), C2 = batch-32 reprojection + splat only."""
     res = {}
+    # what ONE of eight GPUs does in the 8-GPU form of C5 (1 source x 16 views), and round 1's workload (16 views, demo /
+    # RealEstate10K-shaped cameras): few columns per wavefront -> the latency form of the column launch (k_column)
+    res["C5_one_source_16_views"] = small_batch_config(device, 16, "mp3d")
+    res["RealEstate_shaped_16_views"] = small_batch_config(device, 16, "demo")
     m1 = build_model(device)
-    d1, _ = make_inputs(0, 1, device)
+    d1, _ = make_inputs(0, 1, device, cameras="demo")
     for _ in range(2):
         o1 = run_step(m1, d1, 1)
     torch.cuda.synchronize()
@@ -175,7 +234,7 @@ def extra_configs(device):
     dt = sorted(times)[len(times) // 2]
     res["C3_single_view"] = {"frames_per_s": round(1.0 / dt, 3), "ms_per_frame": round(dt * 1e3, 3),
                              "sampled_codes": int(o1["plan"].n_sampled[0]), "ar_positions_walked": 1024 - o1["plan"].first_step}
-    d32, _ = make_inputs(1, 32, device)
+    d32, _ = make_inputs(1, 32, device, cameras="demo")
     pm = m1.pts_transformer
     call = lambda: pm.forward_justpts(d32["img"], d32["depth"], d32["K"], d32["Kinv"], d32["P"], d32["Pinv"], d32["RT2"], d32["RT2inv"])
     for _ in range(3):
@@ -236,7 +295,7 @@ def extra_configs(device):
     vq = VQVAETop().eval()
     vq.load_state_dict({k: torch.from_numpy(v) for k, v in syn.vqvae_state_dict(0).items()})
     vq = vq.to(device)
-    d16, _ = make_inputs(2, 16, device)
+    d16, _ = make_inputs(2, 16, device, cameras="demo")
     gen16 = pm.forward_justpts(d16["img"], d16["depth"], d16["K"], d16["Kinv"], d16["P"], d16["Pinv"], d16["RT2"], d16["RT2inv"])[0]
     timings = {}
     for name, fn in (("encode_codes", lambda: vq.encode_codes(gen16)), ("decode_code", lambda: vq.decode_code(d16["codes"]))):
@@ -309,7 +368,7 @@ def cpu_baseline(host, out, V, budget_s=20.0):
     fp32 network forward per sampled code, models/lmconv/sample.py:54-57) extrapolated to the view's
     number of sampled codes."""
     from oracle import c_oracle, lmconv_oracle as lo
-    v = V - 1  # the +0.6 rad view (largest outpainting region of the sweep)
+    v = min(V, VIEWS_PER_SOURCE) - 1  # the +0.6 rad view of the first source (largest outpainting region of its sweep)
     t0 = time.perf_counter()
     cam = {k: a[v:v + 1] for k, a in host["cam"].items()}
     sampler = c_oracle.project_pts(host["depth"][v:v + 1], cam["K"], cam["Kinv"], cam["Pinv"], host["RT2"][v:v + 1], 256)
@@ -348,7 +407,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--views", type=int, default=16, help="independent novel views per GPU per step")
+    ap.add_argument("--views", type=int, default=128, help="independent novel views per GPU per step (128 = C5: 8 sources x 16 views)")
+    ap.add_argument("--cameras", choices=["mp3d", "demo"], default="mp3d", help="Matterport-shaped (C5) or demo / RealEstate10K-shaped inputs")
     ap.add_argument("--depth", choices=["smooth", "uniform"], default="smooth")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the C3 single-view / C2 splat-only side measurements")
@@ -378,7 +438,7 @@ def main():
 
     V = args.views
     model = build_model(device)
-    d, host = make_inputs(rank, V, device, smooth=args.depth == "smooth")
+    d, host = make_inputs(rank, V, device, smooth=args.depth == "smooth", cameras=args.cameras)
     def barrier():
         D.barrier()
         torch.cuda.synchronize()
@@ -401,10 +461,14 @@ def main():
             "value": round(frames / elapsed, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": (f"C5 per-GPU shard (= C3 batched): 1 source x {V} independent novel views per GPU per step "
-                                    "(yaw sweep +-0.6 rad, demo cameras, 256x256 RGB features, "
-                                    f"{args.depth} depth 1..100, K=128 r=4 alphacomposite splat, 13x13 mask dilation, "
+            "config": {"workload": (f"C5 on every GPU: {host['n_src']} source image(s) x {-(-V // host['n_src'])} independent novel views = {V} views per "
+                                    f"GPU per step (yaw sweep +-0.6 rad per source, "
+                                    + ("Matterport-shaped cameras K = diag(1/tan(hfov/2)) at hfov 90 deg, " if args.cameras == "mp3d"
+                                       else "demo / RealEstate10K-shaped cameras, ")
+                                    + f"256x256 RGB features, {args.depth} depth {'0.5..10' if args.cameras == 'mp3d' else '1..100'}, "
+                                    "K=128 r=4 alphacomposite splat, 13x13 mask dilation, "
                                     "custom generation order, exact incremental AR over the 32x32 code grid, T=0.7)"),
+                       "sources_per_gpu": host["n_src"],
                        "views_per_gpu": V, "image": "256x256", "code_grid": "32x32", "num_classes": 512,
                        "ar_steps_walked": 1024 - plan.first_step,
                        "sampled_codes_per_view_mean": round(float(np.mean(plan.n_sampled)), 1),

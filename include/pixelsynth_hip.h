@@ -113,6 +113,14 @@ int ps_kernel_masks_f32(const int32_t *order, int L, int nrows, int ncols, int k
  *   first_step: smallest order position that is sampled in any image (L if none). */
 int ps_ar_plan(const uint8_t *bg, int B, int S, int G, int32_t *order_loc, uint8_t *region,
                float *mask_init, float *mask_undilated, float *mask_dilated, int32_t *first_step);
+/* (the three mask pointers may all be NULL: callers that keep the plan on the device build the masks there, below) */
+
+/* The three kernel masks of ps_ar_plan / ps_kernel_masks_f32 on the DEVICE, from generation orders that are already there:
+ * order_loc (F,L) int32 device -> mask_init / mask_undilated / mask_dilated (F,9,L) f32 device (type A dil 1, type B dil 1,
+ * type B dil 2; masking.py:287-370).  Saves the 27 floats per location a host-built plan sends over PCIe (14 MB at 128
+ * views); asynchronous on `stream`. */
+int ps_order_masks_f32(const int32_t *order_loc, int F, int H, int W, float *mask_init, float *mask_undilated,
+                       float *mask_dilated, void *stream);
 
 /* Wavefront schedule of an AR run (host).  In the exact incremental form of sample() (models/lmconv/sample.py:24-66)
  * the column of order position i of a frame reads only the finished columns of locations that are a 3x3 tap neighbour

@@ -25,6 +25,7 @@ _PROTOS = {
                                                       c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "ps_generation_order": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "ps_ar_plan": (c_int, [c_void_p, c_int, c_int, c_int] + [c_void_p] * 6),
+    "ps_order_masks_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ps_custom_order": (c_int, [c_int, c_int, c_void_p, c_void_p]),
     "ps_kernel_masks_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "ps_lmconv_workspace_bytes": (c_size_t, [c_int] * 5),

@@ -127,10 +127,12 @@ int ps_kernel_masks_f32(const int32_t *order, int L, int nrows, int ncols, int k
 int ps_ar_plan(const uint8_t *bg, int B, int S, int G, int32_t *order_loc, uint8_t *region, float *mask_init,
                float *mask_undilated, float *mask_dilated, int32_t *first_step)
 {
-    PS_REQUIRE(bg && order_loc && region && mask_init && mask_undilated && mask_dilated, "ar_plan: null pointer");
+    PS_REQUIRE(bg && order_loc && region, "ar_plan: null pointer");
+    PS_REQUIRE((mask_init != nullptr) == (mask_undilated != nullptr) && (mask_init != nullptr) == (mask_dilated != nullptr),
+               "ar_plan: give all three masks or none (ps_order_masks_f32 builds them on the device)");
     PS_REQUIRE(B > 0 && S > 0 && G > 0 && S % G == 0, "ar_plan: bad sizes");
     const int L = G * G;
-    // frames are independent: one worker per frame (up to 16), each with its own scratch; the first failure wins
+    // frames are independent: one worker per frame (up to 64, half the host's cores), each with its own scratch; the first failure wins
     std::vector<int> first_b((size_t)B, L), rc_b((size_t)B, PS_OK);
     std::vector<std::string> msg_b((size_t)B);   // the error channel is thread-local: a worker's message is carried over by hand
     auto one_frame_impl = [&](int b) {
@@ -144,6 +146,7 @@ int ps_ar_plan(const uint8_t *bg, int B, int S, int G, int32_t *order_loc, uint8
             if (reg[ol[i]] && i < first) first = i;
         }
         first_b[b] = first;
+        if (!mask_init) return;
         const size_t mo = (size_t)b * 9 * L;
         if ((rc_b[b] = ps_kernel_masks_f32(order.data(), L, G, G, 3, 1, 0, mask_init + mo))) return;
         if ((rc_b[b] = ps_kernel_masks_f32(order.data(), L, G, G, 3, 1, 1, mask_undilated + mo))) return;
@@ -153,7 +156,8 @@ int ps_ar_plan(const uint8_t *bg, int B, int S, int G, int32_t *order_loc, uint8
         one_frame_impl(b);
         if (rc_b[b]) msg_b[b] = ps::last_error_ref();
     };
-    const int nthreads = std::min(B, 16);
+    const int hw = (int)std::thread::hardware_concurrency();
+    const int nthreads = std::min(B, std::max(1, std::min(64, hw > 0 ? hw / 2 : 16)));   // frames are independent
     if (nthreads <= 1) {
         one_frame(0);
     } else {

@@ -1942,6 +1942,32 @@ __global__ void k_pack_valu_out(const float *wo /*[20][512][4]*/, float *out)
     out[idx] = wo[((size_t)(ch >> 2) * NCLS + o) * 4 + (ch & 3)];
 }
 
+// kernel masks from generation orders, on the device (masking.py:287-370: tap open iff the neighbour precedes the location in
+// the order; centre 0 for type A, 1 for type B).  One block per frame: ranks in LDS, then the 3 x 9 x L mask values.
+__global__ __launch_bounds__(256) void k_order_masks(const int32_t *order_loc, int H, int W, float *m_init, float *m_und, float *m_dil, int *err)
+{
+    extern __shared__ int sRank[];
+    const int L = H * W, f = blockIdx.x;
+    const int32_t *ol = order_loc + (size_t)f * L;
+    for (int k = threadIdx.x; k < L; k += blockDim.x) sRank[k] = -1;
+    __syncthreads();
+    for (int k = threadIdx.x; k < L; k += blockDim.x) {
+        const int q = ol[k];
+        if (q < 0 || q >= L) { *err = 3; continue; }
+        sRank[q] = k;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < 27 * L; k += blockDim.x) {
+        const int kind = k / (9 * L), t = (k / L) % 9, q = k % L;
+        const int dil = kind == 2 ? 2 : 1, r = q / W, c = q - r * W, rr = r + (t / 3 - 1) * dil, cc = c + (t % 3 - 1) * dil;
+        float v;
+        if (t == 4) v = kind == 0 ? 0.0f : 1.0f;
+        else v = (rr >= 0 && rr < H && cc >= 0 && cc < W && sRank[rr * W + cc] >= 0 && sRank[rr * W + cc] < sRank[q]) ? 1.0f : 0.0f;
+        float *dst = kind == 0 ? m_init : kind == 1 ? m_und : m_dil;
+        dst[((size_t)f * 9 + t) * L + q] = v;
+    }
+}
+
 __global__ void k_mask_codes(int32_t *codes, const uint8_t *region, size_t n)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2402,6 +2428,19 @@ int check_handle(ps_pixelcnn *h, int F)
 }  // namespace
 
 extern "C" {
+
+int ps_order_masks_f32(const int32_t *order_loc, int F, int H, int W, float *mask_init, float *mask_undilated, float *mask_dilated,
+                       void *stream)
+{
+    PS_REQUIRE(order_loc && mask_init && mask_undilated && mask_dilated, "order_masks: null pointer");
+    PS_REQUIRE(F > 0 && H > 0 && W > 0 && (size_t)H * W * sizeof(int) <= 64 * 1024, "order_masks: bad sizes");
+    static int *d_err = nullptr;   // (flag for orders that are no permutation; never freed)
+    if (!d_err) { PS_HIP_CHECK(hipMalloc(&d_err, sizeof(int))); PS_HIP_CHECK(hipMemset(d_err, 0, sizeof(int))); }
+    hipLaunchKernelGGL(k_order_masks, dim3(F), dim3(256), (size_t)H * W * sizeof(int), (hipStream_t)stream, order_loc, H, W, mask_init,
+                       mask_undilated, mask_dilated, d_err);
+    PS_LAUNCH_CHECK();
+    return PS_OK;
+}
 
 int ps_pixelcnn_create(const float *const *params, int n_params, int H, int W, int max_frames, ps_pixelcnn **out)
 {

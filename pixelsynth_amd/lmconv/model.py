@@ -299,6 +299,9 @@ COLUMNS_PER_LAUNCH_TP = int(os.environ.get("PS_WAVE_COLS_TP", "1024"))
 TP_MIN_FRAMES = int(os.environ.get("PS_TP_MIN_FRAMES", "24"))
 
 
+_COLS_STAGE = {}
+
+
 def launch_capacity(frames):
     return COLUMNS_PER_LAUNCH_TP if frames >= TP_MIN_FRAMES else COLUMNS_PER_LAUNCH
 
@@ -314,13 +317,20 @@ def wavefronts(order_host, H, W, first_step, device=None, max_cols=None):
         max_cols = launch_capacity(F_)
     nsteps = L - first_step
     n = F_ * nsteps
-    cols = np.empty((max(n, 1), 2), np.int32)
+    cap = 1 << max(10, int(max(n, 1) - 1).bit_length())          # page-locked staging, kept per power-of-two capacity
+    stage = _COLS_STAGE.get(cap) if device is not None else None
+    if device is not None and stage is None:
+        stage = _COLS_STAGE[cap] = torch.empty((cap, 2), dtype=torch.int32, pin_memory=torch.cuda.is_available())
+    cols = stage.numpy() if stage is not None else np.empty((max(n, 1), 2), np.int32)
     wave_start = np.zeros(nsteps + (n + max_cols - 1) // max_cols + 2 if max_cols else nsteps + 1, np.int32)
     nw = ctypes.c_int32(0)
     rc = _lib.lib().ps_ar_wavefronts_capped(_lib.ptr(order_host), F_, H, W, int(first_step), int(max_cols), _lib.ptr(cols),
                                             _lib.ptr(wave_start), ctypes.cast(ctypes.byref(nw), ctypes.c_void_p))
     _lib.check(rc, "ps_ar_wavefronts_capped")
-    cols_t = torch.from_numpy(cols[:n] if n else cols[:0])
     if device is not None:
-        cols_t = cols_t.to(device, non_blocking=True)
+        cols_t = stage[:n].to(device, non_blocking=True)
+        if cols_t.is_cuda:
+            torch.cuda.current_stream().synchronize()             # the staging buffer is free again
+    else:
+        cols_t = torch.from_numpy(cols[:n].copy() if n else cols[:0].copy())
     return cols_t, np.ascontiguousarray(wave_start[:nw.value + 1])
