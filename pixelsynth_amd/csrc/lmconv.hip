@@ -1718,8 +1718,9 @@ __device__ __forceinline__ void chain_role_tp(const TpArgs &a, int tile)
     // this wave's two columns, barrier.  The stage's type fixes Co, NG, the unit list and the post op that follows it
     // (conv_input -> CONVIN with or without nin_skip, conv_out -> GATE, dilated conv -> DIL).
     unsigned cnt_have = 0;
-    auto run_stage = [&](int s, auto TYc, UnitW (&W)[TP_MAXU]) {
+    auto run_stage = [&](int s, auto TYc, auto FIRSTc, UnitW (&W)[TP_MAXU]) {
         constexpr int TY = decltype(TYc)::value;
+        constexpr bool first = decltype(FIRSTc)::value;   // stage 0: its MFMA phase goes ahead of the wait for the neighbour role's first items
         constexpr int kind = TY == TPT_CONVOUT ? PRO_GATE : TY == TPT_DIL ? PRO_DIL : PRO_CONVIN;
         constexpr bool has_skip = TY == TPT_CONVIN_SKIP;
         constexpr int Co = kind == PRO_GATE ? 2 * NF : NF;
@@ -1729,6 +1730,12 @@ __device__ __forceinline__ void chain_role_tp(const TpArgs &a, int tile)
         const StoreCtl sc = store_ctl(1 + s);
         const int nty = li(2 + s, CTL_TP_TYPE);
         const float *nbase = weights_base(2 + s, nty);
+        if (first) {
+#ifdef PS_TP_TRACE_BUILD
+            trace_s = s;
+#endif
+            mfma_units(TYc, W, nty, nbase);
+        }
         wait_counter(cnt_have, s, (unsigned)li(1 + s, CTL_TP_ITEMS));
         cnt_have = counter(min(s + 1, NST - 2));             // looked at a stage later
         TP_STAMP(1);
@@ -1755,7 +1762,7 @@ __device__ __forceinline__ void chain_role_tp(const TpArgs &a, int tile)
 #ifdef PS_TP_TRACE_BUILD
         trace_s = s;
 #endif
-        mfma_units(TYc, W, nty, nbase);
+        if (!first) mfma_units(TYc, W, nty, nbase);
         lds_barrier();
         TP_STAMP(7);
         auto five = [](const float *p, int stride) {
@@ -1777,10 +1784,11 @@ __device__ __forceinline__ void chain_role_tp(const TpArgs &a, int tile)
     auto dispatch_stage = [&](int s, UnitW (&W)[TP_MAXU]) {
         using std::integral_constant;
         const int ty = li(1 + s, CTL_TP_TYPE);
-        if (ty == TPT_CONVOUT) run_stage(s, integral_constant<int, TPT_CONVOUT>{}, W);
-        else if (ty == TPT_CONVIN_SKIP) run_stage(s, integral_constant<int, TPT_CONVIN_SKIP>{}, W);
-        else if (ty == TPT_CONVIN) run_stage(s, integral_constant<int, TPT_CONVIN>{}, W);
-        else run_stage(s, integral_constant<int, TPT_DIL>{}, W);
+        const integral_constant<bool, false> no{};
+        if (ty == TPT_CONVOUT) run_stage(s, integral_constant<int, TPT_CONVOUT>{}, no, W);
+        else if (ty == TPT_CONVIN_SKIP) run_stage(s, integral_constant<int, TPT_CONVIN_SKIP>{}, no, W);
+        else if (ty == TPT_CONVIN) run_stage(s, integral_constant<int, TPT_CONVIN>{}, no, W);
+        else run_stage(s, integral_constant<int, TPT_DIL>{}, no, W);
     };
 
     // ================= u0 = norm_init(u_init): gather over the (earlier) neighbours' codes =================
@@ -1815,7 +1823,8 @@ __device__ __forceinline__ void chain_role_tp(const TpArgs &a, int tile)
     lds_barrier();
 
     // ================= the 32 conv stages =================
-    for (int s = 0; s < NST - 1; ++s) dispatch_stage(s, WA);   // (the last one requests nin_out's record: a dummy, dropped)
+    run_stage(0, std::integral_constant<int, TPT_CONVIN>{}, std::integral_constant<bool, true>{}, WA);   // (stage 0 is a conv_input without nin_skip)
+    for (int s = 1; s < NST - 1; ++s) dispatch_stage(s, WA);   // (the last one requests nin_out's record: a dummy, dropped)
 #undef TP_STAMP
 #undef TP_STAMP2
 
