@@ -412,6 +412,7 @@ def main():
     ap.add_argument("--depth", choices=["smooth", "uniform"], default="smooth")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the C3 single-view / C2 splat-only side measurements")
+    ap.add_argument("--dump-gather", metavar="NPZ", help="rank 0 saves what the last step gathered from all ranks (tests)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -423,7 +424,7 @@ def main():
                              f"--nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port P bench.py --gpus {args.gpus} ...")
     # PS_BENCH_DRYRUN_ONE_GPU=1: every rank uses cuda:0 and the gloo backend -- exercises the multi-rank control
     # flow on a single-GPU box (the numbers of such a run mean nothing)
-    dry = os.environ.get("PS_BENCH_DRYRUN_ONE_GPU") == "1"
+    dry = os.environ.get("PS_BENCH_DRYRUN_ONE_GPU") == "1" or os.environ.get("PS_DRYRUN_ONE_GPU") == "1"
     if dry:
         local = 0
     torch.cuda.set_device(local)
@@ -453,6 +454,8 @@ def main():
     model.outpaint2.engine(32, 32, V).check()  # (outside the timed region) no column launch gave up on an in-launch wait
     elapsed = D.max_over_ranks(dt, None if dry else device)
 
+    if rank == 0 and args.dump_gather and world > 1:
+        np.savez_compressed(args.dump_gather, all_codes=out["all_codes"].cpu().numpy(), all_frames_u8=out["all_frames_u8"].cpu().numpy())
     if rank == 0:
         frames = V * world * args.steps
         plan = out["plan"]

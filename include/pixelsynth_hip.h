@@ -267,6 +267,14 @@ int ps_pixelcnn_time_column_step(ps_pixelcnn *h, const int32_t *codes, const int
                                  float *total_ms, double *flops_per_launch,
                                  double *weight_bytes_per_launch, void *stream);
 
+/* Hard z-buffer scatter of DepthManipulator.project_zbuffer (models/projection/depth_manipulator.py:66-104):
+ * the reference sorts the points by z and assigns  out[b, 0|1, ys, xs] = v0|v1  for all of them at once; with the sequential
+ * semantics of torch's CPU index_put_ the LAST point in sorted order that lands on a pixel stays.  ys / xs (B,N) int32: pixel of
+ * the n-th point in sorted order (inside the image: the reference clamps first), v0 / v1 (B,N) f32 its values; out (B,2,H,W) f32
+ * pre-filled by the caller (the reference's -2); winner (B,H,W) int32 workspace.  z-test = atomic max of the sorted position. */
+int ps_zbuffer_scatter_f32(const int32_t *ys, const int32_t *xs, const float *v0, const float *v1, int B, int N,
+                           int H, int W, float *out, int32_t *winner, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Vector quantisation around the AR loop (VQ-VAE-2 top level, models/vqvae2/vqvae.py) -- SURVEY 8f row 1
  * ------------------------------------------------------------------------------------------- */

@@ -41,6 +41,7 @@ _PROTOS = {
     "ps_ar_wavefronts_capped": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "ps_pixelcnn_status": (c_int, [c_void_p, c_void_p]),
     "ps_pixelcnn_debug_cache": (c_void_p, [c_void_p, c_int, c_int]),
+    "ps_zbuffer_scatter_f32": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p] * 3),
     "ps_vq_nearest_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "ps_vq_embed_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ps_pixelcnn_time_column_step": (c_int, [c_void_p] * 6 + [c_int, c_int, c_int] + [c_void_p] * 5),

@@ -723,4 +723,55 @@ int ps_project_splat_f32(const float *depth, const float *feat, const float *K, 
                       nullptr, nullptr, nullptr, (char *)workspace, p, st);
 }
 
+// ------------------------------------------------------------------------------------------
+// Hard z-buffer of DepthManipulator.project_zbuffer (models/projection/depth_manipulator.py:66-104): the reference sorts
+// the points by z and scatters their source coordinates into the target image with an indexed assignment, so that of
+// several points that land on one pixel the LAST one in sorted order stays (sequential semantics of torch's CPU
+// index_put_).  Here: the z-test is an atomic max on the sorted position per pixel, then every winner writes its values.
+// ys / xs (B,N) int32 pixel of the n-th point in sorted order, v0 / v1 (B,N) its two values; out (B,2,H,W) pre-filled by the
+// caller; winner (B,H,W) int32 workspace.
+// ------------------------------------------------------------------------------------------
+namespace {
+__global__ void k_zb_reset(int32_t *winner, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) winner[i] = -1;
+}
+__global__ void k_zb_test(const int32_t *ys, const int32_t *xs, int B, int N, int H, int W, int32_t *winner, int *bad)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)B * N) return;
+    const int b = (int)(i / N), n = (int)(i - (size_t)b * N), y = ys[i], x = xs[i];
+    if (y < 0 || y >= H || x < 0 || x >= W) { *bad = 1; return; }
+    atomicMax(&winner[((size_t)b * H + y) * W + x], n);
+}
+__global__ void k_zb_write(const int32_t *ys, const int32_t *xs, const float *v0, const float *v1, int B, int N, int H, int W,
+                           const int32_t *winner, float *out)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)B * N) return;
+    const int b = (int)(i / N), n = (int)(i - (size_t)b * N), y = ys[i], x = xs[i];
+    if (y < 0 || y >= H || x < 0 || x >= W) return;
+    if (winner[((size_t)b * H + y) * W + x] != n) return;
+    out[(((size_t)b * 2 + 0) * H + y) * W + x] = v0[i];
+    out[(((size_t)b * 2 + 1) * H + y) * W + x] = v1[i];
+}
+}  // namespace
+
+int ps_zbuffer_scatter_f32(const int32_t *ys, const int32_t *xs, const float *v0, const float *v1, int B, int N, int H, int W,
+                           float *out, int32_t *winner, void *stream)
+{
+    PS_REQUIRE(ys && xs && v0 && v1 && out && winner, "zbuffer_scatter: null pointer");
+    PS_REQUIRE(B > 0 && N > 0 && H > 0 && W > 0, "zbuffer_scatter: bad sizes");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t np = (size_t)B * H * W, nn = (size_t)B * N;
+    static int *d_bad = nullptr;   // (pixels outside the image are a caller error: the reference clamps before it scatters)
+    if (!d_bad) { PS_HIP_CHECK(hipMalloc(&d_bad, sizeof(int))); PS_HIP_CHECK(hipMemset(d_bad, 0, sizeof(int))); }
+    hipLaunchKernelGGL(k_zb_reset, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st, winner, np);
+    hipLaunchKernelGGL(k_zb_test, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, ys, xs, B, N, H, W, winner, d_bad);
+    hipLaunchKernelGGL(k_zb_write, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, ys, xs, v0, v1, B, N, H, W, winner, out);
+    PS_LAUNCH_CHECK();
+    return PS_OK;
+}
+
 }  // extern "C"

@@ -108,7 +108,7 @@ def scene_outputs_to_disk(outputs, directions, num_split, out_dir):
 
 @torch.no_grad()
 def render_pipelined(model, img, depth, cam, chunks, seeds, temperature=0.7):
-    """render_views for several batches of poses, with the host half of batch i + 1 (splat on a side stream, masks back,
+    """render_views for several batches of poses (seeds: per batch, one seed per view), with the host half of batch i + 1 (splat on a side stream, masks back,
     orders / masks / wavefront schedule, uploads) overlapped with the AR run of batch i.  -> list of frames (V_i,3,S,S)."""
     main, side = torch.cuda.current_stream(), torch.cuda.Stream()
 
@@ -123,7 +123,9 @@ def render_pipelined(model, img, depth, cam, chunks, seeds, temperature=0.7):
         if planned is None:
             planned = model.plan_views(*inputs(chunk))
         V = len(chunk)
-        uniforms = torch.rand(V, 1024, generator=torch.Generator(device="cpu").manual_seed(seeds[k])).to(img.device)
+        # the draws of a view are seeded by the VIEW (its index in the trajectory), not by where the sharding put it: a frame is
+        # the same picture on one GPU or eight
+        uniforms = torch.stack([torch.rand(1024, generator=torch.Generator(device="cpu").manual_seed(int(sd))) for sd in seeds[k]]).to(img.device)
         out = model.outpaint_planned(planned, None, temperature=temperature, uniforms=uniforms)
         planned = None
         if k + 1 < len(chunks):
@@ -171,12 +173,20 @@ def main(argv=None):
 
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    # PS_DRYRUN_ONE_GPU=1: every rank uses cuda:0 and the gloo backend -- the multi-rank control flow (sharding, gather, who
+    # writes what) on a single-GPU box
+    dry = os.environ.get("PS_DRYRUN_ONE_GPU") == "1"
+    if dry:
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.distributed.init_process_group("nccl", device_id=device)
+        if dry:
+            torch.distributed.init_process_group("gloo")
+        else:
+            torch.distributed.init_process_group("nccl", device_id=device)
     model = build_model(device, args.pixelcnn, args.vqvae)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
     img = (load_image(args.image) if args.image else torch.from_numpy(syn.image(1000, 1, 3, 256))).to(device)
@@ -197,7 +207,7 @@ def main(argv=None):
     poses = trajectory(model, cam["P"], kind, args.frames)
     mine = D.shard_views(len(poses), rank, world)
     frames = render_pipelined(model, img, depth, cam, [[poses[i] for i in mine[s:s + args.batch]] for s in range(0, len(mine), args.batch)],
-                              seeds=[rank * 1000 + s for s in range(0, len(mine), args.batch)])
+                              seeds=[[1000 + i for i in mine[s:s + args.batch]] for s in range(0, len(mine), args.batch)])
     local_frames = D.to_image_u8(torch.cat(frames)) if frames else torch.empty(0, 3, 256, 256, dtype=torch.uint8, device=device)
     per_rank = (len(poses) + world - 1) // world                         # gather_frames wants equal shards: pad the last round
     if local_frames.shape[0] < per_rank:

@@ -509,10 +509,48 @@ def gen_poses(R):
     print("poses.npz", len(fx))
 
 
+from make_golden_inputs import zbuffer_cases  # noqa: E402  (shared with the tests)
+
+
+def gen_zbuffer(R):
+    """8f row 4: the reference's own DepthManipulator.project_zbuffer (models/projection/depth_manipulator.py:37-104; pure torch),
+    run on ONE CPU thread so that its indexed assignment is sequential (last write per pixel stays).  Stored: the sampler on a
+    strided grid plus checksums of the full tensors, and the projected depth on the strided grid."""
+    import contextlib
+    import io
+    from models.projection.depth_manipulator import DepthManipulator
+    fx = {}
+    nt = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        seeds = {}
+        # torch's sort is not stable, and among 65536 float z values a few are always equal: the order of such a pair changes
+        # the result (the out-of-range flag goes by sorted POSITION).  The fixture defines it: ties in original point order.
+        plain_sort = torch.Tensor.sort
+        torch.Tensor.sort = lambda self, *a, **k: plain_sort(self, *a, **dict(k, stable=True))
+        for name, W, d, cams, RT2 in zbuffer_cases(seeds):
+            dm = DepthManipulator(W)
+            with contextlib.redirect_stdout(io.StringIO()), torch.no_grad():
+                smp, dep = dm.project_zbuffer(t(d), t(cams["K"]), t(cams["Kinv"]), t(cams["Pinv"]), t(RT2))
+            smp, dep = smp.numpy(), dep.numpy()
+            fx[f"{name}_sampler_sub"] = smp[:, :, ::3, ::3].copy()
+            fx[f"{name}_sampler_rowsum"] = smp.astype(np.float64).sum(3)
+            fx[f"{name}_filled"] = np.array([(smp[b, 0] != -2).sum() for b in range(smp.shape[0])])
+            fx[f"{name}_depth_sub"] = dep[:, :, ::5, ::5].copy()
+            fx[f"{name}_RT2"] = RT2
+            fx[f"{name}_seed"] = np.array(0)
+    finally:
+        torch.set_num_threads(nt)
+        torch.Tensor.sort = plain_sort
+    fx["names"] = np.array([c[0] for c in zbuffer_cases()])
+    np.savez_compressed(os.path.join(HERE, "zbuffer.npz"), **fx)
+    print("zbuffer.npz", len(fx), {n: fx[f"{n}_filled"].tolist() for n in fx["names"]})
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     R = _import_reference()
-    which = sys.argv[1:] or ["projection", "orders", "layers", "blocks", "network", "ar", "vqvae", "networks", "poses"]
+    which = sys.argv[1:] or ["projection", "orders", "layers", "blocks", "network", "ar", "vqvae", "networks", "poses", "zbuffer"]
     if "projection" in which:
         gen_projection(R)
     if "orders" in which:
@@ -531,3 +569,5 @@ if __name__ == "__main__":
         gen_networks(R)
     if "poses" in which:
         gen_poses(R)
+    if "zbuffer" in which:
+        gen_zbuffer(R)
