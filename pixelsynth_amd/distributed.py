@@ -60,3 +60,31 @@ def max_over_ranks(seconds, device=None):
 def barrier():
     if dist.is_available() and dist.is_initialized():
         dist.barrier()
+
+
+def owner_of(index, world_size=None):
+    """rank that rendered view / candidate `index` under shard_views' round-robin deal"""
+    if world_size is None:
+        world_size = world()[1]
+    return index % world_size
+
+
+def gather_scores(disc_local, entr_local, n):
+    """Sample ranking across ranks: every rank scored the candidates shard_views(n) gave it -- discriminator score
+    and classifier entropy, two scalars each -- and all ranks need all n of both to apply the rank rule.  One all_gather of a
+    (2, ceil(n / W)) float64 block per rank.  -> (disc (n,), entr (n,)) numpy arrays, by candidate index."""
+    import numpy as np
+    rank, w = world()
+    per = (n + w - 1) // w
+    block = torch.zeros(2, per, dtype=torch.float64)
+    block[0, :len(disc_local)] = torch.as_tensor(list(disc_local), dtype=torch.float64)
+    block[1, :len(entr_local)] = torch.as_tensor(list(entr_local), dtype=torch.float64)
+    if w == 1:
+        return block[0, :n].numpy().copy(), block[1, :n].numpy().copy()
+    if dist.get_backend() != "gloo":
+        block = block.cuda()
+    bufs = [torch.empty_like(block) for _ in range(w)]
+    dist.all_gather(bufs, block)
+    stacked = torch.stack([b.cpu() for b in bufs], 2)            # (2, per, W): candidate k * W + r
+    flat = stacked.reshape(2, -1)[:, :n].numpy()
+    return flat[0].copy(), flat[1].copy()

@@ -131,7 +131,10 @@ class ZbufferModelPts(nn.Module):
             projector = get_decoder(opt)
         self.pts_regressor = pts_regressor
         self.encoder = encoder        # feature encoder when use_rgb_features is off (injected)
-        self.classifier = classifier  # Places365 ResNet-18 of get_best_sample (injected)
+        if classifier is None and max(int(getattr(opt, "num_samples", 1)), 1) > 1:   # z_buffermodel.py:88 (random init until the
+            from .networks import resnet18                                             # Places365 state_dict is loaded, demo.py:233-243)
+            classifier = resnet18(num_classes=365)
+        self.classifier = classifier  # Places365 ResNet-18 of get_best_sample
         if vqvae is None and getattr(opt, "vqvae", False):  # z_buffermodel.py:81-82
             from .vqvae2 import VQVAETop
             vqvae = VQVAETop()
@@ -328,7 +331,8 @@ class ZbufferModelPts(nn.Module):
         im = np.asarray(Image.fromarray(raw).resize((224, 224), Image.BILINEAR), np.float32) / 255.0
         im = (im - np.array([0.485, 0.456, 0.406], np.float32)) / np.array([0.229, 0.224, 0.225], np.float32)
         x = torch.from_numpy(im).permute(2, 0, 1)[None].to(gen_img.device)
-        probs = torch.softmax(self.classifier(x).float().cpu(), 1).squeeze().numpy()
+        with torch.no_grad():
+            probs = torch.softmax(self.classifier(x).float().cpu(), 1).squeeze().numpy()
         probs = np.sort(probs)[::-1]
         return float(-np.sum(probs * np.log(probs)))
 
@@ -338,28 +342,35 @@ class ZbufferModelPts(nn.Module):
         return combined if self.projector is None else self.projector(combined, background_mask)
 
     @torch.no_grad()
-    def get_best_sample(self, plan, codes, background_mask, gen_fs, netD, input_img, uniforms=None):
+    def get_best_sample(self, plan, codes, background_mask, gen_fs, netD, input_img, uniforms=None, shard=False):
         """z_buffermodel.py:244-276 on the fused sampler: num_samples outpaintings of the same view, the best by
         discriminator + entropy rank is kept.  `plan` is the ARPlan of background_mask, `codes` (B,32,32) the VQ-VAE
-        codes of gen_fs.  One sample needs no scorers; more need `netD` and `self.classifier`.
-        uniforms: optional (num_samples,B,L) draws (otherwise torch.Generator seeded i, as sample() reseeds with i)."""
+        codes of gen_fs.  One sample needs no scorers; more need `netD` (pixelsynth_amd.losses.DiscriminatorLoss or the
+        reference's) and `self.classifier`.
+        uniforms: optional (num_samples,B,L) draws (otherwise torch.Generator seeded i, as sample() reseeds with i).
+        shard: under torch.distributed the candidates are dealt over the ranks (candidate i on rank i % W: SURVEY 8e), two
+        scalars per candidate are gathered, every rank applies the rank rule and the owner of the winner broadcasts it."""
+        from . import distributed as D
         n = max(int(getattr(self.opt, "num_samples", 1)), 1)
         if n > 1 and (netD is None or self.classifier is None):
-            raise RuntimeError("num_samples > 1 ranks candidates with the discriminator (netD) and the scene classifier; "
-                               "neither is part of this library -- pass both or use num_samples=1")
+            raise RuntimeError("num_samples > 1 ranks candidates with the discriminator (netD: pixelsynth_amd.losses.DiscriminatorLoss "
+                               "or the reference's) and the scene classifier -- pass netD or use num_samples=1")
         B, G = codes.shape[0], self.obs[1]
         L = G * self.obs[2]
         dev = codes.device
         if uniforms is None:
             uniforms = torch.stack([torch.rand(B, L, generator=torch.Generator(device="cpu").manual_seed(i)) for i in range(n)]).to(dev)
-        # The candidates are independent AR runs of the same view(s): they go through the sampler TOGETHER, as n * B frames
+        rank, world = D.world()
+        mine = D.shard_views(n, rank, world) if (shard and world > 1) else list(range(n))
+        # The candidates are independent AR runs of the same view(s): they go through the sampler TOGETHER, as k * B frames
         # (sample-major) that share the view's order and masks and differ in their draws -- one wavefront schedule, the
-        # launches of one run instead of n runs one after the other (SURVEY 8e: the num_samples candidates are one of
+        # launches of one run instead of k runs one after the other (SURVEY 8e: the num_samples candidates are one of
         # the path's natural parallel axes).
-        per = max(1, min(n, self.sample_batch // max(B, 1)))          # candidates per engine run
-        imgs, disc, entr = [], [], []
-        for s0 in range(0, n, per):
-            k = min(per, n - s0)
+        per = max(1, min(len(mine), self.sample_batch // max(B, 1)))          # candidates per engine run
+        imgs, disc, entr = {}, [], []
+        for s0 in range(0, len(mine), per):
+            idx = mine[s0:s0 + per]
+            k = len(idx)
             rep = lambda t: t.repeat((k,) + (1,) * (t.dim() - 1)).contiguous()
             waves = plan.waves
             if k > 1:
@@ -369,15 +380,23 @@ class ZbufferModelPts(nn.Module):
             eng = self.outpaint2.engine(G, self.obs[2], k * B)
             eng.ar_run(c, rep(plan.order_loc), rep(plan.region), rep(plan.mask_init), rep(plan.mask_undilated),
                        rep(plan.mask_dilated), temperature=self.opt.temperature,
-                       uniforms=uniforms[s0:s0 + k].reshape(k * B, L).contiguous(), first_step=plan.first_step, waves=waves)
+                       uniforms=uniforms[idx].reshape(k * B, L).contiguous(), first_step=plan.first_step, waves=waves)
             eng.check()
-            for j in range(k):
+            for j, i in enumerate(idx):
                 img = self._decode_candidate(gen_fs, background_mask, c[j * B:(j + 1) * B].view(B, G, self.obs[2]))
-                imgs.append(img)
+                imgs[i] = img
                 if n > 1:
                     disc.append(float(netD.run_discriminator_one_step(img, input_img)["D_Fake"].mean().cpu()))
                     entr.append(self._entropy_score(img))
-        return imgs[rank_samples(disc, entr)] if n > 1 else imgs[0]
+        if n == 1:
+            return imgs[0]
+        if len(mine) < n:
+            d_all, e_all = D.gather_scores(disc, entr, n)
+            best = rank_samples(list(d_all), list(e_all))
+            img = imgs[best] if best in imgs else torch.empty_like(next(iter(imgs.values())) if imgs else gen_fs)
+            torch.distributed.broadcast(img, src=D.owner_of(best, world))
+            return img
+        return imgs[rank_samples(disc, entr)]
 
     # ---------------------------------------------------------------- chained trajectories (8f.4)
     def _scene_depth(self, img, batch):

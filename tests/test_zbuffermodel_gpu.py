@@ -266,12 +266,66 @@ def test_get_best_sample_ranks_candidates():
         def run_discriminator_one_step(self, fake, real):
             seen.append(fake)
             return {"D_Fake": fake.mean().reshape(1)}
-    m.classifier = lambda x: torch.cat([x.mean().reshape(1, 1) * k for k in range(1, 11)], 1)
+    class C(torch.nn.Module):   # a stand-in classifier: ten "logits" from the image mean
+        def forward(self, x):
+            return torch.cat([x.mean().reshape(1, 1) * k for k in range(1, 11)], 1)
+    m.classifier = C()
     best = m.get_best_sample(plan, codes, bg, gen_fs, D(), img)
     assert len(seen) == 3 and not torch.equal(seen[0], seen[1])
     disc = [float(s.mean()) for s in seen]
     entr = [m._entropy_score(s) for s in seen]
     assert torch.equal(best, seen[rank_samples(disc, entr)])
+
+
+def test_get_best_sample_runs_end_to_end_with_the_real_scorers():
+    """SURVEY 8f row 3, the quality mode (num_samples > 1) with the scorers of this repository: the multiscale discriminator
+    mirror (weights as in tests/golden/scorers.npz, scores pinned there against the reference's own class) and the ResNet-18
+    the model builds itself, as the reference does (z_buffermodel.py:88).  The kept candidate is the one the reference's rank
+    rule picks from the scores of all candidates; forward_image routes through it."""
+    import argparse
+    from pixelsynth_amd.losses import DiscriminatorLoss
+    from pixelsynth_amd.networks import ResNet18
+    from pixelsynth_amd.z_buffermodel import build_ar_plan, rank_samples
+    torch.manual_seed(0)
+    m = _scene_model(num_samples=4, model_setting="gen_img")
+    assert isinstance(m.classifier, ResNet18)
+    opt = argparse.Namespace(discriminator_losses="pix2pixHD", gan_mode="hinge", norm_D="spectralinstance", ndf=64, output_nc=3,
+                             no_ganFeat_loss=False, isTrain=False, lambda_feat=10.0)
+    netD = DiscriminatorLoss(opt).eval()
+    shapes = {k: tuple(v.shape) for k, v in netD.state_dict().items()}
+    netD.load_state_dict({k: torch.from_numpy(v) for k, v in syn.fill_state_dict(shapes, 9).items()}, strict=True)
+    netD = netD.to(DEV)
+    img = tt(syn.image(31, 1, 3, 256))
+    cam = {k: tt(v) for k, v in syn.demo_cameras(1).items()}
+    RTinv, RT = m.get_rt_from_rot("R", cam["P"])
+    gen_fs, bg = m.pts_transformer.forward_justpts(img, syn.depth_from_image(img), cam["K"], cam["Kinv"], cam["P"],
+                                                   cam["Pinv"], RT, RTinv)
+    plan = build_ar_plan(bg, 32)
+    codes = m.vqvae.encode_codes(gen_fs)
+    seen, disc, entr = [], [], []
+    inner, inner_e = netD.run_discriminator_one_step, m._entropy_score
+
+    def spy(fake, real):            # the scores the model ranks with, as it computed them
+        seen.append(fake.clone())
+        out = inner(fake, real)
+        disc.append(float(out["D_Fake"].mean().cpu()))
+        return out
+
+    def spy_e(g):
+        entr.append(inner_e(g))
+        return entr[-1]
+    netD.run_discriminator_one_step, m._entropy_score = spy, spy_e
+    best = m.get_best_sample(plan, codes, bg, gen_fs, netD, img)
+    assert len(seen) == 4 and all(tuple(s.shape) == (1, 3, 256, 256) for s in seen) and len(entr) == 4
+    assert len(set(np.round(disc, 7))) > 1 and all(np.isfinite(entr))
+    assert torch.equal(best, seen[rank_samples(disc, entr)])
+    for s_, d_ in zip(seen, disc):  # (the convolution library may pick another algorithm on a second call: 1e-4)
+        assert abs(float(inner(s_, img)["D_Fake"].mean()) - d_) < 1e-4
+    seen.clear(); disc.clear(); entr.clear()
+    # the reference-shaped entry point takes the same road (z_buffermodel.py:349)
+    batch = {"images": [img.cpu()], "cameras": [{k: v.cpu() for k, v in cam.items()}], "depths": [syn.depth_from_image(img).cpu()]}
+    _, out = m.forward_image(batch, netD=netD)
+    assert len(seen) == 4 and torch.equal(out["PredImg"], seen[rank_samples(disc, entr)])
 
 
 def test_driver_renders_a_trajectory_and_writes_the_video_layout(tmp_path):
@@ -373,7 +427,10 @@ def test_get_best_sample_batches_the_candidates_without_changing_them():
         def run_discriminator_one_step(self, fake, real):
             seen.append(fake)
             return {"D_Fake": fake.mean().reshape(1)}
-    m.classifier = lambda x: torch.cat([x.mean().reshape(1, 1) * k for k in range(1, 11)], 1)
+    class C(torch.nn.Module):   # a stand-in classifier: ten "logits" from the image mean
+        def forward(self, x):
+            return torch.cat([x.mean().reshape(1, 1) * k for k in range(1, 11)], 1)
+    m.classifier = C()
     m.sample_batch = 3                      # 5 candidates -> engine runs of 3 and 2 frames
     m.get_best_sample(plan, codes, bg, gen_fs, D(), img, uniforms=uni)
     batched = [s.clone() for s in seen]
