@@ -1374,9 +1374,14 @@ __global__ __launch_bounds__(C1_THREADS) void k_column(NbrArgs na, ChainArgs ca)
 //                   at a time; results leave write-through, a per-(stage, tile) counter publishes them.
 // The hand-off (write-through stores -> device-scope counter -> device-scope loads, bounded waits) is the one of k_column.
 // ==========================================================================================
-constexpr int TP_THREADS = 512, TP_WAVES = TP_THREADS / 64, TP_COLS = 16;
+#ifndef PS_TP_WAVES
+#define PS_TP_WAVES 8
+#endif
+constexpr int TP_WAVES = PS_TP_WAVES, TP_THREADS = 64 * TP_WAVES, TP_COLS = 16;   // 8 waves (256 registers per thread) or 16 (128)
+constexpr int TP_NPC = TP_COLS / TP_WAVES;   // columns a wave does the post op of: 2 or 1
 constexpr int TP_MAX_TILES = 64, TP_COL_CAP = TP_MAX_TILES * TP_COLS;   // 1024 columns per launch
-constexpr int TP_MAXU = 7;            // units per wave and stage: ceil(50 / 8)
+constexpr int TP_MAXU = (50 + TP_WAVES - 1) / TP_WAVES;   // units per wave and stage at most: 7 or 4
+constexpr int TP_MINU = (25 + TP_WAVES - 1) / TP_WAVES;   // ... of a 25-unit stage: 4 or 2
 constexpr int XB_LD = 68;             // B-operand layout: dwords per 4-channel group (16 columns x 4 + 4 pad: conflict-free
 constexpr int XB_SIZE = 40 * XB_LD;   //   for the post op's 8-byte writes and for the waves' 16-byte reads)
 constexpr int SP_LD = 5 * 2 * NF + 4; // chain values of one column [j][o] (+ [j][80] of nin_skip): 800 + 4 pad
@@ -1397,7 +1402,7 @@ static_assert(sizeof(NbrWorkTp) == 48, "three 16-byte loads");
 // Stage types of the chain role (what fixes a stage's unit list): conv_input, conv_input + nin_skip, conv_out, dilated conv
 enum { TPT_CONVIN = 0, TPT_CONVIN_SKIP = 1, TPT_CONVOUT = 2, TPT_DIL = 3 };
 __device__ __host__ constexpr int tpt_units(int type) { return type == TPT_CONVIN || type == TPT_DIL ? 25 : 50; }   // (tile, chain) units
-__device__ __host__ constexpr int tpt_nu(int type) { return type == TPT_CONVIN || type == TPT_DIL ? 4 : TP_MAXU; } // per wave, at most
+__device__ __host__ constexpr int tpt_nu(int type) { return type == TPT_CONVIN || type == TPT_DIL ? TP_MINU : TP_MAXU; } // per wave, at most
 __device__ __host__ constexpr int tpt_nh(int type) { return type == TPT_DIL ? 1 : 2; }                              // 16-byte weight loads per unit
 // Unit u of wave w in a stage of a given type, everything that does not depend on the lane: where its B operands sit in the
 // B-operand buffers (floats from sXb; nin_skip's units read sSb = sXb + XB_SIZE), where its chain values go in a column's
@@ -1550,13 +1555,15 @@ __device__ __forceinline__ void chain_role_tp(const TpArgs &a, int tile)
     const bool own = lane < PONO_LANES;
     const int c2 = own ? 2 * lane : 0;
     const f32x2 zero2 = {0.0f, 0.0f};
-    bool pvalid[2];
-    int pcol[2], pfr[2];
-    size_t ploc[2];
-    f32x2 ucur[2] = {zero2, zero2};
+    bool pvalid[TP_NPC];
+    int pcol[TP_NPC], pfr[TP_NPC];
+    size_t ploc[TP_NPC];
+    f32x2 ucur[TP_NPC];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        pcol[k] = wave + 8 * k;
+    for (int k = 0; k < TP_NPC; ++k) ucur[k] = zero2;
+#pragma unroll
+    for (int k = 0; k < TP_NPC; ++k) {
+        pcol[k] = wave + TP_WAVES * k;
         pvalid[k] = pcol[k] < ncl;
         pfr[k] = uni(sC[pcol[k]].f);
         ploc[k] = (size_t)pfr[k] * a.L + uni(sC[pcol[k]].q);
@@ -1583,21 +1590,21 @@ __device__ __forceinline__ void chain_role_tp(const TpArgs &a, int tile)
     auto plain = [](const float *p) { return *PS_GC(f32x2, p); };
     // PONO + finish of BOTH columns of this wave (independent instruction streams, interleaved by the compiler) and the
     // hand-off: next stage's input into the B-operand layout, values to the caches.  KIND / HAS_SKIP are compile-time.
-    auto emit2 = [&](const f32x2 (&y)[2], const f32x2 (&g)[2], const f32x2 (&skip)[2], auto KINDc, auto SKIPc, int in_form, int save_slot,
+    auto emit2 = [&](const f32x2 (&y)[TP_NPC], const f32x2 (&g)[TP_NPC], const f32x2 (&skip)[TP_NPC], auto KINDc, auto SKIPc, int in_form, int save_slot,
                      const StoreCtl &sc) {
         constexpr int kind = decltype(KINDc)::value;
         constexpr bool has_skip = decltype(SKIPc)::value;
-        float mean[2], inv[2];
-        f32x2 d[2];
+        float mean[TP_NPC], inv[TP_NPC];
+        f32x2 d[TP_NPC];
 #pragma unroll
-        for (int k = 0; k < 2; ++k) mean[k] = pono_mean(pono_total(y[k], own));
+        for (int k = 0; k < TP_NPC; ++k) mean[k] = pono_mean(pono_total(y[k], own));
 #pragma unroll
-        for (int k = 0; k < 2; ++k) d[k] = y[k] - mean[k];
+        for (int k = 0; k < TP_NPC; ++k) d[k] = y[k] - mean[k];
 #pragma unroll
-        for (int k = 0; k < 2; ++k) inv[k] = pono_inv(pono_total(d[k] * d[k], own));
+        for (int k = 0; k < TP_NPC; ++k) inv[k] = pono_inv(pono_total(d[k] * d[k], own));
         if (!own) return;
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < TP_NPC; ++k) {
             const f32x2 n = d[k] * inv[k];
             f32x2 out;
             if (kind == PRO_CONVIN) out = post_finish<POST_CONVIN>(n, zero2, skip[k], has_skip, zero2);
@@ -1626,7 +1633,7 @@ __device__ __forceinline__ void chain_role_tp(const TpArgs &a, int tile)
     auto stage_skip_input = [&](int skip_slot) {
         if (skip_slot < 0 || !own) return;
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < TP_NPC; ++k) {
             const int col = pcol[k];
             f32x2 ep, en;
             celu_pair2(*(const f32x2 *)(&sU[skip_slot][col][c2]), ep, en);
@@ -1740,11 +1747,11 @@ __device__ __forceinline__ void chain_role_tp(const TpArgs &a, int tile)
         cnt_have = counter(min(s + 1, NST - 2));             // looked at a stage later
         TP_STAMP(1);
         // operands of this stage's post op: y = ((bias + NA) + centre) + NB (+ gate half, + nin_skip bias); they land under the MFMAs
-        f32x2 ob = plain(pc.bias + c2), obg = zero2, ob2 = zero2, ona[2], onb[2], onag[2], onbg[2];
+        f32x2 ob = plain(pc.bias + c2), obg = zero2, ob2 = zero2, ona[TP_NPC], onb[TP_NPC], onag[TP_NPC], onbg[TP_NPC];
         if (kind == PRO_GATE) obg = plain(pc.bias + NF + c2);
         if (has_skip) ob2 = plain(pc.bias2 + c2);
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < TP_NPC; ++k) {
             const float *nb = a.nbr + (size_t)s * nbr_stage + (size_t)(col0 + (pvalid[k] ? pcol[k] : 0)) * NBR_LD + c2;
 #if PS_TP_EXP == 1
             ona[k] = plain(nb);
@@ -1769,9 +1776,11 @@ __device__ __forceinline__ void chain_role_tp(const TpArgs &a, int tile)
             return chain_total(*(const f32x2 *)p, *(const f32x2 *)(p + stride), *(const f32x2 *)(p + 2 * stride),
                                *(const f32x2 *)(p + 3 * stride), *(const f32x2 *)(p + 4 * stride));
         };
-        f32x2 y[2], g[2] = {zero2, zero2}, skip[2] = {zero2, zero2};
+        f32x2 y[TP_NPC], g[TP_NPC], skip[TP_NPC];
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < TP_NPC; ++k) { g[k] = zero2; skip[k] = zero2; }
+#pragma unroll
+        for (int k = 0; k < TP_NPC; ++k) {
             const float *P = &sP[pcol[k] * SP_LD + c2];
             y[k] = slot_sum2(ob, ona[k], five(P, Co), onb[k]);
             if (kind == PRO_GATE) g[k] = slot_sum2(obg, onag[k], five(P + NF, Co), onbg[k]);
@@ -1796,15 +1805,15 @@ __device__ __forceinline__ void chain_role_tp(const TpArgs &a, int tile)
     {
         const PostCtl pc = post_ctl(0);
         const StoreCtl sc = store_ctl(0);
-        {   // stage 0's weights (conv_input without nin_skip: 4 units x 2 halves)
+        {   // stage 0's weights (conv_input without nin_skip: TP_MINU units x 2 halves)
             const float *b0p = weights_base(1, li(1, CTL_TP_TYPE));
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { WA[u].a0 = *PS_GC(f32x4, b0p + (size_t)(2 * u) * 256); WA[u].a1 = *PS_GC(f32x4, b0p + (size_t)(2 * u + 1) * 256); }
+            for (int u = 0; u < TP_MINU; ++u) { WA[u].a0 = *PS_GC(f32x4, b0p + (size_t)(2 * u) * 256); WA[u].a1 = *PS_GC(f32x4, b0p + (size_t)(2 * u + 1) * 256); }
         }
         cnt_have = counter(0);
-        f32x2 y[2];
+        f32x2 y[TP_NPC];
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < TP_NPC; ++k) {
             const StepCtx &cx = sC[pcol[k]];
             float mA[9];
             int ncode[9], nl[9];
@@ -1816,7 +1825,9 @@ __device__ __forceinline__ void chain_role_tp(const TpArgs &a, int tile)
             for (int tp = 0; tp < 9; ++tp) ncode[tp] = nl[tp] >= 0 ? ncode[tp] : UINIT_CLOSED;
             y[k] = uinit_from_codes<f32x2>(ncode, mA, a.uinit_w, a.uinit_b, c2);
         }
-        const f32x2 z2[2] = {zero2, zero2};
+        f32x2 z2[TP_NPC];
+#pragma unroll
+        for (int k = 0; k < TP_NPC; ++k) z2[k] = zero2;
         emit2(y, z2, z2, std::integral_constant<int, PRO_UINIT>{}, std::integral_constant<bool, false>{}, pc.in_form, pc.save_slot, sc);
         stage_skip_input(sc.skip_slot);
     }
@@ -1847,7 +1858,7 @@ __device__ __forceinline__ void chain_role_tp(const TpArgs &a, int tile)
     }
     lds_barrier();
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < TP_NPC; ++k) {
         if (!pvalid[k]) continue;
         float lg[8];
         const float *Lp = &sP[pcol[k] * SLOG_LD + lane * 8];
@@ -2220,6 +2231,9 @@ int build_stage_table(ps_pixelcnn *h)
     std::vector<StageDesc> st;
     std::vector<NbrWork> work;
     std::vector<NbrWorkTp> work_tp;
+    std::vector<int> tp_items;   // work items per tile of every stage (k_column_tp)
+    int fine_stages = 0;         // PS_TP_FINE_STAGES: tuning (one output tile per item in the first stages: measured no faster)
+    if (const char *cc = getenv("PS_TP_FINE_STAGES")) fine_stages = std::max(0, atoi(cc));
     struct Prev { int pro; const float *bias, *bias2; int has_skip; float *R, *E, *X; int save; } prev;
     prev = Prev{PRO_UINIT, nullptr, nullptr, 0, h->R[0], h->E[0], nullptr, 0};  // u0 is saved in LDS slot 0
     auto push = [&](const float *w, const float *w_skip, const float *in, int in_ld, int NG, int Co, int dil,
@@ -2234,9 +2248,15 @@ int build_stage_table(ps_pixelcnn *h)
         if (has_nbr)
             for (int half = 0; half < 2; ++half)
                 for (int cog = 0; cog < Co / 16; ++cog) work.push_back(NbrWork{w, in, s, half, cog, NG, Co, in_ld, dil, mask_kind});
-        if (has_nbr)   // throughput form: two output tiles per item where the stage has them
+        if (has_nbr) {   // throughput form: two output tiles per item where the stage has them
+            const int step = s < fine_stages ? 16 : 32;
             for (int half = 0; half < 2; ++half)
-                for (int o0 = 0; o0 < Co; o0 += 32) work_tp.push_back(NbrWorkTp{w, in, s, half, o0, o0 + 32 <= Co ? 2 : 1, NG, Co, in_ld, mask_kind - 1});
+                for (int o0 = 0; o0 < Co; o0 += step)
+                    work_tp.push_back(NbrWorkTp{w, in, s, half, o0, (step == 32 && o0 + 32 <= Co) ? 2 : 1, NG, Co, in_ld, mask_kind - 1});
+            tp_items.push_back(2 * ((Co + step - 1) / step));
+        } else {
+            tp_items.push_back(0);
+        }
         // dense algorithmic work per frame of this stage (taps x 2*Co*Cin flops, fp32 weights once)
         const double taps_nbr = has_nbr ? 8.0 : 0.0, cin = NG * 16.0;
         h->flops_nbr += taps_nbr * 2.0 * Co * cin;
@@ -2329,7 +2349,7 @@ int build_stage_table(ps_pixelcnn *h)
             int *c = &ctl[(size_t)(1 + k) * C1_CTL_DWORDS];
             c[CTL_CO] = st[k].Co_pad; c[CTL_NCHAIN] = st[k].nchain; c[CTL_NG] = st[k].NG; c[CTL_NSTEP] = st[k].nstep;
             c[CTL_NBR_ITEMS] = st[k].has_nbr ? 2 * (st[k].Co_pad / 16) : 0;
-            c[CTL_TP_ITEMS] = st[k].has_nbr ? 2 * ((st[k].Co_pad + 31) / 32) : 0;
+            c[CTL_TP_ITEMS] = tp_items[k];
             put_p(1 + k, CTL_WV, st[k].wv);
             // the centre tap (and nin_skip) in the MFMA layout [c/4][o][4]; nin_out's weights are that layout already
             put_p(1 + k, CTL_WC, k == NST - 1 ? st[k].w : st[k].w + (size_t)st[k].center_tap * st[k].NG * 16 * st[k].Co_pad);
