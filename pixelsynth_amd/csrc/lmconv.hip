@@ -2423,9 +2423,12 @@ void run_columns(ps_pixelcnn *h, const StepCtx *rec, int ncols, const int32_t *c
         const int tiles = (n + 15) / 16, nitems = h->nwork * tiles;
         // chain workgroups on XCDs 0 .. cx-1 of the first rows of 8 blocks, neighbour workgroups everywhere else, 256
         // blocks at most (one per CU, all resident)
-        const int cx = h->chain_xcds > 0 ? std::min(8, std::max(h->chain_xcds, (n + 31) / 32)) : std::min(4, (n + 31) / 32);
+        // (the launch holds one workgroup per CU at most: every workgroup is resident, which the in-launch waits rest on;
+        // per_xcd = CUs per XCD of THIS device, 32 on a whole MI355X)
+        const int per_xcd = h->n_cus / 8;
+        const int cx = h->chain_xcds > 0 ? std::min(8, std::max(h->chain_xcds, (n + per_xcd - 1) / per_xcd)) : std::min(4, (n + per_xcd - 1) / per_xcd);
         const int chain_rows = (n + cx - 1) / cx;
-        const int nbr_cus = chain_rows * (8 - cx) + (32 - chain_rows) * 8;
+        const int nbr_cus = chain_rows * (8 - cx) + (per_xcd - chain_rows) * 8;
         const int groups = h->force_groups ? h->force_groups : (nitems > 2 * nbr_cus ? 4 : 2);
         const int nbr_wgs = std::min(nbr_cus, (nitems + groups - 1) / groups);
         NbrArgs na{h->work, rec + done, h->nbr, h->nwork, h->H, h->W, h->L, n, COL_CAP, tiles, cx, h->cnt, nbr_wgs, groups, ca.debug, h->err};
@@ -2480,17 +2483,24 @@ int ps_pixelcnn_create(const float *const *params, int n_params, int H, int W, i
     for (int i = 0; i < n_params; ++i) PS_REQUIRE(params[i], "pixelcnn_create: tensor %d is null", i);
     ps_pixelcnn *h = new ps_pixelcnn();
     h->H = H; h->W = W; h->L = H * W; h->maxF = max_frames;
-    if (const char *cc = getenv("PS_COL_CAP")) h->col_cap = std::max(1, std::min(COL_CAP, atoi(cc)));
+    {   // device size first: the column launches keep one workgroup per CU, all resident
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+            h->n_cus = cus;
+        if (h->n_cus % 8 != 0 || h->n_cus < 16) {
+            ps::fail(PS_ERR_STATE, "pixelcnn_create: %d compute units -- the column launches lay their workgroups out over 8 XCDs", h->n_cus);
+            delete h;
+            return PS_ERR_STATE;
+        }
+        h->col_cap = std::min(COL_CAP, (h->n_cus / 8) * 4);   // at most four XCDs of chains, the rest for the neighbour role
+    }
+    if (const char *cc = getenv("PS_COL_CAP")) h->col_cap = std::max(1, std::min(h->col_cap, atoi(cc)));
     if (const char *cc = getenv("PS_CHAIN_XCDS")) h->chain_xcds = std::max(0, std::min(8, atoi(cc)));
     if (const char *cc = getenv("PS_NBR_GROUPS")) h->force_groups = std::max(0, std::min(NBR_MAX_GROUPS, atoi(cc)));
     if (const char *cc = getenv("PS_TP_MIN_COLS")) h->tp_min_cols = std::max(1, atoi(cc));
     if (const char *cc = getenv("PS_TP_XCDS")) h->tp_xcds = atoi(cc);
     if (const char *cc = getenv("PS_TP_FILL")) h->tp_fill = atoi(cc);
-    {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
-            h->n_cus = cus;
-    }
+
     int rc = PS_OK;
     auto fail_out = [&](int code) { ps_pixelcnn_destroy(h); return code; };
 
