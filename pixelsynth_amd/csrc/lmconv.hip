@@ -116,21 +116,33 @@ __device__ __forceinline__ void item_loc(const ItemMap &m, int item, int L, int 
     q = m.order ? m.order[(size_t)f * L + r] : r;
 }
 
+constexpr int N_XCD = 8;  // gfx950: 8 XCDs, workgroup ids are dealt round-robin over them
+
 struct GemmArgs {
     GemmTap tap[MAX_TAPS];
     ItemMap items;
     int slot_first[5];  // slot s covers taps [slot_first[s], slot_first[s+1])
     int nslots, Cin, Co_pad, H, W, L, nitems, tiles_per_block;
+    int nx, ny, tpx;    // launch geometry (launch_gemm): channel blocks, item blocks, item blocks per XCD
+    int zgrid;          // slots along the grid (nslots), or 1 = every wave walks all slots
     const float *mask;
     size_t mask_fstride;
     float *partial;  // [nslots][nitems][Co_pad]
 };
 
+// a row of zeros: the input row of a lane whose tap is closed, when every mask value of the wave is 0 or 1 (the
+// reference's masks always are): the closed lanes then LOAD their zeros and the chunk loop carries no mask arithmetic
+// (40 vector instructions per chunk that compete with the MFMAs for issue: tools/mfma_rate_probe.hip, 95 % -> 84 %)
+__device__ float g_zero_row[256];
+
+// grid z -> slot, long slots first: (NA, NB, C, SKIP)
+__device__ __forceinline__ int gemm_slot_of(const GemmArgs &a, int z) { return z == 0 ? SLOT_NA : z == 1 && a.nslots > 2 ? SLOT_NB : z == 2 ? SLOT_C : z; }
+
 // One wave = 16 items x (T x 16) output channels of one slot: the gathered input rows (B operand) are loaded once
 // per 80-channel chunk and reused by the T output tiles, so the kernel is bound by the MFMA pipe rather than by
 // the per-CU L1 fill rate (at T = 1 every 40 MFMAs needed 20 KB of operands).
 template <int T>
-__device__ __forceinline__ void gemm_tiles(const GemmArgs &a, int o0, int slot, int first_tile)
+__device__ __forceinline__ void gemm_tiles(const GemmArgs &a, int o0, int z0, int z1, int first_tile)
 {
     const int lane = threadIdx.x & 63, i = lane & 15, kk = lane >> 4;
     const int ngroups = a.Cin >> 4;
@@ -146,50 +158,90 @@ __device__ __forceinline__ void gemm_tiles(const GemmArgs &a, int o0, int slot, 
             r = q / a.W;
             c = q - r * a.W;
         }
+        for (int z = z0; z < z1; ++z) {
+        const int slot = gemm_slot_of(a, z);
         // slot value = taps of the slot added in order, each tap from fresh accumulators: P_t = chunk_total(acc)
         f32x4 tot[T];
 #pragma unroll
         for (int u = 0; u < T; ++u) tot[u] = zero;
-        for (int t = a.slot_first[slot]; t < a.slot_first[slot + 1]; ++t) {
+        // the mask values of all (at most four) taps of the slot are requested together, before the first tap needs one:
+        // fetched inside the tap loop each is a dependent round trip in front of the tap's operand loads
+        const int t0 = a.slot_first[slot], nt = a.slot_first[slot + 1] - t0;
+        float mvs[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            mvs[k] = 0.0f;
+            if (k < nt) {
+                const GemmTap &tq = a.tap[t0 + k];
+                const int rr = r + tq.dr, cc = c + tq.dc;
+                if (valid && rr >= 0 && rr < a.H && cc >= 0 && cc < a.W)
+                    mvs[k] = tq.mask_row >= 0 ? a.mask[(size_t)f * a.mask_fstride + (size_t)tq.mask_row * a.L + q] : 1.0f;
+            }
+        }
+        for (int t = t0; t < t0 + nt; ++t) {
             const GemmTap tp = a.tap[t];
             // Lanes without a live input row still LOAD (row 0 of the cache, a valid address) and discard: a load under a
             // lane condition compiles to branch / load / s_waitcnt vmcnt(0) per load, i.e. the five input loads of a
             // chunk one round trip after the other (k_gemm: 48.8 -> 43.6 us per launch).
-            const float *src = tp.in + 4 * kk;
-            float mv = 0.0f;
+            const int k = t - t0;
+            const float mv = k == 0 ? mvs[0] : k == 1 ? mvs[1] : k == 2 ? mvs[2] : mvs[3];
             const int rr = r + tp.dr, cc = c + tp.dc;
-            if (valid && rr >= 0 && rr < a.H && cc >= 0 && cc < a.W) {
-                mv = tp.mask_row >= 0 ? a.mask[(size_t)f * a.mask_fstride + (size_t)tp.mask_row * a.L + q] : 1.0f;
-                src = tp.in + ((size_t)f * a.L + rr * a.W + cc) * tp.ld + 4 * kk;
-            }
             const bool live = mv != 0.0f;
             if (!__any(live)) continue;  // a masked tap is an exact zero: skipping it does not change the bits
-            if (!live) src = tp.in + 4 * kk;  // (a masked row is not fetched either)
+            // (a masked row is not fetched either)
+            const bool unit = __all(mv == 0.0f || mv == 1.0f);   // wave-uniform: 0/1 masks need no multiply
+            const float *src = live ? tp.in + ((size_t)f * a.L + rr * a.W + cc) * tp.ld + 4 * kk
+                                    : (unit ? g_zero_row : tp.in) + 4 * kk;
+#ifdef PS_GEMM_EXP_HOTB   // timing experiment only (wrong results): every input row is row 0 -> the B operand always hits L1
+            src = tp.in + 4 * kk;
+#endif
             Acc5 acc[T];
 #pragma unroll
             for (int u = 0; u < T; ++u) acc[u] = acc5_zero();
-            const float *wbase = tp.w + ((size_t)kk * a.Co_pad + o0 + i) * 4;
+            // weights through a buffer descriptor: uniform base + uniform offset in SGPRs, ONE 32-bit lane offset -- the ten
+            // weight loads of a chunk need no per-load 64-bit address registers (19 spilled VGPRs otherwise)
+            const uint32_t woff = (uint32_t)((kk * a.Co_pad + o0 + i) * 16);
+            const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)tp.w, 0, 0x7fffffff, 0x00020000);
+            auto wload = [&](int grp, int u) {
+                return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, woff, (grp * 16 * a.Co_pad + 64 * u) * 4, 0));
+            };
             int g = 0;
             for (; g + 5 <= ngroups; g += 5) {
                 f32x4 bv[5];
 #pragma unroll
+#ifdef PS_GEMM_EXP_NOLOAD
+                for (int j = 0; j < 5; ++j) bv[j] = f32x4{mv, (float)g, (float)j, 1.0f};
+#else
                 for (int j = 0; j < 5; ++j) bv[j] = *(const f32x4 *)(src + 16 * (g + j));
+#endif
+                // (the loads must stay unconditional: left to itself the compiler sinks the last one under `live` and waits
+                // for it with vmcnt(0) -- the B round trip and the A round trip of the chunk then run one after the other)
 #pragma unroll
-                for (int j = 0; j < 5; ++j) bv[j] = live ? bv[j] * mv : zero;
+                for (int j = 0; j < 5; ++j) asm volatile("" : "+v"(bv[j]));
+                if (!unit) {
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) bv[j] = live ? bv[j] * mv : zero;
+                }
 #pragma unroll
                 for (int u = 0; u < T; ++u) {
                     f32x4 av[5];
 #pragma unroll
-                    for (int j = 0; j < 5; ++j) av[j] = *(const f32x4 *)(wbase + (size_t)(g + j) * 16 * a.Co_pad + 64 * u);
+#ifdef PS_GEMM_EXP_NOLOAD   // timing experiment only (wrong results): operands made up in registers, no loads at all
+                    for (int j = 0; j < 5; ++j) { av[j] = bv[j] + (float)(g + u); asm volatile("" : "+v"(av[j])); }
+#elif defined(PS_GEMM_EXP_HOTA)   // timing experiment only (wrong results): five fixed weight vectors -> the A operand always hits L1
+                    for (int j = 0; j < 5; ++j) av[j] = wload(j, 0);
+#else
+                    for (int j = 0; j < 5; ++j) av[j] = wload(g + j, u);
+#endif
                     mfma_chunk5(av, bv, acc[u]);
                 }
             }
             for (; g < ngroups; ++g) {  // ragged channel counts of the generic lmconv entry point only
                 const f32x4 raw = *(const f32x4 *)(src + 16 * g);
-                const f32x4 bv = live ? raw * mv : zero;
+                const f32x4 bv = unit ? raw : live ? raw * mv : zero;
 #pragma unroll
                 for (int u = 0; u < T; ++u) {
-                    const f32x4 av = *(const f32x4 *)(wbase + (size_t)g * 16 * a.Co_pad + 64 * u);
+                    const f32x4 av = wload(g, u);
                     f32x4 &a0 = acc[u].v[0];
                     a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, a0, 0, 0, 0);
                     a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, a0, 0, 0, 0);
@@ -206,6 +258,7 @@ __device__ __forceinline__ void gemm_tiles(const GemmArgs &a, int o0, int slot, 
             for (int u = 0; u < T; ++u)
                 *(f32x4 *)(a.partial + ((size_t)slot * a.nitems + item) * a.Co_pad + o0 + 16 * u + kk * 4) = tot[u];
         }
+        }
     }
 }
 
@@ -218,17 +271,31 @@ __device__ __forceinline__ void gemm_tiles(const GemmArgs &a, int o0, int slot, 
 #define PS_GEMM_T 2
 #endif
 constexpr int GEMM_T = PS_GEMM_T;
-__attribute__((amdgpu_waves_per_eu(4, 4)))
+#if PS_GEMM_T <= 2
+#define PS_GEMM_WAVES 4
+#else
+#define PS_GEMM_WAVES 3
+#endif
+__attribute__((amdgpu_waves_per_eu(PS_GEMM_WAVES, PS_GEMM_WAVES)))
 __global__ __launch_bounds__(64) void k_gemm(GemmArgs a)
 {
-    const int z = blockIdx.z;
-    const int slot = z == 0 ? SLOT_NA : z == 1 && a.nslots > 2 ? SLOT_NB : z == 2 ? SLOT_C : z;  // (NA, NB, C, SKIP)
-    const int o0 = blockIdx.x * 16 * GEMM_T, first_tile = blockIdx.y * a.tiles_per_block;
+    // Workgroup ids go round-robin over the 8 XCDs, each with its own L2.  Every XCD gets a contiguous range of item
+    // blocks with ALL their channel blocks and slots (the waves that gather the same input rows, and the rows of
+    // neighbouring items, meet in one L2) instead of five channel blocks of one tile on five XCDs.
+    const int xcd = blockIdx.x & (N_XCD - 1), j = blockIdx.x >> 3;
+    const int x = j % a.nx, t = (j / a.nx) % a.tpx, z = j / (a.nx * a.tpx);
+    const int y = xcd * a.tpx + t;
+    if (y >= a.ny) return;
+    // zgrid = 1: one wave walks ALL slots of its (tile, channel block) -- the wave's start-up (kernel arguments, order and
+    // mask look-ups: two or three dependent round trips) is paid once per nine or ten taps instead of once per slot, and a
+    // single-tap C / SKIP wave was mostly start-up
+    const int z0 = a.zgrid == 1 ? 0 : z, z1 = a.zgrid == 1 ? a.nslots : z + 1;
+    const int o0 = x * 16 * GEMM_T, first_tile = y * a.tiles_per_block;
     const int T = min(GEMM_T, (a.Co_pad - o0) >> 4);
-    if (GEMM_T >= 4 && T == 4) gemm_tiles<4>(a, o0, slot, first_tile);
-    else if (GEMM_T >= 3 && T == 3) gemm_tiles<3>(a, o0, slot, first_tile);
-    else if (GEMM_T >= 2 && T == 2) gemm_tiles<2>(a, o0, slot, first_tile);
-    else gemm_tiles<1>(a, o0, slot, first_tile);
+    if (GEMM_T >= 4 && T == 4) gemm_tiles<4>(a, o0, z0, z1, first_tile);
+    else if (GEMM_T >= 3 && T == 3) gemm_tiles<3>(a, o0, z0, z1, first_tile);
+    else if (GEMM_T >= 2 && T == 2) gemm_tiles<2>(a, o0, z0, z1, first_tile);
+    else gemm_tiles<1>(a, o0, z0, z1, first_tile);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2161,6 +2228,17 @@ void conv_taps(GemmArgs &a, const float *in, int ld, const float *wp, int Cin, i
     a.slot_first[0] = 0; a.slot_first[1] = 4; a.slot_first[2] = 5; a.slot_first[3] = 9; a.slot_first[4] = 9;
 }
 
+// grid of k_gemm: (channel blocks x item blocks x slots) laid out XCD by XCD, see the kernel
+void launch_gemm(GemmArgs &a, int item_blocks, hipStream_t st)
+{
+    static const bool split = getenv("PS_GEMM_SPLIT_SLOTS") != nullptr;   // tuning: one wave per slot
+    a.nx = (a.Co_pad + 16 * GEMM_T - 1) / (16 * GEMM_T);
+    a.ny = item_blocks;
+    a.tpx = (item_blocks + N_XCD - 1) / N_XCD;
+    a.zgrid = split ? a.nslots : 1;
+    hipLaunchKernelGGL(k_gemm, dim3((unsigned)(N_XCD * a.nx * a.tpx * a.zgrid)), dim3(64), 0, st, a);
+}
+
 // ------------------------------------------------------------------------------------------
 // whole-grid evaluation (reference-faithful forward; cache build before the column steps)
 // logits: null (caches only), (F,512,H,W) when nchw, else (F*L,512) by location
@@ -2177,7 +2255,7 @@ void run_grid(ps_pixelcnn *h, int F, const int32_t *codes, const Masks &m, float
         a.H = h->H; a.W = h->W; a.L = h->L; a.nitems = nitems;
         a.mask = mask; a.mask_fstride = (size_t)9 * h->L; a.partial = h->partial; a.tiles_per_block = 1;
         const int tiles = (nitems + 15) / 16;
-        hipLaunchKernelGGL(k_gemm, dim3((a.Co_pad + 16 * GEMM_T - 1) / (16 * GEMM_T), tiles, a.nslots), dim3(64), 0, st, a);
+        launch_gemm(a, tiles, st);
     };
     {   // u_init + norm_init  (model.py:132)
         UinitArgs u{items, codes, m.init, h->uinit_w, h->uinit_b, h->R[0], h->E[0], h->H, h->W, h->L, nitems};
@@ -2836,7 +2914,7 @@ int ps_lmconv_forward_f32(const float *x, const float *mask, size_t mask_batch_s
     a.H = H; a.W = W; a.L = L; a.nitems = B * L; a.mask = mask; a.mask_fstride = mask_batch_stride;
     a.partial = partial; a.tiles_per_block = 2;
     const int tiles = (a.nitems + 15) / 16;
-    hipLaunchKernelGGL(k_gemm, dim3((Cop + 16 * GEMM_T - 1) / (16 * GEMM_T), (tiles + 1) / 2, a.nslots), dim3(64), 0, st, a);
+    launch_gemm(a, (tiles + 1) / 2, st);
     hipLaunchKernelGGL(k_reduce_nchw, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, st, partial, bias, B, Co, Cop, L, y);
     PS_LAUNCH_CHECK();
     return PS_OK;
