@@ -125,6 +125,8 @@ struct GemmArgs {
     int nslots, Cin, Co_pad, H, W, L, nitems, tiles_per_block;
     int nx, ny, tpx;    // launch geometry (launch_gemm): channel blocks, item blocks, item blocks per XCD
     int zgrid;          // slots along the grid (nslots), or 1 = every wave walks all slots
+    const float *sum_bias;  // zgrid == 1 only: the wave adds its slots up itself, y = ((bias + NA) + C) + NB, and stores y in
+                            // place of slot NA (a third of the partial traffic); null = raw slots
     const float *mask;
     size_t mask_fstride;
     float *partial;  // [nslots][nitems][Co_pad]
@@ -158,8 +160,12 @@ __device__ __forceinline__ void gemm_tiles(const GemmArgs &a, int o0, int z0, in
             r = q / a.W;
             c = q - r * a.W;
         }
+        const bool summing = a.sum_bias != nullptr;   // (then z0 = 0, z1 = nslots, slots in the order of the sum: NA, C, NB, SKIP)
+        f32x4 ysum[T];
+#pragma unroll
+        for (int u = 0; u < T; ++u) ysum[u] = zero;
         for (int z = z0; z < z1; ++z) {
-        const int slot = gemm_slot_of(a, z);
+        const int slot = summing ? z : gemm_slot_of(a, z);
         // slot value = taps of the slot added in order, each tap from fresh accumulators: P_t = chunk_total(acc)
         f32x4 tot[T];
 #pragma unroll
@@ -253,10 +259,19 @@ __device__ __forceinline__ void gemm_tiles(const GemmArgs &a, int o0, int z0, in
             for (int u = 0; u < T; ++u) tot[u] = tot[u] + chunk_total(acc[u]);
         }
         // D: row (output channel) = kk*4 + reg, col (item) = i
-        if (valid) {
+        if (summing && slot != SLOT_SKIP) {
 #pragma unroll
             for (int u = 0; u < T; ++u)
-                *(f32x4 *)(a.partial + ((size_t)slot * a.nitems + item) * a.Co_pad + o0 + 16 * u + kk * 4) = tot[u];
+                ysum[u] = (slot == SLOT_NA ? *(const f32x4 *)(a.sum_bias + o0 + 16 * u + kk * 4) : ysum[u]) + tot[u];
+            if (slot != SLOT_NB) continue;
+#pragma unroll
+            for (int u = 0; u < T; ++u) tot[u] = ysum[u];
+        }
+        if (valid) {
+            const int at = summing && slot == SLOT_NB ? SLOT_NA : slot;
+#pragma unroll
+            for (int u = 0; u < T; ++u)
+                *(f32x4 *)(a.partial + ((size_t)at * a.nitems + item) * a.Co_pad + o0 + 16 * u + kk * 4) = tot[u];
         }
         }
     }
@@ -436,6 +451,7 @@ struct PostArgs {
     ItemMap items;
     const float *partial;  // [slots][nitems][Co_pad]
     int nitems, Co_pad, L, has_skip;
+    int summed;            // slot NA of `partial` already holds y = ((bias + NA) + C) + NB (k_gemm with sum_bias)
     const float *bias, *bias2;
     const float *Rin;
     float *Rout, *Eout, *Xout;
@@ -457,9 +473,11 @@ __global__ __launch_bounds__(256) void k_post_grid(PostArgs a)
     const f32x2 zero = {0.0f, 0.0f};
     auto ld = [](const float *p) { return *(const f32x2 *)p; };
     f32x2 g = zero, skip = zero, rin = zero;
-    const f32x2 y = slot_sum2(ld(a.bias + c), ld(P + SLOT_NA * ss), ld(P + SLOT_C * ss), ld(P + SLOT_NB * ss));
+    const f32x2 y = a.summed ? ld(P + SLOT_NA * ss)
+                             : slot_sum2(ld(a.bias + c), ld(P + SLOT_NA * ss), ld(P + SLOT_C * ss), ld(P + SLOT_NB * ss));
     if (KIND == POST_GATE) {
-        g = slot_sum2(ld(a.bias + NF + c), ld(P + SLOT_NA * ss + NF), ld(P + SLOT_C * ss + NF), ld(P + SLOT_NB * ss + NF));
+        g = a.summed ? ld(P + SLOT_NA * ss + NF)
+                     : slot_sum2(ld(a.bias + NF + c), ld(P + SLOT_NA * ss + NF), ld(P + SLOT_C * ss + NF), ld(P + SLOT_NB * ss + NF));
         rin = ld(a.Rin + loc * R_LD + c);
     }
     if (KIND == POST_CONVIN && a.has_skip) skip = ld(P + SLOT_SKIP * ss) + ld(a.bias2 + c);
@@ -2231,11 +2249,17 @@ void conv_taps(GemmArgs &a, const float *in, int ld, const float *wp, int Cin, i
 // grid of k_gemm: (channel blocks x item blocks x slots) laid out XCD by XCD, see the kernel
 void launch_gemm(GemmArgs &a, int item_blocks, hipStream_t st)
 {
-    static const bool split = getenv("PS_GEMM_SPLIT_SLOTS") != nullptr;   // tuning: one wave per slot
+    const bool split = getenv("PS_GEMM_SPLIT_SLOTS") != nullptr;   // tuning: one wave per slot
     a.nx = (a.Co_pad + 16 * GEMM_T - 1) / (16 * GEMM_T);
     a.ny = item_blocks;
     a.tpx = (item_blocks + N_XCD - 1) / N_XCD;
-    a.zgrid = split ? a.nslots : 1;
+    // one wave per slot while that is what it takes to fill the chip (4096 wave slots): a 16-view prefix is 2870 (tile,
+    // channel block) pairs, one view 180 -- walking all slots in one wave would leave most of the SIMDs idle and make
+    // each wave three times as long
+    const char *mm = getenv("PS_GEMM_MERGE_MIN");   // (read per launch: the parity test switches forms inside one process)
+    const int merge_min = mm ? atoi(mm) : 8192;
+    a.zgrid = split || a.nx * a.ny < merge_min ? a.nslots : 1;
+    if (a.zgrid != 1 || a.nslots < 3) a.sum_bias = nullptr;   // (only a wave that walks NA, C and NB can add them up)
     hipLaunchKernelGGL(k_gemm, dim3((unsigned)(N_XCD * a.nx * a.tpx * a.zgrid)), dim3(64), 0, st, a);
 }
 
@@ -2250,12 +2274,14 @@ void run_grid(ps_pixelcnn *h, int F, const int32_t *codes, const Masks &m, float
     const int nitems = F * items.npre;
     if (nitems <= 0) return;  // an AR run that starts at rank 0 has no prefix
     const int pblocks = (nitems + 3) / 4;
-    auto gemm = [&](GemmArgs &a, const float *mask) {
+    auto gemm = [&](GemmArgs &a, const float *mask, const float *sum_bias = nullptr) {   // -> slots summed by the kernel?
         a.items = items;
         a.H = h->H; a.W = h->W; a.L = h->L; a.nitems = nitems;
         a.mask = mask; a.mask_fstride = (size_t)9 * h->L; a.partial = h->partial; a.tiles_per_block = 1;
+        a.sum_bias = sum_bias;
         const int tiles = (nitems + 15) / 16;
         launch_gemm(a, tiles, st);
+        return a.sum_bias != nullptr ? 1 : 0;
     };
     {   // u_init + norm_init  (model.py:132)
         UinitArgs u{items, codes, m.init, h->uinit_w, h->uinit_b, h->R[0], h->E[0], h->H, h->W, h->L, nitems};
@@ -2270,13 +2296,13 @@ void run_grid(ps_pixelcnn *h, int F, const int32_t *codes, const Masks &m, float
             a.slot_first[4] = 10;
             a.nslots = 4;
         }
-        gemm(a, m.und);
-        PostArgs p{items, h->partial, nitems, NF, h->L, G.node_skip >= 0, G.b_in, G.b_skip, nullptr, nullptr, nullptr, h->X[g]};
+        const int sa = gemm(a, m.und, G.b_in);
+        PostArgs p{items, h->partial, nitems, NF, h->L, G.node_skip >= 0, sa, G.b_in, G.b_skip, nullptr, nullptr, nullptr, h->X[g]};
         hipLaunchKernelGGL(k_post_grid<POST_CONVIN>, dim3(pblocks), dim3(256), 0, st, p);
         GemmArgs b{};
         conv_taps(b, h->X[g], 2 * NF, G.w_out, 2 * NF, 2 * NF, 1);                     // conv_out   (layers.py:159)
-        gemm(b, m.und);
-        PostArgs q{items, h->partial, nitems, 2 * NF, h->L, 0, G.b_out, nullptr, h->R[G.node_in], h->R[G.node_out],
+        const int sb = gemm(b, m.und, G.b_out);
+        PostArgs q{items, h->partial, nitems, 2 * NF, h->L, 0, sb, G.b_out, nullptr, h->R[G.node_in], h->R[G.node_out],
                    h->E[G.node_out], nullptr};
         hipLaunchKernelGGL(k_post_grid<POST_GATE>, dim3(pblocks), dim3(256), 0, st, q);   // gate + residual (:160-163)
     };
@@ -2284,8 +2310,8 @@ void run_grid(ps_pixelcnn *h, int F, const int32_t *codes, const Masks &m, float
         const ps_pixelcnn::Dil &D = h->dil[d];
         GemmArgs a{};
         conv_taps(a, h->R[D.node_in], R_LD, D.w, NF, NF, 2);                            // model.py:138,148
-        gemm(a, m.dil);
-        PostArgs p{items, h->partial, nitems, NF, h->L, 0, D.b, nullptr, nullptr, h->R[D.node_out], h->E[D.node_out], nullptr};
+        const int sa = gemm(a, m.dil, D.b);
+        PostArgs p{items, h->partial, nitems, NF, h->L, 0, sa, D.b, nullptr, nullptr, h->R[D.node_out], h->E[D.node_out], nullptr};
         hipLaunchKernelGGL(k_post_grid<POST_DIL>, dim3(pblocks), dim3(256), 0, st, p);
     };
     gated(0); gated(1); dilated(0); gated(2); gated(3); dilated(1); gated(4); gated(5);     // up pass

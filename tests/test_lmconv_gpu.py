@@ -68,6 +68,24 @@ def test_lmconv_broadcast_mask_and_no_bias():
     np.testing.assert_allclose(y.numpy(), ref.numpy(), rtol=1e-5, atol=2e-5)
 
 
+def test_lmconv_fractional_mask_values():
+    """Mask values other than 0 / 1 (the reference multiplies the unfolded input by whatever the mask holds,
+    locally_masked_convolution.py:24-27): the kernel's zero-row shortcut for 0/1 masks must not be taken."""
+    from pixelsynth_amd.lmconv.locally_masked_convolution import lmconv_forward
+    rs = np.random.RandomState(3)
+    for ci, co in ((160, 80), (7, 5)):
+        x = rs.randn(2, ci, 8, 8).astype(np.float32)
+        w = (rs.randn(co, ci, 3, 3) * 0.1).astype(np.float32)
+        b = rs.randn(co).astype(np.float32)
+        m = rs.rand(2, 9, 64).astype(np.float32)
+        m[m < 0.3] = 0.0     # closed taps among fractional ones
+        m[0, :, :16] = 1.0   # and one tile whose values are all 0 / 1 next to tiles whose values are not
+        m[0, 4, :16] = 0.0
+        y = lmconv_forward(tt(x), tt(m), tt(w), tt(b), dilation=1).cpu()
+        ref = lo.lmconv(torch.from_numpy(x), torch.from_numpy(m), torch.from_numpy(w), torch.from_numpy(b), dilation=1)
+        np.testing.assert_allclose(y.numpy(), ref.numpy(), rtol=1e-5, atol=5e-5)
+
+
 def test_blocks_vs_reference_golden(golden_dir):
     from pixelsynth_amd.lmconv.layers import PONO, gated_resnet, nin
     from pixelsynth_amd.lmconv.locally_masked_convolution import locally_masked_conv2d
@@ -134,6 +152,32 @@ def test_network_zero_input_and_batch():
         with torch.no_grad():
             ref = lo.pixelcnn_forward(sd, x.view(1, 512, 32, 32), *[torch.from_numpy(m[b:b + 1]) for m in ms])
         np.testing.assert_allclose(logits[b], ref[0].numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_whole_grid_launch_forms_agree_bit_for_bit(monkeypatch):
+    """k_gemm's two launch forms -- one wave per slot with the slots added up by the post op, and one wave walking
+    all slots and adding them up itself (taken from 8192 (tile, channel block) pairs on) -- give identical logits,
+    and both match the torch twin."""
+    net = make_net(4)
+    sd = {k: torch.from_numpy(v) for k, v in syn.pixelcnn_state_dict(4).items()}
+    dmaps = dict(syn.distance_maps())
+    eng = net.engine(32, 32, 2)
+    codes = syn.codes(9, 2).reshape(2, 1024).astype(np.int32)
+    codes[1, 700:] = -1
+    orders = [c_oracle.custom_idx(32, 32, dmaps[n])[0] for n in ("corner", "rand2")]
+    ms = [np.concatenate([c_oracle.unfolded_masks(o, 32, 32, 3, dil, typ) for o in orders]) for dil, typ in
+          ((1, "A"), (1, "B"), (2, "B"))]
+    run = lambda: eng.forward(tt(codes), *[tt(m) for m in ms]).cpu()
+    monkeypatch.setenv("PS_GEMM_MERGE_MIN", "0")
+    merged = run()
+    monkeypatch.setenv("PS_GEMM_MERGE_MIN", "1000000000")
+    split = run()
+    assert torch.equal(merged, split)
+    x = torch.zeros(1, 512, 1024)
+    x[0, codes[0], np.arange(1024)] = 1
+    with torch.no_grad():
+        ref = lo.pixelcnn_forward(sd, x.view(1, 512, 32, 32), *[torch.from_numpy(m[0:1]) for m in ms])
+    np.testing.assert_allclose(merged[0].numpy(), ref[0].numpy(), rtol=1e-4, atol=1e-4)
 
 
 def _ar_setup(fx):
