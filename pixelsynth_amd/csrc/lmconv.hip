@@ -143,8 +143,10 @@ __device__ __forceinline__ int gemm_slot_of(const GemmArgs &a, int z) { return z
 // One wave = 16 items x (T x 16) output channels of one slot: the gathered input rows (B operand) are loaded once
 // per 80-channel chunk and reused by the T output tiles, so the kernel is bound by the MFMA pipe rather than by
 // the per-CU L1 fill rate (at T = 1 every 40 MFMAs needed 20 KB of operands).
+constexpr int SY_LD = 168;   // floats per item of the fused kernel's LDS tile (160 channels + pad: 16-byte rows, 8 banks apart)
 template <int T>
-__device__ __forceinline__ void gemm_tiles(const GemmArgs &a, int o0, int z0, int z1, int first_tile)
+__device__ __forceinline__ void gemm_tiles(const GemmArgs &a, int o0, int z0, int z1, int first_tile, float *sY = nullptr,
+                                           float *sS = nullptr)
 {
     const int lane = threadIdx.x & 63, i = lane & 15, kk = lane >> 4;
     const int ngroups = a.Cin >> 4;
@@ -267,7 +269,11 @@ __device__ __forceinline__ void gemm_tiles(const GemmArgs &a, int o0, int z0, in
 #pragma unroll
             for (int u = 0; u < T; ++u) tot[u] = ysum[u];
         }
-        if (valid) {
+        if (sY) {   // fused stage kernel: y (and the nin_skip slot) stay in the workgroup's LDS tile
+            float *dst = (slot == SLOT_SKIP ? sS : sY) + i * SY_LD + o0 + kk * 4;
+#pragma unroll
+            for (int u = 0; u < T; ++u) *(f32x4 *)(dst + 16 * u) = tot[u];
+        } else if (valid) {
             const int at = summing && slot == SLOT_NB ? SLOT_NA : slot;
 #pragma unroll
             for (int u = 0; u < T; ++u)
@@ -457,19 +463,17 @@ struct PostArgs {
     float *Rout, *Eout, *Xout;
 };
 
-// whole-grid post op: one wave per item, 4 items per 256-thread block
+// post op of one item by one wave.  `P` points at channel pair c of the item's y (raw slots `ss` floats apart unless
+// a.summed), `S` at the same pair of its nin_skip slot.
 template <int KIND>
-__global__ __launch_bounds__(256) void k_post_grid(PostArgs a)
+__device__ __forceinline__ void post_item(const PostArgs &a, int item, int lane, const float *Pbase, size_t ss, const float *Sbase)
 {
-    const int item = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (item >= a.nitems) return;  // whole waves leave together
     int f, q;
     item_loc(a.items, item, a.L, f, q);
     const size_t loc = (size_t)f * a.L + q;
-    const size_t ss = (size_t)a.nitems * a.Co_pad;
     const bool own = lane < PONO_LANES;
     const int c = own ? 2 * lane : 0;
-    const float *P = a.partial + (size_t)item * a.Co_pad + c;
+    const float *P = Pbase + c;
     const f32x2 zero = {0.0f, 0.0f};
     auto ld = [](const float *p) { return *(const f32x2 *)p; };
     f32x2 g = zero, skip = zero, rin = zero;
@@ -480,7 +484,7 @@ __global__ __launch_bounds__(256) void k_post_grid(PostArgs a)
                      : slot_sum2(ld(a.bias + NF + c), ld(P + SLOT_NA * ss + NF), ld(P + SLOT_C * ss + NF), ld(P + SLOT_NB * ss + NF));
         rin = ld(a.Rin + loc * R_LD + c);
     }
-    if (KIND == POST_CONVIN && a.has_skip) skip = ld(P + SLOT_SKIP * ss) + ld(a.bias2 + c);
+    if (KIND == POST_CONVIN && a.has_skip) skip = ld(Sbase + c) + ld(a.bias2 + c);
     const float mean = pono_mean(pono_total(y, own));
     const f32x2 d = y - mean;
     const float inv = pono_inv(pono_total(d * d, own));
@@ -493,6 +497,42 @@ __global__ __launch_bounds__(256) void k_post_grid(PostArgs a)
         *(f32x2 *)(a.Xout + loc * (2 * NF) + NF + c) = en;
     } else {
         store_raw_celu2(a.Rout, a.Eout, loc, c, out);
+    }
+}
+
+// whole-grid post op: one wave per item, 4 items per 256-thread block
+template <int KIND>
+__global__ __launch_bounds__(256) void k_post_grid(PostArgs a)
+{
+    const int item = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (item >= a.nitems) return;  // whole waves leave together
+    const size_t ss = (size_t)a.nitems * a.Co_pad;
+    const float *P = a.partial + (size_t)item * a.Co_pad;
+    post_item<KIND>(a, item, lane, P, ss, P + SLOT_SKIP * ss);
+}
+
+// One stage of the whole-grid pass in ONE kernel: a workgroup = one tile of 16 items, one wave per block of 32 output
+// channels (3 waves for the 80-channel convs, 5 for conv_out); every wave walks all slots of its block (gemm_tiles,
+// summing form), parks y -- and the nin_skip slot -- in LDS, and after one barrier the waves share out the 16 items for
+// the post op.  No partial sums in HBM, no second launch.  Same arithmetic in the same order as k_gemm + k_post_grid.
+template <int KIND>
+__attribute__((amdgpu_waves_per_eu(PS_GEMM_WAVES, PS_GEMM_WAVES)))
+__global__ __launch_bounds__(320) void k_stage_fused(GemmArgs a, PostArgs p)
+{
+    __shared__ __attribute__((aligned(16))) float sY[16 * SY_LD];
+    __shared__ __attribute__((aligned(16))) float sS[KIND == POST_CONVIN ? 16 * SY_LD : 4];
+    const int xcd = blockIdx.x & (N_XCD - 1), t = blockIdx.x >> 3;
+    const int y = xcd * a.tpx + t;   // tile
+    if (t >= a.tpx || y >= a.ny) return;
+    const int x = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    const int o0 = x * 32;
+    if (a.Co_pad - o0 >= 32) gemm_tiles<2>(a, o0, 0, a.nslots, y, sY, sS);
+    else gemm_tiles<1>(a, o0, 0, a.nslots, y, sY, sS);
+    __syncthreads();
+    for (int it = x; it < 16; it += nw) {
+        const int item = y * 16 + it;
+        if (item >= a.nitems) break;
+        post_item<KIND>(p, item, lane, sY + it * SY_LD, 0, sS + it * SY_LD);
     }
 }
 
@@ -2283,6 +2323,26 @@ void run_grid(ps_pixelcnn *h, int F, const int32_t *codes, const Masks &m, float
         launch_gemm(a, tiles, st);
         return a.sum_bias != nullptr ? 1 : 0;
     };
+    // PS_GEMM_FUSE=1: one launch per stage (k_stage_fused: products + post op, no partial sums in HBM).  Bit-identical
+    // (tested) but measured SLOWER than k_gemm + k_post_grid at 128 frames -- conv_out 488 us against 347 + 29, conv_in 241
+    // against 175 + 17: the five waves of a workgroup wait for each other and the matrix pipes idle under the post op --
+    // so it is not the default.  (Read per call: the parity test switches forms inside one process.)
+    const int tiles_all = (nitems + 15) / 16;
+    const bool fused = getenv("PS_GEMM_FUSE") != nullptr;
+    auto stage = [&](GemmArgs &a, const float *mask, PostArgs &p, int kind) {   // -> true when the post op is done too
+        if (!fused) return false;
+        a.items = items;
+        a.H = h->H; a.W = h->W; a.L = h->L; a.nitems = nitems;
+        a.mask = mask; a.mask_fstride = (size_t)9 * h->L; a.partial = nullptr; a.tiles_per_block = 1;
+        a.sum_bias = p.bias;
+        a.nx = (a.Co_pad + 31) / 32; a.ny = tiles_all; a.tpx = (tiles_all + N_XCD - 1) / N_XCD; a.zgrid = 1;
+        p.summed = 1;
+        const dim3 grid((unsigned)(N_XCD * a.tpx)), block(64 * a.nx);
+        if (kind == POST_CONVIN) hipLaunchKernelGGL(k_stage_fused<POST_CONVIN>, grid, block, 0, st, a, p);
+        else if (kind == POST_GATE) hipLaunchKernelGGL(k_stage_fused<POST_GATE>, grid, block, 0, st, a, p);
+        else hipLaunchKernelGGL(k_stage_fused<POST_DIL>, grid, block, 0, st, a, p);
+        return true;
+    };
     {   // u_init + norm_init  (model.py:132)
         UinitArgs u{items, codes, m.init, h->uinit_w, h->uinit_b, h->R[0], h->E[0], h->H, h->W, h->L, nitems};
         hipLaunchKernelGGL(k_uinit_grid, dim3(pblocks), dim3(256), 0, st, u);
@@ -2296,23 +2356,29 @@ void run_grid(ps_pixelcnn *h, int F, const int32_t *codes, const Masks &m, float
             a.slot_first[4] = 10;
             a.nslots = 4;
         }
-        const int sa = gemm(a, m.und, G.b_in);
-        PostArgs p{items, h->partial, nitems, NF, h->L, G.node_skip >= 0, sa, G.b_in, G.b_skip, nullptr, nullptr, nullptr, h->X[g]};
-        hipLaunchKernelGGL(k_post_grid<POST_CONVIN>, dim3(pblocks), dim3(256), 0, st, p);
+        PostArgs p{items, h->partial, nitems, NF, h->L, G.node_skip >= 0, 0, G.b_in, G.b_skip, nullptr, nullptr, nullptr, h->X[g]};
+        if (!stage(a, m.und, p, POST_CONVIN)) {
+            p.summed = gemm(a, m.und, G.b_in);
+            hipLaunchKernelGGL(k_post_grid<POST_CONVIN>, dim3(pblocks), dim3(256), 0, st, p);
+        }
         GemmArgs b{};
         conv_taps(b, h->X[g], 2 * NF, G.w_out, 2 * NF, 2 * NF, 1);                     // conv_out   (layers.py:159)
-        const int sb = gemm(b, m.und, G.b_out);
-        PostArgs q{items, h->partial, nitems, 2 * NF, h->L, 0, sb, G.b_out, nullptr, h->R[G.node_in], h->R[G.node_out],
+        PostArgs q{items, h->partial, nitems, 2 * NF, h->L, 0, 0, G.b_out, nullptr, h->R[G.node_in], h->R[G.node_out],
                    h->E[G.node_out], nullptr};
-        hipLaunchKernelGGL(k_post_grid<POST_GATE>, dim3(pblocks), dim3(256), 0, st, q);   // gate + residual (:160-163)
+        if (!stage(b, m.und, q, POST_GATE)) {                                           // gate + residual (:160-163)
+            q.summed = gemm(b, m.und, G.b_out);
+            hipLaunchKernelGGL(k_post_grid<POST_GATE>, dim3(pblocks), dim3(256), 0, st, q);
+        }
     };
     auto dilated = [&](int d) {
         const ps_pixelcnn::Dil &D = h->dil[d];
         GemmArgs a{};
         conv_taps(a, h->R[D.node_in], R_LD, D.w, NF, NF, 2);                            // model.py:138,148
-        const int sa = gemm(a, m.dil, D.b);
-        PostArgs p{items, h->partial, nitems, NF, h->L, 0, sa, D.b, nullptr, nullptr, h->R[D.node_out], h->E[D.node_out], nullptr};
-        hipLaunchKernelGGL(k_post_grid<POST_DIL>, dim3(pblocks), dim3(256), 0, st, p);
+        PostArgs p{items, h->partial, nitems, NF, h->L, 0, 0, D.b, nullptr, nullptr, h->R[D.node_out], h->E[D.node_out], nullptr};
+        if (!stage(a, m.dil, p, POST_DIL)) {
+            p.summed = gemm(a, m.dil, D.b);
+            hipLaunchKernelGGL(k_post_grid<POST_DIL>, dim3(pblocks), dim3(256), 0, st, p);
+        }
     };
     gated(0); gated(1); dilated(0); gated(2); gated(3); dilated(1); gated(4); gated(5);     // up pass
     gated(6); gated(7); dilated(2); gated(8); gated(9); gated(10); dilated(3);              // down pass

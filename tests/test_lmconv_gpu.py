@@ -155,9 +155,9 @@ def test_network_zero_input_and_batch():
 
 
 def test_whole_grid_launch_forms_agree_bit_for_bit(monkeypatch):
-    """k_gemm's two launch forms -- one wave per slot with the slots added up by the post op, and one wave walking
-    all slots and adding them up itself (taken from 8192 (tile, channel block) pairs on) -- give identical logits,
-    and both match the torch twin."""
+    """The launch forms of the whole-grid pass -- one wave per slot with the slots added up by the post op; one wave
+    walking all slots and adding them up itself (taken from 8192 (tile, channel block) pairs on); products and post op
+    fused in one kernel (opt-in) -- give identical logits, and match the torch twin."""
     net = make_net(4)
     sd = {k: torch.from_numpy(v) for k, v in syn.pixelcnn_state_dict(4).items()}
     dmaps = dict(syn.distance_maps())
@@ -173,6 +173,10 @@ def test_whole_grid_launch_forms_agree_bit_for_bit(monkeypatch):
     monkeypatch.setenv("PS_GEMM_MERGE_MIN", "1000000000")
     split = run()
     assert torch.equal(merged, split)
+    monkeypatch.setenv("PS_GEMM_FUSE", "1")          # k_stage_fused: products + post op in one launch (opt-in)
+    fused = run()
+    monkeypatch.delenv("PS_GEMM_FUSE")
+    assert torch.equal(fused, split)
     x = torch.zeros(1, 512, 1024)
     x[0, codes[0], np.arange(1024)] = 1
     with torch.no_grad():
