@@ -292,6 +292,25 @@ int ps_vq_nearest_f32(const float *z, int layout, const float *embed, int N, int
 int ps_vq_embed_f32(const int32_t *idx, const float *embed, int B, int HW, int D, int K, float *out,
                     void *stream);
 
+/* ---- refinement decoder, elementwise passes of a ResNet_Block (models/layers/blocks.py:34-73), channels-last --------
+ * All tensors (B, H, W, C) f32 contiguous (torch channels_last storage), C a multiple of 4.
+ * ps_affine_relu_nhwc_f32: LinearNoiseLayer + stored-statistics batch norm + ReLU (models/layers/normalization.py:21-47,
+ *   :170-184; blocks.py:41-47) as one pass, y = max(x * scale[b][c] - shift[b][c], 0); scale, shift (B, C). */
+int ps_affine_relu_nhwc_f32(const float *x, const float *scale, const float *shift, int B, int HW, int C,
+                            float *y, void *stream);
+/* ps_pool_add_nhwc_f32: blocks.py:61-73 with 'Down': out (B, H/2, W/2, C) = avg_pool2d(a, 3, 2, 1) + avg_pool2d(b, 3, 2, 1)
+ *   (zero padding counted in the divisor, torch's default); b may be NULL.  bias (C) or NULL: a per-channel constant still
+ *   to be added to every INPUT pixel (the bias of the convolutions that produced a and b, which ran without it). */
+int ps_pool_add_nhwc_f32(const float *a, const float *b, const float *bias, int B, int H, int W, int C, float *out,
+                         void *stream);
+/* ps_upsample_add_nhwc_f32: blocks.py:61-73 with 'Up': out (B, 2H, 2W, C) = bilinear x2 (align_corners = False) of a,
+ *   plus the same of b unless b is NULL; bias as above. */
+int ps_upsample_add_nhwc_f32(const float *a, const float *b, const float *bias, int B, int H, int W, int C, float *out,
+                             void *stream);
+/* ps_add_bias_nhwc_f32: the residual sum of a block without resampling, out = a + b + bias[c] (bias may be NULL). */
+int ps_add_bias_nhwc_f32(const float *a, const float *b, const float *bias, int B, int HW, int C, float *out,
+                         void *stream);
+
 #ifdef __cplusplus
 }
 #endif

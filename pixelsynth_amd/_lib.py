@@ -44,6 +44,10 @@ _PROTOS = {
     "ps_zbuffer_scatter_f32": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p] * 3),
     "ps_vq_nearest_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "ps_vq_embed_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "ps_affine_relu_nhwc_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "ps_pool_add_nhwc_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "ps_upsample_add_nhwc_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "ps_add_bias_nhwc_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ps_pixelcnn_time_column_step": (c_int, [c_void_p] * 6 + [c_int, c_int, c_int] + [c_void_p] * 5),
     "ps_pixelcnn_ar_step": (c_int, [c_void_p] * 6 + [c_int, c_int, c_int, c_void_p, c_void_p]),
 }

@@ -21,6 +21,7 @@ UNITS = [
     ("splat.hip", ["-ffp-contract=off"]),
     ("lmconv.hip", ["-ffp-contract=off"]),
     ("vq.hip", ["-ffp-contract=off"]),
+    ("nets.hip", ["-ffp-contract=off"]),
     ("host_order.cpp", []),
 ]
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]

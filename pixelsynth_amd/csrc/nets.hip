@@ -1,0 +1,173 @@
+// nets.hip -- the elementwise passes of the refinement decoder's blocks for gfx950 (MI355X).
+//
+// A ResNet_Block of the reference (models/layers/blocks.py:34-73) is, between its convolutions,
+//   LinearNoiseLayer + stored-statistics batch norm + ReLU   (models/layers/normalization.py:21-47, :117-184)
+//   avg_pool 3x3 / 2  or  bilinear x2 of BOTH branches, then their sum                 (blocks.py:61-73)
+// which torch runs as 2 + 3 full passes over (B, C, H, W) activations per block -- about a third of the decoder's time
+// next to MIOpen's convolutions.  Here each is ONE pass over channels-last (NHWC) memory, 16 bytes per lane:
+//   ps_affine_relu_nhwc_f32      y = max(x * scale[b][c] - shift[b][c], 0)
+//   ps_pool_add_nhwc_f32         out = avg_pool2d(a, 3, 2, 1) + avg_pool2d(b, 3, 2, 1)       (count_include_pad, as torch's default)
+//   ps_upsample_add_nhwc_f32     out = bilinear_x2(a) + bilinear_x2(b)                       (align_corners = False)
+//   ps_add_bias_nhwc_f32         out = a + b + bias[c]
+// (b may be NULL: the resampled branch alone.)  The bias of a convolution is a pass of its own in torch; here the convolutions
+// run without it and the per-channel constant rides along in the pass that consumes their output: folded into `shift` of the
+// next norm (host), or the `bias` argument of the resampling / residual kernels.  The convolutions themselves stay on MIOpen: at 16 views they run at ~70 % of the
+// fp32 matrix peak.
+#include "ps_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// x, y: (B, HW, C) channels-last; scale, shift: (B, C)
+__global__ __launch_bounds__(256) void k_affine_relu(const f32x4 *__restrict__ x, const f32x4 *__restrict__ scale,
+                                                     const f32x4 *__restrict__ shift, size_t per_frame4, int C4, size_t total4,
+                                                     f32x4 *__restrict__ y)
+{
+    const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
+        const size_t b = i / per_frame4;
+        const int c4 = (int)(i % C4);
+        const f32x4 v = x[i] * scale[b * C4 + c4] - shift[b * C4 + c4];
+        y[i] = __builtin_elementwise_max(v, zero);
+    }
+}
+
+// 3x3 window sums of a (and b) around input pixel (2 yo, 2 xo), zero padding, divisor 9
+// `bias` (per channel, may be null) is a constant that belongs to every INPUT pixel of the pooled tensors (the bias of the
+// convolutions that produced them, not yet added): it reaches the output with the share of the window inside the image
+__global__ __launch_bounds__(256) void k_pool_add(const f32x4 *__restrict__ a, const f32x4 *__restrict__ b,
+                                                  const f32x4 *__restrict__ bias, int H, int W, int C4, size_t total4,
+                                                  f32x4 *__restrict__ out)
+{
+    const int Ho = H / 2, Wo = W / 2;
+    const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
+        const int c4 = (int)(i % C4);
+        size_t p = i / C4;
+        const int xo = (int)(p % Wo);
+        p /= Wo;
+        const int yo = (int)(p % Ho);
+        const size_t f = p / Ho;
+        f32x4 sa = zero, sb = zero;
+        int inside = 0;
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int yy = 2 * yo + dy;
+            if (yy < 0 || yy >= H) continue;
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int xx = 2 * xo + dx;
+                if (xx < 0 || xx >= W) continue;
+                const size_t at = ((f * H + yy) * W + xx) * C4 + c4;
+                sa += a[at];
+                if (b) sb += b[at];
+                ++inside;
+            }
+        }
+        const float ninth = 1.0f / 9.0f;
+        f32x4 v = b ? sa * ninth + sb * ninth : sa * ninth;
+        if (bias) v += bias[c4] * ((float)inside * ninth);
+        out[i] = v;
+    }
+}
+
+// bilinear x2, align_corners = False: source coordinate (d + 0.5) / 2 - 0.5, clamped at 0; the two source samples and the
+// weight of the second one
+__device__ __forceinline__ void up_src(int d, int n, int &i0, int &i1, float &w1)
+{
+    const float s = fmaxf((d + 0.5f) * 0.5f - 0.5f, 0.0f);
+    i0 = (int)s;
+    i1 = min(i0 + 1, n - 1);
+    w1 = s - (float)i0;
+}
+
+__global__ __launch_bounds__(256) void k_upsample_add(const f32x4 *__restrict__ a, const f32x4 *__restrict__ b,
+                                                      const f32x4 *__restrict__ bias, int H, int W, int C4, size_t total4,
+                                                      f32x4 *__restrict__ out)
+{
+    const int Ho = 2 * H, Wo = 2 * W;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
+        const int c4 = (int)(i % C4);
+        size_t p = i / C4;
+        const int xo = (int)(p % Wo);
+        p /= Wo;
+        const int yo = (int)(p % Ho);
+        const size_t f = p / Ho;
+        int y0, y1, x0, x1;
+        float wy, wx;
+        up_src(yo, H, y0, y1, wy);
+        up_src(xo, W, x0, x1, wx);
+        const size_t r0 = (f * H + y0) * W, r1 = (f * H + y1) * W;
+        const size_t i00 = (r0 + x0) * C4 + c4, i01 = (r0 + x1) * C4 + c4, i10 = (r1 + x0) * C4 + c4, i11 = (r1 + x1) * C4 + c4;
+        const float w00 = (1.0f - wy) * (1.0f - wx), w01 = (1.0f - wy) * wx, w10 = wy * (1.0f - wx), w11 = wy * wx;
+        f32x4 v = a[i00] * w00 + a[i01] * w01 + a[i10] * w10 + a[i11] * w11;
+        if (b) v += b[i00] * w00 + b[i01] * w01 + b[i10] * w10 + b[i11] * w11;
+        if (bias) v += bias[c4];   // (the interpolation weights add up to one)
+        out[i] = v;
+    }
+}
+
+// out = a + b + bias[c]
+__global__ __launch_bounds__(256) void k_add_bias(const f32x4 *__restrict__ a, const f32x4 *__restrict__ b, const f32x4 *__restrict__ bias,
+                                                  int C4, size_t total4, f32x4 *__restrict__ out)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
+        f32x4 v = a[i] + b[i];
+        if (bias) v += bias[i % C4];
+        out[i] = v;
+    }
+}
+
+unsigned grid_for(size_t total4) { return (unsigned)std::min<size_t>((total4 + 255) / 256, 256 * 32); }
+
+}  // namespace
+
+extern "C" {
+
+int ps_affine_relu_nhwc_f32(const float *x, const float *scale, const float *shift, int B, int HW, int C, float *y, void *stream)
+{
+    PS_REQUIRE(x && scale && shift && y, "affine_relu: null pointer");
+    PS_REQUIRE(B > 0 && HW > 0 && C > 0 && C % 4 == 0, "affine_relu: B, HW > 0 and C a positive multiple of 4 required (C = %d)", C);
+    const size_t per_frame4 = (size_t)HW * (C / 4), total4 = per_frame4 * B;
+    hipLaunchKernelGGL(k_affine_relu, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, (const f32x4 *)x,
+                       (const f32x4 *)scale, (const f32x4 *)shift, per_frame4, C / 4, total4, (f32x4 *)y);
+    PS_LAUNCH_CHECK();
+    return PS_OK;
+}
+
+int ps_pool_add_nhwc_f32(const float *a, const float *b, const float *bias, int B, int H, int W, int C, float *out, void *stream)
+{
+    PS_REQUIRE(a && out, "pool_add: null pointer");
+    PS_REQUIRE(B > 0 && H > 1 && W > 1 && H % 2 == 0 && W % 2 == 0 && C > 0 && C % 4 == 0,
+               "pool_add: even H, W and C a multiple of 4 required (H = %d, W = %d, C = %d)", H, W, C);
+    const size_t total4 = (size_t)B * (H / 2) * (W / 2) * (C / 4);
+    hipLaunchKernelGGL(k_pool_add, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, (const f32x4 *)a, (const f32x4 *)b,
+                       (const f32x4 *)bias, H, W, C / 4, total4, (f32x4 *)out);
+    PS_LAUNCH_CHECK();
+    return PS_OK;
+}
+
+int ps_upsample_add_nhwc_f32(const float *a, const float *b, const float *bias, int B, int H, int W, int C, float *out, void *stream)
+{
+    PS_REQUIRE(a && out, "upsample_add: null pointer");
+    PS_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "upsample_add: C a positive multiple of 4 required (C = %d)", C);
+    const size_t total4 = (size_t)B * (2 * H) * (2 * W) * (C / 4);
+    hipLaunchKernelGGL(k_upsample_add, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, (const f32x4 *)a, (const f32x4 *)b,
+                       (const f32x4 *)bias, H, W, C / 4, total4, (f32x4 *)out);
+    PS_LAUNCH_CHECK();
+    return PS_OK;
+}
+
+int ps_add_bias_nhwc_f32(const float *a, const float *b, const float *bias, int B, int HW, int C, float *out, void *stream)
+{
+    PS_REQUIRE(a && b && out, "add_bias: null pointer");
+    PS_REQUIRE(B > 0 && HW > 0 && C > 0 && C % 4 == 0, "add_bias: C a positive multiple of 4 required (C = %d)", C);
+    const size_t total4 = (size_t)B * HW * (C / 4);
+    hipLaunchKernelGGL(k_add_bias, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, (const f32x4 *)a, (const f32x4 *)b,
+                       (const f32x4 *)bias, C / 4, total4, (f32x4 *)out);
+    PS_LAUNCH_CHECK();
+    return PS_OK;
+}
+
+}  // extern "C"

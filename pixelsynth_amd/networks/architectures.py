@@ -131,6 +131,64 @@ def _nhwc(module, x):
     return x.contiguous(memory_format=torch.channels_last)
 
 
+def _is_nhwc_cuda(*ts):
+    """CUDA fp32 tensors in channels_last storage with C a multiple of 4: what csrc/nets.hip takes."""
+    return all(t is not None and t.is_cuda and t.dtype == torch.float32 and t.dim() == 4 and t.size(1) % 4 == 0
+               and t.is_contiguous(memory_format=torch.channels_last) for t in ts)
+
+
+def _empty_nhwc(B, C, H, W, like):
+    return torch.empty((B, C, H, W), dtype=like.dtype, device=like.device, memory_format=torch.channels_last)
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _conv_split(conv, x):
+    """conv(x) as (output WITHOUT the bias, bias) on the inference GPU path -- torch adds a convolution's bias in a pass
+    of its own; here the per-channel constant rides along in whatever pass consumes the output (csrc/nets.hip).  Elsewhere
+    (CPU, autograd, channel counts the kernels do not take): (conv(x), None)."""
+    if conv.bias is None or torch.is_grad_enabled() or not _is_nhwc_cuda(x) or conv.out_channels % 4:
+        return conv(x), None
+    for hook in conv._forward_pre_hooks.values():   # spectral norm recomputes .weight in a forward pre-hook
+        hook(conv, (x,))
+    return F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups), conv.bias
+
+
+def _sum_bias(*bs):
+    bs = [b for b in bs if b is not None]
+    return None if not bs else bs[0] if len(bs) == 1 else (bs[0] + bs[1]).contiguous()
+
+
+def _resample_sum(kind, a, b, bias=None):
+    """_resample(kind, a + bias) + _resample(kind, b) -- blocks.py:61-73 -- as ONE pass through csrc/nets.hip on the GPU
+    (`bias`: per-channel constant still missing from the inputs, see _conv_split)."""
+    from .. import _lib
+    if not _is_nhwc_cuda(a, b) or a.shape != b.shape or (kind and kind != "Up" and (a.size(2) % 2 or a.size(3) % 2)):
+        if bias is not None:
+            a = a + bias.view(1, -1, 1, 1)
+        return _resample(kind, a) + _resample(kind, b)
+    B, C, H, W = a.shape
+    if not kind:
+        out = torch.empty_like(a)
+        _lib.check(_lib.lib().ps_add_bias_nhwc_f32(a.data_ptr(), b.data_ptr(), _ptr(bias), B, H * W, C, out.data_ptr(), _stream()),
+                   "ps_add_bias_nhwc_f32")
+    elif kind == "Up":
+        out = _empty_nhwc(B, C, 2 * H, 2 * W, a)
+        _lib.check(_lib.lib().ps_upsample_add_nhwc_f32(a.data_ptr(), b.data_ptr(), _ptr(bias), B, H, W, C, out.data_ptr(), _stream()),
+                   "ps_upsample_add_nhwc_f32")
+    else:
+        out = _empty_nhwc(B, C, H // 2, W // 2, a)
+        _lib.check(_lib.lib().ps_pool_add_nhwc_f32(a.data_ptr(), b.data_ptr(), _ptr(bias), B, H, W, C, out.data_ptr(), _stream()),
+                   "ps_pool_add_nhwc_f32")
+    return out
+
+
 def _resample(kind, x):
     if kind == "Up":
         return F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)
@@ -152,15 +210,30 @@ class ResNet_Block(nn.Module):
             self.ch_b = _Slots(_0=_conv(opt, in_c, in_o, 1, 1, 0))
 
     @staticmethod
-    def _noise_affine(layer, x, noise):
+    def _noise_affine(layer, x, noise, bias=None):
+        """norm + ReLU of (x + bias): y = max(x * scale[b][c] - shift[b][c], 0), a pending conv bias folded into shift --
+        one HIP pass on the GPU (ps_affine_relu_nhwc_f32)."""
         scale, shift = layer.affine(x, noise)
-        return torch.clamp_min(torch.addcmul(-shift, x, scale), 0)     # norm + ReLU in one pass
+        if bias is not None:
+            shift = shift - bias.view(1, -1, 1, 1) * scale
+        B, C = x.size(0), x.size(1)
+        if _is_nhwc_cuda(x) and scale.numel() in (C, B * C) and not torch.is_grad_enabled():
+            from .. import _lib
+            sc = scale.reshape(-1, C).expand(B, C).contiguous()
+            sh = shift.reshape(-1, C).expand(B, C).contiguous()
+            y = torch.empty_like(x)   # (preserves channels_last)
+            _lib.check(_lib.lib().ps_affine_relu_nhwc_f32(x.data_ptr(), sc.data_ptr(), sh.data_ptr(), B, x.size(2) * x.size(3), C,
+                                                          y.data_ptr(), _stream()), "ps_affine_relu_nhwc_f32")
+            return y
+        return torch.clamp_min(torch.addcmul(-shift, x, scale), 0)
 
     def forward(self, x, noise=(None, None)):
-        a = self.ch_a[2](self._noise_affine(self.ch_a[0], x, noise[0]))
-        a = self.ch_a[5](self._noise_affine(self.ch_a[3], a, noise[1]))
-        b = self.ch_b[0](x) if self.projected else x
-        return _resample(self.resample, a) + (_resample(self.resample, b) if self.projected else b)
+        a, ba = _conv_split(self.ch_a[2], self._noise_affine(self.ch_a[0], x, noise[0]))
+        a, ba = _conv_split(self.ch_a[5], self._noise_affine(self.ch_a[3], a, noise[1], ba))
+        if not self.projected:
+            return _resample_sum(None, a, x, ba)
+        b, bb = _conv_split(self.ch_b[0], x)
+        return _resample_sum(self.resample, a, b, _sum_bias(ba, bb))
 
 
 class ResNetDecoder(nn.Module):

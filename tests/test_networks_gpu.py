@@ -38,3 +38,49 @@ def test_unet_and_decoder_on_the_gpu_match_the_reference(golden_dir):
     with torch.no_grad():
         both = dec(torch.cat([x, img]), torch.cat([bgm, ~bgm]), noise=[n.expand(2, -1) for n in noise])
     np.testing.assert_allclose(both[0].cpu().numpy(), refined[0].cpu().numpy(), rtol=1e-3, atol=1e-4)
+
+
+def test_block_elementwise_kernels_against_torch():
+    """csrc/nets.hip: the one-pass forms of a ResNet_Block's elementwise work (blocks.py:41-47, :61-73) against the torch
+    ops they replace, on channels-last tensors; the torch ops run on the CPU (the definition), fp32, 1e-6."""
+    from pixelsynth_amd import _lib
+    from pixelsynth_amd.networks.architectures import ResNet_Block, _resample, _resample_sum
+    g = torch.Generator().manual_seed(0)
+    st = torch.cuda.current_stream().cuda_stream
+    for B, C, H, W in ((2, 64, 16, 24), (3, 8, 10, 6), (1, 128, 2, 2)):
+        a = torch.randn(B, C, H, W, generator=g)
+        b = torch.randn(B, C, H, W, generator=g)
+        ad, bd = (t.to(DEV).contiguous(memory_format=torch.channels_last) for t in (a, b))
+        bias = torch.randn(C, generator=g)
+        for kind in ("Down", "Up", None):
+            want = _resample(kind, a) + _resample(kind, b)
+            got = _resample_sum(kind, ad, bd)
+            assert got.is_contiguous(memory_format=torch.channels_last) and got.shape == want.shape
+            np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=1e-6, atol=1e-6, err_msg=f"{kind} {B, C, H, W}")
+            # a convolution bias still missing from the inputs (zero padding of the pooling windows stays zero)
+            want = _resample(kind, a + bias.view(1, -1, 1, 1)) + _resample(kind, b)
+            got = _resample_sum(kind, ad, bd, bias.to(DEV))
+            np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=1e-6, atol=2e-6, err_msg=f"{kind} + bias {B, C, H, W}")
+        # single branch through the C ABI (b = NULL)
+        out = torch.empty((B, C, 2 * H, 2 * W), device=DEV).contiguous(memory_format=torch.channels_last)
+        _lib.check(_lib.lib().ps_upsample_add_nhwc_f32(ad.data_ptr(), None, None, B, H, W, C, out.data_ptr(), st), "upsample")
+        np.testing.assert_allclose(out.cpu().numpy(), _resample("Up", a).numpy(), rtol=1e-6, atol=1e-6)
+        out = torch.empty((B, C, H // 2, W // 2), device=DEV).contiguous(memory_format=torch.channels_last)
+        _lib.check(_lib.lib().ps_pool_add_nhwc_f32(ad.data_ptr(), None, None, B, H, W, C, out.data_ptr(), st), "pool")
+        np.testing.assert_allclose(out.cpu().numpy(), _resample("Down", a).numpy(), rtol=1e-6, atol=1e-6)
+        # norm + ReLU, per-sample and shared (1, C) affine
+        for rows in (B, 1):
+            scale, shift = torch.randn(rows, C, 1, 1, generator=g), torch.randn(rows, C, 1, 1, generator=g)
+            layer = type("L", (), {"affine": staticmethod(lambda x, n, s=scale, h=shift: (s.to(x.device), h.to(x.device)))})
+            with torch.no_grad():
+                got = ResNet_Block._noise_affine(layer, ad, None)
+                want = ResNet_Block._noise_affine(layer, a, None)
+                gotb = ResNet_Block._noise_affine(layer, ad, None, bias.to(DEV))
+                wantb = ResNet_Block._noise_affine(layer, a + bias.view(1, -1, 1, 1), None)
+            np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=1e-6, atol=1e-6)
+            np.testing.assert_allclose(gotb.cpu().numpy(), wantb.numpy(), rtol=1e-5, atol=1e-5)
+    # channel counts the kernels do not take (the 3-channel last block) fall back to torch
+    a3 = torch.randn(1, 3, 4, 4, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    np.testing.assert_allclose(_resample_sum("Up", a3, a3).cpu().numpy(), (2 * _resample("Up", a3)).cpu().numpy(), rtol=1e-6)
+    rc = _lib.lib().ps_pool_add_nhwc_f32(a3.data_ptr(), None, None, 1, 4, 4, 3, a3.data_ptr(), st)
+    assert rc != 0 and b"multiple of 4" in _lib.lib().ps_last_error()
