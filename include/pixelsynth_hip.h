@@ -248,7 +248,9 @@ int ps_pixelcnn_status(ps_pixelcnn *h, void *stream);
 
 /* Debugging aid (tools/tp_debug.py; not part of the reference surface): device address of one of the handle's
  * activation caches -- what 0: raw u of node idx (19 nodes, row stride 96 floats), 1: concat_elu(u) of node idx (160),
- * 2: the activation inside gated resnet idx (14 blocks, 160); rows are frame * L + location.  NULL if out of range. */
+ * 2: the activation inside gated resnet idx (14 blocks, 160); rows are frame * L + location; 5: the (33, F) int32 table of
+ * the last AR run's prefix pass -- first order rank evaluated per stage and frame (oracle/prefix_cone_oracle.py).  NULL if
+ * out of range. */
 void *ps_pixelcnn_debug_cache(ps_pixelcnn *h, int what, int idx);
 
 /* Measurement aid for bench.py (not part of the reference surface): evaluates `reps` order positions

@@ -108,12 +108,21 @@ __device__ __forceinline__ f32x4 chunk_total(const Acc5 &a) { return chain_total
 struct ItemMap {
     const int32_t *order;  // (F, L) location by rank, or null = all L locations in raster order
     int npre;              // locations per frame
+    const int32_t *start;  // (F) or null: ranks below start[f] are NOT evaluated at this stage -- nothing reads them
+                           // (k_prefix_starts); only with an order
 };
 __device__ __forceinline__ void item_loc(const ItemMap &m, int item, int L, int &f, int &q)
 {
     f = item / m.npre;
     const int r = item - f * m.npre;
     q = m.order ? m.order[(size_t)f * L + r] : r;
+}
+// is the item evaluated at this stage?
+__device__ __forceinline__ bool item_wanted(const ItemMap &m, int item)
+{
+    if (!m.start) return true;
+    const int f = item / m.npre;
+    return item - f * m.npre >= m.start[f];
 }
 
 constexpr int N_XCD = 8;  // gfx950: 8 XCDs, workgroup ids are dealt round-robin over them
@@ -155,7 +164,8 @@ __device__ __forceinline__ void gemm_tiles(const GemmArgs &a, int o0, int z0, in
         const int tile = first_tile + tt;
         if (tile * 16 >= a.nitems) break;
         const int item = tile * 16 + i;
-        const bool valid = item < a.nitems;
+        const bool valid = item < a.nitems && item_wanted(a.items, item);
+        if (!__any(valid) && !sY) continue;   // a tile nobody reads at this stage (the fused kernel still needs its barrier)
         int f = 0, r = 0, c = 0, q = 0;
         if (valid) {
             item_loc(a.items, item, a.L, f, q);
@@ -505,7 +515,7 @@ template <int KIND>
 __global__ __launch_bounds__(256) void k_post_grid(PostArgs a)
 {
     const int item = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (item >= a.nitems) return;  // whole waves leave together
+    if (item >= a.nitems || !item_wanted(a.items, item)) return;  // whole waves leave together
     const size_t ss = (size_t)a.nitems * a.Co_pad;
     const float *P = a.partial + (size_t)item * a.Co_pad;
     post_item<KIND>(a, item, lane, P, ss, P + SLOT_SKIP * ss);
@@ -532,8 +542,109 @@ __global__ __launch_bounds__(320) void k_stage_fused(GemmArgs a, PostArgs p)
     for (int it = x; it < 16; it += nw) {
         const int item = y * 16 + it;
         if (item >= a.nitems) break;
+        if (!item_wanted(p.items, item)) continue;
         post_item<KIND>(p, item, lane, sY + it * SY_LD, 0, sS + it * SY_LD);
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// Which prefix items does anybody read?  The whole-grid pass over the observed prefix of an AR run exists for ONE reason:
+// the column steps read the finished activations of earlier neighbours.  A column reads, per stage, the open taps of its
+// location -- so from the prefix only a band along the frontier; those items read their own open taps one stage
+// earlier, and so on backwards through the 32 stages: a dependency cone, not the whole prefix at every stage (63-83 %
+// of the work for PixelSynth's orders).  Because the generation order sweeps towards the frontier, the cone
+// of a stage is -- up to a few items -- a SUFFIX of the prefix in rank order, so it is kept as one number per (stage,
+// frame): the smallest rank anyone reads; items of lower rank are skipped at that stage (their cache rows keep whatever
+// they held; nothing reads them).  The taps come from the kernel masks themselves, exactly what the kernels follow.
+// One workgroup per frame; starts[(stage id) * F + f] with stage ids: 0 u_init, 1 + g conv_input / nin_skip of gated
+// block g, 15 + g its conv_out, 29 + d dilated conv d.
+// ------------------------------------------------------------------------------------------
+constexpr int N_EVAL = 1 + 2 * NGATED + 4;   // 33
+struct StartsArgs {
+    const int32_t *order;   // (F, L)
+    const float *mask_und, *mask_dil;   // (F, 9, L): type B dilation 1 / dilation 2
+    int H, W, L, npre, F;
+    int g_in[NGATED], g_out[NGATED], g_skip[NGATED], d_in[4], d_out[4];
+    int32_t *starts;        // (N_EVAL, F)
+};
+constexpr int STARTS_MAXL = 4096;
+__global__ __launch_bounds__(1024) void k_prefix_starts(StartsArgs a)
+{
+    __shared__ int rank[STARTS_MAXL];   // by location
+    __shared__ int s1[STARTS_MAXL];     // by rank < npre: min rank among the open dilation-1 taps of ranks >= r (suffix minimum)
+    __shared__ int s2[STARTS_MAXL];     //                 the same, dilation-2 taps of the dilated mask
+    __shared__ int cmin[2];             // min rank the COLUMNS (ranks >= npre) read through dilation-1 / dilation-2 taps
+    const int f = blockIdx.x, t = threadIdx.x, L = a.L, npre = a.npre;
+    const int32_t *ord = a.order + (size_t)f * L;
+    for (int r = t; r < L; r += 1024) rank[ord[r]] = r;
+    if (t < 2) cmin[t] = npre;
+    __syncthreads();
+    for (int r = t; r < L; r += 1024) {
+        const int q = ord[r], y = q / a.W, x = q - y * a.W;
+        int m1 = npre, m2 = npre;
+        for (int tap = 0; tap < 9; ++tap) {
+            if (tap == 4) continue;
+            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+            if (a.mask_und[((size_t)f * 9 + tap) * L + q] != 0.0f) {
+                const int yy = y + dy, xx = x + dx;
+                if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) m1 = min(m1, rank[yy * a.W + xx]);
+            }
+            if (a.mask_dil[((size_t)f * 9 + tap) * L + q] != 0.0f) {
+                const int yy = y + 2 * dy, xx = x + 2 * dx;
+                if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) m2 = min(m2, rank[yy * a.W + xx]);
+            }
+        }
+        if (r < npre) { s1[r] = m1; s2[r] = m2; }
+        else { atomicMin(&cmin[0], m1); atomicMin(&cmin[1], m2); }
+    }
+    __syncthreads();
+    for (int off = 1; off < npre; off <<= 1) {   // suffix minima by doubling
+        int v1[STARTS_MAXL / 1024], v2[STARTS_MAXL / 1024];
+#pragma unroll
+        for (int k = 0; k < STARTS_MAXL / 1024; ++k) {
+            const int r = t + 1024 * k;
+            if (r < npre) {
+                v1[k] = r + off < npre ? min(s1[r], s1[r + off]) : s1[r];
+                v2[k] = r + off < npre ? min(s2[r], s2[r + off]) : s2[r];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < STARTS_MAXL / 1024; ++k) {
+            const int r = t + 1024 * k;
+            if (r < npre) { s1[r] = v1[k]; s2[r] = v2[k]; }
+        }
+        __syncthreads();
+    }
+    if (t != 0) return;
+    auto suf = [&](const int *s, int r0) { return r0 >= npre ? npre : min(r0, s[r0]); };   // ranks [r0, npre) and all they read
+    int need[NNODE], needX[NGATED];
+    for (int n = 0; n < NNODE; ++n) need[n] = npre;
+    for (int g = 0; g < NGATED; ++g) { needX[g] = cmin[0]; need[a.g_in[g]] = min(need[a.g_in[g]], cmin[0]); }
+    for (int d = 0; d < 4; ++d) need[a.d_in[d]] = min(need[a.d_in[d]], cmin[1]);
+    // backwards through the stages in execution order (run_grid): G = gated block, D = dilated conv
+    const int kind[18] = {0, 0, 1, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
+    const int idx[18] = {0, 1, 0, 2, 3, 1, 4, 5, 6, 7, 2, 8, 9, 10, 3, 11, 12, 13};
+    int32_t *out = a.starts + f;
+    for (int e = 17; e >= 0; --e) {
+        if (kind[e] == 0) {
+            const int g = idx[e];
+            const int so = need[a.g_out[g]];                     // conv_out + gate evaluated from rank so on
+            out[(size_t)(15 + g) * a.F] = so;
+            needX[g] = min(needX[g], suf(s1, so));               //   reads conv_input's output at its open taps
+            need[a.g_in[g]] = min(need[a.g_in[g]], so);          //   and the residual input at the same location
+            const int si = needX[g];                             // conv_input (+ nin_skip) evaluated from rank si on
+            out[(size_t)(1 + g) * a.F] = si;
+            need[a.g_in[g]] = min(need[a.g_in[g]], suf(s1, si));
+            if (a.g_skip[g] >= 0) need[a.g_skip[g]] = min(need[a.g_skip[g]], si);
+        } else {
+            const int d = idx[e];
+            const int sd = need[a.d_out[d]];
+            out[(size_t)(29 + d) * a.F] = sd;
+            need[a.d_in[d]] = min(need[a.d_in[d]], suf(s2, sd));
+        }
+    }
+    out[0] = need[0];   // u_init + norm_init
 }
 
 struct UinitArgs {
@@ -549,7 +660,7 @@ struct UinitArgs {
 __global__ __launch_bounds__(256) void k_uinit_grid(UinitArgs a)
 {
     const int item = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (item >= a.nitems) return;
+    if (item >= a.nitems || !item_wanted(a.items, item)) return;
     int f, q;
     item_loc(a.items, item, a.L, f, q);
     const size_t loc = (size_t)f * a.L + q;
@@ -2210,6 +2321,7 @@ struct ps_pixelcnn {
     float *nbr = nullptr;           // column mode: neighbour slots [NST][2][COL_CAP][160]
     float *col_logits = nullptr;
     StepCtx *ctx = nullptr;         // column records of a run, [maxF * L]
+    int32_t *pstart = nullptr;      // (N_EVAL, F) first rank of the prefix anyone reads, per stage and frame (k_prefix_starts)
     int *ctl1 = nullptr;            // the same for the chain role (scalar-load records)
     unsigned *cnt = nullptr;        // [NST][MAX_TILES] padded completion counters of the neighbour role, never reset
     int *err = nullptr;             // device flag: a bounded wait of the chain role ran out
@@ -2310,10 +2422,22 @@ void launch_gemm(GemmArgs &a, int item_blocks, hipStream_t st)
 void run_grid(ps_pixelcnn *h, int F, const int32_t *codes, const Masks &m, float *logits, bool nchw, hipStream_t st,
               const int32_t *order = nullptr, int npre = -1)
 {
-    const ItemMap items{order, order ? npre : h->L};
-    const int nitems = F * items.npre;
+    const ItemMap all_items{order, order ? npre : h->L, nullptr};
+    const int nitems = F * all_items.npre;
     if (nitems <= 0) return;  // an AR run that starts at rank 0 has no prefix
     const int pblocks = (nitems + 3) / 4;
+    // the prefix of an AR run: only the items somebody reads, stage by stage (k_prefix_starts).  PS_PREFIX_FULL=1: all of them.
+    // (with out_logits the caller also gets the logits of the prefix locations: every item is needed then.  PS_PREFIX_CONE_FORCE
+    // keeps the elimination on for the parity test, which compares the logits of the WALKED locations only.)
+    const bool cone = order && (!logits || getenv("PS_PREFIX_CONE_FORCE")) && h->L <= STARTS_MAXL && !getenv("PS_PREFIX_FULL");
+    if (cone) {
+        StartsArgs sa{order, m.und, m.dil, h->H, h->W, h->L, npre, F, {}, {}, {}, {}, {}, h->pstart};
+        for (int g = 0; g < NGATED; ++g) { sa.g_in[g] = h->gated[g].node_in; sa.g_out[g] = h->gated[g].node_out; sa.g_skip[g] = h->gated[g].node_skip; }
+        for (int d = 0; d < 4; ++d) { sa.d_in[d] = h->dil[d].node_in; sa.d_out[d] = h->dil[d].node_out; }
+        hipLaunchKernelGGL(k_prefix_starts, dim3(F), dim3(1024), 0, st, sa);
+    }
+    ItemMap items = all_items;
+    auto at_stage = [&](int stage_id) { items.start = cone ? h->pstart + (size_t)stage_id * F : nullptr; };
     auto gemm = [&](GemmArgs &a, const float *mask, const float *sum_bias = nullptr) {   // -> slots summed by the kernel?
         a.items = items;
         a.H = h->H; a.W = h->W; a.L = h->L; a.nitems = nitems;
@@ -2344,12 +2468,14 @@ void run_grid(ps_pixelcnn *h, int F, const int32_t *codes, const Masks &m, float
         return true;
     };
     {   // u_init + norm_init  (model.py:132)
+        at_stage(0);
         UinitArgs u{items, codes, m.init, h->uinit_w, h->uinit_b, h->R[0], h->E[0], h->H, h->W, h->L, nitems};
         hipLaunchKernelGGL(k_uinit_grid, dim3(pblocks), dim3(256), 0, st, u);
     }
     auto gated = [&](int g) {
         const ps_pixelcnn::Gated &G = h->gated[g];
         GemmArgs a{};
+        at_stage(1 + g);
         conv_taps(a, h->E[G.node_in], 2 * NF, G.w_in, 2 * NF, NF, 1);                 // conv_input (layers.py:153)
         if (G.node_skip >= 0) {                                                         // nin_skip   (layers.py:155-156)
             a.tap[9] = GemmTap{h->E[G.node_skip], G.w_skip, 0, 0, -1, 2 * NF};
@@ -2362,6 +2488,7 @@ void run_grid(ps_pixelcnn *h, int F, const int32_t *codes, const Masks &m, float
             hipLaunchKernelGGL(k_post_grid<POST_CONVIN>, dim3(pblocks), dim3(256), 0, st, p);
         }
         GemmArgs b{};
+        at_stage(15 + g);
         conv_taps(b, h->X[g], 2 * NF, G.w_out, 2 * NF, 2 * NF, 1);                     // conv_out   (layers.py:159)
         PostArgs q{items, h->partial, nitems, 2 * NF, h->L, 0, 0, G.b_out, nullptr, h->R[G.node_in], h->R[G.node_out],
                    h->E[G.node_out], nullptr};
@@ -2373,6 +2500,7 @@ void run_grid(ps_pixelcnn *h, int F, const int32_t *codes, const Masks &m, float
     auto dilated = [&](int d) {
         const ps_pixelcnn::Dil &D = h->dil[d];
         GemmArgs a{};
+        at_stage(29 + d);
         conv_taps(a, h->R[D.node_in], R_LD, D.w, NF, NF, 2);                            // model.py:138,148
         PostArgs p{items, h->partial, nitems, NF, h->L, 0, 0, D.b, nullptr, nullptr, h->R[D.node_out], h->E[D.node_out], nullptr};
         if (!stage(a, m.dil, p, POST_DIL)) {
@@ -2735,6 +2863,7 @@ int ps_pixelcnn_create(const float *const *params, int n_params, int H, int W, i
     if ((rc = dev_alloc(h, &h->col_logits, (size_t)max_frames * NCLS))) return fail_out(rc);
     if ((rc = dev_alloc(h, &h->nbr, (size_t)NST * 2 * COL_CAP * NBR_LD))) return fail_out(rc);
     if ((rc = dev_alloc(h, &h->ctx, locs))) return fail_out(rc);
+    if ((rc = dev_alloc(h, &h->pstart, (size_t)N_EVAL * max_frames))) return fail_out(rc);
     if ((rc = dev_alloc(h, &h->taps, locs))) return fail_out(rc);
     if ((rc = dev_alloc(h, &h->nbr_tp, (size_t)NST * 2 * TP_COL_CAP * NBR_LD))) return fail_out(rc);
     if ((rc = dev_alloc(h, &h->cnt_tp, tp_cnt_index(NST, 0)))) return fail_out(rc);
@@ -2893,6 +3022,7 @@ void *ps_pixelcnn_debug_cache(ps_pixelcnn *h, int what, int idx)
     if (what == 1 && idx >= 0 && idx < NNODE) return h->E[idx];
     if (what == 2 && idx >= 0 && idx < NGATED) return h->X[idx];
     if (what == 3) return h->nbr_tp;   // neighbour slots of the last throughput launch [NST][2][1024][160]
+    if (what == 5) return h->pstart;   // (33, F) int32 of the last AR run's prefix pass: first rank evaluated per stage and frame
     if (what == 4) {                   // tuning builds: allocate / return the stamp buffer [NST][8] of 64-bit clocks
         if (!h->tp_trace && dev_alloc(h, &h->tp_trace, (size_t)NST * 8) == PS_OK) (void)hipMemset(h->tp_trace, 0, NST * 8 * 8);
         return h->tp_trace;
@@ -3002,7 +3132,7 @@ int ps_lmconv_forward_f32(const float *x, const float *mask, size_t mask_batch_s
     hipLaunchKernelGGL(k_pack_conv, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, st, weight, Co, Ci, Cop, Cp, wp);
     GemmArgs a{};
     conv_taps(a, xcl, Cp, wp, Cp, Cop, dilation);
-    a.items = ItemMap{nullptr, L};
+    a.items = ItemMap{nullptr, L, nullptr};
     a.H = H; a.W = W; a.L = L; a.nitems = B * L; a.mask = mask; a.mask_fstride = mask_batch_stride;
     a.partial = partial; a.tiles_per_block = 2;
     const int tiles = (a.nitems + 15) / 16;

@@ -463,3 +463,58 @@ def test_ar_run_waves_rejects_a_schedule_of_another_run():
                uniforms=u, first_step=first, waves=(bad, wave_start))
     with pytest.raises(RuntimeError, match="outside this run"):
         eng.check()
+
+
+@pytest.mark.parametrize("F_,first", [(5, 320), (12, 600), (3, 905), (40, 640)])   # (40 frames: throughput-form column launches)
+def test_prefix_pass_evaluates_only_what_is_read(F_, first, monkeypatch):
+    """The whole-grid pass over the observed prefix skips, stage by stage, the items nobody reads (k_prefix_starts): the
+    device's (33, F) table of start ranks equals the numpy restatement (oracle/prefix_cone_oracle.py), and codes and
+    logits are bit-identical to a run that evaluates the whole prefix at every stage (PS_PREFIX_FULL=1)."""
+    import ctypes
+    from oracle import prefix_cone_oracle as pc
+    from pixelsynth_amd import _lib
+    from pixelsynth_amd.lmconv.model import wavefronts
+    net = make_net(5)
+    eng = net.engine(32, 32, F_)
+    bgs = syn.background_masks(256)
+    names = ["right_half", "half_plus_island", "ragged", "top_band"]
+    infos = [c_oracle.masks_for_background(bgs[names[b % 4]], 32) for b in range(F_)]
+    order_loc = np.stack([(i["order"][:, 0] * 32 + i["order"][:, 1]) for i in infos]).astype(np.int32)
+    reg = np.zeros((F_, 1024), np.uint8)
+    rs = np.random.RandomState(F_)
+    for b in range(F_):
+        walked = order_loc[b][first:]
+        reg[b, walked[rs.rand(walked.size) < 0.7]] = 1
+        reg[b, order_loc[b][first]] = 1
+    ms = [tt(np.concatenate([i[k] for i in infos])) for k in ("mask_init", "mask_undilated", "mask_dilated")]
+    codes0 = syn.codes(21, F_).reshape(F_, 1024).astype(np.int32)
+    u = tt(np.random.RandomState(4).rand(F_, 1024).astype(np.float32))
+    waves = wavefronts(order_loc, 32, 32, first, DEV)
+
+    def run():
+        c = tt(codes0.copy())
+        lg = eng.ar_run(c, tt(order_loc), tt(reg), *ms, temperature=0.7, uniforms=u, first_step=first, want_logits=True, waves=waves)
+        eng.check()
+        return c, lg
+    monkeypatch.setenv("PS_PREFIX_CONE_FORCE", "1")   # (a run that returns logits evaluates the whole prefix otherwise)
+    c_cone, l_cone = run()
+    monkeypatch.delenv("PS_PREFIX_CONE_FORCE")
+    # the table the prefix pass just used
+    L = _lib.lib()
+    L.ps_pixelcnn_debug_cache.restype = ctypes.c_void_p
+    ptr = L.ps_pixelcnn_debug_cache(eng.handle, 5, 0)
+    assert ptr
+    raw = type("Raw", (), {"__cuda_array_interface__": {"shape": (pc.N_EVAL, F_), "typestr": "<i4", "data": (ptr, False), "version": 2}})()
+    torch.cuda.synchronize()
+    got = torch.as_tensor(raw, device=DEV).clone().cpu().numpy()
+    for b in range(F_):
+        want = pc.prefix_starts(order_loc[b].astype(np.int64), infos[b]["mask_undilated"][0], infos[b]["mask_dilated"][0], 32, 32, first)
+        assert np.array_equal(got[:, b], want), b
+    assert (got < first).any() and (got > 0).any()   # something is evaluated, something is skipped
+    monkeypatch.setenv("PS_PREFIX_FULL", "1")
+    c_full, l_full = run()
+    assert torch.equal(c_cone, c_full)
+    walked = np.zeros((F_, 1024), bool)
+    for b in range(F_):
+        walked[b, order_loc[b][first:]] = True
+    assert torch.equal(l_cone[torch.from_numpy(walked).to(DEV)], l_full[torch.from_numpy(walked).to(DEV)])
