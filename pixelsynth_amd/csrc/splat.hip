@@ -30,7 +30,7 @@ namespace {
 constexpr int TILE = 8;                  // pixels per tile edge: 64 pixels = one wave64
 constexpr float PS_EPS = 1e-2f;          // z_buffer_manipulator.py:8
 constexpr uint32_t CULLED = 0xFFFFFFFFu;
-constexpr int SORT_SMALL_CAP = 1024;     // keys sorted in LDS by one wave
+constexpr int SORT_SMALL_CAP = 512;      // keys sorted in LDS by one wave (4 KB: eight waves per SIMD)
 constexpr int SORT_BIG_CAP = 8192;       // keys sorted in LDS by a 1024-thread workgroup
 
 // ------------------------------------------------------------------------------------------
@@ -292,6 +292,15 @@ __global__ __launch_bounds__(256) void k_bin_fill(const float *__restrict__ pts,
 // per-tile sort: normalised bitonic network (every comparator ascending), so elements beyond n act
 // as +inf without being stored.  `a` is LDS or global memory.
 // ------------------------------------------------------------------------------------------
+// steps are separated by a workgroup barrier -- or, for a single wave (THREADS == 64), by nothing but a compiler fence: the
+// LDS executes one wave's accesses in order
+template <int THREADS>
+__device__ __forceinline__ void sort_step_sync()
+{
+    if (THREADS == 64) asm volatile("" ::: "memory");
+    else __syncthreads();
+}
+
 template <int THREADS, typename Ptr>
 __device__ __forceinline__ void bitonic_sort(Ptr a, int n)
 {
@@ -316,7 +325,7 @@ __device__ __forceinline__ void bitonic_sort(Ptr a, int n)
                     if (x > y) { a[i] = y; a[l] = x; }
                 }
             }
-            __syncthreads();
+            sort_step_sync<THREADS>();
         }
     }
 }
@@ -335,7 +344,7 @@ __global__ __launch_bounds__(64) void k_sort_small(uint64_t *__restrict__ keys,
         return;
     }
     for (uint32_t i = threadIdx.x; i < n; i += 64) s[i] = keys[beg + i];
-    __syncthreads();
+    sort_step_sync<64>();
     bitonic_sort<64>(s, (int)n);
     for (uint32_t i = threadIdx.x; i < n; i += 64) keys[beg + i] = s[i];
 }
@@ -365,6 +374,9 @@ __global__ __launch_bounds__(1024) void k_sort_big(uint64_t *__restrict__ keys,
 // composite: one wave per 8x8 tile, one lane per pixel
 // ------------------------------------------------------------------------------------------
 constexpr int CG = 4;  // channels accumulated per wave; grid.z walks channel groups
+#ifndef PS_COMPOSITE_WAVES
+#define PS_COMPOSITE_WAVES 8
+#endif
 
 __device__ __forceinline__ float bcast(float v, int lane)
 {
@@ -380,6 +392,7 @@ __device__ __forceinline__ float bcast(float v, int lane)
 struct __attribute__((aligned(16))) SplatRec { float x, y, z; uint32_t n; float f[CG]; };
 
 template <int MODE, bool DEBUG_OUT, bool RECIP>
+__attribute__((amdgpu_waves_per_eu(PS_COMPOSITE_WAVES, PS_COMPOSITE_WAVES)))
 __global__ __launch_bounds__(64) void k_composite(
     const uint64_t *__restrict__ keys, const uint32_t *__restrict__ tile_off,
     const float *__restrict__ pts, const float *__restrict__ feat, int N, int C, int S, int tilesX,
