@@ -400,7 +400,10 @@ __global__ __launch_bounds__(64) void k_composite(
     uint8_t *__restrict__ bg0, int32_t *__restrict__ out_idx, float *__restrict__ out_zbuf,
     float *__restrict__ out_dist)
 {
-    __shared__ SplatRec rec[64];
+    // records of a batch, structure of arrays: in the walk every lane fetches a DIFFERENT record, and 32-byte structs put
+    // records j and j + 4 on the same banks (up to 16 lanes per bank); 4-byte columns put j and j + 32 there (2 lanes)
+    __shared__ float sx[64], sy[64], sz[64], sf[CG][64];
+    __shared__ uint32_t sn[64];
     const int tile = blockIdx.x, b = blockIdx.y, c0 = blockIdx.z * CG;
     const int lane = threadIdx.x;
     const int tx = tile % tilesX, ty = tile / tilesX;
@@ -446,23 +449,32 @@ __global__ __launch_bounds__(64) void k_composite(
             const SplatRec r = rnext;
             rnext = fetch(base + 64);
             __syncthreads();  // the previous batch's phase 2 is done with rec[]
-            rec[lane] = r;
+            sx[lane] = r.x; sy[lane] = r.y; sz[lane] = r.z; sn[lane] = r.n;
+#pragma unroll
+            for (int c = 0; c < CG; ++c) sf[c][lane] = r.f[c];
             __syncthreads();
             // phase 1: hit bits
             uint64_t hits = 0;
             if (valid && cnt < K) {
-#pragma unroll 16
-                for (int j = 0; j < 64; ++j) {
-                    const float dx = rec[j].x - xf, dy = rec[j].y - yf;
-                    const float d2 = dx * dx + dy * dy;
-                    hits |= (uint64_t)(d2 < r2) << j;
+                const int nrec = (int)min(64u, end - base);   // (wave-uniform) records staged in this batch, in blocks of 16
+                for (int j0 = 0; j0 < nrec; j0 += 16) {
+#pragma unroll
+                    for (int jj = 0; jj < 16; ++jj) {
+                        const int j = j0 + jj;
+                        const float dx = sx[j] - xf, dy = sy[j] - yf;
+                        const float d2 = dx * dx + dy * dy;
+                        hits |= (uint64_t)(d2 < r2) << j;
+                    }
                 }
             }
             // phase 2: this pixel's hits, front to back
             while (hits && cnt < K) {
                 const int j = __builtin_ctzll(hits);
                 hits &= hits - 1;
-                const SplatRec h = rec[j];
+                SplatRec h;
+                h.x = sx[j]; h.y = sy[j]; h.z = sz[j]; h.n = sn[j];
+#pragma unroll
+                for (int c = 0; c < CG; ++c) h.f[c] = sf[c][j];
                 const float dx = h.x - xf, dy = h.y - yf;
                 const float d2 = dx * dx + dy * dy;
                 float d = RECIP ? d2 * denom : d2 / denom;
