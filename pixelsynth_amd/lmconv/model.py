@@ -293,10 +293,12 @@ import os
 
 # Columns one launch takes (csrc/lmconv.hip): k_column, the latency form -- one CU per column -- takes COL_CAP = 128; waves with
 # more columns run as k_column_tp, the throughput form -- 16-column MFMA chain tiles -- which takes TP_COL_CAP = 1024.  Few
-# frames never fill more than the latency form holds, so their schedule is capped at its capacity.
+# frames never fill more than the latency form holds, so their schedule is capped at its capacity.  The crossover, measured
+# on the bench's sweeps (ms per step, latency form / throughput form): 24 views 7.8 / 11.0, 48: 14.4 / 15.8, 56: 16.5 / 16.6,
+# 64: 19.0 / 17.5, 96: 28.2 / 20.6, 128: 38 / 24.4.
 COLUMNS_PER_LAUNCH = int(os.environ.get("PS_WAVE_COLS", "128"))
 COLUMNS_PER_LAUNCH_TP = int(os.environ.get("PS_WAVE_COLS_TP", "1024"))
-TP_MIN_FRAMES = int(os.environ.get("PS_TP_MIN_FRAMES", "24"))
+TP_MIN_FRAMES = int(os.environ.get("PS_TP_MIN_FRAMES", "60"))
 
 
 _COLS_STAGE = {}

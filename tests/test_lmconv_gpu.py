@@ -489,7 +489,7 @@ def test_prefix_pass_evaluates_only_what_is_read(F_, first, monkeypatch):
     ms = [tt(np.concatenate([i[k] for i in infos])) for k in ("mask_init", "mask_undilated", "mask_dilated")]
     codes0 = syn.codes(21, F_).reshape(F_, 1024).astype(np.int32)
     u = tt(np.random.RandomState(4).rand(F_, 1024).astype(np.float32))
-    waves = wavefronts(order_loc, 32, 32, first, DEV)
+    waves = wavefronts(order_loc, 32, 32, first, DEV, max_cols=1024 if F_ >= 24 else None)
 
     def run():
         c = tt(codes0.copy())
