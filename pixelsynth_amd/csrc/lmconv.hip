@@ -867,6 +867,12 @@ __device__ __forceinline__ f32x4 nbr_tap(const NbrWork &sd, const NbrArgs &a, co
 #pragma unroll
             for (int g = g0; g < g0 + 5; ++g) bv[g] = *PS_GC(f32x4, src + 16 * g);
         }
+#ifndef PS_NBR_NO_PIN
+        // (the loads stay unconditional: otherwise the compiler sinks one of them under `live` and waits for it with
+        // vmcnt(0), which also drains the weight loads in flight -- see gemm_tiles)
+#pragma unroll
+        for (int g = g0; g < g0 + 5; ++g) asm volatile("" : "+v"(bv[g]));
+#endif
 #pragma unroll
         for (int g = g0; g < g0 + 5; ++g) bv[g] = live ? bv[g] * mv : zero;
         const f32x4 (&a5)[5] = *reinterpret_cast<const f32x4 (*)[5]>(&av[g0]);
