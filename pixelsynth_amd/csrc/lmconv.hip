@@ -331,176 +331,6 @@ __global__ __launch_bounds__(64) void k_gemm(GemmArgs a)
     else gemm_tiles<1>(a, o0, z0, z1, first_tile);
 }
 
-// k_gemm_rows: the summing form of k_gemm with the gathered input rows shared through LDS.  A workgroup = one tile of 16
-// items, one wave per block of 32 output channels (5 for conv_out, 3 for the 80-channel convs); for every open tap the 16
-// input rows of the tile (16 x Cin floats, mask already applied: closed lanes are zeros, fractional mask values multiplied
-// in, as the reference does to its unfolded input) are fetched ONCE by the workgroup -- two 16-byte loads per lane, issued a
-// tap ahead, under the previous tap's MFMAs -- into one of two LDS buffers, and every wave reads its B operand from there.
-// k_gemm's waves each fetch them for themselves, five times over, through an L1 that is the bottleneck (with the rows
-// coming out of LDS in a timing experiment the launch went from 260 to 206 us).  One barrier per open tap; the taps a
-// tile skips are the same for all its waves.  Slots, taps, chunks and chains are walked as in gemm_tiles: same bits.
-constexpr int RB_LD = 164;                 // floats per staged row: 160 channels + 4 (rows 4 banks apart)
-constexpr int RB_MAXW = 5;                 // waves per workgroup at most (160 output channels)
-struct RowsItem { int f, r, c, q, valid; };
-constexpr int RB_MAXT = 10;                // taps of a stage at most (9 + nin_skip)
-template <int T, int PER>
-__device__ __forceinline__ void gemm_rows_wave(const GemmArgs &a, int o0, int tile, float *sB, const RowsItem *sItem,
-                                               const float *sMv /* [tap][16] mask value of every (tap, item), 0 = closed / outside */,
-                                               int open_mask)
-{
-    const int lane = threadIdx.x & 63, i = lane & 15, kk = lane >> 4;
-    const int nchunks = a.Cin / 80, row4 = a.Cin >> 2;     // float4 per row
-    const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
-    const int item = tile * 16 + i;
-    const bool my_valid = sItem[i].valid != 0;
-    const int total4 = 16 * row4;
-    // this lane's share of a tap's rows: float4 number idx = threadIdx.x + k * blockDim.x of the 16 x row4, k < PER
-    f32x4 stage[PER];
-    auto tap_rows_issue = [&](int t) {   // global loads of this lane's share (the mask is applied when they are parked)
-        const GemmTap &tp = a.tap[t];
-#pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            stage[k] = zero;
-            const int idx = (int)threadIdx.x + k * (int)blockDim.x;
-            if (idx < total4) {
-                const int row = idx / row4, c4 = idx - row * row4;
-                const RowsItem it = sItem[row];
-                const bool open = sMv[t * 16 + row] != 0.0f;
-                const float *src = open ? tp.in + ((size_t)it.f * a.L + (it.r + tp.dr) * a.W + it.c + tp.dc) * tp.ld : g_zero_row;
-                stage[k] = *(const f32x4 *)(src + 4 * c4);
-            }
-        }
-    };
-    auto tap_rows_park = [&](int t, int buf) {
-#pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            const int idx = (int)threadIdx.x + k * (int)blockDim.x;
-            if (idx < total4) {
-                const int row = idx / row4, c4 = idx - row * row4;
-                const float mv = sMv[t * 16 + row];
-                f32x4 v = stage[k];
-                if (mv != 1.0f) v = mv != 0.0f ? v * mv : zero;
-                *(f32x4 *)(sB + (size_t)buf * 16 * RB_LD + row * RB_LD + 4 * c4) = v;
-            }
-        }
-    };
-    const bool summing = a.sum_bias != nullptr;
-    f32x4 ysum[T];
-#pragma unroll
-    for (int u = 0; u < T; ++u) ysum[u] = zero;
-    const int ntaps = a.slot_first[a.nslots];
-    auto next_open = [&](int t) { while (t < ntaps && !((open_mask >> t) & 1)) ++t; return t; };
-    int t = next_open(0), step = 0;
-    if (t < ntaps) { tap_rows_issue(t); tap_rows_park(t, 0); }
-    __syncthreads();
-    const uint32_t woff = (uint32_t)((kk * a.Co_pad + o0 + i) * 16);
-    for (int z = 0; z < a.nslots; ++z) {
-        const int slot = z;   // (summing form: slots in tap order NA, C, NB, SKIP)
-        f32x4 tot[T];
-#pragma unroll
-        for (int u = 0; u < T; ++u) tot[u] = zero;
-        while (t < a.slot_first[slot + 1]) {   // (t only ever points at open taps, ascending)
-            const GemmTap &tp = a.tap[t];
-            const int tn = next_open(t + 1);
-            if (tn < ntaps) tap_rows_issue(tn);   // in flight under this tap's MFMAs
-            {
-                const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)tp.w, 0, 0x7fffffff, 0x00020000);
-                Acc5 acc[T];
-#pragma unroll
-                for (int u = 0; u < T; ++u) acc[u] = acc5_zero();
-                const float *sb = sB + (size_t)(step & 1) * 16 * RB_LD + i * RB_LD + 4 * kk;
-                for (int chunk = 0; chunk < nchunks; ++chunk) {
-                    f32x4 bv[5];
-#pragma unroll
-                    for (int j = 0; j < 5; ++j) bv[j] = *(const f32x4 *)(sb + 16 * (chunk * 5 + j));
-#pragma unroll
-                    for (int u = 0; u < T; ++u) {
-                        f32x4 av[5];
-#pragma unroll
-                        for (int j = 0; j < 5; ++j)
-                            av[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                                  wrs, woff, ((chunk * 5 + j) * 16 * a.Co_pad + 64 * u) * 4, 0));
-                        mfma_chunk5(av, bv, acc[u]);
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < T; ++u) tot[u] = tot[u] + chunk_total(acc[u]);
-            }
-            if (tn < ntaps) tap_rows_park(tn, (step + 1) & 1);
-            __syncthreads();
-            ++step;
-            t = tn;
-        }
-        if (summing && slot != SLOT_SKIP) {
-#pragma unroll
-            for (int u = 0; u < T; ++u)
-                ysum[u] = (slot == SLOT_NA ? *(const f32x4 *)(a.sum_bias + o0 + 16 * u + kk * 4) : ysum[u]) + tot[u];
-            if (slot != SLOT_NB) continue;
-#pragma unroll
-            for (int u = 0; u < T; ++u) tot[u] = ysum[u];
-        }
-        if (my_valid) {
-            const int at = summing && slot == SLOT_NB ? SLOT_NA : slot;
-#pragma unroll
-            for (int u = 0; u < T; ++u)
-                *(f32x4 *)(a.partial + ((size_t)at * a.nitems + item) * a.Co_pad + o0 + 16 * u + kk * 4) = tot[u];
-        }
-    }
-}
-
-// grid: item tiles laid out XCD by XCD (as k_gemm); block: one wave per 32 output channels.  Needs the summing form
-// (sum_bias, slots in tap order) and Cin = 80 or 160.
-#ifndef PS_ROWS_WAVES
-#define PS_ROWS_WAVES 4
-#endif
-__attribute__((amdgpu_waves_per_eu(PS_ROWS_WAVES, PS_ROWS_WAVES)))
-__global__ __launch_bounds__(64 * RB_MAXW) void k_gemm_rows(GemmArgs a)
-{
-    __shared__ __attribute__((aligned(16))) float sB[2 * 16 * RB_LD];
-    __shared__ RowsItem sItem[16];
-    __shared__ float sMv[RB_MAXT * 16];
-    __shared__ int sOpen;
-    const int xcd = blockIdx.x & (N_XCD - 1), t = blockIdx.x >> 3;
-    const int tile = xcd * a.tpx + t;
-    if (t >= a.tpx || tile >= a.ny) return;
-    const int ntaps = a.slot_first[a.nslots];
-    if (threadIdx.x == 0) sOpen = 0;
-    if (threadIdx.x < 16) {
-        const int item = tile * 16 + threadIdx.x;
-        RowsItem it{0, 0, 0, 0, 0};
-        if (item < a.nitems && item_wanted(a.items, item)) {
-            item_loc(a.items, item, a.L, it.f, it.q);
-            it.r = it.q / a.W;
-            it.c = it.q - it.r * a.W;
-            it.valid = 1;
-        }
-        sItem[threadIdx.x] = it;
-    }
-    __syncthreads();
-    for (int e = threadIdx.x; e < ntaps * 16; e += blockDim.x) {   // mask value of every (tap, item) of the tile
-        const int tp_ = e >> 4, row = e & 15;
-        const RowsItem it = sItem[row];
-        const GemmTap &tq = a.tap[tp_];
-        const int rr = it.r + tq.dr, cc = it.c + tq.dc;
-        float mv = 0.0f;
-        if (it.valid && rr >= 0 && rr < a.H && cc >= 0 && cc < a.W)
-            mv = tq.mask_row >= 0 ? a.mask[(size_t)it.f * a.mask_fstride + (size_t)tq.mask_row * a.L + it.q] : 1.0f;
-        sMv[e] = mv;
-        if (mv != 0.0f) atomicOr(&sOpen, 1 << tp_);
-    }
-    __syncthreads();
-    const int open_mask = sOpen;
-    if (open_mask == 0) {   // nothing to multiply: y = bias for the items that are wanted (a tile nobody reads leaves at once)
-        bool any = false;
-        for (int k = 0; k < 16; ++k) any |= sItem[k].valid != 0;
-        if (!any) return;
-    }
-    const int o0 = (threadIdx.x >> 6) * 32;
-    const bool two = a.Co_pad - o0 >= 32;
-    if (blockDim.x >= 320) { if (two) gemm_rows_wave<2, 2>(a, o0, tile, sB, sItem, sMv, open_mask); else gemm_rows_wave<1, 2>(a, o0, tile, sB, sItem, sMv, open_mask); }
-    else { if (two) gemm_rows_wave<2, 4>(a, o0, tile, sB, sItem, sMv, open_mask); else gemm_rows_wave<1, 4>(a, o0, tile, sB, sItem, sMv, open_mask); }
-}
-
 // ------------------------------------------------------------------------------------------
 // per-item post ops, shared by the whole-grid kernels and the column chain.
 // One wave per item, TWO adjacent channels per lane: lane l < 40 owns channels 2l and 2l + 1 (8-byte accesses, packed
@@ -2590,11 +2420,6 @@ void launch_gemm(GemmArgs &a, int item_blocks, hipStream_t st)
     const int merge_min = mm ? atoi(mm) : 8192;
     a.zgrid = split || a.nx * a.ny < merge_min ? a.nslots : 1;
     if (a.zgrid != 1 || a.nslots < 3) a.sum_bias = nullptr;   // (only a wave that walks NA, C and NB can add them up)
-    if (a.zgrid == 1 && a.sum_bias && a.tiles_per_block == 1 && (a.Cin == 80 || a.Cin == 160) && getenv("PS_GEMM_ROWS")) {   // opt-in while it is slower than k_gemm
-        a.nx = (a.Co_pad + 31) / 32;   // waves per workgroup
-        hipLaunchKernelGGL(k_gemm_rows, dim3((unsigned)(N_XCD * a.tpx)), dim3(64 * a.nx), 0, st, a);
-        return;
-    }
     hipLaunchKernelGGL(k_gemm, dim3((unsigned)(N_XCD * a.nx * a.tpx * a.zgrid)), dim3(64), 0, st, a);
 }
 
