@@ -405,8 +405,8 @@ def cpu_baseline(host, out, V, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--views", type=int, default=128, help="independent novel views per GPU per step (128 = C5: 8 sources x 16 views)")
     ap.add_argument("--cameras", choices=["mp3d", "demo"], default="mp3d", help="Matterport-shaped (C5) or demo / RealEstate10K-shaped inputs")
     ap.add_argument("--depth", choices=["smooth", "uniform"], default="smooth")
