@@ -518,3 +518,53 @@ def test_prefix_pass_evaluates_only_what_is_read(F_, first, monkeypatch):
     for b in range(F_):
         walked[b, order_loc[b][first:]] = True
     assert torch.equal(l_cone[torch.from_numpy(walked).to(DEV)], l_full[torch.from_numpy(walked).to(DEV)])
+
+
+@pytest.mark.parametrize("H,W", [(16, 16), (8, 12)])
+def test_prefix_cone_on_other_grids_and_random_orders(H, W, monkeypatch):
+    """k_prefix_starts on a square and a non-square grid with RANDOM generation orders (where the cone of a stage is far
+    from a suffix of the prefix, so the start ranks give away a lot -- but never too little): device table == numpy
+    restatement, codes and walked logits identical to the full prefix."""
+    import ctypes
+    from oracle import prefix_cone_oracle as pc
+    from pixelsynth_amd import _lib
+    net = make_net(6)
+    F_, L = 3, H * W
+    eng = net.engine(H, W, F_)
+    rs = np.random.RandomState(H * 10 + W)
+    orders = [np.stack(np.unravel_index(rs.permutation(L), (H, W)), 1).astype(np.int32) for _ in range(F_)]
+    masks = [np.concatenate([c_oracle.unfolded_masks(o, H, W, 3, dil, typ) for o in orders]) for dil, typ in ((1, "A"), (1, "B"), (2, "B"))]
+    ms = [tt(m) for m in masks]
+    order_loc = np.stack([o[:, 0] * W + o[:, 1] for o in orders]).astype(np.int32)
+    first = (2 * L) // 3
+    reg = np.zeros((F_, L), np.uint8)
+    for b in range(F_):
+        reg[b, order_loc[b][first:]] = 1
+    codes0 = rs.randint(0, 512, size=(F_, L)).astype(np.int32)
+    u = tt(rs.rand(F_, L).astype(np.float32))
+
+    def run():
+        c = tt(codes0.copy())
+        lg = eng.ar_run(c, tt(order_loc), tt(reg), *ms, temperature=0.9, uniforms=u, first_step=first, want_logits=True)
+        eng.check()
+        return c, lg
+    monkeypatch.setenv("PS_PREFIX_CONE_FORCE", "1")
+    c_cone, l_cone = run()
+    monkeypatch.delenv("PS_PREFIX_CONE_FORCE")
+    lib = _lib.lib()
+    lib.ps_pixelcnn_debug_cache.restype = ctypes.c_void_p
+    ptr = lib.ps_pixelcnn_debug_cache(eng.handle, 5, 0)
+    raw = type("Raw", (), {"__cuda_array_interface__": {"shape": (pc.N_EVAL, F_), "typestr": "<i4", "data": (ptr, False), "version": 2}})()
+    torch.cuda.synchronize()
+    got = torch.as_tensor(raw, device=DEV).clone().cpu().numpy()
+    for b in range(F_):
+        want = pc.prefix_starts(order_loc[b].astype(np.int64), masks[1][b], masks[2][b], H, W, first)
+        assert np.array_equal(got[:, b], want), b
+    monkeypatch.setenv("PS_PREFIX_FULL", "1")
+    c_full, l_full = run()
+    assert torch.equal(c_cone, c_full)
+    walked = np.zeros((F_, L), bool)
+    for b in range(F_):
+        walked[b, order_loc[b][first:]] = True
+    sel = torch.from_numpy(walked).to(DEV)
+    assert torch.equal(l_cone[sel], l_full[sel])
