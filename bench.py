@@ -52,13 +52,18 @@ def build_model(device):
 VIEWS_PER_SOURCE = 16   # config C5: 8 source images x 16 novel views each
 
 
-def make_inputs(rank, V, device, smooth=True, cameras="mp3d"):
+def make_inputs(rank, V, device, smooth=True, cameras="mp3d", ids=None, trajectory="sweep"):
     """V independent (source, target view) pairs: ceil(V / 16) source images, 16 target views each (a yaw sweep of +-0.6 rad,
     the reference's full angle, models/z_buffermodel.py:113).  cameras "mp3d": Matterport/Habitat-shaped (config C5:
     K = diag(1/tan(hfov/2), ., 1, 1) at hfov 90 deg, depth 0.5 .. 10, data/create_rgb_dataset.py:204-216); "demo": the demo /
-    RealEstate10K-shaped cameras of demo.py:36-96 (K = I, P = diag(2,-2,-1,1)), depth 1 .. 100."""
+    RealEstate10K-shaped cameras of demo.py:36-96 (K = I, P = diag(2,-2,-1,1)), depth 1 .. 100.
+    trajectory "circle" (config C4): ONE source, V target poses on the 'C' circle of get_rt_from_rot (z_buffermodel.py:217-225),
+    pose i = C_i/V, every view rendered from the source (create_vid.py-style playback order).
+    ids: this rank's share of a job of V views in TOTAL (strong scaling: the job is built as a whole -- `rank` only seeds it --
+    and the rows `ids` of it are put on the device)."""
     S = 256
-    n_src = max(1, -(-V // VIEWS_PER_SOURCE))
+    circle = trajectory == "circle"
+    n_src = 1 if circle else max(1, -(-V // VIEWS_PER_SOURCE))
     per = -(-V // n_src)
     lo, hi = (0.5, 10.0) if cameras == "mp3d" else (1.0, 100.0)
     cam = (syn.mp3d_cameras if cameras == "mp3d" else syn.demo_cameras)(V)
@@ -74,14 +79,19 @@ def make_inputs(rank, V, device, smooth=True, cameras="mp3d"):
     RT2 = np.empty((V, 4, 4), np.float32)
     RT2inv = np.empty((V, 4, 4), np.float32)
     for v in range(V):
-        inv, rt = syn.yaw_pose(cam["P"][v:v + 1], float(yaws[v]))
+        inv, rt = syn.circle_pose(cam["P"][v:v + 1], v, V) if circle else syn.yaw_pose(cam["P"][v:v + 1], float(yaws[v]))
         RT2[v], RT2inv[v] = rt[0], inv[0]
     codes = syn.codes(3000 + rank, V)
+    uniforms = np.random.RandomState(4000 + rank).rand(V, 1024).astype(np.float32)
+    if ids is not None:   # this rank's rows of the whole job
+        ids = np.asarray(ids, np.int64)
+        img, depth, RT2, RT2inv, codes, uniforms, yaws = (a[ids] for a in (img, depth, RT2, RT2inv, codes, uniforms, yaws))
+        cam = {k: a[ids] for k, a in cam.items()}
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
     dev = dict(img=t(img), depth=t(depth), K=t(cam["K"]), Kinv=t(cam["Kinv"]), P=t(cam["P"]), Pinv=t(cam["Pinv"]),
-               RT2=t(RT2), RT2inv=t(RT2inv), codes=t(codes),
-               uniforms=t(np.random.RandomState(4000 + rank).rand(V, 1024).astype(np.float32)))
-    host = dict(img=img, depth=depth, cam=cam, RT2=RT2, RT2inv=RT2inv, codes=codes, yaws=yaws, n_src=n_src, cameras=cameras)
+               RT2=t(RT2), RT2inv=t(RT2inv), codes=t(codes), uniforms=t(uniforms))
+    host = dict(img=img, depth=depth, cam=cam, RT2=RT2, RT2inv=RT2inv, codes=codes, yaws=yaws, n_src=n_src, cameras=cameras,
+                trajectory=trajectory, per_source=per)
     return dev, host
 
 
@@ -94,8 +104,10 @@ def front(model, d):
 def back(model, d, planned, world):
     """Second half: the AR run (asynchronous), then the path's only collective."""
     out = model.outpaint_planned(planned, d["codes"], temperature=0.7, uniforms=d["uniforms"])
-    if world > 1:  # finished frames of every rank: RCCL all_gather over xGMI
-        out["all_frames_u8"] = D.gather_frames(D.to_image_u8(out["gen_fs"]))
+    if world > 1:  # what the path produced on every rank -- the reprojected views as 8-bit images (the byte volume of finished
+        # frames: the VQ-VAE decode that turns codes into pixels is a next-row component, timed under end_to_end_*) and the
+        # completed 32x32 code grids -- RCCL all_gather over xGMI
+        out["all_features_u8"] = D.gather_frames(D.to_image_u8(out["gen_fs"]))
         out["all_codes"] = D.gather_frames(out["codes"].contiguous())
     return out
 
@@ -193,10 +205,14 @@ def latest_pmc_record(V):
     return None
 
 
-def small_batch_config(device, V, cameras, steps=5):
-    """frames/s and the column launch's roofline numbers of a smaller batch (pipelined steps like the headline)."""
+def small_batch_config(device, V, cameras, steps=5, total=None, trajectory="sweep"):
+    """frames/s and the column launch's roofline numbers of a smaller batch (pipelined steps like the headline).
+    total: the batch is rank 0's share of a job of `total` views over total / V ranks (the 8-GPU forms of C4 / C5)."""
     model = build_model(device)
-    d, _ = make_inputs(0, V, device, cameras=cameras)
+    if total is None:
+        d, _ = make_inputs(0, V, device, cameras=cameras, trajectory=trajectory)
+    else:
+        d, _ = make_inputs(0, total, device, cameras=cameras, trajectory=trajectory, ids=D.shard_views(total, 0, total // V))
     side = torch.cuda.Stream()
     out = run_steps(model, d, 1, 2, side)
     torch.cuda.synchronize()
@@ -220,6 +236,20 @@ def extra_configs(device):
     # RealEstate10K-shaped cameras): few columns per wavefront -> the latency form of the column launch (k_column)
     res["C5_one_source_16_views"] = small_batch_config(device, 16, "mp3d")
     res["RealEstate_shaped_16_views"] = small_batch_config(device, 16, "demo")
+    # The STRONG-scaling forms BASELINE.json names for 8 GPUs, priced from one GPU's measured share (no 8-GPU node behind this
+    # run: a projection, the path has no exchange besides the final gather).  C5 = 128 views in total -> 16 per GPU, dealt
+    # round-robin (rank 0 renders views 0, 8, 16, ...: two of every source's sweep); C4 = the 64-frame circle -> 8 frames per GPU.
+    c5 = small_batch_config(device, 16, "mp3d", total=128)
+    c4 = small_batch_config(device, 8, "demo", total=64, trajectory="circle")
+    c4_1gpu = small_batch_config(device, 64, "demo", total=None, trajectory="circle")
+    res["C4_circle_64_frames_one_gpu"] = c4_1gpu
+    res["projected_per_gpu"] = {
+        "note": "what ONE of eight GPUs runs in the strong-scaling forms of C5 / C4 (python bench.py --total-views 128 | "
+                "--trajectory circle --frames 64 under torch.distributed.run), measured here; x8 is a projection, not a measurement",
+        "C5_total_128_views_8gpus": {"views_per_gpu": 16, "ms_per_step": c5["ms_per_step"], "column_launch": c5["column_launch"],
+                                     "frames_per_s_8gpus_projected": round(128 / (c5["ms_per_step"] * 1e-3), 1)},
+        "C4_circle_64_frames_8gpus": {"frames_per_gpu": 8, "ms_per_step": c4["ms_per_step"], "column_launch": c4["column_launch"],
+                                      "frames_per_s_8gpus_projected": round(64 / (c4["ms_per_step"] * 1e-3), 1)}}
     m1 = build_model(device)
     d1, _ = make_inputs(0, 1, device, cameras="demo")
     for _ in range(2):
@@ -335,6 +365,9 @@ def extra_configs(device):
     res["depth_and_refinement_16_views"] = {"depth_unet_ms": round(timings["depth_unet"] * 1e3, 3),
                                             "refine_decoder_ms": round(timings["refine_decoder"] * 1e3, 3),
                                             "note": "next-row components (SURVEY 8f.2), outside the headline metric"}
+    # the whole pipeline as ONE timed configuration: what a user gets per frame
+    res["end_to_end_16_views"] = end_to_end_config(device, 16)
+    res["end_to_end_128_views"] = end_to_end_config(device, 128, steps=2)
     # the reference's own way of rendering a trajectory -- forward_scene, frames chained on one GPU
     # (every frame rendered from the previous one over the accumulated cloud, VQ-VAE in the loop, no sharding possible)
     import types
@@ -362,6 +395,67 @@ def extra_configs(device):
     return res
 
 
+def end_to_end_config(device, V, steps=3):
+    """What a user of the reference's demo gets per frame (models/z_buffermodel.py:291-419), V views in one pass: depth Unet on
+    the source images -> reproject + splat -> VQ-VAE top codes -> AR outpainting -> decode_code -> get_combined -> refinement
+    decoder, every network in the loop (random-init weights of the reference's shapes), inputs resident, wall clock around
+    synchronised passes.  The dense convolutions (Unet, VQ-VAE, decoder) are MIOpen's -- next-row components; the
+    hot path of the headline metric is the part `hot_path_ms` times inside this pass."""
+    from pixelsynth_amd.z_buffermodel import ZbufferModelPts
+    o = vars(make_opts()).copy()
+    o.update(vars(syn.network_opts()))
+    o.update(vqvae=True, min_z=0.5, max_z=10.0)
+    m = ZbufferModelPts(types.SimpleNamespace(**o)).eval()
+    m.outpaint2.load_state_dict({k: torch.from_numpy(v) for k, v in syn.pixelcnn_state_dict(0).items()})
+    m.vqvae.load_state_dict({k: torch.from_numpy(v) for k, v in syn.vqvae_state_dict(0).items()})
+    for mod in (m.pts_regressor, m.projector):
+        shapes = {k: tuple(v.shape) for k, v in mod.state_dict().items()}
+        mod.load_state_dict({k: torch.from_numpy(v) for k, v in syn.fill_state_dict(shapes, 5).items()})
+    m = m.to(device)
+    d, host = make_inputs(0, V, device, cameras="mp3d")
+    per = host["per_source"]
+    src = d["img"][::per].contiguous()
+    view_src = torch.arange(V, device=device) // per
+    run = lambda: m.synthesize_views(src, view_src, d["K"], d["Kinv"], d["P"], d["Pinv"], d["RT2"], d["RT2inv"], temperature=0.7,
+                                     uniforms=d["uniforms"], check=False)
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    for _ in range(2):
+        out = run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = run()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    m.outpaint2.engine(32, 32, V).check()
+    # the parts, each on its own (synchronised, so their sum exceeds the pass by what the pass overlaps)
+    parts = {}
+    def clock(name, fn, n=3):
+        fn()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(n):
+            r = fn()
+        torch.cuda.synchronize()
+        parts[name] = round((time.perf_counter() - t) / n * 1e3, 3)
+        return r
+    with torch.no_grad():
+        depth_src = clock("depth_unet_ms", lambda: torch.sigmoid(m.pts_regressor(src)) * 9.5 + 0.5)
+        depth = depth_src[view_src].contiguous()
+        planned = clock("reproject_splat_plan_ms", lambda: m.plan_views(d["img"], depth, d["K"], d["Kinv"], d["P"], d["Pinv"], d["RT2"], d["RT2inv"]))
+        codes = clock("vqvae_encode_codes_ms", lambda: m.vqvae.encode_codes(planned["gen_fs"]))
+        o2 = clock("ar_outpaint_ms", lambda: m.outpaint_planned(dict(planned), codes, 0.7, d["uniforms"]))
+        sample = clock("vqvae_decode_code_ms", lambda: m.vqvae.decode_code(o2["codes"]))
+        comb = m.get_combined(o2["gen_fs"], sample, o2["background_mask"])
+        clock("refine_decoder_ms", lambda: m.projector(comb, o2["background_mask"]))
+    m.outpaint2.engine(32, 32, V).check()
+    return {"frames_per_s": round(V / dt, 1), "ms_per_pass": round(dt * 1e3, 3), "views": V, "sources": host["n_src"],
+            "sampled_codes_per_view_mean": round(float(np.mean(out["plan"].n_sampled)), 1), "parts_ms": parts,
+            "hot_path_ms": round(parts["reproject_splat_plan_ms"] + parts["ar_outpaint_ms"], 3),
+            "note": "every network of forward_image in the loop; depth from the (random-init) Unet, so the outpainting region is not "
+                    "the headline's; convolutions of the Unet / VQ-VAE / decoder through MIOpen (SURVEY 8f next rows)"}
+
+
 def cpu_baseline(host, out, V, budget_s=20.0):
     """The oracle (CPU restatement of the reference path, kind 'port') on this box's host cores, on a
     bounded sample: one view's project+splat+order/masks, plus a few reference-style AR steps (one full
@@ -382,23 +476,38 @@ def cpu_baseline(host, out, V, budget_s=20.0):
     masks = tuple(torch.from_numpy(info[k]) for k in ("mask_init", "mask_undilated", "mask_dilated"))
     codes = torch.from_numpy(host["codes"][v:v + 1])
     x = torch.nn.functional.one_hot(codes, 512).permute(0, 3, 1, 2).float()
+    # the CPU path run sensibly: MKL oversubscribes on 1024-location tensors (128 threads: 540 ms per forward where 8 cores
+    # of the survey box took 105 ms), so the thread count is swept and the best one is what is reported
+    all_threads = int(torch.get_num_threads())
+    sweep = {}
     with torch.no_grad():
-        lo.pixelcnn_forward(sd, x, *masks)  # warm-up
+        for nt in sorted({t_ for t_ in (4, 8, 16, 32, 64, all_threads) if t_ <= all_threads}):
+            torch.set_num_threads(nt)
+            lo.pixelcnn_forward(sd, x, *masks)  # warm-up
+            t0 = time.perf_counter()
+            for _ in range(3):
+                lo.pixelcnn_forward(sd, x, *masks)
+            sweep[nt] = (time.perf_counter() - t0) / 3
+        best_nt = min(sweep, key=sweep.get)
+        torch.set_num_threads(best_nt)
         t0 = time.perf_counter()
         n = 0
         while n < 8 or (time.perf_counter() - t0 < budget_s and n < 64):
             lo.pixelcnn_forward(sd, x, *masks)
             n += 1
         t_step = (time.perf_counter() - t0) / n
+        torch.set_num_threads(all_threads)
     frame_s = t_splat + t_plan + n_sampled * t_step
     mean_sampled = float(np.mean(out["plan"].n_sampled))
     frame_mean_s = t_splat + t_plan + mean_sampled * t_step
-    return {"value": round(1.0 / frame_mean_s, 5), "unit": "frames/s", "cores": int(torch.get_num_threads()),
+    return {"value": round(1.0 / frame_mean_s, 5), "unit": "frames/s", "cores": best_nt,
             "kind": "port",
             "sample": (f"1 of {V} views on the host: oracle project+splat {t_splat:.3f}s (C/OpenMP) + order/masks "
                        f"{t_plan * 1e3:.1f}ms + {n} reference-style AR steps at {t_step * 1e3:.1f} ms/step (one full fp32 "
-                       f"forward per sampled code, torch CPU), extrapolated to the sweep's mean of {mean_sampled:.0f} "
-                       f"sampled codes/view (the +0.6 rad view alone: {n_sampled} codes, {frame_s:.1f} s/frame)"),
+                       f"forward per sampled code, torch CPU on {best_nt} threads -- the best of the sweep), extrapolated to the "
+                       f"sweep's mean of {mean_sampled:.0f} sampled codes/view (the +0.6 rad view alone: {n_sampled} codes, "
+                       f"{frame_s:.1f} s/frame)"),
+            "thread_sweep_ms_per_forward": {str(k): round(v * 1e3, 1) for k, v in sweep.items()},
             "host_cpus": os.cpu_count()}
 
 
@@ -408,7 +517,12 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--views", type=int, default=128, help="independent novel views per GPU per step (128 = C5: 8 sources x 16 views)")
-    ap.add_argument("--cameras", choices=["mp3d", "demo"], default="mp3d", help="Matterport-shaped (C5) or demo / RealEstate10K-shaped inputs")
+    ap.add_argument("--total-views", type=int, default=0, help="STRONG scaling: the job is this many views in TOTAL, dealt round-robin over the "
+                    "ranks (C5 proper on 8 GPUs: --total-views 128 = 16 per GPU); overrides --views")
+    ap.add_argument("--trajectory", choices=["sweep", "circle"], default="sweep", help="circle = config C4: one source, --frames poses of the "
+                    "'C' circle (demo cameras), every frame rendered from the source, frames dealt round-robin over the ranks (strong scaling)")
+    ap.add_argument("--frames", type=int, default=64, help="--trajectory circle: frames of the circle in total")
+    ap.add_argument("--cameras", choices=["mp3d", "demo"], default=None, help="Matterport-shaped (C5, default) or demo / RealEstate10K-shaped inputs (default for the circle)")
     ap.add_argument("--depth", choices=["smooth", "uniform"], default="smooth")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the C3 single-view / C2 splat-only side measurements")
@@ -437,9 +551,20 @@ def main():
         else:
             torch.distributed.init_process_group("nccl", device_id=device)
 
-    V = args.views
+    circle = args.trajectory == "circle"
+    if args.cameras is None:
+        args.cameras = "demo" if circle else "mp3d"
+    total = args.frames if circle else args.total_views
+    strong = total > 0
+    if strong and total % world:
+        raise SystemExit(f"{total} views do not deal evenly over {world} ranks")
+    V = total // world if strong else args.views
     model = build_model(device)
-    d, host = make_inputs(rank, V, device, smooth=args.depth == "smooth", cameras=args.cameras)
+    if strong:   # one job for all ranks (seeded as rank 0's), this rank's round-robin share of it
+        d, host = make_inputs(0, total, device, smooth=args.depth == "smooth", cameras=args.cameras, trajectory=args.trajectory,
+                              ids=D.shard_views(total, rank, world))
+    else:
+        d, host = make_inputs(rank, V, device, smooth=args.depth == "smooth", cameras=args.cameras)
     def barrier():
         D.barrier()
         torch.cuda.synchronize()
@@ -455,17 +580,22 @@ def main():
     elapsed = D.max_over_ranks(dt, None if dry else device)
 
     if rank == 0 and args.dump_gather and world > 1:
-        np.savez_compressed(args.dump_gather, all_codes=out["all_codes"].cpu().numpy(), all_frames_u8=out["all_frames_u8"].cpu().numpy())
+        np.savez_compressed(args.dump_gather, all_codes=out["all_codes"].cpu().numpy(), all_features_u8=out["all_features_u8"].cpu().numpy())
     if rank == 0:
-        frames = V * world * args.steps
+        frames = V * world * args.steps   # (strong: V * world = the job's total)
         plan = out["plan"]
         res = {
             "metric": "novel-view frames/sec @256x256 (reproject+AR outpaint)",
             "value": round(frames / elapsed, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": (f"C5 on every GPU: {host['n_src']} source image(s) x {-(-V // host['n_src'])} independent novel views = {V} views per "
-                                    f"GPU per step (yaw sweep +-0.6 rad per source, "
+            "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": ((f"C4: the {total}-frame 'C' circle from one source, {V} frame(s) per GPU per step (every frame rendered from the source, "
+                                     if circle else
+                                     f"{'C5' if total == 128 else 'C5-shaped job'}: {total} views in total = {host['n_src']} source image(s) x {host['per_source']} novel views, "
+                                     f"dealt round-robin, {V} per GPU per step (yaw sweep +-0.6 rad per source, "
+                                     if strong else
+                                     f"{'C5 on every GPU' if V == 128 and args.cameras == 'mp3d' else 'C5-shaped batch on every GPU'}: {host['n_src']} source image(s) x "
+                                     f"{host['per_source']} independent novel views = {V} views per GPU per step (yaw sweep +-0.6 rad per source, ")
                                     + ("Matterport-shaped cameras K = diag(1/tan(hfov/2)) at hfov 90 deg, " if args.cameras == "mp3d"
                                        else "demo / RealEstate10K-shaped cameras, ")
                                     + f"256x256 RGB features, {args.depth} depth {'0.5..10' if args.cameras == 'mp3d' else '1..100'}, "
@@ -475,7 +605,7 @@ def main():
                        "views_per_gpu": V, "image": "256x256", "code_grid": "32x32", "num_classes": 512,
                        "ar_steps_walked": 1024 - plan.first_step,
                        "sampled_codes_per_view_mean": round(float(np.mean(plan.n_sampled)), 1),
-                       "parallelism": f"views sharded over {world} GPU(s), RCCL all_gather of the finished 8-bit frames + codes"},
+                       "parallelism": f"views sharded over {world} GPU(s), RCCL all_gather of the reprojected views (8-bit) + completed code grids"},
         }
         if world == 1:
             try:

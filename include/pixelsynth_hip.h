@@ -24,13 +24,20 @@
 extern "C" {
 #endif
 
-#define PS_ABI_VERSION 1
+#define PS_ABI_VERSION 2
 
 enum { PS_OK = 0, PS_ERR_ARG = -1, PS_ERR_HIP = -2, PS_ERR_WORKSPACE = -3, PS_ERR_STATE = -4 };
 enum { PS_ACC_ALPHACOMPOSITE = 0, PS_ACC_WSUM = 1, PS_ACC_WSUMNORM = 2 }; /* opts.accumulation */
+/* Bits of a caller-owned device status word (`int32_t *status`, zero-initialised by the caller, may be NULL): asynchronous
+ * entry points that can only detect bad DATA on the device raise them there; ps_read_status turns them into an error. */
+enum { PS_STATUS_BAD_ORDER = 1, PS_STATUS_BAD_PIXEL = 2 };
 
 int ps_abi_version(void);
 const char *ps_last_error(void);
+/* Synchronises `stream`, reads the caller's status word and clears it: PS_OK when no asynchronous call that was handed this
+ * word has raised a bit since the last read, otherwise PS_ERR_STATE with the decoded bits in ps_last_error().  (The library
+ * itself keeps no flag: no global mutable state.) */
+int ps_read_status(int32_t *status, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Reprojection + soft z-buffer splat
@@ -118,9 +125,10 @@ int ps_ar_plan(const uint8_t *bg, int B, int S, int G, int32_t *order_loc, uint8
 /* The three kernel masks of ps_ar_plan / ps_kernel_masks_f32 on the DEVICE, from generation orders that are already there:
  * order_loc (F,L) int32 device -> mask_init / mask_undilated / mask_dilated (F,9,L) f32 device (type A dil 1, type B dil 1,
  * type B dil 2; masking.py:287-370).  Saves the 27 floats per location a host-built plan sends over PCIe (14 MB at 128
- * views); asynchronous on `stream`. */
+ * views); asynchronous on `stream`.  An order that is no permutation of the H*W locations raises PS_STATUS_BAD_ORDER in
+ * `status` (its out-of-range entries are skipped). */
 int ps_order_masks_f32(const int32_t *order_loc, int F, int H, int W, float *mask_init, float *mask_undilated,
-                       float *mask_dilated, void *stream);
+                       float *mask_dilated, int32_t *status, void *stream);
 
 /* Wavefront schedule of an AR run (host).  In the exact incremental form of sample() (models/lmconv/sample.py:24-66)
  * the column of order position i of a frame reads only the finished columns of locations that are a 3x3 tap neighbour
@@ -273,9 +281,28 @@ int ps_pixelcnn_time_column_step(ps_pixelcnn *h, const int32_t *codes, const int
  * the reference sorts the points by z and assigns  out[b, 0|1, ys, xs] = v0|v1  for all of them at once; with the sequential
  * semantics of torch's CPU index_put_ the LAST point in sorted order that lands on a pixel stays.  ys / xs (B,N) int32: pixel of
  * the n-th point in sorted order (inside the image: the reference clamps first), v0 / v1 (B,N) f32 its values; out (B,2,H,W) f32
- * pre-filled by the caller (the reference's -2); winner (B,H,W) int32 workspace.  z-test = atomic max of the sorted position. */
+ * pre-filled by the caller (the reference's -2); winner (B,H,W) int32 workspace.  z-test = atomic max of the sorted position.
+ * A pixel outside the image raises PS_STATUS_BAD_PIXEL in `status` and the point is dropped (the reference's indexed
+ * assignment would raise). */
 int ps_zbuffer_scatter_f32(const int32_t *ys, const int32_t *xs, const float *v0, const float *v1, int B, int N,
-                           int H, int W, float *out, int32_t *winner, void *stream);
+                           int H, int W, float *out, int32_t *winner, int32_t *status, void *stream);
+
+/* The projection in front of it, DepthManipulator.project_zbuffer :43-66 and :86-87, one thread per source pixel:
+ *   depth (B,1,W,W) f32, grid (4,W*W) f32 = the module's `grid` buffer (x, y, -1, 1 rows; :20-26), cameras (B,4,4)  ->
+ *   zproj (B,N) f32 = third row of K (RT2 RT1inv) Kinv (grid * depth) (the sort key; the returned depth is -zproj),
+ *   ys / xs (B,N) int32 = ((sampler + 1) * 128).long().clamp(0, 255) with the reference's literals, flag (B,N) f32 = 4 where
+ *   the unclamped coordinate left [0, 255], else 0 -- all by ORIGINAL point position.  W must be 256 for the literals to
+ *   mean what the reference means (the Python mirror refuses anything else). */
+int ps_zbuffer_project_f32(const float *depth, const float *grid, const float *K, const float *Kinv, const float *RT1inv,
+                           const float *RT2, int B, int W, float *zproj, int32_t *ys, int32_t *xs, float *flag, void *stream);
+
+/* ps_zbuffer_scatter_f32 on the outputs of ps_zbuffer_project_f32 and the caller's argsort of zproj (descending, stable):
+ * order (B,N) int64 = point at each sorted position; sorted position n writes  grid_x[order[n]] + flag[n]  and
+ * -grid_y[order[n]] + flag[n]  at pixel (ys, xs)[order[n]] -- the flag by ORIGINAL position on values in SORTED order, as the
+ * reference does (:88-97). */
+int ps_zbuffer_scatter_sorted_f32(const int64_t *order, const int32_t *ys, const int32_t *xs, const float *grid,
+                                  const float *flag, int B, int N, int H, int W, float *out, int32_t *winner,
+                                  int32_t *status, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Vector quantisation around the AR loop (VQ-VAE-2 top level, models/vqvae2/vqvae.py) -- SURVEY 8f row 1

@@ -25,7 +25,8 @@ _PROTOS = {
                                                       c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "ps_generation_order": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "ps_ar_plan": (c_int, [c_void_p, c_int, c_int, c_int] + [c_void_p] * 6),
-    "ps_order_masks_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ps_order_masks_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ps_read_status": (c_int, [c_void_p, c_void_p]),
     "ps_custom_order": (c_int, [c_int, c_int, c_void_p, c_void_p]),
     "ps_kernel_masks_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "ps_lmconv_workspace_bytes": (c_size_t, [c_int] * 5),
@@ -41,7 +42,9 @@ _PROTOS = {
     "ps_ar_wavefronts_capped": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "ps_pixelcnn_status": (c_int, [c_void_p, c_void_p]),
     "ps_pixelcnn_debug_cache": (c_void_p, [c_void_p, c_int, c_int]),
-    "ps_zbuffer_scatter_f32": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p] * 3),
+    "ps_zbuffer_scatter_f32": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p] * 4),
+    "ps_zbuffer_project_f32": (c_int, [c_void_p] * 6 + [c_int, c_int] + [c_void_p] * 5),
+    "ps_zbuffer_scatter_sorted_f32": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_void_p] * 4),
     "ps_vq_nearest_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "ps_vq_embed_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ps_affine_relu_nhwc_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
@@ -97,6 +100,26 @@ def ptr(t):
 def current_stream():
     import torch
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+_STATUS = {}
+
+
+def status_word(device=None):
+    """The caller-owned status word (int32, zero) of a device that asynchronous entry points raise bits in
+    (include/pixelsynth_hip.h: PS_STATUS_*); one per device, owned by this binding -- the library keeps none."""
+    import torch
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    t = _STATUS.get(idx)
+    if t is None:
+        t = _STATUS[idx] = torch.zeros(1, dtype=torch.int32, device=torch.device("cuda", idx))
+    return t
+
+
+def read_status(what, device=None):
+    """Synchronise the current stream and raise if an asynchronous call raised a bit in the device's status word."""
+    check(lib().ps_read_status(ptr(status_word(device)), current_stream()), what)
 
 
 def require_cuda(*tensors):

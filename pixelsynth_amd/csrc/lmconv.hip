@@ -2208,7 +2208,7 @@ __global__ void k_pack_valu_out(const float *wo /*[20][512][4]*/, float *out)
 
 // kernel masks from generation orders, on the device (masking.py:287-370: tap open iff the neighbour precedes the location in
 // the order; centre 0 for type A, 1 for type B).  One block per frame: ranks in LDS, then the 3 x 9 x L mask values.
-__global__ __launch_bounds__(256) void k_order_masks(const int32_t *order_loc, int H, int W, float *m_init, float *m_und, float *m_dil, int *err)
+__global__ __launch_bounds__(256) void k_order_masks(const int32_t *order_loc, int H, int W, float *m_init, float *m_und, float *m_dil, int32_t *status)
 {
     extern __shared__ int sRank[];
     const int L = H * W, f = blockIdx.x;
@@ -2217,7 +2217,7 @@ __global__ __launch_bounds__(256) void k_order_masks(const int32_t *order_loc, i
     __syncthreads();
     for (int k = threadIdx.x; k < L; k += blockDim.x) {
         const int q = ol[k];
-        if (q < 0 || q >= L) { *err = 3; continue; }
+        if (q < 0 || q >= L) { if (status) atomicOr(status, PS_STATUS_BAD_ORDER); continue; }
         sRank[q] = k;
     }
     __syncthreads();
@@ -2706,8 +2706,14 @@ void run_columns(ps_pixelcnn *h, const StepCtx *rec, int ncols, const int32_t *c
             for (int t = 0; t < tiles; ++t) h->tile_uses_tp[t] += 1;
             for (int t = 0; t < TP_MAX_TILES; ++t) ta.tile_uses[t] = h->tile_uses_tp[t];
             int grid;
+            // The XCD-affine layout assumes a whole MI355X (SPX mode: 8 XCDs x 32 CUs, block b on XCD b % 8).  On a partition
+            // (CPX: 32 CUs = one XCD per device) or any other CU count that mapping means nothing: the plain layout is used --
+            // neighbour blocks first in the grid, so they are dispatched ahead of the chain tiles that wait for them.  Either way
+            // the grid holds at most one workgroup per CU and the waits are bounded (40000 polls with s_sleep, tens of ms):
+            // kernels of OTHER streams that hold CUs for a while (bench.py / driver.py overlap the next batch's ~2 ms of splat
+            // kernels with this run) delay a launch, they cannot starve it past the bound.
             const int rows = h->n_cus / 8;   // CUs per XCD
-            if (h->tp_xcds != 0 && h->n_cus % 8 == 0 && rows > 0 && tiles <= 4 * rows) {
+            if (h->tp_xcds != 0 && h->n_cus == 8 * 32 && tiles <= 4 * rows) {
                 const int cx = h->tp_xcds > 0 ? std::max(h->tp_xcds, (tiles + rows - 1) / rows) : (tiles + rows - 1) / rows;
                 ta.chain_xcds = std::min(cx, 7);
                 const int spare = ta.chain_xcds * rows - tiles;
@@ -2768,14 +2774,12 @@ int check_handle(ps_pixelcnn *h, int F)
 extern "C" {
 
 int ps_order_masks_f32(const int32_t *order_loc, int F, int H, int W, float *mask_init, float *mask_undilated, float *mask_dilated,
-                       void *stream)
+                       int32_t *status, void *stream)
 {
     PS_REQUIRE(order_loc && mask_init && mask_undilated && mask_dilated, "order_masks: null pointer");
     PS_REQUIRE(F > 0 && H > 0 && W > 0 && (size_t)H * W * sizeof(int) <= 64 * 1024, "order_masks: bad sizes");
-    static int *d_err = nullptr;   // (flag for orders that are no permutation; never freed)
-    if (!d_err) { PS_HIP_CHECK(hipMalloc(&d_err, sizeof(int))); PS_HIP_CHECK(hipMemset(d_err, 0, sizeof(int))); }
     hipLaunchKernelGGL(k_order_masks, dim3(F), dim3(256), (size_t)H * W * sizeof(int), (hipStream_t)stream, order_loc, H, W, mask_init,
-                       mask_undilated, mask_dilated, d_err);
+                       mask_undilated, mask_dilated, status);
     PS_LAUNCH_CHECK();
     return PS_OK;
 }

@@ -487,7 +487,7 @@ __global__ __launch_bounds__(64) void k_composite(
 #pragma unroll
                     for (int c = 0; c < CG; ++c) {
                         const float f = h.f[c];
-                        if (MODE == PS_ACC_ALPHACOMPOSITE) acc[c] = acc[c] + f * cum * a;
+                        if (MODE == PS_ACC_ALPHACOMPOSITE) acc[c] = acc[c] + cum * a * f;   // PyTorch3D: cum_alpha * alpha * feature
                         else if (MODE == PS_ACC_WSUM) acc[c] = acc[c] + f * a;
                         else acc[c] = acc[c] + f * a / tsum;
                     }
@@ -749,54 +749,158 @@ int ps_project_splat_f32(const float *depth, const float *feat, const float *K, 
 }
 
 // ------------------------------------------------------------------------------------------
-// Hard z-buffer of DepthManipulator.project_zbuffer (models/projection/depth_manipulator.py:66-104): the reference sorts
-// the points by z and scatters their source coordinates into the target image with an indexed assignment, so that of
-// several points that land on one pixel the LAST one in sorted order stays (sequential semantics of torch's CPU
-// index_put_).  Here: the z-test is an atomic max on the sorted position per pixel, then every winner writes its values.
-// ys / xs (B,N) int32 pixel of the n-th point in sorted order, v0 / v1 (B,N) its two values; out (B,2,H,W) pre-filled by the
-// caller; winner (B,H,W) int32 workspace.
+// Hard z-buffer of DepthManipulator.project_zbuffer (models/projection/depth_manipulator.py:37-104).
+//   k_zb_project   :43-66 -- one thread per source pixel: p = grid * depth (w = 1), X = K (RT2 RT1inv) Kinv p in the
+//                  association order of the reference's products (mul, add, ascending k; this unit is built with
+//                  -ffp-contract=off), EPS rule, the literal (sampler + 1) * 128 pixel mapping, .long().clamp(0, 255) and the
+//                  out-of-range flag (:86-87).  Everything by ORIGINAL point position; the sort by z stays with the caller.
+//   k_zb_test / k_zb_write   the z-test: the reference scatters the sorted points with an indexed assignment, so that of
+//                  several points on one pixel the LAST one in sorted order stays (sequential semantics of torch's CPU
+//                  index_put_).  Here: atomic max of the sorted position per pixel, then every winner writes its values.
+//                  With `order` (the caller's argsort) the per-point data is read through it and the values are built in
+//                  place: v0 = grid_x[order[n]] + flag[n], v1 = -grid_y[order[n]] + flag[n] -- the flag by ORIGINAL position
+//                  on values in SORTED order, a quirk of the reference that is kept (:88-97).
+// A pixel outside the image raises bit 1 of the caller's status word (ps_read_status) and the point is dropped.
 // ------------------------------------------------------------------------------------------
 namespace {
+__global__ __launch_bounds__(256) void k_zb_project(const float *__restrict__ depth, const float *__restrict__ grid,
+                                                    const float *__restrict__ K, const float *__restrict__ Kinv,
+                                                    const float *__restrict__ RT1inv, const float *__restrict__ RT2, int N,
+                                                    float *__restrict__ zproj, int32_t *__restrict__ ys, int32_t *__restrict__ xs,
+                                                    float *__restrict__ flag)
+{
+    __shared__ float sRT[16], sK[16], sKinv[16];
+    const int b = blockIdx.y;
+    if (threadIdx.x < 16) {
+        const int i = threadIdx.x >> 2, j = threadIdx.x & 3;
+        const float *A = RT2 + b * 16, *Bm = RT1inv + b * 16;
+        float acc = A[i * 4 + 0] * Bm[0 * 4 + j];
+        acc = acc + A[i * 4 + 1] * Bm[1 * 4 + j];
+        acc = acc + A[i * 4 + 2] * Bm[2 * 4 + j];
+        acc = acc + A[i * 4 + 3] * Bm[3 * 4 + j];
+        sRT[threadIdx.x] = acc;
+        sK[threadIdx.x] = K[b * 16 + threadIdx.x];
+        sKinv[threadIdx.x] = Kinv[b * 16 + threadIdx.x];
+    }
+    __syncthreads();
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const float d = depth[(size_t)b * N + n];
+    float p[4] = {grid[n] * d, grid[N + n] * d, grid[2 * (size_t)N + n] * d, 1.0f}, c[4], w[4], X[4];
+    mat4_vec(sKinv, p, c);
+    mat4_vec(sRT, c, w);
+    mat4_vec(sK, w, X);
+    const bool bad = fabsf(X[2]) < PS_EPS;
+    float sx = X[0] / -X[2], sy = X[1] / -X[2];
+    if (bad) { sx = -10.0f; sy = -10.0f; }
+    sy = -sy;
+    const float tx = (sx + 1.0f) * 128.0f, ty = (sy + 1.0f) * 128.0f;
+    // .long() truncates towards zero, then clamp(0, 255); NaN -> 0 like the reference's LONG_MIN
+    auto pixel = [](float t) { return !(t > 0.0f) ? 0 : t >= 255.0f ? 255 : (int)t; };
+    const size_t o = (size_t)b * N + n;
+    zproj[o] = X[2];
+    xs[o] = pixel(tx);
+    ys[o] = pixel(ty);
+    flag[o] = (tx < 0.0f || tx > 255.0f || ty < 0.0f || ty > 255.0f) ? 4.0f : 0.0f;
+}
 __global__ void k_zb_reset(int32_t *winner, size_t n)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) winner[i] = -1;
 }
-__global__ void k_zb_test(const int32_t *ys, const int32_t *xs, int B, int N, int H, int W, int32_t *winner, int *bad)
+__global__ void k_zb_test(const int64_t *order, const int32_t *ys, const int32_t *xs, int B, int N, int H, int W, int32_t *winner,
+                          int32_t *status)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)B * N) return;
-    const int b = (int)(i / N), n = (int)(i - (size_t)b * N), y = ys[i], x = xs[i];
-    if (y < 0 || y >= H || x < 0 || x >= W) { *bad = 1; return; }
+    const int b = (int)(i / N), n = (int)(i - (size_t)b * N);
+    size_t src = i;
+    if (order) {
+        const int64_t p = order[i];
+        if (p < 0 || p >= N) { if (status) atomicOr(status, PS_STATUS_BAD_PIXEL); return; }
+        src = (size_t)b * N + (size_t)p;
+    }
+    const int y = ys[src], x = xs[src];
+    if (y < 0 || y >= H || x < 0 || x >= W) { if (status) atomicOr(status, PS_STATUS_BAD_PIXEL); return; }
     atomicMax(&winner[((size_t)b * H + y) * W + x], n);
 }
-__global__ void k_zb_write(const int32_t *ys, const int32_t *xs, const float *v0, const float *v1, int B, int N, int H, int W,
-                           const int32_t *winner, float *out)
+__global__ void k_zb_write(const int64_t *order, const int32_t *ys, const int32_t *xs, const float *v0, const float *v1,
+                           const float *grid, const float *flag, int B, int N, int H, int W, const int32_t *winner, float *out)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)B * N) return;
-    const int b = (int)(i / N), n = (int)(i - (size_t)b * N), y = ys[i], x = xs[i];
+    const int b = (int)(i / N), n = (int)(i - (size_t)b * N);
+    size_t src = i;
+    int64_t p = n;
+    if (order) {
+        p = order[i];
+        if (p < 0 || p >= N) return;
+        src = (size_t)b * N + (size_t)p;
+    }
+    const int y = ys[src], x = xs[src];
     if (y < 0 || y >= H || x < 0 || x >= W) return;
     if (winner[((size_t)b * H + y) * W + x] != n) return;
-    out[(((size_t)b * 2 + 0) * H + y) * W + x] = v0[i];
-    out[(((size_t)b * 2 + 1) * H + y) * W + x] = v1[i];
+    float a0, a1;
+    if (order) { a0 = grid[p] + flag[i]; a1 = -grid[N + p] + flag[i]; }   // (flag by original position n, values by sorted source p)
+    else { a0 = v0[i]; a1 = v1[i]; }
+    out[(((size_t)b * 2 + 0) * H + y) * W + x] = a0;
+    out[(((size_t)b * 2 + 1) * H + y) * W + x] = a1;
 }
 }  // namespace
 
+int ps_zbuffer_project_f32(const float *depth, const float *grid, const float *K, const float *Kinv, const float *RT1inv,
+                           const float *RT2, int B, int W, float *zproj, int32_t *ys, int32_t *xs, float *flag, void *stream)
+{
+    PS_REQUIRE(depth && grid && K && Kinv && RT1inv && RT2 && zproj && ys && xs && flag, "zbuffer_project: null pointer");
+    PS_REQUIRE(B > 0 && W > 1, "zbuffer_project: B > 0 and W > 1 required");
+    const int N = W * W;
+    hipLaunchKernelGGL(k_zb_project, dim3((N + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, depth, grid, K, Kinv, RT1inv, RT2,
+                       N, zproj, ys, xs, flag);
+    PS_LAUNCH_CHECK();
+    return PS_OK;
+}
+
+static int zb_scatter(const int64_t *order, const int32_t *ys, const int32_t *xs, const float *v0, const float *v1, const float *grid,
+                      const float *flag, int B, int N, int H, int W, float *out, int32_t *winner, int32_t *status, hipStream_t st)
+{
+    const size_t np = (size_t)B * H * W, nn = (size_t)B * N;
+    hipLaunchKernelGGL(k_zb_reset, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st, winner, np);
+    hipLaunchKernelGGL(k_zb_test, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, order, ys, xs, B, N, H, W, winner, status);
+    hipLaunchKernelGGL(k_zb_write, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, order, ys, xs, v0, v1, grid, flag, B, N, H, W,
+                       winner, out);
+    PS_LAUNCH_CHECK();
+    return PS_OK;
+}
+
 int ps_zbuffer_scatter_f32(const int32_t *ys, const int32_t *xs, const float *v0, const float *v1, int B, int N, int H, int W,
-                           float *out, int32_t *winner, void *stream)
+                           float *out, int32_t *winner, int32_t *status, void *stream)
 {
     PS_REQUIRE(ys && xs && v0 && v1 && out && winner, "zbuffer_scatter: null pointer");
     PS_REQUIRE(B > 0 && N > 0 && H > 0 && W > 0, "zbuffer_scatter: bad sizes");
+    return zb_scatter(nullptr, ys, xs, v0, v1, nullptr, nullptr, B, N, H, W, out, winner, status, (hipStream_t)stream);
+}
+
+int ps_zbuffer_scatter_sorted_f32(const int64_t *order, const int32_t *ys, const int32_t *xs, const float *grid, const float *flag,
+                                  int B, int N, int H, int W, float *out, int32_t *winner, int32_t *status, void *stream)
+{
+    PS_REQUIRE(order && ys && xs && grid && flag && out && winner, "zbuffer_scatter_sorted: null pointer");
+    PS_REQUIRE(B > 0 && N > 0 && H > 0 && W > 0, "zbuffer_scatter_sorted: bad sizes");
+    return zb_scatter(order, ys, xs, nullptr, nullptr, grid, flag, B, N, H, W, out, winner, status, (hipStream_t)stream);
+}
+
+int ps_read_status(int32_t *status, void *stream)
+{
+    PS_REQUIRE(status, "read_status: null pointer");
     hipStream_t st = (hipStream_t)stream;
-    const size_t np = (size_t)B * H * W, nn = (size_t)B * N;
-    static int *d_bad = nullptr;   // (pixels outside the image are a caller error: the reference clamps before it scatters)
-    if (!d_bad) { PS_HIP_CHECK(hipMalloc(&d_bad, sizeof(int))); PS_HIP_CHECK(hipMemset(d_bad, 0, sizeof(int))); }
-    hipLaunchKernelGGL(k_zb_reset, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st, winner, np);
-    hipLaunchKernelGGL(k_zb_test, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, ys, xs, B, N, H, W, winner, d_bad);
-    hipLaunchKernelGGL(k_zb_write, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, ys, xs, v0, v1, B, N, H, W, winner, out);
-    PS_LAUNCH_CHECK();
-    return PS_OK;
+    int32_t v = 0;
+    PS_HIP_CHECK(hipMemcpyAsync(&v, status, sizeof(v), hipMemcpyDeviceToHost, st));
+    PS_HIP_CHECK(hipStreamSynchronize(st));
+    if (!v) return PS_OK;
+    PS_HIP_CHECK(hipMemsetAsync(status, 0, sizeof(v), st));
+    return ps::fail(PS_ERR_STATE, "device status 0x%x:%s%s", (unsigned)v,
+                    (v & PS_STATUS_BAD_ORDER) ? " a generation order that is no permutation of the grid (ps_order_masks_f32);" : "",
+                    (v & PS_STATUS_BAD_PIXEL) ? " points outside the image or the sort order dropped by the z-buffer scatter "
+                                                "(ps_zbuffer_scatter_f32: the reference clamps before it scatters);" : "");
 }
 
 }  // extern "C"

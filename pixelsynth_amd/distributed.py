@@ -69,6 +69,33 @@ def owner_of(index, world_size=None):
     return index % world_size
 
 
+def broadcast_from(tensor, src, device):
+    """Broadcast `tensor` from rank `src` to every rank; the other ranks pass None (or anything) and learn shape and dtype
+    from the owner first -- a rank that holds no candidate of its own cannot know the shape of a decoded / refined image
+    (it is not gen_fs's when the features are not RGB).  -> the tensor, on `device`, on every rank."""
+    rank, w = world()
+    if w == 1:
+        return tensor
+    gloo = dist.get_backend() == "gloo"
+    meta = torch.zeros(8, dtype=torch.int64)
+    if rank == src:
+        meta[0] = tensor.dim()
+        meta[1:1 + tensor.dim()] = torch.tensor(tensor.shape, dtype=torch.int64)
+        meta[7] = {torch.float32: 0, torch.uint8: 1, torch.float16: 2, torch.bfloat16: 3}[tensor.dtype]
+    meta = meta if gloo else meta.to(device)
+    dist.broadcast(meta, src=src)
+    meta = meta.cpu()
+    shape = tuple(int(x) for x in meta[1:1 + int(meta[0])])
+    dtype = (torch.float32, torch.uint8, torch.float16, torch.bfloat16)[int(meta[7])]
+    if rank == src:
+        buf = tensor.contiguous()
+        buf = buf.cpu() if gloo else buf
+    else:
+        buf = torch.empty(shape, dtype=dtype, device="cpu" if gloo else device)
+    dist.broadcast(buf, src=src)
+    return buf.to(device)
+
+
 def gather_scores(disc_local, entr_local, n):
     """Sample ranking across ranks: every rank scored the candidates shard_views(n) gave it -- discriminator score
     and classifier entropy, two scalars each -- and all ranks need all n of both to apply the rank rule.  One all_gather of a

@@ -301,7 +301,10 @@ COLUMNS_PER_LAUNCH_TP = int(os.environ.get("PS_WAVE_COLS_TP", "1024"))
 TP_MIN_FRAMES = int(os.environ.get("PS_TP_MIN_FRAMES", "60"))
 
 
-_COLS_STAGE = {}
+import threading
+
+_COLS_STAGE = {}            # page-locked staging for the schedule upload, one buffer per power-of-two capacity, the two largest kept
+_COLS_LOCK = threading.Lock()
 
 
 def launch_capacity(frames):
@@ -317,12 +320,21 @@ def wavefronts(order_host, H, W, first_step, device=None, max_cols=None):
     F_, L = order_host.shape
     if max_cols is None:
         max_cols = launch_capacity(F_)
+    with _COLS_LOCK:     # the staging buffer is shared state: one schedule is staged at a time
+        return _wavefronts(order_host, F_, L, H, W, first_step, device, max_cols)
+
+
+def _wavefronts(order_host, F_, L, H, W, first_step, device, max_cols):
+    import ctypes
     nsteps = L - first_step
     n = F_ * nsteps
     cap = 1 << max(10, int(max(n, 1) - 1).bit_length())          # page-locked staging, kept per power-of-two capacity
     stage = _COLS_STAGE.get(cap) if device is not None else None
     if device is not None and stage is None:
         stage = _COLS_STAGE[cap] = torch.empty((cap, 2), dtype=torch.int32, pin_memory=torch.cuda.is_available())
+        for old in sorted(_COLS_STAGE)[:-2]:                     # (bounded: callers that vary their batch do not pile up pinned memory)
+            if old != cap:
+                del _COLS_STAGE[old]
     cols = stage.numpy() if stage is not None else np.empty((max(n, 1), 2), np.int32)
     wave_start = np.zeros(nsteps + (n + max_cols - 1) // max_cols + 2 if max_cols else nsteps + 1, np.int32)
     nw = ctypes.c_int32(0)

@@ -155,7 +155,16 @@ def _conv_split(conv, x):
     (CPU, autograd, channel counts the kernels do not take): (conv(x), None)."""
     if conv.bias is None or torch.is_grad_enabled() or not _is_nhwc_cuda(x) or conv.out_channels % 4:
         return conv(x), None
-    for hook in conv._forward_pre_hooks.values():   # spectral norm recomputes .weight in a forward pre-hook
+    # Only a plain Conv2d, or one whose single extra is the legacy torch.nn.utils.spectral_norm pre-hook (it recomputes
+    # .weight from weight_orig / u / v and returns nothing), is taken apart here; anything else -- forward hooks, the
+    # parametrizations API, a pre-hook that edits the input, another padding mode -- goes through Module.__call__ untouched.
+    from torch.nn.utils.spectral_norm import SpectralNorm
+    pre = list(conv._forward_pre_hooks.values())
+    plain = (type(conv) is nn.Conv2d and not conv._forward_hooks and not getattr(conv, "parametrizations", None)
+             and conv.padding_mode == "zeros" and all(isinstance(h, SpectralNorm) for h in pre))
+    if not plain:
+        return conv(x), None
+    for hook in pre:
         hook(conv, (x,))
     return F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups), conv.bias
 

@@ -4,8 +4,10 @@ the visible / invisible regions of a target view: every source pixel is unprojec
 and the source coordinate of the point that wins the z-test is written at the pixel it lands on -- a backward sampler for
 grid_sample.
 
-The projection is a handful of (B,4,4) products, done with torch on the device in the reference's association order; the
-z-test scatter -- the part with a data-dependent write order -- is the HIP kernel ps_zbuffer_scatter_f32.  What "wins" is
+Both halves are HIP kernels behind the C ABI: ps_zbuffer_project_f32 (unprojection, the (B,4,4) camera products in the
+reference's association order, EPS rule, pixel mapping and out-of-range flag: one thread per source pixel instead of a dozen
+small torch launches) and ps_zbuffer_scatter_sorted_f32 (the z-test, the part with a data-dependent write order); the sort by
+projected z in between is torch's (stable, descending -- what the reference calls).  What "wins" is
 defined by what the reference computes on the CPU (index_put_ processes the sorted points in order, the last write stays):
 points sorted by projected z, descending, stably; of several points on one pixel the one sorted LAST stays.  (That is the
 FARTHEST point -- z is negative in front of the camera -- whatever the reference's comment intends; its CUDA path leaves the
@@ -37,31 +39,23 @@ class DepthManipulator(nn.Module):
         """depth (B,1,w,h), cameras (B,4,4) -> (bilinear_sampler (B,2,w,h), projected depth (B,1,w,h))."""
         _lib.require_cuda(depth, K, K_inv, RTinv_cam1, RT_cam2)
         bs, _, w, h = depth.size()
-        orig_xys = self.grid.to(depth.device).repeat(bs, 1, 1, 1)
-        xys = orig_xys * depth
-        xys[:, -1, :] = 1
-        xys = xys.view(bs, 4, -1)
-        cam1_X = K_inv.bmm(xys)
-        RT = RT_cam2.bmm(RTinv_cam1)
-        wrld_X = RT.bmm(cam1_X)
-        xy_proj = K.bmm(wrld_X)
-        mask = xy_proj[:, 2:3, :].abs() < EPS
-        sampler = xy_proj[:, 0:2, :] / -xy_proj[:, 2:3, :]
-        sampler[mask.repeat(1, 2, 1)] = -10
-        sampler[:, 1, :] = -sampler[:, 1, :]
-        tsampler = ((sampler + 1) * 128).view(bs, 2, -1)
-        _, sampler_inds = xy_proj[:, 2:3, :].sort(dim=2, descending=True, stable=True)
-        order = sampler_inds[:, 0]                                                   # (B,N) point at each sorted position
-        xs = torch.gather(tsampler[:, 0], 1, order).long().clamp(min=0, max=255)
-        ys = torch.gather(tsampler[:, 1], 1, order).long().clamp(min=0, max=255)
-        flag = ((tsampler < 0) | (tsampler > 255)).float().max(dim=1)[0] * 4         # (B,N), by ORIGINAL position (:86-87)
-        oxy = orig_xys[:, :2].reshape(bs, 2, -1)
-        v0 = (torch.gather(oxy[:, 0], 1, order) + flag).contiguous()
-        v1 = (-torch.gather(oxy[:, 1], 1, order) + flag).contiguous()
-        out = torch.full((bs, 2, w, h), -2.0, device=depth.device, dtype=torch.float32)
-        winner = torch.empty(bs, w, h, dtype=torch.int32, device=depth.device)
-        ys32, xs32 = ys.to(torch.int32).contiguous(), xs.to(torch.int32).contiguous()
-        rc = _lib.lib().ps_zbuffer_scatter_f32(_lib.ptr(ys32), _lib.ptr(xs32), _lib.ptr(v0), _lib.ptr(v1), bs, w * h, w, h,
-                                               _lib.ptr(out), _lib.ptr(winner), _lib.current_stream())
-        _lib.check(rc, "ps_zbuffer_scatter_f32")
-        return out, -xy_proj[:, 2:3, :].view(bs, 1, w, h)
+        if w != 256 or h != 256:   # the literals 128 / 255 of :66-90 only mean "the image" at 256 (the reference indexes out of bounds below it)
+            raise ValueError(f"DepthManipulator.project_zbuffer: {w}x{h} input; the reference's pixel mapping is written for 256x256")
+        dev, N = depth.device, w * h
+        grid = self.grid.to(dev).reshape(4, N).contiguous()
+        f32 = lambda t: t.to(torch.float32).contiguous()
+        depth, K, K_inv, RTinv_cam1, RT_cam2 = f32(depth), f32(K), f32(K_inv), f32(RTinv_cam1), f32(RT_cam2)
+        zproj = torch.empty(bs, N, dtype=torch.float32, device=dev)
+        ys, xs = torch.empty(bs, N, dtype=torch.int32, device=dev), torch.empty(bs, N, dtype=torch.int32, device=dev)
+        flag = torch.empty(bs, N, dtype=torch.float32, device=dev)
+        L = _lib.lib()
+        _lib.check(L.ps_zbuffer_project_f32(_lib.ptr(depth), _lib.ptr(grid), _lib.ptr(K), _lib.ptr(K_inv), _lib.ptr(RTinv_cam1),
+                                            _lib.ptr(RT_cam2), bs, w, _lib.ptr(zproj), _lib.ptr(ys), _lib.ptr(xs), _lib.ptr(flag),
+                                            _lib.current_stream()), "ps_zbuffer_project_f32")
+        order = zproj.sort(dim=1, descending=True, stable=True)[1].contiguous()      # (B,N) point at each sorted position (:68)
+        out = torch.full((bs, 2, w, h), -2.0, device=dev, dtype=torch.float32)
+        winner = torch.empty(bs, w, h, dtype=torch.int32, device=dev)
+        _lib.check(L.ps_zbuffer_scatter_sorted_f32(_lib.ptr(order), _lib.ptr(ys), _lib.ptr(xs), _lib.ptr(grid), _lib.ptr(flag), bs, N,
+                                                   w, h, _lib.ptr(out), _lib.ptr(winner), _lib.ptr(_lib.status_word(dev)),
+                                                   _lib.current_stream()), "ps_zbuffer_scatter_sorted_f32")
+        return out, (-zproj).view(bs, 1, w, h)

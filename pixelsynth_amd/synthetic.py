@@ -302,6 +302,18 @@ def fill_state_dict(shapes, seed=0):
     return out
 
 
+def resnet_state_dict(shapes, seed=0):
+    """fill_state_dict for the ResNet-18 scene classifier with wider convolution / head weights (U(+-sqrt(3 / fan_in))): the
+    activations keep their scale through the 18 layers (He-uniform's sqrt(6) saturates the softmax of this residual stack: the
+    reference's own entropy formula then yields 0 * log 0), so that the logits -- and the entropy score built on them -- are not
+    degenerate numbers a wrong layer could hide behind (logit std about 1.4, entropy about 4.3 of log 365 = 5.9)."""
+    out = fill_state_dict(shapes, seed)
+    for k, v in out.items():
+        if k.endswith(".weight") and v.ndim >= 2:
+            out[k] = (v * math.sqrt(3.0)).astype(np.float32)
+    return out
+
+
 def network_opts(**kw):
     """The generator options PixelSynth trains with (scripts/train_dpr_realestate.sh); an argparse.Namespace, which
     the reference tests with `"name" in opt`."""

@@ -45,15 +45,24 @@ class ARPlan:
         return self._n_sampled
 
 
-_PINNED = {}
+import collections
+import threading
+
+_PINNED = collections.OrderedDict()
+_PINNED_MAX = 12                       # staging buffers kept (four per batch shape): the oldest shapes are released
+_PLAN_LOCK = threading.RLock()         # the staging buffers are shared state: one plan is staged at a time per process
 
 
 def _pinned(name, shape, dtype):
-    """Page-locked staging buffers, kept per (name, shape): pageable copies ran at ~0.6 GB/s on the MI355X hosts."""
+    """Page-locked staging buffers (pageable copies ran at ~0.6 GB/s on the MI355X hosts), kept per (name, shape) in a small
+    LRU: callers that vary their batch size do not pile up pinned host memory.  Used under _PLAN_LOCK."""
     key = (name, tuple(shape), dtype)
-    t = _PINNED.get(key)
+    t = _PINNED.pop(key, None)
     if t is None:
-        t = _PINNED[key] = torch.empty(shape, dtype=dtype, pin_memory=True)
+        t = torch.empty(shape, dtype=dtype, pin_memory=True)
+    _PINNED[key] = t
+    while len(_PINNED) > _PINNED_MAX:
+        _PINNED.popitem(last=False)
     return t
 
 
@@ -62,6 +71,11 @@ def build_ar_plan(background_mask, G=32, device=None):
     One device->host copy of the mask (the reference does four, z_buffermodel.py:662-669), the integer work (pooling,
     distance transforms, generation order) in C++ on the host (csrc/host_order.cpp), the orders back up, and the three
     kernel masks built from them on the device (ps_order_masks_f32) -- nothing bigger than the orders crosses PCIe."""
+    with _PLAN_LOCK:
+        return _build_ar_plan(background_mask, G, device)
+
+
+def _build_ar_plan(background_mask, G, device):
     import ctypes
     device = device or (background_mask.device if background_mask.is_cuda else torch.device("cuda", torch.cuda.current_device()))
     B, S, _ = background_mask.shape
@@ -82,14 +96,39 @@ def build_ar_plan(background_mask, G=32, device=None):
     d_order, d_region = order_t.to(device, non_blocking=True), region_t.to(device, non_blocking=True)
     masks = [torch.empty(B, 9, L, dtype=torch.float32, device=device) for _ in range(3)]
     rc = _lib.lib().ps_order_masks_f32(_lib.ptr(d_order), B, G, G, _lib.ptr(masks[0]), _lib.ptr(masks[1]), _lib.ptr(masks[2]),
-                                       _lib.current_stream())
+                                       _lib.ptr(_lib.status_word(device)), _lib.current_stream())
     _lib.check(rc, "ps_order_masks_f32")
     order_host = order_loc.copy()       # (the staging buffer is reused by the next plan)
     plan = ARPlan(d_order, d_region, masks[0], masks[1], masks[2], int(first.value), order_host, G)
     plan._n_sampled = region.sum(1).astype(int)
     from .lmconv.model import wavefronts
     plan.waves = wavefronts(order_host, G, G, plan.first_step, device)   # (cols on the device, wave_start on the host)
-    torch.cuda.current_stream().synchronize()   # the staging buffers are free again
+    _lib.read_status("ps_order_masks_f32", device)   # synchronises: the staging buffers are free again, and a bad order is an error
+    return plan
+
+
+def plan_from_reference_args(gen_order, masks, sample_region, G=32, device=None):
+    """The ARPlan of values in the REFERENCE's form (what get_masks_for_batch returns without compact=True and what
+    get_best_sample / sample() are handed, z_buffermodel.py:244-248): gen_order = list of (L,2) (row, col) arrays by rank,
+    masks = (masks_init (b*513,9,L), masks_undilated (b*160,9,L), masks_dilated (b*80,9,L)) or their compact (b,9,L) forms,
+    sample_region (b,G,G) = self.downsample(background_mask.float()): a block is sampled where it equals 1 (sample.py:24-41)."""
+    from .lmconv.locally_masked_convolution import compact_mask
+    from .lmconv.model import wavefronts
+    device = device or torch.device("cuda", torch.cuda.current_device())
+    B, L = len(gen_order), G * G
+    order_host = np.stack([np.asarray(g, np.int64)[:, 0] * G + np.asarray(g, np.int64)[:, 1] for g in gen_order]).astype(np.int32)
+    region_host = (sample_region.detach().reshape(B, L).cpu().numpy() == 1).astype(np.uint8)
+    first = L
+    for b in range(B):
+        hit = np.nonzero(region_host[b][order_host[b]])[0]
+        if hit.size:
+            first = min(first, int(hit[0]))
+    m = [compact_mask(t.to(device), B, c).to(torch.float32) for t, c in zip(masks, (513, 160, 80))]
+    m = [(t.expand(B, -1, -1) if t.size(0) == 1 and B > 1 else t).contiguous() for t in m]
+    plan = ARPlan(torch.from_numpy(order_host).to(device), torch.from_numpy(region_host).to(device), m[0], m[1], m[2], first,
+                  order_host, G)
+    plan._n_sampled = region_host.sum(1).astype(int)
+    plan.waves = wavefronts(order_host, G, G, first, device)
     return plan
 
 
@@ -272,6 +311,29 @@ class ZbufferModelPts(nn.Module):
             self.outpaint2.engine(self.obs[1], self.obs[2], fs.shape[0]).check()
         return out
 
+    @torch.no_grad()
+    def synthesize_views(self, src_imgs, view_src, K, K_inv, input_RT, input_RTinv, output_RT, output_RTinv, temperature=None,
+                         uniforms=None, depths=None, check=True):
+        """END TO END for V independent (source, target view) pairs in one pass -- the batched counterpart of forward_image
+        (z_buffermodel.py:291-419, num_samples = 1): depth Unet on the n_src SOURCE images (once per source, not per view),
+        reproject + splat, VQ-VAE top codes of the reprojected views, AR outpainting, decode_code, get_combined, refinement
+        decoder.  src_imgs (n_src,3,S,S); view_src (V,) long: the source of every view; cameras / poses (V,4,4);
+        depths (n_src,1,S,S) stands in for the regressor when the model has none.
+        -> dict(PredImg (V,3,S,S), FeaturesImg, background_mask, codes, depth)."""
+        if self.pts_regressor is not None:
+            depth_src = torch.sigmoid(self.pts_regressor(src_imgs)) * (self.opt.max_z - self.opt.min_z) + self.opt.min_z   # :303-308
+        else:
+            depth_src = depths
+        fs_src = src_imgs if getattr(self.opt, "use_rgb_features", True) else self.encoder(src_imgs)
+        planned = self.plan_views(fs_src[view_src].contiguous(), depth_src[view_src].contiguous(), K, K_inv, input_RT, input_RTinv,
+                                  output_RT, output_RTinv)
+        out = self.outpaint_planned(planned, None, self.opt.temperature if temperature is None else temperature, uniforms)
+        pred = self._decode_candidate(out["gen_fs"], out["background_mask"], out["codes"])
+        if check:
+            self.outpaint2.engine(self.obs[1], self.obs[2], K.shape[0]).check()
+        return dict(PredImg=pred, FeaturesImg=out["gen_fs"], background_mask=out["background_mask"], codes=out["codes"],
+                    depth=depth_src, plan=out["plan"])
+
     # ---------------------------------------------------------------- reference-shaped single image path
     @torch.no_grad()
     def forward_image(self, batch, netD=None):
@@ -300,7 +362,7 @@ class ZbufferModelPts(nn.Module):
         if paired:
             outputs["OutputImg"] = output_img
         if getattr(self.opt, "no_outpainting", False):   # :383-384
-            outputs["PredImg"] = gen_fs if self.projector is None else self.projector(gen_fs)
+            outputs["PredImg"] = gen_fs if self.projector is None else self.projector(gen_fs, None)
             return None, outputs
         if self.vqvae is not None:
             enc = getattr(self.vqvae, "encode_codes", None)      # our mirror: top codes only, int32, on the device
@@ -309,7 +371,8 @@ class ZbufferModelPts(nn.Module):
             downsampled_fs = batch["codes"].to(dev)
         if max(int(getattr(self.opt, "num_samples", 1)), 1) > 1:   # :349 -> get_best_sample with opt.num_samples candidates
             plan = self.get_masks_for_batch(output_RT, input_RTinv, background_mask, compact=True)
-            outputs["PredImg"] = self.get_best_sample(plan, downsampled_fs, background_mask, gen_fs, netD, input_img)
+            outputs["PredImg"] = self.get_best_sample(plan, downsampled_fs, background_mask, gen_fs, netD, input_img,
+                                                      shard=bool(getattr(self.opt, "shard_samples", False)))
             return None, outputs
         masks_init, masks_undilated, masks_dilated, gen_order = self.get_masks_for_batch(output_RT, input_RTinv,
                                                                                          background_mask)
@@ -342,15 +405,24 @@ class ZbufferModelPts(nn.Module):
         return combined if self.projector is None else self.projector(combined, background_mask)
 
     @torch.no_grad()
-    def get_best_sample(self, plan, codes, background_mask, gen_fs, netD, input_img, uniforms=None, shard=False):
+    def get_best_sample(self, *args, uniforms=None, shard=False):
         """z_buffermodel.py:244-276 on the fused sampler: num_samples outpaintings of the same view, the best by
-        discriminator + entropy rank is kept.  `plan` is the ARPlan of background_mask, `codes` (B,32,32) the VQ-VAE
-        codes of gen_fs.  One sample needs no scorers; more need `netD` (pixelsynth_amd.losses.DiscriminatorLoss or the
-        reference's) and `self.classifier`.
+        discriminator + entropy rank is kept.  Two call forms:
+          get_best_sample(gen_order, masks, downsampled_fs, background_mask, gen_fs, netD, input_img)   the reference's (:244),
+              gen_order / masks as get_masks_for_batch returns them;
+          get_best_sample(plan, codes, background_mask, gen_fs, netD, input_img)                         with the compact ARPlan.
+        `codes` / downsampled_fs (B,32,32): the VQ-VAE codes of gen_fs.  One sample needs no scorers; more need `netD`
+        (pixelsynth_amd.losses.DiscriminatorLoss or the reference's) and `self.classifier`.
         uniforms: optional (num_samples,B,L) draws (otherwise torch.Generator seeded i, as sample() reseeds with i).
-        shard: under torch.distributed the candidates are dealt over the ranks (candidate i on rank i % W: SURVEY 8e), two
-        scalars per candidate are gathered, every rank applies the rank rule and the owner of the winner broadcasts it."""
+        shard (or opt.shard_samples through forward_image): under torch.distributed the candidates are dealt over the ranks
+        (candidate i on rank i % W: SURVEY 8e), two scalars per candidate are gathered, every rank applies the rank rule and
+        the owner of the winner broadcasts it."""
         from . import distributed as D
+        if isinstance(args[0], ARPlan):
+            plan, codes, background_mask, gen_fs, netD, input_img = args
+        else:
+            gen_order, masks, codes, background_mask, gen_fs, netD, input_img = args
+            plan = plan_from_reference_args(gen_order, masks, self.downsample(background_mask.float()), self.obs[1], gen_fs.device)
         n = max(int(getattr(self.opt, "num_samples", 1)), 1)
         if n > 1 and (netD is None or self.classifier is None):
             raise RuntimeError("num_samples > 1 ranks candidates with the discriminator (netD: pixelsynth_amd.losses.DiscriminatorLoss "
@@ -361,7 +433,7 @@ class ZbufferModelPts(nn.Module):
         if uniforms is None:
             uniforms = torch.stack([torch.rand(B, L, generator=torch.Generator(device="cpu").manual_seed(i)) for i in range(n)]).to(dev)
         rank, world = D.world()
-        mine = D.shard_views(n, rank, world) if (shard and world > 1) else list(range(n))
+        mine = D.shard_views(n, rank, world) if (shard and world > 1 and n > 1) else list(range(n))
         # The candidates are independent AR runs of the same view(s): they go through the sampler TOGETHER, as k * B frames
         # (sample-major) that share the view's order and masks and differ in their draws -- one wavefront schedule, the
         # launches of one run instead of k runs one after the other (the num_samples candidates are one of
@@ -393,9 +465,8 @@ class ZbufferModelPts(nn.Module):
         if len(mine) < n:
             d_all, e_all = D.gather_scores(disc, entr, n)
             best = rank_samples(list(d_all), list(e_all))
-            img = imgs[best] if best in imgs else torch.empty_like(next(iter(imgs.values())) if imgs else gen_fs)
-            torch.distributed.broadcast(img, src=D.owner_of(best, world))
-            return img
+            return D.broadcast_from(imgs.get(best), D.owner_of(best, world), gen_fs.device)   # (a rank without candidates
+                                                                                               # learns the shape from the owner)
         return imgs[rank_samples(disc, entr)]
 
     # ---------------------------------------------------------------- chained trajectories (8f.4)
@@ -491,8 +562,35 @@ class ZbufferModelPts(nn.Module):
                 st.numerator = i
         return None, outputs
 
+    @torch.no_grad()
+    def forward_gen_order(self, batch):
+        """z_buffermodel.py:594-639 (model_setting 'get_gen_order'): depth, reprojection + splat, generation order --
+        -> (None, {"gen_order": (B,L,2) int64 device tensor of (row, col) by rank})."""
+        dev = next(self.parameters()).device
+        input_img = batch["images"][0].to(dev)
+        cam = {k: v.to(dev) for k, v in batch["cameras"][0].items() if torch.is_tensor(v)}
+        K, K_inv, input_RT, input_RTinv = cam["K"], cam["Kinv"], cam["P"], cam["Pinv"]
+        if len(batch["cameras"]) > 1 and "P" in batch["cameras"][-1]:   # process_batch hands over the target pose (:127-130) ...
+            output_RT, output_RTinv = batch["cameras"][-1]["P"].to(dev), batch["cameras"][-1]["Pinv"].to(dev)
+        else:                                                           # ... a demo-style batch has the direction instead
+            output_RTinv, output_RT = self.get_rt_from_rot(self.opt.direction, input_RT)
+        if self.pts_regressor is not None and not getattr(self.opt, "use_gt_depth", False):
+            if getattr(self.opt, "use_inverse_depth", False):            # :606-610
+                regressed_pts = 1. / (torch.sigmoid(self.pts_regressor(input_img)) * 10 + 0.01)
+            else:
+                regressed_pts = torch.sigmoid(self.pts_regressor(input_img)) * (self.opt.max_z - self.opt.min_z) + self.opt.min_z
+        else:
+            regressed_pts = batch["depths"][0].to(dev)
+        fs = input_img if getattr(self.opt, "use_rgb_features", True) else self.encoder(input_img)
+        _, background_mask = self.pts_transformer.forward_justpts(fs, regressed_pts, K, K_inv, input_RT, input_RTinv,
+                                                                  output_RT, output_RTinv)
+        plan = self.get_masks_for_batch(output_RT, input_RTinv, background_mask, compact=True)
+        return None, {"gen_order": torch.from_numpy(np.stack(plan.gen_order)).to(dev)}
+
     def forward(self, batch, netD=None):
         """z_buffermodel.py:278-290."""
         if self.opt.model_setting in ('gen_scene', 'gen_two_imgs'):
             return self.forward_scene(batch, netD)
+        if self.opt.model_setting == 'get_gen_order':
+            return self.forward_gen_order(batch)
         return self.forward_image(batch, netD)

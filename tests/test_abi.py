@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/pixelsynth_hip.h but not exported"
     assert set(_lib.exported_symbols()) == set(names), "python prototypes out of sync with the header"
-    assert L.ps_abi_version() == 1
+    assert L.ps_abi_version() == 2
 
 
 def test_error_channel():

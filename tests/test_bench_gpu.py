@@ -68,25 +68,59 @@ def test_two_rank_bench_gathers_what_single_rank_runs_produce(tmp_path):
         torch.cuda.synchronize()
         # gather_frames orders by view index under the round-robin deal: rank r's v-th view sits at row v * world + r
         assert np.array_equal(got["all_codes"][rank::2], o["codes"].cpu().numpy()), f"rank {rank}: gathered codes differ"
-        assert np.array_equal(got["all_frames_u8"][rank::2], D.to_image_u8(o["gen_fs"]).cpu().numpy())
+        assert np.array_equal(got["all_features_u8"][rank::2], D.to_image_u8(o["gen_fs"]).cpu().numpy())
     model.outpaint2.engine(32, 32, 16).check()
 
 
+def test_strong_scaling_forms_one_rank_and_two(tmp_path):
+    """The forms BASELINE.json names for several GPUs -- a job of a fixed TOTAL size dealt round-robin over the ranks: C5
+    (--total-views) and C4 (--trajectory circle --frames 64).  One rank runs the whole 64-frame circle (C4 at its size); two ranks
+    (both on cuda:0, gloo) gather, in view order, exactly the rows the whole job gives in one process."""
+    import numpy as np
+    import torch
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--trajectory", "circle",
+                          "--frames", "64", "--no-cpu-baseline", "--no-extra"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["scaling"] == "strong" and d["config"]["views_per_gpu"] == 64 and d["config"]["workload"].startswith("C4")
+    assert abs(d["value"] - 64 * 1e3 / d["ms_per_step"]) / d["value"] < 1e-3
+    dump = str(tmp_path / "gather.npz")
+    out = _torchrun([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--total-views", "32", "--no-cpu-baseline",
+                     "--no-extra", "--dump-gather", dump], {})
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["views_per_gpu"] == 16
+    assert abs(d["value"] - 32 * 1e3 / d["ms_per_step"]) / d["value"] < 1e-3          # the job's total / wall time
+    got = np.load(dump)
+    sys.path.insert(0, ROOT)
+    import bench
+    from pixelsynth_amd import distributed as D
+    dev = torch.device("cuda", 0)
+    model = bench.build_model(dev)
+    dd, _ = bench.make_inputs(0, 32, dev)
+    o = bench.run_step(model, dd, 1)
+    torch.cuda.synchronize()
+    model.outpaint2.engine(32, 32, 32).check()
+    assert np.array_equal(got["all_codes"], o["codes"].cpu().numpy())
+    assert np.array_equal(got["all_features_u8"], D.to_image_u8(o["gen_fs"]).cpu().numpy())
+
+
 def test_two_rank_driver_writes_the_whole_circle(tmp_path):
-    """C4's form at two ranks on one GPU: `driver --trajectory circle --frames 9` -- views dealt round-robin, frames gathered,
-    rank 0 writes video/0.png (the source) .. video/9.png; every frame equal to what a single-rank run writes."""
+    """C4 at its size, one rank and two ranks on one GPU: `driver --trajectory circle --frames 64` -- views dealt round-robin,
+    frames gathered, rank 0 writes video/0.png (the source) .. video/64.png; every frame equal to what a single-rank run writes."""
     from PIL import Image
     import numpy as np
     outs = {}
     for nproc in (1, 2):
         od = str(tmp_path / f"n{nproc}")
-        args = ["-m", "pixelsynth_amd.driver", "--trajectory", "circle", "--frames", "9", "--batch", "4", "--out", od]
+        args = ["-m", "pixelsynth_amd.driver", "--trajectory", "circle", "--frames", "64", "--batch", "16", "--out", od]
         if nproc == 1:
             r = subprocess.run([sys.executable] + args, capture_output=True, text=True, timeout=900, cwd=ROOT)
         else:
             r = _torchrun(args, {}, nproc=2)
         assert r.returncode == 0, r.stderr[-3000:]
-        outs[nproc] = [np.asarray(Image.open(os.path.join(od, "video", f"{i}.png"))) for i in range(10)]
-    for i in range(10):   # (a view's draws are seeded by the view, not by the rank or batch it falls in)
+        outs[nproc] = [np.asarray(Image.open(os.path.join(od, "video", f"{i}.png"))) for i in range(65)]
+    assert len({o.tobytes() for o in outs[1][1:]}) > 32     # the circle really moves
+    for i in range(65):   # (a view's draws are seeded by the view, not by the rank or batch it falls in)
         assert outs[1][i].shape == (256, 256, 3)
         assert np.array_equal(outs[1][i], outs[2][i]), f"frame {i} differs between the 1-rank and the 2-rank run"

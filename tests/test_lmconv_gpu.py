@@ -251,6 +251,37 @@ def test_ar_wavefront_run_teacher_forced_vs_reference_sample_trace(golden_dir, c
     assert len(waves[1]) - 1 < len(region)      # fewer launches than sampled positions: the schedule is a real wavefront one
 
 
+@pytest.mark.parametrize("copies", [64, 72])
+def test_throughput_form_teacher_forced_vs_reference_sample_trace(golden_dir, copies):
+    """The HEADLINE kernel against the reference directly: the trace frame replicated `copies` times (same order, same forced
+    codes) makes every wavefront wider than the latency form takes, so the column launches run as k_column_tp (16-column MFMA
+    chain tiles; 72 copies leave ragged tiles); the logits every sampled position of EVERY copy was decided from are compared
+    with the logits the reference's own sample() loop saw at that step (tests/golden/ar_trace.npz, models/lmconv/sample.py:54-66)."""
+    from pixelsynth_amd.lmconv.model import wavefronts
+    fx = np.load(os.path.join(golden_dir, "ar_trace.npz"))
+    net = make_net(int(fx["wseed"]))
+    eng = net.engine(32, 32, copies)
+    order, region, order_loc, reg, first = _ar_setup(fx)
+    mi, mu, md = masks_for(order)
+    rep = lambda a: np.ascontiguousarray(np.repeat(a, copies, 0))
+    codes0 = rep(syn.codes(int(fx["codes_seed"]), 1).reshape(1, 1024).astype(np.int32))
+    final = rep(fx["final_codes"].astype(np.int32).reshape(1, 1024))
+    c = tt(codes0.copy())
+    waves = wavefronts(rep(order_loc), 32, 32, first, DEV, max_cols=1024)
+    widths = np.diff(waves[1])
+    assert (widths > 128).mean() > 0.9          # the launches of this run are throughput-form launches
+    out = eng.ar_run(c, tt(rep(order_loc)), tt(rep(reg)), mi, mu, md, temperature=0.7, forced=tt(final), first_step=first,
+                     want_logits=True, waves=waves)
+    eng.check()
+    torch.cuda.synchronize()
+    assert np.array_equal(c.cpu().numpy(), final)
+    got = out.cpu().numpy()
+    sel = np.array([i * 32 + j for i, j in region])[::4]
+    for f in range(copies):
+        np.testing.assert_allclose(got[f, sel], fx["step_logits"], rtol=1e-4, atol=1e-4, err_msg=f"copy {f}")
+    assert np.array_equal(got[0], got[copies - 1])   # and the copies agree bit for bit, wherever they sit in a tile
+
+
 def test_ar_fused_sampling_inverse_cdf_and_determinism():
     net = make_net(3)
     F_ = 3

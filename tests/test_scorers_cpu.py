@@ -65,6 +65,27 @@ def test_resnet18_has_the_published_layout():
     assert tuple(out.shape) == (2, 365)
 
 
+def test_resnet18_mirror_equals_the_functional_twin_numerically():
+    """The ResNet-18 pinned NUMERICALLY (torchvision is absent): the product's module and oracle/resnet_oracle.py -- a functional
+    restatement of the published architecture written from the state_dict keys, sharing no code with the module -- give the
+    same logits on the same weights, and the same entropy score on the reference's reinterpreted 224x224 input."""
+    from oracle import resnet_oracle as ro
+    from pixelsynth_amd.networks import resnet18
+    from pixelsynth_amd.z_buffermodel import ZbufferModelPts
+    net = resnet18(num_classes=365).eval()
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    sd = {k: torch.from_numpy(v) for k, v in syn.resnet_state_dict(shapes, 3).items()}
+    net.load_state_dict(sd, strict=True)
+    x = torch.from_numpy(syn.image(77, 2, 3, 224))
+    with torch.no_grad():
+        got, want = net(x), ro.resnet18_forward(sd, x)
+    assert float(want.std()) > 1e-2
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-4, atol=1e-4)
+    holder = type("H", (), {"classifier": net, "_entropy_score": ZbufferModelPts._entropy_score})()
+    img = torch.from_numpy(syn.image(5, 1, 3, 256))
+    assert abs(holder._entropy_score(img) - ro.entropy_score(sd, img)) < 1e-4
+
+
 def test_candidate_scores_gathered_across_ranks_rank_like_one_process():
     """the num_samples candidates of a view are independent; with them dealt over the ranks only two scalars per
     candidate travel.  gloo, world size 2: the gathered scores and the kept index equal the single-process ones."""

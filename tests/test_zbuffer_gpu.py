@@ -35,11 +35,47 @@ def test_zbuffer_scatter_kernel_is_the_sequential_last_write():
     winner = torch.empty(B, H, W, dtype=torch.int32, device=DEV)
     dev = [tt(a) for a in (ys, xs, v0, v1)]     # (kept alive: a temporary's block would be handed to the next upload)
     rc = _lib.lib().ps_zbuffer_scatter_f32(*[_lib.ptr(a) for a in dev], B, N, H, W, _lib.ptr(out), _lib.ptr(winner),
-                                           _lib.current_stream())
+                                           _lib.ptr(_lib.status_word(DEV)), _lib.current_stream())
     _lib.check(rc, "ps_zbuffer_scatter_f32")
-    torch.cuda.synchronize()
+    _lib.read_status("ps_zbuffer_scatter_f32", DEV)      # synchronises; nothing was dropped
     assert np.array_equal(out.cpu().numpy(), want)
     assert (want == -2).any() and (want != -2).any()
+
+
+def test_status_word_reports_dropped_points_and_bad_orders():
+    """Data errors only the device can see -- a pixel outside the image in the z-buffer scatter, a generation order that is no
+    permutation -- raise a bit in the CALLER's status word; ps_read_status turns it into an error (message through
+    ps_last_error) and clears it.  The library holds no flag of its own."""
+    B, N, H, W = 1, 64, 8, 8
+    ys = np.zeros((B, N), np.int32)
+    xs = np.zeros((B, N), np.int32)
+    ys[0, 5] = H                                           # outside
+    v = np.zeros((B, N), np.float32)
+    out = torch.full((B, 2, H, W), -2.0, device=DEV)
+    winner = torch.empty(B, H, W, dtype=torch.int32, device=DEV)
+    dev = [tt(a) for a in (ys, xs, v, v)]
+    st = _lib.status_word(DEV)
+    _lib.check(_lib.lib().ps_zbuffer_scatter_f32(*[_lib.ptr(a) for a in dev], B, N, H, W, _lib.ptr(out), _lib.ptr(winner), _lib.ptr(st),
+                                                 _lib.current_stream()), "ps_zbuffer_scatter_f32")
+    with pytest.raises(RuntimeError, match="outside the image"):
+        _lib.read_status("scatter", DEV)
+    _lib.read_status("scatter", DEV)                       # cleared by the read
+    order = torch.arange(16, dtype=torch.int32, device=DEV).view(1, 16).clone()
+    order[0, 3] = 99                                       # no permutation of the 4x4 grid
+    masks = [torch.empty(1, 9, 16, device=DEV) for _ in range(3)]
+    _lib.check(_lib.lib().ps_order_masks_f32(_lib.ptr(order), 1, 4, 4, *[_lib.ptr(m) for m in masks], _lib.ptr(st),
+                                             _lib.current_stream()), "ps_order_masks_f32")
+    with pytest.raises(RuntimeError, match="no permutation"):
+        _lib.read_status("order_masks", DEV)
+    _lib.read_status("order_masks", DEV)
+
+
+def test_depth_manipulator_refuses_sizes_the_reference_literals_do_not_cover():
+    from pixelsynth_amd.projection.depth_manipulator import DepthManipulator
+    dm = DepthManipulator(128)
+    eye = torch.eye(4, device=DEV)[None]
+    with pytest.raises(ValueError, match="256x256"):
+        dm.project_zbuffer(torch.ones(1, 1, 128, 128, device=DEV), eye, eye, eye, eye)
 
 
 def test_depth_manipulator_matches_the_reference_outputs():

@@ -441,3 +441,76 @@ def test_get_best_sample_batches_the_candidates_without_changing_them():
     for a, b in zip(batched, seen):
         assert torch.equal(a, b)
     assert not torch.equal(batched[0], batched[1])
+
+
+def test_get_best_sample_takes_the_reference_signature():
+    """z_buffermodel.py:244: get_best_sample(gen_order, masks, downsampled_fs, background_mask, gen_fs, netD, input_img) with
+    gen_order / masks as get_masks_for_batch returns them (the reference's layouts) gives exactly what the compact-plan form
+    gives: same candidates, same winner."""
+    from pixelsynth_amd.z_buffermodel import build_ar_plan
+    m = _scene_model(num_samples=3)
+    img = tt(syn.image(31, 1, 3, 256))
+    cam = {k: tt(v) for k, v in syn.demo_cameras(1).items()}
+    RTinv, RT = m.get_rt_from_rot("R", cam["P"], 2, 2)
+    gen_fs, bg = m.pts_transformer.forward_justpts(img, syn.depth_from_image(img), cam["K"], cam["Kinv"], cam["P"],
+                                                   cam["Pinv"], RT, RTinv)
+    codes = m.vqvae.encode_codes(gen_fs)
+    seen = []
+
+    class D:
+        def run_discriminator_one_step(self, fake, real):
+            seen.append(fake.clone())
+            return {"D_Fake": fake.mean().reshape(1)}
+    class C(torch.nn.Module):
+        def forward(self, x):
+            return torch.cat([x.mean().reshape(1, 1) * k for k in range(1, 11)], 1)
+    m.classifier = C()
+    best_plan = m.get_best_sample(build_ar_plan(bg, 32), codes, bg, gen_fs, D(), img)
+    first = [s for s in seen]
+    seen.clear()
+    mi, mu, md, gen_order = m.get_masks_for_batch(RT, cam["Pinv"], bg)            # the reference's return value (:641-701)
+    best_ref = m.get_best_sample(gen_order, (mi, mu, md), codes, bg, gen_fs, D(), img)
+    assert len(first) == len(seen) == 3
+    for a, b in zip(first, seen):
+        assert torch.equal(a, b)
+    assert torch.equal(best_plan, best_ref)
+
+
+def test_forward_gen_order_dispatch():
+    """model_setting 'get_gen_order' (z_buffermodel.py:284-285, 594-639): forward() returns the generation order of the view,
+    (B, L, 2) (row, col) by rank -- the oracle's order for the background mask the splat produces."""
+    m = make_model(model_setting="get_gen_order")
+    cam = {k: torch.from_numpy(v) for k, v in syn.demo_cameras(1).items()}
+    img, depth = torch.from_numpy(syn.image(4, 1, 3, 256)), torch.from_numpy(syn.depth_smooth(5, 1, 256, 1.0, 100.0))
+    batch = {"images": [img], "cameras": [cam], "depths": [depth]}
+    loss, out = m(batch)
+    assert loss is None and set(out) == {"gen_order"}
+    go = out["gen_order"]
+    assert go.is_cuda and tuple(go.shape) == (1, 1024, 2) and go.dtype == torch.int64
+    RTinv, RT = m.get_rt_from_rot("R", tt(syn.demo_cameras(1)["P"]))
+    c = {k: tt(v) for k, v in syn.demo_cameras(1).items()}
+    _, bg = m.pts_transformer.forward_justpts(img.to(DEV), depth.to(DEV), c["K"], c["Kinv"], c["P"], c["Pinv"], RT, RTinv)
+    want = c_oracle.masks_for_background(bg[0].cpu().numpy(), 32)["order"]
+    assert np.array_equal(go[0].cpu().numpy(), want)
+    # a batch that carries the target camera (process_batch's form) uses it
+    batch2 = {"images": [img, img], "cameras": [cam, {"P": RT.cpu(), "Pinv": RTinv.cpu()}], "depths": [depth]}
+    assert torch.equal(m(batch2)[1]["gen_order"], go)
+
+
+def test_sharded_sample_ranking_two_ranks_equals_one(tmp_path):
+    """get_best_sample(shard=True) under two ranks (both on cuda:0, gloo): candidates dealt round-robin, two scalars per
+    candidate gathered, the winner broadcast from its owner (shape learnt from the owner) -- every rank ends with the image the
+    single-process ranking keeps; also with fewer candidates than ranks would need (n = 1 ... handled upstream) and with a
+    non-RGB feature count, where the broadcast buffer cannot be guessed from gen_fs."""
+    import subprocess
+    import sys
+    import socket
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, PS_DRYRUN_ONE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "tests", "_shard_samples_worker.py"), str(tmp_path)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-3000:]
