@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpixelsynth_hip.so")
+LIB_PATH = os.environ.get("PS_HIP_LIB") or os.path.join(_HERE, "libpixelsynth_hip.so")   # (PS_HIP_LIB: tuning builds)
 _lib = None
 
 c_void_p, c_int, c_float, c_double, c_size_t = (ctypes.c_void_p, ctypes.c_int, ctypes.c_float,

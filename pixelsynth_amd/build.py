@@ -13,7 +13,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIB = os.path.join(HERE, "libpixelsynth_hip.so")
+LIB = os.environ.get("PS_HIP_LIB") or os.path.join(HERE, "libpixelsynth_hip.so")   # (PS_HIP_LIB: tuning builds, with PS_OBJ_SUFFIX)
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
@@ -40,7 +40,7 @@ def build(force=False, verbose=True):
         sp = os.path.join(CSRC, src)
         if not os.path.exists(sp):
             continue
-        obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
+        obj = os.path.join(CSRC, os.path.splitext(src)[0] + os.environ.get("PS_OBJ_SUFFIX", "") + ".o")
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(sp), dep_m):
             cmd = [HIPCC, "-x", "hip", "-c", sp, "-o", obj] + COMMON + flags
             if verbose:

@@ -523,6 +523,330 @@ __global__ __launch_bounds__(256) void k_post_grid(PostArgs a)
     post_item<KIND>(a, item, lane, P, ss, P + SLOT_SKIP * ss);
 }
 
+// ------------------------------------------------------------------------------------------
+// k_gemm_wg: the whole-grid products with the receptive-field window shared through LDS (round 3).
+//
+// k_gemm gives every wave its own 16 items x 32 output channels and lets it gather its input rows and fetch its weights from
+// L1 / L2 by itself.  Here a WORKGROUP of four waves -- one per SIMD: five-wave workgroups (one wave per 16 of 80 channels)
+// were measured first and never got more than two of them resident on a CU, 3 + 3 + 2 + 2 waves, the doubly loaded SIMDs
+// setting the pace -- owns a tile of 16 * TI items and ALL output channels of the conv, 20 MFMA tiles, five per wave:
+//   conv_out (160 channels, TI = 2)   wave w: output tiles 2w, 2w + 1 for both item tiles, + output tile 8 + w / 2 for item tile w & 1
+//   conv_input / dilated (80, TI = 4) wave w: output tile w for the four item tiles,        + output tile 4 for item tile w
+//   * the gathered input rows of a tap (operand B: 16 * TI items x Cin channels, mask applied, closed or absent rows as zeros)
+//     are staged in LDS ONCE per workgroup, in the lane order of the MFMA fragment, and read from there by all four waves
+//     (conflict-free ds_read_b128); the rows of the NEXT open tap are requested before the MFMAs of this one and parked after
+//     them (two buffers and one barrier per tap; conv_input, whose 64 x 160 rows take 40 KB, has one buffer and two barriers);
+//   * a wave's weights (operand A) come straight from L2 into registers, one accumulation chain ahead of their use, and are
+//     used for up to four item tiles (k_gemm: one);
+//   * the four waves walk the SAME items, so the barriers cost no skew; a tap that is closed for the whole tile of items is
+//     skipped by all of them (an exact zero); a tap that is open for some of them is computed for all, on zeros where it
+//     is closed -- tot + 0 is tot, so the bits do not change -- which keeps the tap body free of branches.
+// Arithmetic and order are k_gemm's summing form to the bit: per tap five accumulation chains (chain j = channel groups j,
+// j + 5 in MFMA order), tap value (((a0 + a1) + a2) + a3) + a4, taps added in order into the slot, y = ((bias + NA) + C) + NB
+// stored in place of slot NA, the nin_skip slot raw.  Taken for launches of at least PS_GEMM_WG_MIN item tiles.
+// ------------------------------------------------------------------------------------------
+constexpr int GW_WAVES = 4, GW_THREADS = 64 * GW_WAVES;
+enum { GW_CONVOUT = 0, GW_CONVIN = 1, GW_DIL = 2 };
+#ifdef PS_WG_TRACE_BUILD   // tuning builds: shader-clock stamps of wave 0 of the first 32 workgroups, per kernel variant
+__device__ unsigned long long g_wg_trace[3][32][16];
+__device__ unsigned long long g_wg_span[3][4096][2];   // wall clock (100 MHz) at the start and the end of every workgroup, + hw id
+#define WG_STAMP(k) do { if (y < 32 && tid == 0 && (k) < 16) g_wg_trace[KIND][y][(k)] = clock64(); } while (0)
+#else
+#define WG_STAMP(k) do { } while (0)
+#endif
+// waves per SIMD the register budget is cut for: the full-size forms (five tiles per wave) take two, the others three
+constexpr int gw_occ(int kind, int ti) { return (kind == GW_CONVOUT && ti == 2) || (kind == GW_CONVIN && ti == 4) ? 2 : 3; }
+template <int KIND, int TI>
+__attribute__((amdgpu_waves_per_eu(gw_occ(KIND, TI), gw_occ(KIND, TI))))
+__global__ __launch_bounds__(GW_THREADS) void k_gemm_wg(GemmArgs a, PostArgs pa, int fuse_post)
+{
+    constexpr int NGH = KIND == GW_DIL ? 1 : 2, NG = 5 * NGH, MI = 16 * TI;
+    constexpr int POSTK = KIND == GW_CONVOUT ? POST_GATE : KIND == GW_CONVIN ? POST_CONVIN : POST_DIL;
+    constexpr int YLD = KIND == GW_DIL ? 84 : 168;      // floats per item of the post op's LDS tile: y (+ gate half / nin_skip slot) + pad
+    constexpr int NAU = KIND == GW_CONVOUT ? 3 : 2;     // distinct output tiles (A operands) of a wave
+    constexpr int NBU = TI + 1;                         // B operands of a wave: the TI item tiles + the fifth tile's own copy
+    constexpr bool DB = MI * NG * 16 <= 6144;           // two B buffers while they take no more than 48 KB
+    constexpr int BUF = TI * NG * 64;                   // f32x4 per B buffer: [item tile][channel group][lane]
+    constexpr int SU = (TI * NG + GW_WAVES - 1) / GW_WAVES;   // 1 KB staging units per wave and tap (the last one may be absent)
+    constexpr bool SU_EVEN = TI * NG % GW_WAVES == 0;
+    static_assert(MI <= 64, "one lane per item in the set-up");
+    constexpr int NB4 = (DB ? 2 : 1) * BUF > MI * YLD / 4 ? (DB ? 2 : 1) * BUF : MI * YLD / 4;   // (the post op's tile reuses the B buffers)
+    __shared__ f32x4 sB[NB4];
+    __shared__ int sRow[MAX_TAPS * MI];      // input row of (tap, item), -1 = closed (mask 0, outside the grid, item not evaluated)
+    __shared__ float sMv[MAX_TAPS * MI];     // its mask value
+    __shared__ int sItem[MI];                // item index, -1 = not evaluated here
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, i = lane & 15, kk = lane >> 4;
+    const int xcd = blockIdx.x & (N_XCD - 1), tb = blockIdx.x >> 3;
+    const int y = xcd * a.tpx + tb;          // contiguous item ranges per XCD, as in k_gemm
+    if (tb >= a.tpx || y >= a.ny) return;
+    const int item0 = y * MI;
+    const int ntaps = a.slot_first[a.nslots];
+    const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+    WG_STAMP(0);
+#ifdef PS_WG_TRACE_BUILD
+    if (tid == 0 && y < 4096) g_wg_span[KIND][y][0] = wall_clock64();
+#endif
+    // ---- set-up: rows and mask values of every (tap, item) of the tile; wave w does taps w, w + 4, w + 8
+    {
+        const int m = lane & (MI - 1);
+        const int item = item0 + m;
+        const bool valid = item < a.nitems && item_wanted(a.items, item);
+        int f = 0, q = 0, r = 0, c = 0;
+        if (valid) {
+            item_loc(a.items, item, a.L, f, q);
+            r = q / a.W;
+            c = q - r * a.W;
+        }
+        if (wave == 0 && lane < MI) sItem[m] = valid ? item : -1;
+        for (int t = wave; t < ntaps; t += GW_WAVES) {
+            const GemmTap tp = a.tap[t];
+            const int rr = r + tp.dr, cc = c + tp.dc;
+            float mv = 0.0f;
+            if (valid && rr >= 0 && rr < a.H && cc >= 0 && cc < a.W)
+                mv = tp.mask_row >= 0 ? a.mask[(size_t)f * a.mask_fstride + (size_t)tp.mask_row * a.L + q] : 1.0f;
+            if (lane < MI) {
+                sRow[t * MI + m] = mv != 0.0f ? (f * a.L + rr * a.W + cc) : -1;
+                sMv[t * MI + m] = mv;
+            }
+        }
+    }
+    __syncthreads();
+    WG_STAMP(1);
+    // live bits [4 t, 4 t + TI): item tile ti has an open lane at tap t (wave-uniform; the same in every wave)
+    unsigned long long live = 0;
+    for (int t = 0; t < ntaps; ++t) {
+        const unsigned long long b = __ballot(sRow[t * MI + (lane & (MI - 1))] >= 0);
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti)
+            if ((b >> (16 * ti)) & 0xFFFFull) live |= 1ull << (4 * t + ti);
+    }
+    if (live == 0 && __ballot(sItem[lane & (MI - 1)] >= 0) == 0ull) return;   // nothing of this tile is evaluated here
+    auto tiles_of = [&](int t) { return (unsigned)((live >> (4 * t)) & 0xFull); };
+    auto next_live = [&](int t) {   // first tap after t with an open item tile, or ntaps
+        int n = t + 1;
+        while (n < ntaps && tiles_of(n) == 0) ++n;
+        return n;
+    };
+    // ---- staging: unit u of this wave = (item tile, channel group) (wave + 4 u); lane (kk, i) carries channels 16 g + 4 kk .. + 3 of
+    // item i; rows and mask values are looked up once per item tile
+    f32x4 sv[SU];
+    auto stage_load = [&](int t) {
+        const GemmTap tp = a.tap[t];
+        int row[TI];
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti) row[ti] = sRow[t * MI + ti * 16 + i];
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+            const int unit = wave + GW_WAVES * u, ti = unit / NG, g = unit - ti * NG;
+            if (!SU_EVEN && u == SU - 1 && unit >= TI * NG) continue;   // (wave-uniform)
+            int r = row[0];
+#pragma unroll
+            for (int k = 1; k < TI; ++k) r = ti == k ? row[k] : r;
+            sv[u] = *(const f32x4 *)(tp.in + (size_t)(r >= 0 ? r : 0) * tp.ld + 16 * g + 4 * kk);   // (unconditional: see gemm_tiles)
+        }
+    };
+    auto stage_store = [&](int t, int buf) {
+        int row[TI];
+        float mvv[TI];
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti) { row[ti] = sRow[t * MI + ti * 16 + i]; mvv[ti] = sMv[t * MI + ti * 16 + i]; }
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+            const int unit = wave + GW_WAVES * u, ti = unit / NG, g = unit - ti * NG;
+            if (!SU_EVEN && u == SU - 1 && unit >= TI * NG) continue;
+            int r = row[0];
+            float mv = mvv[0];
+#pragma unroll
+            for (int k = 1; k < TI; ++k) { r = ti == k ? row[k] : r; mv = ti == k ? mvv[k] : mv; }
+            sB[buf * BUF + (ti * NG + g) * 64 + lane] = r >= 0 ? sv[u] * mv : zero;   // (x * 1.0f is x: 0 / 1 masks cost nothing)
+        }
+    };
+    // ---- the wave's five tiles: A operand (output tile) and B operand (item tile) of each
+    //   conv_out:          (a0,b0) (a0,b1) (a1,b0) (a1,b1) (a2,bx)     a0 = 2w, a1 = 2w + 1, a2 = 8 + w / 2, bx = item tile w & 1
+    //   conv_input / dil:  (a0,b0) (a0,b1) (a0,b2) (a0,b3) (a1,bx)     a0 = w, a1 = 4, bx = item tile w
+    // (with fewer item tiles than the full-size forms -- conv_out TI = 1, conv_input / dilated TI = 2 -- a wave has the tiles of
+    // its first NT4 = 2 (conv_out: its two output tiles) or TI combinations, and the fifth tile exists for the waves whose item tile
+    // it would be: 3 + 3 + 2 + 2 or 3 + 2 + 3 + 2 tiles; three such workgroups fit a CU and even each other's SIMDs out)
+    constexpr int NT4 = KIND == GW_CONVOUT ? 2 * TI : TI;       // tiles ahead of the "fifth" one
+    constexpr int NTL = NT4 + 1;
+    auto a_of = [](int k) constexpr { return KIND == GW_CONVOUT ? (k < NT4 ? k / TI : 2) : (k < NT4 ? 0 : 1); };
+    auto b_of = [](int k) constexpr { return k < NT4 ? (KIND == GW_CONVOUT ? k % TI : k) : TI; };
+    const int tixr = KIND == GW_CONVOUT ? (wave & 1) : wave;    // item tile of the fifth tile ...
+    const bool has5 = tixr < TI;                                // ... if the workgroup has that item tile
+    const int tix = has5 ? tixr : 0;
+    int ot[NAU];                                                // output tile of A operand n
+    if (KIND == GW_CONVOUT) { ot[0] = 2 * wave; ot[1] = 2 * wave + 1; ot[NAU - 1] = 8 + (wave >> 1); }
+    else { ot[0] = wave; ot[1] = 4; }
+    static_assert(KIND != GW_CONVOUT || TI <= 2, "conv_out: the fifth tile's item tile is w & 1");
+    auto o_of = [&](int k) { return 16 * ot[a_of(k)]; };                       // first output channel of tile k
+    auto m_of = [&](int k) { return (k < NT4 ? b_of(k) : tix) * 16 + i; };     // this lane's item of tile k (column i of the tile)
+    f32x4 tot[NTL], ysum[NTL];
+#pragma unroll
+    for (int k = 0; k < NTL; ++k) { tot[k] = zero; ysum[k] = zero; }
+    uint32_t woff[NAU];
+#pragma unroll
+    for (int n = 0; n < NAU; ++n) woff[n] = (uint32_t)((kk * a.Co_pad + 16 * ot[n] + i) * 16);
+    auto wload = [&](const __amdgpu_buffer_rsrc_t &wrs, int grp, int n) {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, woff[n], grp * 16 * a.Co_pad * 4, 0));
+    };
+    f32x4 av[NGH][NAU];           // chain 0's weights of the CURRENT tap: requested before the previous tap's barrier (a0_load), so that a
+    auto a0_load = [&](int t) {   // tap does not open with a memory round trip that every wave of the workgroup sits through together
+        const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)a.tap[t].w, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+        for (int h = 0; h < NGH; ++h)
+#pragma unroll
+            for (int n = 0; n < NAU; ++n) av[h][n] = wload(wrs, 5 * h, n);
+    };
+    // products of tap t from buffer `buf`, added to tot[].  ALL: every item tile has an open lane -- straight-line code; else the
+    // tiles of closed item tiles are left out (an exact zero) behind wave-uniform branches, one per tile and chain.
+    auto tap_products = [&](int t, int buf, auto ALLc) {
+        constexpr bool ALL = decltype(ALLc)::value;     // every tile of this wave is computed
+        const unsigned tl = tiles_of(t);
+        bool lv[NTL];
+#pragma unroll
+        for (int k = 0; k < NTL; ++k) lv[k] = ALL || (k < NT4 ? ((tl >> b_of(k)) & 1u) != 0 : has5 && ((tl >> tix) & 1u));
+        const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)a.tap[t].w, 0, 0x7fffffff, 0x00020000);
+        f32x4 taptot[NTL], an[NGH][NAU];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            if (j < 4) {   // the next chain's weights are requested under this chain's MFMAs ...
+#pragma unroll
+                for (int h = 0; h < NGH; ++h)
+#pragma unroll
+                    for (int n = 0; n < NAU; ++n) an[h][n] = wload(wrs, j + 1 + 5 * h, n);
+            }
+            f32x4 bv[NGH][NBU], acc[NTL];
+#pragma unroll
+            for (int h = 0; h < NGH; ++h) {
+#pragma unroll
+                for (int ti = 0; ti < TI; ++ti) bv[h][ti] = sB[buf * BUF + (ti * NG + j + 5 * h) * 64 + lane];
+                bv[h][TI] = sB[buf * BUF + (tix * NG + j + 5 * h) * 64 + lane];
+            }
+            __builtin_amdgcn_sched_barrier(0);   // ... and the scheduler may not pull their consumers up to them
+            // chain j of the five tiles: group j (c = 0..3), then group j + 5 -- the tiles are independent accumulators
+            if (ALL) {
+#pragma unroll
+                for (int h = 0; h < NGH; ++h)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+#pragma unroll
+                        for (int k = 0; k < NTL; ++k)
+                            acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[h][a_of(k)][c], bv[h][b_of(k)][c], h == 0 && c == 0 ? zero : acc[k], 0, 0, 0);
+#pragma unroll
+                for (int k = 0; k < NTL; ++k) taptot[k] = j == 0 ? acc[k] : taptot[k] + acc[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < NTL; ++k) {
+                    if (!lv[k]) continue;
+#pragma unroll
+                    for (int h = 0; h < NGH; ++h)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[h][a_of(k)][c], bv[h][b_of(k)][c], h == 0 && c == 0 ? zero : acc[k], 0, 0, 0);
+                    taptot[k] = j == 0 ? acc[k] : taptot[k] + acc[k];
+                }
+            }
+            if (j < 4) {
+#pragma unroll
+                for (int h = 0; h < NGH; ++h)
+#pragma unroll
+                    for (int n = 0; n < NAU; ++n) av[h][n] = an[h][n];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int k = 0; k < NTL; ++k)
+            if (lv[k]) tot[k] = tot[k] + taptot[k];
+    };
+    auto tap_dispatch = [&](int t, int buf) {
+        if (has5 && tiles_of(t) == (1u << TI) - 1u) tap_products(t, buf, std::integral_constant<bool, true>{});
+        else tap_products(t, buf, std::integral_constant<bool, false>{});
+    };
+    // ---- the taps in slot order NA, C, NB (, SKIP); the open ones staged through sB
+    int cur = next_live(-1), buf = 0;
+    if (cur < ntaps) {
+        stage_load(cur);
+        a0_load(cur);
+        stage_store(cur, 0);
+    }
+    __syncthreads();
+    WG_STAMP(2);
+    int nstamp = 3;
+    (void)nstamp;
+    for (int slot = 0; slot < a.nslots; ++slot) {
+        for (int t = a.slot_first[slot]; t < a.slot_first[slot + 1]; ++t) {
+            if (t != cur) continue;              // no open lane in the whole tile: an exact zero, skipped by every wave
+            const int nxt = next_live(t);
+            if (nxt < ntaps) stage_load(nxt);    // in flight under the MFMAs
+            tap_dispatch(t, buf);
+            if (nxt < ntaps) a0_load(nxt);
+            if (DB) {
+                if (nxt < ntaps) stage_store(nxt, buf ^ 1);
+                __syncthreads();                 // next tap's rows visible; everybody is done with this tap's
+                buf ^= 1;
+            } else {
+                __syncthreads();                 // everybody is done with this tap's rows
+                if (nxt < ntaps) stage_store(nxt, 0);
+                __syncthreads();
+            }
+            cur = nxt;
+            WG_STAMP(nstamp);
+            ++nstamp;
+        }
+        if (slot == SLOT_SKIP) {
+            if (fuse_post) {   // (all taps are done: the B buffers are free -- the last tap ended with a barrier)
+                float *sY = (float *)sB;
+#pragma unroll
+                for (int k = 0; k < NTL; ++k)
+                    if (k < NT4 || has5) *(f32x4 *)(sY + m_of(k) * YLD + NF + o_of(k) + kk * 4) = tot[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < NTL; ++k) {
+                    const int item = (k < NT4 || has5) ? sItem[m_of(k)] : -1;
+                    if (item >= 0) *(f32x4 *)(a.partial + ((size_t)SLOT_SKIP * a.nitems + item) * a.Co_pad + o_of(k) + kk * 4) = tot[k];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NTL; ++k)
+                ysum[k] = (slot == SLOT_NA ? *(const f32x4 *)(a.sum_bias + o_of(k) + kk * 4) : ysum[k]) + tot[k];
+            if (slot == SLOT_NB && !fuse_post) {
+#pragma unroll
+                for (int k = 0; k < NTL; ++k) {
+                    const int item = (k < NT4 || has5) ? sItem[m_of(k)] : -1;
+                    if (item >= 0) *(f32x4 *)(a.partial + ((size_t)SLOT_NA * a.nitems + item) * a.Co_pad + o_of(k) + kk * 4) = ysum[k];
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NTL; ++k) tot[k] = zero;
+    }
+    // ---- the post op of the stage, in the same launch: y (and the gate half / the nin_skip slot) of the tile's items go through
+    // LDS -- a row per item, where post_item (the code of k_post_grid) finds them -- and the four waves share out the items.
+    // No partial sums in HBM, no second launch; the other workgroups of the CU keep the matrix pipes busy meanwhile.
+    if (fuse_post) {
+        float *sY = (float *)sB;
+        // (conv_input with nin_skip: the skip slot was parked above, after the barrier of the last tap; here the taps are done too)
+#pragma unroll
+        for (int k = 0; k < NTL; ++k)
+            if (k < NT4 || has5) *(f32x4 *)(sY + m_of(k) * YLD + o_of(k) + kk * 4) = ysum[k];
+        __syncthreads();
+        for (int m = wave; m < MI; m += GW_WAVES) {
+            const int item = sItem[m];
+            if (item < 0) continue;   // (wave-uniform)
+            post_item<POSTK>(pa, item, lane, sY + m * YLD, 0, sY + m * YLD + NF);
+        }
+    }
+    WG_STAMP(15);
+#ifdef PS_WG_TRACE_BUILD
+    if (tid == 0 && y < 4096) {
+        unsigned hw = 0;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        g_wg_span[KIND][y][1] = (wall_clock64() << 16) | (hw & 0xffffu);
+    }
+#endif
+}
+
 // One stage of the whole-grid pass in ONE kernel: a workgroup = one tile of 16 items, one wave per block of 32 output
 // channels (3 waves for the 80-channel convs, 5 for conv_out); every wave walks all slots of its block (gemm_tiles,
 // summing form), parks y -- and the nin_skip slot -- in LDS, and after one barrier the waves share out the 16 items for
@@ -1049,6 +1373,13 @@ __device__ __forceinline__ int draw_code(const float (&lg)[8], float temperature
 // Workgroup barrier that only drains LDS traffic.  __syncthreads() also waits for every outstanding
 // global access (vmcnt(0)), which would serialise the weight / neighbour-slot prefetches of k_chain
 // against its two barriers per stage; the data exchanged between the waves here lives in LDS only.
+// Bound of the in-launch waits on the neighbour role's completion counters: a hang guard, not a schedule.  A wait is normally
+// over before it starts; it lasts when workgroups of the launch are not resident yet because kernels of ANOTHER stream hold their
+// CUs (bench.py / driver.py run the next batch's splat under this batch's AR run: a stream of 64-thread workgroups can keep a
+// 512- or 1024-thread workgroup that needs most of a CU's LDS waiting for as long as that kernel lasts, milliseconds).  Round 2's
+// bounds (20 000 / 40 000 polls of >= 128 clocks: a few ms) were inside that range and expired now and then (one bench run in
+// six); 2^24 polls are seconds -- still finite, so a lost workgroup ends as an error from ps_pixelcnn_status, not as a hung GPU.
+constexpr int WAIT_SPINS = 1 << 24;
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -1267,7 +1598,7 @@ __device__ __forceinline__ void chain_role(const ChainArgs &a, int wg)
             if (a.debug & 1) return;
             int spins = 0;
             while ((int)(have - need) < 0) {
-                if (++spins > 20000) { if (lane == 0) *a.err = 1; break; }
+                if (++spins > WAIT_SPINS) { if (lane == 0) *a.err = 1; break; }
                 __builtin_amdgcn_s_sleep(2);
                 have = counter(k);
             }
@@ -1821,7 +2152,7 @@ __device__ __forceinline__ void chain_role_tp(const TpArgs &a, int tile)
         const unsigned need = my_uses * items_per_tile;
         int spins = 0;
         while ((int)(have - need) < 0) {
-            if (++spins > 40000) { if (lane == 0) *a.err = 1; break; }
+            if (++spins > WAIT_SPINS) { if (lane == 0) *a.err = 1; break; }
             __builtin_amdgcn_s_sleep(2);
             have = counter(k);
         }
@@ -2407,7 +2738,8 @@ void conv_taps(GemmArgs &a, const float *in, int ld, const float *wp, int Cin, i
 }
 
 // grid of k_gemm: (channel blocks x item blocks x slots) laid out XCD by XCD, see the kernel
-void launch_gemm(GemmArgs &a, int item_blocks, hipStream_t st)
+// -> true when the post op `post` was done in the same launch (k_gemm_wg)
+bool launch_gemm(GemmArgs &a, int item_blocks, hipStream_t st, const PostArgs *post = nullptr)
 {
     const bool split = getenv("PS_GEMM_SPLIT_SLOTS") != nullptr;   // tuning: one wave per slot
     a.nx = (a.Co_pad + 16 * GEMM_T - 1) / (16 * GEMM_T);
@@ -2420,7 +2752,34 @@ void launch_gemm(GemmArgs &a, int item_blocks, hipStream_t st)
     const int merge_min = mm ? atoi(mm) : 8192;
     a.zgrid = split || a.nx * a.ny < merge_min ? a.nslots : 1;
     if (a.zgrid != 1 || a.nslots < 3) a.sum_bias = nullptr;   // (only a wave that walks NA, C and NB can add them up)
+    // the workgroup form (k_gemm_wg: input rows shared through LDS) from PS_GEMM_WG_MIN item tiles on, for the shapes of the
+    // network's 3x3 convs; it produces the summed form (y in place of slot NA), bit-identical to k_gemm's
+    const char *wm = getenv("PS_GEMM_WG_MIN");
+    const int wg_min = wm ? atoi(wm) : 2048;
+    const bool shape_ok = (a.Cin == 2 * NF || a.Cin == NF) && (a.Co_pad == NF || (a.Co_pad == 2 * NF && a.Cin == 2 * NF));
+    if (a.sum_bias && a.zgrid == 1 && shape_ok && item_blocks >= wg_min && a.tiles_per_block == 1) {
+        const int kind = a.Co_pad == 2 * NF ? GW_CONVOUT : a.Cin == 2 * NF ? GW_CONVIN : GW_DIL;
+        // item tiles per workgroup (tuning: PS_WG_TI = "out,in,dil")
+        int ti_of[3] = {2, 2, 2};
+        if (const char *e = getenv("PS_WG_TI")) sscanf(e, "%d,%d,%d", &ti_of[0], &ti_of[1], &ti_of[2]);
+        const int TI = ti_of[kind], MI = 16 * TI;
+        a.ny = (a.nitems + MI - 1) / MI;
+        a.tpx = (a.ny + N_XCD - 1) / N_XCD;
+        const dim3 grid((unsigned)(N_XCD * a.tpx)), block(GW_THREADS);
+        const bool fuse = post && !getenv("PS_GEMM_WG_NOFUSE");   // (tuning / parity: products only, k_post_grid afterwards)
+        PostArgs pp{};
+        if (fuse) { pp = *post; pp.summed = 1; }
+        const int fz = fuse ? 1 : 0;
+        if (kind == GW_CONVOUT && TI == 1) hipLaunchKernelGGL((k_gemm_wg<GW_CONVOUT, 1>), grid, block, 0, st, a, pp, fz);
+        else if (kind == GW_CONVOUT) hipLaunchKernelGGL((k_gemm_wg<GW_CONVOUT, 2>), grid, block, 0, st, a, pp, fz);
+        else if (kind == GW_CONVIN && TI == 2) hipLaunchKernelGGL((k_gemm_wg<GW_CONVIN, 2>), grid, block, 0, st, a, pp, fz);
+        else if (kind == GW_CONVIN) hipLaunchKernelGGL((k_gemm_wg<GW_CONVIN, 4>), grid, block, 0, st, a, pp, fz);
+        else if (TI == 2) hipLaunchKernelGGL((k_gemm_wg<GW_DIL, 2>), grid, block, 0, st, a, pp, fz);
+        else hipLaunchKernelGGL((k_gemm_wg<GW_DIL, 4>), grid, block, 0, st, a, pp, fz);
+        return fuse;
+    }
     hipLaunchKernelGGL(k_gemm, dim3((unsigned)(N_XCD * a.nx * a.tpx * a.zgrid)), dim3(64), 0, st, a);
+    return false;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2446,13 +2805,14 @@ void run_grid(ps_pixelcnn *h, int F, const int32_t *codes, const Masks &m, float
     }
     ItemMap items = all_items;
     auto at_stage = [&](int stage_id) { items.start = cone ? h->pstart + (size_t)stage_id * F : nullptr; };
-    auto gemm = [&](GemmArgs &a, const float *mask, const float *sum_bias = nullptr) {   // -> slots summed by the kernel?
+    // -> 0: raw slots in `partial`, 1: slots summed by the kernel, 2: the post op `post` done by the kernel as well
+    auto gemm = [&](GemmArgs &a, const float *mask, const float *sum_bias = nullptr, const PostArgs *post = nullptr) {
         a.items = items;
         a.H = h->H; a.W = h->W; a.L = h->L; a.nitems = nitems;
         a.mask = mask; a.mask_fstride = (size_t)9 * h->L; a.partial = h->partial; a.tiles_per_block = 1;
         a.sum_bias = sum_bias;
         const int tiles = (nitems + 15) / 16;
-        launch_gemm(a, tiles, st);
+        if (launch_gemm(a, tiles, st, post)) return 2;
         return a.sum_bias != nullptr ? 1 : 0;
     };
     // PS_GEMM_FUSE=1: one launch per stage (k_stage_fused: products + post op, no partial sums in HBM).  Bit-identical
@@ -2492,8 +2852,8 @@ void run_grid(ps_pixelcnn *h, int F, const int32_t *codes, const Masks &m, float
         }
         PostArgs p{items, h->partial, nitems, NF, h->L, G.node_skip >= 0, 0, G.b_in, G.b_skip, nullptr, nullptr, nullptr, h->X[g]};
         if (!stage(a, m.und, p, POST_CONVIN)) {
-            p.summed = gemm(a, m.und, G.b_in);
-            hipLaunchKernelGGL(k_post_grid<POST_CONVIN>, dim3(pblocks), dim3(256), 0, st, p);
+            p.summed = gemm(a, m.und, G.b_in, &p);
+            if (p.summed < 2) hipLaunchKernelGGL(k_post_grid<POST_CONVIN>, dim3(pblocks), dim3(256), 0, st, p);
         }
         GemmArgs b{};
         at_stage(15 + g);
@@ -2501,8 +2861,8 @@ void run_grid(ps_pixelcnn *h, int F, const int32_t *codes, const Masks &m, float
         PostArgs q{items, h->partial, nitems, 2 * NF, h->L, 0, 0, G.b_out, nullptr, h->R[G.node_in], h->R[G.node_out],
                    h->E[G.node_out], nullptr};
         if (!stage(b, m.und, q, POST_GATE)) {                                           // gate + residual (:160-163)
-            q.summed = gemm(b, m.und, G.b_out);
-            hipLaunchKernelGGL(k_post_grid<POST_GATE>, dim3(pblocks), dim3(256), 0, st, q);
+            q.summed = gemm(b, m.und, G.b_out, &q);
+            if (q.summed < 2) hipLaunchKernelGGL(k_post_grid<POST_GATE>, dim3(pblocks), dim3(256), 0, st, q);
         }
     };
     auto dilated = [&](int d) {
@@ -2512,8 +2872,8 @@ void run_grid(ps_pixelcnn *h, int F, const int32_t *codes, const Masks &m, float
         conv_taps(a, h->R[D.node_in], R_LD, D.w, NF, NF, 2);                            // model.py:138,148
         PostArgs p{items, h->partial, nitems, NF, h->L, 0, 0, D.b, nullptr, nullptr, h->R[D.node_out], h->E[D.node_out], nullptr};
         if (!stage(a, m.dil, p, POST_DIL)) {
-            p.summed = gemm(a, m.dil, D.b);
-            hipLaunchKernelGGL(k_post_grid<POST_DIL>, dim3(pblocks), dim3(256), 0, st, p);
+            p.summed = gemm(a, m.dil, D.b, &p);
+            if (p.summed < 2) hipLaunchKernelGGL(k_post_grid<POST_DIL>, dim3(pblocks), dim3(256), 0, st, p);
         }
     };
     gated(0); gated(1); dilated(0); gated(2); gated(3); dilated(1); gated(4); gated(5);     // up pass
@@ -3035,6 +3395,10 @@ void *ps_pixelcnn_debug_cache(ps_pixelcnn *h, int what, int idx)
     if (what == 2 && idx >= 0 && idx < NGATED) return h->X[idx];
     if (what == 3) return h->nbr_tp;   // neighbour slots of the last throughput launch [NST][2][1024][160]
     if (what == 5) return h->pstart;   // (33, F) int32 of the last AR run's prefix pass: first rank evaluated per stage and frame
+#ifdef PS_WG_TRACE_BUILD
+    if (what == 6) { void *p = nullptr; return hipGetSymbolAddress(&p, HIP_SYMBOL(g_wg_trace)) == hipSuccess ? p : nullptr; }
+    if (what == 7) { void *p = nullptr; return hipGetSymbolAddress(&p, HIP_SYMBOL(g_wg_span)) == hipSuccess ? p : nullptr; }
+#endif
     if (what == 4) {                   // tuning builds: allocate / return the stamp buffer [NST][8] of 64-bit clocks
         if (!h->tp_trace && dev_alloc(h, &h->tp_trace, (size_t)NST * 8) == PS_OK) (void)hipMemset(h->tp_trace, 0, NST * 8 * 8);
         return h->tp_trace;
