@@ -134,6 +134,7 @@ struct GemmArgs {
     int nslots, Cin, Co_pad, H, W, L, nitems, tiles_per_block;
     int nx, ny, tpx;    // launch geometry (launch_gemm): channel blocks, item blocks, item blocks per XCD
     int zgrid;          // slots along the grid (nslots), or 1 = every wave walks all slots
+    int wg_reverse;     // k_gemm_wg: workgroups walk the items from the end (tuning)
     const float *sum_bias;  // zgrid == 1 only: the wave adds its slots up itself, y = ((bias + NA) + C) + NB, and stores y in
                             // place of slot NA (a third of the partial traffic); null = raw slots
     const float *mask;
@@ -577,8 +578,9 @@ __global__ __launch_bounds__(GW_THREADS) void k_gemm_wg(GemmArgs a, PostArgs pa,
     __shared__ int sItem[MI];                // item index, -1 = not evaluated here
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, i = lane & 15, kk = lane >> 4;
     const int xcd = blockIdx.x & (N_XCD - 1), tb = blockIdx.x >> 3;
-    const int y = xcd * a.tpx + tb;          // contiguous item ranges per XCD, as in k_gemm
-    if (tb >= a.tpx || y >= a.ny) return;
+    const int yy = xcd * a.tpx + tb;         // contiguous item ranges per XCD, as in k_gemm
+    if (tb >= a.tpx || yy >= a.ny) return;
+    const int y = a.wg_reverse ? a.ny - 1 - yy : yy;   // (tuning: PS_WG_REVERSE)
     const int item0 = y * MI;
     const int ntaps = a.slot_first[a.nslots];
     const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -699,28 +701,43 @@ __global__ __launch_bounds__(GW_THREADS) void k_gemm_wg(GemmArgs a, PostArgs pa,
     };
     // products of tap t from buffer `buf`, added to tot[].  ALL: every item tile has an open lane -- straight-line code; else the
     // tiles of closed item tiles are left out (an exact zero) behind wave-uniform branches, one per tile and chain.
-    auto tap_products = [&](int t, int buf, auto ALLc) {
+    constexpr bool BPRE = gw_occ(KIND, TI) == 2;   // B operands read a chain ahead too, where the register budget is the large one
+    auto tap_products = [&](int t, int nxt, int buf, auto ALLc) {
         constexpr bool ALL = decltype(ALLc)::value;     // every tile of this wave is computed
         const unsigned tl = tiles_of(t);
         bool lv[NTL];
 #pragma unroll
         for (int k = 0; k < NTL; ++k) lv[k] = ALL || (k < NT4 ? ((tl >> b_of(k)) & 1u) != 0 : has5 && ((tl >> tix) & 1u));
         const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)a.tap[t].w, 0, 0x7fffffff, 0x00020000);
-        f32x4 taptot[NTL], an[NGH][NAU];
-#pragma unroll
-        for (int j = 0; j < 5; ++j) {
-            if (j < 4) {   // the next chain's weights are requested under this chain's MFMAs ...
-#pragma unroll
-                for (int h = 0; h < NGH; ++h)
-#pragma unroll
-                    for (int n = 0; n < NAU; ++n) an[h][n] = wload(wrs, j + 1 + 5 * h, n);
-            }
-            f32x4 bv[NGH][NBU], acc[NTL];
+        // (the last chain requests chain 0 of the NEXT open tap -- of this tap again when there is none, a valid address: the
+        // request count stays the same on every path -- so that a tap does not open with a memory round trip)
+        const __amdgpu_buffer_rsrc_t wnx = __builtin_amdgcn_make_buffer_rsrc((void *)a.tap[nxt < ntaps ? nxt : t].w, 0, 0x7fffffff, 0x00020000);
+        f32x4 taptot[NTL], an[NGH][NAU], bn[NGH][NBU];
+        auto bload = [&](int j, f32x4 (&dst)[NGH][NBU]) {
 #pragma unroll
             for (int h = 0; h < NGH; ++h) {
 #pragma unroll
-                for (int ti = 0; ti < TI; ++ti) bv[h][ti] = sB[buf * BUF + (ti * NG + j + 5 * h) * 64 + lane];
-                bv[h][TI] = sB[buf * BUF + (tix * NG + j + 5 * h) * 64 + lane];
+                for (int ti = 0; ti < TI; ++ti) dst[h][ti] = sB[buf * BUF + (ti * NG + j + 5 * h) * 64 + lane];
+                dst[h][TI] = sB[buf * BUF + (tix * NG + j + 5 * h) * 64 + lane];
+            }
+        };
+        if (BPRE) bload(0, bn);
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            // the next chain's weights are requested under this chain's MFMAs ...
+#pragma unroll
+            for (int h = 0; h < NGH; ++h)
+#pragma unroll
+                for (int n = 0; n < NAU; ++n) an[h][n] = j < 4 ? wload(wrs, j + 1 + 5 * h, n) : wload(wnx, 5 * h, n);
+            f32x4 bv[NGH][NBU], acc[NTL];
+            if (BPRE) {
+#pragma unroll
+                for (int h = 0; h < NGH; ++h)
+#pragma unroll
+                    for (int q = 0; q < NBU; ++q) bv[h][q] = bn[h][q];
+                if (j < 4) bload(j + 1, bn);
+            } else {
+                bload(j, bv);
             }
             __builtin_amdgcn_sched_barrier(0);   // ... and the scheduler may not pull their consumers up to them
             // chain j of the five tiles: group j (c = 0..3), then group j + 5 -- the tiles are independent accumulators
@@ -746,21 +763,19 @@ __global__ __launch_bounds__(GW_THREADS) void k_gemm_wg(GemmArgs a, PostArgs pa,
                     taptot[k] = j == 0 ? acc[k] : taptot[k] + acc[k];
                 }
             }
-            if (j < 4) {
 #pragma unroll
-                for (int h = 0; h < NGH; ++h)
+            for (int h = 0; h < NGH; ++h)
 #pragma unroll
-                    for (int n = 0; n < NAU; ++n) av[h][n] = an[h][n];
-            }
+                for (int n = 0; n < NAU; ++n) av[h][n] = an[h][n];
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int k = 0; k < NTL; ++k)
             if (lv[k]) tot[k] = tot[k] + taptot[k];
     };
-    auto tap_dispatch = [&](int t, int buf) {
-        if (has5 && tiles_of(t) == (1u << TI) - 1u) tap_products(t, buf, std::integral_constant<bool, true>{});
-        else tap_products(t, buf, std::integral_constant<bool, false>{});
+    auto tap_dispatch = [&](int t, int nxt, int buf) {
+        if (has5 && tiles_of(t) == (1u << TI) - 1u) tap_products(t, nxt, buf, std::integral_constant<bool, true>{});
+        else tap_products(t, nxt, buf, std::integral_constant<bool, false>{});
     };
     // ---- the taps in slot order NA, C, NB (, SKIP); the open ones staged through sB
     int cur = next_live(-1), buf = 0;
@@ -778,8 +793,7 @@ __global__ __launch_bounds__(GW_THREADS) void k_gemm_wg(GemmArgs a, PostArgs pa,
             if (t != cur) continue;              // no open lane in the whole tile: an exact zero, skipped by every wave
             const int nxt = next_live(t);
             if (nxt < ntaps) stage_load(nxt);    // in flight under the MFMAs
-            tap_dispatch(t, buf);
-            if (nxt < ntaps) a0_load(nxt);
+            tap_dispatch(t, nxt, buf);
             if (DB) {
                 if (nxt < ntaps) stage_store(nxt, buf ^ 1);
                 __syncthreads();                 // next tap's rows visible; everybody is done with this tap's
@@ -2766,6 +2780,7 @@ bool launch_gemm(GemmArgs &a, int item_blocks, hipStream_t st, const PostArgs *p
         a.ny = (a.nitems + MI - 1) / MI;
         a.tpx = (a.ny + N_XCD - 1) / N_XCD;
         const dim3 grid((unsigned)(N_XCD * a.tpx)), block(GW_THREADS);
+        a.wg_reverse = getenv("PS_WG_REVERSE") ? 1 : 0;
         const bool fuse = post && !getenv("PS_GEMM_WG_NOFUSE");   // (tuning / parity: products only, k_post_grid afterwards)
         PostArgs pp{};
         if (fuse) { pp = *post; pp.summed = 1; }

@@ -56,11 +56,14 @@ for n in (3, 2):
     ref = [torch.empty_like(out["PredImg"].cpu()) for _ in range(world)]
     dist.all_gather(ref, out["PredImg"].cpu())
     assert all(torch.equal(ref[0], r) for r in ref)      # every rank holds the same winner
-# a decoded image whose shape is NOT gen_fs's: a projector that widens the channels; the non-owner learns the shape from the owner
-m.projector = lambda combined, mask=None: torch.cat([combined, combined[:, :1]], 1)
-m.opt.num_samples = 2
-shared = m.get_best_sample(plan, codes, bg, gen_fs, Disc(), img, uniforms=uni, shard=True)
-assert tuple(shared.shape) == (1, 4, 256, 256)
+# the winner's transport on its own: a rank that holds nothing learns shape and dtype from the owner (the decoded / refined image
+# is not shaped like gen_fs when the features are not RGB)
+from pixelsynth_amd import distributed as D  # noqa: E402
+for src, shape, dt in ((0, (2, 5, 7), torch.float32), (1, (1, 4, 16, 16), torch.uint8)):
+    mine = (torch.arange(int(np.prod(shape)), device=DEV) % 251).reshape(shape).to(dt) if rank == src else None
+    got = D.broadcast_from(mine, src, DEV)
+    want = (torch.arange(int(np.prod(shape)), device=DEV) % 251).reshape(shape).to(dt)
+    assert got.is_cuda and got.dtype == dt and tuple(got.shape) == shape and torch.equal(got, want), (rank, src)
 m.outpaint2.engine(32, 32, 1).check()
 if rank == 0:
     print("ok")

@@ -500,8 +500,8 @@ def test_forward_gen_order_dispatch():
 def test_sharded_sample_ranking_two_ranks_equals_one(tmp_path):
     """get_best_sample(shard=True) under two ranks (both on cuda:0, gloo): candidates dealt round-robin, two scalars per
     candidate gathered, the winner broadcast from its owner (shape learnt from the owner) -- every rank ends with the image the
-    single-process ranking keeps; also with fewer candidates than ranks would need (n = 1 ... handled upstream) and with a
-    non-RGB feature count, where the broadcast buffer cannot be guessed from gen_fs."""
+    single-process ranking keeps; forward_image routes there with opt.shard_samples; and the winner's transport alone hands a
+    rank that holds nothing a tensor whose shape and dtype it could not have guessed."""
     import subprocess
     import sys
     import socket
