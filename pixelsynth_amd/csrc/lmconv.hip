@@ -1963,8 +1963,25 @@ __global__ __launch_bounds__(C1_THREADS) void k_column(NbrArgs na, ChainArgs ca)
 //                   at a time; results leave write-through, a per-(stage, tile) counter publishes them.
 // The hand-off (write-through stores -> device-scope counter -> device-scope loads, bounded waits) is the one of k_column.
 // ==========================================================================================
+// The chain role of k_column_tp: 0 = chain_role_tp (round 2: eight waves, (output tile, chain) units dealt round-robin, post op of
+// two columns per wave after a trip of the chain values through LDS) -- the default; 1 = chain_role_tp2 (round 3: ten waves, one
+// output tile with all its chains per wave, post op in the MFMA layout).  Both are bit-identical to the walk (the tests pass with
+// either).  Measured at C5's 128 views, per launch, chain role alone / whole launch: 0: 125 / 148 us; 1: 126 / 156 us as first
+// written (a third of the vector instructions, but ten waves leave the neighbour role 168 registers: 92 -> 98 us alone), and no
+// arrangement of its memory requests got below that: next stage's operands and control values fetched under the post op 148
+// alone, weights refilled in place under the MFMAs in one burst 158, one request per five MFMAs 131.  What a stage costs either
+// way (~8 k cycles) is not instruction count: ~3.2-3.8 k cycles of MFMA on one CU's four pipes, ~2.5 k cycles in which the CU's
+// vector-memory path (64 bytes a clock) carries the stage's 100 KB of centre-tap weights, ~2.5 k of post op and barriers, and
+// because every wave of the workgroup is in the same phase at the same time the three do not overlap.
+#ifndef PS_TP_CHAIN2
+#define PS_TP_CHAIN2 0
+#endif
 #ifndef PS_TP_WAVES
+#if PS_TP_CHAIN2
+#define PS_TP_WAVES 10
+#else
 #define PS_TP_WAVES 8
+#endif
 #endif
 constexpr int TP_WAVES = PS_TP_WAVES, TP_THREADS = 64 * TP_WAVES, TP_COLS = 16;   // 8 waves (256 registers per thread) or 16 (128)
 constexpr int TP_NPC = TP_COLS / TP_WAVES;   // columns a wave does the post op of: 2 or 1
@@ -2101,6 +2118,7 @@ __device__ __forceinline__ void nbr_role_tp(const TpArgs &a, int nb)
     }
 }
 
+#if !PS_TP_CHAIN2
 __device__ __forceinline__ void chain_role_tp(const TpArgs &a, int tile)
 {
     // (Both 16-byte-accessed buffers are DECLARED as 16-byte elements: behind a float array and a run-time index hipcc cannot
@@ -2471,22 +2489,374 @@ __device__ __forceinline__ void chain_role_tp(const TpArgs &a, int tile)
     }
 }
 
+#endif   // !PS_TP_CHAIN2
+
+// ------------------------------------------------------------------------------------------
+// chain_role_tp2 (round 3): the chain role of k_column_tp with the post op done IN THE MFMA LAYOUT.
+// chain_role_tp deals the (output tile, accumulation chain) units of a stage round-robin to eight waves, parks the five chain
+// values of every output in LDS, and after a barrier every wave does the post op of two columns, two channels per lane on 40
+// lanes: ~300 vector instructions per wave and stage, the longest part of a stage (2.5-3.8 k of its 7-12 k cycles, with ~0.8 k
+// more for the trip of the chain values through LDS).  Here a 640-thread workgroup has ten waves and wave w owns OUTPUT TILE w
+// of the stage with all five of its chains (conv_out: 10 tiles of 160 channels; conv_input: tiles 0-4, and nin_skip's five
+// tiles on waves 5-9), so that an output's chain values meet in registers: lane (kk, i) holds channels 16 w + 4 kk .. + 3 of
+// column i -- the D layout of the MFMA -- and does everything elementwise right there: chain total, ((bias + NA) + centre) +
+// NB with 16-byte operand loads, PONO's normalisation, gate / skip / residual, concat-ELU, and ONE 16-byte store per array
+// straight into the B-operand layout of the next stage and into the caches.  What has to cross lanes are PONO's two sums over
+// the 80 channels of a column: 4 -> 8 -> 16 channels inside the wave (lanes i, i + 16, i + 32, i + 48), five tile sums per
+// column through 320 bytes of LDS, in pono_total's association order -- two more LDS barriers per stage, on almost no data.
+// The gate half / the nin_skip slot reach the waves that hold y through 5 KB of LDS ahead of the first of them.
+// Same arithmetic, same order, bit-identical results (the tests compare with the walk and with the reference's trace).
+// ------------------------------------------------------------------------------------------
+#if PS_TP_CHAIN2
+__device__ __forceinline__ float xlane_add(float x, int mask) { return x + __shfl_xor(x, mask, 64); }
+__device__ __forceinline__ void chain_role_tp2(const TpArgs &a, int tile)
+{
+    static_assert(TP_WAVES == 10, "one output tile of a 160-channel stage per wave");
+    __shared__ f32x4 sXS4[2 * XB_SIZE / 4];                                // B-operand layout: input of the centre taps, and behind
+    float *const sXS = (float *)sXS4;                                      //   it concat_elu(u_k) feeding nin_skip
+    float *const sXb = sXS, *const sSb = sXS + XB_SIZE;
+    __shared__ f32x4 sP4[TP_COLS * SLOG_LD / 4];                           // logits of the tile's columns (the end of the chain)
+    __shared__ f32x4 sU4[8 * TP_COLS * NF / 4];                            // u0..u7 of the tile's columns [slot][col][80]
+    __shared__ f32x4 sG4[5 * 64];                                          // gate half / nin_skip slot of the stage, [tile][lane]
+    __shared__ float sStat[2][5][TP_COLS];                                 // PONO: per-tile sums of y and of (y - mean)^2 per column
+    __shared__ __attribute__((aligned(16))) StepCtx sC[TP_COLS];
+    __shared__ __attribute__((aligned(16))) int sCtl[(NST + 1) * C1_CTL_DWORDS];
+    const int t = threadIdx.x, wave = uni(t >> 6), lane = t & 63, i = lane & 15, kk = lane >> 4;
+    const int col0 = tile * TP_COLS;
+    const int ncl = min(TP_COLS, a.ncols - col0);   // columns of this tile (>= 1)
+    {
+        const int nq = (int)(sizeof(StepCtx) / 16);
+        for (int k = t; k < TP_COLS * nq; k += TP_THREADS) {
+            const int c = min(k / nq, ncl - 1);     // absent columns repeat the last one (their results are dropped)
+            ((uint4 *)sC)[k] = ((const uint4 *)(a.ctx + col0 + c))[k % nq];
+        }
+        for (int k = t; k < XB_SIZE; k += TP_THREADS) { sXb[k] = 0.0f; sSb[k] = 0.0f; }
+        for (int k = t; k < (NST + 1) * C1_CTL_DWORDS / 4; k += TP_THREADS) ((uint4 *)sCtl)[k] = ((const uint4 *)a.ctl1)[k];
+    }
+    __syncthreads();
+    auto li = [&](int rec, int field) { return uni(sCtl[rec * C1_CTL_DWORDS + field]); };
+    auto lpf = [&](int rec, int field) {
+        const unsigned lo = (unsigned)li(rec, field), hi = (unsigned)li(rec, field + 1);
+        return (float *)(((unsigned long long)hi << 32) | lo);
+    };
+    const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+    const bool ywave = wave < 5;                       // holds y of output tile `wave` (channels 16 wave .. + 15)
+    const int otw = ywave ? wave : wave - 5;           // the tile of y this wave pairs with (gate half / nin_skip slot)
+    const bool cvalid = i < ncl;
+    const int fr = sC[i].f;
+    const size_t loc = (size_t)fr * a.L + sC[i].q;     // this lane's column
+    const int ch = 16 * otw + 4 * kk;                  // this lane's channels (of y; the gate wave's are 80 + ch)
+    const int xg = (ch >> 2) * XB_LD + i * 4;          // their place in the B-operand layout (floats)
+    const size_t nbr_half = (size_t)TP_COL_CAP * NBR_LD, nbr_stage = 2 * nbr_half;
+    const unsigned my_uses = a.tile_uses[tile];
+    // The counter is requested a stage before it is looked at.  It must stay a VECTOR value until then: a wave-uniform load is
+    // turned into a scalar by v_readfirstlane where it is issued, i.e. the wave waits for it -- and for every load in front of
+    // it -- on the spot (~1 k cycles per stage).  The lane offset below is zero, but not to the compiler.
+    int vzero = 0;
+    asm volatile("" : "+v"(vzero));
+    auto counter = [&](int k) { return __hip_atomic_load(a.cnt + tp_cnt_index(k, tile) + vzero, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto wait_counter = [&](unsigned have, int k, unsigned items_per_tile) {
+        if (a.debug & 1) return;
+        const unsigned need = my_uses * items_per_tile;
+        int spins = 0;
+        while (__builtin_amdgcn_ballot_w64((int)(have - need) < 0) != 0ull) {
+            if (++spins > WAIT_SPINS) { if (lane == 0) *a.err = 1; break; }
+            __builtin_amdgcn_s_sleep(2);
+            have = counter(k);
+        }
+        asm volatile("" ::: "memory");
+    };
+    auto fresh4 = [](const float *p) {   // 16 bytes another workgroup of this launch wrote (device-scope loads, past this CU's L1)
+        const unsigned long long lo = __hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long hi = __hip_atomic_load((const unsigned long long *)p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return f32x4{__uint_as_float((unsigned)lo), __uint_as_float((unsigned)(lo >> 32)), __uint_as_float((unsigned)hi),
+                     __uint_as_float((unsigned)(hi >> 32))};
+    };
+    auto plain4 = [](const float *p) { return *PS_GC(f32x4, p); };
+    // sum over the 80 channels of every column, in pono_total's order: 2 + 2 channels in the lane, 4 + 4 and 8 + 8 across the
+    // lanes of the wave (tile sums), then R0 = t0 + t1, R1 = t2 + t3, R2 = t4 through LDS, total = R2 + (R1 + R0)
+    auto tile_sum = [&](const f32x4 &v) {
+        float q = (v[0] + v[1]) + (v[2] + v[3]);
+        q = xlane_add(q, 16);
+        q = xlane_add(q, 32);
+        return q;
+    };
+    auto total_of = [&](int which) {
+        const float t0 = sStat[which][0][i], t1 = sStat[which][1][i], t2 = sStat[which][2][i], t3 = sStat[which][3][i], t4 = sStat[which][4][i];
+        return t4 + ((t2 + t3) + (t0 + t1));
+    };
+#ifdef PS_TP_TRACE_BUILD
+    int trace_s = 0;
+    const int trace_wave = a.debug >> 8;   // PS_COLUMN_DEBUG = 256 * wave (+ mode): the wave whose stamps are kept
+#define TP2_STAMP(slot) do { if (a.trace && tile == 0 && t == 64 * trace_wave) a.trace[trace_s * 8 + (slot)] = clock64(); } while (0)
+#else
+#define TP2_STAMP(slot) do { } while (0)
+#endif
+    f32x4 ucur = zero;   // u of this lane's (column, channels): the residual input of the next gate
+    // everything after the products: y = this lane's four channels of its column (y waves), aux = the gate half / nin_skip slot
+    // (waves 5-9).  KIND / HAS_SKIP are compile-time; in_form, save_slot, skip_slot wave-uniform.
+    // weights of this wave's tile of a stage: NG 16-byte loads from the standard packed layout [c / 4][o][4] (the centre tap of
+    // the conv, or nin_skip's matrix for waves 5-9 of a conv_input with skip)
+    f32x4 wl[10];
+    const float *wcur_base = nullptr; // this wave's weights of the stage whose control values are in nctl ...
+    size_t wcur_gs = 0;
+    const float *wq_base = nullptr;   // ... and this wave's weights of the stage AFTER the one whose control values are in nctl
+    size_t wq_gs = 0;                 //   (floats between channel groups): requested under that stage's own MFMAs
+    auto weight_address = [&](int rec) {   // (every wave, idle ones and 5-group stages included, gets ten valid addresses: the request
+        const int cv = sCtl[rec * C1_CTL_DWORDS + (lane & (C1_CTL_DWORDS - 1))];   // count stays the same on every path)
+        auto fi = [&](int field) { return __builtin_amdgcn_readlane(cv, field); };
+        auto fp = [&](int field) { return (const float *)(((unsigned long long)(unsigned)fi(field + 1) << 32) | (unsigned)fi(field)); };
+        const int ty = fi(CTL_TP_TYPE);
+        const int Co = ty == TPT_CONVOUT ? 2 * NF : NF;
+        const float *w = (!ywave && ty == TPT_CONVIN_SKIP) ? fp(CTL_WS) : fp(CTL_WC);
+        const int o = (ty == TPT_CONVOUT ? wave : otw) * 16 + i;
+        wq_base = w + ((size_t)kk * Co + o) * 4;
+        wq_gs = (size_t)16 * Co;
+    };
+    // The NEXT stage's control values and post-op operands are fetched at the head of this phase (prefetch_stage): a stage then
+    // opens with its products, not with ~1.5 k cycles of descriptor reads, counter check and operand requests.
+    struct StageCtl { int ty, in_form, save_slot, skip_slot; float *R, *E, *X; };
+    StageCtl nctl{};
+    f32x4 nob = zero, nona = zero, nonb = zero;
+    unsigned cnt_have = 0;
+    auto prefetch_stage = [&](int s) {   // stage s < NST - 1: its record is 1 + s
+        const int rec = 1 + s;
+        // the whole 32-dword record with ONE LDS read (a dword per lane), its fields by v_readlane: a ds_read + readfirstlane per
+        // field were two dozen dependent round trips on the critical path of every stage
+        const int cv = sCtl[rec * C1_CTL_DWORDS + (lane & (C1_CTL_DWORDS - 1))];
+        auto fi = [&](int field) { return __builtin_amdgcn_readlane(cv, field); };
+        auto fp = [&](int field) { return (float *)(((unsigned long long)(unsigned)fi(field + 1) << 32) | (unsigned)fi(field)); };
+        nctl = StageCtl{fi(CTL_TP_TYPE), fi(CTL_IN_FORM), fi(CTL_SAVE_SLOT), fi(CTL_SKIP_SLOT), fp(CTL_R), fp(CTL_E), fp(CTL_X)};
+        const float *bias = fp(CTL_BIAS), *bias2 = fp(CTL_BIAS2);
+        wait_counter(cnt_have, s, (unsigned)fi(CTL_TP_ITEMS));
+        cnt_have = counter(min(s + 1, NST - 2));             // looked at a stage later
+        // (requested by every wave alike -- idle ones drop them -- so that the request count is the same on every path)
+        const int och = nctl.ty == TPT_CONVOUT ? 16 * wave + 4 * kk : ch;   // channel of this lane in the stage's output (gate half: 80 + ch)
+        nob = plain4((!ywave && nctl.ty == TPT_CONVIN_SKIP) ? bias2 + ch : bias + och);
+        const float *nb = a.nbr + (size_t)s * nbr_stage + (size_t)(col0 + (cvalid ? i : 0)) * NBR_LD + och;
+        nona = fresh4(nb);
+        nonb = fresh4(nb + nbr_half);
+        weight_address(2 + s);
+    };
+    auto finish = [&](const f32x4 &yv, const f32x4 &aux, bool has_aux, auto KINDc, auto SKIPc, int in_form, int save_slot, int skip_slot,
+                      float *R, float *E, float *X, int next_stage) {
+        constexpr int kind = decltype(KINDc)::value;
+        constexpr bool has_skip = decltype(SKIPc)::value;
+        if (next_stage < NST - 1) prefetch_stage(next_stage);
+        if (!ywave && has_aux) sG4[otw * 64 + lane] = aux;
+        if (ywave) {
+            const float ts = tile_sum(yv);
+            if (kk == 0) sStat[0][wave][i] = ts;
+        }
+        TP2_STAMP(4);
+        lds_barrier();
+        TP2_STAMP(5);
+        f32x4 d = zero;
+        if (ywave) {
+            const float mean = pono_mean(total_of(0));
+            d = yv - mean;
+            const float ts = tile_sum(d * d);
+            if (kk == 0) sStat[1][wave][i] = ts;
+        }
+        lds_barrier();
+        TP2_STAMP(6);
+        if (ywave) {
+            const float inv = pono_inv(total_of(1));
+            const f32x4 n = d * inv;
+            f32x4 out = n;
+            if (kind == PRO_CONVIN && has_skip) out = n + sG4[otw * 64 + lane];
+            if (kind == PRO_GATE) {
+                const f32x4 g = sG4[otw * 64 + lane];
+                out = ucur + n * f32x4{sigmoid1(g[0]), sigmoid1(g[1]), sigmoid1(g[2]), sigmoid1(g[3])};
+            }
+            f32x4 ep, en;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { float p_, n_; celu_pair(out[e], p_, n_); ep[e] = p_; en[e] = n_; }
+            if (cvalid) {
+                if (in_form == IN_CELU) { sXS4[xg >> 2] = ep; sXS4[(xg + 20 * XB_LD) >> 2] = en; }
+                else if (in_form == IN_RAW) sXS4[xg >> 2] = out;
+                else sXS4[xg >> 2] = ep;
+                if (kind == PRO_CONVIN) {
+                    *PS_G(f32x4, X + loc * (2 * NF) + ch) = ep;
+                    *PS_G(f32x4, X + loc * (2 * NF) + NF + ch) = en;
+                } else {
+                    *PS_G(f32x4, R + loc * R_LD + ch) = out;
+                    *PS_G(f32x4, E + loc * (2 * NF) + ch) = ep;
+                    *PS_G(f32x4, E + loc * (2 * NF) + NF + ch) = en;
+                    if (save_slot >= 0) sU4[((save_slot * TP_COLS + i) * NF + ch) >> 2] = out;
+                }
+            }
+            if (kind != PRO_CONVIN) ucur = out;
+            if (skip_slot >= 0) {   // concat_elu(u_k) of the saved u the NEXT stage's nin_skip reads
+                const f32x4 u = sU4[((skip_slot * TP_COLS + i) * NF + ch) >> 2];   // (written above when it is this very u: same lane, in order)
+                f32x4 sp, sn;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { float p_, n_; celu_pair(u[e], p_, n_); sp[e] = p_; sn[e] = n_; }
+                sXS4[(XB_SIZE + xg) >> 2] = sp;
+                sXS4[(XB_SIZE + xg + 20 * XB_LD) >> 2] = sn;
+            }
+        }
+        TP2_STAMP(7);
+        lds_barrier();
+    };
+    // one conv stage.  TY fixes the products (which waves, how many groups) and the post op that follows.
+    auto run_stage = [&](int s, auto TYc) {
+        constexpr int TY = decltype(TYc)::value;
+        constexpr int kind = TY == TPT_CONVOUT ? PRO_GATE : TY == TPT_DIL ? PRO_DIL : PRO_CONVIN;
+        constexpr bool has_skip = TY == TPT_CONVIN_SKIP;
+        constexpr bool second = TY == TPT_CONVOUT || TY == TPT_CONVIN_SKIP;   // waves 5-9 have products too
+        constexpr int NGH = TY == TPT_DIL ? 1 : 2;
+        using std::integral_constant;
+        const bool active = ywave || second;
+#ifdef PS_TP_TRACE_BUILD
+        trace_s = s;
+#endif
+        TP2_STAMP(0);
+        // this stage's control values and operands were fetched during the previous stage's post op
+        const StageCtl c = nctl;
+        const f32x4 ob = nob, ona = nona, onb = nonb;
+        TP2_STAMP(1);
+        f32x4 tsum = zero;
+        TP2_STAMP(2);
+        // Weights go through the CU's vector-memory path at 64 bytes a clock: 10 waves x 10 KB = ~1700 cycles per stage that only
+        // the matrix phase is long enough to cover -- and only if every wave spreads its requests BETWEEN its own MFMAs (all waves
+        // run the same phase at the same time: requests bunched behind the MFMAs, or in front of the post op, queue up there).
+        // One register buffer, refilled in place, a 16-byte request per five MFMAs:
+        //   first half of the products (groups 0-4, wl[0..4])   <-  wl[5..9] of THIS stage  (needed by the second half)
+        //   second half (groups 5-9, wl[5..9])                  <-  wl[0..4] of the NEXT stage
+        const float *wc = wcur_base, *wn = wq_base;     // this stage's / the next stage's weights of this wave
+        const size_t gc = wcur_gs, gn = wq_gs;
+        if (active) {
+            const f32x4 *x4 = (!ywave && has_skip) ? sXS4 + XB_SIZE / 4 : sXS4;
+            Acc5 acc = acc5_zero();
+#pragma unroll
+            for (int h = 0; h < NGH; ++h) {
+                f32x4 bx[5];
+#pragma unroll
+                for (int j = 0; j < 5; ++j) bx[j] = x4[((4 * (j + 5 * h) + kk) * XB_LD + i * 4) >> 2];
+                f32x4 nw[5];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+#pragma unroll
+                    for (int j = 0; j < 5; ++j)
+                        acc.v[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[j + 5 * h][c], bx[j][c], acc.v[j], 0, 0, 0);
+                    // requests of this quarter: 2, 1, 1, 1
+#pragma unroll
+                    for (int q = (c == 0 ? 0 : c + 1); q < (c == 0 ? 2 : c + 2); ++q)
+                        nw[q] = (h == 0 && NGH == 2) ? *PS_GC(f32x4, wc + (5 + q) * gc) : *PS_GC(f32x4, wn + q * gn);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int q = 0; q < 5; ++q) wl[(h == 0 && NGH == 2) ? 5 + q : q] = nw[q];
+            }
+            tsum = chunk_total(acc);
+        } else {   // no products in this stage: only the next stage's first half is due
+#pragma unroll
+            for (int q = 0; q < 5; ++q) wl[q] = *PS_GC(f32x4, wn + q * gn);
+        }
+        wcur_base = wn;
+        wcur_gs = gn;
+        f32x4 yv;
+        if (!ywave && has_skip) yv = tsum + ob;                          // nin_skip slot + its bias (layers.py:155-156)
+        else yv = ((ob + ona) + tsum) + onb;                             // y = ((bias + NA) + centre) + NB
+#ifdef PS_TP_TRACE_BUILD
+        if (a.trace && tile == 0 && t == 64 * trace_wave && yv[0] != 12345.678f) a.trace[trace_s * 8 + 3] = clock64();
+#endif
+        finish(yv, yv, second, integral_constant<int, kind>{}, integral_constant<bool, has_skip>{}, c.in_form, c.save_slot, c.skip_slot, c.R, c.E,
+               c.X, s + 1);
+    };
+    // ================= u0 = norm_init(u_init): gather over the (earlier) neighbours' codes =================
+    {
+        weight_address(1);           // stage 0's first half: requested here, under the gather (the second under its own MFMAs)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) wl[j] = *PS_GC(f32x4, wq_base + j * wq_gs);
+        wcur_base = wq_base;
+        wcur_gs = wq_gs;
+        cnt_have = counter(0);
+        f32x4 y = zero;
+        if (ywave) {
+            const StepCtx &cx = sC[i];
+            float mA[9];
+            int ncode[9], nl[9];
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) { mA[tp] = cx.m[0][tp]; nl[tp] = cx.nloc[tp]; }
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) ncode[tp] = a.codes_in[(size_t)fr * a.L + max(nl[tp], 0)];
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) ncode[tp] = nl[tp] >= 0 ? ncode[tp] : UINIT_CLOSED;
+            y = uinit_from_codes<f32x4>(ncode, mA, a.uinit_w, a.uinit_b, ch);
+        }
+        finish(y, y, false, std::integral_constant<int, PRO_UINIT>{}, std::integral_constant<bool, false>{}, li(0, CTL_IN_FORM),
+               li(0, CTL_SAVE_SLOT), li(0, CTL_SKIP_SLOT), lpf(0, CTL_R), lpf(0, CTL_E), lpf(0, CTL_X), 0);
+    }
+    // ================= the 32 conv stages =================
+    for (int s = 0; s < NST - 1; ++s) {
+        using std::integral_constant;
+        const int ty = nctl.ty;
+        if (ty == TPT_CONVOUT) run_stage(s, integral_constant<int, TPT_CONVOUT>{});
+        else if (ty == TPT_CONVIN_SKIP) run_stage(s, integral_constant<int, TPT_CONVIN_SKIP>{});
+        else if (ty == TPT_CONVIN) run_stage(s, integral_constant<int, TPT_CONVIN>{});
+        else run_stage(s, integral_constant<int, TPT_DIL>{});
+    }
+    // ================= nin_out(elu(u)) (model.py:153): 32 output tiles x 5 chains of 4 MFMAs, logits, draw =================
+    {
+        f32x4 bx[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) bx[j] = sXS4[((4 * j + kk) * XB_LD + i * 4) >> 2];
+        for (int ot = wave; ot < NCLS / 16; ot += TP_WAVES) {
+            f32x4 av[5];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) av[j] = *PS_GC(f32x4, a.out_w + ((size_t)(4 * j + kk) * NCLS + ot * 16 + i) * 4);
+            Acc5 acc = acc5_zero();
+            mfma_chunk5(av, bx, acc);
+            sP4[(i * SLOG_LD + ot * 16 + kk * 4) >> 2] = chunk_total(acc);
+        }
+    }
+    lds_barrier();
+    for (int col = wave; col < ncl; col += TP_WAVES) {
+        float lg[8];
+        const f32x4 lo = sP4[(col * SLOG_LD + lane * 8) >> 2], hi = sP4[((col * SLOG_LD + lane * 8) >> 2) + 1];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { lg[q] = lo[q] + a.out_b[lane * 8 + q]; lg[4 + q] = hi[q] + a.out_b[lane * 8 + 4 + q]; }
+        const int cf = uni(sC[col].f);
+        const size_t cloc = (size_t)cf * a.L + uni(sC[col].q);
+        if (a.out_logits) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) a.out_logits[cloc * NCLS + lane * 8 + q] = lg[q];
+        }
+        if (a.step_logits) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) a.step_logits[(size_t)cf * NCLS + lane * 8 + q] = lg[q];
+        }
+        if (a.codes && a.region[cloc]) {
+            const int code = a.forced ? a.forced[cloc] : draw_code(lg, a.temperature, a.uniforms[cloc], lane);
+            if (lane == 0) a.codes[cloc] = code;
+        }
+    }
+}
+#endif
+
 // chain_xcds = 0: blocks [0, nbr_wgs) neighbour role (they never wait for anything), the blocks after them one chain tile each.
 // chain_xcds = cx > 0 (speed only; block b runs on XCD b % 8): the chain tiles are the blocks on XCDs 0 .. cx-1, whose L2s then
 // hold the 2.8 MB of centre-tap weights instead of sharing their bandwidth with the neighbour role's operand stream; every
 // other block is a neighbour workgroup (the spare CUs of the chain XCDs too when fill is set).
+#if PS_TP_CHAIN2
+#define CHAIN_ROLE_TP chain_role_tp2
+#else
+#define CHAIN_ROLE_TP chain_role_tp
+#endif
 __global__ __launch_bounds__(TP_THREADS) void k_column_tp(TpArgs a)
 {
     const int b = blockIdx.x, cx = a.chain_xcds;
     if (cx == 0) {
         if (b < a.nbr_wgs) { if ((a.debug & 3) != 3) nbr_role_tp(a, b); }
-        else if ((a.debug & 3) != 2) chain_role_tp(a, b - a.nbr_wgs);
+        else if ((a.debug & 3) != 2) CHAIN_ROLE_TP(a, b - a.nbr_wgs);
         return;
     }
     const int x = b & 7, slot = b >> 3;
     if (x < cx) {
         const int tile = slot * cx + x;
-        if (tile < a.tiles) { if ((a.debug & 3) != 2) chain_role_tp(a, tile); }
+        if (tile < a.tiles) { if ((a.debug & 3) != 2) CHAIN_ROLE_TP(a, tile); }
         else if (a.fill_nbr >= 0 && (a.debug & 3) != 3) nbr_role_tp(a, a.fill_nbr + (tile - a.tiles));
     } else if ((a.debug & 3) != 3) {
         nbr_role_tp(a, slot * (8 - cx) + (x - cx));
