@@ -135,6 +135,20 @@ def run_steps(model, d, world, n, side):
     return out
 
 
+def run_steps_overlapped(model, d, world, n, runner):
+    """n steps on the two compute-unit partitions of pixelsynth_amd.pipeline.OverlappedOutpainter: the column launches of step i
+    on one, the reprojection / splat / planning and most of the whole-grid prefix pass of step i + 1 on the other.  Same work
+    per step, the steps are independent; results identical to n x run_step (tests/test_bench_gpu.py)."""
+    def after(i, out):
+        if world > 1:
+            out["all_features_u8"] = D.gather_frames(D.to_image_u8(out["gen_fs"]))
+            out["all_codes"] = D.gather_frames(out["codes"].contiguous())
+    batch = dict(img=d["img"], depth=d["depth"], K=d["K"], Kinv=d["Kinv"], P=d["P"], Pinv=d["Pinv"], RT2=d["RT2"], RT2inv=d["RT2inv"],
+                 codes=d["codes"], uniforms=d["uniforms"])
+    outs = runner.run([batch] * n, temperature=0.7, after=after)
+    return outs[-1] if outs else None
+
+
 def measure_roofline(model, d, out, V):
     """Average launch of k_column -- the dominant kernel: one launch per WAVEFRONT of independent columns (one column =
     one order position of one frame) -- over a whole AR run of this step's views, measured with HIP events on the stream
@@ -524,6 +538,11 @@ def main():
     ap.add_argument("--frames", type=int, default=64, help="--trajectory circle: frames of the circle in total")
     ap.add_argument("--cameras", choices=["mp3d", "demo"], default=None, help="Matterport-shaped (C5, default) or demo / RealEstate10K-shaped inputs (default for the circle)")
     ap.add_argument("--depth", choices=["smooth", "uniform"], default="smooth")
+    ap.add_argument("--overlap", action="store_true", help="experiment (measured slower, DESIGN.md section 5): steps pipelined over two compute-unit "
+                    "partitions (pixelsynth_amd/pipeline.py) instead of one stream + a side stream")
+    ap.add_argument("--cus-main", type=int, default=int(os.environ.get("PS_CUS_MAIN", "160")), help="compute units of the column launches' partition")
+    ap.add_argument("--prefix-share", type=float, default=float(os.environ.get("PS_PREFIX_SHARE", "0.6")),
+                    help="fraction of a step's frames whose prefix pass runs beside the previous step's column launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the C3 single-view / C2 splat-only side measurements")
     ap.add_argument("--dump-gather", metavar="NPZ", help="rank 0 saves what the last step gathered from all ranks (tests)")
@@ -570,12 +589,26 @@ def main():
         torch.cuda.synchronize()
 
     side = torch.cuda.Stream()
-    out = run_steps(model, d, world, args.warmup, side) if args.warmup > 0 else None
+    # throughput-form batches (the column launches leave a third of the chip idle) are pipelined over two compute-unit
+    # partitions; small batches (latency form) keep round 2's single-stream pipeline
+    from pixelsynth_amd.lmconv.model import TP_MIN_FRAMES
+    overlap = args.overlap and V >= TP_MIN_FRAMES
+    runner = None
+    if overlap:
+        from pixelsynth_amd.pipeline import OverlappedOutpainter
+        runner = OverlappedOutpainter(model, cus_main=args.cus_main, prefix_share=args.prefix_share, device=device)
+        steps_fn = lambda k: run_steps_overlapped(model, d, world, k, runner)
+    else:
+        steps_fn = lambda k: run_steps(model, d, world, k, side)
+    out = steps_fn(args.warmup) if args.warmup > 0 else None
     barrier()
     t0 = time.perf_counter()
-    out = run_steps(model, d, world, args.steps, side)
+    out = steps_fn(args.steps)
     barrier()
     dt = time.perf_counter() - t0
+    if runner is not None:
+        runner.check()
+        runner.close()
     model.outpaint2.engine(32, 32, V).check()  # (outside the timed region) no column launch gave up on an in-launch wait
     elapsed = D.max_over_ranks(dt, None if dry else device)
 
@@ -605,7 +638,10 @@ def main():
                        "views_per_gpu": V, "image": "256x256", "code_grid": "32x32", "num_classes": 512,
                        "ar_steps_walked": 1024 - plan.first_step,
                        "sampled_codes_per_view_mean": round(float(np.mean(plan.n_sampled)), 1),
-                       "parallelism": f"views sharded over {world} GPU(s), RCCL all_gather of the reprojected views (8-bit) + completed code grids"},
+                       "parallelism": f"views sharded over {world} GPU(s), RCCL all_gather of the reprojected views (8-bit) + completed code grids",
+                       "step_pipeline": (f"two compute-unit partitions: column launches of step i on {args.cus_main} CUs, splat / plan and "
+                                         f"{args.prefix_share:.0%} of the prefix pass of step i + 1 on the other {256 - args.cus_main}" if overlap else
+                                         "one stream; host half of step i + 1 on an unmasked side stream")},
         }
         if world == 1:
             try:

@@ -228,6 +228,32 @@ int ps_pixelcnn_ar_run_waves(ps_pixelcnn *h, int32_t *codes, const int32_t *orde
                              int first_step, const int32_t *wave_cols, const int32_t *wave_start,
                              int n_waves, float *out_logits, void *stream);
 
+/* The two halves of ps_pixelcnn_ar_run_waves as calls of their own, for callers that overlap them across batches (the column
+ * launches of one batch are bound by the latency of their 33 dependent stages and leave about a third of the chip idle; the
+ * whole-grid pass of the NEXT batch fills it when it runs beside them, on another handle and another stream):
+ *   ps_pixelcnn_ar_prefix   frames [frame_begin, frame_end) of the F: their sampled codes are masked out and the whole-grid pass
+ *                           over their observed prefix (order positions < first_step) fills the handle's activation caches.
+ *                           Disjoint frame ranges are independent -- they may be issued on different streams;
+ *   ps_pixelcnn_ar_columns  the column launches of all F frames (schedule as for ps_pixelcnn_ar_run_waves), after every frame's
+ *                           prefix pass has completed (the caller orders the streams).
+ * Together they do exactly what ps_pixelcnn_ar_run_waves(..., out_logits = NULL, ...) does. */
+int ps_pixelcnn_ar_prefix(ps_pixelcnn *h, int32_t *codes, const int32_t *order, const uint8_t *sample_region,
+                          const float *mask_init, const float *mask_undilated, const float *mask_dilated, int F,
+                          int first_step, int frame_begin, int frame_end, void *stream);
+int ps_pixelcnn_ar_columns(ps_pixelcnn *h, int32_t *codes, const int32_t *order, const uint8_t *sample_region,
+                           const float *mask_init, const float *mask_undilated, const float *mask_dilated,
+                           const int32_t *forced, const float *uniforms, float temperature, int F, int first_step,
+                           const int32_t *wave_cols, const int32_t *wave_start, int n_waves, void *stream);
+/* Compute units the stream of this handle's column launches can use (a multiple of 8; 0 = all of the device): a column launch
+ * keeps one workgroup per compute unit resident, so a caller that confines the stream to part of the chip
+ * (ps_stream_create_cu_range) says so here. */
+int ps_pixelcnn_set_compute_units(ps_pixelcnn *h, int n_cus);
+/* A stream whose kernels run on compute units [first_cu, first_cu + n_cus) only, in the numbering of hipExtStreamCreateWithCUMask
+ * (contiguous ranges are spread evenly over the XCDs: measured on MI355X, tools/cumask_probe.hip).  Two such streams over
+ * disjoint ranges share no compute unit.  The handle is a hipStream_t; destroy it with ps_stream_destroy. */
+int ps_stream_create_cu_range(int first_cu, int n_cus, void **stream);
+int ps_stream_destroy(void *stream);
+
 /* bench.py aid: ps_pixelcnn_ar_run_waves (uniforms, no logits) with a HIP event pair around every column launch on
  * the caller's stream; synchronises.  launches / total_ms: the k_column launches of the run and their summed
  * duration; flops_per_column: dense flops of one column (11.163 MFLOP). */

@@ -110,19 +110,21 @@ struct ItemMap {
     int npre;              // locations per frame
     const int32_t *start;  // (F) or null: ranks below start[f] are NOT evaluated at this stage -- nothing reads them
                            // (k_prefix_starts); only with an order
+    int f0;                // first frame of the pass (a pass over frames [f0, f0 + n): item 0 is rank 0 of frame f0)
 };
 __device__ __forceinline__ void item_loc(const ItemMap &m, int item, int L, int &f, int &q)
 {
-    f = item / m.npre;
-    const int r = item - f * m.npre;
+    const int fl = item / m.npre;
+    const int r = item - fl * m.npre;
+    f = m.f0 + fl;
     q = m.order ? m.order[(size_t)f * L + r] : r;
 }
 // is the item evaluated at this stage?
 __device__ __forceinline__ bool item_wanted(const ItemMap &m, int item)
 {
     if (!m.start) return true;
-    const int f = item / m.npre;
-    return item - f * m.npre >= m.start[f];
+    const int fl = item / m.npre;
+    return item - fl * m.npre >= m.start[m.f0 + fl];
 }
 
 constexpr int N_XCD = 8;  // gfx950: 8 XCDs, workgroup ids are dealt round-robin over them
@@ -906,6 +908,7 @@ struct StartsArgs {
     int H, W, L, npre, F;
     int g_in[NGATED], g_out[NGATED], g_skip[NGATED], d_in[4], d_out[4];
     int32_t *starts;        // (N_EVAL, F)
+    int f0;                 // frames [f0, f0 + gridDim.x) of the F
 };
 constexpr int STARTS_MAXL = 4096;
 __global__ __launch_bounds__(1024) void k_prefix_starts(StartsArgs a)
@@ -914,7 +917,7 @@ __global__ __launch_bounds__(1024) void k_prefix_starts(StartsArgs a)
     __shared__ int s1[STARTS_MAXL];     // by rank < npre: min rank among the open dilation-1 taps of ranks >= r (suffix minimum)
     __shared__ int s2[STARTS_MAXL];     //                 the same, dilation-2 taps of the dilated mask
     __shared__ int cmin[2];             // min rank the COLUMNS (ranks >= npre) read through dilation-1 / dilation-2 taps
-    const int f = blockIdx.x, t = threadIdx.x, L = a.L, npre = a.npre;
+    const int f = a.f0 + blockIdx.x, t = threadIdx.x, L = a.L, npre = a.npre;
     const int32_t *ord = a.order + (size_t)f * L;
     for (int r = t; r < L; r += 1024) rank[ord[r]] = r;
     if (t < 2) cmin[t] = npre;
@@ -3061,6 +3064,7 @@ struct ps_pixelcnn {
     ColTaps *taps = nullptr;        // neighbour rows of the columns of a run, [maxF * L]
     unsigned long long *tp_trace = nullptr;   // tuning builds: stamps of the last k_column_tp launch (ps_pixelcnn_debug_cache what 4)
     int n_cus = 256;                // compute units of the device: workgroups of a column launch that are resident together
+    bool xcd_even = true;           // n_cus is an even share of the 8 XCDs of a whole MI355X (block b runs on XCD b % 8)
     int tp_min_cols = COL_CAP + 1;  // PS_TP_MIN_COLS: tuning
     int tp_xcds = -1;               // PS_TP_XCDS: 0 = chain tiles anywhere, -1 = on as few XCDs as hold them, n = on at least n XCDs
     int tp_fill = 1;                // PS_TP_FILL: neighbour workgroups on the spare CUs of the chain XCDs
@@ -3139,7 +3143,7 @@ bool launch_gemm(GemmArgs &a, int item_blocks, hipStream_t st, const PostArgs *p
     // the workgroup form (k_gemm_wg: input rows shared through LDS) from PS_GEMM_WG_MIN item tiles on, for the shapes of the
     // network's 3x3 convs; it produces the summed form (y in place of slot NA), bit-identical to k_gemm's
     const char *wm = getenv("PS_GEMM_WG_MIN");
-    const int wg_min = wm ? atoi(wm) : 2048;
+    const int wg_min = wm ? atoi(wm) : 1024;
     const bool shape_ok = (a.Cin == 2 * NF || a.Cin == NF) && (a.Co_pad == NF || (a.Co_pad == 2 * NF && a.Cin == 2 * NF));
     if (a.sum_bias && a.zgrid == 1 && shape_ok && item_blocks >= wg_min && a.tiles_per_block == 1) {
         const int kind = a.Co_pad == 2 * NF ? GW_CONVOUT : a.Cin == 2 * NF ? GW_CONVIN : GW_DIL;
@@ -3171,11 +3175,14 @@ bool launch_gemm(GemmArgs &a, int item_blocks, hipStream_t st, const PostArgs *p
 // whole-grid evaluation (reference-faithful forward; cache build before the column steps)
 // logits: null (caches only), (F,512,H,W) when nchw, else (F*L,512) by location
 // ------------------------------------------------------------------------------------------
+// (with an order: the pass can be restricted to frames [f0, f0 + nf) of the F -- independent passes over disjoint frame ranges
+// may run on different streams)
 void run_grid(ps_pixelcnn *h, int F, const int32_t *codes, const Masks &m, float *logits, bool nchw, hipStream_t st,
-              const int32_t *order = nullptr, int npre = -1)
+              const int32_t *order = nullptr, int npre = -1, int f0 = 0, int nf = -1)
 {
-    const ItemMap all_items{order, order ? npre : h->L, nullptr};
-    const int nitems = F * all_items.npre;
+    if (nf < 0) nf = F;
+    const ItemMap all_items{order, order ? npre : h->L, nullptr, f0};
+    const int nitems = nf * all_items.npre;
     if (nitems <= 0) return;  // an AR run that starts at rank 0 has no prefix
     const int pblocks = (nitems + 3) / 4;
     // the prefix of an AR run: only the items somebody reads, stage by stage (k_prefix_starts).  PS_PREFIX_FULL=1: all of them.
@@ -3183,18 +3190,20 @@ void run_grid(ps_pixelcnn *h, int F, const int32_t *codes, const Masks &m, float
     // keeps the elimination on for the parity test, which compares the logits of the WALKED locations only.)
     const bool cone = order && (!logits || getenv("PS_PREFIX_CONE_FORCE")) && h->L <= STARTS_MAXL && !getenv("PS_PREFIX_FULL");
     if (cone) {
-        StartsArgs sa{order, m.und, m.dil, h->H, h->W, h->L, npre, F, {}, {}, {}, {}, {}, h->pstart};
+        StartsArgs sa{order, m.und, m.dil, h->H, h->W, h->L, npre, F, {}, {}, {}, {}, {}, h->pstart, f0};
         for (int g = 0; g < NGATED; ++g) { sa.g_in[g] = h->gated[g].node_in; sa.g_out[g] = h->gated[g].node_out; sa.g_skip[g] = h->gated[g].node_skip; }
         for (int d = 0; d < 4; ++d) { sa.d_in[d] = h->dil[d].node_in; sa.d_out[d] = h->dil[d].node_out; }
-        hipLaunchKernelGGL(k_prefix_starts, dim3(F), dim3(1024), 0, st, sa);
+        hipLaunchKernelGGL(k_prefix_starts, dim3(nf), dim3(1024), 0, st, sa);
     }
+    float *const part = h->partial + (size_t)4 * f0 * h->L * (2 * NF);
     ItemMap items = all_items;
     auto at_stage = [&](int stage_id) { items.start = cone ? h->pstart + (size_t)stage_id * F : nullptr; };
     // -> 0: raw slots in `partial`, 1: slots summed by the kernel, 2: the post op `post` done by the kernel as well
     auto gemm = [&](GemmArgs &a, const float *mask, const float *sum_bias = nullptr, const PostArgs *post = nullptr) {
         a.items = items;
         a.H = h->H; a.W = h->W; a.L = h->L; a.nitems = nitems;
-        a.mask = mask; a.mask_fstride = (size_t)9 * h->L; a.partial = h->partial; a.tiles_per_block = 1;
+        a.mask = mask; a.mask_fstride = (size_t)9 * h->L; a.tiles_per_block = 1;
+        a.partial = h->partial + (size_t)4 * f0 * h->L * (2 * NF);   // (the frame range's own part of the scratch: passes over disjoint ranges may run side by side)
         a.sum_bias = sum_bias;
         const int tiles = (nitems + 15) / 16;
         if (launch_gemm(a, tiles, st, post)) return 2;
@@ -3235,7 +3244,7 @@ void run_grid(ps_pixelcnn *h, int F, const int32_t *codes, const Masks &m, float
             a.slot_first[4] = 10;
             a.nslots = 4;
         }
-        PostArgs p{items, h->partial, nitems, NF, h->L, G.node_skip >= 0, 0, G.b_in, G.b_skip, nullptr, nullptr, nullptr, h->X[g]};
+        PostArgs p{items, part, nitems, NF, h->L, G.node_skip >= 0, 0, G.b_in, G.b_skip, nullptr, nullptr, nullptr, h->X[g]};
         if (!stage(a, m.und, p, POST_CONVIN)) {
             p.summed = gemm(a, m.und, G.b_in, &p);
             if (p.summed < 2) hipLaunchKernelGGL(k_post_grid<POST_CONVIN>, dim3(pblocks), dim3(256), 0, st, p);
@@ -3243,7 +3252,7 @@ void run_grid(ps_pixelcnn *h, int F, const int32_t *codes, const Masks &m, float
         GemmArgs b{};
         at_stage(15 + g);
         conv_taps(b, h->X[g], 2 * NF, G.w_out, 2 * NF, 2 * NF, 1);                     // conv_out   (layers.py:159)
-        PostArgs q{items, h->partial, nitems, 2 * NF, h->L, 0, 0, G.b_out, nullptr, h->R[G.node_in], h->R[G.node_out],
+        PostArgs q{items, part, nitems, 2 * NF, h->L, 0, 0, G.b_out, nullptr, h->R[G.node_in], h->R[G.node_out],
                    h->E[G.node_out], nullptr};
         if (!stage(b, m.und, q, POST_GATE)) {                                           // gate + residual (:160-163)
             q.summed = gemm(b, m.und, G.b_out, &q);
@@ -3255,7 +3264,7 @@ void run_grid(ps_pixelcnn *h, int F, const int32_t *codes, const Masks &m, float
         GemmArgs a{};
         at_stage(29 + d);
         conv_taps(a, h->R[D.node_in], R_LD, D.w, NF, NF, 2);                            // model.py:138,148
-        PostArgs p{items, h->partial, nitems, NF, h->L, 0, 0, D.b, nullptr, nullptr, h->R[D.node_out], h->E[D.node_out], nullptr};
+        PostArgs p{items, part, nitems, NF, h->L, 0, 0, D.b, nullptr, nullptr, h->R[D.node_out], h->E[D.node_out], nullptr};
         if (!stage(a, m.dil, p, POST_DIL)) {
             p.summed = gemm(a, m.dil, D.b, &p);
             if (p.summed < 2) hipLaunchKernelGGL(k_post_grid<POST_DIL>, dim3(pblocks), dim3(256), 0, st, p);
@@ -3270,7 +3279,7 @@ void run_grid(ps_pixelcnn *h, int F, const int32_t *codes, const Masks &m, float
     a.slot_first[0] = 0; a.slot_first[1] = 1;
     a.tap[0] = GemmTap{h->E[NNODE - 1], h->out_w, 0, 0, -1, 2 * NF};
     gemm(a, nullptr);
-    hipLaunchKernelGGL(k_logits_grid, dim3(nitems), dim3(256), 0, st, items, h->partial, h->out_b, nitems, h->L, nchw ? 1 : 0,
+    hipLaunchKernelGGL(k_logits_grid, dim3(nitems), dim3(256), 0, st, items, part, h->out_b, nitems, h->L, nchw ? 1 : 0,
                        logits);
 }
 
@@ -3451,14 +3460,15 @@ void run_columns(ps_pixelcnn *h, const StepCtx *rec, int ncols, const int32_t *c
             for (int t = 0; t < tiles; ++t) h->tile_uses_tp[t] += 1;
             for (int t = 0; t < TP_MAX_TILES; ++t) ta.tile_uses[t] = h->tile_uses_tp[t];
             int grid;
-            // The XCD-affine layout assumes a whole MI355X (SPX mode: 8 XCDs x 32 CUs, block b on XCD b % 8).  On a partition
+            // The XCD-affine layout assumes a whole MI355X (SPX mode: 8 XCDs x 32 CUs, block b on XCD b % 8) or an even share of its
+            // XCDs (a stream confined to compute units [0, 8 k): k per XCD, ps_stream_create_cu_range).  On a partition
             // (CPX: 32 CUs = one XCD per device) or any other CU count that mapping means nothing: the plain layout is used --
             // neighbour blocks first in the grid, so they are dispatched ahead of the chain tiles that wait for them.  Either way
             // the grid holds at most one workgroup per CU and the waits are bounded (40000 polls with s_sleep, tens of ms):
             // kernels of OTHER streams that hold CUs for a while (bench.py / driver.py overlap the next batch's ~2 ms of splat
             // kernels with this run) delay a launch, they cannot starve it past the bound.
             const int rows = h->n_cus / 8;   // CUs per XCD
-            if (h->tp_xcds != 0 && h->n_cus == 8 * 32 && tiles <= 4 * rows) {
+            if (h->tp_xcds != 0 && h->xcd_even && tiles <= 4 * rows) {
                 const int cx = h->tp_xcds > 0 ? std::max(h->tp_xcds, (tiles + rows - 1) / rows) : (tiles + rows - 1) / rows;
                 ta.chain_xcds = std::min(cx, 7);
                 const int spare = ta.chain_xcds * rows - tiles;
@@ -3542,6 +3552,7 @@ int ps_pixelcnn_create(const float *const *params, int n_params, int H, int W, i
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
             h->n_cus = cus;
+        h->xcd_even = h->n_cus == 8 * 32;
         if (h->n_cus % 8 != 0 || h->n_cus < 16) {
             ps::fail(PS_ERR_STATE, "pixelcnn_create: %d compute units -- the column launches lay their workgroups out over 8 XCDs", h->n_cus);
             delete h;
@@ -3678,14 +3689,18 @@ int ps_pixelcnn_ar_step(ps_pixelcnn *h, const int32_t *codes, const int32_t *ord
 
 // The AR run: whole-grid pass over the observed prefix, then the remaining columns -- wavefront by wavefront when the
 // caller brings a schedule (ps_ar_wavefronts), else position by position (one column per frame and launch).
+enum { AR_PREFIX = 1, AR_COLUMNS = 2 };
 static int ar_run_impl(ps_pixelcnn *h, int32_t *codes, const int32_t *order, const uint8_t *sample_region,
                        const float *mask_init, const float *mask_undilated, const float *mask_dilated,
                        const int32_t *forced, const float *uniforms, float temperature, int F, int first_step,
-                       const int32_t *wave_cols, const int32_t *wave_start, int n_waves, float *out_logits, void *stream)
+                       const int32_t *wave_cols, const int32_t *wave_start, int n_waves, float *out_logits, void *stream,
+                       int phases = AR_PREFIX | AR_COLUMNS, int f0 = 0, int nf = -1)
 {
     if (int rc = check_handle(h, F)) return rc;
+    if (nf < 0) nf = F;
     PS_REQUIRE(codes && order && sample_region && mask_init && mask_undilated && mask_dilated, "pixelcnn_ar_run: null pointer");
-    PS_REQUIRE((forced != nullptr) != (uniforms != nullptr), "pixelcnn_ar_run: give exactly one of forced / uniforms");
+    PS_REQUIRE(f0 >= 0 && nf >= 0 && f0 + nf <= F, "pixelcnn_ar_prefix: frames [%d, %d) outside the run's %d", f0, f0 + nf, F);
+    PS_REQUIRE(!(phases & AR_COLUMNS) || (forced != nullptr) != (uniforms != nullptr), "pixelcnn_ar_run: give exactly one of forced / uniforms");
     PS_REQUIRE(first_step >= 0 && first_step <= h->L, "pixelcnn_ar_run: first_step out of range");
     PS_REQUIRE(temperature > 0.0f, "pixelcnn_ar_run: temperature must be > 0");
     const int nsteps = h->L - first_step;
@@ -3698,11 +3713,15 @@ static int ar_run_impl(ps_pixelcnn *h, int32_t *codes, const int32_t *order, con
     }
     hipStream_t st = (hipStream_t)stream;
     const Masks m{mask_init, mask_undilated, mask_dilated};
-    const size_t n = (size_t)F * h->L;
-    hipLaunchKernelGGL(k_mask_codes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, codes, sample_region, n);
-    // whole-grid pass: exact for every location that precedes the first sampled one; with out_logits it also
-    // yields their logits, by location (the walked positions are overwritten by the column steps)
-    run_grid(h, F, codes, m, out_logits, false, st, order, first_step);
+    if (phases & AR_PREFIX) {   // frames [f0, f0 + nf): sampled codes masked out, whole-grid pass over the observed prefix
+        const size_t n = (size_t)nf * h->L, off = (size_t)f0 * h->L;
+        if (n > 0) hipLaunchKernelGGL(k_mask_codes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, codes + off, sample_region + off, n);
+        // whole-grid pass: exact for every location that precedes the first sampled one; with out_logits it also
+        // yields their logits, by location (the walked positions are overwritten by the column steps)
+        run_grid(h, F, codes, m, out_logits, false, st, order, first_step, f0, nf);
+        PS_LAUNCH_CHECK();
+    }
+    if (!(phases & AR_COLUMNS)) return PS_OK;
     ChainArgs ca{};
     ca.codes = codes; ca.region = sample_region; ca.forced = forced; ca.uniforms = uniforms;
     ca.out_logits = out_logits; ca.temperature = temperature;
@@ -3742,6 +3761,60 @@ int ps_pixelcnn_ar_run_waves(ps_pixelcnn *h, int32_t *codes, const int32_t *orde
     PS_REQUIRE(wave_cols && wave_start, "pixelcnn_ar_run_waves: null schedule");
     return ar_run_impl(h, codes, order, sample_region, mask_init, mask_undilated, mask_dilated, forced, uniforms, temperature, F,
                        first_step, wave_cols, wave_start, n_waves, out_logits, stream);
+}
+
+int ps_pixelcnn_ar_prefix(ps_pixelcnn *h, int32_t *codes, const int32_t *order, const uint8_t *sample_region, const float *mask_init,
+                          const float *mask_undilated, const float *mask_dilated, int F, int first_step, int frame_begin, int frame_end,
+                          void *stream)
+{
+    return ar_run_impl(h, codes, order, sample_region, mask_init, mask_undilated, mask_dilated, nullptr, nullptr, 1.0f, F, first_step, nullptr,
+                       nullptr, 0, nullptr, stream, AR_PREFIX, frame_begin, frame_end - frame_begin);
+}
+
+int ps_pixelcnn_ar_columns(ps_pixelcnn *h, int32_t *codes, const int32_t *order, const uint8_t *sample_region, const float *mask_init,
+                           const float *mask_undilated, const float *mask_dilated, const int32_t *forced, const float *uniforms,
+                           float temperature, int F, int first_step, const int32_t *wave_cols, const int32_t *wave_start, int n_waves,
+                           void *stream)
+{
+    PS_REQUIRE(wave_cols && wave_start, "pixelcnn_ar_columns: the wavefront schedule is required");
+    return ar_run_impl(h, codes, order, sample_region, mask_init, mask_undilated, mask_dilated, forced, uniforms, temperature, F, first_step,
+                       wave_cols, wave_start, n_waves, nullptr, stream, AR_COLUMNS);
+}
+
+int ps_pixelcnn_set_compute_units(ps_pixelcnn *h, int n_cus)
+{
+    PS_REQUIRE(h, "pixelcnn: null handle");
+    int dev = 0, cus = 0;
+    PS_HIP_CHECK(hipGetDevice(&dev));
+    PS_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    if (n_cus <= 0) n_cus = cus;
+    PS_REQUIRE(n_cus % 8 == 0 && n_cus >= 16 && n_cus <= cus, "pixelcnn_set_compute_units: %d compute units (a multiple of 8 in [16, %d])", n_cus, cus);
+    h->n_cus = n_cus;
+    h->xcd_even = cus == 8 * 32 && n_cus % 8 == 0;
+    h->col_cap = std::min(COL_CAP, (h->n_cus / 8) * 4);
+    return PS_OK;
+}
+
+int ps_stream_create_cu_range(int first_cu, int n_cus, void **stream)
+{
+    PS_REQUIRE(stream, "stream_create_cu_range: null pointer");
+    int dev = 0, cus = 0;
+    PS_HIP_CHECK(hipGetDevice(&dev));
+    PS_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    PS_REQUIRE(first_cu >= 0 && n_cus > 0 && first_cu + n_cus <= cus && cus <= 1024, "stream_create_cu_range: compute units [%d, %d) of %d",
+               first_cu, first_cu + n_cus, cus);
+    uint32_t mask[32] = {};
+    for (int c = first_cu; c < first_cu + n_cus; ++c) mask[c >> 5] |= 1u << (c & 31);
+    hipStream_t st = nullptr;
+    PS_HIP_CHECK(hipExtStreamCreateWithCUMask(&st, (uint32_t)((cus + 31) / 32), mask));
+    *stream = (void *)st;
+    return PS_OK;
+}
+
+int ps_stream_destroy(void *stream)
+{
+    if (stream) PS_HIP_CHECK(hipStreamDestroy((hipStream_t)stream));
+    return PS_OK;
 }
 
 int ps_pixelcnn_time_ar_run_waves(ps_pixelcnn *h, int32_t *codes, const int32_t *order, const uint8_t *sample_region,
@@ -3893,7 +3966,7 @@ int ps_lmconv_forward_f32(const float *x, const float *mask, size_t mask_batch_s
     hipLaunchKernelGGL(k_pack_conv, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, st, weight, Co, Ci, Cop, Cp, wp);
     GemmArgs a{};
     conv_taps(a, xcl, Cp, wp, Cp, Cop, dilation);
-    a.items = ItemMap{nullptr, L, nullptr};
+    a.items = ItemMap{nullptr, L, nullptr, 0};
     a.H = H; a.W = W; a.L = L; a.nitems = B * L; a.mask = mask; a.mask_fstride = mask_batch_stride;
     a.partial = partial; a.tiles_per_block = 2;
     const int tiles = (a.nitems + 15) / 16;

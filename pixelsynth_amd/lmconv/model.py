@@ -135,6 +135,42 @@ class PixelCNNEngine:
             _lib.check(rc, "ps_pixelcnn_ar_run_waves")
         return out
 
+    def _ar_args(self, codes, order, region, mask_init, mask_undilated, mask_dilated):
+        F_ = codes.shape[0]
+        _lib.require_cuda(codes, order, region, mask_init, mask_undilated, mask_dilated)
+        masks = self._frame_masks(F_, mask_init, mask_undilated, mask_dilated)
+        for name, t, dt in (("codes", codes, torch.int32), ("order", order, torch.int32), ("region", region, torch.uint8)):
+            self._frame_arg(F_, name, t, dt)
+        return F_, masks
+
+    def ar_prefix(self, codes, order, region, mask_init, mask_undilated, mask_dilated, first_step, frame_begin=0, frame_end=None):
+        """First half of ar_run for frames [frame_begin, frame_end): sampled codes masked out, whole-grid pass over their observed
+        prefix.  Asynchronous on the current stream; disjoint frame ranges may go to different streams (ps_pixelcnn_ar_prefix)."""
+        F_, (mi, mu, md) = self._ar_args(codes, order, region, mask_init, mask_undilated, mask_dilated)
+        rc = _lib.lib().ps_pixelcnn_ar_prefix(self.handle, _lib.ptr(codes), _lib.ptr(order), _lib.ptr(region), _lib.ptr(mi), _lib.ptr(mu),
+                                              _lib.ptr(md), F_, int(first_step), int(frame_begin), int(F_ if frame_end is None else frame_end),
+                                              _lib.current_stream())
+        _lib.check(rc, "ps_pixelcnn_ar_prefix")
+
+    def ar_columns(self, codes, order, region, mask_init, mask_undilated, mask_dilated, waves, temperature=1.0, forced=None, uniforms=None,
+                   first_step=0):
+        """Second half of ar_run: the column launches of all frames, wavefront by wavefront (ps_pixelcnn_ar_columns); every frame's
+        ar_prefix must have completed (stream order / events are the caller's)."""
+        F_, (mi, mu, md) = self._ar_args(codes, order, region, mask_init, mask_undilated, mask_dilated)
+        _lib.require_cuda(forced, uniforms)
+        self._frame_arg(F_, "forced", forced, torch.int32)
+        self._frame_arg(F_, "uniforms", uniforms, torch.float32)
+        cols, wave_start = waves
+        _lib.require_cuda(cols)
+        rc = _lib.lib().ps_pixelcnn_ar_columns(self.handle, _lib.ptr(codes), _lib.ptr(order), _lib.ptr(region), _lib.ptr(mi), _lib.ptr(mu),
+                                               _lib.ptr(md), _lib.ptr(forced), _lib.ptr(uniforms), float(temperature), F_, int(first_step),
+                                               _lib.ptr(cols), _lib.ptr(wave_start), len(wave_start) - 1, _lib.current_stream())
+        _lib.check(rc, "ps_pixelcnn_ar_columns")
+
+    def set_compute_units(self, n_cus):
+        """Compute units the stream of this engine's column launches can use (0 = the whole device)."""
+        _lib.check(_lib.lib().ps_pixelcnn_set_compute_units(self.handle, int(n_cus)), "ps_pixelcnn_set_compute_units")
+
     def ar_step(self, codes, order, mask_init, mask_undilated, mask_dilated, step, first_step):
         F_ = codes.shape[0]
         mask_init, mask_undilated, mask_dilated = self._frame_masks(F_, mask_init, mask_undilated, mask_dilated)
@@ -231,18 +267,28 @@ class OurPixelCNN(nn.Module):
         self._engine_sig = None
 
     # ---- HIP engine -------------------------------------------------------------------------
-    def engine(self, H=32, W=32, max_frames=1):
-        """The ps_pixelcnn handle for the current parameters (rebuilt when they change)."""
+    def engine(self, H=32, W=32, max_frames=1, slot=0):
+        """The ps_pixelcnn handle for the current parameters (rebuilt when they change).  slot: callers that overlap the runs of
+        two batches keep two handles -- each owns its activation caches."""
         if not self._engine_ok:
             raise RuntimeError("the fused HIP PixelCNN engine implements PixelSynth's OurPixelCNN configuration only")
         sd = self.state_dict()
         sig = (H, W, tuple((sd[k].data_ptr(), sd[k]._version) for k in PARAM_KEYS))
-        if self._engine is None or self._engine_sig != sig or self._engine.max_frames < max_frames:
-            if self._engine is not None:
-                self._engine.close()
-            self._engine = PixelCNNEngine(sd, H, W, max(max_frames, getattr(self._engine, "max_frames", 1)))
-            self._engine_sig = sig
-        return self._engine
+        if slot == 0:
+            if self._engine is None or self._engine_sig != sig or self._engine.max_frames < max_frames:
+                if self._engine is not None:
+                    self._engine.close()
+                self._engine = PixelCNNEngine(sd, H, W, max(max_frames, getattr(self._engine, "max_frames", 1)))
+                self._engine_sig = sig
+            return self._engine
+        extra = self.__dict__.setdefault("_engine_slots", {})
+        eng, esig = extra.get(slot, (None, None))
+        if eng is None or esig != sig or eng.max_frames < max_frames:
+            if eng is not None:
+                eng.close()
+            eng = PixelCNNEngine(sd, H, W, max(max_frames, getattr(eng, "max_frames", 1)))
+            extra[slot] = (eng, sig)
+        return eng
 
     @staticmethod
     def onehot_to_codes(x):

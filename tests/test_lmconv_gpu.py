@@ -647,3 +647,50 @@ def test_prefix_cone_on_other_grids_and_random_orders(H, W, monkeypatch):
         walked[b, order_loc[b][first:]] = True
     sel = torch.from_numpy(walked).to(DEV)
     assert torch.equal(l_cone[sel], l_full[sel])
+
+
+def test_ar_prefix_and_columns_as_separate_calls_equal_the_run():
+    """ps_pixelcnn_ar_prefix over two disjoint frame ranges -- on two streams, each confined to its own compute units
+    (ps_stream_create_cu_range) -- followed by ps_pixelcnn_ar_columns on a handle told how many compute units its stream has,
+    gives the codes of ps_pixelcnn_ar_run_waves bit for bit."""
+    from pixelsynth_amd.lmconv.model import wavefronts
+    from pixelsynth_amd.pipeline import CuRangeStream
+    net = make_net(3)
+    F_, first = 70, 800
+    bgs = syn.background_masks(256)
+    names = ["right_half", "half_plus_island", "ragged", "top_band"]
+    infos = [c_oracle.masks_for_background(bgs[names[b % 4]], 32) for b in range(F_)]
+    order_loc = np.stack([(i["order"][:, 0] * 32 + i["order"][:, 1]) for i in infos]).astype(np.int32)
+    reg = np.zeros((F_, 1024), np.uint8)
+    rs = np.random.RandomState(2)
+    for b in range(F_):
+        walked = order_loc[b][first:]
+        reg[b, walked[rs.rand(walked.size) < 0.8]] = 1
+        reg[b, order_loc[b][first]] = 1
+    ms = [tt(np.concatenate([i[k] for i in infos])) for k in ("mask_init", "mask_undilated", "mask_dilated")]
+    codes0 = syn.codes(17, F_).reshape(F_, 1024).astype(np.int32)
+    u = tt(np.random.RandomState(9).rand(F_, 1024).astype(np.float32))
+    o, r = tt(order_loc), tt(reg)
+    waves = wavefronts(order_loc, 32, 32, first, DEV)
+    eng = net.engine(32, 32, F_)
+    c_ref = tt(codes0.copy())
+    eng.ar_run(c_ref, o, r, *ms, temperature=0.7, uniforms=u, first_step=first, waves=waves)
+    eng.check()
+    A, B = CuRangeStream(0, 160), CuRangeStream(160, 96)
+    eng2 = net.engine(32, 32, F_, slot=1)
+    eng2.set_compute_units(160)
+    c = tt(codes0.copy())
+    torch.cuda.synchronize()
+    with torch.cuda.stream(B.stream):
+        eng2.ar_prefix(c, o, r, *ms, first, 0, 41)
+        done = torch.cuda.Event()
+        done.record(B.stream)
+    with torch.cuda.stream(A.stream):
+        eng2.ar_prefix(c, o, r, *ms, first, 41, F_)
+        A.stream.wait_event(done)
+        eng2.ar_columns(c, o, r, *ms, waves, temperature=0.7, uniforms=u, first_step=first)
+    A.stream.synchronize()
+    eng2.check()
+    eng2.set_compute_units(0)
+    assert torch.equal(c, c_ref)
+    assert (c.cpu().numpy()[reg == 1] != codes0[reg == 1]).any()
