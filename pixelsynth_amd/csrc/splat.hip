@@ -401,7 +401,13 @@ __global__ __launch_bounds__(64) void k_composite(
     float *__restrict__ out_dist)
 {
     // records of a batch, structure of arrays: in the walk every lane fetches a DIFFERENT record, and 32-byte structs put
-    // records j and j + 4 on the same banks (up to 16 lanes per bank); 4-byte columns put j and j + 32 there (2 lanes)
+    // records j and j + 4 on the same banks (up to 16 lanes per bank); 4-byte columns put j and j + 32 there (2 lanes).
+    // Round 3, measured and not kept (all 19 parity checks green; 32 frames, this kernel 405 us as it is): the record as two
+    // 16-byte halves / as 8-byte pairs with TWO hits fetched and their alphas computed per trip of the walk (independent work
+    // over the LDS round trip) -- both need more than the 64 registers of eight waves per SIMD (spilled there: 3.0-3.2 ms); with
+    // 96 / 103 registers at five / four waves per SIMD 417 / 435 us; the hit mask as two 32-bit words: 405 us.  The walk is not
+    // short of independent instructions; what it pays for is the LDS itself (about 900 LDS instructions per tile, half of them
+    // the broadcast reads of the test phase) at eight waves per SIMD.
     __shared__ float sx[64], sy[64], sz[64], sf[CG][64];
     __shared__ uint32_t sn[64];
     const int tile = blockIdx.x, b = blockIdx.y, c0 = blockIdx.z * CG;
