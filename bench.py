@@ -101,9 +101,9 @@ def front(model, d):
     return model.plan_views(d["img"], d["depth"], d["K"], d["Kinv"], d["P"], d["Pinv"], d["RT2"], d["RT2inv"])
 
 
-def back(model, d, planned, world):
+def back(model, d, planned, world, columns_on=None):
     """Second half: the AR run (asynchronous), then the path's only collective."""
-    out = model.outpaint_planned(planned, d["codes"], temperature=0.7, uniforms=d["uniforms"])
+    out = model.outpaint_planned(planned, d["codes"], temperature=0.7, uniforms=d["uniforms"], columns_on=columns_on)
     if world > 1:  # what the path produced on every rank -- the reprojected views as 8-bit images (the byte volume of finished
         # frames: the VQ-VAE decode that turns codes into pixels is a next-row component, timed under end_to_end_*) and the
         # completed 32x32 code grids -- RCCL all_gather over xGMI
@@ -119,15 +119,27 @@ def run_step(model, d, world):
 def run_steps(model, d, world, n, side):
     """n steps, software-pipelined: while the device runs the AR loop of step i (main stream), the host half of step
     i + 1 -- splat on the side stream, masks back, planning, uploads -- is already under way.  Same work per step, the
-    steps are independent; results identical to n x run_step."""
+    steps are independent; results identical to n x run_step.
+    """
     main = torch.cuda.current_stream()
     planned, out = None, None
     for i in range(n):
         if planned is None:
             planned = front(model, d)
+        # The side stream's kernels of step i + 1 (the splat: a swarm of 64-thread workgroups) are held back until step i's
+        # whole-grid prefix pass starts, i.e. until step i - 1's column launches are through: a column launch keeps one large
+        # workgroup per compute unit resident, and the splat's workgroups, let loose beside the column launches, fill the
+        # compute units between two launches and hold the next launch up until they retire (under rocprofv3: 194 instead of
+        # 154 us per launch while the splat runs).  The step takes the same 22 ms either way -- the splat's 2.5 ms are paid
+        # beside the prefix pass or beside the columns -- but no in-launch wait of a column launch is at the mercy of another
+        # stream any more.
+        gate = torch.cuda.Event()
+        gate.record(main)
         out = back(model, d, planned, world)
         planned = None
         if i + 1 < n:
+            if not os.environ.get("PS_BENCH_NO_GATE"):
+                side.wait_event(gate)
             with torch.cuda.stream(side):
                 planned = front(model, d)
             model.adopt_planned(planned, main)
@@ -540,7 +552,7 @@ def main():
     ap.add_argument("--depth", choices=["smooth", "uniform"], default="smooth")
     ap.add_argument("--overlap", action="store_true", help="experiment (measured slower, DESIGN.md section 5): steps pipelined over two compute-unit "
                     "partitions (pixelsynth_amd/pipeline.py) instead of one stream + a side stream")
-    ap.add_argument("--cus-main", type=int, default=int(os.environ.get("PS_CUS_MAIN", "160")), help="compute units of the column launches' partition")
+    ap.add_argument("--cus-main", type=int, default=int(os.environ.get("PS_CUS_MAIN", "160")), help="--overlap: compute units of the column launches' partition")
     ap.add_argument("--prefix-share", type=float, default=float(os.environ.get("PS_PREFIX_SHARE", "0.6")),
                     help="fraction of a step's frames whose prefix pass runs beside the previous step's column launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -9,6 +9,10 @@ follows batch i's columns on A.  Both streams are confined with a compute-unit m
 column launch keeps one workgroup per compute unit resident and must not find its compute units taken by another
 stream's workgroups (which is also why round 2's unmasked side stream made an in-launch wait expire now and then).
 
+MEASURED (round 3, C5's 128 views per batch): 24.4 ms per batch against 22.3 ms for the one-stream pipeline of bench.py -- the
+column launches run at 200-217 us on 160 compute units where their share of the chip predicts 167, and stream B is saturated by
+the splat and 60 % of a prefix pass.  Kept as an opt-in experiment (bench.py --overlap), not the default.
+
 The batches are independent (the same work as `outpaint_views` batch by batch, bit-identical results: the prefix pass of
 disjoint frame ranges is independent, and each batch has its own engine handle, i.e. its own activation caches).
 There is no reference counterpart: the reference renders one view at a time (demo.py:247-251).
@@ -20,10 +24,18 @@ import torch
 from . import _lib
 
 
+# Partitions of the 256 compute units this module has been run on.  Others are refused: with 176, 208 or 216 compute units the
+# column launches never got all their workgroups resident (bench runs had to be killed), with 224 they ran at a third of their
+# speed -- how the dispatcher deals workgroups over a masked queue's compute units is not something to guess at.
+VALIDATED_SPLITS = (128, 160, 192)
+
+
 class CuRangeStream:
     """A torch stream whose kernels run on compute units [first, first + n) only."""
 
     def __init__(self, first, n, device=None):
+        if (int(first), int(n)) not in [(0, k) for k in VALIDATED_SPLITS] + [(k, 256 - k) for k in VALIDATED_SPLITS]:
+            raise ValueError(f"compute units [{first}, {first + n}): only the splits of 256 at {VALIDATED_SPLITS} have been validated")
         self.first, self.n = int(first), int(n)
         self._raw = ctypes.c_void_p()
         with torch.cuda.device(device if device is not None else torch.cuda.current_device()):

@@ -280,9 +280,12 @@ class ZbufferModelPts(nn.Module):
                 t.record_stream(stream)
 
     @torch.no_grad()
-    def outpaint_planned(self, planned, codes, temperature=0.7, uniforms=None, forced=None):
+    def outpaint_planned(self, planned, codes, temperature=0.7, uniforms=None, forced=None, columns_on=None):
         """Second half: AR outpainting of the 32x32 code grids (a13) of the views prepared by plan_views; asynchronous
-        on the current stream.  Adds `codes` (V,32,32) int32 to the dict and returns it."""
+        on the current stream.  Adds `codes` (V,32,32) int32 to the dict and returns it.
+        columns_on: a pixelsynth_amd.pipeline.CuRangeStream -- the column launches go to that stream (confined to its compute
+        units, where no other stream's workgroups can take the compute units a launch needs), the whole-grid prefix pass stays
+        on the current stream, which then waits for the columns.  (Experimental, see pixelsynth_amd/pipeline.py.)"""
         gen_fs, plan = planned["gen_fs"], planned["plan"]
         V = gen_fs.shape[0]
         L = self.obs[1] * self.obs[2]
@@ -292,8 +295,21 @@ class ZbufferModelPts(nn.Module):
         eng = self.outpaint2.engine(self.obs[1], self.obs[2], V)
         if forced is None and uniforms is None:
             uniforms = torch.rand(V, L, device=gen_fs.device, dtype=torch.float32)
-        eng.ar_run(c32, plan.order_loc, plan.region, plan.mask_init, plan.mask_undilated, plan.mask_dilated,
-                   temperature=temperature, uniforms=uniforms, forced=forced, first_step=plan.first_step, waves=plan.waves)
+        if columns_on is None or plan.waves[0].shape[0] == 0:
+            eng.ar_run(c32, plan.order_loc, plan.region, plan.mask_init, plan.mask_undilated, plan.mask_dilated,
+                       temperature=temperature, uniforms=uniforms, forced=forced, first_step=plan.first_step, waves=plan.waves)
+        else:
+            cur, col = torch.cuda.current_stream(), columns_on.stream
+            eng.set_compute_units(columns_on.n)
+            eng.ar_prefix(c32, plan.order_loc, plan.region, plan.mask_init, plan.mask_undilated, plan.mask_dilated, plan.first_step)
+            col.wait_stream(cur)
+            for t in (c32, plan.order_loc, plan.region, plan.mask_init, plan.mask_undilated, plan.mask_dilated, plan.waves[0], uniforms, forced):
+                if t is not None and t.numel():
+                    t.record_stream(col)
+            with torch.cuda.stream(col):
+                eng.ar_columns(c32, plan.order_loc, plan.region, plan.mask_init, plan.mask_undilated, plan.mask_dilated, plan.waves,
+                               temperature=temperature, uniforms=uniforms, forced=forced, first_step=plan.first_step)
+            cur.wait_stream(col)
         planned["codes"] = c32.view(V, self.obs[1], self.obs[2])
         return planned
 
