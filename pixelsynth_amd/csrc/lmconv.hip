@@ -1237,6 +1237,10 @@ __device__ __forceinline__ void store_through(float *p, const f32x4 &v)
 {
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 3" : : "v"(PS_G(f32x4, p)), "v"(v) : "memory");
 }
+__device__ __forceinline__ void store_through2(float *p, const f32x2 &v)
+{
+    asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" : : "v"(PS_G(f32x2, p)), "v"(v) : "memory");
+}
 __device__ __forceinline__ void signal_done(unsigned *counter, int lane)
 {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through stores have left
@@ -2040,22 +2044,48 @@ struct TpArgs {
     const float *uniforms;
     float *out_logits, *step_logits;
     float temperature;
-    unsigned tile_uses[TP_MAX_TILES];
+    // counter (k, t) stands at uses x (items of stage k per tile) when tile t's slots of stage k are there: uses_lo for the stages
+    // below `split` (computed a launch AHEAD, see nbr_role_tp), uses_hi for the others (computed by this launch)
+    unsigned tile_uses_lo[TP_MAX_TILES], tile_uses_hi[TP_MAX_TILES];
+    int split;                // stages [0, split) of a launch are the previous launch's business when it could see this one coming
+    // the neighbour role's share: work entries [w_from, nwork) for this launch's columns, then [0, w_upto) for the NEXT launch's
+    int w_from, w_upto;
+    const ColTaps *taps_next;
+    int ncols_next, tiles_next;
+    float *nbr_next;          // the other half of the double-buffered slots
+    unsigned *cnt_next;       // and of the counters
+    unsigned *done;           // [NST] padded: chain tiles that have published the input of stage k (all launches so far)
+    unsigned done_target;     // what done[k] reads when every tile of THIS launch has
+    int publish_upto;         // stages whose input the chain tiles publish (0: nobody looks)
+    int nbr_map;              // item -> wave mapping of the neighbour role: 0 = the waves of a workgroup take consecutive items, 1 = consecutive items go to different workgroups
     int *err;
     int debug;
     unsigned long long *trace;   // tuning builds (-DPS_TP_TRACE_BUILD): [NST][8] shader-clock stamps of tile 0, wave 0
 };
 
-template <int T, int NG>
+// AHEAD: the item belongs to the NEXT launch's columns.  Some of the rows it gathers were written by chain tiles of THIS launch,
+// on other XCDs: they were stored write-through and their stage's `done` counter has been seen.  What remains is a stale copy
+// in this CU's L1 or this XCD's L2, which can only be there if the line was read earlier in this launch (both are invalidated
+// when a kernel starts): (1) rows of 80 floats (the dilated convs' input) share 128-byte lines with their neighbours' -- those
+// items gather with device-scope loads (sc1), which go past both caches, at the price of no reuse between the ~10 items that
+// read a row (all rows that way: the neighbour role took 163 instead of 95 us); (2) rows of 160 floats are whole lines, and the
+// only reads of a row that is not finished were the dummy reads of closed taps (row 0) -- a closed lane now reads a row some
+// other lane of the wave gathers anyway.
+#ifndef PS_TP_POLL_SLEEP
+#define PS_TP_POLL_SLEEP 8
+#endif
+template <int T, int NG, bool AHEAD>
 __device__ __forceinline__ void nbr_item_tp(const NbrWorkTp &wk, const TpArgs &a, int ctile, int lane)
 {
     const int i = lane & 15, kk = lane >> 4;
     const int col = ctile * TP_COLS + i;
-    const bool valid = col < a.ncols;
+    const bool valid = col < (AHEAD ? a.ncols_next : a.ncols);
+    const ColTaps *const taps = AHEAD ? a.taps_next : a.taps;
     const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
     typedef int i32x4 __attribute__((ext_vector_type(4)));
     i32x4 rows = {-1, -1, -1, -1};
-    if (valid) rows = *PS_GC(i32x4, &a.taps[col].row[wk.kind][wk.half * 4]);
+    if (valid) rows = *PS_GC(i32x4, &taps[col].row[wk.kind][wk.half * 4]);
+    const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc((void *)wk.in, 0, 0x7fffffff, 0x00020000);
     f32x4 tot[T];
 #pragma unroll
     for (int u = 0; u < T; ++u) tot[u] = zero;
@@ -2064,9 +2094,11 @@ __device__ __forceinline__ void nbr_item_tp(const NbrWorkTp &wk, const TpArgs &a
     for (int tq = 0; tq < 4; ++tq) {
         const int row = rows[tq];
         const bool live = row >= 0;
-        if (!__any(live)) continue;   // (a closed tap is an exact zero)
+        const unsigned long long open = __builtin_amdgcn_ballot_w64(live);
+        if (open == 0ull) continue;   // (a closed tap is an exact zero)
+        const int safe = __shfl(row, __builtin_ctzll(open), 64);   // closed lanes read (and drop) a row that is being read anyway
         const int t = wk.half * 5 + tq;
-        const float *src = wk.in + (size_t)(live ? row : 0) * wk.in_ld + 4 * kk;
+        const float *src = wk.in + (size_t)(live ? row : safe) * wk.in_ld + 4 * kk;
         const float *wbase = wk.w + (size_t)t * NG * gstride + ((size_t)kk * wk.Co_pad + wk.o0 + i) * 4;
         Acc5 acc[T];
 #pragma unroll
@@ -2074,8 +2106,15 @@ __device__ __forceinline__ void nbr_item_tp(const NbrWorkTp &wk, const TpArgs &a
 #pragma unroll
         for (int g0 = 0; g0 < NG; g0 += 5) {
             f32x4 bv[5];
+            if (AHEAD && NG == 5) {
+                const int voff = ((live ? row : safe) * wk.in_ld + 4 * kk) * 4;
 #pragma unroll
-            for (int g = 0; g < 5; ++g) bv[g] = *PS_GC(f32x4, src + 16 * (g0 + g));
+                for (int g = 0; g < 5; ++g)
+                    bv[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(irs, voff + 64 * (g0 + g), 0, 16 /* sc1 */));
+            } else {
+#pragma unroll
+                for (int g = 0; g < 5; ++g) bv[g] = *PS_GC(f32x4, src + 16 * (g0 + g));
+            }
 #pragma unroll
             for (int g = 0; g < 5; ++g) bv[g] = live ? bv[g] : zero;   // (mask values are 0 / 1: no multiply needed)
 #pragma unroll
@@ -2090,19 +2129,37 @@ __device__ __forceinline__ void nbr_item_tp(const NbrWorkTp &wk, const TpArgs &a
         for (int u = 0; u < T; ++u) tot[u] = tot[u] + chunk_total(acc[u]);
     }
     if (valid) {
-        float *dst = a.nbr + (((size_t)wk.stage * 2 + wk.half) * TP_COL_CAP + col) * NBR_LD + wk.o0 + kk * 4;
+        float *dst = (AHEAD ? a.nbr_next : a.nbr) + (((size_t)wk.stage * 2 + wk.half) * TP_COL_CAP + col) * NBR_LD + wk.o0 + kk * 4;
 #pragma unroll
         for (int u = 0; u < T; ++u) store_through(dst + 16 * u, tot[u]);
     }
 }
 
+// The neighbour role of a launch, one launch ahead where it can be.  The NA / NB slots of a column only read finished columns of
+// EARLIER launches and, of the launch in front of its own, what that launch's chain tiles have already stored -- never its own
+// launch's results.  So the slots of the stages [0, split) of launch i + 1 are computed by the neighbour role of launch i, behind
+// launch i's chain tiles (which publish, stage by stage, that the input of stage k is in memory: `done`), and launch i + 1 finds
+// them ready: its chain tiles start without waiting for a cold neighbour role (work records, first weights into the XCDs' L2s,
+// ~13-15 us at the head of every launch before).  The stages [split, NST) stay with the launch itself -- they are not needed
+// before its chain has walked `split` stages, and the tail of the launch in front would otherwise hang on its last `done`s.
+// A wave's items: this launch's own entries [w_from, nwork) x tiles first (they wait for nothing), then the next launch's
+// [0, w_upto) x tiles_next, stage-major.  Slots and completion counters are double-buffered by launch parity.
 __device__ __forceinline__ void nbr_role_tp(const TpArgs &a, int nb)
 {
     const int wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int gw = nb * TP_WAVES + wave, nw = a.nbr_wgs * TP_WAVES;
-    const int nitems = a.nwork * a.tiles;
+    const int gw = a.nbr_map ? wave * a.nbr_wgs + nb : nb * TP_WAVES + wave, nw = a.nbr_wgs * TP_WAVES;
+    const int n_own = (a.nwork - a.w_from) * a.tiles;
+    const int nitems = n_own + a.w_upto * a.tiles_next;
     for (int item = gw; item < nitems; item += nw) {
-        const int witem = item / a.tiles, ctile = item - witem * a.tiles;
+        const bool ahead = item >= n_own;
+        int witem, ctile;
+        if (!ahead) {
+            const int q = item / a.tiles;
+            witem = a.w_from + q; ctile = item - q * a.tiles;
+        } else {
+            const int j = item - n_own;
+            witem = j / a.tiles_next; ctile = j - witem * a.tiles_next;
+        }
         NbrWorkTp wk;
         {   // wave-uniform record: scalar loads
             typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -2112,12 +2169,30 @@ __device__ __forceinline__ void nbr_role_tp(const TpArgs &a, int nb)
             r[0] = p[0]; r[1] = p[1]; r[2] = p[2];
             __builtin_memcpy(&wk, r, sizeof(wk));
         }
-        if (wk.T == 2) {
-            if (wk.NG == 10) nbr_item_tp<2, 10>(wk, a, ctile, lane); else nbr_item_tp<2, 5>(wk, a, ctile, lane);
+        if (ahead) {   // the chain tiles of this launch have stored the input of the item's stage (bounded wait; normally long past)
+            const unsigned *dp = a.done + (size_t)wk.stage * CNT_PAD;
+            unsigned have = __hip_atomic_load(dp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int spins = 0;
+            while ((int)(have - a.done_target) < 0) {
+                if (++spins > WAIT_SPINS) { if (lane == 0) *a.err = 1; break; }
+                __builtin_amdgcn_s_sleep(PS_TP_POLL_SLEEP);
+                have = __hip_atomic_load(dp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            asm volatile("" ::: "memory");
+            if (wk.T == 2) {
+                if (wk.NG == 10) nbr_item_tp<2, 10, true>(wk, a, ctile, lane); else nbr_item_tp<2, 5, true>(wk, a, ctile, lane);
+            } else {
+                if (wk.NG == 10) nbr_item_tp<1, 10, true>(wk, a, ctile, lane); else nbr_item_tp<1, 5, true>(wk, a, ctile, lane);
+            }
+            signal_done(a.cnt_next + tp_cnt_index(wk.stage, ctile), lane);
         } else {
-            if (wk.NG == 10) nbr_item_tp<1, 10>(wk, a, ctile, lane); else nbr_item_tp<1, 5>(wk, a, ctile, lane);
+            if (wk.T == 2) {
+                if (wk.NG == 10) nbr_item_tp<2, 10, false>(wk, a, ctile, lane); else nbr_item_tp<2, 5, false>(wk, a, ctile, lane);
+            } else {
+                if (wk.NG == 10) nbr_item_tp<1, 10, false>(wk, a, ctile, lane); else nbr_item_tp<1, 5, false>(wk, a, ctile, lane);
+            }
+            signal_done(a.cnt + tp_cnt_index(wk.stage, ctile), lane);
         }
-        signal_done(a.cnt + tp_cnt_index(wk.stage, ctile), lane);
     }
 }
 
@@ -2179,12 +2254,12 @@ __device__ __forceinline__ void chain_role_tp(const TpArgs &a, int tile)
         ploc[k] = (size_t)pfr[k] * a.L + uni(sC[pcol[k]].q);
     }
     const size_t nbr_half = (size_t)TP_COL_CAP * NBR_LD, nbr_stage = 2 * nbr_half;
-    const unsigned my_uses = a.tile_uses[tile];
+    const unsigned uses_lo = a.tile_uses_lo[tile], uses_hi = a.tile_uses_hi[tile];
     auto counter = [&](int k) { return __hip_atomic_load(a.cnt + tp_cnt_index(k, tile), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
     // `have`: the counter as requested a stage earlier (normally past the target already); bounded
     auto wait_counter = [&](unsigned have, int k, unsigned items_per_tile) {
         if (a.debug & 1) return;
-        const unsigned need = my_uses * items_per_tile;
+        const unsigned need = (k < a.split ? uses_lo : uses_hi) * items_per_tile;
         int spins = 0;
         while ((int)(have - need) < 0) {
             if (++spins > WAIT_SPINS) { if (lane == 0) *a.err = 1; break; }
@@ -2227,13 +2302,14 @@ __device__ __forceinline__ void chain_role_tp(const TpArgs &a, int tile)
             if (in_form == IN_CELU) { *(f32x2 *)&sXb[xb_index(c2, col)] = ep; *(f32x2 *)&sXb[xb_index(NF + c2, col)] = en; }
             else if (in_form == IN_RAW) *(f32x2 *)&sXb[xb_index(c2, col)] = out;
             else *(f32x2 *)&sXb[xb_index(c2, col)] = ep;
+            // (write-through: the neighbour role of this very launch reads them, on other XCDs, for the next launch's columns)
             if (kind == PRO_CONVIN) {
-                *PS_G(f32x2, sc.X + ploc[k] * (2 * NF) + c2) = ep;
-                *PS_G(f32x2, sc.X + ploc[k] * (2 * NF) + NF + c2) = en;
+                store_through2(sc.X + ploc[k] * (2 * NF) + c2, ep);
+                store_through2(sc.X + ploc[k] * (2 * NF) + NF + c2, en);
             } else {
-                *PS_G(f32x2, sc.R + ploc[k] * R_LD + c2) = out;
-                *PS_G(f32x2, sc.E + ploc[k] * (2 * NF) + c2) = ep;
-                *PS_G(f32x2, sc.E + ploc[k] * (2 * NF) + NF + c2) = en;
+                store_through2(sc.R + ploc[k] * R_LD + c2, out);
+                store_through2(sc.E + ploc[k] * (2 * NF) + c2, ep);
+                store_through2(sc.E + ploc[k] * (2 * NF) + NF + c2, en);
                 ucur[k] = out;
                 if (save_slot >= 0) *(f32x2 *)(&sU[save_slot][col][c2]) = out;
             }
@@ -2380,7 +2456,17 @@ __device__ __forceinline__ void chain_role_tp(const TpArgs &a, int tile)
         trace_s = s;
 #endif
         if (!first) mfma_units(TYc, W, nty, nbase);
+        // Publishing the input of THIS stage (stored by the post op in front of it, write-through): vmcnt retires in order, so once
+        // nothing but the next stage's weight requests (the newest 2 x nnu operations) is outstanding, this wave's stores have
+        // been acknowledged; after the barrier that holds for the workgroup.  (Stage 0 issued its weights first: it drains.)
+        const bool publish = s < a.publish_upto;
+        if (publish) {
+            if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (tpt_nu(nty) == TP_MAXU) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * TP_MAXU) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * TP_MINU) : "memory");
+        }
         lds_barrier();
+        if (publish && t == 0) __hip_atomic_fetch_add(a.done + (size_t)s * CNT_PAD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         TP_STAMP(7);
         auto five = [](const float *p, int stride) {
             return chain_total(*(const f32x2 *)p, *(const f32x2 *)(p + stride), *(const f32x2 *)(p + 2 * stride),
@@ -2551,7 +2637,7 @@ __device__ __forceinline__ void chain_role_tp2(const TpArgs &a, int tile)
     const int ch = 16 * otw + 4 * kk;                  // this lane's channels (of y; the gate wave's are 80 + ch)
     const int xg = (ch >> 2) * XB_LD + i * 4;          // their place in the B-operand layout (floats)
     const size_t nbr_half = (size_t)TP_COL_CAP * NBR_LD, nbr_stage = 2 * nbr_half;
-    const unsigned my_uses = a.tile_uses[tile];
+    const unsigned my_uses = a.tile_uses_hi[tile];   // (this variant predates the look-ahead: the host keeps split = 0 for it)
     // The counter is requested a stage before it is looked at.  It must stay a VECTOR value until then: a wave-uniform load is
     // turned into a scalar by v_readfirstlane where it is issued, i.e. the wave waits for it -- and for every load in front of
     // it -- on the spot (~1 k cycles per stage).  The lane offset below is zero, but not to the compiler.
@@ -3060,7 +3146,15 @@ struct ps_pixelcnn {
     TpUnit *units_tp = nullptr;     // unit tables of the four stage types [4][TP_WAVES][TP_MAXU]
     float *nbr_tp = nullptr;        // neighbour slots [NST][2][TP_COL_CAP][160]
     unsigned *cnt_tp = nullptr;     // [NST][TP_MAX_TILES] padded completion counters, never reset
-    unsigned tile_uses_tp[TP_MAX_TILES] = {};
+    // look-ahead of the neighbour role (nbr_role_tp): slots, counters and their targets are double-buffered by launch parity
+    unsigned tile_uses_tp_lo[2][TP_MAX_TILES] = {}, tile_uses_tp_hi[2][TP_MAX_TILES] = {};
+    unsigned *done_tp = nullptr;    // [NST] padded: chain tiles that have published the input of stage k, never reset
+    unsigned done_total = 0;        // what they stand at when every publishing launch so far is through
+    int tp_ahead = 12;              // PS_TP_AHEAD: stages [0, tp_ahead) of a launch are computed by the launch in front of it (0: off)
+    int tp_wsplit = 0;              // first entry of work_tp whose stage is >= tp_ahead
+    const StepCtx *ahead_rec = nullptr;   // the launch the last one prepared: its first record, its columns, the parity it wrote to
+    int ahead_n = 0, ahead_parity = 0;
+    int tp_launch_no = 0;           // throughput-form launches of the current run so far (tuning: PS_TP_TRACE_LAUNCH)
     ColTaps *taps = nullptr;        // neighbour rows of the columns of a run, [maxF * L]
     unsigned long long *tp_trace = nullptr;   // tuning builds: stamps of the last k_column_tp launch (ps_pixelcnn_debug_cache what 4)
     int n_cus = 256;                // compute units of the device: workgroups of a column launch that are resident together
@@ -3428,12 +3522,17 @@ int build_stage_table(ps_pixelcnn *h)
     if (int rc = dev_alloc(h, &h->work_tp, work_tp.size())) return rc;
     PS_HIP_CHECK(hipMemcpy(h->work_tp, work_tp.data(), work_tp.size() * sizeof(NbrWorkTp), hipMemcpyHostToDevice));
     h->nwork_tp = (int)work_tp.size();
+    h->tp_wsplit = 0;
+    while (h->tp_wsplit < h->nwork_tp && work_tp[h->tp_wsplit].stage < h->tp_ahead) ++h->tp_wsplit;   // (entries are stage-major)
     return PS_OK;
 }
 
 // `ncols` independent columns (records rec[0..ncols)): neighbour taps of every conv and the centre-tap chains + draw,
 // in launches of at most col_cap columns.
-void run_columns(ps_pixelcnn *h, const StepCtx *rec, int ncols, const int32_t *codes, ChainArgs ca, hipStream_t st)
+// next_rec / next_ncols: the columns of the launch that FOLLOWS on this stream, when the caller knows it (a wavefront schedule):
+// the throughput form computes their first stages' neighbour slots a launch ahead (nbr_role_tp).
+void run_columns(ps_pixelcnn *h, const StepCtx *rec, int ncols, const int32_t *codes, ChainArgs ca, hipStream_t st,
+                 const StepCtx *next_rec = nullptr, int next_ncols = 0)
 {
     ca.ctl1 = h->ctl1; ca.nbr = h->nbr;
     ca.uinit_w = h->uinit_w; ca.uinit_b = h->uinit_b; ca.codes_in = codes;
@@ -3444,21 +3543,53 @@ void run_columns(ps_pixelcnn *h, const StepCtx *rec, int ncols, const int32_t *c
     if (ncols >= h->tp_min_cols) {   // throughput form: 16-column chain tiles, up to TP_COL_CAP columns per launch
         TpArgs ta{};
         ta.units = h->units_tp;
-        ta.work = h->work_tp; ta.nbr = h->nbr_tp; ta.cnt = h->cnt_tp; ta.nwork = h->nwork_tp;
+        ta.work = h->work_tp; ta.nwork = h->nwork_tp;
+        ta.done = h->done_tp; ta.split = h->tp_ahead;
+        const size_t nbr_half_buf = (size_t)NST * 2 * TP_COL_CAP * NBR_LD, cnt_half_buf = tp_cnt_index(NST, 0);
         ta.ctl1 = h->ctl1; ta.uinit_w = h->uinit_w; ta.uinit_b = h->uinit_b; ta.codes_in = codes;
         ta.out_w = h->out_w; ta.out_b = h->out_b; ta.L = h->L;
         ta.codes = ca.codes; ta.region = ca.region; ta.forced = ca.forced; ta.uniforms = ca.uniforms;
         ta.out_logits = ca.out_logits; ta.step_logits = ca.step_logits; ta.temperature = ca.temperature;
         ta.err = h->err; ta.debug = ca.debug;
         ta.trace = h->tp_trace;
+        static const int nbr_map = getenv("PS_TP_NBR_MAP") ? atoi(getenv("PS_TP_NBR_MAP")) : 0;
+        ta.nbr_map = nbr_map;
+        static const int trace_sel = getenv("PS_TP_TRACE_LAUNCH") ? atoi(getenv("PS_TP_TRACE_LAUNCH")) : -1;   // tuning: stamps of that launch of the run only
         const int cap = std::min(TP_COL_CAP, std::max(TP_COLS, (h->n_cus / 2) * TP_COLS));   // at least half of the CUs to the neighbour role
         const ColTaps *taps = h->taps + (rec - h->ctx);
         for (int done = 0; done < ncols; done += cap) {
             const int n = std::min(cap, ncols - done);
             const int tiles = (n + TP_COLS - 1) / TP_COLS;
             ta.taps = taps + done; ta.ctx = rec + done; ta.ncols = n; ta.tiles = tiles;
-            for (int t = 0; t < tiles; ++t) h->tile_uses_tp[t] += 1;
-            for (int t = 0; t < TP_MAX_TILES; ++t) ta.tile_uses[t] = h->tile_uses_tp[t];
+            // did the launch in front prepare this one?  then its slots of the stages [0, split) are in the buffers of `par`
+            const bool prepared = h->tp_ahead > 0 && h->ahead_rec == rec + done && h->ahead_n == n;
+            const int par = prepared ? h->ahead_parity : 0;
+            ta.nbr = h->nbr_tp + par * nbr_half_buf; ta.cnt = h->cnt_tp + par * cnt_half_buf;
+            ta.nbr_next = h->nbr_tp + (par ^ 1) * nbr_half_buf; ta.cnt_next = h->cnt_tp + (par ^ 1) * cnt_half_buf;
+            ta.w_from = prepared ? h->tp_wsplit : 0;
+            // and what follows this one: the rest of an oversized wavefront, or the caller's next wavefront if it takes this form
+            const StepCtx *nrec = nullptr;
+            int nn = 0;
+            if (done + cap < ncols) { nrec = rec + done + cap; nn = std::min(cap, ncols - done - cap); }
+            else if (next_rec && next_ncols >= h->tp_min_cols) { nrec = next_rec; nn = std::min(cap, next_ncols); }
+            const bool ahead = h->tp_ahead > 0 && nrec != nullptr && !(ca.debug & 2);
+            ta.w_upto = ahead ? h->tp_wsplit : 0;
+            ta.taps_next = ahead ? h->taps + (nrec - h->ctx) : ta.taps;
+            ta.ncols_next = ahead ? nn : 0;
+            ta.tiles_next = ahead ? (nn + TP_COLS - 1) / TP_COLS : 1;
+            ta.publish_upto = ahead ? h->tp_ahead : 0;
+            if (ahead) h->done_total += (unsigned)tiles;
+            ta.done_target = h->done_total;
+            static const int exp_mode = getenv("PS_TP_AHEAD_EXP") ? atoi(getenv("PS_TP_AHEAD_EXP")) : 0;   // timing experiments (results invalid)
+            if (exp_mode == 1) ta.done_target = 0;                       // look-ahead items do not wait for the chain tiles
+            if (exp_mode == 2) { ta.w_upto = 0; ta.w_from = 0; }         // chain tiles publish, nobody looks ahead
+            for (int t = 0; t < tiles; ++t) {
+                if (!prepared) h->tile_uses_tp_lo[par][t] += 1;
+                h->tile_uses_tp_hi[par][t] += 1;
+            }
+            for (int t = 0; t < TP_MAX_TILES; ++t) { ta.tile_uses_lo[t] = h->tile_uses_tp_lo[par][t]; ta.tile_uses_hi[t] = h->tile_uses_tp_hi[par][t]; }
+            if (ahead) for (int t = 0; t < ta.tiles_next; ++t) h->tile_uses_tp_lo[par ^ 1][t] += 1;
+            h->ahead_rec = ahead ? nrec : nullptr; h->ahead_n = nn; h->ahead_parity = par ^ 1;
             int grid;
             // The XCD-affine layout assumes a whole MI355X (SPX mode: 8 XCDs x 32 CUs, block b on XCD b % 8) or an even share of its
             // XCDs (a stream confined to compute units [0, 8 k): k per XCD, ps_stream_create_cu_range).  On a partition
@@ -3481,6 +3612,8 @@ void run_columns(ps_pixelcnn *h, const StepCtx *rec, int ncols, const int32_t *c
                 ta.nbr_wgs = std::max(1, std::min(h->n_cus - tiles, (h->nwork_tp * tiles + TP_WAVES - 1) / TP_WAVES));
                 grid = ta.nbr_wgs + tiles;
             }
+            ta.trace = (trace_sel < 0 || trace_sel == h->tp_launch_no) ? h->tp_trace : nullptr;
+            h->tp_launch_no += 1;
             timed(h, st, TAG_CHAIN, [&]() { hipLaunchKernelGGL(k_column_tp, dim3(grid), dim3(TP_THREADS), 0, st, ta); });
         }
         return;
@@ -3566,6 +3699,10 @@ int ps_pixelcnn_create(const float *const *params, int n_params, int H, int W, i
     if (const char *cc = getenv("PS_TP_MIN_COLS")) h->tp_min_cols = std::max(1, atoi(cc));
     if (const char *cc = getenv("PS_TP_XCDS")) h->tp_xcds = atoi(cc);
     if (const char *cc = getenv("PS_TP_FILL")) h->tp_fill = atoi(cc);
+    if (const char *cc = getenv("PS_TP_AHEAD")) h->tp_ahead = std::min(NST - 1, std::max(0, atoi(cc)));
+#if PS_TP_CHAIN2
+    h->tp_ahead = 0;
+#endif
 
     int rc = PS_OK;
     auto fail_out = [&](int code) { ps_pixelcnn_destroy(h); return code; };
@@ -3633,9 +3770,11 @@ int ps_pixelcnn_create(const float *const *params, int n_params, int H, int W, i
     if ((rc = dev_alloc(h, &h->ctx, locs))) return fail_out(rc);
     if ((rc = dev_alloc(h, &h->pstart, (size_t)N_EVAL * max_frames))) return fail_out(rc);
     if ((rc = dev_alloc(h, &h->taps, locs))) return fail_out(rc);
-    if ((rc = dev_alloc(h, &h->nbr_tp, (size_t)NST * 2 * TP_COL_CAP * NBR_LD))) return fail_out(rc);
-    if ((rc = dev_alloc(h, &h->cnt_tp, tp_cnt_index(NST, 0)))) return fail_out(rc);
-    if (hipMemset(h->cnt_tp, 0, tp_cnt_index(NST, 0) * sizeof(unsigned)) != hipSuccess) {
+    if ((rc = dev_alloc(h, &h->nbr_tp, (size_t)2 * NST * 2 * TP_COL_CAP * NBR_LD))) return fail_out(rc);
+    if ((rc = dev_alloc(h, &h->cnt_tp, 2 * tp_cnt_index(NST, 0)))) return fail_out(rc);
+    if ((rc = dev_alloc(h, &h->done_tp, (size_t)NST * CNT_PAD))) return fail_out(rc);
+    if (hipMemset(h->cnt_tp, 0, 2 * tp_cnt_index(NST, 0) * sizeof(unsigned)) != hipSuccess ||
+        hipMemset(h->done_tp, 0, (size_t)NST * CNT_PAD * sizeof(unsigned)) != hipSuccess) {
         ps::fail(PS_ERR_HIP, "pixelcnn_create: hipMemset failed");
         return fail_out(PS_ERR_HIP);
     }
@@ -3732,10 +3871,16 @@ static int ar_run_impl(ps_pixelcnn *h, int32_t *codes, const int32_t *order, con
     PS_LAUNCH_CHECK();
     // launches are enqueued eagerly: the host stays far ahead of the GPU (a hipGraph replay was measured slower, and
     // the completion-counter target changes with every launch anyway)
+    h->tp_launch_no = 0;
     if (wave_cols) {
-        for (int w = 0; w < n_waves; ++w)
-            if (wave_start[w + 1] > wave_start[w])
-                run_columns(h, h->ctx + wave_start[w], wave_start[w + 1] - wave_start[w], codes, ca, st);
+        for (int w = 0; w < n_waves; ++w) {
+            if (wave_start[w + 1] <= wave_start[w]) continue;
+            int nx = w + 1;
+            while (nx < n_waves && wave_start[nx + 1] <= wave_start[nx]) ++nx;
+            const int nnext = nx < n_waves ? wave_start[nx + 1] - wave_start[nx] : 0;
+            run_columns(h, h->ctx + wave_start[w], wave_start[w + 1] - wave_start[w], codes, ca, st,
+                        nnext > 0 ? h->ctx + wave_start[nx] : nullptr, nnext);
+        }
     } else {
         for (int sidx = 0; sidx < nsteps; ++sidx) run_columns(h, h->ctx + (size_t)sidx * F, F, codes, ca, st);
     }

@@ -519,6 +519,45 @@ def test_ar_wavefront_schedule_is_bit_identical_to_the_walk(F_, first, cap):
     assert (c_wave.cpu().numpy()[reg == 1] != codes0[reg == 1]).any()
 
 
+@pytest.mark.parametrize("ahead", ["0", "5", "12", "31"])
+def test_throughput_form_look_ahead_depths_are_bit_identical_to_the_walk(ahead, monkeypatch):
+    """k_column_tp's neighbour role computes the slots of the first PS_TP_AHEAD stages of launch i + 1 during launch i, behind
+    launch i's chain tiles (double-buffered slots and counters, `done` counters published by the chain tiles, write-through
+    stores).  Whatever the depth -- none, the default, all but the last stage -- and for full, ragged and oversized (split)
+    wavefronts, codes and logits must equal the position-by-position walk bit for bit; the run is repeated on the same handle,
+    so the never-reset counters of both parities are exercised past their first use."""
+    from pixelsynth_amd.lmconv.model import wavefronts
+    monkeypatch.setenv("PS_TP_AHEAD", ahead)
+    net = make_net(3)
+    for F_, first, cap in [(72, 640, 1024), (40, 820, 200), (100, 990, 0)]:
+        eng = net.engine(32, 32, F_, slot=100 + int(ahead))     # a handle of its own: the depth is read when it is created
+        bgs = syn.background_masks(256)
+        names = ["right_half", "half_plus_island", "ragged", "all", "top_band"]
+        infos = [c_oracle.masks_for_background(bgs[names[b % 5]], 32) for b in range(F_)]
+        order_loc = np.stack([(i["order"][:, 0] * 32 + i["order"][:, 1]) for i in infos]).astype(np.int32)
+        reg = np.zeros((F_, 1024), np.uint8)
+        rs = np.random.RandomState(F_)
+        for b in range(F_):
+            walked = order_loc[b][first:]
+            reg[b, walked[rs.rand(walked.size) < 0.8]] = 1
+            reg[b, order_loc[b][first]] = 1
+        ms = [tt(np.concatenate([i[k] for i in infos])) for k in ("mask_init", "mask_undilated", "mask_dilated")]
+        codes0 = syn.codes(13, F_).reshape(F_, 1024).astype(np.int32)
+        u = tt(np.random.RandomState(8).rand(F_, 1024).astype(np.float32))
+        c_walk = tt(codes0.copy())
+        l_walk = net.engine(32, 32, F_).ar_run(c_walk, tt(order_loc), tt(reg), *ms, temperature=0.7, uniforms=u, first_step=first,
+                                                want_logits=True, waves=wavefronts(order_loc, 32, 32, first, DEV, max_cols=128))
+        waves = wavefronts(order_loc, 32, 32, first, DEV, max_cols=cap)
+        assert (np.diff(waves[1]) > 128).sum() >= 3          # several throughput-form launches in a row
+        for rep in range(2):
+            c_wave = tt(codes0.copy())
+            l_wave = eng.ar_run(c_wave, tt(order_loc), tt(reg), *ms, temperature=0.7, uniforms=u, first_step=first, want_logits=True,
+                                waves=waves)
+            eng.check()
+            assert torch.equal(c_walk, c_wave), (F_, first, cap, rep)
+            assert torch.equal(l_walk, l_wave), (F_, first, cap, rep)
+
+
 def test_ar_run_waves_rejects_a_schedule_of_another_run():
     """The host checks the schedule's shape (column count, monotone wave_start); entries that name frames / positions
     outside the run are caught on the device and reported by check(), without touching memory out of bounds."""
