@@ -2205,7 +2205,6 @@ __device__ __forceinline__ void chain_role_tp(const TpArgs &a, int tile)
     __shared__ f32x4 sXS4[2 * XB_SIZE / 4];                                // B-operand layout: input of the centre taps, and behind
     float *const sXS = (float *)sXS4;                                      //   it concat_elu(u_k) feeding nin_skip
     float *const sXb = sXS, *const sSb = sXS + XB_SIZE;
-    __shared__ __attribute__((aligned(16))) TpUnit sUnit[4 * TP_WAVES * TP_MAXU];   // the unit tables of the four stage types
     __shared__ f32x4 sP4[TP_COLS * SP_LD / 4];                             // chain values of the stage [col][j][o]; logits at the end
     float *const sP = (float *)sP4;
     __shared__ __attribute__((aligned(16))) float sU[8][TP_COLS][NF];      // u0..u7 of the tile's columns
@@ -2223,7 +2222,6 @@ __device__ __forceinline__ void chain_role_tp(const TpArgs &a, int tile)
         }
         for (int k = t; k < XB_SIZE; k += TP_THREADS) { sXb[k] = 0.0f; sSb[k] = 0.0f; }
         for (int k = t; k < (NST + 1) * C1_CTL_DWORDS / 4; k += TP_THREADS) ((uint4 *)sCtl)[k] = ((const uint4 *)a.ctl1)[k];
-        for (int k = t; k < 4 * TP_WAVES * TP_MAXU; k += TP_THREADS) ((uint4 *)sUnit)[k] = ((const uint4 *)a.units)[k];
     }
     __syncthreads();
     auto li = [&](int rec, int field) { return uni(sCtl[rec * C1_CTL_DWORDS + field]); };
@@ -2356,18 +2354,25 @@ __device__ __forceinline__ void chain_role_tp(const TpArgs &a, int tile)
     // to arrive, and the requests go out while the matrix pipe works through MFMAs already issued.  The B operands of the
     // second half (group j + 5) take the registers of the first half's.  Units 0 .. NU-2 exist for every wave, unit NU-1 for
     // the first waves only (`last`).
-    auto mfma_units = [&](auto TYc, UnitW (&W)[TP_MAXU], int nty, const float *nbase) {
+    auto mfma_units = [&](auto TYc, UnitW (&W)[TP_MAXU], int nty, const float *nbase, auto &&after_first) {
         constexpr int TY = decltype(TYc)::value, NU = tpt_nu(TY), NH = tpt_nh(TY);
         const bool last = wave + TP_WAVES * (NU - 1) < tpt_units(TY);
-        const TpUnit *ut = sUnit + (TY * TP_WAVES + wave) * TP_MAXU;
         f32x4 b[NU], acc[NU];
         int b1i[NU], dst[NU];
+        // where unit n = wave + TP_WAVES u finds its B operand and parks its chain value: scalar arithmetic on the (uniform) wave
+        // index -- the table in LDS that used to hold these cost a round trip in front of the first B read of every stage
+        constexpr int CoT = TY == TPT_CONVOUT ? 2 * NF : NF, UM = 5 * (CoT >> 4);
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
-            const uint4 raw = ((const uint4 *)ut)[u];   // {b0, b1, dst, -}
-            b[u] = sXS4[((int)raw.x + lane_b) >> 2];
-            b1i[u] = ((int)raw.y + lane_b) >> 2;
-            dst[u] = ((int)raw.z + lane_d) >> 2;
+            const int n = min(wave + TP_WAVES * u, tpt_units(TY) - 1);   // absent units name a valid one (never stored)
+            const bool skp = n >= UM;
+            const int m = skp ? n - UM : n, ot = m / 5, j = m - 5 * ot;
+            const int b0 = (skp ? XB_SIZE : 0) + 4 * j * XB_LD;
+            const int b1 = b0 + (TY == TPT_DIL ? 0 : 20 * XB_LD);
+            const int d0 = (skp ? 5 * CoT + j * NF : j * CoT) + ot * 16;
+            b[u] = sXS4[(b0 + lane_b) >> 2];
+            b1i[u] = (b1 + lane_b) >> 2;
+            dst[u] = (d0 + lane_d) >> 2;
             acc[u] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         }
         const int nnu = tpt_nu(nty);   // units per wave of the next stage: 4 or 7 (every unit has two KBs in the stage's copy)
@@ -2378,6 +2383,7 @@ __device__ __forceinline__ void chain_role_tp(const TpArgs &a, int tile)
 #pragma unroll
             for (int u = 0; u < NU - 1; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(W[u].a0[c], b[u][c], acc[u], 0, 0, 0);
             if (last) acc[NU - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(W[NU - 1].a0[c], b[NU - 1][c], acc[NU - 1], 0, 0, 0);
+            if (c == 0) after_first();   // (the post op's operand requests go out while the matrix pipe has work queued)
         }
         TP_STAMP2(4, true);
         if (NH == 2) {
@@ -2411,6 +2417,14 @@ __device__ __forceinline__ void chain_role_tp(const TpArgs &a, int tile)
     // this wave's two columns, barrier.  The stage's type fixes Co, NG, the unit list and the post op that follows it
     // (conv_input -> CONVIN with or without nin_skip, conv_out -> GATE, dilated conv -> DIL).
     unsigned cnt_have = 0;
+    // Control records: a record is 32 dwords, ONE LDS read (a dword per lane) puts it in a register and v_readlane hands out its
+    // fields -- a ds_read + v_readfirstlane per field were two dozen round trips at the head of every stage.  cvA holds the
+    // record of the stage about to run, cvB the next one's (its type and weights are needed for the requests under this stage's
+    // MFMAs); the one after that is read at the head of the post phase.
+    auto read_rec = [&](int rec) { return sCtl[min(rec, NST) * C1_CTL_DWORDS + (lane & (C1_CTL_DWORDS - 1))]; };
+    int cvA = read_rec(1), cvB = read_rec(2);
+    auto fi = [](int cv, int field) { return __builtin_amdgcn_readlane(cv, field); };
+    auto fpf = [&](int cv, int field) { return (float *)(((unsigned long long)(unsigned)fi(cv, field + 1) << 32) | (unsigned)fi(cv, field)); };
     auto run_stage = [&](int s, auto TYc, auto FIRSTc, UnitW (&W)[TP_MAXU]) {
         constexpr int TY = decltype(TYc)::value;
         constexpr bool first = decltype(FIRSTc)::value;   // stage 0: its MFMA phase goes ahead of the wait for the neighbour role's first items
@@ -2419,46 +2433,49 @@ __device__ __forceinline__ void chain_role_tp(const TpArgs &a, int tile)
         constexpr int Co = kind == PRO_GATE ? 2 * NF : NF;
         using std::integral_constant;
         TP_STAMP(0);
-        const PostCtl pc = post_ctl(1 + s);     // stage s and the post op that follows it
-        const StoreCtl sc = store_ctl(1 + s);
-        const int nty = li(2 + s, CTL_TP_TYPE);
-        const float *nbase = weights_base(2 + s, nty);
-        if (first) {
-#ifdef PS_TP_TRACE_BUILD
-            trace_s = s;
-#endif
-            mfma_units(TYc, W, nty, nbase);
-        }
-        wait_counter(cnt_have, s, (unsigned)li(1 + s, CTL_TP_ITEMS));
-        cnt_have = counter(min(s + 1, NST - 2));             // looked at a stage later
-        TP_STAMP(1);
+        const PostCtl pc{Co, kind, has_skip, fi(cvA, CTL_IN_FORM), fi(cvA, CTL_SAVE_SLOT), 0, fpf(cvA, CTL_BIAS), fpf(cvA, CTL_BIAS2)};
+        const StoreCtl sc{kind, fi(cvA, CTL_SKIP_SLOT), fpf(cvA, CTL_R), fpf(cvA, CTL_E), fpf(cvA, CTL_X)};
+        const unsigned items = (unsigned)fi(cvA, CTL_TP_ITEMS);
+        const int nty = fi(cvB, CTL_TP_TYPE);
+        const float *nbase = fpf(cvB, CTL_WTP) + ((size_t)wave * tpt_nu(nty) * 2 * 64 + lane) * 4;
         // operands of this stage's post op: y = ((bias + NA) + centre) + NB (+ gate half, + nin_skip bias); they land under the MFMAs
-        f32x2 ob = plain(pc.bias + c2), obg = zero2, ob2 = zero2, ona[TP_NPC], onb[TP_NPC], onag[TP_NPC], onbg[TP_NPC];
-        if (kind == PRO_GATE) obg = plain(pc.bias + NF + c2);
-        if (has_skip) ob2 = plain(pc.bias2 + c2);
+        f32x2 ob = zero2, obg = zero2, ob2 = zero2, ona[TP_NPC], onb[TP_NPC], onag[TP_NPC], onbg[TP_NPC];
+        auto request_operands = [&]() {
+            wait_counter(cnt_have, s, items);
+            cnt_have = counter(min(s + 1, NST - 2));             // looked at a stage later
+            TP_STAMP(1);
+            ob = plain(pc.bias + c2);
+            if (kind == PRO_GATE) obg = plain(pc.bias + NF + c2);
+            if (has_skip) ob2 = plain(pc.bias2 + c2);
 #pragma unroll
-        for (int k = 0; k < TP_NPC; ++k) {
-            const float *nb = a.nbr + (size_t)s * nbr_stage + (size_t)(col0 + (pvalid[k] ? pcol[k] : 0)) * NBR_LD + c2;
+            for (int k = 0; k < TP_NPC; ++k) {
+                const float *nb = a.nbr + (size_t)s * nbr_stage + (size_t)(col0 + (pvalid[k] ? pcol[k] : 0)) * NBR_LD + c2;
 #if PS_TP_EXP == 1
-            ona[k] = plain(nb);
-            onb[k] = plain(nb + nbr_half);
-            if (kind == PRO_GATE) { onag[k] = plain(nb + NF); onbg[k] = plain(nb + nbr_half + NF); }
+                ona[k] = plain(nb);
+                onb[k] = plain(nb + nbr_half);
+                if (kind == PRO_GATE) { onag[k] = plain(nb + NF); onbg[k] = plain(nb + nbr_half + NF); }
 #elif PS_TP_EXP == 2
-            ona[k] = onb[k] = onag[k] = onbg[k] = zero2; (void)nb;
+                ona[k] = onb[k] = onag[k] = onbg[k] = zero2; (void)nb;
 #else
-            ona[k] = fresh(nb);
-            onb[k] = fresh(nb + nbr_half);
-            if (kind == PRO_GATE) { onag[k] = fresh(nb + NF); onbg[k] = fresh(nb + nbr_half + NF); }
+                ona[k] = fresh(nb);
+                onb[k] = fresh(nb + nbr_half);
+                if (kind == PRO_GATE) { onag[k] = fresh(nb + NF); onbg[k] = fresh(nb + nbr_half + NF); }
 #endif
-        }
-        TP_STAMP(2);
+            }
+            TP_STAMP(2);
+        };
 #ifdef PS_TP_TRACE_BUILD
         trace_s = s;
 #endif
-        if (!first) mfma_units(TYc, W, nty, nbase);
+        if (first) {
+            mfma_units(TYc, W, nty, nbase, []() {});
+            request_operands();
+        } else {
+            mfma_units(TYc, W, nty, nbase, request_operands);
+        }
         // Publishing the input of THIS stage (stored by the post op in front of it, write-through): vmcnt retires in order, so once
         // nothing but the next stage's weight requests (the newest 2 x nnu operations) is outstanding, this wave's stores have
-        // been acknowledged; after the barrier that holds for the workgroup.  (Stage 0 issued its weights first: it drains.)
+        // been acknowledged; after the barrier that holds for the workgroup.  (Stage 0 requested its operands last: it drains.)
         const bool publish = s < a.publish_upto;
         if (publish) {
             if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -2468,6 +2485,7 @@ __device__ __forceinline__ void chain_role_tp(const TpArgs &a, int tile)
         lds_barrier();
         if (publish && t == 0) __hip_atomic_fetch_add(a.done + (size_t)s * CNT_PAD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         TP_STAMP(7);
+        const int cvC = read_rec(3 + s);
         auto five = [](const float *p, int stride) {
             return chain_total(*(const f32x2 *)p, *(const f32x2 *)(p + stride), *(const f32x2 *)(p + 2 * stride),
                                *(const f32x2 *)(p + 3 * stride), *(const f32x2 *)(p + 4 * stride));
@@ -2484,11 +2502,12 @@ __device__ __forceinline__ void chain_role_tp(const TpArgs &a, int tile)
         }
         emit2(y, g, skip, integral_constant<int, kind>{}, integral_constant<bool, has_skip>{}, pc.in_form, pc.save_slot, sc);
         stage_skip_input(sc.skip_slot);
+        cvA = cvB; cvB = cvC;
         lds_barrier();
     };
     auto dispatch_stage = [&](int s, UnitW (&W)[TP_MAXU]) {
         using std::integral_constant;
-        const int ty = li(1 + s, CTL_TP_TYPE);
+        const int ty = fi(cvA, CTL_TP_TYPE);
         const integral_constant<bool, false> no{};
         if (ty == TPT_CONVOUT) run_stage(s, integral_constant<int, TPT_CONVOUT>{}, no, W);
         else if (ty == TPT_CONVIN_SKIP) run_stage(s, integral_constant<int, TPT_CONVIN_SKIP>{}, no, W);
@@ -3161,7 +3180,8 @@ struct ps_pixelcnn {
     bool xcd_even = true;           // n_cus is an even share of the 8 XCDs of a whole MI355X (block b runs on XCD b % 8)
     int tp_min_cols = COL_CAP + 1;  // PS_TP_MIN_COLS: tuning
     int tp_xcds = -1;               // PS_TP_XCDS: 0 = chain tiles anywhere, -1 = on as few XCDs as hold them, n = on at least n XCDs
-    int tp_fill = 1;                // PS_TP_FILL: neighbour workgroups on the spare CUs of the chain XCDs
+    int tp_fill = 0;                // PS_TP_FILL: neighbour workgroups on the spare CUs of the chain XCDs (off since the neighbour role
+                                    // works a launch ahead: it has time to spare, and the chain tiles are faster with their XCDs' L2 to themselves)
     int col_cap = COL_CAP;          // columns per launch (PS_COL_CAP: tuning)
     int chain_xcds = 0;             // PS_CHAIN_XCDS: tuning (0 = automatic)
     int force_groups = 0;           // PS_NBR_GROUPS: tuning (0 = automatic)
@@ -3603,10 +3623,12 @@ void run_columns(ps_pixelcnn *h, const StepCtx *rec, int ncols, const int32_t *c
                 const int cx = h->tp_xcds > 0 ? std::max(h->tp_xcds, (tiles + rows - 1) / rows) : (tiles + rows - 1) / rows;
                 ta.chain_xcds = std::min(cx, 7);
                 const int spare = ta.chain_xcds * rows - tiles;
-                ta.nbr_wgs = (8 - ta.chain_xcds) * rows;
+                static const int grid_rows = getenv("PS_TP_GRID_ROWS") ? atoi(getenv("PS_TP_GRID_ROWS")) : 0;   // tuning: fewer neighbour workgroups
+                const int use_rows = grid_rows > 0 ? std::min(rows, std::max(grid_rows, (tiles + ta.chain_xcds - 1) / ta.chain_xcds)) : rows;
+                ta.nbr_wgs = (8 - ta.chain_xcds) * use_rows;
                 ta.fill_nbr = -1;
-                if (h->tp_fill && spare > 0) { ta.fill_nbr = ta.nbr_wgs; ta.nbr_wgs += spare; }
-                grid = h->n_cus;
+                if (h->tp_fill && spare > 0 && use_rows == rows) { ta.fill_nbr = ta.nbr_wgs; ta.nbr_wgs += spare; }
+                grid = use_rows * 8;
             } else {
                 ta.chain_xcds = 0; ta.fill_nbr = -1;
                 ta.nbr_wgs = std::max(1, std::min(h->n_cus - tiles, (h->nwork_tp * tiles + TP_WAVES - 1) / TP_WAVES));
