@@ -1167,16 +1167,31 @@ struct NbrArgs {
     int nbr_wgs, groups;  // neighbour-role workgroups of the launch; work items each of them runs at a time (2 or 4)
     int debug;            // tuning only
     int *err;             // set to 1 if a bounded wait ran out (ps_pixelcnn_status)
+    // look-ahead (as in the throughput form, nbr_role_tp): work entries [w_from, nwork) for this launch's columns, then entries
+    // [0, w_upto) -- the stages below the split -- for the NEXT launch's columns, into the other half of the double-buffered
+    // slots / counters, each item once the chain workgroups of this launch have published the input of its stage (`done`)
+    int w_from, w_upto;
+    const StepCtx *ctx_next;
+    int ncols_next, tiles_next;
+    float *nbr_next;
+    unsigned *cnt_next;
+    const unsigned *done;
+    unsigned done_target;
+    int split;            // the stages below it are the look-ahead's
 };
 
 // one neighbour tap of one conv for 16 columns x 16 output channels, from fresh accumulators
-template <int NG, bool EAGER>
+// AHEAD: an item of the NEXT launch's columns.  Some of its rows were stored (write-through) by chain workgroups of THIS launch
+// on other XCDs; a stale copy can only be in this CU's L1 / this XCD's L2 if the line was read earlier in the launch: rows of
+// 80 floats share lines with their neighbours' (device-scope loads for those), and the dummy reads of closed lanes -- which is why
+// a closed lane reads a row another lane gathers anyway, in every launch (see nbr_item_tp).
+template <int NG, bool EAGER, bool AHEAD = false>
 __device__ __forceinline__ f32x4 nbr_tap(const NbrWork &sd, const NbrArgs &a, const StepCtx *recs, int t, int o0, int col, bool valid,
                                          int i, int kk)
 {
     const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
     float mv = 0.0f;
-    const float *src = sd.in + 4 * kk;  // lanes without an input row load row 0 and drop it
+    int row = -1;
     if (valid) {
         const StepCtx &cx = recs[col];
         const int q = cx.q, f = cx.f;
@@ -1184,12 +1199,15 @@ __device__ __forceinline__ f32x4 nbr_tap(const NbrWork &sd, const NbrArgs &a, co
         const int rr = r + (t / 3 - 1) * sd.dil, cc = c + (t % 3 - 1) * sd.dil;
         if (rr >= 0 && rr < a.H && cc >= 0 && cc < a.W) {
             mv = cx.m[sd.mask_kind][t];
-            src = sd.in + ((size_t)f * a.L + rr * a.W + cc) * sd.in_ld + 4 * kk;
+            row = f * a.L + rr * a.W + cc;
         }
     }
     const bool live = mv != 0.0f;
-    if (!__any(live)) return zero;
-    if (!live) src = sd.in + 4 * kk;  // a masked row is not fetched either (one shared line instead of sixteen different ones)
+    const unsigned long long open = __builtin_amdgcn_ballot_w64(live);
+    if (open == 0ull) return zero;
+    const int safe = __shfl(row, __builtin_ctzll(open), 64);   // a masked row is not fetched: the lane reads one that is being read anyway
+    const int rowq = live ? row : safe;
+    const float *src = sd.in + (size_t)rowq * sd.in_ld + 4 * kk;
     Acc5 acc = acc5_zero();
     const float *wbase = sd.w + (size_t)t * NG * 16 * sd.Co_pad + ((size_t)kk * sd.Co_pad + o0 + i) * 4;
     f32x4 av[NG], bv[NG];
@@ -1200,15 +1218,21 @@ __device__ __forceinline__ f32x4 nbr_tap(const NbrWork &sd, const NbrArgs &a, co
     // under the lane condition `live ? *p : 0` -- one round trip per load, see k_gemm -- was within 1 % of that.)
 #pragma unroll
     for (int g = 0; g < NG; ++g) av[g] = *PS_GC(f32x4, wbase + (size_t)g * 16 * sd.Co_pad);
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc((void *)sd.in, 0, 0x7fffffff, 0x00020000);
+    [[maybe_unused]] const int voff = (rowq * sd.in_ld + 4 * kk) * 4;
+    auto brow = [&](int g) {
+        if (AHEAD && NG == 5) return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(irs, voff + 64 * g, 0, 16 /* sc1 */));
+        return *PS_GC(f32x4, src + 16 * g);
+    };
     if (EAGER) {
 #pragma unroll
-        for (int g = 0; g < NG; ++g) bv[g] = *PS_GC(f32x4, src + 16 * g);
+        for (int g = 0; g < NG; ++g) bv[g] = brow(g);
     }
 #pragma unroll
     for (int g0 = 0; g0 < NG; g0 += 5) {
         if (!EAGER) {
 #pragma unroll
-            for (int g = g0; g < g0 + 5; ++g) bv[g] = *PS_GC(f32x4, src + 16 * g);
+            for (int g = g0; g < g0 + 5; ++g) bv[g] = brow(g);
         }
 #ifndef PS_NBR_NO_PIN
         // (the loads stay unconditional: otherwise the compiler sinks one of them under `live` and waits for it with
@@ -1259,6 +1283,13 @@ __device__ __forceinline__ void signal_done(unsigned *counter, int lane)
 // (Tried and dropped, each slower because the 128-register budget of a 1024-thread workgroup spills: fetching the next
 // round's records a round ahead; one wave per item with its four taps in sequence and no barrier; items of two column
 // tiles that keep the tap's weights in registers.)
+// Bound of the in-launch waits on the neighbour role's completion counters: a hang guard, not a schedule.  A wait is normally
+// over before it starts; it lasts when workgroups of the launch are not resident yet because kernels of ANOTHER stream hold their
+// CUs (bench.py / driver.py run the next batch's splat under this batch's AR run: a stream of 64-thread workgroups can keep a
+// 512- or 1024-thread workgroup that needs most of a CU's LDS waiting for as long as that kernel lasts, milliseconds).  Round 2's
+// bounds (20 000 / 40 000 polls of >= 128 clocks: a few ms) were inside that range and expired now and then (one bench run in
+// six); 2^24 polls are seconds -- still finite, so a lost workgroup ends as an error from ps_pixelcnn_status, not as a hung GPU.
+constexpr int WAIT_SPINS = 1 << 24;
 constexpr int NBR_MAX_GROUPS = 4;
 constexpr int NWORK_MAX = 512;  // work-table entries the neighbour role can stage (this network: 460)
 
@@ -1268,17 +1299,20 @@ __device__ __forceinline__ void nbr_role(const NbrArgs &a, int nb)
     // the launch's column records and the work table, staged once: a round then starts with two LDS reads instead of
     // two dependent trips to memory (work record -> column record) before its operands can even be requested
     __shared__ __attribute__((aligned(16))) StepCtx sCtx[COL_CAP];
+    __shared__ __attribute__((aligned(16))) StepCtx sCtxN[COL_CAP];   // the NEXT launch's records (look-ahead)
     __shared__ __attribute__((aligned(16))) NbrWork sWork[NWORK_MAX];
-    __shared__ unsigned sArr[2][NBR_MAX_GROUPS], sRd[NBR_MAX_GROUPS];
+    __shared__ unsigned sArr[2][NBR_MAX_GROUPS], sRd[NBR_MAX_GROUPS], sGo[NBR_MAX_GROUPS];   // sGo: look-ahead stages wave 0 has seen published, + 1
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, i = lane & 15, kk = lane >> 4;
     const int grp4 = wave >> 2, w4 = wave & 3;
     if (nb >= a.nbr_wgs) return;
     {
-        if (threadIdx.x < NBR_MAX_GROUPS) { sArr[0][threadIdx.x] = 0; sArr[1][threadIdx.x] = 0; sRd[threadIdx.x] = 0; }
+        if (threadIdx.x < NBR_MAX_GROUPS) { sArr[0][threadIdx.x] = 0; sArr[1][threadIdx.x] = 0; sRd[threadIdx.x] = 0; sGo[threadIdx.x] = 0; }
         const int nc = a.ncols * (int)(sizeof(StepCtx) / 16), nw = a.nwork * (int)(sizeof(NbrWork) / 16);
-        for (int k = threadIdx.x; k < nc + nw; k += (int)blockDim.x) {
+        const int nx = a.w_upto > 0 ? a.ncols_next * (int)(sizeof(StepCtx) / 16) : 0;
+        for (int k = threadIdx.x; k < nc + nw + nx; k += (int)blockDim.x) {
             if (k < nc) ((uint4 *)sCtx)[k] = ((const uint4 *)a.ctx)[k];
-            else ((uint4 *)sWork)[k - nc] = ((const uint4 *)a.work)[k - nc];
+            else if (k < nc + nw) ((uint4 *)sWork)[k - nc] = ((const uint4 *)a.work)[k - nc];
+            else ((uint4 *)sCtxN)[k - nc - nw] = ((const uint4 *)a.ctx_next)[k - nc - nw];
         }
         __syncthreads();
     }
@@ -1290,7 +1324,8 @@ __device__ __forceinline__ void nbr_role(const NbrArgs &a, int nb)
     //            because a tap wave may be one round ahead of wave 0); wave 0 adds up round r once it reads 3 (r / 2 + 1);
     //   sRd[g]   rounds wave 0 has consumed; a tap wave reuses exchange buffer r & 1 once rounds <= r - 2 are consumed.
     // Every wait is bounded (a lost wave sets the handle's error flag instead of hanging the GPU).
-    const int nitems = a.nwork * a.tiles, per_round = a.nbr_wgs * a.groups;
+    const int n_own = (a.nwork - a.w_from) * a.tiles;
+    const int nitems = n_own + a.w_upto * a.tiles_next, per_round = a.nbr_wgs * a.groups;
     unsigned *pending = nullptr;  // counter of the item this group finished in the previous round, not yet published
     auto spin_until = [&](const unsigned *flag, unsigned want) {
         int spins = 0;
@@ -1300,19 +1335,78 @@ __device__ __forceinline__ void nbr_role(const NbrArgs &a, int nb)
         }
     };
     unsigned r = 0;  // rounds this group has worked on
+    int ready_upto = -1;   // look-ahead: stages whose input the chain workgroups of this launch are known to have published
     for (int base = 0; base < nitems; base += per_round) {
         const int item = base + nb * a.groups + grp4;
         if (item >= nitems) break;  // (the four waves of a group agree)
-        const int witem = item / a.tiles, ctile = item - witem * a.tiles, par = r & 1;
+        const bool ahead = item >= n_own;
+        int witem, ctile;
+        if (!ahead) {
+            const int q = item / a.tiles;
+            witem = a.w_from + q; ctile = item - q * a.tiles;
+        } else {
+            const int j = item - n_own;
+            witem = j / a.tiles_next; ctile = j - witem * a.tiles_next;
+        }
+        const int par = r & 1;
         const NbrWork wk = sWork[witem];
         const int col = ctile * 16 + i;
-        const bool valid = col < a.ncols;
+        const bool valid = col < (ahead ? a.ncols_next : a.ncols);
         const int t = wk.half * 5 + w4;  // taps 0..3 (NA) or 5..8 (NB)
         f32x4 part;
-        if (r == 0) part = wk.NG == 10 ? nbr_tap<10, true>(wk, a, sCtx, t, wk.cog * 16, col, valid, i, kk)
-                                       : nbr_tap<5, true>(wk, a, sCtx, t, wk.cog * 16, col, valid, i, kk);
-        else part = wk.NG == 10 ? nbr_tap<10, false>(wk, a, sCtx, t, wk.cog * 16, col, valid, i, kk)
-                                : nbr_tap<5, false>(wk, a, sCtx, t, wk.cog * 16, col, valid, i, kk);
+        if (ahead && wk.stage > ready_upto) {
+            // The chain workgroups of this launch must have stored the input of the item's stage (`done`).  Only the group's wave 0
+            // looks at the counters in memory -- the other three take its word through LDS -- and it polls slowly: with every wave
+            // polling every 0.2 us the counters' lines were hammered from 2752 waves, and the chains' own device-scope traffic (and
+            // their publishing atomics, on the same lines) slowed down by 1.4 us per look-ahead stage.  One look at the LAST
+            // look-ahead stage's counter settles it for the rest of the launch when the chains are that far already; otherwise
+            // wait for this stage's (bounded) -- but not with this group's previous item unpublished behind the wait: the chains
+            // that publish `done` may be waiting for exactly that item.
+            unsigned val;
+            if (w4 == 0) {
+                const unsigned *dl = a.done + (size_t)(a.split - 1) * CNT_PAD;
+                if ((int)(__hip_atomic_load(dl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.done_target) >= 0) {
+                    val = (unsigned)a.split;
+                } else {
+#ifdef PS_LA_COUNT
+                    if (lane == 0) atomicAdd((unsigned *)a.done + (size_t)wk.stage * CNT_PAD + 1, 1u);
+#endif
+                    if (pending) {
+                        signal_done(pending, lane);
+                        pending = nullptr;
+                    }
+                    const unsigned *dp = a.done + (size_t)wk.stage * CNT_PAD;
+                    unsigned have = __hip_atomic_load(dp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    int spins = 0;
+                    while ((int)(have - a.done_target) < 0) {
+                        if (++spins > (WAIT_SPINS >> 4)) { if (lane == 0) *a.err = 1; break; }
+                        __builtin_amdgcn_s_sleep(100);
+                        have = __hip_atomic_load(dp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    val = (unsigned)wk.stage + 1u;
+                }
+                asm volatile("" ::: "memory");
+                if (lane == 0) __hip_atomic_store(&sGo[grp4], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
+                int spins = 0;
+                while ((val = __hip_atomic_load(&sGo[grp4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < (unsigned)wk.stage + 1u) {
+                    if (++spins > WAIT_SPINS) { if (lane == 0) *a.err = 1; break; }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
+            ready_upto = (int)val - 1;
+            asm volatile("" ::: "memory");
+        }
+        if (ahead) {
+            part = wk.NG == 10 ? nbr_tap<10, false, true>(wk, a, sCtxN, t, wk.cog * 16, col, valid, i, kk)
+                               : nbr_tap<5, false, true>(wk, a, sCtxN, t, wk.cog * 16, col, valid, i, kk);
+        } else if (r == 0) {
+            part = wk.NG == 10 ? nbr_tap<10, true>(wk, a, sCtx, t, wk.cog * 16, col, valid, i, kk)
+                               : nbr_tap<5, true>(wk, a, sCtx, t, wk.cog * 16, col, valid, i, kk);
+        } else {
+            part = wk.NG == 10 ? nbr_tap<10, false>(wk, a, sCtx, t, wk.cog * 16, col, valid, i, kk)
+                               : nbr_tap<5, false>(wk, a, sCtx, t, wk.cog * 16, col, valid, i, kk);
+        }
         if (w4 != 0) {
             if (r >= 2) spin_until(&sRd[grp4], r - 1);
             *(f32x4 *)(&sNP[par][grp4][w4][i][kk * 4]) = part;
@@ -1329,11 +1423,11 @@ __device__ __forceinline__ void nbr_role(const NbrArgs &a, int nb)
                 f32x4 tot = zero + part;
 #pragma unroll
                 for (int w = 1; w < 4; ++w) tot = tot + *(const f32x4 *)(&sNP[par][grp4][w][i][kk * 4]);
-                store_through(a.nbr + (((size_t)wk.stage * 2 + wk.half) * a.col_stride + col) * NBR_LD + wk.cog * 16 + kk * 4, tot);
+                store_through((ahead ? a.nbr_next : a.nbr) + (((size_t)wk.stage * 2 + wk.half) * a.col_stride + col) * NBR_LD + wk.cog * 16 + kk * 4, tot);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (lane == 0) __hip_atomic_store(&sRd[grp4], r + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            pending = a.cnt + cnt_index(wk.stage, ctile);
+            pending = (ahead ? a.cnt_next : a.cnt) + cnt_index(wk.stage, ctile);
         }
         ++r;
     }
@@ -1364,6 +1458,13 @@ struct ChainArgs {
     unsigned long long *trace; // optional [NST][10] shader-clock stamps of workgroup 0 (tuning aid)
     int debug;                 // tuning only (PS_COLUMN_DEBUG): 1 = chains do not wait for the neighbour slots, 2 = no chains,
                                // 3 = no neighbour role and no waiting
+    // look-ahead form (k_column_la, chain_role<FPW, true>): the slots of the stages below `la_split` were computed by the launch in
+    // front (use counts uses_lo), the others by this one (uses_hi); `nbr` / `cnt` are the halves of this launch's parity; the
+    // columns publish, stage by stage, that the input of stage k is in memory (`done`) for the neighbour role's look-ahead items
+    int la_split;
+    unsigned uses_lo[MAX_TILES], uses_hi[MAX_TILES];
+    unsigned *done;
+    int publish_upto;
 };
 
 // categorical draw from logits / T by inverse CDF with one uniform (sample.py:60-66); lane l holds classes 8l..8l+7
@@ -1394,13 +1495,6 @@ __device__ __forceinline__ int draw_code(const float (&lg)[8], float temperature
 // Workgroup barrier that only drains LDS traffic.  __syncthreads() also waits for every outstanding
 // global access (vmcnt(0)), which would serialise the weight / neighbour-slot prefetches of k_chain
 // against its two barriers per stage; the data exchanged between the waves here lives in LDS only.
-// Bound of the in-launch waits on the neighbour role's completion counters: a hang guard, not a schedule.  A wait is normally
-// over before it starts; it lasts when workgroups of the launch are not resident yet because kernels of ANOTHER stream hold their
-// CUs (bench.py / driver.py run the next batch's splat under this batch's AR run: a stream of 64-thread workgroups can keep a
-// 512- or 1024-thread workgroup that needs most of a CU's LDS waiting for as long as that kernel lasts, milliseconds).  Round 2's
-// bounds (20 000 / 40 000 polls of >= 128 clocks: a few ms) were inside that range and expired now and then (one bench run in
-// six); 2^24 polls are seconds -- still finite, so a lost workgroup ends as an error from ps_pixelcnn_status, not as a hung GPU.
-constexpr int WAIT_SPINS = 1 << 24;
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -1510,7 +1604,11 @@ __device__ __forceinline__ StoreCtl load_store_ctl(const int *ctl, int rec)
                     ctl_p<float>(ctl, rec, CTL_E), ctl_p<float>(ctl, rec, CTL_X)};
 }
 
-template <int FPW>
+__device__ __forceinline__ void store_through1(float *p, float v)
+{
+    asm volatile("global_store_dword %0, %1, off sc1" : : "v"(PS_G(float, p)), "v"(v) : "memory");
+}
+template <int FPW, bool LA = false>
 __device__ __forceinline__ void chain_role(const ChainArgs &a, int wg)
 {
     static_assert(FPW >= 1 && FPW <= 2, "waves 0..12 run the chains, wave 13 stores, the last FPW waves do the post ops");
@@ -1612,10 +1710,11 @@ __device__ __forceinline__ void chain_role(const ChainArgs &a, int wg)
         // completion counter of stage k; `have` is a value loaded earlier (normally already
         // past the target, so this costs nothing); bounded, so a lost neighbour workgroup cannot hang the GPU
         const int my_tile = (pvalid ? pfr : 0) >> 4;
-        const unsigned my_uses = a.tile_uses[my_tile];
+        const unsigned my_uses = LA ? 0u : a.tile_uses[my_tile];
+        const unsigned uses_lo = LA ? a.uses_lo[my_tile] : 0u, uses_hi = LA ? a.uses_hi[my_tile] : 0u;
         auto counter = [&](int k) { return __hip_atomic_load(a.cnt + cnt_index(k, my_tile), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
         auto wait_counter = [&](unsigned have, int k, unsigned items_per_tile) {
-            const unsigned need = my_uses * items_per_tile;
+            const unsigned need = (LA ? (k < a.la_split ? uses_lo : uses_hi) : my_uses) * items_per_tile;
             if (a.debug & 1) return;
             int spins = 0;
             while ((int)(have - need) < 0) {
@@ -1794,7 +1893,16 @@ __device__ __forceinline__ void chain_role(const ChainArgs &a, int wg)
                 for (int k = 0; k < 2; ++k) {
                     if (k == 1 && !hasB) break;
                     const float ep = sOut[f][1][ch[k]], en = sOut[f][2][ch[k]];
-                    if (c.kind == PRO_CONVIN) {
+                    if (LA) {   // (write-through: the neighbour role of this very launch reads them for the next launch's columns)
+                        if (c.kind == PRO_CONVIN) {
+                            store_through1(c.X + 2 * off80[f] + ch[k], ep);
+                            store_through1(c.X + 2 * off80[f] + NF + ch[k], en);
+                        } else {
+                            store_through1(c.R + offR[f] + ch[k], sOut[f][0][ch[k]]);
+                            store_through1(c.E + 2 * off80[f] + ch[k], ep);
+                            store_through1(c.E + 2 * off80[f] + NF + ch[k], en);
+                        }
+                    } else if (c.kind == PRO_CONVIN) {
                         *PS_G(float, c.X + 2 * off80[f] + ch[k]) = ep;
                         *PS_G(float, c.X + 2 * off80[f] + NF + ch[k]) = en;
                     } else {
@@ -1824,6 +1932,13 @@ __device__ __forceinline__ void chain_role(const ChainArgs &a, int wg)
         store_outputs(sc);
         StoreCtl sn = load_store_ctl(a.ctl1, 1);
         for (int s = 0; s < NST - 2; ++s) {
+            // (look-ahead form: everything but the stores of the LAST store_outputs -- the input of stage s: 2 or 3 stores per
+            // channel pass, two passes per frame -- has been acknowledged once vmcnt is down to their number, so after the barrier
+            // below the control wave may publish that the input of stage s - 1 is in memory)
+            if (LA) {
+                if (sc.kind == PRO_CONVIN) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(4 * FPW) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" : : "n"(6 * FPW) : "memory");
+            }
             sc = sn;                // record 1 + s
             lds_barrier();          // chains of stage s done: sSkip is free, the u_k were saved long ago
             stage_skip_input(sc);   // for stage s + 1, whose chains start after the next barrier
@@ -1851,6 +1966,8 @@ __device__ __forceinline__ void chain_role(const ChainArgs &a, int wg)
         for (int s = 0; s < NST - 2; ++s) {
             lds_barrier();
             touch(6 + s);
+            if (LA && s >= 1 && s - 1 < a.publish_upto && lane == 0)   // (see the store wave)
+                __hip_atomic_fetch_add(a.done + (size_t)(s - 1) * CNT_PAD, (unsigned)min(FPW, a.ncols - f0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             lds_barrier();
         }
         load_out_weights();
@@ -1943,6 +2060,24 @@ __global__ __launch_bounds__(C1_THREADS) void k_column(NbrArgs na, ChainArgs ca)
         if (x < cx) {
             const int col = row * cx + x;
             if (col < ca.ncols && (ca.debug & 3) != 2) chain_role<1>(ca, col);
+        } else if ((ca.debug & 3) != 3) {
+            nbr_role(na, row * (8 - cx) + (x - cx));
+        }
+    } else if ((ca.debug & 3) != 3) {
+        nbr_role(na, chain_rows * (8 - cx) + (row - chain_rows) * 8 + x);
+    }
+}
+
+// k_column_la: the same launch where the host knows what follows on the stream (a wavefront schedule): the neighbour role works
+// a launch ahead for the first stages (nbr_role with w_from / w_upto set), the columns publish their stores (chain_role<1, true>).
+__global__ __launch_bounds__(C1_THREADS) void k_column_la(NbrArgs na, ChainArgs ca)
+{
+    const int b = blockIdx.x, cx = na.chain_xcds, x = b & 7, row = b >> 3;
+    const int chain_rows = (ca.ncols + cx - 1) / cx;  // rows of 8 blocks (one per XCD) that hold chain workgroups
+    if (row < chain_rows) {
+        if (x < cx) {
+            const int col = row * cx + x;
+            if (col < ca.ncols && (ca.debug & 3) != 2) chain_role<1, true>(ca, col);
         } else if ((ca.debug & 3) != 3) {
             nbr_role(na, row * (8 - cx) + (x - cx));
         }
@@ -3174,6 +3309,14 @@ struct ps_pixelcnn {
     const StepCtx *ahead_rec = nullptr;   // the launch the last one prepared: its first record, its columns, the parity it wrote to
     int ahead_n = 0, ahead_parity = 0;
     int tp_launch_no = 0;           // throughput-form launches of the current run so far (tuning: PS_TP_TRACE_LAUNCH)
+    // the same look-ahead for the latency form (k_column_la; from one latency-form launch to the next): `nbr` and `cnt` hold two halves
+    unsigned col_uses_lo[2][MAX_TILES] = {}, col_uses_hi[2][MAX_TILES] = {};
+    unsigned *done_col = nullptr;   // [NST] padded: columns that have published the input of stage k, never reset
+    unsigned done_col_total = 0;
+    int col_ahead = 16;             // PS_COL_AHEAD: stages computed a launch ahead (0: off -- k_column as before)
+    int col_wsplit = 0;             // first entry of `work` whose stage is >= col_ahead
+    const StepCtx *col_ahead_rec = nullptr;
+    int col_ahead_n = 0, col_ahead_parity = 0;
     ColTaps *taps = nullptr;        // neighbour rows of the columns of a run, [maxF * L]
     unsigned long long *tp_trace = nullptr;   // tuning builds: stamps of the last k_column_tp launch (ps_pixelcnn_debug_cache what 4)
     int n_cus = 256;                // compute units of the device: workgroups of a column launch that are resident together
@@ -3538,6 +3681,8 @@ int build_stage_table(ps_pixelcnn *h)
     if (int rc = dev_alloc(h, &h->work, work.size())) return rc;
     PS_HIP_CHECK(hipMemcpy(h->work, work.data(), work.size() * sizeof(NbrWork), hipMemcpyHostToDevice));
     h->nwork = (int)work.size();
+    h->col_wsplit = 0;
+    while (h->col_wsplit < h->nwork && work[h->col_wsplit].stage < h->col_ahead) ++h->col_wsplit;   // (entries are stage-major)
     PS_REQUIRE(h->nwork <= NWORK_MAX, "pixelcnn: %d neighbour work entries exceed the staging table", h->nwork);
     if (int rc = dev_alloc(h, &h->work_tp, work_tp.size())) return rc;
     PS_HIP_CHECK(hipMemcpy(h->work_tp, work_tp.data(), work_tp.size() * sizeof(NbrWorkTp), hipMemcpyHostToDevice));
@@ -3640,9 +3785,10 @@ void run_columns(ps_pixelcnn *h, const StepCtx *rec, int ncols, const int32_t *c
         }
         return;
     }
+    const size_t nbr_half_col = (size_t)NST * 2 * COL_CAP * NBR_LD, cnt_half_col = cnt_index(NST, 0);
     for (int done = 0; done < ncols; done += h->col_cap) {
         const int n = std::min(h->col_cap, ncols - done);
-        const int tiles = (n + 15) / 16, nitems = h->nwork * tiles;
+        const int tiles = (n + 15) / 16;
         // chain workgroups on XCDs 0 .. cx-1 of the first rows of 8 blocks, neighbour workgroups everywhere else, 256
         // blocks at most (one per CU, all resident)
         // (the launch holds one workgroup per CU at most: every workgroup is resident, which the in-launch waits rest on;
@@ -3651,15 +3797,53 @@ void run_columns(ps_pixelcnn *h, const StepCtx *rec, int ncols, const int32_t *c
         const int cx = h->chain_xcds > 0 ? std::min(8, std::max(h->chain_xcds, (n + per_xcd - 1) / per_xcd)) : std::min(4, (n + per_xcd - 1) / per_xcd);
         const int chain_rows = (n + cx - 1) / cx;
         const int nbr_cus = chain_rows * (8 - cx) + (per_xcd - chain_rows) * 8;
+        // the look-ahead, from one latency-form launch to the next (as in the throughput form above): was this launch prepared, and
+        // what follows it -- the rest of an oversized wavefront or the caller's next wavefront, if that takes this form too
+        const bool prepared = h->col_ahead > 0 && h->col_ahead_rec == rec + done && h->col_ahead_n == n;
+        const int par = prepared ? h->col_ahead_parity : 0;
+        const StepCtx *nrec = nullptr;
+        int nn = 0;
+        if (done + h->col_cap < ncols) { nrec = rec + done + h->col_cap; nn = std::min(h->col_cap, ncols - done - h->col_cap); }
+        else if (next_rec && next_ncols > 0 && next_ncols < h->tp_min_cols) { nrec = next_rec; nn = std::min(h->col_cap, next_ncols); }
+        const bool ahead = h->col_ahead > 0 && nrec != nullptr && !(ca.debug & 2);
+        bool la = prepared || ahead;
+        for (int t = 0; t < tiles && !la; ++t)   // (k_column keeps ONE use count per tile for all stages: should a prepared launch
+            la = h->col_uses_lo[0][t] != h->col_uses_hi[0][t];   // ever not have followed, the two-count form takes over)
+        static const int col_exp = getenv("PS_COL_AHEAD_EXP") ? atoi(getenv("PS_COL_AHEAD_EXP")) : 0;   // timing experiments (results invalid)
+        // 2: the columns publish, nobody looks ahead; 3: look-ahead items, nobody publishes or waits
+        const int w_from = prepared && col_exp != 2 ? h->col_wsplit : 0, w_upto = ahead && col_exp != 2 ? h->col_wsplit : 0;
+        const int tiles_next = ahead ? (nn + 15) / 16 : 1;
+        const int nitems = (h->nwork - w_from) * tiles + w_upto * tiles_next;
         const int groups = h->force_groups ? h->force_groups : (nitems > 2 * nbr_cus ? 4 : 2);
         const int nbr_wgs = std::min(nbr_cus, (nitems + groups - 1) / groups);
-        NbrArgs na{h->work, rec + done, h->nbr, h->nwork, h->H, h->W, h->L, n, COL_CAP, tiles, cx, h->cnt, nbr_wgs, groups, ca.debug, h->err};
+        NbrArgs na{h->work, rec + done, h->nbr + par * nbr_half_col, h->nwork, h->H, h->W, h->L, n, COL_CAP, tiles, cx,
+                   h->cnt + par * cnt_half_col, nbr_wgs, groups, ca.debug, h->err};
+        na.w_from = w_from; na.w_upto = w_upto;
+        na.ctx_next = ahead ? nrec : rec + done; na.ncols_next = ahead ? nn : 0; na.tiles_next = tiles_next;
+        na.nbr_next = h->nbr + (par ^ 1) * nbr_half_col; na.cnt_next = h->cnt + (par ^ 1) * cnt_half_col;
+        na.done = h->done_col; na.split = std::max(1, h->col_ahead);
+        if (ahead) h->done_col_total += (unsigned)n;   // (every column publishes once per stage)
+        na.done_target = col_exp == 3 ? 0u : h->done_col_total;
         ca.ctx = rec + done; ca.ncols = n;
-        for (int t = 0; t < tiles; ++t) h->tile_uses[t] += 1;
-        for (int t = 0; t < MAX_TILES; ++t) ca.tile_uses[t] = h->tile_uses[t];
+        ca.nbr = na.nbr; ca.cnt = na.cnt;
         const int in_chain_rows = chain_rows * (8 - cx);
         const int rows = nbr_wgs <= in_chain_rows ? chain_rows : chain_rows + (nbr_wgs - in_chain_rows + 7) / 8;
-        timed(h, st, TAG_CHAIN, [&]() { hipLaunchKernelGGL(k_column, dim3(rows * 8), dim3(C1_THREADS), 0, st, na, ca); });
+        if (la) {
+            for (int t = 0; t < tiles; ++t) {
+                if (!prepared) h->col_uses_lo[par][t] += 1;
+                h->col_uses_hi[par][t] += 1;
+            }
+            for (int t = 0; t < MAX_TILES; ++t) { ca.uses_lo[t] = h->col_uses_lo[par][t]; ca.uses_hi[t] = h->col_uses_hi[par][t]; }
+            if (ahead) for (int t = 0; t < tiles_next; ++t) h->col_uses_lo[par ^ 1][t] += 1;
+            ca.la_split = h->col_ahead; ca.done = h->done_col; ca.publish_upto = ahead && col_exp != 3 ? h->col_ahead : 0;
+            h->col_ahead_rec = ahead ? nrec : nullptr; h->col_ahead_n = nn; h->col_ahead_parity = par ^ 1;
+            timed(h, st, TAG_CHAIN, [&]() { hipLaunchKernelGGL(k_column_la, dim3(rows * 8), dim3(C1_THREADS), 0, st, na, ca); });
+        } else {   // a launch nobody prepared and that prepares nobody (a walk position by position): one set of use counts for all stages
+            h->col_ahead_rec = nullptr;
+            for (int t = 0; t < tiles; ++t) { h->col_uses_lo[0][t] += 1; h->col_uses_hi[0][t] += 1; }
+            for (int t = 0; t < MAX_TILES; ++t) ca.tile_uses[t] = h->col_uses_hi[0][t];
+            timed(h, st, TAG_CHAIN, [&]() { hipLaunchKernelGGL(k_column, dim3(rows * 8), dim3(C1_THREADS), 0, st, na, ca); });
+        }
     }
 }
 
@@ -3722,6 +3906,7 @@ int ps_pixelcnn_create(const float *const *params, int n_params, int H, int W, i
     if (const char *cc = getenv("PS_TP_XCDS")) h->tp_xcds = atoi(cc);
     if (const char *cc = getenv("PS_TP_FILL")) h->tp_fill = atoi(cc);
     if (const char *cc = getenv("PS_TP_AHEAD")) h->tp_ahead = std::min(NST - 1, std::max(0, atoi(cc)));
+    if (const char *cc = getenv("PS_COL_AHEAD")) h->col_ahead = std::min(NST - 4, std::max(0, atoi(cc)));
 #if PS_TP_CHAIN2
     h->tp_ahead = 0;
 #endif
@@ -3788,7 +3973,12 @@ int ps_pixelcnn_create(const float *const *params, int n_params, int H, int W, i
     if (locs * NCLS > pfloats) pfloats = locs * NCLS;
     if ((rc = dev_alloc(h, &h->partial, pfloats))) return fail_out(rc);
     if ((rc = dev_alloc(h, &h->col_logits, (size_t)max_frames * NCLS))) return fail_out(rc);
-    if ((rc = dev_alloc(h, &h->nbr, (size_t)NST * 2 * COL_CAP * NBR_LD))) return fail_out(rc);
+    if ((rc = dev_alloc(h, &h->nbr, (size_t)2 * NST * 2 * COL_CAP * NBR_LD))) return fail_out(rc);
+    if ((rc = dev_alloc(h, &h->done_col, (size_t)NST * CNT_PAD))) return fail_out(rc);
+    if (hipMemset(h->done_col, 0, (size_t)NST * CNT_PAD * sizeof(unsigned)) != hipSuccess) {
+        ps::fail(PS_ERR_HIP, "pixelcnn_create: hipMemset failed");
+        return fail_out(PS_ERR_HIP);
+    }
     if ((rc = dev_alloc(h, &h->ctx, locs))) return fail_out(rc);
     if ((rc = dev_alloc(h, &h->pstart, (size_t)N_EVAL * max_frames))) return fail_out(rc);
     if ((rc = dev_alloc(h, &h->taps, locs))) return fail_out(rc);
@@ -3800,9 +3990,9 @@ int ps_pixelcnn_create(const float *const *params, int n_params, int H, int W, i
         ps::fail(PS_ERR_HIP, "pixelcnn_create: hipMemset failed");
         return fail_out(PS_ERR_HIP);
     }
-    if ((rc = dev_alloc(h, &h->cnt, cnt_index(NST, 0)))) return fail_out(rc);
+    if ((rc = dev_alloc(h, &h->cnt, 2 * cnt_index(NST, 0)))) return fail_out(rc);
     if ((rc = dev_alloc(h, &h->err, 1))) return fail_out(rc);
-    if (hipMemset(h->cnt, 0, cnt_index(NST, 0) * sizeof(unsigned)) != hipSuccess || hipMemset(h->err, 0, sizeof(int)) != hipSuccess) {
+    if (hipMemset(h->cnt, 0, 2 * cnt_index(NST, 0) * sizeof(unsigned)) != hipSuccess || hipMemset(h->err, 0, sizeof(int)) != hipSuccess) {
         ps::fail(PS_ERR_HIP, "pixelcnn_create: hipMemset failed");
         return fail_out(PS_ERR_HIP);
     }
@@ -4018,6 +4208,7 @@ void *ps_pixelcnn_debug_cache(ps_pixelcnn *h, int what, int idx)
     if (what == 0 && idx >= 0 && idx < NNODE) return h->R[idx];
     if (what == 1 && idx >= 0 && idx < NNODE) return h->E[idx];
     if (what == 2 && idx >= 0 && idx < NGATED) return h->X[idx];
+    if (what == 8) return h->done_col; // tuning: the latency form's `done` counters [NST][CNT_PAD] (dword 1 of a row: look-ahead waits that had to wait)
     if (what == 3) return h->nbr_tp;   // neighbour slots of the last throughput launch [NST][2][1024][160]
     if (what == 5) return h->pstart;   // (33, F) int32 of the last AR run's prefix pass: first rank evaluated per stage and frame
 #ifdef PS_WG_TRACE_BUILD

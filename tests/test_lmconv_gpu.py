@@ -558,6 +558,43 @@ def test_throughput_form_look_ahead_depths_are_bit_identical_to_the_walk(ahead, 
             assert torch.equal(l_walk, l_wave), (F_, first, cap, rep)
 
 
+@pytest.mark.parametrize("ahead", ["0", "5", "28"])
+def test_latency_form_look_ahead_depths_are_bit_identical_to_the_walk(ahead, monkeypatch):
+    """The same look-ahead in the latency form (k_column_la: the four-wave items of nbr_role for the NEXT launch's columns behind this
+    launch's chain workgroups, which publish their stores through the store / control waves): depths other than the default,
+    launches of 1 .. 128 columns, oversized wavefronts split by the launcher, a run repeated on the same handle, and a walk
+    position by position (k_column, one use count for all stages) on that handle in between."""
+    from pixelsynth_amd.lmconv.model import wavefronts
+    monkeypatch.setenv("PS_COL_AHEAD", ahead)
+    net = make_net(3)
+    for F_, first, cap in [(5, 320, 128), (20, 700, 16), (40, 900, 0)]:
+        eng = net.engine(32, 32, F_, slot=200 + int(ahead))     # a handle of its own: the depth is read when it is created
+        bgs = syn.background_masks(256)
+        names = ["right_half", "half_plus_island", "ragged", "all", "top_band"]
+        infos = [c_oracle.masks_for_background(bgs[names[b % 5]], 32) for b in range(F_)]
+        order_loc = np.stack([(i["order"][:, 0] * 32 + i["order"][:, 1]) for i in infos]).astype(np.int32)
+        reg = np.zeros((F_, 1024), np.uint8)
+        rs = np.random.RandomState(F_)
+        for b in range(F_):
+            walked = order_loc[b][first:]
+            reg[b, walked[rs.rand(walked.size) < 0.8]] = 1
+            reg[b, order_loc[b][first]] = 1
+        ms = [tt(np.concatenate([i[k] for i in infos])) for k in ("mask_init", "mask_undilated", "mask_dilated")]
+        codes0 = syn.codes(13, F_).reshape(F_, 1024).astype(np.int32)
+        u = tt(np.random.RandomState(8).rand(F_, 1024).astype(np.float32))
+        waves = wavefronts(order_loc, 32, 32, first, DEV, max_cols=cap)
+        outs = []
+        for kind in ("waves", "walk", "waves"):
+            c = tt(codes0.copy())
+            lg = eng.ar_run(c, tt(order_loc), tt(reg), *ms, temperature=0.7, uniforms=u, first_step=first, want_logits=True,
+                            waves=waves if kind == "waves" else None)
+            eng.check()
+            outs.append((c, lg))
+        for c, lg in outs[1:]:
+            assert torch.equal(outs[0][0], c), (F_, first, cap)
+            assert torch.equal(outs[0][1], lg), (F_, first, cap)
+
+
 def test_ar_run_waves_rejects_a_schedule_of_another_run():
     """The host checks the schedule's shape (column count, monotone wave_start); entries that name frames / positions
     outside the run are caught on the device and reported by check(), without touching memory out of bounds."""

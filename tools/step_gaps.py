@@ -9,11 +9,12 @@ for r in rows:
     r["s"], r["e"] = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
     r["n"] = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:30]
 rows.sort(key=lambda r: r["s"])
-mainq = max(set(r["Queue_Id"] for r in rows), key=lambda q: sum(1 for r in rows if r["Queue_Id"] == q and "k_column_tp" in r["n"]))
+mainq = max(set(r["Queue_Id"] for r in rows), key=lambda q: sum(1 for r in rows if r["Queue_Id"] == q and r["n"].startswith("k_column")))
 main = [r for r in rows if r["Queue_Id"] == mainq]
 # a step starts with its k_mask_codes (ar_run's first kernel)
 starts = [i for i, r in enumerate(main) if r["n"].startswith("k_mask_codes")]
-for a, b in zip(starts[4:7], starts[5:8]):
+mid = max(1, min(4, len(starts) - 4))   # (the last AR runs of a bench run are the roofline timing runs: no splat beside them)
+for a, b in zip(starts[mid:mid + 3], starts[mid + 1:mid + 4]):
     seg = main[a:b]
     t0, t1 = seg[0]["s"], main[b]["s"]
     busy = defaultdict(lambda: [0, 0])
