@@ -2207,7 +2207,7 @@ struct TpArgs {
 // only reads of a row that is not finished were the dummy reads of closed taps (row 0) -- a closed lane now reads a row some
 // other lane of the wave gathers anyway.
 #ifndef PS_TP_POLL_SLEEP
-#define PS_TP_POLL_SLEEP 8
+#define PS_TP_POLL_SLEEP 100
 #endif
 template <int T, int NG, bool AHEAD>
 __device__ __forceinline__ void nbr_item_tp(const NbrWorkTp &wk, const TpArgs &a, int ctile, int lane)
@@ -2285,6 +2285,10 @@ __device__ __forceinline__ void nbr_role_tp(const TpArgs &a, int nb)
     const int gw = a.nbr_map ? wave * a.nbr_wgs + nb : nb * TP_WAVES + wave, nw = a.nbr_wgs * TP_WAVES;
     const int n_own = (a.nwork - a.w_from) * a.tiles;
     const int nitems = n_own + a.w_upto * a.tiles_next;
+    __shared__ unsigned sReadyTp;   // look-ahead stages some wave of this workgroup has seen published, + 1
+    if (threadIdx.x == 0) sReadyTp = 0;
+    __syncthreads();
+    int ready_upto = -1;
     for (int item = gw; item < nitems; item += nw) {
         const bool ahead = item >= n_own;
         int witem, ctile;
@@ -2304,14 +2308,30 @@ __device__ __forceinline__ void nbr_role_tp(const TpArgs &a, int nb)
             r[0] = p[0]; r[1] = p[1]; r[2] = p[2];
             __builtin_memcpy(&wk, r, sizeof(wk));
         }
-        if (ahead) {   // the chain tiles of this launch have stored the input of the item's stage (bounded wait; normally long past)
-            const unsigned *dp = a.done + (size_t)wk.stage * CNT_PAD;
-            unsigned have = __hip_atomic_load(dp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            int spins = 0;
-            while ((int)(have - a.done_target) < 0) {
-                if (++spins > WAIT_SPINS) { if (lane == 0) *a.err = 1; break; }
-                __builtin_amdgcn_s_sleep(PS_TP_POLL_SLEEP);
-                have = __hip_atomic_load(dp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ahead) {
+            // The chain tiles of this launch must have stored the input of the item's stage (`done`; bounded wait, normally long
+            // past).  What a wave learns it leaves in LDS for the others of its workgroup, it looks at the LAST look-ahead stage's
+            // counter first (that settles the rest of the launch), and it polls slowly: every wave polling every 0.2 us hammers the
+            // counters' lines, which the chain tiles' publishing atomics and device-scope loads then queue behind (k_column_la).
+            if (wk.stage > ready_upto) {
+                unsigned val = __hip_atomic_load(&sReadyTp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (val < (unsigned)wk.stage + 1u) {
+                    const unsigned *dl = a.done + (size_t)(a.split - 1) * CNT_PAD;
+                    if ((int)(__hip_atomic_load(dl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.done_target) >= 0) {
+                        val = (unsigned)a.split;
+                    } else {
+                        const unsigned *dp = a.done + (size_t)wk.stage * CNT_PAD;
+                        int spins = 0;
+                        while ((int)(__hip_atomic_load(dp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.done_target) < 0 &&
+                               __hip_atomic_load(&sReadyTp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (unsigned)wk.stage + 1u) {
+                            if (++spins > (WAIT_SPINS >> 4)) { if (lane == 0) *a.err = 1; break; }
+                            __builtin_amdgcn_s_sleep(PS_TP_POLL_SLEEP);
+                        }
+                        val = (unsigned)wk.stage + 1u;
+                    }
+                    if (lane == 0) __hip_atomic_fetch_max(&sReadyTp, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                ready_upto = (int)val - 1;
             }
             asm volatile("" ::: "memory");
             if (wk.T == 2) {
