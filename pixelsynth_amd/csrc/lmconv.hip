@@ -3341,7 +3341,8 @@ struct ps_pixelcnn {
     unsigned long long *tp_trace = nullptr;   // tuning builds: stamps of the last k_column_tp launch (ps_pixelcnn_debug_cache what 4)
     int n_cus = 256;                // compute units of the device: workgroups of a column launch that are resident together
     bool xcd_even = true;           // n_cus is an even share of the 8 XCDs of a whole MI355X (block b runs on XCD b % 8)
-    int tp_min_cols = COL_CAP + 1;  // PS_TP_MIN_COLS: tuning
+    int tp_min_cols = 2 * COL_CAP + 1;  // PS_TP_MIN_COLS: a wavefront of up to 256 columns is two latency-form launches (2 x 48 us) rather than one
+                                        // throughput-form launch (130 us whatever its width); measured crossover 257 .. 385 columns
     int tp_xcds = -1;               // PS_TP_XCDS: 0 = chain tiles anywhere, -1 = on as few XCDs as hold them, n = on at least n XCDs
     int tp_fill = 0;                // PS_TP_FILL: neighbour workgroups on the spare CUs of the chain XCDs (off since the neighbour role
                                     // works a launch ahead: it has time to spare, and the chain tiles are faster with their XCDs' L2 to themselves)
