@@ -231,7 +231,7 @@ def latest_pmc_record(V):
     return None
 
 
-def small_batch_config(device, V, cameras, steps=5, total=None, trajectory="sweep"):
+def small_batch_config(device, V, cameras, steps=20, total=None, trajectory="sweep"):
     """frames/s and the column launch's roofline numbers of a smaller batch (pipelined steps like the headline).
     total: the batch is rank 0's share of a job of `total` views over total / V ranks (the 8-GPU forms of C4 / C5)."""
     model = build_model(device)
@@ -240,7 +240,7 @@ def small_batch_config(device, V, cameras, steps=5, total=None, trajectory="swee
     else:
         d, _ = make_inputs(0, total, device, cameras=cameras, trajectory=trajectory, ids=D.shard_views(total, 0, total // V))
     side = torch.cuda.Stream()
-    out = run_steps(model, d, 1, 2, side)
+    out = run_steps(model, d, 1, 3, side)      # (a 6 ms step is close to what the host needs to plan and enqueue one: short runs scatter)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     out = run_steps(model, d, 1, steps, side)
