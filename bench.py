@@ -195,7 +195,9 @@ def measure_roofline(model, d, out, V):
         traffic, traffic_src, mfma_util = pmc.get("traffic_bytes_per_launch"), pmc.get("source"), pmc.get("mfma")
     tp = cols_per_launch > 128
     kernel = ("k_column_tp (throughput form of the column launch, one launch per wavefront of up to 1024 independent AR columns: "
-              "16-column MFMA chain tiles + one wave per neighbour item)" if tp else
+              "16-column MFMA chain tiles + one wave per neighbour item, the neighbour role a launch ahead of the chain tiles; "
+              "wavefronts of up to 256 columns as two launches of the latency form k_column_la -- the average is over all "
+              "column launches of the AR run)" if tp else
               "k_column (one launch per wavefront of independent AR columns: per-column centre-tap chains + "
               "neighbour-tap slots of all 32 masked convs)")
     return {"bound": "mfma", "kernel": kernel,
