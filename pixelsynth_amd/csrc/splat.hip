@@ -377,6 +377,23 @@ constexpr int CG = 4;  // channels accumulated per wave; grid.z walks channel gr
 #ifndef PS_COMPOSITE_WAVES
 #define PS_COMPOSITE_WAVES 8
 #endif
+#ifndef PS_COMPOSITE_PK
+#define PS_COMPOSITE_PK 1
+#endif
+
+// Correctly rounded square root of d in [1e-3, 1] (the clamped dist^2 / r^2 of a hit): the hardware's 1-ulp v_sqrt_f32 and the check of
+// its two neighbours that sqrtf itself expands to -- without sqrtf's rescaling of inputs below 2^-96 and its pass-through of 0 / inf,
+// 7 of its 16 instructions, in a loop body of ~46.  Equal to sqrtf bit for bit on the whole range (tools/sqrt_probe.hip checks
+// every float in [2^-20, 2]).
+__device__ __forceinline__ float sqrt_rn_unit(float x)
+{
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float sm = __uint_as_float(__float_as_uint(s) - 1u), sp = __uint_as_float(__float_as_uint(s) + 1u);
+    const float em = __builtin_fmaf(-sm, s, x), ep = __builtin_fmaf(-sp, s, x);
+    float r = em <= 0.0f ? sm : s;
+    r = ep > 0.0f ? sp : r;
+    return r;
+}
 
 __device__ __forceinline__ float bcast(float v, int lane)
 {
@@ -408,7 +425,11 @@ __global__ __launch_bounds__(64) void k_composite(
     // 96 / 103 registers at five / four waves per SIMD 417 / 435 us; the hit mask as two 32-bit words: 405 us.  The walk is not
     // short of independent instructions; what it pays for is the LDS itself (about 900 LDS instructions per tile, half of them
     // the broadcast reads of the test phase) at eight waves per SIMD.
-    __shared__ float sx[64], sy[64], sz[64], sf[CG][64];
+    // What did pay (second half of round 3; 32 frames: 432 -> 362 us): the kernel is bound by vector-ALU ISSUE (the eight waves of a SIMD
+    // together execute 2.5 instructions' worth per instruction slot), so instruction count is the lever -- the test phase two records
+    // per packed instruction with the hit mask built by a carry chain (10 -> 5.5 instructions per record), and the square root of a hit
+    // without sqrtf's handling of ranges its argument cannot be in (16 -> 9 instructions of the walk's ~46 per hit).
+    __shared__ __attribute__((aligned(8))) float sx[64], sy[64], sz[64], sf[CG][64];
     __shared__ uint32_t sn[64];
     const int tile = blockIdx.x, b = blockIdx.y, c0 = blockIdx.z * CG;
     const int lane = threadIdx.x;
@@ -462,6 +483,36 @@ __global__ __launch_bounds__(64) void k_composite(
             // phase 1: hit bits
             uint64_t hits = 0;
             if (valid && cnt < K) {
+#if PS_COMPOSITE_PK
+                // Two records per packed instruction (v_pk_add / v_pk_mul: the same IEEE operations, two at a time), and the mask
+                // built by the carry chain: v_cmp writes vcc, v_addc computes h + h + vcc = (h << 1) | hit -- one instruction per
+                // record instead of select + shift + or.  Records go in descending order, so record j ends up at bit j of its
+                // 32-bit word; a block of 16 with no record in it (wave-uniform) is sixteen zero bits.
+                const int nrec = (int)min(64u, end - base);
+                typedef float pk2 __attribute__((ext_vector_type(2)));
+                const pk2 xf2 = {xf, xf}, yf2 = {yf, yf};
+                const float r2v = r2;
+                uint32_t hw[2] = {0u, 0u};
+#pragma unroll
+                for (int blk = 3; blk >= 0; --blk) {
+                    uint32_t h = hw[blk >> 1];
+                    if (blk * 16 < nrec) {
+#pragma unroll
+                        for (int jj = 14; jj >= 0; jj -= 2) {
+                            const int j = blk * 16 + jj;                       // records j + 1, then j
+                            const pk2 xs = *(const pk2 *)&sx[j], ys = *(const pk2 *)&sy[j];
+                            const pk2 dx = xs - xf2, dy = ys - yf2;
+                            const pk2 d2 = dx * dx + dy * dy;
+                            asm("v_cmp_lt_f32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(h) : "v"(d2.y), "v"(r2v) : "vcc");
+                            asm("v_cmp_lt_f32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(h) : "v"(d2.x), "v"(r2v) : "vcc");
+                        }
+                    } else {
+                        h <<= 16;
+                    }
+                    hw[blk >> 1] = h;
+                }
+                hits = ((uint64_t)hw[1] << 32) | hw[0];
+#else
                 const int nrec = (int)min(64u, end - base);   // (wave-uniform) records staged in this batch, in blocks of 16
                 for (int j0 = 0; j0 < nrec; j0 += 16) {
 #pragma unroll
@@ -472,6 +523,7 @@ __global__ __launch_bounds__(64) void k_composite(
                         hits |= (uint64_t)(d2 < r2) << j;
                     }
                 }
+#endif
             }
             // phase 2: this pixel's hits, front to back
             while (hits && cnt < K) {
@@ -485,7 +537,7 @@ __global__ __launch_bounds__(64) void k_composite(
                 const float d2 = dx * dx + dy * dy;
                 float d = RECIP ? d2 * denom : d2 / denom;
                 d = fminf(fmaxf(d, 1e-3f), 1.0f);
-                float a = 1.0f - sqrtf(d);
+                float a = 1.0f - sqrt_rn_unit(d);
                 if (tau != 1.0f) a = powf(a, tau);
                 if (MODE == PS_ACC_WSUMNORM && pass == 0) {
                     tsum = tsum + a;
