@@ -330,12 +330,87 @@ __device__ __forceinline__ void bitonic_sort(Ptr a, int n)
     }
 }
 
-// one wave per tile (grid: tiles x frames); lists longer than SORT_SMALL_CAP are queued for k_sort_big
+// one wave per tile (grid: tiles x frames); lists longer than SORT_SMALL_CAP are queued for k_sort_big.
+// The keys live in REGISTERS, KPL per lane (element e = lane * KPL + r), padded with +inf: the comparators of a bitonic network at
+// distance j < KPL are compare-exchanges between two registers of a lane, the others an exchange with lane ^ (j / KPL) -- two
+// cross-lane moves, a 64-bit compare and two selects per key and step, no address arithmetic, no loop: about a third of the
+// instructions of the same network run through LDS (round 2: one wave, indices and bounds computed per comparator).  Keys are unique,
+// so the result is THE sorted list whatever the network.
+// lane ^ M's value: a DPP quad permutation for M = 1, 2 (no LDS instruction at all), ds_swizzle's xor mode inside 32 lanes for
+// M = 4, 8, 16 (no address register), ds_bpermute for 32
+template <int M>
+__device__ __forceinline__ uint32_t xor_lane32(uint32_t v)
+{
+    if (M == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);        // quad_perm [1,0,3,2]
+    else if (M == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+    else if (M < 32) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, (M << 10) | 0x1F);          // bit-mask mode: and 0x1f, or 0, xor M
+    else return (uint32_t)__shfl_xor((int)v, M, 64);
+}
+template <int M>
+__device__ __forceinline__ uint64_t shfl_xor64(uint64_t v)
+{
+    return ((uint64_t)xor_lane32<M>((uint32_t)(v >> 32)) << 32) | xor_lane32<M>((uint32_t)v);
+}
+template <int KPL>
+__device__ __forceinline__ void wave_sort(uint64_t (&v)[KPL], int lane)
+{
+    constexpr int N = 64 * KPL;
+#pragma unroll
+    for (int k = 2; k <= N; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j >= 1; j >>= 1) {
+            if (j < KPL) {
+#pragma unroll
+                for (int r = 0; r < KPL; ++r) {
+                    const int p = r ^ j;
+                    if (p < r) continue;
+                    const bool up = ((lane * KPL + r) & k) == 0;      // ascending block?  (bit k is the same for r and p: k > j)
+                    const bool sw = (v[r] > v[p]) == up;
+                    const uint64_t a = sw ? v[p] : v[r], b = sw ? v[r] : v[p];
+                    v[r] = a; v[p] = b;
+                }
+            } else {
+                constexpr int lj_max = 32;
+                const int lj = j / KPL;
+                const bool lower = (lane & lj) == 0;
+#pragma unroll
+                for (int r = 0; r < KPL; ++r) {
+                    uint64_t o;
+                    switch (lj) {   // (compile-time: the loops are unrolled)
+                    case 1: o = shfl_xor64<1>(v[r]); break;
+                    case 2: o = shfl_xor64<2>(v[r]); break;
+                    case 4: o = shfl_xor64<4>(v[r]); break;
+                    case 8: o = shfl_xor64<8>(v[r]); break;
+                    case 16: o = shfl_xor64<16>(v[r]); break;
+                    default: o = shfl_xor64<lj_max>(v[r]); break;
+                    }
+                    const bool up = ((lane * KPL + r) & k) == 0;
+                    v[r] = ((v[r] < o) == (lower == up)) ? v[r] : o;   // the lower lane of an ascending pair keeps the smaller key
+                }
+            }
+        }
+    }
+}
+template <int KPL>
+__device__ __forceinline__ void sort_tile_regs(uint64_t *__restrict__ keys, uint32_t n, int lane)
+{
+    uint64_t v[KPL];
+#pragma unroll
+    for (int r = 0; r < KPL; ++r) {
+        const uint32_t e = (uint32_t)lane * KPL + r;
+        v[r] = e < n ? keys[e] : ~0ull;
+    }
+    wave_sort<KPL>(v, lane);
+#pragma unroll
+    for (int r = 0; r < KPL; ++r) {
+        const uint32_t e = (uint32_t)lane * KPL + r;
+        if (e < n) keys[e] = v[r];
+    }
+}
 __global__ __launch_bounds__(64) void k_sort_small(uint64_t *__restrict__ keys,
                                                    const uint32_t *__restrict__ tile_off, int NT,
                                                    uint32_t *__restrict__ worklist)
 {
-    __shared__ uint64_t s[SORT_SMALL_CAP];
     const uint32_t t = blockIdx.y * (NT + 1) + blockIdx.x;  // index into the (B, NT+1) offset table
     const uint32_t beg = tile_off[t], n = tile_off[t + 1] - beg;
     if (n < 2) return;
@@ -343,10 +418,12 @@ __global__ __launch_bounds__(64) void k_sort_small(uint64_t *__restrict__ keys,
         if (threadIdx.x == 0) worklist[1 + atomicAdd(&worklist[0], 1u)] = t;
         return;
     }
-    for (uint32_t i = threadIdx.x; i < n; i += 64) s[i] = keys[beg + i];
-    sort_step_sync<64>();
-    bitonic_sort<64>(s, (int)n);
-    for (uint32_t i = threadIdx.x; i < n; i += 64) keys[beg + i] = s[i];
+    static_assert(SORT_SMALL_CAP == 512, "eight keys per lane at most");
+    const int lane = threadIdx.x;
+    if (n <= 64) sort_tile_regs<1>(keys + beg, n, lane);
+    else if (n <= 128) sort_tile_regs<2>(keys + beg, n, lane);
+    else if (n <= 256) sort_tile_regs<4>(keys + beg, n, lane);
+    else sort_tile_regs<8>(keys + beg, n, lane);
 }
 
 __global__ __launch_bounds__(1024) void k_sort_big(uint64_t *__restrict__ keys,

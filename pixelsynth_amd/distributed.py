@@ -10,6 +10,33 @@ import torch
 import torch.distributed as dist
 
 
+import contextlib
+import os
+
+
+@contextlib.contextmanager
+def shared_device_turn():
+    """Column launches keep one workgroup per compute unit resident and wait, inside the launch, for each other (chain workgroups
+    for neighbour slots, the look-ahead items of the neighbour role for the chains' published stores).  That is safe for ONE
+    column-launching process per GPU -- the deployment: one process per GPU -- next to kernels that never wait (splat, GEMMs, other
+    frameworks' kernels).  Two processes whose column launches meet on the same GPU can hold each other's compute units until the
+    bounded waits give up (ps_pixelcnn_status then reports it).  The only place ranks share a GPU here is the single-GPU dry run of
+    the multi-rank control flow (PS_DRYRUN_ONE_GPU=1, tests): there the ranks take turns -- a file lock around the AR run, released
+    when the device is idle again."""
+    if os.environ.get("PS_DRYRUN_ONE_GPU") != "1" and os.environ.get("PS_BENCH_DRYRUN_ONE_GPU") != "1":
+        yield
+        return
+    import fcntl
+    import tempfile
+    with open(os.path.join(tempfile.gettempdir(), "pixelsynth_dryrun_gpu.lock"), "w") as fh:
+        fcntl.flock(fh, fcntl.LOCK_EX)
+        try:
+            yield
+            torch.cuda.synchronize()
+        finally:
+            fcntl.flock(fh, fcntl.LOCK_UN)
+
+
 def world():
     return (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
 

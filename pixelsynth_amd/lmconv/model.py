@@ -123,16 +123,18 @@ class PixelCNNEngine:
         head = (self.handle, _lib.ptr(codes), _lib.ptr(order), _lib.ptr(region), _lib.ptr(mask_init),
                 _lib.ptr(mask_undilated), _lib.ptr(mask_dilated), _lib.ptr(forced), _lib.ptr(uniforms),
                 float(temperature), F_, int(first_step))
-        if waves is None or waves[0].shape[0] == 0:  # (nothing to walk: only the whole-grid pass runs)
-            rc = _lib.lib().ps_pixelcnn_ar_run(*head, _lib.ptr(out), _lib.current_stream())
-            _lib.check(rc, "ps_pixelcnn_ar_run")
-        else:
-            cols, wave_start = waves
-            _lib.require_cuda(cols)
-            assert cols.dtype == torch.int32 and wave_start.dtype == np.int32
-            rc = _lib.lib().ps_pixelcnn_ar_run_waves(*head, _lib.ptr(cols), _lib.ptr(wave_start), len(wave_start) - 1,
-                                                     _lib.ptr(out), _lib.current_stream())
-            _lib.check(rc, "ps_pixelcnn_ar_run_waves")
+        from ..distributed import shared_device_turn
+        with shared_device_turn():   # (a no-op but in the single-GPU dry run of several ranks)
+            if waves is None or waves[0].shape[0] == 0:  # (nothing to walk: only the whole-grid pass runs)
+                rc = _lib.lib().ps_pixelcnn_ar_run(*head, _lib.ptr(out), _lib.current_stream())
+                _lib.check(rc, "ps_pixelcnn_ar_run")
+            else:
+                cols, wave_start = waves
+                _lib.require_cuda(cols)
+                assert cols.dtype == torch.int32 and wave_start.dtype == np.int32
+                rc = _lib.lib().ps_pixelcnn_ar_run_waves(*head, _lib.ptr(cols), _lib.ptr(wave_start), len(wave_start) - 1,
+                                                         _lib.ptr(out), _lib.current_stream())
+                _lib.check(rc, "ps_pixelcnn_ar_run_waves")
         return out
 
     def _ar_args(self, codes, order, region, mask_init, mask_undilated, mask_dilated):
@@ -162,10 +164,12 @@ class PixelCNNEngine:
         self._frame_arg(F_, "uniforms", uniforms, torch.float32)
         cols, wave_start = waves
         _lib.require_cuda(cols)
-        rc = _lib.lib().ps_pixelcnn_ar_columns(self.handle, _lib.ptr(codes), _lib.ptr(order), _lib.ptr(region), _lib.ptr(mi), _lib.ptr(mu),
-                                               _lib.ptr(md), _lib.ptr(forced), _lib.ptr(uniforms), float(temperature), F_, int(first_step),
-                                               _lib.ptr(cols), _lib.ptr(wave_start), len(wave_start) - 1, _lib.current_stream())
-        _lib.check(rc, "ps_pixelcnn_ar_columns")
+        from ..distributed import shared_device_turn
+        with shared_device_turn():
+            rc = _lib.lib().ps_pixelcnn_ar_columns(self.handle, _lib.ptr(codes), _lib.ptr(order), _lib.ptr(region), _lib.ptr(mi), _lib.ptr(mu),
+                                                   _lib.ptr(md), _lib.ptr(forced), _lib.ptr(uniforms), float(temperature), F_, int(first_step),
+                                                   _lib.ptr(cols), _lib.ptr(wave_start), len(wave_start) - 1, _lib.current_stream())
+            _lib.check(rc, "ps_pixelcnn_ar_columns")
 
     def set_compute_units(self, n_cus):
         """Compute units the stream of this engine's column launches can use (0 = the whole device)."""
