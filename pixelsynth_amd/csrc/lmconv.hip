@@ -2048,9 +2048,13 @@ __device__ __forceinline__ void chain_role(const ChainArgs &a, int wg)
 // Both start together: the chain only needs the neighbour slots of stage s when it reaches the post op of stage s,
 // and by then the neighbour role is normally past that stage (its items are ordered by stage); completion counters
 // per stage (device-scope atomics) and write-through stores carry the hand-off, every wait is bounded.
-// The neighbour workgroups never wait for anything and never share an XCD with the chain workgroups (the other
-// blocks of the chain XCDs exit at once), and a launch holds at most 32 chain workgroups per chain XCD, so waiting
-// chains cannot keep the neighbour role off the chip: the launch cannot deadlock.
+// The neighbour workgroups never share an XCD with the chain workgroups (the other blocks of the chain XCDs exit at once), a
+// launch holds at most 32 chain workgroups per chain XCD, and all workgroups of a launch are resident together (one per CU at
+// most).  On its own items the neighbour role waits for nothing, so waiting chains cannot keep it from finishing; its look-ahead
+// items (k_column_la: the next launch's first stages) wait for the chains' `done` counters, which the chains publish before they
+// can get to waiting for anything that comes after those items in a group's list -- a group publishes its previous item before it
+// waits.  What the design does NOT cover is a second process running column launches on the same GPU (two launches can then hold
+// each other's CUs until the bounded waits give up): one column-launching process per GPU (DESIGN, section 7).
 // ==========================================================================================
 __global__ __launch_bounds__(C1_THREADS) void k_column(NbrArgs na, ChainArgs ca)
 {
@@ -3099,7 +3103,7 @@ __device__ __forceinline__ void chain_role_tp2(const TpArgs &a, int tile)
 }
 #endif
 
-// chain_xcds = 0: blocks [0, nbr_wgs) neighbour role (they never wait for anything), the blocks after them one chain tile each.
+// chain_xcds = 0: blocks [0, nbr_wgs) neighbour role (dispatched first: the chain tiles wait for their items), the blocks after them one chain tile each.
 // chain_xcds = cx > 0 (speed only; block b runs on XCD b % 8): the chain tiles are the blocks on XCDs 0 .. cx-1, whose L2s then
 // hold the 2.8 MB of centre-tap weights instead of sharing their bandwidth with the neighbour role's operand stream; every
 // other block is a neighbour workgroup (the spare CUs of the chain XCDs too when fill is set).
