@@ -3430,7 +3430,7 @@ bool launch_gemm(GemmArgs &a, int item_blocks, hipStream_t st, const PostArgs *p
     if (a.sum_bias && a.zgrid == 1 && shape_ok && item_blocks >= wg_min && a.tiles_per_block == 1) {
         const int kind = a.Co_pad == 2 * NF ? GW_CONVOUT : a.Cin == 2 * NF ? GW_CONVIN : GW_DIL;
         // item tiles per workgroup (tuning: PS_WG_TI = "out,in,dil")
-        int ti_of[3] = {2, 2, 2};
+        int ti_of[3] = {1, 2, 2};   // (conv_out with 16 items per workgroup: 168 registers, three workgroups per CU -- 0.6 % of the 128-view step over {2, 2, 2})
         if (const char *e = getenv("PS_WG_TI")) sscanf(e, "%d,%d,%d", &ti_of[0], &ti_of[1], &ti_of[2]);
         const int TI = ti_of[kind], MI = 16 * TI;
         a.ny = (a.nitems + MI - 1) / MI;
