@@ -106,14 +106,25 @@ def back(model, d, planned, world, columns_on=None):
     out = model.outpaint_planned(planned, d["codes"], temperature=0.7, uniforms=d["uniforms"], columns_on=columns_on)
     if world > 1:  # what the path produced on every rank -- the reprojected views as 8-bit images (the byte volume of finished
         # frames: the VQ-VAE decode that turns codes into pixels is a next-row component, timed under end_to_end_*) and the
-        # completed 32x32 code grids -- RCCL all_gather over xGMI
-        out["all_features_u8"] = D.gather_frames(D.to_image_u8(out["gen_fs"]))
-        out["all_codes"] = D.gather_frames(out["codes"].contiguous())
+        # completed 32x32 code grids -- RCCL all_gather over xGMI.  Started here, collected by finish_gathers() when the NEXT
+        # step has been enqueued: 25 MB per rank and step at 128 views take the ring a couple of ms, which then pass beside the
+        # next step's whole-grid pass instead of in front of it (PS_BENCH_SYNC_GATHER=1: collected at once, as in round 2)
+        out["_gathers"] = (D.gather_frames_start(D.to_image_u8(out["gen_fs"])), D.gather_frames_start(out["codes"].contiguous()))
+        if os.environ.get("PS_BENCH_SYNC_GATHER") == "1":
+            finish_gathers(out)
+    return out
+
+
+def finish_gathers(out):
+    """The step's collectives are through (for the current stream): their results into the step's dict."""
+    g = out.pop("_gathers", None) if out is not None else None
+    if g is not None:
+        out["all_features_u8"], out["all_codes"] = g[0].result(), g[1].result()
     return out
 
 
 def run_step(model, d, world):
-    return back(model, d, front(model, d), world)
+    return finish_gathers(back(model, d, front(model, d), world))
 
 
 def run_steps(model, d, world, n, side):
@@ -135,7 +146,8 @@ def run_steps(model, d, world, n, side):
         # stream any more.
         gate = torch.cuda.Event()
         gate.record(main)
-        out = back(model, d, planned, world)
+        prev, out = out, back(model, d, planned, world)
+        finish_gathers(prev)      # (the previous step's collectives: this step is enqueued behind them now)
         planned = None
         if i + 1 < n:
             if not os.environ.get("PS_BENCH_NO_GATE"):
@@ -144,7 +156,7 @@ def run_steps(model, d, world, n, side):
                 planned = front(model, d)
             model.adopt_planned(planned, main)
             main.wait_stream(side)
-    return out
+    return finish_gathers(out)
 
 
 def run_steps_overlapped(model, d, world, n, runner):

@@ -49,23 +49,49 @@ def shard_views(n_views, rank=None, world_size=None):
     return list(range(rank, n_views, world_size))
 
 
-def gather_frames(local, n_views=None):
-    """all_gather of the finished frames.  local: (V_local, ...) tensor, same V_local on every rank (pad the
-    last round when n_views is not a multiple of the world size).  Returns (W*V_local, ...) ordered by VIEW
-    index when the views were dealt with shard_views (view v sits at row v); trimmed to n_views if given."""
+class PendingGather:
+    """An all_gather of finished frames under way (gather_frames_start); result() waits for it -- on the device, for the current
+    stream, with RCCL -- and puts the rows in view order."""
+
+    def __init__(self, local, n_views, work=None, bufs=None, staged=None):
+        self.local, self.n_views, self.work, self.bufs, self.staged = local, n_views, work, bufs, staged
+
+    def result(self):
+        local = self.local
+        if self.bufs is None:
+            return local if self.n_views is None else local[:self.n_views]
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+        bufs = self.bufs
+        if self.staged.device != local.device:
+            bufs = [b.to(local.device) for b in bufs]
+        stacked = torch.stack(bufs, 1)                      # (V_local, W, ...): row v_local*W + r = view index
+        out = stacked.reshape(-1, *local.shape[1:])
+        return out if self.n_views is None else out[:self.n_views]
+
+
+def gather_frames_start(local, n_views=None):
+    """Start the all_gather of the finished frames and return at once (-> PendingGather): the collective runs on the backend's own
+    stream, behind what the current stream has enqueued so far, and whatever the caller enqueues next -- the following batch's
+    whole-grid pass -- runs beside it.  (Beside COLUMN launches it would gain nothing: a launch wants every compute unit, and
+    waits for the ones the collective's kernels hold.)  local as for gather_frames."""
     rank, w = world()
     if w == 1:
-        return local if n_views is None else local[:n_views]
+        return PendingGather(local, n_views)
     staged = local.contiguous()
     if staged.is_cuda and dist.get_backend() == "gloo":
         staged = staged.cpu()  # gloo has no device all_gather: host staging (tests / single-GPU dry runs only)
     bufs = [torch.empty_like(staged) for _ in range(w)]
-    dist.all_gather(bufs, staged)
-    if staged.device != local.device:
-        bufs = [b.to(local.device) for b in bufs]
-    stacked = torch.stack(bufs, 1)                      # (V_local, W, ...): row v_local*W + r = view index
-    out = stacked.reshape(-1, *local.shape[1:])
-    return out if n_views is None else out[:n_views]
+    work = dist.all_gather(bufs, staged, async_op=True)
+    return PendingGather(local, n_views, work, bufs, staged)
+
+
+def gather_frames(local, n_views=None):
+    """all_gather of the finished frames.  local: (V_local, ...) tensor, same V_local on every rank (pad the
+    last round when n_views is not a multiple of the world size).  Returns (W*V_local, ...) ordered by VIEW
+    index when the views were dealt with shard_views (view v sits at row v); trimmed to n_views if given."""
+    return gather_frames_start(local, n_views).result()
 
 
 def to_image_u8(frames):
