@@ -36,6 +36,10 @@ def _worker(rank, world_size, port, n_views, q):
         D.barrier()
         all_frames = D.gather_frames(frames, n_views)
         all_codes = D.gather_frames(codes, n_views)
+        # the asynchronous form bench.py pipelines (two collectives in flight, collected later, in any order): the same rows
+        pend_f, pend_c = D.gather_frames_start(frames, n_views), D.gather_frames_start(codes, n_views)
+        late_c, late_f = pend_c.result(), pend_f.result()
+        assert torch.equal(late_f, all_frames) and torch.equal(late_c, all_codes)
         ok = all(bool((all_frames[v] == float(v)).all()) and bool((all_codes[v] == v).all()) for v in range(n_views))
         t = D.max_over_ranks(1.0 + rank)
         q.put((rank, mine, ok, tuple(all_frames.shape), t))
