@@ -101,14 +101,20 @@ def front(model, d):
     return model.plan_views(d["img"], d["depth"], d["K"], d["Kinv"], d["P"], d["Pinv"], d["RT2"], d["RT2inv"])
 
 
-def back(model, d, planned, world, columns_on=None):
-    """Second half: the AR run (asynchronous), then the path's only collective."""
-    out = model.outpaint_planned(planned, d["codes"], temperature=0.7, uniforms=d["uniforms"], columns_on=columns_on)
+def back(model, d, planned, world, prev=None):
+    """Second half: the AR run (asynchronous), then the path's only collective.
+    prev: the previous step's result, whose gathers are still in flight: the stream waits for them between this step's prefix
+    pass and its first column launch (see finish_gathers)."""
+    out = model.outpaint_planned(planned, d["codes"], temperature=0.7, uniforms=d["uniforms"],
+                                 between=(lambda: finish_gathers(prev)) if prev is not None and "_gathers" in prev else None)
     if world > 1:  # what the path produced on every rank -- the reprojected views as 8-bit images (the byte volume of finished
         # frames: the VQ-VAE decode that turns codes into pixels is a next-row component, timed under end_to_end_*) and the
-        # completed 32x32 code grids -- RCCL all_gather over xGMI.  Started here, collected by finish_gathers() when the NEXT
-        # step has been enqueued: 25 MB per rank and step at 128 views take the ring a couple of ms, which then pass beside the
-        # next step's whole-grid pass instead of in front of it (PS_BENCH_SYNC_GATHER=1: collected at once, as in round 2)
+        # completed 32x32 code grids -- RCCL all_gather over xGMI.  Started here as asynchronous collectives, collected by
+        # finish_gathers() in the NEXT step, between its whole-grid prefix pass and its first column launch: 25 MB per rank and
+        # step at 128 views take the ring a couple of ms, which then pass beside the prefix pass -- whose small workgroups fit
+        # around the collective's kernels -- and never beside a column launch, which keeps one workgroup per compute unit
+        # resident and would wait for the ones a late peer's collective still holds (round-3 advice).
+        # PS_BENCH_SYNC_GATHER=1: collected at once, in front of the next step.
         out["_gathers"] = (D.gather_frames_start(D.to_image_u8(out["gen_fs"])), D.gather_frames_start(out["codes"].contiguous()))
         if os.environ.get("PS_BENCH_SYNC_GATHER") == "1":
             finish_gathers(out)
@@ -141,13 +147,13 @@ def run_steps(model, d, world, n, side):
         # whole-grid prefix pass starts, i.e. until step i - 1's column launches are through: a column launch keeps one large
         # workgroup per compute unit resident, and the splat's workgroups, let loose beside the column launches, fill the
         # compute units between two launches and hold the next launch up until they retire (under rocprofv3: 194 instead of
-        # 154 us per launch while the splat runs).  The step takes the same 22 ms either way -- the splat's 2.5 ms are paid
+        # 154 us per launch while the splat runs).  The step takes the same time either way -- the splat's 2.5 ms are paid
         # beside the prefix pass or beside the columns -- but no in-launch wait of a column launch is at the mercy of another
         # stream any more.
         gate = torch.cuda.Event()
         gate.record(main)
-        prev, out = out, back(model, d, planned, world)
-        finish_gathers(prev)      # (the previous step's collectives: this step is enqueued behind them now)
+        prev, out = out, back(model, d, planned, world, prev=out)
+        finish_gathers(prev)      # (a step without column launches has not collected them)
         planned = None
         if i + 1 < n:
             if not os.environ.get("PS_BENCH_NO_GATE"):
@@ -157,20 +163,6 @@ def run_steps(model, d, world, n, side):
             model.adopt_planned(planned, main)
             main.wait_stream(side)
     return finish_gathers(out)
-
-
-def run_steps_overlapped(model, d, world, n, runner):
-    """n steps on the two compute-unit partitions of pixelsynth_amd.pipeline.OverlappedOutpainter: the column launches of step i
-    on one, the reprojection / splat / planning and most of the whole-grid prefix pass of step i + 1 on the other.  Same work
-    per step, the steps are independent; results identical to n x run_step (tests/test_bench_gpu.py)."""
-    def after(i, out):
-        if world > 1:
-            out["all_features_u8"] = D.gather_frames(D.to_image_u8(out["gen_fs"]))
-            out["all_codes"] = D.gather_frames(out["codes"].contiguous())
-    batch = dict(img=d["img"], depth=d["depth"], K=d["K"], Kinv=d["Kinv"], P=d["P"], Pinv=d["Pinv"], RT2=d["RT2"], RT2inv=d["RT2inv"],
-                 codes=d["codes"], uniforms=d["uniforms"])
-    outs = runner.run([batch] * n, temperature=0.7, after=after)
-    return outs[-1] if outs else None
 
 
 def measure_roofline(model, d, out, V):
@@ -564,11 +556,6 @@ def main():
     ap.add_argument("--frames", type=int, default=64, help="--trajectory circle: frames of the circle in total")
     ap.add_argument("--cameras", choices=["mp3d", "demo"], default=None, help="Matterport-shaped (C5, default) or demo / RealEstate10K-shaped inputs (default for the circle)")
     ap.add_argument("--depth", choices=["smooth", "uniform"], default="smooth")
-    ap.add_argument("--overlap", action="store_true", help="experiment (measured slower, DESIGN.md section 5): steps pipelined over two compute-unit "
-                    "partitions (pixelsynth_amd/pipeline.py) instead of one stream + a side stream")
-    ap.add_argument("--cus-main", type=int, default=int(os.environ.get("PS_CUS_MAIN", "160")), help="--overlap: compute units of the column launches' partition")
-    ap.add_argument("--prefix-share", type=float, default=float(os.environ.get("PS_PREFIX_SHARE", "0.6")),
-                    help="fraction of a step's frames whose prefix pass runs beside the previous step's column launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the C3 single-view / C2 splat-only side measurements")
     ap.add_argument("--dump-gather", metavar="NPZ", help="rank 0 saves what the last step gathered from all ranks (tests)")
@@ -615,26 +602,13 @@ def main():
         torch.cuda.synchronize()
 
     side = torch.cuda.Stream()
-    # throughput-form batches (the column launches leave a third of the chip idle) are pipelined over two compute-unit
-    # partitions; small batches (latency form) keep round 2's single-stream pipeline
-    from pixelsynth_amd.lmconv.model import TP_MIN_FRAMES
-    overlap = args.overlap and V >= TP_MIN_FRAMES
-    runner = None
-    if overlap:
-        from pixelsynth_amd.pipeline import OverlappedOutpainter
-        runner = OverlappedOutpainter(model, cus_main=args.cus_main, prefix_share=args.prefix_share, device=device)
-        steps_fn = lambda k: run_steps_overlapped(model, d, world, k, runner)
-    else:
-        steps_fn = lambda k: run_steps(model, d, world, k, side)
+    steps_fn = lambda k: run_steps(model, d, world, k, side)
     out = steps_fn(args.warmup) if args.warmup > 0 else None
     barrier()
     t0 = time.perf_counter()
     out = steps_fn(args.steps)
     barrier()
     dt = time.perf_counter() - t0
-    if runner is not None:
-        runner.check()
-        runner.close()
     model.outpaint2.engine(32, 32, V).check()  # (outside the timed region) no column launch gave up on an in-launch wait
     elapsed = D.max_over_ranks(dt, None if dry else device)
 
@@ -665,9 +639,7 @@ def main():
                        "ar_steps_walked": 1024 - plan.first_step,
                        "sampled_codes_per_view_mean": round(float(np.mean(plan.n_sampled)), 1),
                        "parallelism": f"views sharded over {world} GPU(s), RCCL all_gather of the reprojected views (8-bit) + completed code grids",
-                       "step_pipeline": (f"two compute-unit partitions: column launches of step i on {args.cus_main} CUs, splat / plan and "
-                                         f"{args.prefix_share:.0%} of the prefix pass of step i + 1 on the other {256 - args.cus_main}" if overlap else
-                                         "one stream; host half of step i + 1 on an unmasked side stream")},
+                       "step_pipeline": "one stream; host half of step i + 1 on an unmasked side stream"},
         }
         if world == 1:
             try:

@@ -254,16 +254,6 @@ int ps_pixelcnn_set_compute_units(ps_pixelcnn *h, int n_cus);
 int ps_stream_create_cu_range(int first_cu, int n_cus, void **stream);
 int ps_stream_destroy(void *stream);
 
-/* bench.py aid: ps_pixelcnn_ar_run_waves (uniforms, no logits) with a HIP event pair around every column launch on
- * the caller's stream; synchronises.  launches / total_ms: the k_column launches of the run and their summed
- * duration; flops_per_column: dense flops of one column (11.163 MFLOP). */
-int ps_pixelcnn_time_ar_run_waves(ps_pixelcnn *h, int32_t *codes, const int32_t *order,
-                                  const uint8_t *sample_region, const float *mask_init,
-                                  const float *mask_undilated, const float *mask_dilated,
-                                  const float *uniforms, float temperature, int F, int first_step,
-                                  const int32_t *wave_cols, const int32_t *wave_start, int n_waves,
-                                  int *launches, float *total_ms, double *flops_per_column, void *stream);
-
 /* One order position of the loop above for callers that draw the sample themselves (the drop-in
  * sample() keeps torch.multinomial): evaluates the column of location order[f][step] for every
  * image and writes its logits (F,512).  step == first_step additionally (re)builds the caches with
@@ -279,29 +269,6 @@ int ps_pixelcnn_ar_step(ps_pixelcnn *h, const int32_t *codes, const int32_t *ord
  * synchronises `stream` and returns PS_OK, or an error if any launch since the handle's creation hit that
  * limit (its results are then invalid).  Tests, smoke() and bench.py call it after their runs. */
 int ps_pixelcnn_status(ps_pixelcnn *h, void *stream);
-
-/* Debugging aid (tools/tp_debug.py; not part of the reference surface): device address of one of the handle's
- * activation caches -- what 0: raw u of node idx (19 nodes, row stride 96 floats), 1: concat_elu(u) of node idx (160),
- * 2: the activation inside gated resnet idx (14 blocks, 160); rows are frame * L + location; 5: the (33, F) int32 table of
- * the last AR run's prefix pass -- first order rank evaluated per stage and frame (oracle/prefix_cone_oracle.py).  NULL if
- * out of range. */
-void *ps_pixelcnn_debug_cache(ps_pixelcnn *h, int what, int idx);
-
-/* Measurement aid for bench.py (not part of the reference surface): evaluates `reps` order positions
- * eagerly on `stream` (at position `step`, without drawing) with a HIP event pair around every kernel
- * launch and returns the number of launches and their summed duration in ms:
- *   [0] unused (0 launches; the neighbour taps had their own kernel before the single-launch column step)
- *   [1] k_column (one launch per order position here: neighbour-tap slots of all 32 masked convs on MFMA +
- *       the per-frame centre-tap chains, post ops and draw)
- * flops_per_launch / weight_bytes_per_launch [2]: dense algorithmic work of one launch, split as
- *   [0] neighbour taps, [1] centre-tap chain (2*Co*Cin per tap and frame; fp32 weight bytes streamed once,
- *   per frame for [1]).  Synchronises the stream. */
-#define PS_PROF_NTAGS 2
-int ps_pixelcnn_time_column_step(ps_pixelcnn *h, const int32_t *codes, const int32_t *order,
-                                 const float *mask_init, const float *mask_undilated,
-                                 const float *mask_dilated, int F, int step, int reps, int *launches,
-                                 float *total_ms, double *flops_per_launch,
-                                 double *weight_bytes_per_launch, void *stream);
 
 /* Hard z-buffer scatter of DepthManipulator.project_zbuffer (models/projection/depth_manipulator.py:66-104):
  * the reference sorts the points by z and assigns  out[b, 0|1, ys, xs] = v0|v1  for all of them at once; with the sequential

@@ -1,4 +1,5 @@
-"""ctypes binding of libpixelsynth_hip.so (the C ABI declared in include/pixelsynth_hip.h).
+"""ctypes binding of libpixelsynth_hip.so (the C ABI declared in include/pixelsynth_hip.h; the measurement / tuning / debugging
+entry points tests, bench.py and tools use are declared in include/pixelsynth_hip_debug.h).
 
 The product path has NO fallback: if the shared library is missing or a call fails, a RuntimeError
 is raised.  Nothing here (or anywhere under pixelsynth_amd/) imports oracle/.
@@ -47,6 +48,8 @@ _PROTOS = {
     "ps_ar_wavefronts_capped": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "ps_pixelcnn_status": (c_int, [c_void_p, c_void_p]),
     "ps_pixelcnn_debug_cache": (c_void_p, [c_void_p, c_int, c_int]),
+    "ps_pixelcnn_set_tuning": (c_int, [c_void_p, ctypes.c_char_p, c_int]),
+    "ps_pixelcnn_get_tuning": (c_int, [c_void_p, ctypes.c_char_p, c_void_p]),
     "ps_zbuffer_scatter_f32": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p] * 4),
     "ps_zbuffer_project_f32": (c_int, [c_void_p] * 6 + [c_int, c_int] + [c_void_p] * 5),
     "ps_zbuffer_scatter_sorted_f32": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_void_p] * 4),
@@ -62,7 +65,7 @@ _PROTOS = {
 
 
 def exported_symbols():
-    """Names every entry point include/pixelsynth_hip.h declares (used by the CPU load test)."""
+    """Names every entry point include/pixelsynth_hip.h and include/pixelsynth_hip_debug.h declare (used by the CPU load test)."""
     return sorted(_PROTOS)
 
 
@@ -123,8 +126,11 @@ def status_word(device=None):
 
 
 def read_status(what, device=None):
-    """Synchronise the current stream and raise if an asynchronous call raised a bit in the device's status word."""
-    check(lib().ps_read_status(ptr(status_word(device)), current_stream()), what)
+    """Synchronise the current stream OF THE STATUS WORD'S DEVICE and raise if an asynchronous call raised a bit in it."""
+    import torch
+    word = status_word(device)
+    with torch.cuda.device(word.device):
+        check(lib().ps_read_status(ptr(word), ctypes.c_void_p(torch.cuda.current_stream(word.device).cuda_stream)), what)
 
 
 def require_cuda(*tensors):

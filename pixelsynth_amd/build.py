@@ -3,7 +3,7 @@
     python -m pixelsynth_amd.build [--force]
 
 One object per translation unit, linked into pixelsynth_amd/libpixelsynth_hip.so.  Both HIP units are built
-with -ffp-contract=off: splat.hip because its index paths must be bit-exact against the oracle, lmconv.hip so
+with -ffp-contract=off: splat.hip because its index paths must be bit-exact against the oracle, the lmconv*.hip units so
 that the post ops inlined into different kernels (whole-grid vs column step) round identically; the matrix
 products are explicit MFMA intrinsics and are not affected.
 """
@@ -20,17 +20,21 @@ ARCH = "gfx950"
 UNITS = [
     ("splat.hip", ["-ffp-contract=off"]),
     ("lmconv.hip", ["-ffp-contract=off"]),
+    ("lmconv_grid.hip", ["-ffp-contract=off"]),
+    ("lmconv_column.hip", ["-ffp-contract=off"]),
+    ("lmconv_tp.hip", ["-ffp-contract=off"]),
     ("vq.hip", ["-ffp-contract=off"]),
     ("nets.hip", ["-ffp-contract=off"]),
     ("host_order.cpp", []),
 ]
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
-COMMON += os.environ.get("PS_EXTRA_HIPCC_FLAGS", "").split()  # tuning builds, e.g. -DPS_CHAIN_TRACE_BUILD
+COMMON += os.environ.get("PS_EXTRA_HIPCC_FLAGS", "").split()  # tuning builds, e.g. -DPS_TUNING_BUILD -DPS_CHAIN_TRACE_BUILD
 
 
 def _deps():
     return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [
-        os.path.join(os.path.dirname(HERE), "include", "pixelsynth_hip.h")]
+        os.path.join(os.path.dirname(HERE), "include", "pixelsynth_hip.h"),
+        os.path.join(os.path.dirname(HERE), "include", "pixelsynth_hip_debug.h")]
 
 
 def build(force=False, verbose=True):

@@ -1,0 +1,1005 @@
+// lmconv_grid.hip -- whole-grid mode of the locally-masked PixelCNN engine: items = (frame, location) pairs of the full grid or of the
+// observed prefix of every generation order.  The reference-faithful OurPixelCNN.forward (models/lmconv/model.py:110-155) and the
+// cache build an AR run starts from; also the generic NCHW entry point of one locally masked convolution
+// (models/lmconv/locally_masked_convolution.py:11-50).
+//   k_gemm        one wave = 16 items x 32 output channels of one split-K slot (small launches)
+//   k_gemm_wg     a workgroup = 16/32 items x ALL output channels, input rows shared through LDS, post op fused (large launches)
+//   k_post_grid / k_uinit_grid / k_logits_grid, k_prefix_starts (which prefix items anybody reads)
+#include "lmconv_handle.h"
+
+namespace pslm {
+
+struct GemmTap {
+    const float *in;   // channels-last input [F][L][ld]
+    const float *w;    // packed weights of this tap [Cin/4][Co_pad][4]
+    int dr, dc;        // neighbour offset (already times dilation)
+    int mask_row;      // row of the (F,9,L) mask, -1 = unmasked
+    int ld;            // channels per location in `in`
+};
+
+// ==========================================================================================
+// whole-grid mode: items = (frame, location) pairs of the full grid
+// ==========================================================================================
+// Items of a whole-grid pass: every (frame, location) pair, or -- with a generation order -- only the first
+// `npre` locations of each frame in that order (the observed prefix an AR run starts from; later locations
+// are produced by the column steps, and no earlier location ever reads them).
+struct ItemMap {
+    const int32_t *order;  // (F, L) location by rank, or null = all L locations in raster order
+    int npre;              // locations per frame
+    const int32_t *start;  // (F) or null: ranks below start[f] are NOT evaluated at this stage -- nothing reads them
+                           // (k_prefix_starts); only with an order
+    int f0;                // first frame of the pass (a pass over frames [f0, f0 + n): item 0 is rank 0 of frame f0)
+};
+__device__ __forceinline__ void item_loc(const ItemMap &m, int item, int L, int &f, int &q)
+{
+    const int fl = item / m.npre;
+    const int r = item - fl * m.npre;
+    f = m.f0 + fl;
+    q = m.order ? m.order[(size_t)f * L + r] : r;
+}
+// is the item evaluated at this stage?
+__device__ __forceinline__ bool item_wanted(const ItemMap &m, int item)
+{
+    if (!m.start) return true;
+    const int fl = item / m.npre;
+    return item - fl * m.npre >= m.start[m.f0 + fl];
+}
+
+struct GemmArgs {
+    GemmTap tap[MAX_TAPS];
+    ItemMap items;
+    int slot_first[5];  // slot s covers taps [slot_first[s], slot_first[s+1])
+    int nslots, Cin, Co_pad, H, W, L, nitems, tiles_per_block;
+    int nx, ny, tpx;    // launch geometry (launch_gemm): channel blocks, item blocks, item blocks per XCD
+    int zgrid;          // slots along the grid (nslots), or 1 = every wave walks all slots
+    const float *sum_bias;  // zgrid == 1 only: the wave adds its slots up itself, y = ((bias + NA) + C) + NB, and stores y in
+                            // place of slot NA (a third of the partial traffic); null = raw slots
+    const float *mask;
+    size_t mask_fstride;
+    float *partial;  // [nslots][nitems][Co_pad]
+};
+
+// a row of zeros: the input row of a lane whose tap is closed, when every mask value of the wave is 0 or 1 (the
+// reference's masks always are): the closed lanes then LOAD their zeros and the chunk loop carries no mask arithmetic
+// (40 vector instructions per chunk that compete with the MFMAs for issue: tools/mfma_rate_probe.hip, 95 % -> 84 %)
+constexpr int ZERO_ROW = 4096;   // floats: as many input channels as a closed lane may walk through it
+__device__ float g_zero_row[ZERO_ROW];
+
+// grid z -> slot, long slots first: (NA, NB, C, SKIP)
+__device__ __forceinline__ int gemm_slot_of(const GemmArgs &a, int z) { return z == 0 ? SLOT_NA : z == 1 && a.nslots > 2 ? SLOT_NB : z == 2 ? SLOT_C : z; }
+
+// One wave = 16 items x (T x 16) output channels of one slot: the gathered input rows (B operand) are loaded once
+// per 80-channel chunk and reused by the T output tiles, so the kernel is bound by the MFMA pipe rather than by
+// the per-CU L1 fill rate (at T = 1 every 40 MFMAs needed 20 KB of operands).
+template <int T>
+__device__ __forceinline__ void gemm_tiles(const GemmArgs &a, int o0, int z0, int z1, int first_tile)
+{
+    const int lane = threadIdx.x & 63, i = lane & 15, kk = lane >> 4;
+    const int ngroups = a.Cin >> 4;
+    const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int tt = 0; tt < a.tiles_per_block; ++tt) {
+        const int tile = first_tile + tt;
+        if (tile * 16 >= a.nitems) break;
+        const int item = tile * 16 + i;
+        const bool valid = item < a.nitems && item_wanted(a.items, item);
+        if (!__any(valid)) continue;   // a tile nobody reads at this stage
+        int f = 0, r = 0, c = 0, q = 0;
+        if (valid) {
+            item_loc(a.items, item, a.L, f, q);
+            r = q / a.W;
+            c = q - r * a.W;
+        }
+        const bool summing = a.sum_bias != nullptr;   // (then z0 = 0, z1 = nslots, slots in the order of the sum: NA, C, NB, SKIP)
+        f32x4 ysum[T];
+#pragma unroll
+        for (int u = 0; u < T; ++u) ysum[u] = zero;
+        for (int z = z0; z < z1; ++z) {
+        const int slot = summing ? z : gemm_slot_of(a, z);
+        // slot value = taps of the slot added in order, each tap from fresh accumulators: P_t = chunk_total(acc)
+        f32x4 tot[T];
+#pragma unroll
+        for (int u = 0; u < T; ++u) tot[u] = zero;
+        // the mask values of all (at most four) taps of the slot are requested together, before the first tap needs one:
+        // fetched inside the tap loop each is a dependent round trip in front of the tap's operand loads
+        const int t0 = a.slot_first[slot], nt = a.slot_first[slot + 1] - t0;
+        float mvs[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            mvs[k] = 0.0f;
+            if (k < nt) {
+                const GemmTap &tq = a.tap[t0 + k];
+                const int rr = r + tq.dr, cc = c + tq.dc;
+                if (valid && rr >= 0 && rr < a.H && cc >= 0 && cc < a.W)
+                    mvs[k] = tq.mask_row >= 0 ? a.mask[(size_t)f * a.mask_fstride + (size_t)tq.mask_row * a.L + q] : 1.0f;
+            }
+        }
+        for (int t = t0; t < t0 + nt; ++t) {
+            const GemmTap tp = a.tap[t];
+            // Lanes without a live input row still LOAD (row 0 of the cache, a valid address) and discard: a load under a
+            // lane condition compiles to branch / load / s_waitcnt vmcnt(0) per load, i.e. the five input loads of a
+            // chunk one round trip after the other (k_gemm: 48.8 -> 43.6 us per launch).
+            const int k = t - t0;
+            const float mv = k == 0 ? mvs[0] : k == 1 ? mvs[1] : k == 2 ? mvs[2] : mvs[3];
+            const int rr = r + tp.dr, cc = c + tp.dc;
+            const bool live = mv != 0.0f;
+            if (!__any(live)) continue;  // a masked tap is an exact zero: skipping it does not change the bits
+            // (a masked row is not fetched either)
+            const bool unit = a.Cin <= ZERO_ROW && __all(mv == 0.0f || mv == 1.0f);   // wave-uniform: 0/1 masks need no multiply
+            const float *src = live ? tp.in + ((size_t)f * a.L + rr * a.W + cc) * tp.ld + 4 * kk
+                                    : (unit ? g_zero_row : tp.in) + 4 * kk;
+            Acc5 acc[T];
+#pragma unroll
+            for (int u = 0; u < T; ++u) acc[u] = acc5_zero();
+            // weights through a buffer descriptor: uniform base + uniform offset in SGPRs, ONE 32-bit lane offset -- the ten
+            // weight loads of a chunk need no per-load 64-bit address registers (19 spilled VGPRs otherwise)
+            const uint32_t woff = (uint32_t)((kk * a.Co_pad + o0 + i) * 16);
+            const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)tp.w, 0, 0x7fffffff, 0x00020000);
+            auto wload = [&](int grp, int u) {
+                return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, woff, (grp * 16 * a.Co_pad + 64 * u) * 4, 0));
+            };
+            int g = 0;
+            for (; g + 5 <= ngroups; g += 5) {
+                f32x4 bv[5];
+#pragma unroll
+                for (int j = 0; j < 5; ++j) bv[j] = *(const f32x4 *)(src + 16 * (g + j));
+                // (the loads must stay unconditional: left to itself the compiler sinks the last one under `live` and waits
+                // for it with vmcnt(0) -- the B round trip and the A round trip of the chunk then run one after the other)
+#pragma unroll
+                for (int j = 0; j < 5; ++j) asm volatile("" : "+v"(bv[j]));
+                if (!unit) {
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) bv[j] = live ? bv[j] * mv : zero;
+                }
+#pragma unroll
+                for (int u = 0; u < T; ++u) {
+                    f32x4 av[5];
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) av[j] = wload(g + j, u);
+                    mfma_chunk5(av, bv, acc[u]);
+                }
+            }
+            for (; g < ngroups; ++g) {  // ragged channel counts of the generic lmconv entry point only
+                const f32x4 raw = *(const f32x4 *)(src + 16 * g);
+                const f32x4 bv = unit ? raw : live ? raw * mv : zero;
+#pragma unroll
+                for (int u = 0; u < T; ++u) {
+                    const f32x4 av = wload(g, u);
+                    f32x4 &a0 = acc[u].v[0];
+                    a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, a0, 0, 0, 0);
+                    a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, a0, 0, 0, 0);
+                    a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, a0, 0, 0, 0);
+                    a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, a0, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < T; ++u) tot[u] = tot[u] + chunk_total(acc[u]);
+        }
+        // D: row (output channel) = kk*4 + reg, col (item) = i
+        if (summing && slot != SLOT_SKIP) {
+#pragma unroll
+            for (int u = 0; u < T; ++u)
+                ysum[u] = (slot == SLOT_NA ? *(const f32x4 *)(a.sum_bias + o0 + 16 * u + kk * 4) : ysum[u]) + tot[u];
+            if (slot != SLOT_NB) continue;
+#pragma unroll
+            for (int u = 0; u < T; ++u) tot[u] = ysum[u];
+        }
+        if (valid) {
+            const int at = summing && slot == SLOT_NB ? SLOT_NA : slot;
+#pragma unroll
+            for (int u = 0; u < T; ++u)
+                *(f32x4 *)(a.partial + ((size_t)at * a.nitems + item) * a.Co_pad + o0 + 16 * u + kk * 4) = tot[u];
+        }
+        }
+    }
+}
+
+// grid (ceil(Co_pad / 64), item blocks, nslots), one wave per block.  Blocks are dispatched x fastest, z slowest, and a
+// wave of the four-tap slots NA / NB lives four times as long as one of the single-tap slots C / SKIP: the slot is the
+// slowest dimension, long slots first, so that the kernel's tail is made of short waves.
+// 16-channel output tiles per wave: 2 (with four waves per SIMD) measured best -- 4: 55.7 us, 2: 51.1, 2 at four waves per
+// SIMD: 49.3, 1: 60.2 us per launch at 16 frames
+#ifndef PS_GEMM_T
+#define PS_GEMM_T 2
+#endif
+constexpr int GEMM_T = PS_GEMM_T;
+#if PS_GEMM_T <= 2
+#define PS_GEMM_WAVES 4
+#else
+#define PS_GEMM_WAVES 3
+#endif
+__attribute__((amdgpu_waves_per_eu(PS_GEMM_WAVES, PS_GEMM_WAVES)))
+__global__ __launch_bounds__(64) void k_gemm(GemmArgs a)
+{
+    // Workgroup ids go round-robin over the 8 XCDs, each with its own L2.  Every XCD gets a contiguous range of item
+    // blocks with ALL their channel blocks and slots (the waves that gather the same input rows, and the rows of
+    // neighbouring items, meet in one L2) instead of five channel blocks of one tile on five XCDs.
+    const int xcd = blockIdx.x & (N_XCD - 1), j = blockIdx.x >> 3;
+    const int x = j % a.nx, t = (j / a.nx) % a.tpx, z = j / (a.nx * a.tpx);
+    const int y = xcd * a.tpx + t;
+    if (y >= a.ny) return;
+    // zgrid = 1: one wave walks ALL slots of its (tile, channel block) -- the wave's start-up (kernel arguments, order and
+    // mask look-ups: two or three dependent round trips) is paid once per nine or ten taps instead of once per slot, and a
+    // single-tap C / SKIP wave was mostly start-up
+    const int z0 = a.zgrid == 1 ? 0 : z, z1 = a.zgrid == 1 ? a.nslots : z + 1;
+    const int o0 = x * 16 * GEMM_T, first_tile = y * a.tiles_per_block;
+    const int T = min(GEMM_T, (a.Co_pad - o0) >> 4);
+    if (GEMM_T >= 4 && T == 4) gemm_tiles<4>(a, o0, z0, z1, first_tile);
+    else if (GEMM_T >= 3 && T == 3) gemm_tiles<3>(a, o0, z0, z1, first_tile);
+    else if (GEMM_T >= 2 && T == 2) gemm_tiles<2>(a, o0, z0, z1, first_tile);
+    else gemm_tiles<1>(a, o0, z0, z1, first_tile);
+}
+
+__device__ __forceinline__ void store_raw_celu2(float *R, float *E, size_t loc, int c, const f32x2 &u)
+{
+    f32x2 ep, en;
+    celu_pair2(u, ep, en);
+    *(f32x2 *)(R + loc * R_LD + c) = u;
+    *(f32x2 *)(E + loc * (2 * NF) + c) = ep;
+    *(f32x2 *)(E + loc * (2 * NF) + NF + c) = en;
+}
+
+struct PostArgs {
+    ItemMap items;
+    const float *partial;  // [slots][nitems][Co_pad]
+    int nitems, Co_pad, L, has_skip;
+    int summed;            // slot NA of `partial` already holds y = ((bias + NA) + C) + NB (k_gemm with sum_bias)
+    const float *bias, *bias2;
+    const float *Rin;
+    float *Rout, *Eout, *Xout;
+};
+
+// post op of one item by one wave.  `P` points at channel pair c of the item's y (raw slots `ss` floats apart unless
+// a.summed), `S` at the same pair of its nin_skip slot.
+template <int KIND>
+__device__ __forceinline__ void post_item(const PostArgs &a, int item, int lane, const float *Pbase, size_t ss, const float *Sbase)
+{
+    int f, q;
+    item_loc(a.items, item, a.L, f, q);
+    const size_t loc = (size_t)f * a.L + q;
+    const bool own = lane < PONO_LANES;
+    const int c = own ? 2 * lane : 0;
+    const float *P = Pbase + c;
+    const f32x2 zero = {0.0f, 0.0f};
+    auto ld = [](const float *p) { return *(const f32x2 *)p; };
+    f32x2 g = zero, skip = zero, rin = zero;
+    const f32x2 y = a.summed ? ld(P + SLOT_NA * ss)
+                             : slot_sum2(ld(a.bias + c), ld(P + SLOT_NA * ss), ld(P + SLOT_C * ss), ld(P + SLOT_NB * ss));
+    if (KIND == POST_GATE) {
+        g = a.summed ? ld(P + SLOT_NA * ss + NF)
+                     : slot_sum2(ld(a.bias + NF + c), ld(P + SLOT_NA * ss + NF), ld(P + SLOT_C * ss + NF), ld(P + SLOT_NB * ss + NF));
+        rin = ld(a.Rin + loc * R_LD + c);
+    }
+    if (KIND == POST_CONVIN && a.has_skip) skip = ld(Sbase + c) + ld(a.bias2 + c);
+    const float mean = pono_mean(pono_total(y, own));
+    const f32x2 d = y - mean;
+    const float inv = pono_inv(pono_total(d * d, own));
+    if (!own) return;
+    const f32x2 out = post_finish<KIND>(d * inv, g, skip, a.has_skip != 0, rin);
+    if (KIND == POST_CONVIN) {
+        f32x2 ep, en;
+        celu_pair2(out, ep, en);
+        *(f32x2 *)(a.Xout + loc * (2 * NF) + c) = ep;
+        *(f32x2 *)(a.Xout + loc * (2 * NF) + NF + c) = en;
+    } else {
+        store_raw_celu2(a.Rout, a.Eout, loc, c, out);
+    }
+}
+
+// whole-grid post op: one wave per item, 4 items per 256-thread block
+template <int KIND>
+__global__ __launch_bounds__(256) void k_post_grid(PostArgs a)
+{
+    const int item = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (item >= a.nitems || !item_wanted(a.items, item)) return;  // whole waves leave together
+    const size_t ss = (size_t)a.nitems * a.Co_pad;
+    const float *P = a.partial + (size_t)item * a.Co_pad;
+    post_item<KIND>(a, item, lane, P, ss, P + SLOT_SKIP * ss);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_gemm_wg: the whole-grid products with the receptive-field window shared through LDS (round 3).
+//
+// k_gemm gives every wave its own 16 items x 32 output channels and lets it gather its input rows and fetch its weights from
+// L1 / L2 by itself.  Here a WORKGROUP of four waves -- one per SIMD: five-wave workgroups (one wave per 16 of 80 channels)
+// were measured first and never got more than two of them resident on a CU, 3 + 3 + 2 + 2 waves, the doubly loaded SIMDs
+// setting the pace -- owns a tile of 16 * TI items and ALL output channels of the conv, 20 MFMA tiles, five per wave:
+//   conv_out (160 channels, TI = 2)   wave w: output tiles 2w, 2w + 1 for both item tiles, + output tile 8 + w / 2 for item tile w & 1
+//   conv_input / dilated (80, TI = 4) wave w: output tile w for the four item tiles,        + output tile 4 for item tile w
+//   * the gathered input rows of a tap (operand B: 16 * TI items x Cin channels, mask applied, closed or absent rows as zeros)
+//     are staged in LDS ONCE per workgroup, in the lane order of the MFMA fragment, and read from there by all four waves
+//     (conflict-free ds_read_b128); the rows of the NEXT open tap are requested before the MFMAs of this one and parked after
+//     them (two buffers and one barrier per tap; conv_input, whose 64 x 160 rows take 40 KB, has one buffer and two barriers);
+//   * a wave's weights (operand A) come straight from L2 into registers, one accumulation chain ahead of their use, and are
+//     used for up to four item tiles (k_gemm: one);
+//   * the four waves walk the SAME items, so the barriers cost no skew; a tap that is closed for the whole tile of items is
+//     skipped by all of them (an exact zero); a tap that is open for some of them is computed for all, on zeros where it
+//     is closed -- tot + 0 is tot, so the bits do not change -- which keeps the tap body free of branches.
+// Arithmetic and order are k_gemm's summing form to the bit: per tap five accumulation chains (chain j = channel groups j,
+// j + 5 in MFMA order), tap value (((a0 + a1) + a2) + a3) + a4, taps added in order into the slot, y = ((bias + NA) + C) + NB
+// stored in place of slot NA, the nin_skip slot raw.  Taken for launches of at least PS_GEMM_WG_MIN item tiles.
+// ------------------------------------------------------------------------------------------
+constexpr int GW_WAVES = 4, GW_THREADS = 64 * GW_WAVES;
+enum { GW_CONVOUT = 0, GW_CONVIN = 1, GW_DIL = 2 };
+#ifdef PS_WG_TRACE_BUILD   // tuning builds: shader-clock stamps of wave 0 of the first 32 workgroups, per kernel variant
+__device__ unsigned long long g_wg_trace[3][32][16];
+__device__ unsigned long long g_wg_span[3][4096][2];   // wall clock (100 MHz) at the start and the end of every workgroup, + hw id
+#define WG_STAMP(k) do { if (y < 32 && tid == 0 && (k) < 16) g_wg_trace[KIND][y][(k)] = clock64(); } while (0)
+#else
+#define WG_STAMP(k) do { } while (0)
+#endif
+// waves per SIMD the register budget is cut for: the full-size forms (five tiles per wave) take two, the others three
+constexpr int gw_occ(int kind, int ti) { return (kind == GW_CONVOUT && ti == 2) || (kind == GW_CONVIN && ti == 4) ? 2 : 3; }
+template <int KIND, int TI>
+__attribute__((amdgpu_waves_per_eu(gw_occ(KIND, TI), gw_occ(KIND, TI))))
+__global__ __launch_bounds__(GW_THREADS) void k_gemm_wg(GemmArgs a, PostArgs pa, int fuse_post)
+{
+    constexpr int NGH = KIND == GW_DIL ? 1 : 2, NG = 5 * NGH, MI = 16 * TI;
+    constexpr int POSTK = KIND == GW_CONVOUT ? POST_GATE : KIND == GW_CONVIN ? POST_CONVIN : POST_DIL;
+    constexpr int YLD = KIND == GW_DIL ? 84 : 168;      // floats per item of the post op's LDS tile: y (+ gate half / nin_skip slot) + pad
+    constexpr int NAU = KIND == GW_CONVOUT ? 3 : 2;     // distinct output tiles (A operands) of a wave
+    constexpr int NBU = TI + 1;                         // B operands of a wave: the TI item tiles + the fifth tile's own copy
+    constexpr bool DB = MI * NG * 16 <= 6144;           // two B buffers while they take no more than 48 KB
+    constexpr int BUF = TI * NG * 64;                   // f32x4 per B buffer: [item tile][channel group][lane]
+    constexpr int SU = (TI * NG + GW_WAVES - 1) / GW_WAVES;   // 1 KB staging units per wave and tap (the last one may be absent)
+    constexpr bool SU_EVEN = TI * NG % GW_WAVES == 0;
+    static_assert(MI <= 64, "one lane per item in the set-up");
+    constexpr int NB4 = (DB ? 2 : 1) * BUF > MI * YLD / 4 ? (DB ? 2 : 1) * BUF : MI * YLD / 4;   // (the post op's tile reuses the B buffers)
+    __shared__ f32x4 sB[NB4];
+    __shared__ int sRow[MAX_TAPS * MI];      // input row of (tap, item), -1 = closed (mask 0, outside the grid, item not evaluated)
+    __shared__ float sMv[MAX_TAPS * MI];     // its mask value
+    __shared__ int sItem[MI];                // item index, -1 = not evaluated here
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, i = lane & 15, kk = lane >> 4;
+    const int xcd = blockIdx.x & (N_XCD - 1), tb = blockIdx.x >> 3;
+    const int yy = xcd * a.tpx + tb;         // contiguous item ranges per XCD, as in k_gemm
+    if (tb >= a.tpx || yy >= a.ny) return;
+    const int y = yy;
+    const int item0 = y * MI;
+    const int ntaps = a.slot_first[a.nslots];
+    const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+    WG_STAMP(0);
+#ifdef PS_WG_TRACE_BUILD
+    if (tid == 0 && y < 4096) g_wg_span[KIND][y][0] = wall_clock64();
+#endif
+    // ---- set-up: rows and mask values of every (tap, item) of the tile; wave w does taps w, w + 4, w + 8
+    {
+        const int m = lane & (MI - 1);
+        const int item = item0 + m;
+        const bool valid = item < a.nitems && item_wanted(a.items, item);
+        int f = 0, q = 0, r = 0, c = 0;
+        if (valid) {
+            item_loc(a.items, item, a.L, f, q);
+            r = q / a.W;
+            c = q - r * a.W;
+        }
+        if (wave == 0 && lane < MI) sItem[m] = valid ? item : -1;
+        for (int t = wave; t < ntaps; t += GW_WAVES) {
+            const GemmTap tp = a.tap[t];
+            const int rr = r + tp.dr, cc = c + tp.dc;
+            float mv = 0.0f;
+            if (valid && rr >= 0 && rr < a.H && cc >= 0 && cc < a.W)
+                mv = tp.mask_row >= 0 ? a.mask[(size_t)f * a.mask_fstride + (size_t)tp.mask_row * a.L + q] : 1.0f;
+            if (lane < MI) {
+                sRow[t * MI + m] = mv != 0.0f ? (f * a.L + rr * a.W + cc) : -1;
+                sMv[t * MI + m] = mv;
+            }
+        }
+    }
+    __syncthreads();
+    WG_STAMP(1);
+    // live bits [4 t, 4 t + TI): item tile ti has an open lane at tap t (wave-uniform; the same in every wave)
+    unsigned long long live = 0;
+    for (int t = 0; t < ntaps; ++t) {
+        const unsigned long long b = __ballot(sRow[t * MI + (lane & (MI - 1))] >= 0);
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti)
+            if ((b >> (16 * ti)) & 0xFFFFull) live |= 1ull << (4 * t + ti);
+    }
+    if (live == 0 && __ballot(sItem[lane & (MI - 1)] >= 0) == 0ull) return;   // nothing of this tile is evaluated here
+    auto tiles_of = [&](int t) { return (unsigned)((live >> (4 * t)) & 0xFull); };
+    auto next_live = [&](int t) {   // first tap after t with an open item tile, or ntaps
+        int n = t + 1;
+        while (n < ntaps && tiles_of(n) == 0) ++n;
+        return n;
+    };
+    // ---- staging: unit u of this wave = (item tile, channel group) (wave + 4 u); lane (kk, i) carries channels 16 g + 4 kk .. + 3 of
+    // item i; rows and mask values are looked up once per item tile
+    f32x4 sv[SU];
+    auto stage_load = [&](int t) {
+        const GemmTap tp = a.tap[t];
+        int row[TI];
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti) row[ti] = sRow[t * MI + ti * 16 + i];
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+            const int unit = wave + GW_WAVES * u, ti = unit / NG, g = unit - ti * NG;
+            if (!SU_EVEN && u == SU - 1 && unit >= TI * NG) continue;   // (wave-uniform)
+            int r = row[0];
+#pragma unroll
+            for (int k = 1; k < TI; ++k) r = ti == k ? row[k] : r;
+            sv[u] = *(const f32x4 *)(tp.in + (size_t)(r >= 0 ? r : 0) * tp.ld + 16 * g + 4 * kk);   // (unconditional: see gemm_tiles)
+        }
+    };
+    auto stage_store = [&](int t, int buf) {
+        int row[TI];
+        float mvv[TI];
+#pragma unroll
+        for (int ti = 0; ti < TI; ++ti) { row[ti] = sRow[t * MI + ti * 16 + i]; mvv[ti] = sMv[t * MI + ti * 16 + i]; }
+#pragma unroll
+        for (int u = 0; u < SU; ++u) {
+            const int unit = wave + GW_WAVES * u, ti = unit / NG, g = unit - ti * NG;
+            if (!SU_EVEN && u == SU - 1 && unit >= TI * NG) continue;
+            int r = row[0];
+            float mv = mvv[0];
+#pragma unroll
+            for (int k = 1; k < TI; ++k) { r = ti == k ? row[k] : r; mv = ti == k ? mvv[k] : mv; }
+            sB[buf * BUF + (ti * NG + g) * 64 + lane] = r >= 0 ? sv[u] * mv : zero;   // (x * 1.0f is x: 0 / 1 masks cost nothing)
+        }
+    };
+    // ---- the wave's five tiles: A operand (output tile) and B operand (item tile) of each
+    //   conv_out:          (a0,b0) (a0,b1) (a1,b0) (a1,b1) (a2,bx)     a0 = 2w, a1 = 2w + 1, a2 = 8 + w / 2, bx = item tile w & 1
+    //   conv_input / dil:  (a0,b0) (a0,b1) (a0,b2) (a0,b3) (a1,bx)     a0 = w, a1 = 4, bx = item tile w
+    // (with fewer item tiles than the full-size forms -- conv_out TI = 1, conv_input / dilated TI = 2 -- a wave has the tiles of
+    // its first NT4 = 2 (conv_out: its two output tiles) or TI combinations, and the fifth tile exists for the waves whose item tile
+    // it would be: 3 + 3 + 2 + 2 or 3 + 2 + 3 + 2 tiles; three such workgroups fit a CU and even each other's SIMDs out)
+    constexpr int NT4 = KIND == GW_CONVOUT ? 2 * TI : TI;       // tiles ahead of the "fifth" one
+    constexpr int NTL = NT4 + 1;
+    auto a_of = [](int k) constexpr { return KIND == GW_CONVOUT ? (k < NT4 ? k / TI : 2) : (k < NT4 ? 0 : 1); };
+    auto b_of = [](int k) constexpr { return k < NT4 ? (KIND == GW_CONVOUT ? k % TI : k) : TI; };
+    const int tixr = KIND == GW_CONVOUT ? (wave & 1) : wave;    // item tile of the fifth tile ...
+    const bool has5 = tixr < TI;                                // ... if the workgroup has that item tile
+    const int tix = has5 ? tixr : 0;
+    int ot[NAU];                                                // output tile of A operand n
+    if (KIND == GW_CONVOUT) { ot[0] = 2 * wave; ot[1] = 2 * wave + 1; ot[NAU - 1] = 8 + (wave >> 1); }
+    else { ot[0] = wave; ot[1] = 4; }
+    static_assert(KIND != GW_CONVOUT || TI <= 2, "conv_out: the fifth tile's item tile is w & 1");
+    auto o_of = [&](int k) { return 16 * ot[a_of(k)]; };                       // first output channel of tile k
+    auto m_of = [&](int k) { return (k < NT4 ? b_of(k) : tix) * 16 + i; };     // this lane's item of tile k (column i of the tile)
+    f32x4 tot[NTL], ysum[NTL];
+#pragma unroll
+    for (int k = 0; k < NTL; ++k) { tot[k] = zero; ysum[k] = zero; }
+    uint32_t woff[NAU];
+#pragma unroll
+    for (int n = 0; n < NAU; ++n) woff[n] = (uint32_t)((kk * a.Co_pad + 16 * ot[n] + i) * 16);
+    auto wload = [&](const __amdgpu_buffer_rsrc_t &wrs, int grp, int n) {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, woff[n], grp * 16 * a.Co_pad * 4, 0));
+    };
+    f32x4 av[NGH][NAU];           // chain 0's weights of the CURRENT tap: requested before the previous tap's barrier (a0_load), so that a
+    auto a0_load = [&](int t) {   // tap does not open with a memory round trip that every wave of the workgroup sits through together
+        const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)a.tap[t].w, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+        for (int h = 0; h < NGH; ++h)
+#pragma unroll
+            for (int n = 0; n < NAU; ++n) av[h][n] = wload(wrs, 5 * h, n);
+    };
+    // products of tap t from buffer `buf`, added to tot[].  ALL: every item tile has an open lane -- straight-line code; else the
+    // tiles of closed item tiles are left out (an exact zero) behind wave-uniform branches, one per tile and chain.
+    constexpr bool BPRE = gw_occ(KIND, TI) == 2;   // B operands read a chain ahead too, where the register budget is the large one
+    auto tap_products = [&](int t, int nxt, int buf, auto ALLc) {
+        constexpr bool ALL = decltype(ALLc)::value;     // every tile of this wave is computed
+        const unsigned tl = tiles_of(t);
+        bool lv[NTL];
+#pragma unroll
+        for (int k = 0; k < NTL; ++k) lv[k] = ALL || (k < NT4 ? ((tl >> b_of(k)) & 1u) != 0 : has5 && ((tl >> tix) & 1u));
+        const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)a.tap[t].w, 0, 0x7fffffff, 0x00020000);
+        // (the last chain requests chain 0 of the NEXT open tap -- of this tap again when there is none, a valid address: the
+        // request count stays the same on every path -- so that a tap does not open with a memory round trip)
+        const __amdgpu_buffer_rsrc_t wnx = __builtin_amdgcn_make_buffer_rsrc((void *)a.tap[nxt < ntaps ? nxt : t].w, 0, 0x7fffffff, 0x00020000);
+        f32x4 taptot[NTL], an[NGH][NAU], bn[NGH][NBU];
+        auto bload = [&](int j, f32x4 (&dst)[NGH][NBU]) {
+#pragma unroll
+            for (int h = 0; h < NGH; ++h) {
+#pragma unroll
+                for (int ti = 0; ti < TI; ++ti) dst[h][ti] = sB[buf * BUF + (ti * NG + j + 5 * h) * 64 + lane];
+                dst[h][TI] = sB[buf * BUF + (tix * NG + j + 5 * h) * 64 + lane];
+            }
+        };
+        if (BPRE) bload(0, bn);
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            // the next chain's weights are requested under this chain's MFMAs ...
+#pragma unroll
+            for (int h = 0; h < NGH; ++h)
+#pragma unroll
+                for (int n = 0; n < NAU; ++n) an[h][n] = j < 4 ? wload(wrs, j + 1 + 5 * h, n) : wload(wnx, 5 * h, n);
+            f32x4 bv[NGH][NBU], acc[NTL];
+            if (BPRE) {
+#pragma unroll
+                for (int h = 0; h < NGH; ++h)
+#pragma unroll
+                    for (int q = 0; q < NBU; ++q) bv[h][q] = bn[h][q];
+                if (j < 4) bload(j + 1, bn);
+            } else {
+                bload(j, bv);
+            }
+            __builtin_amdgcn_sched_barrier(0);   // ... and the scheduler may not pull their consumers up to them
+            // chain j of the five tiles: group j (c = 0..3), then group j + 5 -- the tiles are independent accumulators
+            if (ALL) {
+#pragma unroll
+                for (int h = 0; h < NGH; ++h)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+#pragma unroll
+                        for (int k = 0; k < NTL; ++k)
+                            acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[h][a_of(k)][c], bv[h][b_of(k)][c], h == 0 && c == 0 ? zero : acc[k], 0, 0, 0);
+#pragma unroll
+                for (int k = 0; k < NTL; ++k) taptot[k] = j == 0 ? acc[k] : taptot[k] + acc[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < NTL; ++k) {
+                    if (!lv[k]) continue;
+#pragma unroll
+                    for (int h = 0; h < NGH; ++h)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[h][a_of(k)][c], bv[h][b_of(k)][c], h == 0 && c == 0 ? zero : acc[k], 0, 0, 0);
+                    taptot[k] = j == 0 ? acc[k] : taptot[k] + acc[k];
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < NGH; ++h)
+#pragma unroll
+                for (int n = 0; n < NAU; ++n) av[h][n] = an[h][n];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int k = 0; k < NTL; ++k)
+            if (lv[k]) tot[k] = tot[k] + taptot[k];
+    };
+    auto tap_dispatch = [&](int t, int nxt, int buf) {
+        if (has5 && tiles_of(t) == (1u << TI) - 1u) tap_products(t, nxt, buf, std::integral_constant<bool, true>{});
+        else tap_products(t, nxt, buf, std::integral_constant<bool, false>{});
+    };
+    // ---- the taps in slot order NA, C, NB (, SKIP); the open ones staged through sB
+    int cur = next_live(-1), buf = 0;
+    if (cur < ntaps) {
+        stage_load(cur);
+        a0_load(cur);
+        stage_store(cur, 0);
+    }
+    __syncthreads();
+    WG_STAMP(2);
+    int nstamp = 3;
+    (void)nstamp;
+    for (int slot = 0; slot < a.nslots; ++slot) {
+        for (int t = a.slot_first[slot]; t < a.slot_first[slot + 1]; ++t) {
+            if (t != cur) continue;              // no open lane in the whole tile: an exact zero, skipped by every wave
+            const int nxt = next_live(t);
+            if (nxt < ntaps) stage_load(nxt);    // in flight under the MFMAs
+            tap_dispatch(t, nxt, buf);
+            if (DB) {
+                if (nxt < ntaps) stage_store(nxt, buf ^ 1);
+                __syncthreads();                 // next tap's rows visible; everybody is done with this tap's
+                buf ^= 1;
+            } else {
+                __syncthreads();                 // everybody is done with this tap's rows
+                if (nxt < ntaps) stage_store(nxt, 0);
+                __syncthreads();
+            }
+            cur = nxt;
+            WG_STAMP(nstamp);
+            ++nstamp;
+        }
+        if (slot == SLOT_SKIP) {
+            if (fuse_post) {   // (all taps are done: the B buffers are free -- the last tap ended with a barrier)
+                float *sY = (float *)sB;
+#pragma unroll
+                for (int k = 0; k < NTL; ++k)
+                    if (k < NT4 || has5) *(f32x4 *)(sY + m_of(k) * YLD + NF + o_of(k) + kk * 4) = tot[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < NTL; ++k) {
+                    const int item = (k < NT4 || has5) ? sItem[m_of(k)] : -1;
+                    if (item >= 0) *(f32x4 *)(a.partial + ((size_t)SLOT_SKIP * a.nitems + item) * a.Co_pad + o_of(k) + kk * 4) = tot[k];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NTL; ++k)
+                ysum[k] = (slot == SLOT_NA ? *(const f32x4 *)(a.sum_bias + o_of(k) + kk * 4) : ysum[k]) + tot[k];
+            if (slot == SLOT_NB && !fuse_post) {
+#pragma unroll
+                for (int k = 0; k < NTL; ++k) {
+                    const int item = (k < NT4 || has5) ? sItem[m_of(k)] : -1;
+                    if (item >= 0) *(f32x4 *)(a.partial + ((size_t)SLOT_NA * a.nitems + item) * a.Co_pad + o_of(k) + kk * 4) = ysum[k];
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NTL; ++k) tot[k] = zero;
+    }
+    // ---- the post op of the stage, in the same launch: y (and the gate half / the nin_skip slot) of the tile's items go through
+    // LDS -- a row per item, where post_item (the code of k_post_grid) finds them -- and the four waves share out the items.
+    // No partial sums in HBM, no second launch; the other workgroups of the CU keep the matrix pipes busy meanwhile.
+    if (fuse_post) {
+        float *sY = (float *)sB;
+        // (conv_input with nin_skip: the skip slot was parked above, after the barrier of the last tap; here the taps are done too)
+#pragma unroll
+        for (int k = 0; k < NTL; ++k)
+            if (k < NT4 || has5) *(f32x4 *)(sY + m_of(k) * YLD + o_of(k) + kk * 4) = ysum[k];
+        __syncthreads();
+        for (int m = wave; m < MI; m += GW_WAVES) {
+            const int item = sItem[m];
+            if (item < 0) continue;   // (wave-uniform)
+            post_item<POSTK>(pa, item, lane, sY + m * YLD, 0, sY + m * YLD + NF);
+        }
+    }
+    WG_STAMP(15);
+#ifdef PS_WG_TRACE_BUILD
+    if (tid == 0 && y < 4096) {
+        unsigned hw = 0;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        g_wg_span[KIND][y][1] = (wall_clock64() << 16) | (hw & 0xffffu);
+    }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------
+// Which prefix items does anybody read?  The whole-grid pass over the observed prefix of an AR run exists for ONE reason:
+// the column steps read the finished activations of earlier neighbours.  A column reads, per stage, the open taps of its
+// location -- so from the prefix only a band along the frontier; those items read their own open taps one stage
+// earlier, and so on backwards through the 32 stages: a dependency cone, not the whole prefix at every stage (63-83 %
+// of the work for PixelSynth's orders).  Because the generation order sweeps towards the frontier, the cone
+// of a stage is -- up to a few items -- a SUFFIX of the prefix in rank order, so it is kept as one number per (stage,
+// frame): the smallest rank anyone reads; items of lower rank are skipped at that stage (their cache rows keep whatever
+// they held; nothing reads them).  The taps come from the kernel masks themselves, exactly what the kernels follow.
+// One workgroup per frame; starts[(stage id) * F + f] with stage ids: 0 u_init, 1 + g conv_input / nin_skip of gated
+// block g, 15 + g its conv_out, 29 + d dilated conv d.
+// ------------------------------------------------------------------------------------------
+struct StartsArgs {
+    const int32_t *order;   // (F, L)
+    const float *mask_und, *mask_dil;   // (F, 9, L): type B dilation 1 / dilation 2
+    int H, W, L, npre, F;
+    int g_in[NGATED], g_out[NGATED], g_skip[NGATED], d_in[4], d_out[4];
+    int32_t *starts;        // (N_EVAL, F)
+    int f0;                 // frames [f0, f0 + gridDim.x) of the F
+};
+constexpr int STARTS_MAXL = 4096;
+__global__ __launch_bounds__(1024) void k_prefix_starts(StartsArgs a)
+{
+    __shared__ int rank[STARTS_MAXL];   // by location
+    __shared__ int s1[STARTS_MAXL];     // by rank < npre: min rank among the open dilation-1 taps of ranks >= r (suffix minimum)
+    __shared__ int s2[STARTS_MAXL];     //                 the same, dilation-2 taps of the dilated mask
+    __shared__ int cmin[2];             // min rank the COLUMNS (ranks >= npre) read through dilation-1 / dilation-2 taps
+    const int f = a.f0 + blockIdx.x, t = threadIdx.x, L = a.L, npre = a.npre;
+    const int32_t *ord = a.order + (size_t)f * L;
+    for (int r = t; r < L; r += 1024) rank[ord[r]] = r;
+    if (t < 2) cmin[t] = npre;
+    __syncthreads();
+    for (int r = t; r < L; r += 1024) {
+        const int q = ord[r], y = q / a.W, x = q - y * a.W;
+        int m1 = npre, m2 = npre;
+        for (int tap = 0; tap < 9; ++tap) {
+            if (tap == 4) continue;
+            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+            if (a.mask_und[((size_t)f * 9 + tap) * L + q] != 0.0f) {
+                const int yy = y + dy, xx = x + dx;
+                if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) m1 = min(m1, rank[yy * a.W + xx]);
+            }
+            if (a.mask_dil[((size_t)f * 9 + tap) * L + q] != 0.0f) {
+                const int yy = y + 2 * dy, xx = x + 2 * dx;
+                if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) m2 = min(m2, rank[yy * a.W + xx]);
+            }
+        }
+        if (r < npre) { s1[r] = m1; s2[r] = m2; }
+        else { atomicMin(&cmin[0], m1); atomicMin(&cmin[1], m2); }
+    }
+    __syncthreads();
+    for (int off = 1; off < npre; off <<= 1) {   // suffix minima by doubling
+        int v1[STARTS_MAXL / 1024], v2[STARTS_MAXL / 1024];
+#pragma unroll
+        for (int k = 0; k < STARTS_MAXL / 1024; ++k) {
+            const int r = t + 1024 * k;
+            if (r < npre) {
+                v1[k] = r + off < npre ? min(s1[r], s1[r + off]) : s1[r];
+                v2[k] = r + off < npre ? min(s2[r], s2[r + off]) : s2[r];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < STARTS_MAXL / 1024; ++k) {
+            const int r = t + 1024 * k;
+            if (r < npre) { s1[r] = v1[k]; s2[r] = v2[k]; }
+        }
+        __syncthreads();
+    }
+    if (t != 0) return;
+    auto suf = [&](const int *s, int r0) { return r0 >= npre ? npre : min(r0, s[r0]); };   // ranks [r0, npre) and all they read
+    int need[NNODE], needX[NGATED];
+    for (int n = 0; n < NNODE; ++n) need[n] = npre;
+    for (int g = 0; g < NGATED; ++g) { needX[g] = cmin[0]; need[a.g_in[g]] = min(need[a.g_in[g]], cmin[0]); }
+    for (int d = 0; d < 4; ++d) need[a.d_in[d]] = min(need[a.d_in[d]], cmin[1]);
+    // backwards through the stages in execution order (run_grid): G = gated block, D = dilated conv
+    const int kind[18] = {0, 0, 1, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
+    const int idx[18] = {0, 1, 0, 2, 3, 1, 4, 5, 6, 7, 2, 8, 9, 10, 3, 11, 12, 13};
+    int32_t *out = a.starts + f;
+    for (int e = 17; e >= 0; --e) {
+        if (kind[e] == 0) {
+            const int g = idx[e];
+            const int so = need[a.g_out[g]];                     // conv_out + gate evaluated from rank so on
+            out[(size_t)(15 + g) * a.F] = so;
+            needX[g] = min(needX[g], suf(s1, so));               //   reads conv_input's output at its open taps
+            need[a.g_in[g]] = min(need[a.g_in[g]], so);          //   and the residual input at the same location
+            const int si = needX[g];                             // conv_input (+ nin_skip) evaluated from rank si on
+            out[(size_t)(1 + g) * a.F] = si;
+            need[a.g_in[g]] = min(need[a.g_in[g]], suf(s1, si));
+            if (a.g_skip[g] >= 0) need[a.g_skip[g]] = min(need[a.g_skip[g]], si);
+        } else {
+            const int d = idx[e];
+            const int sd = need[a.d_out[d]];
+            out[(size_t)(29 + d) * a.F] = sd;
+            need[a.d_in[d]] = min(need[a.d_in[d]], suf(s2, sd));
+        }
+    }
+    out[0] = need[0];   // u_init + norm_init
+}
+
+struct UinitArgs {
+    ItemMap items;
+    const int32_t *codes;  // (F,L), -1 = all-zero input
+    const float *mask;     // mask_init (F,9,L)
+    const float *w;        // [9][513][NF]
+    const float *bias;
+    float *Rout, *Eout;
+    int H, W, L, nitems;
+};
+
+__global__ __launch_bounds__(256) void k_uinit_grid(UinitArgs a)
+{
+    const int item = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (item >= a.nitems || !item_wanted(a.items, item)) return;
+    int f, q;
+    item_loc(a.items, item, a.L, f, q);
+    const size_t loc = (size_t)f * a.L + q;
+    const bool own = lane < PONO_LANES;
+    const int c = own ? 2 * lane : 0;
+    float mA[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) mA[t] = a.mask[((size_t)f * 9 + t) * a.L + q];
+    const f32x2 y = uinit_gather<f32x2>(a.codes + (size_t)f * a.L, mA, a.w, a.bias, q, a.H, a.W, c);
+    const float mean = pono_mean(pono_total(y, own));   // norm_init
+    const f32x2 d = y - mean;
+    const float inv = pono_inv(pono_total(d * d, own));
+    if (own) store_raw_celu2(a.Rout, a.Eout, loc, c, d * inv);
+}
+
+// logits = nin_out partial + bias; nchw: (F,512,H,W) like the reference, else (nitems,512)
+__global__ __launch_bounds__(256) void k_logits_grid(ItemMap items, const float *partial, const float *bias, int nitems, int L,
+                                                     int nchw, float *logits)
+{
+    const int item = blockIdx.x;
+    int f, q;
+    item_loc(items, item, L, f, q);
+    for (int o = threadIdx.x; o < NCLS; o += 256) {
+        const float v = partial[(size_t)item * NCLS + o] + bias[o];
+        if (nchw) logits[((size_t)f * NCLS + o) * L + q] = v;
+        else logits[((size_t)f * L + q) * NCLS + o] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// generic NCHW lmconv helpers
+// ------------------------------------------------------------------------------------------
+__global__ void k_nchw_to_cl(const float *x, int B, int C, int Cpad, int L, float *out)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)B * L * Cpad) return;
+    const int c = i % Cpad;
+    const size_t bl = i / Cpad;
+    const int l = bl % L;
+    const int b = bl / L;
+    out[i] = c < C ? x[((size_t)b * C + c) * L + l] : 0.0f;
+}
+
+// (Co,Ci,3,3) -> [9][Cpad/4][Co_pad][4]
+__global__ void k_pack_conv(const float *w, int Co, int Ci, int Co_pad, int Cpad, float *out)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t per_tap = (size_t)Cpad * Co_pad;
+    if (i >= 9 * per_tap) return;
+    const int t = i / per_tap;
+    const size_t r = i % per_tap;
+    const int c4 = r / ((size_t)Co_pad * 4);
+    const int o = (r / 4) % Co_pad;
+    const int c = c4 * 4 + (r & 3);
+    out[i] = (o < Co && c < Ci) ? w[((size_t)o * Ci + c) * 9 + t] : 0.0f;
+}
+
+__global__ void k_reduce_nchw(const float *partial, const float *bias, int B, int Co, int Co_pad, int L, float *y)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)B * Co * L) return;
+    const int l = i % L;
+    const int o = (i / L) % Co;
+    const int b = i / ((size_t)L * Co);
+    const size_t nitems = (size_t)B * L, item = (size_t)b * L + l;
+    const size_t ss = nitems * Co_pad, at = item * Co_pad + o;
+    y[i] = slot_sum(bias ? bias[o] : 0.0f, partial[SLOT_NA * ss + at], partial[SLOT_C * ss + at], partial[SLOT_NB * ss + at]);
+}
+
+// 3x3 taps in slot order: NA = taps 0..3, C = tap 4, NB = taps 5..8 (+ optional SKIP appended by the caller)
+void conv_taps(GemmArgs &a, const float *in, int ld, const float *wp, int Cin, int Co_pad, int dil)
+{
+    a.Cin = Cin;
+    a.Co_pad = Co_pad;
+    const size_t per_tap = (size_t)Cin * Co_pad;
+    for (int t = 0; t < 9; ++t)
+        a.tap[t] = GemmTap{in, wp + t * per_tap, (t / 3 - 1) * dil, (t % 3 - 1) * dil, t, ld};
+    a.nslots = 3;
+    a.slot_first[0] = 0; a.slot_first[1] = 4; a.slot_first[2] = 5; a.slot_first[3] = 9; a.slot_first[4] = 9;
+}
+
+// grid of k_gemm: (channel blocks x item blocks x slots) laid out XCD by XCD, see the kernel
+// -> true when the post op `post` was done in the same launch (k_gemm_wg)
+bool launch_gemm(GemmArgs &a, int item_blocks, hipStream_t st, const Tuning &tune, const PostArgs *post = nullptr)
+{
+    a.nx = (a.Co_pad + 16 * GEMM_T - 1) / (16 * GEMM_T);
+    a.ny = item_blocks;
+    a.tpx = (item_blocks + N_XCD - 1) / N_XCD;
+    // one wave per slot while that is what it takes to fill the chip (4096 wave slots): a 16-view prefix is 2870 (tile,
+    // channel block) pairs, one view 180 -- walking all slots in one wave would leave most of the SIMDs idle and make
+    // each wave three times as long
+    a.zgrid = a.nx * a.ny < tune.gemm_merge_min ? a.nslots : 1;
+    if (a.zgrid != 1 || a.nslots < 3) a.sum_bias = nullptr;   // (only a wave that walks NA, C and NB can add them up)
+    // the workgroup form (k_gemm_wg: input rows shared through LDS) from tune.gemm_wg_min item tiles on, for the shapes of the
+    // network's 3x3 convs; it produces the summed form (y in place of slot NA), bit-identical to k_gemm's
+    const bool shape_ok = (a.Cin == 2 * NF || a.Cin == NF) && (a.Co_pad == NF || (a.Co_pad == 2 * NF && a.Cin == 2 * NF));
+    if (a.sum_bias && a.zgrid == 1 && shape_ok && item_blocks >= tune.gemm_wg_min && a.tiles_per_block == 1) {
+        const int kind = a.Co_pad == 2 * NF ? GW_CONVOUT : a.Cin == 2 * NF ? GW_CONVIN : GW_DIL;
+        // item tiles per workgroup (conv_out with 16 items per workgroup: 168 registers, three workgroups per CU -- 0.6 % of the
+        // 128-view step over {2, 2, 2})
+        const int TI = kind == GW_CONVOUT ? tune.wg_ti_out : kind == GW_CONVIN ? tune.wg_ti_in : tune.wg_ti_dil, MI = 16 * TI;
+        a.ny = (a.nitems + MI - 1) / MI;
+        a.tpx = (a.ny + N_XCD - 1) / N_XCD;
+        const dim3 grid((unsigned)(N_XCD * a.tpx)), block(GW_THREADS);
+        const bool fuse = post != nullptr;
+        PostArgs pp{};
+        if (fuse) { pp = *post; pp.summed = 1; }
+        const int fz = fuse ? 1 : 0;
+        if (kind == GW_CONVOUT && TI == 1) hipLaunchKernelGGL((k_gemm_wg<GW_CONVOUT, 1>), grid, block, 0, st, a, pp, fz);
+        else if (kind == GW_CONVOUT) hipLaunchKernelGGL((k_gemm_wg<GW_CONVOUT, 2>), grid, block, 0, st, a, pp, fz);
+        else if (kind == GW_CONVIN && TI == 2) hipLaunchKernelGGL((k_gemm_wg<GW_CONVIN, 2>), grid, block, 0, st, a, pp, fz);
+        else if (kind == GW_CONVIN) hipLaunchKernelGGL((k_gemm_wg<GW_CONVIN, 4>), grid, block, 0, st, a, pp, fz);
+        else if (TI == 2) hipLaunchKernelGGL((k_gemm_wg<GW_DIL, 2>), grid, block, 0, st, a, pp, fz);
+        else hipLaunchKernelGGL((k_gemm_wg<GW_DIL, 4>), grid, block, 0, st, a, pp, fz);
+        return fuse;
+    }
+    hipLaunchKernelGGL(k_gemm, dim3((unsigned)(N_XCD * a.nx * a.tpx * a.zgrid)), dim3(64), 0, st, a);
+    return false;
+}
+
+// ------------------------------------------------------------------------------------------
+// whole-grid evaluation (reference-faithful forward; cache build before the column steps)
+// logits: null (caches only), (F,512,H,W) when nchw, else (F*L,512) by location
+// ------------------------------------------------------------------------------------------
+// (with an order: the pass can be restricted to frames [f0, f0 + nf) of the F -- independent passes over disjoint frame ranges
+// may run on different streams)
+void run_grid(ps_pixelcnn *h, int F, const int32_t *codes, const Masks &m, float *logits, bool nchw, hipStream_t st,
+              const int32_t *order, int npre, int f0, int nf)
+{
+    if (nf < 0) nf = F;
+    const ItemMap all_items{order, order ? npre : h->L, nullptr, f0};
+    const int nitems = nf * all_items.npre;
+    if (nitems <= 0) return;  // an AR run that starts at rank 0 has no prefix
+    const int pblocks = (nitems + 3) / 4;
+    // the prefix of an AR run: only the items somebody reads, stage by stage (k_prefix_starts).  tune.prefix_full: all of them.
+    // (with out_logits the caller also gets the logits of the prefix locations: every item is needed then.  tune.prefix_cone_force
+    // keeps the elimination on for the parity test, which compares the logits of the WALKED locations only.)
+    const bool cone = order && (!logits || h->tune.prefix_cone_force) && h->L <= STARTS_MAXL && !h->tune.prefix_full;
+    if (cone) {
+        StartsArgs sa{order, m.und, m.dil, h->H, h->W, h->L, npre, F, {}, {}, {}, {}, {}, h->pstart, f0};
+        for (int g = 0; g < NGATED; ++g) { sa.g_in[g] = h->gated[g].node_in; sa.g_out[g] = h->gated[g].node_out; sa.g_skip[g] = h->gated[g].node_skip; }
+        for (int d = 0; d < 4; ++d) { sa.d_in[d] = h->dil[d].node_in; sa.d_out[d] = h->dil[d].node_out; }
+        hipLaunchKernelGGL(k_prefix_starts, dim3(nf), dim3(1024), 0, st, sa);
+    }
+    float *const part = h->partial + (size_t)4 * f0 * h->L * (2 * NF);
+    ItemMap items = all_items;
+    auto at_stage = [&](int stage_id) { items.start = cone ? h->pstart + (size_t)stage_id * F : nullptr; };
+    // -> 0: raw slots in `partial`, 1: slots summed by the kernel, 2: the post op `post` done by the kernel as well
+    auto gemm = [&](GemmArgs &a, const float *mask, const float *sum_bias = nullptr, const PostArgs *post = nullptr) {
+        a.items = items;
+        a.H = h->H; a.W = h->W; a.L = h->L; a.nitems = nitems;
+        a.mask = mask; a.mask_fstride = (size_t)9 * h->L; a.tiles_per_block = 1;
+        a.partial = h->partial + (size_t)4 * f0 * h->L * (2 * NF);   // (the frame range's own part of the scratch: passes over disjoint ranges may run side by side)
+        a.sum_bias = sum_bias;
+        const int tiles = (nitems + 15) / 16;
+        if (launch_gemm(a, tiles, st, h->tune, post)) return 2;
+        return a.sum_bias != nullptr ? 1 : 0;
+    };
+    {   // u_init + norm_init  (model.py:132)
+        at_stage(0);
+        UinitArgs u{items, codes, m.init, h->uinit_w, h->uinit_b, h->R[0], h->E[0], h->H, h->W, h->L, nitems};
+        hipLaunchKernelGGL(k_uinit_grid, dim3(pblocks), dim3(256), 0, st, u);
+    }
+    auto gated = [&](int g) {
+        const ps_pixelcnn::Gated &G = h->gated[g];
+        GemmArgs a{};
+        at_stage(1 + g);
+        conv_taps(a, h->E[G.node_in], 2 * NF, G.w_in, 2 * NF, NF, 1);                 // conv_input (layers.py:153)
+        if (G.node_skip >= 0) {                                                         // nin_skip   (layers.py:155-156)
+            a.tap[9] = GemmTap{h->E[G.node_skip], G.w_skip, 0, 0, -1, 2 * NF};
+            a.slot_first[4] = 10;
+            a.nslots = 4;
+        }
+        PostArgs p{items, part, nitems, NF, h->L, G.node_skip >= 0, 0, G.b_in, G.b_skip, nullptr, nullptr, nullptr, h->X[g]};
+        p.summed = gemm(a, m.und, G.b_in, &p);
+        if (p.summed < 2) hipLaunchKernelGGL(k_post_grid<POST_CONVIN>, dim3(pblocks), dim3(256), 0, st, p);
+        GemmArgs b{};
+        at_stage(15 + g);
+        conv_taps(b, h->X[g], 2 * NF, G.w_out, 2 * NF, 2 * NF, 1);                     // conv_out   (layers.py:159)
+        PostArgs q{items, part, nitems, 2 * NF, h->L, 0, 0, G.b_out, nullptr, h->R[G.node_in], h->R[G.node_out],
+                   h->E[G.node_out], nullptr};
+        q.summed = gemm(b, m.und, G.b_out, &q);                                         // gate + residual (:160-163)
+        if (q.summed < 2) hipLaunchKernelGGL(k_post_grid<POST_GATE>, dim3(pblocks), dim3(256), 0, st, q);
+    };
+    auto dilated = [&](int d) {
+        const ps_pixelcnn::Dil &D = h->dil[d];
+        GemmArgs a{};
+        at_stage(29 + d);
+        conv_taps(a, h->R[D.node_in], R_LD, D.w, NF, NF, 2);                            // model.py:138,148
+        PostArgs p{items, part, nitems, NF, h->L, 0, 0, D.b, nullptr, nullptr, h->R[D.node_out], h->E[D.node_out], nullptr};
+        p.summed = gemm(a, m.dil, D.b, &p);
+        if (p.summed < 2) hipLaunchKernelGGL(k_post_grid<POST_DIL>, dim3(pblocks), dim3(256), 0, st, p);
+    };
+    gated(0); gated(1); dilated(0); gated(2); gated(3); dilated(1); gated(4); gated(5);     // up pass
+    gated(6); gated(7); dilated(2); gated(8); gated(9); gated(10); dilated(3);              // down pass
+    gated(11); gated(12); gated(13);
+    if (!logits) return;
+    GemmArgs a{};                                                                         // nin_out(elu(u)) model.py:153
+    a.Cin = NF; a.Co_pad = NCLS; a.nslots = 1;
+    a.slot_first[0] = 0; a.slot_first[1] = 1;
+    a.tap[0] = GemmTap{h->E[NNODE - 1], h->out_w, 0, 0, -1, 2 * NF};
+    gemm(a, nullptr);
+    hipLaunchKernelGGL(k_logits_grid, dim3(nitems), dim3(256), 0, st, items, part, h->out_b, nitems, h->L, nchw ? 1 : 0,
+                       logits);
+}
+
+}  // namespace pslm
+
+using namespace pslm;
+
+extern "C" {
+
+size_t ps_lmconv_workspace_bytes(int B, int Ci, int Co, int H, int W)
+{
+    if (B <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0) return 0;
+    const size_t L = (size_t)H * W, Cp = pad16(Ci), Cop = pad16(Co);
+    size_t o = 0;
+    o = ps::align_up(o + (size_t)B * L * Cp * 4, 256);
+    o = ps::align_up(o + 9 * Cp * Cop * 4, 256);
+    o = ps::align_up(o + 3 * (size_t)B * L * Cop * 4, 256);
+    return o;
+}
+
+int ps_lmconv_forward_f32(const float *x, const float *mask, size_t mask_batch_stride, const float *weight,
+                          const float *bias, int B, int Ci, int Co, int H, int W, int dilation, float *y,
+                          void *workspace, size_t workspace_bytes, void *stream)
+{
+    PS_REQUIRE(x && mask && weight && y && workspace, "lmconv_forward: null pointer");
+    PS_REQUIRE(B > 0 && Ci > 0 && Co > 0 && H > 0 && W > 0 && dilation > 0, "lmconv_forward: bad sizes");
+    const size_t need = ps_lmconv_workspace_bytes(B, Ci, Co, H, W);
+    if (workspace_bytes < need)
+        return ps::fail(PS_ERR_WORKSPACE, "lmconv_forward: workspace %zu < required %zu bytes", workspace_bytes, need);
+    hipStream_t st = (hipStream_t)stream;
+    const int L = H * W, Cp = pad16(Ci), Cop = pad16(Co);
+    char *ws = (char *)workspace;
+    float *xcl = (float *)ws;
+    size_t o = ps::align_up((size_t)B * L * Cp * 4, 256);
+    float *wp = (float *)(ws + o);
+    o = ps::align_up(o + (size_t)9 * Cp * Cop * 4, 256);
+    float *partial = (float *)(ws + o);
+    const size_t n1 = (size_t)B * L * Cp, n2 = (size_t)9 * Cp * Cop, n3 = (size_t)B * Co * L;
+    hipLaunchKernelGGL(k_nchw_to_cl, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, st, x, B, Ci, Cp, L, xcl);
+    hipLaunchKernelGGL(k_pack_conv, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, st, weight, Co, Ci, Cop, Cp, wp);
+    GemmArgs a{};
+    conv_taps(a, xcl, Cp, wp, Cp, Cop, dilation);
+    a.items = ItemMap{nullptr, L, nullptr, 0};
+    a.H = H; a.W = W; a.L = L; a.nitems = B * L; a.mask = mask; a.mask_fstride = mask_batch_stride;
+    a.partial = partial; a.tiles_per_block = 2;
+    const int tiles = (a.nitems + 15) / 16;
+    launch_gemm(a, (tiles + 1) / 2, st, Tuning{});
+    hipLaunchKernelGGL(k_reduce_nchw, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, st, partial, bias, B, Co, Cop, L, y);
+    PS_LAUNCH_CHECK();
+    return PS_OK;
+}
+
+}  // extern "C"

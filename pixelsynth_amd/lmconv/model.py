@@ -64,6 +64,20 @@ class PixelCNNEngine:
         """Synchronise and raise if any column launch of this engine gave up on an in-launch wait (ps_pixelcnn_status)."""
         _lib.check(_lib.lib().ps_pixelcnn_status(self.handle, _lib.current_stream()), "ps_pixelcnn_status")
 
+    def set_tuning(self, **values):
+        """Tuning values of the handle by name (include/pixelsynth_hip_debug.h: ps_pixelcnn_set_tuning) -- which launch form the
+        whole-grid pass takes from which size on, the look-ahead depths of the column launches, ...  None of them changes
+        results; the parity tests use this to run every form inside one process."""
+        for k, v in values.items():
+            _lib.check(_lib.lib().ps_pixelcnn_set_tuning(self.handle, k.encode(), int(v)), f"ps_pixelcnn_set_tuning({k})")
+        return self
+
+    def get_tuning(self, key):
+        v = ctypes.c_int(0)
+        _lib.check(_lib.lib().ps_pixelcnn_get_tuning(self.handle, key.encode(), ctypes.cast(ctypes.byref(v), ctypes.c_void_p)),
+                   f"ps_pixelcnn_get_tuning({key})")
+        return v.value
+
     def close(self):
         if getattr(self, "handle", None):
             _lib.lib().ps_pixelcnn_destroy(self.handle)
@@ -186,6 +200,31 @@ class PixelCNNEngine:
                                             int(first_step), _lib.ptr(logits), _lib.current_stream())
         _lib.check(rc, "ps_pixelcnn_ar_step")
         return logits
+
+
+# Partitions of the 256 compute units this module has been run on.  Others are refused: with 176, 208 or 216 compute units the
+# column launches never got all their workgroups resident (bench runs had to be killed), with 224 they ran at a third of their
+# speed -- how the dispatcher deals workgroups over a masked queue's compute units is not something to guess at.
+VALIDATED_SPLITS = (128, 160, 192)
+
+
+class CuRangeStream:
+    """A torch stream whose kernels run on compute units [first, first + n) only."""
+
+    def __init__(self, first, n, device=None):
+        if (int(first), int(n)) not in [(0, k) for k in VALIDATED_SPLITS] + [(k, 256 - k) for k in VALIDATED_SPLITS]:
+            raise ValueError(f"compute units [{first}, {first + n}): only the splits of 256 at {VALIDATED_SPLITS} have been validated")
+        self.first, self.n = int(first), int(n)
+        self._raw = ctypes.c_void_p()
+        with torch.cuda.device(device if device is not None else torch.cuda.current_device()):
+            _lib.check(_lib.lib().ps_stream_create_cu_range(self.first, self.n, ctypes.byref(self._raw)), "ps_stream_create_cu_range")
+            self.stream = torch.cuda.ExternalStream(self._raw.value)
+
+    def close(self):
+        """Drain the stream.  It is NOT destroyed: torch's caching allocator may still hold events recorded on it (record_stream),
+        and querying them after hipStreamDestroy crashed at interpreter exit; the runtime reclaims the stream with the process."""
+        if getattr(self, "_raw", None) and self._raw.value:
+            self.stream.synchronize()
 
 
 def _resnet_stack(n, nr_filters, nonlinearity, conv_op, feature_norm_op, skip, dropout_prob):

@@ -238,6 +238,20 @@ class ZbufferModelPts(nn.Module):
             new_RT = mtx.bmm(input_RT)
         return torch.inverse(new_RT), new_RT
 
+    # ---------------------------------------------------------------- depth of the source image (forward_image :303-311, :606-612)
+    def regress_depth(self, input_img, given=None):
+        """The reference's depth rule, ONE place for every entry point: the regressor's sigmoid scaled to [min_z, max_z], or
+        1 / (10 sigmoid + 0.01) with opt.use_inverse_depth (landscape datasets), or the given depth with opt.use_gt_depth --
+        and `given` stands in for the regressor when the model has none (the synthetic benchmark)."""
+        if self.pts_regressor is None or getattr(self.opt, "use_gt_depth", False):
+            if given is None:
+                raise ValueError("no depth regressor (or opt.use_gt_depth): the batch must carry the depth")
+            return given
+        raw = torch.sigmoid(self.pts_regressor(input_img))
+        if getattr(self.opt, "use_inverse_depth", False):
+            return 1. / (raw * 10 + 0.01)
+        return raw * (self.opt.max_z - self.opt.min_z) + self.opt.min_z
+
     # ---------------------------------------------------------------- a7
     def get_masks_for_batch(self, output_RT, input_RTinv, background_mask, compact=False):
         """z_buffermodel.py:641-701.  Default return value matches the reference: masks repeated per input
@@ -280,12 +294,13 @@ class ZbufferModelPts(nn.Module):
                 t.record_stream(stream)
 
     @torch.no_grad()
-    def outpaint_planned(self, planned, codes, temperature=0.7, uniforms=None, forced=None, columns_on=None):
+    def outpaint_planned(self, planned, codes, temperature=0.7, uniforms=None, forced=None, between=None):
         """Second half: AR outpainting of the 32x32 code grids (a13) of the views prepared by plan_views; asynchronous
         on the current stream.  Adds `codes` (V,32,32) int32 to the dict and returns it.
-        columns_on: a pixelsynth_amd.pipeline.CuRangeStream -- the column launches go to that stream (confined to its compute
-        units, where no other stream's workgroups can take the compute units a launch needs), the whole-grid prefix pass stays
-        on the current stream, which then waits for the columns.  (Experimental, see pixelsynth_amd/pipeline.py.)"""
+        between: a callable run on the current stream BETWEEN the whole-grid prefix pass and the first column launch (the two
+        halves of the AR run, ps_pixelcnn_ar_prefix / ps_pixelcnn_ar_columns).  bench.py / driver.py make the stream wait there
+        for the previous step's asynchronous frame gather: the collective's kernels then run beside the prefix pass -- whose
+        small workgroups fit around them -- and are through before a column launch asks for every compute unit."""
         gen_fs, plan = planned["gen_fs"], planned["plan"]
         V = gen_fs.shape[0]
         L = self.obs[1] * self.obs[2]
@@ -295,21 +310,16 @@ class ZbufferModelPts(nn.Module):
         eng = self.outpaint2.engine(self.obs[1], self.obs[2], V)
         if forced is None and uniforms is None:
             uniforms = torch.rand(V, L, device=gen_fs.device, dtype=torch.float32)
-        if columns_on is None or plan.waves[0].shape[0] == 0:
+        if between is None or plan.waves[0].shape[0] == 0:
             eng.ar_run(c32, plan.order_loc, plan.region, plan.mask_init, plan.mask_undilated, plan.mask_dilated,
                        temperature=temperature, uniforms=uniforms, forced=forced, first_step=plan.first_step, waves=plan.waves)
+            if between is not None:
+                between()
         else:
-            cur, col = torch.cuda.current_stream(), columns_on.stream
-            eng.set_compute_units(columns_on.n)
             eng.ar_prefix(c32, plan.order_loc, plan.region, plan.mask_init, plan.mask_undilated, plan.mask_dilated, plan.first_step)
-            col.wait_stream(cur)
-            for t in (c32, plan.order_loc, plan.region, plan.mask_init, plan.mask_undilated, plan.mask_dilated, plan.waves[0], uniforms, forced):
-                if t is not None and t.numel():
-                    t.record_stream(col)
-            with torch.cuda.stream(col):
-                eng.ar_columns(c32, plan.order_loc, plan.region, plan.mask_init, plan.mask_undilated, plan.mask_dilated, plan.waves,
-                               temperature=temperature, uniforms=uniforms, forced=forced, first_step=plan.first_step)
-            cur.wait_stream(col)
+            between()
+            eng.ar_columns(c32, plan.order_loc, plan.region, plan.mask_init, plan.mask_undilated, plan.mask_dilated, plan.waves,
+                           temperature=temperature, uniforms=uniforms, forced=forced, first_step=plan.first_step)
         planned["codes"] = c32.view(V, self.obs[1], self.obs[2])
         return planned
 
@@ -336,10 +346,7 @@ class ZbufferModelPts(nn.Module):
         decoder.  src_imgs (n_src,3,S,S); view_src (V,) long: the source of every view; cameras / poses (V,4,4);
         depths (n_src,1,S,S) stands in for the regressor when the model has none.
         -> dict(PredImg (V,3,S,S), FeaturesImg, background_mask, codes, depth)."""
-        if self.pts_regressor is not None:
-            depth_src = torch.sigmoid(self.pts_regressor(src_imgs)) * (self.opt.max_z - self.opt.min_z) + self.opt.min_z   # :303-308
-        else:
-            depth_src = depths
+        depth_src = self.regress_depth(src_imgs, depths)   # :303-311
         fs_src = src_imgs if getattr(self.opt, "use_rgb_features", True) else self.encoder(src_imgs)
         planned = self.plan_views(fs_src[view_src].contiguous(), depth_src[view_src].contiguous(), K, K_inv, input_RT, input_RTinv,
                                   output_RT, output_RTinv)
@@ -366,10 +373,7 @@ class ZbufferModelPts(nn.Module):
             output_RT, output_RTinv = batch["cameras"][-1]["P"].to(dev), batch["cameras"][-1]["Pinv"].to(dev)
         else:
             output_RTinv, output_RT = self.get_rt_from_rot(self.opt.direction, input_RT)
-        if self.pts_regressor is not None:
-            regressed_pts = torch.sigmoid(self.pts_regressor(input_img)) * (self.opt.max_z - self.opt.min_z) + self.opt.min_z
-        else:
-            regressed_pts = batch["depths"][0].to(dev)
+        regressed_pts = self.regress_depth(input_img, batch["depths"][0].to(dev) if "depths" in batch else None)   # :303-311
         fs = input_img if getattr(self.opt, "use_rgb_features", True) else self.encoder(input_img)
         gen_fs, background_mask = self.pts_transformer.forward_justpts(fs, regressed_pts, K, K_inv, input_RT,
                                                                       input_RTinv, output_RT, output_RTinv)
@@ -590,13 +594,7 @@ class ZbufferModelPts(nn.Module):
             output_RT, output_RTinv = batch["cameras"][-1]["P"].to(dev), batch["cameras"][-1]["Pinv"].to(dev)
         else:                                                           # ... a demo-style batch has the direction instead
             output_RTinv, output_RT = self.get_rt_from_rot(self.opt.direction, input_RT)
-        if self.pts_regressor is not None and not getattr(self.opt, "use_gt_depth", False):
-            if getattr(self.opt, "use_inverse_depth", False):            # :606-610
-                regressed_pts = 1. / (torch.sigmoid(self.pts_regressor(input_img)) * 10 + 0.01)
-            else:
-                regressed_pts = torch.sigmoid(self.pts_regressor(input_img)) * (self.opt.max_z - self.opt.min_z) + self.opt.min_z
-        else:
-            regressed_pts = batch["depths"][0].to(dev)
+        regressed_pts = self.regress_depth(input_img, batch["depths"][0].to(dev) if "depths" in batch else None)   # :606-612
         fs = input_img if getattr(self.opt, "use_rgb_features", True) else self.encoder(input_img)
         _, background_mask = self.pts_transformer.forward_justpts(fs, regressed_pts, K, K_inv, input_RT, input_RTinv,
                                                                   output_RT, output_RTinv)

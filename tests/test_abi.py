@@ -13,19 +13,29 @@ from pixelsynth_amd import _lib, synthetic as syn
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def header_symbols():
-    txt = open(os.path.join(ROOT, "include", "pixelsynth_hip.h")).read()
+def header_symbols(name="pixelsynth_hip.h"):
+    txt = open(os.path.join(ROOT, "include", name)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(ps_[a-z0-9_]+)\s*\(", txt)))
 
 
+DEBUG_ONLY = {"ps_pixelcnn_set_tuning", "ps_pixelcnn_get_tuning", "ps_pixelcnn_time_ar_run_waves", "ps_pixelcnn_time_column_step",
+              "ps_pixelcnn_debug_cache"}
+
+
 def test_library_exports_every_declared_symbol():
     L = _lib.lib()
-    names = header_symbols()
+    names, debug = header_symbols(), header_symbols("pixelsynth_hip_debug.h")
     assert len(names) >= 10
-    for n in names:
-        assert hasattr(L, n), f"{n} declared in include/pixelsynth_hip.h but not exported"
-    assert set(_lib.exported_symbols()) == set(names), "python prototypes out of sync with the header"
+    for n in names + debug:
+        assert hasattr(L, n), f"{n} declared in include/ but not exported"
+    assert set(debug) == DEBUG_ONLY and not set(names) & DEBUG_ONLY, "measurement / tuning entry points belong in pixelsynth_hip_debug.h"
+    assert set(_lib.exported_symbols()) == set(names) | set(debug), "python prototypes out of sync with the headers"
+    # ... and nothing else of the ps_ namespace leaves the library
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith("ps_")}
+    assert exported == set(names) | set(debug), exported ^ (set(names) | set(debug))
     assert L.ps_abi_version() == 2
 
 

@@ -154,10 +154,11 @@ def test_network_zero_input_and_batch():
         np.testing.assert_allclose(logits[b], ref[0].numpy(), rtol=1e-4, atol=1e-4)
 
 
-def test_whole_grid_launch_forms_agree_bit_for_bit(monkeypatch):
+def test_whole_grid_launch_forms_agree_bit_for_bit():
     """The launch forms of the whole-grid pass -- one wave per slot with the slots added up by the post op; one wave
-    walking all slots and adding them up itself (taken from 8192 (tile, channel block) pairs on); products and post op
-    fused in one kernel (opt-in) -- give identical logits, and match the torch twin."""
+    walking all slots and adding them up itself (taken from 8192 (tile, channel block) pairs on); the workgroup form with
+    the input rows shared through LDS and the post op in its tail, at every tile size -- give identical logits, and match
+    the torch twin."""
     net = make_net(4)
     sd = {k: torch.from_numpy(v) for k, v in syn.pixelcnn_state_dict(4).items()}
     dmaps = dict(syn.distance_maps())
@@ -168,21 +169,19 @@ def test_whole_grid_launch_forms_agree_bit_for_bit(monkeypatch):
     ms = [np.concatenate([c_oracle.unfolded_masks(o, 32, 32, 3, dil, typ) for o in orders]) for dil, typ in
           ((1, "A"), (1, "B"), (2, "B"))]
     run = lambda: eng.forward(tt(codes), *[tt(m) for m in ms]).cpu()
-    monkeypatch.setenv("PS_GEMM_MERGE_MIN", "0")
+    big = 1 << 30
+    eng.set_tuning(gemm_merge_min=0, gemm_wg_min=big)
     merged = run()
-    monkeypatch.setenv("PS_GEMM_MERGE_MIN", "1000000000")
+    eng.set_tuning(gemm_merge_min=big)
     split = run()
     assert torch.equal(merged, split)
-    monkeypatch.setenv("PS_GEMM_MERGE_MIN", "0")
-    monkeypatch.setenv("PS_GEMM_WG_MIN", "1")         # k_gemm_wg: five-wave workgroups, input rows shared through LDS (large launches)
+    eng.set_tuning(gemm_merge_min=0, gemm_wg_min=1)   # k_gemm_wg: four-wave workgroups, input rows shared through LDS, post op fused (large launches)
     wg = run()
-    monkeypatch.setenv("PS_GEMM_WG_MIN", "1000000000")
-    monkeypatch.setenv("PS_GEMM_MERGE_MIN", "1000000000")
     assert torch.equal(wg, split)
-    monkeypatch.setenv("PS_GEMM_FUSE", "1")          # k_stage_fused: products + post op in one launch (opt-in)
-    fused = run()
-    monkeypatch.delenv("PS_GEMM_FUSE")
-    assert torch.equal(fused, split)
+    for ti in ((2, 2, 2), (1, 4, 4), (2, 4, 2)):      # item tiles per workgroup: conv_out / conv_input / dilated
+        eng.set_tuning(wg_ti_out=ti[0], wg_ti_in=ti[1], wg_ti_dil=ti[2])
+        assert torch.equal(run(), split), ti
+    eng.set_tuning(gemm_merge_min=8192, gemm_wg_min=1024, wg_ti_out=1, wg_ti_in=2, wg_ti_dil=2)
     x = torch.zeros(1, 512, 1024)
     x[0, codes[0], np.arange(1024)] = 1
     with torch.no_grad():
@@ -191,7 +190,7 @@ def test_whole_grid_launch_forms_agree_bit_for_bit(monkeypatch):
 
 
 @pytest.mark.parametrize("F_,first", [(7, 600), (3, 905), (33, 333)])
-def test_workgroup_gemm_form_under_the_prefix_cone_is_bit_identical(F_, first, monkeypatch):
+def test_workgroup_gemm_form_under_the_prefix_cone_is_bit_identical(F_, first):
     """k_gemm_wg (the whole-grid products with the receptive-field rows staged in LDS once per workgroup) against k_gemm on
     the prefix pass of an AR run -- rank-ordered items, ragged last tiles, per-stage start ranks of the dependency cone,
     frames with different orders: sampled codes and the logits of every walked location identical bit for bit."""
@@ -212,17 +211,17 @@ def test_workgroup_gemm_form_under_the_prefix_cone_is_bit_identical(F_, first, m
     codes0 = syn.codes(23, F_).reshape(F_, 1024).astype(np.int32)
     u = tt(np.random.RandomState(5).rand(F_, 1024).astype(np.float32))
     waves = wavefronts(order_loc, 32, 32, first, DEV)
-    monkeypatch.setenv("PS_PREFIX_CONE_FORCE", "1")
-    monkeypatch.setenv("PS_GEMM_MERGE_MIN", "0")
+    eng.set_tuning(prefix_cone_force=1, gemm_merge_min=0)
 
     def run(wg_min):
-        monkeypatch.setenv("PS_GEMM_WG_MIN", wg_min)
+        eng.set_tuning(gemm_wg_min=wg_min)
         c = tt(codes0.copy())
         lg = eng.ar_run(c, tt(order_loc), tt(reg), *ms, temperature=0.7, uniforms=u, first_step=first, want_logits=True, waves=waves)
         eng.check()
         return c, lg
-    c_wg, l_wg = run("1")
-    c_ref, l_ref = run("1000000000")
+    c_wg, l_wg = run(1)
+    c_ref, l_ref = run(1 << 30)
+    eng.set_tuning(prefix_cone_force=0, gemm_merge_min=8192, gemm_wg_min=1024)
     assert torch.equal(c_wg, c_ref)
     walked = np.zeros((F_, 1024), bool)
     for b in range(F_):
@@ -520,17 +519,18 @@ def test_ar_wavefront_schedule_is_bit_identical_to_the_walk(F_, first, cap):
 
 
 @pytest.mark.parametrize("ahead", ["0", "5", "12", "31"])
-def test_throughput_form_look_ahead_depths_are_bit_identical_to_the_walk(ahead, monkeypatch):
-    """k_column_tp's neighbour role computes the slots of the first PS_TP_AHEAD stages of launch i + 1 during launch i, behind
+def test_throughput_form_look_ahead_depths_are_bit_identical_to_the_walk(ahead):
+    """k_column_tp's neighbour role computes the slots of the first tp_ahead stages of launch i + 1 during launch i, behind
     launch i's chain tiles (double-buffered slots and counters, `done` counters published by the chain tiles, write-through
     stores).  Whatever the depth -- none, the default, all but the last stage -- and for full, ragged and oversized (split)
     wavefronts, codes and logits must equal the position-by-position walk bit for bit; the run is repeated on the same handle,
     so the never-reset counters of both parities are exercised past their first use."""
     from pixelsynth_amd.lmconv.model import wavefronts
-    monkeypatch.setenv("PS_TP_AHEAD", ahead)
     net = make_net(3)
     for F_, first, cap in [(72, 640, 1024), (40, 820, 200), (100, 990, 0)]:
-        eng = net.engine(32, 32, F_, slot=100 + int(ahead))     # a handle of its own: the depth is read when it is created
+        eng = net.engine(32, 32, F_, slot=100 + int(ahead))     # a handle of its own: the depth is fixed by the first column launch
+        if eng.get_tuning("tp_ahead") != int(ahead):
+            eng.set_tuning(tp_ahead=int(ahead))
         bgs = syn.background_masks(256)
         names = ["right_half", "half_plus_island", "ragged", "all", "top_band"]
         infos = [c_oracle.masks_for_background(bgs[names[b % 5]], 32) for b in range(F_)]
@@ -559,16 +559,17 @@ def test_throughput_form_look_ahead_depths_are_bit_identical_to_the_walk(ahead, 
 
 
 @pytest.mark.parametrize("ahead", ["0", "5", "28"])
-def test_latency_form_look_ahead_depths_are_bit_identical_to_the_walk(ahead, monkeypatch):
+def test_latency_form_look_ahead_depths_are_bit_identical_to_the_walk(ahead):
     """The same look-ahead in the latency form (k_column_la: the four-wave items of nbr_role for the NEXT launch's columns behind this
     launch's chain workgroups, which publish their stores through the store / control waves): depths other than the default,
     launches of 1 .. 128 columns, oversized wavefronts split by the launcher, a run repeated on the same handle, and a walk
     position by position (k_column, one use count for all stages) on that handle in between."""
     from pixelsynth_amd.lmconv.model import wavefronts
-    monkeypatch.setenv("PS_COL_AHEAD", ahead)
     net = make_net(3)
     for F_, first, cap in [(5, 320, 128), (20, 700, 16), (40, 900, 0)]:
-        eng = net.engine(32, 32, F_, slot=200 + int(ahead))     # a handle of its own: the depth is read when it is created
+        eng = net.engine(32, 32, F_, slot=200 + int(ahead))     # a handle of its own: the depth is fixed by the first column launch
+        if eng.get_tuning("col_ahead") != int(ahead):
+            eng.set_tuning(col_ahead=int(ahead))
         bgs = syn.background_masks(256)
         names = ["right_half", "half_plus_island", "ragged", "all", "top_band"]
         infos = [c_oracle.masks_for_background(bgs[names[b % 5]], 32) for b in range(F_)]
@@ -621,10 +622,10 @@ def test_ar_run_waves_rejects_a_schedule_of_another_run():
 
 
 @pytest.mark.parametrize("F_,first", [(5, 320), (12, 600), (3, 905), (40, 640)])   # (40 frames: throughput-form column launches)
-def test_prefix_pass_evaluates_only_what_is_read(F_, first, monkeypatch):
+def test_prefix_pass_evaluates_only_what_is_read(F_, first):
     """The whole-grid pass over the observed prefix skips, stage by stage, the items nobody reads (k_prefix_starts): the
     device's (33, F) table of start ranks equals the numpy restatement (oracle/prefix_cone_oracle.py), and codes and
-    logits are bit-identical to a run that evaluates the whole prefix at every stage (PS_PREFIX_FULL=1)."""
+    logits are bit-identical to a run that evaluates the whole prefix at every stage (tuning value prefix_full)."""
     import ctypes
     from oracle import prefix_cone_oracle as pc
     from pixelsynth_amd import _lib
@@ -651,9 +652,9 @@ def test_prefix_pass_evaluates_only_what_is_read(F_, first, monkeypatch):
         lg = eng.ar_run(c, tt(order_loc), tt(reg), *ms, temperature=0.7, uniforms=u, first_step=first, want_logits=True, waves=waves)
         eng.check()
         return c, lg
-    monkeypatch.setenv("PS_PREFIX_CONE_FORCE", "1")   # (a run that returns logits evaluates the whole prefix otherwise)
+    eng.set_tuning(prefix_cone_force=1)   # (a run that returns logits evaluates the whole prefix otherwise)
     c_cone, l_cone = run()
-    monkeypatch.delenv("PS_PREFIX_CONE_FORCE")
+    eng.set_tuning(prefix_cone_force=0)
     # the table the prefix pass just used
     L = _lib.lib()
     L.ps_pixelcnn_debug_cache.restype = ctypes.c_void_p
@@ -666,8 +667,9 @@ def test_prefix_pass_evaluates_only_what_is_read(F_, first, monkeypatch):
         want = pc.prefix_starts(order_loc[b].astype(np.int64), infos[b]["mask_undilated"][0], infos[b]["mask_dilated"][0], 32, 32, first)
         assert np.array_equal(got[:, b], want), b
     assert (got < first).any() and (got > 0).any()   # something is evaluated, something is skipped
-    monkeypatch.setenv("PS_PREFIX_FULL", "1")
+    eng.set_tuning(prefix_full=1)
     c_full, l_full = run()
+    eng.set_tuning(prefix_full=0)
     assert torch.equal(c_cone, c_full)
     walked = np.zeros((F_, 1024), bool)
     for b in range(F_):
@@ -676,7 +678,7 @@ def test_prefix_pass_evaluates_only_what_is_read(F_, first, monkeypatch):
 
 
 @pytest.mark.parametrize("H,W", [(16, 16), (8, 12)])
-def test_prefix_cone_on_other_grids_and_random_orders(H, W, monkeypatch):
+def test_prefix_cone_on_other_grids_and_random_orders(H, W):
     """k_prefix_starts on a square and a non-square grid with RANDOM generation orders (where the cone of a stage is far
     from a suffix of the prefix, so the start ranks give away a lot -- but never too little): device table == numpy
     restatement, codes and walked logits identical to the full prefix."""
@@ -703,9 +705,9 @@ def test_prefix_cone_on_other_grids_and_random_orders(H, W, monkeypatch):
         lg = eng.ar_run(c, tt(order_loc), tt(reg), *ms, temperature=0.9, uniforms=u, first_step=first, want_logits=True)
         eng.check()
         return c, lg
-    monkeypatch.setenv("PS_PREFIX_CONE_FORCE", "1")
+    eng.set_tuning(prefix_cone_force=1)
     c_cone, l_cone = run()
-    monkeypatch.delenv("PS_PREFIX_CONE_FORCE")
+    eng.set_tuning(prefix_cone_force=0)
     lib = _lib.lib()
     lib.ps_pixelcnn_debug_cache.restype = ctypes.c_void_p
     ptr = lib.ps_pixelcnn_debug_cache(eng.handle, 5, 0)
@@ -715,8 +717,9 @@ def test_prefix_cone_on_other_grids_and_random_orders(H, W, monkeypatch):
     for b in range(F_):
         want = pc.prefix_starts(order_loc[b].astype(np.int64), masks[1][b], masks[2][b], H, W, first)
         assert np.array_equal(got[:, b], want), b
-    monkeypatch.setenv("PS_PREFIX_FULL", "1")
+    eng.set_tuning(prefix_full=1)
     c_full, l_full = run()
+    eng.set_tuning(prefix_full=0)
     assert torch.equal(c_cone, c_full)
     walked = np.zeros((F_, L), bool)
     for b in range(F_):
@@ -730,7 +733,7 @@ def test_ar_prefix_and_columns_as_separate_calls_equal_the_run():
     (ps_stream_create_cu_range) -- followed by ps_pixelcnn_ar_columns on a handle told how many compute units its stream has,
     gives the codes of ps_pixelcnn_ar_run_waves bit for bit."""
     from pixelsynth_amd.lmconv.model import wavefronts
-    from pixelsynth_amd.pipeline import CuRangeStream
+    from pixelsynth_amd.lmconv.model import CuRangeStream
     net = make_net(3)
     F_, first = 70, 800
     bgs = syn.background_masks(256)
@@ -769,4 +772,8 @@ def test_ar_prefix_and_columns_as_separate_calls_equal_the_run():
     eng2.check()
     eng2.set_compute_units(0)
     assert torch.equal(c, c_ref)
+    # a frame range that is not a range of the run is an error, not "all frames" (round-3 advice)
+    for lo, hi in ((0, -1), (5, 3), (0, F_ + 1), (-1, 4)):
+        with pytest.raises(RuntimeError, match="not a range"):
+            eng2.ar_prefix(c, o, r, *ms, first, lo, hi)
     assert (c.cpu().numpy()[reg == 1] != codes0[reg == 1]).any()

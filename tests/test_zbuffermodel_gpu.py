@@ -516,31 +516,3 @@ def test_sharded_sample_ranking_two_ranks_equals_one(tmp_path):
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-3000:]
 
 
-def test_overlapped_outpainter_equals_batch_by_batch():
-    """pixelsynth_amd.pipeline.OverlappedOutpainter (column launches of batch i and front + prefix pass of batch i + 1 on two
-    compute-unit partitions, two engine handles) returns, batch for batch, exactly what outpaint_views returns."""
-    import sys
-    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    import bench
-    from pixelsynth_amd.pipeline import OverlappedOutpainter
-    dev = torch.device(DEV)
-    model = bench.build_model(dev)
-    V = 64
-    batches = []
-    for k in range(3):
-        d, _ = bench.make_inputs(k, V, dev)
-        batches.append(dict(img=d["img"], depth=d["depth"], K=d["K"], Kinv=d["Kinv"], P=d["P"], Pinv=d["Pinv"], RT2=d["RT2"],
-                            RT2inv=d["RT2inv"], codes=d["codes"], uniforms=d["uniforms"]))
-    want = []
-    for b in batches:
-        o = model.outpaint_views(b["img"], b["depth"], b["K"], b["Kinv"], b["P"], b["Pinv"], b["RT2"], b["RT2inv"], b["codes"],
-                                 temperature=0.7, uniforms=b["uniforms"])
-        want.append((o["codes"].clone(), o["gen_fs"].clone()))
-    runner = OverlappedOutpainter(model, cus_main=160, prefix_share=0.5, device=dev)
-    outs = runner.run(batches, temperature=0.7)
-    torch.cuda.synchronize()
-    runner.check()
-    runner.close()
-    for (c, g), o in zip(want, outs):
-        assert torch.equal(o["codes"], c) and torch.equal(o["gen_fs"], g)
-    assert not torch.equal(outs[0]["codes"], outs[1]["codes"])

@@ -11,7 +11,8 @@ stream's workgroups (which is also why round 2's unmasked side stream made an in
 
 MEASURED (round 3, C5's 128 views per batch): 24.4 ms per batch against 22.3 ms for the one-stream pipeline of bench.py -- the
 column launches run at 200-217 us on 160 compute units where their share of the chip predicts 167, and stream B is saturated by
-the splat and 60 % of a prefix pass.  Kept as an opt-in experiment (bench.py --overlap), not the default.
+the splat and 60 % of a prefix pass.  An experiment that LOST (round 3): moved out of the package in round 4; it needs
+`columns_on` support in ZbufferModelPts.outpaint_planned, which went with it (git history: round 3, pixelsynth_amd/pipeline.py).
 
 The batches are independent (the same work as `outpaint_views` batch by batch, bit-identical results: the prefix pass of
 disjoint frame ranges is independent, and each batch has its own engine handle, i.e. its own activation caches).
@@ -21,32 +22,12 @@ import ctypes
 
 import torch
 
-from . import _lib
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from pixelsynth_amd import _lib  # noqa: E402
 
 
-# Partitions of the 256 compute units this module has been run on.  Others are refused: with 176, 208 or 216 compute units the
-# column launches never got all their workgroups resident (bench runs had to be killed), with 224 they ran at a third of their
-# speed -- how the dispatcher deals workgroups over a masked queue's compute units is not something to guess at.
-VALIDATED_SPLITS = (128, 160, 192)
-
-
-class CuRangeStream:
-    """A torch stream whose kernels run on compute units [first, first + n) only."""
-
-    def __init__(self, first, n, device=None):
-        if (int(first), int(n)) not in [(0, k) for k in VALIDATED_SPLITS] + [(k, 256 - k) for k in VALIDATED_SPLITS]:
-            raise ValueError(f"compute units [{first}, {first + n}): only the splits of 256 at {VALIDATED_SPLITS} have been validated")
-        self.first, self.n = int(first), int(n)
-        self._raw = ctypes.c_void_p()
-        with torch.cuda.device(device if device is not None else torch.cuda.current_device()):
-            _lib.check(_lib.lib().ps_stream_create_cu_range(self.first, self.n, ctypes.byref(self._raw)), "ps_stream_create_cu_range")
-            self.stream = torch.cuda.ExternalStream(self._raw.value)
-
-    def close(self):
-        """Drain the stream.  It is NOT destroyed: torch's caching allocator may still hold events recorded on it (record_stream),
-        and querying them after hipStreamDestroy crashed at interpreter exit; the runtime reclaims the stream with the process."""
-        if getattr(self, "_raw", None) and self._raw.value:
-            self.stream.synchronize()
+from pixelsynth_amd.lmconv.model import CuRangeStream, VALIDATED_SPLITS  # noqa: F401
 
 
 class OverlappedOutpainter:
