@@ -152,6 +152,9 @@ const TuningEntry tuning_table[] = {
     {"tp_ahead", &Tuning::tp_ahead, 0, NST - 2}, {"col_ahead", &Tuning::col_ahead, 0, NST - 4},
     {"tp_min_cols", &Tuning::tp_min_cols, 1, 1 << 30}, {"tp_xcds", &Tuning::tp_xcds, -1, 7}, {"tp_fill", &Tuning::tp_fill, 0, 1},
     {"col_cap", &Tuning::col_cap, 1, COL_CAP}, {"chain_xcds", &Tuning::chain_xcds, 0, 8}, {"nbr_groups", &Tuning::nbr_groups, 0, NBR_MAX_GROUPS},
+#ifdef PS_TUNING_BUILD   // timing experiments whose results are INVALID (1: chains do not wait for the neighbour slots, 2: no chains, 3: no
+    {"column_debug", &Tuning::column_debug, 0, 1 << 20},   // neighbour role and no waiting; + 256 x the traced wave): tuning builds only
+#endif
 };
 const TuningEntry *find_tuning(const char *key)
 {
@@ -316,7 +319,7 @@ void run_columns(ps_pixelcnn *h, const StepCtx *rec, int ncols, const int32_t *c
     ca.out_b = h->out_b;
     ca.H = h->H; ca.W = h->W; ca.L = h->L; ca.col_stride = COL_CAP;
     ca.cnt = h->cnt; ca.err = h->err;
-    ca.debug = h->column_debug;   // (0 outside tuning builds)
+    ca.debug = h->tune.column_debug;   // (0 outside tuning builds)
     if (ncols >= h->tune.tp_min_cols) run_columns_tp(h, rec, ncols, ca, st, next_rec, next_ncols);
     else run_columns_la(h, rec, ncols, ca, st, next_rec, next_ncols);
 }
@@ -377,9 +380,6 @@ int ps_pixelcnn_create(const float *const *params, int n_params, int H, int W, i
     tuning_from_env(h->tune);
     h->env_col_cap = h->tune.col_cap;
     h->tune.col_cap = std::min(h->env_col_cap, (h->n_cus / 8) * 4);   // at most four XCDs of chains, the rest for the neighbour role
-#ifdef PS_TUNING_BUILD   // timing experiments whose results are INVALID (chains that do not wait, roles switched off): tuning builds only
-    if (const char *dbg = getenv("PS_COLUMN_DEBUG")) h->column_debug = atoi(dbg);
-#endif
 
     int rc = PS_OK;
     auto fail_out = [&](int code) { ps_pixelcnn_destroy(h); return code; };
@@ -688,8 +688,8 @@ void *ps_pixelcnn_debug_cache(ps_pixelcnn *h, int what, int idx)
     if (what == 6) { void *p = nullptr; return hipGetSymbolAddress(&p, HIP_SYMBOL(g_wg_trace)) == hipSuccess ? p : nullptr; }
     if (what == 7) { void *p = nullptr; return hipGetSymbolAddress(&p, HIP_SYMBOL(g_wg_span)) == hipSuccess ? p : nullptr; }
 #endif
-    if (what == 4) {                   // tuning builds: allocate / return the stamp buffer [NST][8] of 64-bit clocks
-        if (!h->tp_trace && dev_alloc(h, &h->tp_trace, (size_t)NST * 8) == PS_OK) (void)hipMemset(h->tp_trace, 0, NST * 8 * 8);
+    if (what == 4) {                   // tuning builds: allocate / return the stamp buffer [2][NST][8] of 64-bit clocks
+        if (!h->tp_trace && dev_alloc(h, &h->tp_trace, (size_t)3 * NST * 8) == PS_OK) (void)hipMemset(h->tp_trace, 0, 3 * NST * 8 * 8);
         return h->tp_trace;
     }
     return nullptr;

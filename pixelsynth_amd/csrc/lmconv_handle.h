@@ -95,6 +95,7 @@ struct Tuning {
     int col_cap = COL_CAP;       // columns per latency-form launch
     int chain_xcds = 0;          // latency form: XCDs that hold chain workgroups (0 = automatic)
     int nbr_groups = 0;          // latency form: work items a neighbour workgroup runs at a time (0 = automatic)
+    int column_debug = 0;        // settable in tuning builds only (-DPS_TUNING_BUILD): timing experiments whose results are INVALID
 };
 
 }  // namespace pslm
@@ -151,7 +152,6 @@ struct ps_pixelcnn {
     bool xcd_even = true;           // n_cus is an even share of the 8 XCDs of a whole MI355X (block b runs on XCD b % 8)
     pslm::Tuning tune;
     int env_col_cap = 0;            // PS_COL_CAP as read at creation (re-applied when the compute-unit count changes)
-    int column_debug = 0;           // tuning builds only (-DPS_TUNING_BUILD, PS_COLUMN_DEBUG): timing experiments whose results are INVALID
     // bench.py profiling aid (ps_pixelcnn_time_column_step): event pair around every launch, by kernel tag
     struct ProfRec { int tag; hipEvent_t e0, e1; };
     std::vector<ProfRec> *prof = nullptr;

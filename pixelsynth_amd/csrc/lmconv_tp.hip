@@ -285,16 +285,25 @@ __device__ __forceinline__ void chain_role_tp(const TpArgs &a, int tile)
     }
     const size_t nbr_half = (size_t)TP_COL_CAP * NBR_LD, nbr_stage = 2 * nbr_half;
     const unsigned uses_lo = a.tile_uses_lo[tile], uses_hi = a.tile_uses_hi[tile];
-    auto counter = [&](int k) { return __hip_atomic_load(a.cnt + tp_cnt_index(k, tile), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    // The counter is requested a stage before it is looked at.  It must stay a VECTOR value until then (round 4, read off the ISA): a
+    // wave-uniform load is turned into a scalar by v_readfirstlane where it is ISSUED, i.e. the wave waits for it on the spot -- and,
+    // vmcnt retiring in order, for every store and weight request in front of it; and a polling loop that reloads the value makes
+    // the compiler wait for ALL outstanding memory operations at the loop's head, so the first look is peeled off the loop.  The
+    // lane offset below is zero, but not to the compiler.
+    int vzero = 0;
+    asm volatile("" : "+v"(vzero));
+    auto counter = [&](int k) { return __hip_atomic_load(a.cnt + tp_cnt_index(k, tile) + vzero, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
     // `have`: the counter as requested a stage earlier (normally past the target already); bounded
     auto wait_counter = [&](unsigned have, int k, unsigned items_per_tile) {
         if (a.debug & 1) return;
         const unsigned need = (k < a.split ? uses_lo : uses_hi) * items_per_tile;
-        int spins = 0;
-        while ((int)(have - need) < 0) {
-            if (++spins > WAIT_SPINS) { if (lane == 0) *a.err = 1; break; }
-            __builtin_amdgcn_s_sleep(2);
-            have = counter(k);
+        if (__builtin_amdgcn_ballot_w64((int)(have - need) < 0) != 0ull) {
+            int spins = 0;
+            do {
+                if (++spins > WAIT_SPINS) { if (lane == 0) *a.err = 1; break; }
+                __builtin_amdgcn_s_sleep(2);
+                have = counter(k);
+            } while (__builtin_amdgcn_ballot_w64((int)(have - need) < 0) != 0ull);
         }
         asm volatile("" ::: "memory");
     };
