@@ -1,6 +1,8 @@
 """Tuning aid: average k_column / k_column_tp launch of a whole AR run of V views (HIP events around every launch), as is and
-with a role switched off (PS_COLUMN_DEBUG: 1 = chains do not wait for the neighbour slots, 2 = no chains, 3 = no neighbour role
-and no waiting).   usage: python tools/tp_time.py [views] [modes e.g. 0,2,3]"""
+with a role switched off (tuning value column_debug, which exists in -DPS_TUNING_BUILD builds only: 1 = chains do not wait for the
+neighbour slots, 2 = no chains, 3 = no neighbour role and no waiting; the codes of such runs are INVALID).
+usage: bash tools/tp_trace.sh is the model for the build; then
+   PS_HIP_LIB=gpurun_out/libps_trace.so python tools/tp_time.py [views] [modes e.g. 0,2,3]"""
 import ctypes
 import os
 import sys
@@ -22,7 +24,7 @@ eng = model.outpaint2.engine(32, 32, V)
 cols, wave_start = plan.waves
 print(f"V={V}: {cols.shape[0]} columns in {len(wave_start) - 1} waves, first_step {plan.first_step}")
 for mode in modes:
-    os.environ["PS_COLUMN_DEBUG"] = str(mode)
+    eng.set_tuning(column_debug=mode)
     launches, total_ms, fpc = ctypes.c_int(0), ctypes.c_float(0.0), ctypes.c_double(0.0)
     res = []
     for _ in range(3):
@@ -42,4 +44,4 @@ for mode in modes:
         eng.check()
     except RuntimeError as e:
         print("   (status:", str(e)[:80], ")")
-os.environ["PS_COLUMN_DEBUG"] = "0"
+eng.set_tuning(column_debug=0)
