@@ -324,6 +324,12 @@ enum { GW_CONVOUT = 0, GW_CONVIN = 1, GW_DIL = 2 };
 __device__ unsigned long long g_wg_trace[3][32][16];
 __device__ unsigned long long g_wg_span[3][4096][2];   // wall clock (100 MHz) at the start and the end of every workgroup, + hw id
 #define WG_STAMP(k) do { if (y < 32 && tid == 0 && (k) < 16) g_wg_trace[KIND][y][(k)] = clock64(); } while (0)
+void *wg_trace_symbol(int what)
+{
+    void *p = nullptr;
+    const hipError_t e = what == 6 ? hipGetSymbolAddress(&p, HIP_SYMBOL(g_wg_trace)) : hipGetSymbolAddress(&p, HIP_SYMBOL(g_wg_span));
+    return e == hipSuccess ? p : nullptr;
+}
 #else
 #define WG_STAMP(k) do { } while (0)
 #endif

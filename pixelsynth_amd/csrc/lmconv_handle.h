@@ -210,5 +210,8 @@ void launch_pack_valu_out(const float *wo, float *out);
 void run_columns_tp(ps_pixelcnn *h, const StepCtx *rec, int ncols, const ChainArgs &ca, hipStream_t st, const StepCtx *next_rec, int next_ncols);
 int tp_weights_floats(int type);   // floats of a stage's centre-tap (+ nin_skip) weights in the throughput chain role's own order
 void launch_pack_tp(const float *wc, const float *ws, int Co, int NG, int type, float *out);
+#ifdef PS_WG_TRACE_BUILD
+void *wg_trace_symbol(int what);   // k_gemm_wg's stamp arrays (lmconv_grid.hip), tuning builds
+#endif
 
 }  // namespace pslm

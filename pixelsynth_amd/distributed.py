@@ -74,8 +74,11 @@ class PendingGather:
 def gather_frames_start(local, n_views=None):
     """Start the all_gather of the finished frames and return at once (-> PendingGather): the collective runs on the backend's own
     stream, behind what the current stream has enqueued so far, and whatever the caller enqueues next -- the following batch's
-    whole-grid pass -- runs beside it.  (Beside COLUMN launches it would gain nothing: a launch wants every compute unit, and
-    waits for the ones the collective's kernels hold.)  local as for gather_frames."""
+    whole-grid pass -- runs beside it.  It must be COLLECTED (PendingGather.result(): the current stream waits for it) before the
+    caller's next column launch is enqueued: a column launch keeps one workgroup per compute unit resident, and its in-launch
+    waits are bounded -- a collective kernel still holding compute units when the launch starts would stall it.  bench.py does so
+    through outpaint_planned(between=...), between the next step's prefix pass and its first column launch.
+    local as for gather_frames."""
     rank, w = world()
     if w == 1:
         return PendingGather(local, n_views)

@@ -2,7 +2,8 @@
 ps_pixelcnn_time_column_step).
 usage: python tools/column_time.py [views] [reps]
 env: PS_CHAIN_TRACE=file (needs a -DPS_CHAIN_TRACE_BUILD build; read with tools/chain_trace.py),
-     PS_COLUMN_DEBUG=1|2|3 (chains do not wait / no chains / no neighbour role), PS_COL_CAP, PS_CHAIN_XCDS, PS_NBR_GROUPS"""
+     PS_COLUMN_DEBUG=1|2|3 (chains do not wait / no chains / no neighbour role; a -DPS_TUNING_BUILD build only), PS_COL_CAP,
+     PS_CHAIN_XCDS, PS_NBR_GROUPS (tuning values, read when the handle is created)"""
 import ctypes
 import os
 import sys

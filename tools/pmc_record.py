@@ -1,0 +1,75 @@
+"""Builds profiles/<tag>_k_column_pmc.json -- the record bench.py's roofline.traffic / mfma_counters come from -- out of what
+tools/collect_profiles.sh <tag> left under gpurun_out/<tag>/ (pmc_summary.txt: rocprofv3 --pmc, one pass per group; kernel_stats.csv:
+the kernel-trace pass).   usage: python tools/pmc_record.py <tag> [views]"""
+import csv
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+tag = sys.argv[1]
+views = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", tag)
+pmc = defaultdict(dict)      # kernel -> counter -> (dispatches, mean)
+for line in open(os.path.join(root, "pmc_summary.txt")):
+    m = re.match(r"\s+(\S.*?)\s+(\w+)\s+dispatches\s+(\d+)\s+mean\s+([\d.]+)\s+total", line)
+    if m:
+        pmc[m.group(1).replace("pslm::", "")][m.group(2)] = (int(m.group(3)), float(m.group(4)))
+avg_us = {}
+for r in csv.DictReader(open(os.path.join(root, "kernel_stats.csv"))):
+    n = r["Name"].replace("(anonymous namespace)::", "").replace("void ", "").replace("pslm::", "")
+    avg_us[n.split("(")[0]] = float(r["AverageNs"]) / 1e3
+CLK = 2.4e3   # shader cycles per us
+SIMDS = 1024
+
+
+def busy(kernel):   # v_mfma_f32_16x16x4_f32: 32 cycles each
+    n = pmc[kernel]["SQ_INSTS_MFMA"][1]
+    return round(n * 32 / SIMDS / (avg_us[kernel] * CLK), 4)
+
+
+def traffic(kernel):   # gfx950: FETCH_SIZE (KB) reports half of the bytes of wide coalesced reads -> doubled; WRITE_SIZE as is
+    return int(round((2 * pmc[kernel]["FETCH_SIZE"][1] + pmc[kernel]["WRITE_SIZE"][1]) * 1024))
+
+
+tp, la = "k_column_tp", "k_column_la"
+ntp, nla = pmc[tp]["FETCH_SIZE"][0], pmc[la]["FETCH_SIZE"][0]
+rec = {
+    "kernel": f"k_column_tp ({ntp} dispatches) + k_column_la ({nla}: wavefronts of up to 256 columns as two latency-form launches)",
+    "views": views,
+    "workload": "bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra (C5: 8 sources x 16 views = 128 views per GPU; 3 pipelined steps + "
+                "the 3 timed AR runs of measure_roofline)",
+    "dispatches": ntp + nla,
+    "FETCH_SIZE_KB_mean": round((pmc[tp]["FETCH_SIZE"][1] * ntp + pmc[la]["FETCH_SIZE"][1] * nla) / (ntp + nla), 3),
+    "WRITE_SIZE_KB_mean": round((pmc[tp]["WRITE_SIZE"][1] * ntp + pmc[la]["WRITE_SIZE"][1] * nla) / (ntp + nla), 3),
+    "correction": "MI355X_MICROARCH.md / HBM: on gfx950 FETCH_SIZE reports 1/2 of the bytes of wide (16 B/lane) coalesced streaming reads -> "
+                  "doubled; WRITE_SIZE uncalibrated, taken as is; both count the L2's memory-side requests (Infinity-Cache hits included)",
+    "traffic_bytes_per_launch": int(round((traffic(tp) * ntp + traffic(la) * nla) / (ntp + nla))),
+    "mfma": {
+        "SQ_INSTS_MFMA_per_launch": int(round((pmc[tp]["SQ_INSTS_MFMA"][1] * ntp + pmc[la]["SQ_INSTS_MFMA"][1] * nla) / (ntp + nla))),
+        "mfma_busy_fraction_of_all_simd_cycles": round((busy(tp) * avg_us[tp] * ntp + busy(la) * avg_us[la] * nla)
+                                                       / (avg_us[tp] * ntp + avg_us[la] * nla), 4),
+        tp: {"SQ_INSTS_MFMA_per_launch": int(pmc[tp]["SQ_INSTS_MFMA"][1]), "mfma_busy_fraction_of_all_simd_cycles": busy(tp),
+             "avg_us_under_trace": round(avg_us[tp], 1)},
+        la: {"SQ_INSTS_MFMA_per_launch": int(pmc[la]["SQ_INSTS_MFMA"][1]), "mfma_busy_fraction_of_all_simd_cycles": busy(la),
+             "avg_us_under_trace": round(avg_us[la], 1),
+             "note": "the latency form's chains are fp32 FMA on the vector ALU; MFMA only in the neighbour role"},
+        "note": "v_mfma_f32_16x16x4_f32 only (32 cycles each), all 1024 SIMDs at 2.4 GHz, whole launches (durations of the kernel-trace pass)",
+    },
+    "per_kernel": {k: {"dispatches": pmc[k]["FETCH_SIZE"][0], "FETCH_SIZE_KB_mean": round(pmc[k]["FETCH_SIZE"][1]),
+                       "WRITE_SIZE_KB_mean": round(pmc[k]["WRITE_SIZE"][1]), "traffic_bytes_per_launch": traffic(k)} for k in (tp, la)},
+    "k_gemm_wg": {k: {"dispatches": pmc[k]["FETCH_SIZE"][0], "FETCH_SIZE_KB_mean": round(pmc[k]["FETCH_SIZE"][1]),
+                      "WRITE_SIZE_KB_mean": round(pmc[k]["WRITE_SIZE"][1]), "SQ_INSTS_MFMA_per_launch": int(pmc[k]["SQ_INSTS_MFMA"][1]),
+                      "avg_us_under_trace": round(avg_us[k], 1), "mfma_busy_fraction_of_all_simd_cycles": busy(k)}
+                  for k in sorted(pmc) if k.startswith("k_gemm_wg")},
+    "source": f"profiles/{tag}_bench_v{views}_pmc_summary.txt + profiles/{tag}_bench_v{views}_kernel_stats.csv (tools/collect_profiles.sh {tag}; "
+              "tools/pmc_record.py); traffic_bytes_per_launch is the average over ALL column launches of an AR run, as bench.py's avg_launch_us is",
+}
+out = os.path.join(os.path.dirname(root), "..", "profiles")
+for src, dst in (("kernel_stats.csv", f"{tag}_bench_v{views}_kernel_stats.csv"), ("pmc_summary.txt", f"{tag}_bench_v{views}_pmc_summary.txt")):
+    with open(os.path.join(root, src)) as fi, open(os.path.join(out, dst), "w") as fo:
+        fo.write(fi.read())
+with open(os.path.join(out, f"{tag}_k_column_pmc.json"), "w") as fh:
+    json.dump(rec, fh, indent=1)
+print(json.dumps(rec, indent=1))

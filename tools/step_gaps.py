@@ -7,7 +7,7 @@ from collections import defaultdict
 rows = list(csv.DictReader(open(sys.argv[1])))
 for r in rows:
     r["s"], r["e"] = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
-    r["n"] = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:30]
+    r["n"] = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("pslm::", "").replace("void ", "").split("(")[0][:30]
 rows.sort(key=lambda r: r["s"])
 mainq = max(set(r["Queue_Id"] for r in rows), key=lambda q: sum(1 for r in rows if r["Queue_Id"] == q and r["n"].startswith("k_column")))
 main = [r for r in rows if r["Queue_Id"] == mainq]

@@ -1,9 +1,10 @@
 #!/bin/bash
-# k_gemm_wg: item tiles per workgroup (PS_WG_TI = out,in,dil): bit-identity tests and kernel times per combination
+# k_gemm_wg: item tiles per workgroup (arguments like 1,2,2 = tuning values wg_ti_out, wg_ti_in, wg_ti_dil, set through
+# PS_WG_TI_OUT / PS_WG_TI_IN / PS_WG_TI_DIL at handle creation): bit-identity tests and kernel times per combination
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for ti in "$@"; do
-  export PS_WG_TI=$ti
-  echo "== PS_WG_TI=$ti: $(python -m pytest tests/test_lmconv_gpu.py -x -q -k 'launch_forms or workgroup_gemm' 2>&1 | tail -1)"
+  IFS=, read o i d <<< "$ti"; export PS_WG_TI_OUT=$o PS_WG_TI_IN=$i PS_WG_TI_DIL=$d
+  echo "== wg_ti out,in,dil = $ti: $(python -m pytest tests/test_lmconv_gpu.py -x -q -k 'launch_forms or workgroup_gemm' 2>&1 | tail -1)"
   out=gpurun_out/ti_$ti; mkdir -p $out
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o bench -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra > $out/bench.json 2> $out/stats.log
   f=$(find $out -name "*kernel_stats.csv" | head -1)

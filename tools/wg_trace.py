@@ -36,11 +36,14 @@ for v, name in enumerate(("conv_out <2,2,2>", "conv_in <1,2,2>", "dilated <1,2,1
         print(f"  wg {y:2d}: setup {int(r[1] - r[0]):6d}  first staging {int(r[2] - r[1]):6d}  taps {taps}  total {int(r[15] - r[0])}")
 
 p7 = L.ps_pixelcnn_debug_cache(eng.handle, 7, 0)
-sp = torch.as_tensor(_Raw(p7, (3, 4096, 2)), device=device).cpu().numpy()
+sp = torch.as_tensor(_Raw(p7, (3, 4096, 2)), device=device).cpu().numpy().view(np.uint64)
 for v, name in enumerate(("conv_out <2,2,2>", "conv_in <1,2,2>", "dilated <1,2,1>")):
-    t0, t1, hw = sp[v, :, 0], sp[v, :, 1] >> 16, sp[v, :, 1] & 0xffff
+    t0, t1, hw = sp[v, :, 0].astype(np.int64), (sp[v, :, 1] >> np.uint64(16)).astype(np.int64), (sp[v, :, 1] & np.uint64(0xffff)).astype(np.int64)
+    t0 = t0 & ((1 << 48) - 1)
     ok = (t0 > 0) & (t1 > t0) & (t1 - t0 < 10 ** 6)
     # keep the workgroups of the LAST launch: starts within 1 ms of the latest start
+    if not ok.any():
+        print(name, ": no spans"); continue
     ok &= t0 > t0[ok].max() - 100000
     a, b = t0[ok], t1[ok]
     base = a.min()
