@@ -685,7 +685,7 @@ void *ps_pixelcnn_debug_cache(ps_pixelcnn *h, int what, int idx)
     if (what == 3) return h->nbr_tp;   // neighbour slots of the last throughput launch [NST][2][1024][160]
     if (what == 5) return h->pstart;   // (33, F) int32 of the last AR run's prefix pass: first rank evaluated per stage and frame
 #ifdef PS_WG_TRACE_BUILD
-    if (what == 6 || what == 7) return wg_trace_symbol(what);   // (lmconv_grid.hip)
+    if (what == 6 || what == 7 || what == 9) return wg_trace_symbol(what);   // (lmconv_grid.hip)
 #endif
     if (what == 4) {                   // tuning builds: allocate / return the stamp buffer [2][NST][8] of 64-bit clocks
         if (!h->tp_trace && dev_alloc(h, &h->tp_trace, (size_t)3 * NST * 8) == PS_OK) (void)hipMemset(h->tp_trace, 0, 3 * NST * 8 * 8);
