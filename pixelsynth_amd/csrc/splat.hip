@@ -485,7 +485,9 @@ __device__ __forceinline__ float bcast(float v, int lane)
 //      predicated blend bodies per pixel.
 struct __attribute__((aligned(16))) SplatRec { float x, y, z; uint32_t n; float f[CG]; };
 
-template <int MODE, bool DEBUG_OUT, bool RECIP>
+// NC: channels a wave carries -- CG, or 3 when the features have exactly three (RGB: every configuration of the reference): the
+// fourth accumulator of a group of four costs one LDS read and two vector instructions per hit of a walk of ~46
+template <int MODE, bool DEBUG_OUT, bool RECIP, int NC = CG>
 __attribute__((amdgpu_waves_per_eu(PS_COMPOSITE_WAVES, PS_COMPOSITE_WAVES)))
 __global__ __launch_bounds__(64) void k_composite(
     const uint64_t *__restrict__ keys, const uint32_t *__restrict__ tile_off,
@@ -506,7 +508,7 @@ __global__ __launch_bounds__(64) void k_composite(
     // together execute 2.5 instructions' worth per instruction slot), so instruction count is the lever -- the test phase two records
     // per packed instruction with the hit mask built by a carry chain (10 -> 5.5 instructions per record), and the square root of a hit
     // without sqrtf's handling of ranges its argument cannot be in (16 -> 9 instructions of the walk's ~46 per hit).
-    __shared__ __attribute__((aligned(8))) float sx[64], sy[64], sz[64], sf[CG][64];
+    __shared__ __attribute__((aligned(8))) float sx[64], sy[64], sz[64], sf[NC][64];
     __shared__ uint32_t sn[64];
     const int tile = blockIdx.x, b = blockIdx.y, c0 = blockIdx.z * CG;
     const int lane = threadIdx.x;
@@ -515,12 +517,12 @@ __global__ __launch_bounds__(64) void k_composite(
     const bool valid = xi < S && yi < S;
     const float xf = pix_to_ndc(S - 1 - xi, S), yf = pix_to_ndc(S - 1 - yi, S);
     const uint32_t beg = tile_off[(size_t)b * (NT + 1) + tile], end = tile_off[(size_t)b * (NT + 1) + tile + 1];
-    const int ncg = min(CG, C - c0);
+    const int ncg = min(NC, C - c0);
     const size_t pix = ((size_t)b * S + yi) * S + xi;
 
-    float acc[CG];
+    float acc[NC];
 #pragma unroll
-    for (int c = 0; c < CG; ++c) acc[c] = 0.0f;
+    for (int c = 0; c < NC; ++c) acc[c] = 0.0f;
     float cum = 1.0f, tsum = 0.0f;
     int cnt = 0;
 
@@ -533,7 +535,7 @@ __global__ __launch_bounds__(64) void k_composite(
             SplatRec r;
             r.x = INFINITY; r.y = 0.0f; r.z = 0.0f; r.n = 0;  // lanes past the end carry x = +inf: never a hit
 #pragma unroll
-            for (int c = 0; c < CG; ++c) r.f[c] = 0.0f;
+            for (int c = 0; c < NC; ++c) r.f[c] = 0.0f;
             if (base < end && lane < (int)min(64u, end - base)) {
                 r.n = (uint32_t)keys[base + lane];
                 const float *p = pts + ((size_t)b * N + r.n) * 3;
@@ -542,7 +544,7 @@ __global__ __launch_bounds__(64) void k_composite(
                 r.z = p[2];
                 if (pass == 1) {
 #pragma unroll
-                    for (int c = 0; c < CG; ++c)
+                    for (int c = 0; c < NC; ++c)
                         if (c < ncg) r.f[c] = feat[((size_t)b * C + c0 + c) * N + r.n];
                 }
             }
@@ -555,7 +557,7 @@ __global__ __launch_bounds__(64) void k_composite(
             __syncthreads();  // the previous batch's phase 2 is done with rec[]
             sx[lane] = r.x; sy[lane] = r.y; sz[lane] = r.z; sn[lane] = r.n;
 #pragma unroll
-            for (int c = 0; c < CG; ++c) sf[c][lane] = r.f[c];
+            for (int c = 0; c < NC; ++c) sf[c][lane] = r.f[c];
             __syncthreads();
             // phase 1: hit bits
             uint64_t hits = 0;
@@ -609,7 +611,7 @@ __global__ __launch_bounds__(64) void k_composite(
                 SplatRec h;
                 h.x = sx[j]; h.y = sy[j]; h.z = sz[j]; h.n = sn[j];
 #pragma unroll
-                for (int c = 0; c < CG; ++c) h.f[c] = sf[c][j];
+                for (int c = 0; c < NC; ++c) h.f[c] = sf[c][j];
                 const float dx = h.x - xf, dy = h.y - yf;
                 const float d2 = dx * dx + dy * dy;
                 float d = RECIP ? d2 * denom : d2 / denom;
@@ -620,7 +622,7 @@ __global__ __launch_bounds__(64) void k_composite(
                     tsum = tsum + a;
                 } else {
 #pragma unroll
-                    for (int c = 0; c < CG; ++c) {
+                    for (int c = 0; c < NC; ++c) {
                         const float f = h.f[c];
                         if (MODE == PS_ACC_ALPHACOMPOSITE) acc[c] = acc[c] + cum * a * f;   // PyTorch3D: cum_alpha * alpha * feature
                         else if (MODE == PS_ACC_WSUM) acc[c] = acc[c] + f * a;
@@ -640,7 +642,7 @@ __global__ __launch_bounds__(64) void k_composite(
     }
     if (!valid) return;
 #pragma unroll
-    for (int c = 0; c < CG; ++c)
+    for (int c = 0; c < NC; ++c)
         if (c < ncg) out_feat[((size_t)b * C + c0 + c) * S * S + (size_t)yi * S + xi] = acc[c];
     if (blockIdx.z == 0) {
         bg0[pix] = (uint8_t)(cnt == 0);
@@ -728,12 +730,13 @@ void launch_composite(bool debug, bool recip, dim3 grid, hipStream_t st, const u
                       float *out_feat, uint8_t *bg0, int32_t *out_idx, float *out_zbuf,
                       float *out_dist)
 {
-#define PS_COMPOSITE(DBG, RCP)                                                                     \
-    hipLaunchKernelGGL((k_composite<MODE, DBG, RCP>), grid, dim3(64), 0, st, keys, tile_off, pts,  \
-                       feat, N, C, S, tilesX, NT, r2, denom, tau, K, out_feat, bg0, out_idx,       \
+#define PS_COMPOSITE(DBG, RCP, NCH)                                                                \
+    hipLaunchKernelGGL((k_composite<MODE, DBG, RCP, NCH>), grid, dim3(64), 0, st, keys, tile_off,  \
+                       pts, feat, N, C, S, tilesX, NT, r2, denom, tau, K, out_feat, bg0, out_idx,  \
                        out_zbuf, out_dist)
-    if (debug) { if (recip) PS_COMPOSITE(true, true); else PS_COMPOSITE(true, false); }
-    else       { if (recip) PS_COMPOSITE(false, true); else PS_COMPOSITE(false, false); }
+    if (debug) { if (recip) PS_COMPOSITE(true, true, CG); else PS_COMPOSITE(true, false, CG); }
+    else if (C == 3) { if (recip) PS_COMPOSITE(false, true, 3); else PS_COMPOSITE(false, false, 3); }
+    else       { if (recip) PS_COMPOSITE(false, true, CG); else PS_COMPOSITE(false, false, CG); }
 #undef PS_COMPOSITE
 }
 
