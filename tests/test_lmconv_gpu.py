@@ -777,3 +777,15 @@ def test_ar_prefix_and_columns_as_separate_calls_equal_the_run():
         with pytest.raises(RuntimeError, match="not a range"):
             eng2.ar_prefix(c, o, r, *ms, first, lo, hi)
     assert (c.cpu().numpy()[reg == 1] != codes0[reg == 1]).any()
+    # tuning values by name (include/pixelsynth_hip_debug.h): unknown names and values outside a value's range are errors; the
+    # look-ahead depths are fixed by the handle's first column launch; the results-invalid switches do not exist in the product build
+    with pytest.raises(RuntimeError, match="no tuning value named"):
+        eng2.set_tuning(no_such_value=1)
+    with pytest.raises(RuntimeError, match="no tuning value named"):
+        eng2.set_tuning(column_debug=1)
+    with pytest.raises(RuntimeError, match="outside"):
+        eng2.set_tuning(wg_ti_out=3)
+    with pytest.raises(RuntimeError, match="before the handle's first column launch"):
+        eng2.set_tuning(tp_ahead=(eng2.get_tuning("tp_ahead") + 1) % 8)
+    eng2.set_tuning(tp_ahead=eng2.get_tuning("tp_ahead"))   # (the same value: nothing to change, no error)
+    assert eng2.get_tuning("tp_min_cols") == 257
