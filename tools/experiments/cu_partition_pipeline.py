@@ -14,6 +14,10 @@ column launches run at 200-217 us on 160 compute units where their share of the 
 the splat and 60 % of a prefix pass.  An experiment that LOST (round 3): moved out of the package in round 4; it needs
 `columns_on` support in ZbufferModelPts.outpaint_planned, which went with it (git history: round 3, pixelsynth_amd/pipeline.py).
 
+Known weaknesses left as they were when the experiment lost (round-3 advice): the slot's engine may be rebuilt before the wait for
+batch k - 2's column launches (safe only through hipFree's implicit synchronisation), and tensors allocated on streams A / B go back
+to the caller's stream without record_stream.  Fix both before reviving it.
+
 The batches are independent (the same work as `outpaint_views` batch by batch, bit-identical results: the prefix pass of
 disjoint frame ranges is independent, and each batch has its own engine handle, i.e. its own activation caches).
 There is no reference counterpart: the reference renders one view at a time (demo.py:247-251).
