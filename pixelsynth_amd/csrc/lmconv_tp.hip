@@ -244,6 +244,11 @@ __device__ __forceinline__ void chain_role_tp(const TpArgs &a, int tile)
     __shared__ __attribute__((aligned(16))) int sCtl[(NST + 1) * C1_CTL_DWORDS];   // the control records (a scalar load from memory at
                                                                                   // every stage start cost ~1000 cycles of its ~8000)
     const int t = threadIdx.x, wave = uni(t >> 6), lane = t & 63, i = lane & 15, kk = lane >> 4;
+#ifdef PS_TUNING_BUILD   // timing experiments (results INVALID): column_debug bits 16 / 32 / 64 = no cache stores / no post-op operand requests / no weight refill
+    const bool dbg_nostore = (a.debug & 16) != 0, dbg_noops = (a.debug & 32) != 0, dbg_norefill = (a.debug & 64) != 0;
+#else
+    constexpr bool dbg_nostore = false, dbg_noops = false, dbg_norefill = false;
+#endif
     const int col0 = tile * TP_COLS;
     const int ncl = min(TP_COLS, a.ncols - col0);   // columns of this tile (>= 1)
     {
@@ -343,12 +348,16 @@ __device__ __forceinline__ void chain_role_tp(const TpArgs &a, int tile)
             else *(f32x2 *)&sXb[xb_index(c2, col)] = ep;
             // (write-through: the neighbour role of this very launch reads them, on other XCDs, for the next launch's columns)
             if (kind == PRO_CONVIN) {
-                store_through2(sc.X + ploc[k] * (2 * NF) + c2, ep);
-                store_through2(sc.X + ploc[k] * (2 * NF) + NF + c2, en);
+                if (!dbg_nostore) {
+                    store_through2(sc.X + ploc[k] * (2 * NF) + c2, ep);
+                    store_through2(sc.X + ploc[k] * (2 * NF) + NF + c2, en);
+                }
             } else {
-                store_through2(sc.R + ploc[k] * R_LD + c2, out);
-                store_through2(sc.E + ploc[k] * (2 * NF) + c2, ep);
-                store_through2(sc.E + ploc[k] * (2 * NF) + NF + c2, en);
+                if (!dbg_nostore) {
+                    store_through2(sc.R + ploc[k] * R_LD + c2, out);
+                    store_through2(sc.E + ploc[k] * (2 * NF) + c2, ep);
+                    store_through2(sc.E + ploc[k] * (2 * NF) + NF + c2, en);
+                }
                 ucur[k] = out;
                 if (save_slot >= 0) *(f32x2 *)(&sU[save_slot][col][c2]) = out;
             }
@@ -434,17 +443,17 @@ __device__ __forceinline__ void chain_role_tp(const TpArgs &a, int tile)
                 if (last) acc[NU - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(W[NU - 1].a1[c], b[NU - 1][c], acc[NU - 1], 0, 0, 0);
 #pragma unroll
                 for (int u = 2 * c; u < 2 * c + 2; ++u)
-                    if (u < TP_MAXU && u < nnu) W[u].a0 = *PS_GC(f32x4, nbase + (size_t)(2 * u) * 256);
+                    if (u < TP_MAXU && u < nnu && !dbg_norefill) W[u].a0 = *PS_GC(f32x4, nbase + (size_t)(2 * u) * 256);
             }
         } else {
 #pragma unroll
             for (int u = 0; u < TP_MAXU; ++u)
-                if (u < nnu) W[u].a0 = *PS_GC(f32x4, nbase + (size_t)(2 * u) * 256);
+                if (u < nnu && !dbg_norefill) W[u].a0 = *PS_GC(f32x4, nbase + (size_t)(2 * u) * 256);
         }
         TP_STAMP2(5, true);
 #pragma unroll
         for (int u = 0; u < TP_MAXU; ++u)
-            if (u < nnu) W[u].a1 = *PS_GC(f32x4, nbase + (size_t)(2 * u + 1) * 256);
+            if (u < nnu && !dbg_norefill) W[u].a1 = *PS_GC(f32x4, nbase + (size_t)(2 * u + 1) * 256);
 #pragma unroll
         for (int u = 0; u < NU - 1; ++u) sP4[dst[u]] = acc[u];
         if (last) sP4[dst[NU - 1]] = acc[NU - 1];
@@ -482,6 +491,7 @@ __device__ __forceinline__ void chain_role_tp(const TpArgs &a, int tile)
             wait_counter(cnt_have, s, items);
             cnt_have = counter(min(s + 1, NST - 2));             // looked at a stage later
             TP_STAMP(1);
+            if (dbg_noops) return;
             ob = plain(pc.bias + c2);
             if (kind == PRO_GATE) obg = plain(pc.bias + NF + c2);
             if (has_skip) ob2 = plain(pc.bias2 + c2);
