@@ -268,6 +268,9 @@ def extra_configs(device):
     # RealEstate10K-shaped cameras): few columns per wavefront -> the latency form of the column launch (k_column)
     res["C5_one_source_16_views"] = small_batch_config(device, 16, "mp3d")
     res["RealEstate_shaped_16_views"] = small_batch_config(device, 16, "demo")
+    # where the path's throughput saturates: 16 sources x 16 views per step (the column launches are bound by the latency of their
+    # dependent stages, so a step's time grows more slowly than its batch up to ~1000 columns per launch; tools/batch_sweep.py)
+    res["C5_shaped_16_sources_256_views"] = small_batch_config(device, 256, "mp3d", steps=8)
     # The STRONG-scaling forms BASELINE.json names for 8 GPUs, priced from one GPU's measured share (no 8-GPU node behind this
     # run: a projection, the path has no exchange besides the final gather).  C5 = 128 views in total -> 16 per GPU, dealt
     # round-robin (rank 0 renders views 0, 8, 16, ...: two of every source's sweep); C4 = the 64-frame circle -> 8 frames per GPU.
