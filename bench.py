@@ -15,6 +15,7 @@ synthetic.  The only collective is the RCCL all_gather of the finished frames (n
 Prints ONE JSON line (rank 0) with the contract fields plus `roofline` and `cpu_baseline`.
 """
 import argparse
+import gc
 import ctypes
 import json
 import os
@@ -237,26 +238,56 @@ def latest_pmc_record(V):
     return None
 
 
+_SIDE = {}
+
+
+def side_stream():
+    """ONE side stream per device for the whole process: the runtime deals streams onto a handful of hardware queues in turn, and
+    which queue a configuration's side stream shares with whom should not depend on how many configurations ran before it."""
+    dev = torch.cuda.current_device()
+    if dev not in _SIDE:
+        _SIDE[dev] = torch.cuda.Stream()
+    return _SIDE[dev]
+
+
+def cool_down(seconds=2.0):
+    """Side configurations are measured one after the other on one GPU, and a heavy one leaves the board at its power limit: the
+    64-frame circle measured right behind the 256-view batch took 15.9 ms per step instead of 13.0, the 256-view batch behind the
+    end-to-end passes 45 ms instead of 35.  An idle moment in front of each gives every configuration the same start."""
+    torch.cuda.synchronize()
+    time.sleep(seconds)
+
+
 def small_batch_config(device, V, cameras, steps=20, total=None, trajectory="sweep"):
     """frames/s and the column launch's roofline numbers of a smaller batch (pipelined steps like the headline).
     total: the batch is rank 0's share of a job of `total` views over total / V ranks (the 8-GPU forms of C4 / C5)."""
+    cool_down()
     model = build_model(device)
     if total is None:
         d, _ = make_inputs(0, V, device, cameras=cameras, trajectory=trajectory)
     else:
         d, _ = make_inputs(0, total, device, cameras=cameras, trajectory=trajectory, ids=D.shard_views(total, 0, total // V))
-    side = torch.cuda.Stream()
+    side = side_stream()
     out = run_steps(model, d, 1, 3, side)      # (a 6 ms step is close to what the host needs to plan and enqueue one: short runs scatter)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     out = run_steps(model, d, 1, steps, side)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    model.outpaint2.engine(32, 32, V).check()
+    eng = model.outpaint2.engine(32, 32, V)
+    eng.check()
     r = measure_roofline(model, d, out, V)
-    return {"frames_per_s": round(V / dt, 1), "ms_per_step": round(dt * 1e3, 3), "views": V, "cameras": cameras,
-            "sampled_codes_per_view_mean": round(float(np.mean(out["plan"].n_sampled)), 1),
-            "column_launch": {k: r[k] for k in ("achieved", "frac", "avg_launch_us", "columns_per_launch", "launches_per_ar_run")}}
+    res = {"frames_per_s": round(V / dt, 1), "ms_per_step": round(dt * 1e3, 3), "views": V, "cameras": cameras,
+           "sampled_codes_per_view_mean": round(float(np.mean(out["plan"].n_sampled)), 1),
+           "column_launch": {k: r[k] for k in ("achieved", "frac", "avg_launch_us", "columns_per_launch", "launches_per_ar_run")}}
+    # the engine's activation caches (27.8 MB per view) go back HERE: left to the garbage collector, their hipFree -- a device
+    # synchronisation of several ms at 256 views -- lands in the timed region of whichever configuration runs next
+    eng.close()
+    del model, d, out, eng
+    gc.collect()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    return res
 
 
 def extra_configs(device):
@@ -269,7 +300,7 @@ def extra_configs(device):
     res["C5_one_source_16_views"] = small_batch_config(device, 16, "mp3d")
     res["RealEstate_shaped_16_views"] = small_batch_config(device, 16, "demo")
     # where the path's throughput saturates: 16 sources x 16 views per step (the column launches are bound by the latency of their
-    # dependent stages, so a step's time grows more slowly than its batch up to ~1000 columns per launch; tools/batch_sweep.py)
+    # dependent stages, so a step's time grows more slowly than its batch up to ~1000 columns per launch; tools/batch_sweep.py).
     res["C5_shaped_16_sources_256_views"] = small_batch_config(device, 256, "mp3d", steps=8)
     # The STRONG-scaling forms BASELINE.json names for 8 GPUs, priced from one GPU's measured share (no 8-GPU node behind this
     # run: a projection, the path has no exchange besides the final gather).  C5 = 128 views in total -> 16 per GPU, dealt
@@ -604,7 +635,7 @@ def main():
         D.barrier()
         torch.cuda.synchronize()
 
-    side = torch.cuda.Stream()
+    side = side_stream()
     steps_fn = lambda k: run_steps(model, d, world, k, side)
     out = steps_fn(args.warmup) if args.warmup > 0 else None
     barrier()
