@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256) void k_post_grid(PostArgs a)
 //     is closed -- tot + 0 is tot, so the bits do not change -- which keeps the tap body free of branches.
 // Arithmetic and order are k_gemm's summing form to the bit: per tap five accumulation chains (chain j = channel groups j,
 // j + 5 in MFMA order), tap value (((a0 + a1) + a2) + a3) + a4, taps added in order into the slot, y = ((bias + NA) + C) + NB
-// stored in place of slot NA, the nin_skip slot raw.  Taken for launches of at least PS_GEMM_WG_MIN item tiles.
+// stored in place of slot NA, the nin_skip slot raw.  Taken for launches of at least `gemm_wg_min` item tiles (struct Tuning).
 // ------------------------------------------------------------------------------------------
 constexpr int GW_WAVES = 4, GW_THREADS = 64 * GW_WAVES;
 enum { GW_CONVOUT = 0, GW_CONVIN = 1, GW_DIL = 2 };

@@ -66,7 +66,7 @@ struct ChainArgs {
                                // never reset, counter (k, t) stands at tile_uses[t] x (items of stage k per tile) when done
     int *err;                  // set to 1 if a bounded wait ran out (ps_pixelcnn_status)
     unsigned long long *trace; // optional [NST][10] shader-clock stamps of workgroup 0 (tuning aid)
-    int debug;                 // tuning only (PS_COLUMN_DEBUG): 1 = chains do not wait for the neighbour slots, 2 = no chains,
+    int debug;                 // tuning builds only (Tuning::column_debug): 1 = chains do not wait for the neighbour slots, 2 = no chains,
                                // 3 = no neighbour role and no waiting
     // look-ahead form (k_column_la, chain_role<FPW, true>): the slots of the stages below `la_split` were computed by the launch in
     // front (use counts uses_lo), the others by this one (uses_hi); `nbr` / `cnt` are the halves of this launch's parity; the
@@ -151,7 +151,7 @@ struct ps_pixelcnn {
     int n_cus = 256;                // compute units of the device: workgroups of a column launch that are resident together
     bool xcd_even = true;           // n_cus is an even share of the 8 XCDs of a whole MI355X (block b runs on XCD b % 8)
     pslm::Tuning tune;
-    int env_col_cap = 0;            // PS_COL_CAP as read at creation (re-applied when the compute-unit count changes)
+    int env_col_cap = 0;            // col_cap as asked for (environment at creation or set_tuning); re-applied when the compute-unit count changes
     // bench.py profiling aid (ps_pixelcnn_time_column_step): event pair around every launch, by kernel tag
     struct ProfRec { int tag; hipEvent_t e0, e1; };
     std::vector<ProfRec> *prof = nullptr;

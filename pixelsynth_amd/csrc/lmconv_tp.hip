@@ -382,7 +382,7 @@ __device__ __forceinline__ void chain_role_tp(const TpArgs &a, int tile)
     // base register, the rest immediates.
 #ifdef PS_TP_TRACE_BUILD
     int trace_s = 0;
-    const int trace_wave = a.debug >> 8;   // PS_COLUMN_DEBUG = 256 * wave (+ mode): the wave whose stamps are kept
+    const int trace_wave = a.debug >> 8;   // column_debug = 256 * wave (+ mode): the wave whose stamps are kept
 #define TP_STAMP(slot) do { if (a.trace && tile == 0 && t == 64 * trace_wave) a.trace[s * 8 + (slot)] = clock64(); } while (0)
 #define TP_STAMP2(slot, dep) do { if (a.trace && tile == 0 && t == 64 * trace_wave && (dep)) a.trace[trace_s * 8 + (slot)] = clock64(); } while (0)
 #else
