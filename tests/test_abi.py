@@ -87,3 +87,26 @@ def test_generation_order_matches_oracle():
         assert np.array_equal(D, ref["D"]), name
         assert np.array_equal(order, ref["order"]), name
         assert np.array_equal(blocks, ref["bg32"]), name
+
+
+def test_tuning_names_in_the_integration_notes_are_the_ones_the_library_knows():
+    """INTEGRATION.md section E lists the tuning values by name; the table in csrc/lmconv.hip is what ps_pixelcnn_set_tuning accepts.
+    Every documented name must exist, and every name of the product build must be documented."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "pixelsynth_amd", "csrc", "lmconv.hip")).read()
+    table = src[src.index("const TuningEntry tuning_table[]"):src.index("const TuningEntry *find_tuning")]
+    product = table.split("#ifdef PS_TUNING_BUILD")[0]
+    known = set(re.findall(r'\{"(\w+)", &Tuning::', product))
+    tuning_only = set(re.findall(r'\{"(\w+)", &Tuning::', table)) - known
+    assert known and tuning_only == {"column_debug"}
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    sec = doc[doc.index("## E. Tuning values"):doc.index("## F. Two headers")]
+    rows = [line.split("|")[1] for line in sec.splitlines() if line.startswith("| `")]
+    documented = set(re.findall(r"`(\w+)`", " ".join(rows)))
+    assert documented == known, (sorted(documented - known), sorted(known - documented))
+    # and struct Tuning has a field for each
+    hdr = open(os.path.join(root, "pixelsynth_amd", "csrc", "lmconv_handle.h")).read()
+    fields = hdr[hdr.index("struct Tuning {"):hdr.index("};", hdr.index("struct Tuning {"))]
+    for name in known | tuning_only:
+        assert re.search(r"\b%s\b" % name, fields), name
