@@ -110,3 +110,22 @@ def test_tuning_names_in_the_integration_notes_are_the_ones_the_library_knows():
     fields = hdr[hdr.index("struct Tuning {"):hdr.index("};", hdr.index("struct Tuning {"))]
     for name in known | tuning_only:
         assert re.search(r"\b%s\b" % name, fields), name
+
+
+def test_profiles_readme_lists_what_is_there():
+    """profiles/README.md is how bench.py finds the PMC record of roofline.traffic (the LAST *_k_column_pmc.json it names for the run's
+    number of views), and how a reader finds the evidence: every file it names exists, every file there is named."""
+    import json
+    import sys
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+    text = open(os.path.join(root, "README.md")).read()
+    named = set(re.findall(r"`(r\d\d_[\w.]+\.(?:csv|json|txt))`", text))
+    there = {f for f in os.listdir(root) if f != "README.md"}
+    assert named <= there, sorted(named - there)
+    assert there <= named, sorted(there - named)
+    sys.path.insert(0, os.path.dirname(root))
+    import bench
+    rec = bench.latest_pmc_record(128)
+    assert rec is not None and rec["views"] == 128 and rec["traffic_bytes_per_launch"] > 0
+    newest = sorted(f for f in there if f.endswith("_k_column_pmc.json"))[-1]
+    assert json.load(open(os.path.join(root, newest)))["traffic_bytes_per_launch"] == rec["traffic_bytes_per_launch"], newest
