@@ -244,10 +244,10 @@ __device__ __forceinline__ void chain_role_tp(const TpArgs &a, int tile)
     __shared__ __attribute__((aligned(16))) int sCtl[(NST + 1) * C1_CTL_DWORDS];   // the control records (a scalar load from memory at
                                                                                   // every stage start cost ~1000 cycles of its ~8000)
     const int t = threadIdx.x, wave = uni(t >> 6), lane = t & 63, i = lane & 15, kk = lane >> 4;
-#ifdef PS_TUNING_BUILD   // timing experiments (results INVALID): column_debug bits 16 / 32 / 64 = no cache stores / no post-op operand requests / no weight refill
-    const bool dbg_nostore = (a.debug & 16) != 0, dbg_noops = (a.debug & 32) != 0, dbg_norefill = (a.debug & 64) != 0;
+#ifdef PS_TUNING_BUILD   // timing experiments (results INVALID): column_debug bits 16 / 32 / 64 / 128 = no cache stores / no post-op operand requests / no weight refill / no post op at all
+    const bool dbg_nostore = (a.debug & 16) != 0, dbg_noops = (a.debug & 32) != 0, dbg_norefill = (a.debug & 64) != 0, dbg_nopost = (a.debug & 128) != 0;   // (128: no post op)
 #else
-    constexpr bool dbg_nostore = false, dbg_noops = false, dbg_norefill = false;
+    constexpr bool dbg_nostore = false, dbg_noops = false, dbg_norefill = false, dbg_nopost = false;
 #endif
     const int col0 = tile * TP_COLS;
     const int ncl = min(TP_COLS, a.ncols - col0);   // columns of this tile (>= 1)
@@ -533,6 +533,7 @@ __device__ __forceinline__ void chain_role_tp(const TpArgs &a, int tile)
         f32x2 y[TP_NPC], g[TP_NPC], skip[TP_NPC];
 #pragma unroll
         for (int k = 0; k < TP_NPC; ++k) { g[k] = zero2; skip[k] = zero2; }
+        if (dbg_nopost) { cvA = cvB; cvB = cvC; lds_barrier(); return; }
 #pragma unroll
         for (int k = 0; k < TP_NPC; ++k) {
             const float *P = &sP[pcol[k] * SP_LD + c2];
