@@ -245,7 +245,7 @@ __device__ __forceinline__ void chain_role_tp(const TpArgs &a, int tile)
                                                                                   // every stage start cost ~1000 cycles of its ~8000)
     const int t = threadIdx.x, wave = uni(t >> 6), lane = t & 63, i = lane & 15, kk = lane >> 4;
 #ifdef PS_TUNING_BUILD   // timing experiments (results INVALID): column_debug bits 16 / 32 / 64 / 128 = no cache stores / no post-op operand requests / no weight refill / no post op at all
-    const bool dbg_nostore = (a.debug & 16) != 0, dbg_noops = (a.debug & 32) != 0, dbg_norefill = (a.debug & 64) != 0, dbg_nopost = (a.debug & 128) != 0;   // (128: no post op)
+    const bool dbg_nostore = (a.debug & 16) != 0, dbg_noops = (a.debug & 32) != 0, dbg_norefill = (a.debug & 64) != 0, dbg_nopost = (a.debug & 128) != 0;
 #else
     constexpr bool dbg_nostore = false, dbg_noops = false, dbg_norefill = false, dbg_nopost = false;
 #endif

@@ -16,6 +16,8 @@ model = bench.build_model(device)
 d, _ = bench.make_inputs(0, V, device)
 out = bench.run_step(model, d, 1)
 eng = model.outpaint2.engine(32, 32, V)
+if len(sys.argv) > 2:   # column_debug of the tuning build (roles / memory operations / phases switched off: results invalid)
+    eng.set_tuning(column_debug=int(sys.argv[2]))
 p = _lib.lib().ps_pixelcnn_debug_cache(eng.handle, 4, 0)
 out = bench.run_step(model, d, 1)
 torch.cuda.synchronize()
