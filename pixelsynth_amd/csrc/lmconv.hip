@@ -148,6 +148,7 @@ struct TuningEntry { const char *key; int Tuning::*field; int lo, hi; };
 const TuningEntry tuning_table[] = {
     {"gemm_merge_min", &Tuning::gemm_merge_min, 0, 1 << 30}, {"gemm_wg_min", &Tuning::gemm_wg_min, 1, 1 << 30},
     {"wg_ti_out", &Tuning::wg_ti_out, 1, 2}, {"wg_ti_in", &Tuning::wg_ti_in, 2, 4}, {"wg_ti_dil", &Tuning::wg_ti_dil, 2, 4},
+    {"item_sort", &Tuning::item_sort, 0, 2},
     {"prefix_full", &Tuning::prefix_full, 0, 1}, {"prefix_cone_force", &Tuning::prefix_cone_force, 0, 1},
     {"tp_ahead", &Tuning::tp_ahead, 0, NST - 2}, {"col_ahead", &Tuning::col_ahead, 0, NST - 4},
     {"tp_min_cols", &Tuning::tp_min_cols, 1, 1 << 30}, {"tp_xcds", &Tuning::tp_xcds, -1, 7}, {"tp_fill", &Tuning::tp_fill, 0, 1},
@@ -162,13 +163,23 @@ const TuningEntry *find_tuning(const char *key)
         if (strcmp(e.key, key) == 0) return &e;
     return nullptr;
 }
-// PS_<KEY in upper case>, e.g. PS_TP_AHEAD=8
+// a value inside [lo, hi] that no launch form exists for: k_gemm_wg has conv_input / dilated kernels for 2 and 4 item tiles only
+bool tuning_value_ok(const TuningEntry &e, int v)
+{
+    if (v < e.lo || v > e.hi) return false;
+    if (e.field == &Tuning::wg_ti_in || e.field == &Tuning::wg_ti_dil) return v == 2 || v == 4;
+    return true;
+}
+// PS_<KEY in upper case>, e.g. PS_TP_AHEAD=8 (a value no form exists for is ignored)
 void tuning_from_env(Tuning &t)
 {
     for (const TuningEntry &e : tuning_table) {
         std::string name = "PS_";
         for (const char *c = e.key; *c; ++c) name += (char)toupper(*c);
-        if (const char *v = getenv(name.c_str())) t.*(e.field) = std::min(e.hi, std::max(e.lo, atoi(v)));
+        if (const char *v = getenv(name.c_str())) {
+            const int x = std::min(e.hi, std::max(e.lo, atoi(v)));
+            if (tuning_value_ok(e, x)) t.*(e.field) = x;
+        }
     }
 }
 // where the look-ahead depths split the (stage-major) work tables
@@ -451,6 +462,9 @@ int ps_pixelcnn_create(const float *const *params, int n_params, int H, int W, i
     }
     if ((rc = dev_alloc(h, &h->ctx, locs))) return fail_out(rc);
     if ((rc = dev_alloc(h, &h->pstart, (size_t)N_EVAL * max_frames))) return fail_out(rc);
+    if ((rc = dev_alloc(h, &h->perm, 2 * locs))) return fail_out(rc);
+    if ((rc = dev_alloc(h, &h->perm_sorted, 2 * locs))) return fail_out(rc);
+    if ((rc = dev_alloc(h, &h->perm_cnt, (size_t)2 * 512 * max_frames))) return fail_out(rc);
     if ((rc = dev_alloc(h, &h->taps, locs))) return fail_out(rc);
     if ((rc = dev_alloc(h, &h->nbr_tp, (size_t)2 * NST * 2 * TP_COL_CAP * NBR_LD))) return fail_out(rc);
     if ((rc = dev_alloc(h, &h->cnt_tp, 2 * tp_cnt_index(NST, 0)))) return fail_out(rc);
@@ -700,6 +714,7 @@ int ps_pixelcnn_set_tuning(ps_pixelcnn *h, const char *key, int value)
     const TuningEntry *e = find_tuning(key);
     PS_REQUIRE(e, "pixelcnn_set_tuning: no tuning value named '%s'", key);
     PS_REQUIRE(value >= e->lo && value <= e->hi, "pixelcnn_set_tuning: %s = %d outside [%d, %d]", key, value, e->lo, e->hi);
+    PS_REQUIRE(tuning_value_ok(*e, value), "pixelcnn_set_tuning: no launch form for %s = %d", key, value);
     const bool depth = e->field == &Tuning::tp_ahead || e->field == &Tuning::col_ahead;
     // the never-reset completion counters count items per stage under ONE look-ahead depth: it is fixed by the first column launch
     if (depth && h->columns_launched && h->tune.*(e->field) != value)

@@ -29,7 +29,15 @@ struct ItemMap {
     const int32_t *start;  // (F) or null: ranks below start[f] are NOT evaluated at this stage -- nothing reads them
                            // (k_prefix_starts); only with an order
     int f0;                // first frame of the pass (a pass over frames [f0, f0 + n): item 0 is rank 0 of frame f0)
+    const int32_t *perm;   // or null: position p of the products' item list holds item perm[p] -- the items grouped by their set of
+                           // open taps (k_perm_*), so that a tile of 16 / 32 items shares its taps; the post ops walk the items as they are
 };
+// item at position `pos` of the products' item list, -1 past its end
+__device__ __forceinline__ int item_at(const ItemMap &m, int pos, int nitems)
+{
+    if (pos >= nitems) return -1;
+    return m.perm ? m.perm[pos] : pos;
+}
 __device__ __forceinline__ void item_loc(const ItemMap &m, int item, int L, int &f, int &q)
 {
     const int fl = item / m.npre;
@@ -83,8 +91,8 @@ __device__ __forceinline__ void gemm_tiles(const GemmArgs &a, int o0, int z0, in
     for (int tt = 0; tt < a.tiles_per_block; ++tt) {
         const int tile = first_tile + tt;
         if (tile * 16 >= a.nitems) break;
-        const int item = tile * 16 + i;
-        const bool valid = item < a.nitems && item_wanted(a.items, item);
+        const int item = item_at(a.items, tile * 16 + i, a.nitems);
+        const bool valid = item >= 0 && item_wanted(a.items, item);
         if (!__any(valid)) continue;   // a tile nobody reads at this stage
         int f = 0, r = 0, c = 0, q = 0;
         if (valid) {
@@ -394,8 +402,8 @@ __global__ __launch_bounds__(GW_THREADS) void k_gemm_wg(GemmArgs a, PostArgs pa,
     // ---- set-up: rows and mask values of every (tap, item) of the tile; wave w does taps w, w + 4, w + 8
     {
         const int m = lane & (MI - 1);
-        const int item = item0 + m;
-        const bool valid = item < a.nitems && item_wanted(a.items, item);
+        const int item = item_at(a.items, item0 + m, a.nitems);
+        const bool valid = item >= 0 && item_wanted(a.items, item);
         int f = 0, q = 0, r = 0, c = 0;
         if (valid) {
             item_loc(a.items, item, a.L, f, q);
@@ -778,6 +786,113 @@ __global__ __launch_bounds__(1024) void k_prefix_starts(StartsArgs a)
     out[0] = need[0];   // u_init + norm_init
 }
 
+// ------------------------------------------------------------------------------------------
+// Items grouped by their set of open taps (round 5).  A tile of the products computes a tap for all its items as soon as ONE of
+// them has it open; a location has 4.7 of its 9 taps open on average (of every adjacent pair exactly one precedes the other), a
+// tile of 16 consecutive ranks of a frame 7.1 of 9, a tile of 32 already 8.1 -- a third of the MFMA work of the pass multiplied
+// zeros.  The masks of a frame take about 40 distinct tap sets, so the items are SORTED by tap set (9 bits: tap t open and inside
+// the grid) and the products walk that list: 4.8 taps per tile of 16, 4.85 per tile of 32.  A closed tap adds an exact zero, so
+// which items share a tile changes no bit; the post ops and every cache row are addressed by the item itself, as before.
+// Order inside a tap set: frame, then rank (neighbouring ranks are neighbouring locations: their input rows are the same lines).
+// `nparts` > 1: one sort per share of the frames, so that the contiguous range of tiles an XCD takes (k_gemm / k_gemm_wg) reads
+// the rows of ITS frames only.  Three small launches per pass and mask kind (dilation 1, dilation 2):
+//   k_perm_sort     per frame: (tap set << 12 | rank) of its items, sorted (bitonic, LDS), and the run length of every tap set
+//   k_perm_scan     first position of every (share, tap set, frame) run: exclusive scan over [share][tap set][frame]
+//   k_perm_scatter  per frame: perm[first + index in the run] = item
+// ------------------------------------------------------------------------------------------
+struct PermArgs {
+    const int32_t *order;               // (F, L) or null (raster)
+    const float *mask[2];               // (F, 9, L): type B dilation 1 / dilation 2
+    int H, W, L, npre, f0, nf, nparts;
+    uint32_t *sorted[2];                // [nf][npre]
+    int32_t *cnt[2];                    // [nparts][512][frames per share]
+    int32_t *perm[2];                   // [nf * npre]
+};
+constexpr int PERM_KEYS = 512;
+__device__ __forceinline__ int perm_fpp(const PermArgs &a) { return (a.nf + a.nparts - 1) / a.nparts; }   // frames per share
+__device__ __forceinline__ size_t perm_cnt_index(const PermArgs &a, int fl, int key)
+{
+    const int fpp = perm_fpp(a), part = fl / fpp;
+    return ((size_t)part * PERM_KEYS + key) * fpp + (fl - part * fpp);
+}
+__global__ __launch_bounds__(1024) void k_perm_sort(PermArgs a)
+{
+    __shared__ uint32_t s[STARTS_MAXL];
+    __shared__ int hist[PERM_KEYS];
+    const int fl = blockIdx.x, kind = blockIdx.y, f = a.f0 + fl, t = threadIdx.x, dil = kind + 1;
+    const float *mask = a.mask[kind];
+    int P = 2;
+    while (P < a.npre) P <<= 1;
+    for (int r = t; r < P; r += 1024) {
+        uint32_t v = 0xFFFFFFFFu;
+        if (r < a.npre) {
+            const int q = a.order ? a.order[(size_t)f * a.L + r] : r, y = q / a.W, x = q - y * a.W;
+            uint32_t key = 0;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int yy = y + (tap / 3 - 1) * dil, xx = x + (tap % 3 - 1) * dil;
+                if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W && mask[((size_t)f * 9 + tap) * a.L + q] != 0.0f) key |= 1u << tap;
+            }
+            v = key << 12 | (uint32_t)r;
+        }
+        s[r] = v;
+    }
+    for (int k = t; k < PERM_KEYS; k += 1024) hist[k] = 0;
+    __syncthreads();
+    for (int k = 2; k <= P; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = t; i < P; i += 1024) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const uint32_t x = s[i], y = s[l];
+                    if ((x > y) == ((i & k) == 0)) { s[i] = y; s[l] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = t; i < a.npre; i += 1024) {
+        a.sorted[kind][(size_t)fl * a.npre + i] = s[i];
+        atomicAdd(&hist[s[i] >> 12], 1);
+    }
+    __syncthreads();
+    for (int k = t; k < PERM_KEYS; k += 1024) a.cnt[kind][perm_cnt_index(a, fl, k)] = hist[k];
+}
+__global__ __launch_bounds__(1024) void k_perm_scan(PermArgs a)
+{
+    __shared__ int part[1024];
+    const int kind = blockIdx.x, t = threadIdx.x;
+    const int n = a.nparts * PERM_KEYS * perm_fpp(a), chunk = (n + 1023) / 1024;
+    int32_t *c = a.cnt[kind];
+    const int lo = min(n, t * chunk), hi = min(n, lo + chunk);
+    int sum = 0;
+    for (int i = lo; i < hi; ++i) sum += c[i];
+    part[t] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int v = t >= off ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int run = part[t] - sum;
+    for (int i = lo; i < hi; ++i) { const int v = c[i]; c[i] = run; run += v; }
+}
+__global__ __launch_bounds__(1024) void k_perm_scatter(PermArgs a)
+{
+    __shared__ int first[PERM_KEYS];
+    const int fl = blockIdx.x, kind = blockIdx.y, t = threadIdx.x;
+    const uint32_t *s = a.sorted[kind] + (size_t)fl * a.npre;
+    for (int i = t; i < a.npre; i += 1024) {
+        const uint32_t key = s[i] >> 12;
+        if (i == 0 || (s[i - 1] >> 12) != key) first[key] = i;
+    }
+    __syncthreads();
+    for (int i = t; i < a.npre; i += 1024) {
+        const uint32_t v = s[i], key = v >> 12;
+        a.perm[kind][a.cnt[kind][perm_cnt_index(a, fl, (int)key)] + i - first[key]] = fl * a.npre + (int)(v & 4095u);
+    }
+}
+
 struct UinitArgs {
     ItemMap items;
     const int32_t *codes;  // (F,L), -1 = all-zero input
@@ -942,12 +1057,31 @@ void run_grid(ps_pixelcnn *h, int F, const int32_t *codes, const Masks &m, float
         for (int d = 0; d < 4; ++d) { sa.d_in[d] = h->dil[d].node_in; sa.d_out[d] = h->dil[d].node_out; }
         hipLaunchKernelGGL(k_prefix_starts, dim3(nf), dim3(1024), 0, st, sa);
     }
+    // the products' item lists, grouped by open-tap set (one per mask kind); the frame range's own part of the scratch
+    const int32_t *perm[2] = {nullptr, nullptr};
+    if (h->tune.item_sort && h->L <= STARTS_MAXL && all_items.npre >= 2) {
+        PermArgs pa{};
+        pa.order = order; pa.mask[0] = m.und; pa.mask[1] = m.dil;
+        pa.H = h->H; pa.W = h->W; pa.L = h->L; pa.npre = all_items.npre; pa.f0 = f0; pa.nf = nf;
+        pa.nparts = h->tune.item_sort == 2 && nf >= 2 * N_XCD && nf % N_XCD == 0 ? N_XCD : 1;   // (even shares only: the table is [share][tap set][frame])
+        const size_t locs = (size_t)h->maxF * h->L;
+        for (int k = 0; k < 2; ++k) {
+            pa.sorted[k] = h->perm_sorted + k * locs + (size_t)f0 * h->L;
+            pa.perm[k] = h->perm + k * locs + (size_t)f0 * h->L;
+            pa.cnt[k] = h->perm_cnt + ((size_t)k * h->maxF + f0) * PERM_KEYS;
+            perm[k] = pa.perm[k];
+        }
+        hipLaunchKernelGGL(k_perm_sort, dim3(nf, 2), dim3(1024), 0, st, pa);
+        hipLaunchKernelGGL(k_perm_scan, dim3(2), dim3(1024), 0, st, pa);
+        hipLaunchKernelGGL(k_perm_scatter, dim3(nf, 2), dim3(1024), 0, st, pa);
+    }
     float *const part = h->partial + (size_t)4 * f0 * h->L * (2 * NF);
     ItemMap items = all_items;
     auto at_stage = [&](int stage_id) { items.start = cone ? h->pstart + (size_t)stage_id * F : nullptr; };
     // -> 0: raw slots in `partial`, 1: slots summed by the kernel, 2: the post op `post` done by the kernel as well
     auto gemm = [&](GemmArgs &a, const float *mask, const float *sum_bias = nullptr, const PostArgs *post = nullptr) {
         a.items = items;
+        a.items.perm = mask == m.und ? perm[0] : mask == m.dil ? perm[1] : nullptr;
         a.H = h->H; a.W = h->W; a.L = h->L; a.nitems = nitems;
         a.mask = mask; a.mask_fstride = (size_t)9 * h->L; a.tiles_per_block = 1;
         a.partial = h->partial + (size_t)4 * f0 * h->L * (2 * NF);   // (the frame range's own part of the scratch: passes over disjoint ranges may run side by side)

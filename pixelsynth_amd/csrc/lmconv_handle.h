@@ -85,6 +85,8 @@ struct Tuning {
     int gemm_merge_min = 8192;   // (tile, channel block) pairs from which one k_gemm wave walks all slots of its tile
     int gemm_wg_min = 1024;      // item tiles from which the whole-grid products take the workgroup form (k_gemm_wg)
     int wg_ti_out = 1, wg_ti_in = 2, wg_ti_dil = 2;   // item tiles per k_gemm_wg workgroup: conv_out / conv_input / dilated
+    int item_sort = 2;           // whole-grid products: items grouped by their set of open taps (round 5).  0 = natural (frame, rank)
+                                 // order, 1 = one sort over all frames, 2 = one per XCD share of the frames (the rows of a frame stay in one L2)
     int prefix_full = 0;         // 1: the prefix pass evaluates every item (no dependency-cone elimination)
     int prefix_cone_force = 0;   // 1: keep the elimination on when the caller asks for logits (parity tests: walked locations only)
     int tp_ahead = 12;           // stages [0, tp_ahead) of a throughput-form launch are computed by the launch in front of it (0: off)
@@ -118,6 +120,10 @@ struct ps_pixelcnn {
     float *col_logits = nullptr;
     pslm::StepCtx *ctx = nullptr;   // column records of a run, [maxF * L]
     int32_t *pstart = nullptr;      // (N_EVAL, F) first rank of the prefix anyone reads, per stage and frame (k_prefix_starts)
+    // items of a whole-grid pass grouped by open-tap set (k_perm_*, lmconv_grid.hip): [2 mask kinds][maxF * L] each
+    int32_t *perm = nullptr;        // position -> natural item index (frame-local: fl * npre + rank)
+    uint32_t *perm_sorted = nullptr;   // scratch: (key << 12 | rank) of every frame, sorted
+    int32_t *perm_cnt = nullptr;    // scratch: [2][512 * maxF] run lengths -> first positions
     int *ctl1 = nullptr;            // the chain roles' control records
     unsigned *cnt = nullptr;        // [2][NST][MAX_TILES] padded completion counters of the neighbour role, never reset
     int *err = nullptr;             // device flag: a bounded wait of a column launch ran out

@@ -181,7 +181,15 @@ def test_whole_grid_launch_forms_agree_bit_for_bit():
     for ti in ((2, 2, 2), (1, 4, 4), (2, 4, 2)):      # item tiles per workgroup: conv_out / conv_input / dilated
         eng.set_tuning(wg_ti_out=ti[0], wg_ti_in=ti[1], wg_ti_dil=ti[2])
         assert torch.equal(run(), split), ti
-    eng.set_tuning(gemm_merge_min=8192, gemm_wg_min=1024, wg_ti_out=1, wg_ti_in=2, wg_ti_dil=2)
+    # the products' items in natural (frame, rank) order instead of grouped by open-tap set: a closed tap adds an exact zero, so
+    # which items share a tile changes no bit -- in either gemm form
+    eng.set_tuning(item_sort=0)
+    assert torch.equal(run(), split)
+    eng.set_tuning(gemm_wg_min=big)
+    assert torch.equal(run(), split)
+    eng.set_tuning(item_sort=1)
+    assert torch.equal(run(), split)
+    eng.set_tuning(gemm_merge_min=8192, gemm_wg_min=1024, wg_ti_out=1, wg_ti_in=2, wg_ti_dil=2, item_sort=2)
     x = torch.zeros(1, 512, 1024)
     x[0, codes[0], np.arange(1024)] = 1
     with torch.no_grad():
@@ -189,7 +197,7 @@ def test_whole_grid_launch_forms_agree_bit_for_bit():
     np.testing.assert_allclose(merged[0].numpy(), ref[0].numpy(), rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize("F_,first", [(7, 600), (3, 905), (33, 333)])
+@pytest.mark.parametrize("F_,first", [(7, 600), (3, 905), (33, 333), (16, 500)])
 def test_workgroup_gemm_form_under_the_prefix_cone_is_bit_identical(F_, first):
     """k_gemm_wg (the whole-grid products with the receptive-field rows staged in LDS once per workgroup) against k_gemm on
     the prefix pass of an AR run -- rank-ordered items, ragged last tiles, per-stage start ranks of the dependency cone,
@@ -213,21 +221,23 @@ def test_workgroup_gemm_form_under_the_prefix_cone_is_bit_identical(F_, first):
     waves = wavefronts(order_loc, 32, 32, first, DEV)
     eng.set_tuning(prefix_cone_force=1, gemm_merge_min=0)
 
-    def run(wg_min):
-        eng.set_tuning(gemm_wg_min=wg_min)
+    def run(wg_min, item_sort=2):
+        eng.set_tuning(gemm_wg_min=wg_min, item_sort=item_sort)
         c = tt(codes0.copy())
         lg = eng.ar_run(c, tt(order_loc), tt(reg), *ms, temperature=0.7, uniforms=u, first_step=first, want_logits=True, waves=waves)
         eng.check()
         return c, lg
     c_wg, l_wg = run(1)
     c_ref, l_ref = run(1 << 30)
-    eng.set_tuning(prefix_cone_force=0, gemm_merge_min=8192, gemm_wg_min=1024)
-    assert torch.equal(c_wg, c_ref)
+    c_nat, l_nat = run(1, item_sort=0)        # items in natural order / one sort over all frames (16 frames: default = one per XCD share)
+    c_one, l_one = run(1 << 30, item_sort=1)
+    eng.set_tuning(prefix_cone_force=0, gemm_merge_min=8192, gemm_wg_min=1024, item_sort=2)
+    assert torch.equal(c_wg, c_ref) and torch.equal(c_nat, c_ref) and torch.equal(c_one, c_ref)
     walked = np.zeros((F_, 1024), bool)
     for b in range(F_):
         walked[b, order_loc[b][first:]] = True
     sel = torch.from_numpy(walked).to(DEV)
-    assert torch.equal(l_wg[sel], l_ref[sel])
+    assert torch.equal(l_wg[sel], l_ref[sel]) and torch.equal(l_nat[sel], l_ref[sel]) and torch.equal(l_one[sel], l_ref[sel])
     assert (c_wg.cpu().numpy()[reg == 1] != codes0[reg == 1]).any()
 
 
