@@ -465,6 +465,7 @@ int ps_pixelcnn_create(const float *const *params, int n_params, int H, int W, i
     if ((rc = dev_alloc(h, &h->perm, 2 * locs))) return fail_out(rc);
     if ((rc = dev_alloc(h, &h->perm_sorted, 2 * locs))) return fail_out(rc);
     if ((rc = dev_alloc(h, &h->perm_cnt, (size_t)2 * 512 * max_frames))) return fail_out(rc);
+    if ((rc = dev_alloc(h, &h->perm_tsum, (size_t)2 * max_frames))) return fail_out(rc);
     if ((rc = dev_alloc(h, &h->taps, locs))) return fail_out(rc);
     if ((rc = dev_alloc(h, &h->nbr_tp, (size_t)2 * NST * 2 * TP_COL_CAP * NBR_LD))) return fail_out(rc);
     if ((rc = dev_alloc(h, &h->cnt_tp, 2 * tp_cnt_index(NST, 0)))) return fail_out(rc);

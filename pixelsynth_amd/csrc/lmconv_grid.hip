@@ -260,27 +260,24 @@ struct PostArgs {
 };
 
 // post op of one item by one wave.  `P` points at channel pair c of the item's y (raw slots `ss` floats apart unless
-// a.summed), `S` at the same pair of its nin_skip slot.
+// a.summed), `S` at the same pair of its nin_skip slot; `loc` = the item's cache row, `rin` = the residual input of a gate
+// (R[node_in] at the location), `b2` = the nin_skip bias -- both fetched by the caller, who can do so for several items at once.
 template <int KIND>
-__device__ __forceinline__ void post_item(const PostArgs &a, int item, int lane, const float *Pbase, size_t ss, const float *Sbase)
+__device__ __forceinline__ void post_item_at(const PostArgs &a, size_t loc, int lane, const float *Pbase, size_t ss, const float *Sbase,
+                                             const f32x2 &rin, const f32x2 &b2)
 {
-    int f, q;
-    item_loc(a.items, item, a.L, f, q);
-    const size_t loc = (size_t)f * a.L + q;
     const bool own = lane < PONO_LANES;
     const int c = own ? 2 * lane : 0;
     const float *P = Pbase + c;
     const f32x2 zero = {0.0f, 0.0f};
     auto ld = [](const float *p) { return *(const f32x2 *)p; };
-    f32x2 g = zero, skip = zero, rin = zero;
+    f32x2 g = zero, skip = zero;
     const f32x2 y = a.summed ? ld(P + SLOT_NA * ss)
                              : slot_sum2(ld(a.bias + c), ld(P + SLOT_NA * ss), ld(P + SLOT_C * ss), ld(P + SLOT_NB * ss));
-    if (KIND == POST_GATE) {
+    if (KIND == POST_GATE)
         g = a.summed ? ld(P + SLOT_NA * ss + NF)
                      : slot_sum2(ld(a.bias + NF + c), ld(P + SLOT_NA * ss + NF), ld(P + SLOT_C * ss + NF), ld(P + SLOT_NB * ss + NF));
-        rin = ld(a.Rin + loc * R_LD + c);
-    }
-    if (KIND == POST_CONVIN && a.has_skip) skip = ld(Sbase + c) + ld(a.bias2 + c);
+    if (KIND == POST_CONVIN && a.has_skip) skip = ld(Sbase + c) + b2;
     const float mean = pono_mean(pono_total(y, own));
     const f32x2 d = y - mean;
     const float inv = pono_inv(pono_total(d * d, own));
@@ -294,6 +291,18 @@ __device__ __forceinline__ void post_item(const PostArgs &a, int item, int lane,
     } else {
         store_raw_celu2(a.Rout, a.Eout, loc, c, out);
     }
+}
+template <int KIND>
+__device__ __forceinline__ void post_item(const PostArgs &a, int item, int lane, const float *Pbase, size_t ss, const float *Sbase)
+{
+    int f, q;
+    item_loc(a.items, item, a.L, f, q);
+    const size_t loc = (size_t)f * a.L + q;
+    const int c = lane < PONO_LANES ? 2 * lane : 0;
+    const f32x2 zero = {0.0f, 0.0f};
+    const f32x2 rin = KIND == POST_GATE ? *(const f32x2 *)(a.Rin + loc * R_LD + c) : zero;
+    const f32x2 b2 = KIND == POST_CONVIN && a.has_skip ? *(const f32x2 *)(a.bias2 + c) : zero;
+    post_item_at<KIND>(a, loc, lane, Pbase, ss, Sbase, rin, b2);
 }
 
 // whole-grid post op: one wave per item, 4 items per 256-thread block
@@ -367,6 +376,7 @@ __global__ __launch_bounds__(GW_THREADS) void k_gemm_wg(GemmArgs a, PostArgs pa,
     __shared__ int sRow[MAX_TAPS * MI];      // input row of (tap, item), -1 = closed (mask 0, outside the grid, item not evaluated)
     __shared__ float sMv[MAX_TAPS * MI];     // its mask value
     __shared__ int sItem[MI];                // item index, -1 = not evaluated here
+    __shared__ int sLoc[MI];                 // its cache row (frame * L + location)
 #ifdef PS_WG_TRACE_BUILD
     __shared__ unsigned long long sChain[4][24];   // tuning builds: stamps inside ONE tap (the fourth open one), per wave: phases of the tap loop
     int tapno = 0;                                 // [16..20]; with -DPS_WG_CHAIN_STAMPS also 5 chains x (start, MFMAs issued, next weights in) [0..15]
@@ -410,7 +420,7 @@ __global__ __launch_bounds__(GW_THREADS) void k_gemm_wg(GemmArgs a, PostArgs pa,
             r = q / a.W;
             c = q - r * a.W;
         }
-        if (wave == 0 && lane < MI) sItem[m] = valid ? item : -1;
+        if (wave == 0 && lane < MI) { sItem[m] = valid ? item : -1; sLoc[m] = valid ? f * a.L + q : 0; }
         for (int t = wave; t < ntaps; t += GW_WAVES) {
             const GemmTap tp = a.tap[t];
             const int rr = r + tp.dr, cc = c + tp.dc;
@@ -667,15 +677,30 @@ __global__ __launch_bounds__(GW_THREADS) void k_gemm_wg(GemmArgs a, PostArgs pa,
     WG_STAMP(14);
     if (fuse_post) {
         float *sY = (float *)sB;
+        // the wave's items are m = wave, wave + 4, ...: what their post ops read from memory -- the residual input of a gate, a row
+        // per item -- is requested for ALL of them here, ahead of the parking and the barrier (fetched item by item inside the loop,
+        // each was a dependent round trip -- order look-up, then the row -- in front of its item: 9-19 k cycles of a workgroup's life)
+        constexpr int NPI = MI / GW_WAVES;
+        const int pc = lane < PONO_LANES ? 2 * lane : 0;
+        const f32x2 z2 = {0.0f, 0.0f};
+        f32x2 rin[NPI], b2 = z2;
+        int ploc[NPI];
+#pragma unroll
+        for (int k = 0; k < NPI; ++k) {
+            ploc[k] = sLoc[wave + GW_WAVES * k];
+            rin[k] = POSTK == POST_GATE ? *(const f32x2 *)(pa.Rin + (size_t)ploc[k] * R_LD + pc) : z2;   // (row 0 for an absent item: loaded, dropped)
+        }
+        if (POSTK == POST_CONVIN && pa.has_skip) b2 = *(const f32x2 *)(pa.bias2 + pc);
         // (conv_input with nin_skip: the skip slot was parked above, after the barrier of the last tap; here the taps are done too)
 #pragma unroll
         for (int k = 0; k < NTL; ++k)
             if (k < NT4 || has5) *(f32x4 *)(sY + m_of(k) * YLD + o_of(k) + kk * 4) = ysum[k];
         __syncthreads();
-        for (int m = wave; m < MI; m += GW_WAVES) {
-            const int item = sItem[m];
-            if (item < 0) continue;   // (wave-uniform)
-            post_item<POSTK>(pa, item, lane, sY + m * YLD, 0, sY + m * YLD + NF);
+#pragma unroll
+        for (int k = 0; k < NPI; ++k) {
+            const int m = wave + GW_WAVES * k;
+            if (sItem[m] < 0) continue;   // (wave-uniform)
+            post_item_at<POSTK>(pa, (size_t)ploc[k], lane, sY + m * YLD, 0, sY + m * YLD + NF, rin[k], b2);
         }
     }
     WG_STAMP(15);
@@ -797,7 +822,8 @@ __global__ __launch_bounds__(1024) void k_prefix_starts(StartsArgs a)
 // `nparts` > 1: one sort per share of the frames, so that the contiguous range of tiles an XCD takes (k_gemm / k_gemm_wg) reads
 // the rows of ITS frames only.  Three small launches per pass and mask kind (dilation 1, dilation 2):
 //   k_perm_sort     per frame: (tap set << 12 | rank) of its items, sorted (bitonic, LDS), and the run length of every tap set
-//   k_perm_scan     first position of every (share, tap set, frame) run: exclusive scan over [share][tap set][frame]
+//   k_perm_scan     first position of every (share, tap set, frame) run: exclusive scan over [share][tap set][frame], in tiles of
+//                   1024 entries (the tiles' totals are scanned by every block of the next launch for itself)
 //   k_perm_scatter  per frame: perm[first + index in the run] = item
 // ------------------------------------------------------------------------------------------
 struct PermArgs {
@@ -806,6 +832,7 @@ struct PermArgs {
     int H, W, L, npre, f0, nf, nparts;
     uint32_t *sorted[2];                // [nf][npre]
     int32_t *cnt[2];                    // [nparts][512][frames per share]
+    int32_t *tsum[2];                   // totals of the table's tiles of 1024 entries
     int32_t *perm[2];                   // [nf * npre]
 };
 constexpr int PERM_KEYS = 512;
@@ -857,30 +884,42 @@ __global__ __launch_bounds__(1024) void k_perm_sort(PermArgs a)
     __syncthreads();
     for (int k = t; k < PERM_KEYS; k += 1024) a.cnt[kind][perm_cnt_index(a, fl, k)] = hist[k];
 }
-__global__ __launch_bounds__(1024) void k_perm_scan(PermArgs a)
+// block-wide exclusive scan of one value per thread (1024 threads); returns the exclusive prefix, *total = the block's sum
+__device__ __forceinline__ int block_exscan_1024(int v, int *sh /*[1024]*/, int *total)
 {
-    __shared__ int part[1024];
-    const int kind = blockIdx.x, t = threadIdx.x;
-    const int n = a.nparts * PERM_KEYS * perm_fpp(a), chunk = (n + 1023) / 1024;
-    int32_t *c = a.cnt[kind];
-    const int lo = min(n, t * chunk), hi = min(n, lo + chunk);
-    int sum = 0;
-    for (int i = lo; i < hi; ++i) sum += c[i];
-    part[t] = sum;
+    const int t = threadIdx.x;
+    sh[t] = v;
     __syncthreads();
     for (int off = 1; off < 1024; off <<= 1) {
-        const int v = t >= off ? part[t - off] : 0;
+        const int u = t >= off ? sh[t - off] : 0;
         __syncthreads();
-        part[t] += v;
+        sh[t] += u;
         __syncthreads();
     }
-    int run = part[t] - sum;
-    for (int i = lo; i < hi; ++i) { const int v = c[i]; c[i] = run; run += v; }
+    *total = sh[1023];
+    return sh[t] - v;
+}
+// grid (tiles of 1024 table entries, mask kinds): run lengths -> exclusive prefix inside the tile, + the tile's total
+__global__ __launch_bounds__(1024) void k_perm_scan(PermArgs a)
+{
+    __shared__ int sh[1024];
+    const int kind = blockIdx.y, i = blockIdx.x * 1024 + threadIdx.x;
+    const int n = a.nparts * PERM_KEYS * perm_fpp(a);
+    int32_t *c = a.cnt[kind];
+    int total;
+    const int ex = block_exscan_1024(i < n ? c[i] : 0, sh, &total);
+    if (i < n) c[i] = ex;
+    if (threadIdx.x == 0) a.tsum[kind][blockIdx.x] = total;
 }
 __global__ __launch_bounds__(1024) void k_perm_scatter(PermArgs a)
 {
     __shared__ int first[PERM_KEYS];
+    __shared__ int sh[1024];
+    __shared__ int tbase[1024];          // first position of every tile of the run-length table (its tiles' totals, scanned)
     const int fl = blockIdx.x, kind = blockIdx.y, t = threadIdx.x;
+    const int ntiles = (a.nparts * PERM_KEYS * perm_fpp(a) + 1023) / 1024;   // <= 1024: maxF <= 2048 (checked by the caller)
+    int total;
+    tbase[t] = block_exscan_1024(t < ntiles ? a.tsum[kind][t] : 0, sh, &total);
     const uint32_t *s = a.sorted[kind] + (size_t)fl * a.npre;
     for (int i = t; i < a.npre; i += 1024) {
         const uint32_t key = s[i] >> 12;
@@ -889,7 +928,8 @@ __global__ __launch_bounds__(1024) void k_perm_scatter(PermArgs a)
     __syncthreads();
     for (int i = t; i < a.npre; i += 1024) {
         const uint32_t v = s[i], key = v >> 12;
-        a.perm[kind][a.cnt[kind][perm_cnt_index(a, fl, (int)key)] + i - first[key]] = fl * a.npre + (int)(v & 4095u);
+        const size_t e = perm_cnt_index(a, fl, (int)key);
+        a.perm[kind][a.cnt[kind][e] + tbase[e >> 10] + i - first[key]] = fl * a.npre + (int)(v & 4095u);
     }
 }
 
@@ -1059,7 +1099,7 @@ void run_grid(ps_pixelcnn *h, int F, const int32_t *codes, const Masks &m, float
     }
     // the products' item lists, grouped by open-tap set (one per mask kind); the frame range's own part of the scratch
     const int32_t *perm[2] = {nullptr, nullptr};
-    if (h->tune.item_sort && h->L <= STARTS_MAXL && all_items.npre >= 2) {
+    if (h->tune.item_sort && h->L <= STARTS_MAXL && all_items.npre >= 2 && nf <= 2048) {
         PermArgs pa{};
         pa.order = order; pa.mask[0] = m.und; pa.mask[1] = m.dil;
         pa.H = h->H; pa.W = h->W; pa.L = h->L; pa.npre = all_items.npre; pa.f0 = f0; pa.nf = nf;
@@ -1069,10 +1109,11 @@ void run_grid(ps_pixelcnn *h, int F, const int32_t *codes, const Masks &m, float
             pa.sorted[k] = h->perm_sorted + k * locs + (size_t)f0 * h->L;
             pa.perm[k] = h->perm + k * locs + (size_t)f0 * h->L;
             pa.cnt[k] = h->perm_cnt + ((size_t)k * h->maxF + f0) * PERM_KEYS;
+            pa.tsum[k] = h->perm_tsum + (size_t)k * h->maxF + f0;
             perm[k] = pa.perm[k];
         }
         hipLaunchKernelGGL(k_perm_sort, dim3(nf, 2), dim3(1024), 0, st, pa);
-        hipLaunchKernelGGL(k_perm_scan, dim3(2), dim3(1024), 0, st, pa);
+        hipLaunchKernelGGL(k_perm_scan, dim3((pa.nparts * PERM_KEYS * ((nf + pa.nparts - 1) / pa.nparts) + 1023) / 1024, 2), dim3(1024), 0, st, pa);
         hipLaunchKernelGGL(k_perm_scatter, dim3(nf, 2), dim3(1024), 0, st, pa);
     }
     float *const part = h->partial + (size_t)4 * f0 * h->L * (2 * NF);

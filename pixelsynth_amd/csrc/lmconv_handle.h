@@ -124,6 +124,7 @@ struct ps_pixelcnn {
     int32_t *perm = nullptr;        // position -> natural item index (frame-local: fl * npre + rank)
     uint32_t *perm_sorted = nullptr;   // scratch: (key << 12 | rank) of every frame, sorted
     int32_t *perm_cnt = nullptr;    // scratch: [2][512 * maxF] run lengths -> first positions
+    int32_t *perm_tsum = nullptr;   // scratch: [2][maxF] totals of that table's tiles of 1024 entries
     int *ctl1 = nullptr;            // the chain roles' control records
     unsigned *cnt = nullptr;        // [2][NST][MAX_TILES] padded completion counters of the neighbour role, never reset
     int *err = nullptr;             // device flag: a bounded wait of a column launch ran out
