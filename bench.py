@@ -51,6 +51,9 @@ def build_model(device):
 
 
 VIEWS_PER_SOURCE = 16   # config C5: 8 source images x 16 novel views each
+# PS_BENCH_FORCE_COLLECTIVE=1: a single-rank run creates the RCCL process group all the same and sends its gathers, barrier and
+# max-over-ranks through it -- the multi-GPU code path (`world > 1` in back()) executed on the one GPU a test box has
+FORCE_COLLECTIVE = os.environ.get("PS_BENCH_FORCE_COLLECTIVE") == "1"
 
 
 def make_inputs(rank, V, device, smooth=True, cameras="mp3d", ids=None, trajectory="sweep"):
@@ -108,7 +111,7 @@ def back(model, d, planned, world, prev=None):
     pass and its first column launch (see finish_gathers)."""
     out = model.outpaint_planned(planned, d["codes"], temperature=0.7, uniforms=d["uniforms"],
                                  between=(lambda: finish_gathers(prev)) if prev is not None and "_gathers" in prev else None)
-    if world > 1:  # what the path produced on every rank -- the reprojected views as 8-bit images (the byte volume of finished
+    if world > 1 or FORCE_COLLECTIVE:  # what the path produced on every rank -- the reprojected views as 8-bit images (the byte volume of finished
         # frames: the VQ-VAE decode that turns codes into pixels is a next-row component, timed under end_to_end_*) and the
         # completed 32x32 code grids -- RCCL all_gather over xGMI.  Started here as asynchronous collectives, collected by
         # finish_gathers() in the NEXT step, between its whole-grid prefix pass and its first column launch: 25 MB per rank and
@@ -116,7 +119,8 @@ def back(model, d, planned, world, prev=None):
         # around the collective's kernels -- and never beside a column launch, which keeps one workgroup per compute unit
         # resident and would wait for the ones a late peer's collective still holds (round-3 advice).
         # PS_BENCH_SYNC_GATHER=1: collected at once, in front of the next step.
-        out["_gathers"] = (D.gather_frames_start(D.to_image_u8(out["gen_fs"])), D.gather_frames_start(out["codes"].contiguous()))
+        out["_gathers"] = (D.gather_frames_start(D.to_image_u8(out["gen_fs"]), force_collective=FORCE_COLLECTIVE),
+                           D.gather_frames_start(out["codes"].contiguous(), force_collective=FORCE_COLLECTIVE))
         if os.environ.get("PS_BENCH_SYNC_GATHER") == "1":
             finish_gathers(out)
     return out
@@ -167,13 +171,15 @@ def run_steps(model, d, world, n, side):
 
 
 def measure_roofline(model, d, out, V):
-    """Average launch of k_column -- the dominant kernel: one launch per WAVEFRONT of independent columns (one column =
-    one order position of one frame) -- over a whole AR run of this step's views, measured with HIP events on the stream
-    the launches go to (ps_pixelcnn_time_ar_run_waves), against the dense algorithmic fp32 work of its columns:
-    11.163 MFLOP per column = the 33-stage centre-tap chain (fp32 FMA chains on the vector ALU, one CU per column)
-    plus the neighbour-tap partial sums of all 32 masked convs (fp32 MFMA on the other XCDs, masked taps skipped).
-    Both share the fp32 dense peak of gfx950 (157.3 TFLOP/s: packed-FMA VALU rate = fp32 MFMA rate).  A launch is
-    bounded by the LATENCY of the 33 dependent stages, not by throughput -- DESIGN.md section 4 has the cycle budget."""
+    """Average column launch -- the dominant kernel: one launch per WAVEFRONT of independent columns (one column = one order
+    position of one frame) -- over a whole AR run of this step's views, measured with HIP events on the stream the launches go to
+    (ps_pixelcnn_time_ar_run_waves, median of three runs), against the dense algorithmic fp32 work of its columns:
+    10.42 MFLOP per column = the 32 matrix stages' centre taps (the chain role: 16-column MFMA tiles in the throughput form
+    k_column_tp, fp32 FMA chains on the vector ALU in the latency form k_column_la) plus the neighbour-tap partial sums of all 32
+    masked convs (fp32 MFMA in both forms, masked taps skipped) -- the u_init product is a gather and is not priced.  fp32 MFMA and
+    packed fp32 FMA share gfx950's dense fp32 peak (157.3 TFLOP/s).  A launch is bounded by the LATENCY of its 33 dependent stages,
+    not by throughput; `traffic`, `mfma_counters` and `kernel_table` come from the newest committed PMC record
+    of the same workload (profiles/README.md names it) -- counter passes cannot run inside a timed bench."""
     plan = out["plan"]
     eng = model.outpaint2.engine(32, 32, V)
     cols, wave_start = plan.waves
@@ -194,10 +200,11 @@ def measure_roofline(model, d, out, V):
     cols_per_launch = ncols / max(1, launches.value)
     fl = fpc.value * cols_per_launch
     tf = fl / (us * 1e-6) / 1e12
-    traffic, traffic_src, mfma_util = None, None, None
+    traffic, traffic_src, mfma_util, kernel_table = None, None, None, None
     pmc = latest_pmc_record(V)   # PMC passes cannot run inside the timed bench: committed summary of the same workload
     if pmc:
         traffic, traffic_src, mfma_util = pmc.get("traffic_bytes_per_launch"), pmc.get("source"), pmc.get("mfma")
+        kernel_table = pmc.get("kernel_table")
     tp = cols_per_launch > 128
     kernel = ("k_column_tp (throughput form of the column launch, one launch per wavefront of up to 1024 independent AR columns: "
               "16-column MFMA chain tiles + one wave per neighbour item, the neighbour role a launch ahead of the chain tiles; "
@@ -211,6 +218,7 @@ def measure_roofline(model, d, out, V):
             "algorithmic_flops_per_launch": round(fl), "avg_launch_us": round(us, 3),
             "flops_per_column": round(fpc.value), "columns_per_launch": round(cols_per_launch, 2),
             "launches_per_ar_run": launches.value, "wavefronts": len(wave_start) - 1, "columns": ncols,
+            "kernel_table": kernel_table,
             "walk_positions_without_wavefronts": 1024 - plan.first_step,
             "reference_definition": {
                 "what": "the same launch priced at what the reference schedules for its columns (SURVEY 8d): one whole-grid "
@@ -609,13 +617,14 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
+    if world > 1 or FORCE_COLLECTIVE:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if dry:
-            torch.distributed.init_process_group("gloo")
+            torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
         else:
-            torch.distributed.init_process_group("nccl", device_id=device)
+            torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     circle = args.trajectory == "circle"
     if args.cameras is None:
@@ -644,9 +653,9 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     model.outpaint2.engine(32, 32, V).check()  # (outside the timed region) no column launch gave up on an in-launch wait
-    elapsed = D.max_over_ranks(dt, None if dry else device)
+    elapsed = D.max_over_ranks(dt, None if dry else device, force_collective=FORCE_COLLECTIVE)
 
-    if rank == 0 and args.dump_gather and world > 1:
+    if rank == 0 and args.dump_gather and (world > 1 or FORCE_COLLECTIVE):
         np.savez_compressed(args.dump_gather, all_codes=out["all_codes"].cpu().numpy(), all_features_u8=out["all_features_u8"].cpu().numpy())
     if rank == 0:
         frames = V * world * args.steps   # (strong: V * world = the job's total)
@@ -675,9 +684,18 @@ def main():
                        "parallelism": f"views sharded over {world} GPU(s), RCCL all_gather of the reprojected views (8-bit) + completed code grids",
                        "step_pipeline": "one stream; host half of step i + 1 on an unmasked side stream"},
         }
+        if torch.distributed.is_available() and torch.distributed.is_initialized():   # what the backend itself reports (tools/scale.sh)
+            res["collective"] = {"backend": torch.distributed.get_backend(), "world_size": torch.distributed.get_world_size(),
+                                 "forced_on_one_rank": bool(FORCE_COLLECTIVE and world == 1)}
         if world == 1:
             try:
                 res["roofline"] = measure_roofline(model, d, out, V)
+                # the step as a whole against the same peak: every view is ONE whole-grid forward's worth of matrix work (SURVEY 8d:
+                # 11.43095 GFLOP, prefix pass + columns), whatever it is scheduled as; splat, planning and launch gaps count as time
+                step_tf = V * 11.43095e9 / (elapsed / args.steps) / 1e12
+                res["roofline"]["step"] = {"what": "views x 11.43095 GFLOP (one whole-grid forward's worth per view) / ms_per_step, the "
+                                                   "timed step with everything in it", "achieved": round(step_tf, 3), "peak": FP32_MFMA_PEAK_TF,
+                                           "unit": "TFLOP/s", "frac": round(step_tf / FP32_MFMA_PEAK_TF, 4)}
             except Exception as e:  # measurement aid must not sink the headline number
                 res["roofline"] = {"error": repr(e)}
             if not args.no_cpu_baseline:
@@ -691,7 +709,7 @@ def main():
                 except Exception as e:
                     res["other_single_gpu_configs"] = {"error": repr(e)}
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if world > 1 or FORCE_COLLECTIVE:
         torch.distributed.destroy_process_group()
 
 

@@ -158,17 +158,18 @@ int ps_ar_plan(const uint8_t *bg, int B, int S, int G, int32_t *order_loc, uint8
         if (rc_b[b]) msg_b[b] = ps::last_error_ref();
     };
     // frames are independent.  One process per GPU on an 8-GPU node shares the host: WORLD_SIZE / LOCAL_WORLD_SIZE (set by
-    // torch.distributed.run) divide the cores, PS_PLAN_THREADS overrides; read once per process, not per plan
-    // (16 at most: 128 frames take 1.8 ms on 16 threads and 3.5 ms on 64 -- thread start-up, measured with tools/plan_time.py)
-    static const int plan_threads = []() {
+    // torch.distributed.run) divide the cores -- that default is worked out once per process; PS_PLAN_THREADS overrides it and is
+    // read on every call (one getenv per plan of ~2 ms), so that a thread-count sweep inside one process measures what it says
+    // (16 at most by default: 128 frames take 1.8 ms on 16 threads and 3.5 ms on 64 -- thread start-up, measured with tools/plan_time.py)
+    static const int default_threads = []() {
         const int hw = (int)std::thread::hardware_concurrency();
         int share = 1;
         if (const char *e = getenv("LOCAL_WORLD_SIZE")) share = std::max(1, atoi(e));
         else if (const char *e2 = getenv("WORLD_SIZE")) share = std::max(1, atoi(e2));
-        int n = std::max(1, std::min(16, hw > 0 ? hw / (2 * share) : 16));
-        if (const char *e = getenv("PS_PLAN_THREADS")) n = std::max(1, atoi(e));
-        return n;
+        return std::max(1, std::min(16, hw > 0 ? hw / (2 * share) : 16));
     }();
+    int plan_threads = default_threads;
+    if (const char *e = getenv("PS_PLAN_THREADS")) plan_threads = std::max(1, atoi(e));
     const int nthreads = std::min(B, plan_threads);
     if (nthreads <= 1) {
         one_frame(0);

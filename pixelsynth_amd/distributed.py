@@ -71,7 +71,14 @@ class PendingGather:
         return out if self.n_views is None else out[:self.n_views]
 
 
-def gather_frames_start(local, n_views=None):
+def _collective(force):
+    """Does a call go through the backend?  With more than one rank always; on a single rank only when asked to (`force_collective`:
+    the one-rank RCCL execution of the -m gpu tests and of `PS_BENCH_FORCE_COLLECTIVE=1 python bench.py` -- the same calls, streams
+    and waits a multi-GPU job makes, on the one GPU a test box has) and a process group exists."""
+    return world()[1] > 1 or (force and dist.is_available() and dist.is_initialized())
+
+
+def gather_frames_start(local, n_views=None, force_collective=False):
     """Start the all_gather of the finished frames and return at once (-> PendingGather): the collective runs on the backend's own
     stream, behind what the current stream has enqueued so far, and whatever the caller enqueues next -- the following batch's
     whole-grid pass -- runs beside it.  It must be COLLECTED (PendingGather.result(): the current stream waits for it) before the
@@ -80,7 +87,7 @@ def gather_frames_start(local, n_views=None):
     through outpaint_planned(between=...), between the next step's prefix pass and its first column launch.
     local as for gather_frames."""
     rank, w = world()
-    if w == 1:
+    if not _collective(force_collective):
         return PendingGather(local, n_views)
     staged = local.contiguous()
     if staged.is_cuda and dist.get_backend() == "gloo":
@@ -90,11 +97,11 @@ def gather_frames_start(local, n_views=None):
     return PendingGather(local, n_views, work, bufs, staged)
 
 
-def gather_frames(local, n_views=None):
+def gather_frames(local, n_views=None, force_collective=False):
     """all_gather of the finished frames.  local: (V_local, ...) tensor, same V_local on every rank (pad the
     last round when n_views is not a multiple of the world size).  Returns (W*V_local, ...) ordered by VIEW
     index when the views were dealt with shard_views (view v sits at row v); trimmed to n_views if given."""
-    return gather_frames_start(local, n_views).result()
+    return gather_frames_start(local, n_views, force_collective).result()
 
 
 def to_image_u8(frames):
@@ -103,10 +110,10 @@ def to_image_u8(frames):
     return ((frames.clamp(-1.0, 1.0) * 0.5 + 0.5) * 255.0 + 0.5).to(torch.uint8)
 
 
-def max_over_ranks(seconds, device=None):
+def max_over_ranks(seconds, device=None, force_collective=False):
     """Slowest rank's wall time (bench.py contract: take the MAX over ranks)."""
     rank, w = world()
-    if w == 1:
+    if not _collective(force_collective):
         return float(seconds)
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -125,12 +132,12 @@ def owner_of(index, world_size=None):
     return index % world_size
 
 
-def broadcast_from(tensor, src, device):
+def broadcast_from(tensor, src, device, force_collective=False):
     """Broadcast `tensor` from rank `src` to every rank; the other ranks pass None (or anything) and learn shape and dtype
     from the owner first -- a rank that holds no candidate of its own cannot know the shape of a decoded / refined image
     (it is not gen_fs's when the features are not RGB).  -> the tensor, on `device`, on every rank."""
     rank, w = world()
-    if w == 1:
+    if not _collective(force_collective):
         return tensor
     gloo = dist.get_backend() == "gloo"
     meta = torch.zeros(8, dtype=torch.int64)
@@ -152,7 +159,7 @@ def broadcast_from(tensor, src, device):
     return buf.to(device)
 
 
-def gather_scores(disc_local, entr_local, n):
+def gather_scores(disc_local, entr_local, n, force_collective=False):
     """Sample ranking across ranks: every rank scored the candidates shard_views(n) gave it -- discriminator score
     and classifier entropy, two scalars each -- and all ranks need all n of both to apply the rank rule.  One all_gather of a
     (2, ceil(n / W)) float64 block per rank.  -> (disc (n,), entr (n,)) numpy arrays, by candidate index."""
@@ -162,7 +169,7 @@ def gather_scores(disc_local, entr_local, n):
     block = torch.zeros(2, per, dtype=torch.float64)
     block[0, :len(disc_local)] = torch.as_tensor(list(disc_local), dtype=torch.float64)
     block[1, :len(entr_local)] = torch.as_tensor(list(entr_local), dtype=torch.float64)
-    if w == 1:
+    if not _collective(force_collective):
         return block[0, :n].numpy().copy(), block[1, :n].numpy().copy()
     if dist.get_backend() != "gloo":
         block = block.cuda()

@@ -298,7 +298,7 @@ class ZbufferModelPts(nn.Module):
         """Second half: AR outpainting of the 32x32 code grids (a13) of the views prepared by plan_views; asynchronous
         on the current stream.  Adds `codes` (V,32,32) int32 to the dict and returns it.
         between: a callable run on the current stream BETWEEN the whole-grid prefix pass and the first column launch (the two
-        halves of the AR run, ps_pixelcnn_ar_prefix / ps_pixelcnn_ar_columns).  bench.py / driver.py make the stream wait there
+        halves of the AR run, ps_pixelcnn_ar_prefix / ps_pixelcnn_ar_columns).  bench.py makes the stream wait there
         for the previous step's asynchronous frame gather: the collective's kernels then run beside the prefix pass -- whose
         small workgroups fit around them -- and are through before a column launch asks for every compute unit."""
         gen_fs, plan = planned["gen_fs"], planned["plan"]

@@ -408,6 +408,52 @@ def test_plan_views_then_outpaint_planned_equals_outpaint_views_also_across_stre
     assert torch.equal(out["gen_fs"], ref["gen_fs"]) and torch.equal(out["background_mask"], ref["background_mask"])
 
 
+def test_outpaint_planned_with_a_between_callback_runs_it_once_after_the_prefix_pass():
+    """outpaint_planned(between=...) is the split form of the AR run -- ps_pixelcnn_ar_prefix, the callback, ps_pixelcnn_ar_columns --
+    that bench.py takes under torch.distributed (the stream waits there for the previous step's gathers).  The callback runs
+    exactly once, on the current stream, after the whole-grid prefix pass and before the first column launch, and the codes are
+    those of the unsplit run (between=None)."""
+    m = make_model()
+    V = 3
+    cam = syn.demo_cameras(V)
+    img, depth = tt(syn.image(61, V, 3, 256)), tt(syn.depth_smooth(62, V, 256, 1.0, 100.0))
+    rts = [syn.yaw_pose(cam["P"][v:v + 1], y) for v, y in enumerate((0.6, -0.45, 0.3))]
+    RT2, RT2inv = tt(np.concatenate([r[1] for r in rts])), tt(np.concatenate([r[0] for r in rts]))
+    codes, uni = tt(syn.codes(63, V)), tt(np.random.RandomState(64).rand(V, 1024).astype(np.float32))
+    args = (img, depth, tt(cam["K"]), tt(cam["Kinv"]), tt(cam["P"]), tt(cam["Pinv"]), RT2, RT2inv)
+    ref = m.outpaint_planned(m.plan_views(*args), codes, temperature=0.7, uniforms=uni)
+    ref_codes = ref["codes"].clone()
+    eng = m.outpaint2.engine(32, 32, V)
+    calls, seen = [], {}
+    real_prefix, real_columns = eng.ar_prefix, eng.ar_columns
+
+    def between():
+        calls.append(len(calls))
+        seen["order"] = list(seen.get("order", [])) + ["between"]
+        # on the current stream, behind the prefix pass: a marker the column launches must come after
+        seen["marker"] = torch.cuda.Event(enable_timing=True)
+        seen["marker"].record()
+
+    def prefix(*a, **k):
+        seen["order"] = list(seen.get("order", [])) + ["prefix"]
+        return real_prefix(*a, **k)
+
+    def columns(*a, **k):
+        seen["order"] = list(seen.get("order", [])) + ["columns"]
+        return real_columns(*a, **k)
+    eng.ar_prefix, eng.ar_columns = prefix, columns
+    try:
+        out = m.outpaint_planned(m.plan_views(*args), codes, temperature=0.7, uniforms=uni, between=between)
+    finally:
+        eng.ar_prefix, eng.ar_columns = real_prefix, real_columns
+    torch.cuda.synchronize()
+    eng.check()
+    assert calls == [0] and seen["order"] == ["prefix", "between", "columns"]
+    assert seen["marker"].query()
+    assert torch.equal(out["codes"], ref_codes)
+    assert (out["codes"].cpu().numpy() != syn.codes(63, V)).any()     # the region was outpainted at all
+
+
 def test_get_best_sample_batches_the_candidates_without_changing_them():
     """The num_samples candidates of a view run through the sampler together (sample-parallel frames); every candidate
     must be exactly what a run of its own produces."""

@@ -63,9 +63,31 @@ rec = {
                       "WRITE_SIZE_KB_mean": round(pmc[k]["WRITE_SIZE"][1]), "SQ_INSTS_MFMA_per_launch": int(pmc[k]["SQ_INSTS_MFMA"][1]),
                       "avg_us_under_trace": round(avg_us[k], 1), "mfma_busy_fraction_of_all_simd_cycles": busy(k)}
                   for k in sorted(pmc) if k.startswith("k_gemm_wg")},
+    "kernel_table": None,   # filled below
     "source": f"profiles/{tag}_bench_v{views}_pmc_summary.txt + profiles/{tag}_bench_v{views}_kernel_stats.csv (tools/collect_profiles.sh {tag}; "
               "tools/pmc_record.py); traffic_bytes_per_launch is the average over ALL column launches of an AR run, as bench.py's avg_launch_us is",
 }
+# where a step's time is: every kernel of the profiled command that takes more than 0.5 % of it.  The command runs 3 pipelined steps
+# and the 3 extra AR runs of measure_roofline: the AR kernels (namespace pslm) are dispatched 6 times per "step's worth", the splat
+# kernels 3 times.
+stats = {}
+for r in csv.DictReader(open(os.path.join(root, "kernel_stats.csv"))):
+    raw = r["Name"].replace("(anonymous namespace)::", "").replace("void ", "")
+    stats[raw.replace("pslm::", "").split("(")[0]] = (int(r["Calls"]), float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6, "pslm::" in raw)
+total_ms = sum(v[2] for v in stats.values())
+table = []
+for k, (calls, us, ms, ar) in sorted(stats.items(), key=lambda kv: -kv[1][2]):
+    if ms < 0.005 * total_ms:
+        continue
+    row = {"kernel": k, "launches_per_step": round(calls / (6 if ar else 3), 1), "avg_us_under_trace": round(us, 1)}
+    c = pmc.get(k, {})
+    if "SQ_INSTS_MFMA" in c and c["SQ_INSTS_MFMA"][1] > 0:
+        row["mfma_busy"] = busy(k)
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        row["traffic_MB_per_launch"] = round(traffic(k) / 1e6, 1)
+    row["ms_per_step"] = round(row["launches_per_step"] * us / 1e3, 3)
+    table.append(row)
+rec["kernel_table"] = table
 out = os.path.join(os.path.dirname(root), "..", "profiles")
 for src, dst in (("kernel_stats.csv", f"{tag}_bench_v{views}_kernel_stats.csv"), ("pmc_summary.txt", f"{tag}_bench_v{views}_pmc_summary.txt")):
     with open(os.path.join(root, src)) as fi, open(os.path.join(out, dst), "w") as fo:
