@@ -31,7 +31,7 @@ def main():
             busy = busy @ busy + 1.0                      # something on the current stream the collectives run beside
         got_c, got_f = pend_c.result(), pend_f.result()   # Work.wait(): the current STREAM waits, the host does not
         tail = (got_f.float().sum() + got_c.float().sum()).item()   # consumed on the current stream, after the wait
-        res["rows_equal"] = bool(torch.equal(got_f, u8) and torch.equal(got_c, codes) and got_f.is_cuda) and np.isfinite(tail)
+        res["rows_equal"] = bool(torch.equal(got_f, u8) and torch.equal(got_c, codes) and got_f.is_cuda and np.isfinite(tail))
         res["sync_form_equal"] = bool(torch.equal(D.gather_frames(codes, 16, force_collective=True), codes))
         img = torch.rand(1, 3, 32, 32, device=dev)
         b = D.broadcast_from(img, 0, dev, force_collective=True)
