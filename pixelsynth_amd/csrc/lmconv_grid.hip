@@ -605,6 +605,13 @@ __global__ __launch_bounds__(GW_THREADS) void k_gemm_wg(GemmArgs a, PostArgs pa,
         if (has5 && tiles_of(t) == (1u << TI) - 1u) tap_products(t, nxt, buf, std::integral_constant<bool, true>{});
         else tap_products(t, nxt, buf, std::integral_constant<bool, false>{});
     };
+    // The barrier of a tap exchanges LDS data only (the staged rows): it drains the LDS queue, not the vector-memory queue --
+    // __syncthreads() would also sit out the weight requests of the next tap's first chain, issued just before it on purpose.
+#ifndef PS_WG_TAP_SYNCTHREADS
+    auto tap_barrier = [] { lds_barrier(); };
+#else
+    auto tap_barrier = [] { __syncthreads(); };
+#endif
     // ---- the taps in slot order NA, C, NB (, SKIP); the open ones staged through sB
     int cur = next_live(-1), buf = 0;
     if (cur < ntaps) {
@@ -628,13 +635,13 @@ __global__ __launch_bounds__(GW_THREADS) void k_gemm_wg(GemmArgs a, PostArgs pa,
             if (DB) {
                 if (nxt < ntaps) stage_store(nxt, buf ^ 1);
                 CH_STAMP(19);
-                __syncthreads();                 // next tap's rows visible; everybody is done with this tap's
+                tap_barrier();                   // next tap's rows visible; everybody is done with this tap's
                 CH_STAMP(20);
                 buf ^= 1;
             } else {
-                __syncthreads();                 // everybody is done with this tap's rows
+                tap_barrier();                   // everybody is done with this tap's rows
                 if (nxt < ntaps) stage_store(nxt, 0);
-                __syncthreads();
+                tap_barrier();
             }
             cur = nxt;
             WG_STAMP(nstamp < 14 ? nstamp : 13);
@@ -709,6 +716,217 @@ __global__ __launch_bounds__(GW_THREADS) void k_gemm_wg(GemmArgs a, PostArgs pa,
     if (a.trace_on && (y & 127) == 0 && (y >> 7) < 32 && tid < 96) g_wg_chain[KIND][y >> 7][tid / 24][tid % 24] = sChain[tid / 24][tid % 24];
 #endif
     span_end();
+}
+
+// ------------------------------------------------------------------------------------------
+// k_gemm_ws: the whole-grid products with the WEIGHTS shared through LDS (round 5).
+//
+// k_gemm_wg fetches a wave's weights from L2 into registers for every 16 (or 32) items: at the full MFMA rate that stream alone
+// is 32 B/clk per CU against the ~41 B/clk a CU's vector-memory path passes -- the kernel sat at 0.45-0.5 MFMA-busy whatever was
+// done to its waves.  With the items grouped by open-tap set (k_perm_*), 64 consecutive items share their taps as well as 16 do,
+// so the operands change places:
+//   * a workgroup of four waves owns 64 items; wave w owns item tile w (16 items) and ALL output channels (10 or 5 MFMA tiles);
+//   * operand A, the weights of one (tap, accumulation chain) -- 20 KB for conv_out -- is staged in LDS ONCE per workgroup, in
+//     MFMA fragment order, two buffers: the chunk after the current one is requested into registers before the chain's MFMAs and
+//     parked behind them, one LDS-only barrier per chunk.  A weight byte fetched from L2 now feeds 64 items instead of 16;
+//   * operand B, a wave's own 16 input rows, goes straight from L2 to its registers a chain ahead (nobody else reads them);
+//   * a tap that is closed for all 16 items of a wave is skipped by that wave (it keeps the barriers), a tap closed for all 64
+//     is skipped by the workgroup; the post op runs in the tail exactly as in k_gemm_wg.
+// Arithmetic and order are k_gemm's to the bit (five chains per tap, chain j = channel groups j, j + 5 in MFMA order, tap value
+// (((a0 + a1) + a2) + a3) + a4, taps added in order into the slot, y = ((bias + NA) + C) + NB, the nin_skip slot raw).
+// ------------------------------------------------------------------------------------------
+#ifndef PS_WS_EXP   // tuning builds only (results INVALID): 1 no MFMAs, 2 no weight staging, 4 no input-row loads, 8 no chunk barriers, 16 no post op
+#define PS_WS_EXP 0
+#endif
+constexpr int WS_WAVES = 4, WS_THREADS = 64 * WS_WAVES, WS_MI = 16 * WS_WAVES;
+constexpr int ws_occ(int kind) { return kind == GW_CONVOUT ? 2 : 3; }
+template <int KIND>
+__attribute__((amdgpu_waves_per_eu(ws_occ(KIND), ws_occ(KIND))))
+__global__ __launch_bounds__(WS_THREADS) void k_gemm_ws(GemmArgs a, PostArgs pa)
+{
+    constexpr int NGH = KIND == GW_DIL ? 1 : 2, NOT = KIND == GW_CONVOUT ? 10 : 5, CO = 16 * NOT, MI = WS_MI;
+    constexpr int POSTK = KIND == GW_CONVOUT ? POST_GATE : KIND == GW_CONVIN ? POST_CONVIN : POST_DIL;
+    constexpr int YLD = KIND == GW_DIL ? 84 : 168;
+    constexpr int HALF = 4 * CO;                 // f32x4 of one 16-channel group of a tap's weights: [kk][o]
+    constexpr int CHUNK = NGH * HALF;            // one (tap, chain) chunk: groups j and j + 5
+    constexpr int SVN = (CHUNK + WS_THREADS - 1) / WS_THREADS;   // staging elements per thread (the last one may be absent)
+    constexpr int NB4 = 2 * CHUNK > MI * YLD / 4 ? 2 * CHUNK : MI * YLD / 4;   // (the post op's tile reuses the weight buffers)
+    constexpr int NQ = NGH * NOT;                // A fragments of a chain, in the order they are used: q = h * NOT + tile
+    __shared__ f32x4 sA[NB4];
+    __shared__ int sRow[MAX_TAPS * MI];
+    __shared__ float sMv[MAX_TAPS * MI];
+    __shared__ int sItem[MI], sLoc[MI];
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, i = lane & 15, kk = lane >> 4;
+    const int xcd = blockIdx.x & (N_XCD - 1), tb = blockIdx.x >> 3;
+    const int y = xcd * a.tpx + tb;              // contiguous item ranges per XCD, as in k_gemm
+    if (tb >= a.tpx || y >= a.ny) return;
+    const int item0 = y * MI, ntaps = a.slot_first[a.nslots];
+    const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+    {   // ---- set-up: rows and mask values of every (tap, item): lane = item, wave w does taps w, w + 4, w + 8
+        const int item = item_at(a.items, item0 + lane, a.nitems);
+        const bool valid = item >= 0 && item_wanted(a.items, item);
+        int f = 0, q = 0, r = 0, c = 0;
+        if (valid) {
+            item_loc(a.items, item, a.L, f, q);
+            r = q / a.W;
+            c = q - r * a.W;
+        }
+        if (wave == 0) { sItem[lane] = valid ? item : -1; sLoc[lane] = valid ? f * a.L + q : 0; }
+        for (int t = wave; t < ntaps; t += WS_WAVES) {
+            const GemmTap tp = a.tap[t];
+            const int rr = r + tp.dr, cc = c + tp.dc;
+            float mv = 0.0f;
+            if (valid && rr >= 0 && rr < a.H && cc >= 0 && cc < a.W)
+                mv = tp.mask_row >= 0 ? a.mask[(size_t)f * a.mask_fstride + (size_t)tp.mask_row * a.L + q] : 1.0f;
+            sRow[t * MI + lane] = mv != 0.0f ? (f * a.L + rr * a.W + cc) : -1;
+            sMv[t * MI + lane] = mv;
+        }
+    }
+    __syncthreads();
+    // taps with an open item in the workgroup / in this wave's item tile (wave-uniform)
+    unsigned wg_live = 0, my_live = 0;
+    for (int t = 0; t < ntaps; ++t) {
+        const unsigned long long b = __ballot(sRow[t * MI + lane] >= 0);
+        if (b) wg_live |= 1u << t;
+        if ((b >> (16 * wave)) & 0xFFFFull) my_live |= 1u << t;
+    }
+    if (wg_live == 0 && __ballot(sItem[lane] >= 0) == 0ull) return;   // nothing of this tile is evaluated here
+    auto next_live = [&](int t) {   // first tap after t that is open somewhere in the workgroup, or ntaps
+        int n = t + 1;
+        while (n < ntaps && !((wg_live >> n) & 1u)) ++n;
+        return n;
+    };
+    // ---- weights: element e = tid + 256 s of a chunk is (h, kk, o); it comes from [group j + 5 h][kk][o] of the tap's packed weights
+    // and goes to [h][output tile][lane (o % 16, kk)] of the buffer -- the order the MFMA A fragments are read in
+    int goff[SVN], loff[SVN];
+#pragma unroll
+    for (int sx = 0; sx < SVN; ++sx) {
+        const int e = min(tid + WS_THREADS * sx, CHUNK - 1), h = e / HALF, r = e - h * HALF, k4 = r / CO, o = r - k4 * CO;
+        goff[sx] = h * 5 * HALF + r;
+        loff[sx] = h * HALF + (o >> 4) * 64 + k4 * 16 + (o & 15);
+    }
+    f32x4 sv[SVN];
+    auto w_load = [&](int t, int j) {
+        const f32x4 *w = (const f32x4 *)a.tap[t].w + j * HALF;
+#pragma unroll
+        for (int sx = 0; sx < SVN; ++sx) sv[sx] = w[goff[sx]];   // (the absent element of the last round re-reads a valid one)
+    };
+    auto w_store = [&](int buf) {
+#pragma unroll
+        for (int sx = 0; sx < SVN; ++sx)
+            if (sx < SVN - 1 || CHUNK % WS_THREADS == 0 || tid + WS_THREADS * sx < CHUNK) sA[buf * CHUNK + loff[sx]] = sv[sx];
+    };
+    // ---- input rows of this wave's 16 items: lane (i, kk) carries channels 16 g + 4 kk .. + 3 of item i
+    const float *bsrc = nullptr;     // row of the tap being loaded (the zero row where it is closed: loaded, dropped)
+    float bmv = 0.0f;
+    bool bopen = false;
+    f32x4 bn[NGH];                   // a chain ahead
+    auto b_tap = [&](int t) {        // the lane's row of tap t
+        const int row = sRow[t * MI + wave * 16 + i];
+        bmv = sMv[t * MI + wave * 16 + i];
+        bopen = row >= 0;
+        bsrc = (bopen ? a.tap[t].in + (size_t)row * a.tap[t].ld : (const float *)g_zero_row) + 4 * kk;
+    };
+    auto b_load = [&](int j) {
+#pragma unroll
+        for (int h = 0; h < NGH; ++h) bn[h] = *(const f32x4 *)(bsrc + 16 * (j + 5 * h));
+    };
+    f32x4 tot[NOT], ysum[NOT];
+#pragma unroll
+    for (int k = 0; k < NOT; ++k) { tot[k] = zero; ysum[k] = zero; }
+    int cur = next_live(-1), buf = 0;
+    if (cur < ntaps) {
+        w_load(cur, 0);
+        b_tap(cur);
+        b_load(0);
+        w_store(0);
+    }
+    lds_barrier();
+    for (int slot = 0; slot < a.nslots; ++slot) {
+        for (int t = a.slot_first[slot]; t < a.slot_first[slot + 1]; ++t) {
+            if (t != cur) continue;              // closed for the whole workgroup: an exact zero, skipped by every wave
+            const int nxt = next_live(t);
+            const bool mine = (my_live >> t) & 1u;
+            f32x4 taptot[NOT];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                // the chunk after this one into registers, under the MFMAs (of this tap again when there is none: same requests on every path)
+                if (!(PS_WS_EXP & 2)) { if (j < 4) w_load(t, j + 1); else w_load(nxt < ntaps ? nxt : t, 0); }
+                f32x4 bv[NGH];
+#pragma unroll
+                for (int h = 0; h < NGH; ++h) bv[h] = bopen ? bn[h] * bmv : zero;   // (x * 1.0f is x: 0 / 1 masks cost nothing)
+                if (j == 4) b_tap(nxt < ntaps ? nxt : t);
+                if (!(PS_WS_EXP & 4)) b_load(j < 4 ? j + 1 : 0);
+                if (mine && !(PS_WS_EXP & 1)) {
+                    const f32x4 *A = sA + buf * CHUNK + lane;
+                    // the A fragments of the pair after this one are requested BEFORE this pair's MFMAs and nothing may sink them
+                    // behind (left alone, the scheduler read every pair's fragments right in front of its MFMAs: an LDS round
+                    // trip per 8 MFMAs)
+                    f32x4 acc[NOT], w0 = A[0], w1 = A[64], w2 = zero, w3 = zero;
+#pragma unroll
+                    for (int q = 0; q < NQ; q += 2) {
+                        if (q + 2 < NQ) w2 = A[((q + 2) / NOT) * HALF + ((q + 2) % NOT) * 64];
+                        if (q + 3 < NQ) w3 = A[((q + 3) / NOT) * HALF + ((q + 3) % NOT) * 64];
+                        __builtin_amdgcn_sched_barrier(0);
+                        const int h0 = q / NOT, k0 = q % NOT, h1 = (q + 1) / NOT, k1 = (q + 1) % NOT;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            acc[k0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[c], bv[h0][c], h0 == 0 && c == 0 ? zero : acc[k0], 0, 0, 0);
+                            if (q + 1 < NQ)
+                                acc[k1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[c], bv[h1][c], h1 == 0 && c == 0 ? zero : acc[k1], 0, 0, 0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        w0 = w2;
+                        w1 = w3;
+                    }
+#pragma unroll
+                    for (int k = 0; k < NOT; ++k) taptot[k] = j == 0 ? acc[k] : taptot[k] + acc[k];
+                }
+                if (!(PS_WS_EXP & 2)) w_store(buf ^ 1);
+                if (!(PS_WS_EXP & 8)) lds_barrier();                   // the next chunk is visible; everybody is done with this one
+                buf ^= 1;
+            }
+            if (mine && !(PS_WS_EXP & 1)) {
+#pragma unroll
+                for (int k = 0; k < NOT; ++k) tot[k] = tot[k] + taptot[k];
+            }
+            cur = nxt;
+        }
+        if (slot == SLOT_SKIP) {                 // (the last slot: every chunk is consumed, the buffers are free)
+            float *sY = (float *)sA;
+#pragma unroll
+            for (int k = 0; k < NOT; ++k) *(f32x4 *)(sY + (wave * 16 + i) * YLD + NF + 16 * k + kk * 4) = tot[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < NOT; ++k) ysum[k] = (slot == SLOT_NA ? *(const f32x4 *)(a.sum_bias + 16 * k + kk * 4) : ysum[k]) + tot[k];
+        }
+#pragma unroll
+        for (int k = 0; k < NOT; ++k) tot[k] = zero;
+    }
+    // ---- the post op of the stage on the workgroup's 64 items, 16 per wave (as in k_gemm_wg)
+    {
+        float *sY = (float *)sA;
+        constexpr int NPI = MI / WS_WAVES;
+        const int pc = lane < PONO_LANES ? 2 * lane : 0;
+        const f32x2 z2 = {0.0f, 0.0f};
+        f32x2 rin[NPI], b2 = z2;
+        int ploc[NPI];
+#pragma unroll
+        for (int k = 0; k < NPI; ++k) {
+            ploc[k] = sLoc[wave + WS_WAVES * k];
+            rin[k] = POSTK == POST_GATE ? *(const f32x2 *)(pa.Rin + (size_t)ploc[k] * R_LD + pc) : z2;
+        }
+        if (POSTK == POST_CONVIN && pa.has_skip) b2 = *(const f32x2 *)(pa.bias2 + pc);
+#pragma unroll
+        for (int k = 0; k < NOT; ++k) *(f32x4 *)(sY + (wave * 16 + i) * YLD + 16 * k + kk * 4) = ysum[k];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NPI; ++k) {
+            const int m = wave + WS_WAVES * k;
+            if (sItem[m] < 0 || (PS_WS_EXP & 16)) continue;   // (wave-uniform)
+            post_item_at<POSTK>(pa, (size_t)ploc[k], lane, sY + m * YLD, 0, sY + m * YLD + NF, rin[k], b2);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -836,6 +1054,21 @@ struct PermArgs {
     int32_t *perm[2];                   // [nf * npre]
 };
 constexpr int PERM_KEYS = 512;
+// Sort key of a tap set: its place in the order (number of open taps, descending; then the 9-bit set).  The workgroups of a launch
+// are dispatched in item order, so the tiles with the most taps -- the longest jobs -- start first and the launch's tail is made of
+// the cheapest ones (longest-processing-time-first: a tile of 7 open taps costs twice one of 3, and 64-item workgroups fill the
+// chip only two to three times over).
+struct PermBins { unsigned short v[PERM_KEYS]; };
+constexpr PermBins make_perm_bins()
+{
+    PermBins t{};
+    int n = 0;
+    for (int pc = 9; pc >= 0; --pc)
+        for (int p = 0; p < PERM_KEYS; ++p)
+            if (__builtin_popcount((unsigned)p) == pc) t.v[p] = (unsigned short)n++;
+    return t;
+}
+__device__ const PermBins g_perm_bin = make_perm_bins();
 __device__ __forceinline__ int perm_fpp(const PermArgs &a) { return (a.nf + a.nparts - 1) / a.nparts; }   // frames per share
 __device__ __forceinline__ size_t perm_cnt_index(const PermArgs &a, int fl, int key)
 {
@@ -860,7 +1093,11 @@ __global__ __launch_bounds__(1024) void k_perm_sort(PermArgs a)
                 const int yy = y + (tap / 3 - 1) * dil, xx = x + (tap % 3 - 1) * dil;
                 if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W && mask[((size_t)f * 9 + tap) * a.L + q] != 0.0f) key |= 1u << tap;
             }
+#ifdef PS_PERM_PLAIN_BINS   // (tuning builds: the tap sets in the order of their 9-bit value)
             v = key << 12 | (uint32_t)r;
+#else
+            v = (uint32_t)g_perm_bin.v[key] << 12 | (uint32_t)r;
+#endif
         }
         s[r] = v;
     }
@@ -1057,6 +1294,17 @@ bool launch_gemm(GemmArgs &a, int item_blocks, hipStream_t st, const Tuning &tun
         const int per_pass = kind == GW_DIL ? 4 : 14;
         a.trace_on = a.ny >= 2048 && seen[kind]++ % per_pass == (sel < per_pass ? sel : per_pass - 1);
 #endif
+        if (tune.gemm_ws && post != nullptr) {   // weights shared through LDS, 64 items per workgroup (round 5)
+            a.ny = (a.nitems + WS_MI - 1) / WS_MI;
+            a.tpx = (a.ny + N_XCD - 1) / N_XCD;
+            PostArgs pw = *post;
+            pw.summed = 1;
+            const dim3 gws((unsigned)(N_XCD * a.tpx)), bws(WS_THREADS);
+            if (kind == GW_CONVOUT) hipLaunchKernelGGL((k_gemm_ws<GW_CONVOUT>), gws, bws, 0, st, a, pw);
+            else if (kind == GW_CONVIN) hipLaunchKernelGGL((k_gemm_ws<GW_CONVIN>), gws, bws, 0, st, a, pw);
+            else hipLaunchKernelGGL((k_gemm_ws<GW_DIL>), gws, bws, 0, st, a, pw);
+            return true;
+        }
         const bool fuse = post != nullptr;
         PostArgs pp{};
         if (fuse) { pp = *post; pp.summed = 1; }

@@ -175,9 +175,12 @@ def test_whole_grid_launch_forms_agree_bit_for_bit():
     eng.set_tuning(gemm_merge_min=big)
     split = run()
     assert torch.equal(merged, split)
-    eng.set_tuning(gemm_merge_min=0, gemm_wg_min=1)   # k_gemm_wg: four-wave workgroups, input rows shared through LDS, post op fused (large launches)
+    eng.set_tuning(gemm_merge_min=0, gemm_wg_min=1, gemm_ws=0)   # k_gemm_wg: four-wave workgroups, input rows shared through LDS, post op fused (large launches)
     wg = run()
     assert torch.equal(wg, split)
+    eng.set_tuning(gemm_ws=1)                         # k_gemm_ws: 64 items per workgroup, the WEIGHTS shared through LDS
+    assert torch.equal(run(), split)
+    eng.set_tuning(gemm_ws=0)
     for ti in ((2, 2, 2), (1, 4, 4), (2, 4, 2)):      # item tiles per workgroup: conv_out / conv_input / dilated
         eng.set_tuning(wg_ti_out=ti[0], wg_ti_in=ti[1], wg_ti_dil=ti[2])
         assert torch.equal(run(), split), ti
@@ -189,7 +192,9 @@ def test_whole_grid_launch_forms_agree_bit_for_bit():
     assert torch.equal(run(), split)
     eng.set_tuning(item_sort=1)
     assert torch.equal(run(), split)
-    eng.set_tuning(gemm_merge_min=8192, gemm_wg_min=1024, wg_ti_out=1, wg_ti_in=2, wg_ti_dil=2, item_sort=2)
+    eng.set_tuning(gemm_wg_min=1, gemm_ws=1)
+    assert torch.equal(run(), split)                  # (k_gemm_ws over one sort of all frames)
+    eng.set_tuning(gemm_merge_min=8192, gemm_wg_min=1024, wg_ti_out=1, wg_ti_in=2, wg_ti_dil=2, item_sort=2, gemm_ws=0)
     x = torch.zeros(1, 512, 1024)
     x[0, codes[0], np.arange(1024)] = 1
     with torch.no_grad():
@@ -221,8 +226,8 @@ def test_workgroup_gemm_form_under_the_prefix_cone_is_bit_identical(F_, first):
     waves = wavefronts(order_loc, 32, 32, first, DEV)
     eng.set_tuning(prefix_cone_force=1, gemm_merge_min=0)
 
-    def run(wg_min, item_sort=2):
-        eng.set_tuning(gemm_wg_min=wg_min, item_sort=item_sort)
+    def run(wg_min, item_sort=2, gemm_ws=0):
+        eng.set_tuning(gemm_wg_min=wg_min, item_sort=item_sort, gemm_ws=gemm_ws)
         c = tt(codes0.copy())
         lg = eng.ar_run(c, tt(order_loc), tt(reg), *ms, temperature=0.7, uniforms=u, first_step=first, want_logits=True, waves=waves)
         eng.check()
@@ -231,13 +236,15 @@ def test_workgroup_gemm_form_under_the_prefix_cone_is_bit_identical(F_, first):
     c_ref, l_ref = run(1 << 30)
     c_nat, l_nat = run(1, item_sort=0)        # items in natural order / one sort over all frames (16 frames: default = one per XCD share)
     c_one, l_one = run(1 << 30, item_sort=1)
-    eng.set_tuning(prefix_cone_force=0, gemm_merge_min=8192, gemm_wg_min=1024, item_sort=2)
-    assert torch.equal(c_wg, c_ref) and torch.equal(c_nat, c_ref) and torch.equal(c_one, c_ref)
+    c_old, l_old = run(1, gemm_ws=1)          # k_gemm_ws (weights through LDS, 64 items per workgroup) instead of k_gemm_wg (rows through LDS)
+    eng.set_tuning(prefix_cone_force=0, gemm_merge_min=8192, gemm_wg_min=1024, item_sort=2, gemm_ws=0)
+    assert torch.equal(c_wg, c_ref) and torch.equal(c_nat, c_ref) and torch.equal(c_one, c_ref) and torch.equal(c_old, c_ref)
     walked = np.zeros((F_, 1024), bool)
     for b in range(F_):
         walked[b, order_loc[b][first:]] = True
     sel = torch.from_numpy(walked).to(DEV)
     assert torch.equal(l_wg[sel], l_ref[sel]) and torch.equal(l_nat[sel], l_ref[sel]) and torch.equal(l_one[sel], l_ref[sel])
+    assert torch.equal(l_old[sel], l_ref[sel])
     assert (c_wg.cpu().numpy()[reg == 1] != codes0[reg == 1]).any()
 
 
