@@ -22,7 +22,7 @@
 namespace {
 
 // cv2.distanceTransform(src, DIST_L2, 5): two-pass chamfer, 16.16 fixed point, metrics
-// (1, 1.4, 2.1969); portable OpenCV definition (DESIGN.md "third-party semantics").
+// (1, 1.4, 2.1969); portable OpenCV definition ("Parity unpinned").
 struct Chamfer5 {
     static constexpr uint32_t INIT = 0x7FFFFFFF >> 2;
     // forward-pass neighbourhood (dy, dx, metric id); the backward pass mirrors it

@@ -796,7 +796,7 @@ __device__ __forceinline__ void chain_role(const ChainArgs &a, int wg)
 // items (k_column_la: the next launch's first stages) wait for the chains' `done` counters, which the chains publish before they
 // can get to waiting for anything that comes after those items in a group's list -- a group publishes its previous item before it
 // waits.  What the design does NOT cover is a second process running column launches on the same GPU (two launches can then hold
-// each other's CUs until the bounded waits give up): one column-launching process per GPU (DESIGN, section 7).
+// each other's CUs until the bounded waits give up): one column-launching process per GPU.
 // ==========================================================================================
 __global__ __launch_bounds__(C1_THREADS) void k_column(NbrArgs na, ChainArgs ca)
 {

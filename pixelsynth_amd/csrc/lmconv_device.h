@@ -228,7 +228,7 @@ constexpr int NBR_LD = 2 * NF;
 // Completion counters of the neighbour role: one per (stage, 16-column tile of the launch), each on its own 128-byte
 // line -- several thousand items finish per launch, and atomics on one line are served one after the other by the
 // memory side (counters packed in two lines made the neighbour role atomics-bound and every chain's polls queue behind
-// them: 128 columns 84 -> see DESIGN).  A chain only watches the counters of its own tile.
+// them: 128 columns 84 -> 72 us, docs/LAB_NOTEBOOK.md).  A chain only watches the counters of its own tile.
 constexpr int COL_CAP = 128;  // columns per launch: 4 chain XCDs x 32 CUs (larger wavefronts are split)
 constexpr int MAX_TILES = COL_CAP / 16, CNT_PAD = 32 /* dwords */;
 constexpr int C1_THREADS = 1024;    // latency-form workgroups

@@ -934,7 +934,7 @@ __global__ __launch_bounds__(WS_THREADS) void k_gemm_ws(GemmArgs a, PostArgs pa)
 // the column steps read the finished activations of earlier neighbours.  A column reads, per stage, the open taps of its
 // location -- so from the prefix only a band along the frontier; those items read their own open taps one stage
 // earlier, and so on backwards through the 32 stages: a dependency cone, not the whole prefix at every stage (63-83 %
-// of the work for PixelSynth's orders, DESIGN.md).  Because the generation order sweeps towards the frontier, the cone
+// of the work for PixelSynth's orders, DESIGN.md section 4.3).  Because the generation order sweeps towards the frontier, the cone
 // of a stage is -- up to a few items -- a SUFFIX of the prefix in rank order, so it is kept as one number per (stage,
 // frame): the smallest rank anyone reads; items of lower rank are skipped at that stage (their cache rows keep whatever
 // they held; nothing reads them).  The taps come from the kernel masks themselves, exactly what the kernels follow.
@@ -1275,12 +1275,13 @@ bool launch_gemm(GemmArgs &a, int item_blocks, hipStream_t st, const Tuning &tun
     // one wave per slot while that is what it takes to fill the chip (4096 wave slots): a 16-view prefix is 2870 (tile,
     // channel block) pairs, one view 180 -- walking all slots in one wave would leave most of the SIMDs idle and make
     // each wave three times as long
-    a.zgrid = a.nx * a.ny < tune.gemm_merge_min ? a.nslots : 1;
-    if (a.zgrid != 1 || a.nslots < 3) a.sum_bias = nullptr;   // (only a wave that walks NA, C and NB can add them up)
-    // the workgroup form (k_gemm_wg: input rows shared through LDS) from tune.gemm_wg_min item tiles on, for the shapes of the
-    // network's 3x3 convs; it produces the summed form (y in place of slot NA), bit-identical to k_gemm's
+    // the workgroup forms (k_gemm_wg: input rows shared through LDS; k_gemm_ws: weights shared through LDS) from tune.gemm_wg_min item
+    // tiles on, for the shapes of the network's 3x3 convs; they produce the summed form (y in place of slot NA), bit-identical to k_gemm's
     const bool shape_ok = (a.Cin == 2 * NF || a.Cin == NF) && (a.Co_pad == NF || (a.Co_pad == 2 * NF && a.Cin == 2 * NF));
-    if (a.sum_bias && a.zgrid == 1 && shape_ok && item_blocks >= tune.gemm_wg_min && a.tiles_per_block == 1) {
+    const bool wg_form = a.sum_bias && a.nslots >= 3 && shape_ok && item_blocks >= tune.gemm_wg_min && a.tiles_per_block == 1;
+    a.zgrid = a.nx * a.ny < tune.gemm_merge_min && !wg_form ? a.nslots : 1;
+    if (a.zgrid != 1 || a.nslots < 3) a.sum_bias = nullptr;   // (only a wave that walks NA, C and NB can add them up)
+    if (wg_form) {
         const int kind = a.Co_pad == 2 * NF ? GW_CONVOUT : a.Cin == 2 * NF ? GW_CONVIN : GW_DIL;
         // item tiles per workgroup (conv_out with 16 items per workgroup: 168 registers, three workgroups per CU -- 0.6 % of the
         // 128-view step over {2, 2, 2})

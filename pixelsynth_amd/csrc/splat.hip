@@ -3,7 +3,7 @@
 // Replaces, behind the C ABI of include/pixelsynth_hip.h:
 //   PtsManipulator.project_pts / project_pts_cumulative   models/projection/z_buffer_manipulator.py:50-83, 221-266
 //   RasterizePointsXYsBlending.forward                    models/layers/z_buffer_layers.py:55-131
-//   + PyTorch3D rasterize_points / compositing it calls   (third party, semantics in DESIGN.md)
+//   + PyTorch3D rasterize_points / compositing it calls   (third party, semantics in DESIGN.md section 2)
 //
 // Pipeline (all on the caller's stream, no host sync, no allocation):
 //   k_project        1 thread / point: p = grid*depth, X = K (RT2 RT1inv) Kinv p, divide, EPS rule

@@ -112,7 +112,7 @@ _SIDE = {}
 def _side_stream():
     """ONE side stream per device and process.  The runtime deals the streams a process creates onto a few hardware queues in turn,
     and one of every eight shares the main stream's queue -- its kernels then run behind the main stream's instead of beside them
-    (+25 % per step).  A stream created once, early, is the same stream on every call."""
+    (docs/LAB_NOTEBOOK.md, "Which stream the side stream is": +25 % per step).  A stream created once, early, is the same stream on every call."""
     dev = torch.cuda.current_device()
     if dev not in _SIDE:
         _SIDE[dev] = torch.cuda.Stream()
