@@ -463,6 +463,7 @@ int ps_pixelcnn_create(const float *const *params, int n_params, int H, int W, i
     if ((rc = dev_alloc(h, &h->ctx, locs))) return fail_out(rc);
     if ((rc = dev_alloc(h, &h->pstart, (size_t)N_EVAL * max_frames))) return fail_out(rc);
     if ((rc = dev_alloc(h, &h->perm, 2 * locs))) return fail_out(rc);
+    if ((rc = dev_alloc(h, &h->permq, 2 * locs))) return fail_out(rc);
     if ((rc = dev_alloc(h, &h->perm_sorted, 2 * locs))) return fail_out(rc);
     if ((rc = dev_alloc(h, &h->perm_cnt, (size_t)2 * 512 * max_frames))) return fail_out(rc);
     if ((rc = dev_alloc(h, &h->perm_tsum, (size_t)2 * max_frames))) return fail_out(rc);

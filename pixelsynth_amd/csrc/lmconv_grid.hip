@@ -31,6 +31,7 @@ struct ItemMap {
     int f0;                // first frame of the pass (a pass over frames [f0, f0 + n): item 0 is rank 0 of frame f0)
     const int32_t *perm;   // or null: position p of the products' item list holds item perm[p] -- the items grouped by their set of
                            // open taps (k_perm_*), so that a tile of 16 / 32 items shares its taps; the post ops walk the items as they are
+    const int2 *permq;     // the same list as (item, location) pairs: one load instead of the chain position -> item -> order -> location
 };
 // item at position `pos` of the products' item list, -1 past its end
 __device__ __forceinline__ int item_at(const ItemMap &m, int pos, int nitems)
@@ -409,24 +410,37 @@ __global__ __launch_bounds__(GW_THREADS) void k_gemm_wg(GemmArgs a, PostArgs pa,
 #else
     auto span_end = [&]() { };
 #endif
-    // ---- set-up: rows and mask values of every (tap, item) of the tile; wave w does taps w, w + 4, w + 8
+    // ---- set-up: rows and mask values of every (tap, item) of the tile; wave w does taps w, w + 4, w + 8.
+    // Where the products' items were sorted, k_perm_scatter left (item, location | tap set << 12 | fractional-masks flag << 21)
+    // pairs: ONE load per lane instead of the chain position -> item -> order -> location -> nine mask values, which was 8-12 k
+    // cycles at the head of an 80 k-cycle workgroup (tools/wg_trace.py, round 5); with 0 / 1 masks -- the reference's always are --
+    // the tap set says what the mask values are.
     {
-        const int m = lane & (MI - 1);
-        const int item = item_at(a.items, item0 + m, a.nitems);
-        const bool valid = item >= 0 && item_wanted(a.items, item);
-        int f = 0, q = 0, r = 0, c = 0;
-        if (valid) {
-            item_loc(a.items, item, a.L, f, q);
-            r = q / a.W;
-            c = q - r * a.W;
+        const int m = lane & (MI - 1), pos = item0 + m;
+        int item = -1, q = 0, pat = 0x1ff;
+        bool frac = true;
+        if (pos < a.nitems) {
+            if (a.items.permq) {
+                const int2 v = a.items.permq[pos];
+                item = v.x; q = v.y & 4095; pat = (v.y >> 12) & 0x1ff; frac = (v.y >> 21) & 1;
+            } else {
+                int fq;
+                item = item_at(a.items, pos, a.nitems);
+                item_loc(a.items, item, a.L, fq, q);
+            }
         }
+        const bool valid = item >= 0 && item_wanted(a.items, item);
+        const int f = a.items.f0 + (item >= 0 ? item / a.items.npre : 0), r = q / a.W, c = q - r * a.W;
         if (wave == 0 && lane < MI) { sItem[m] = valid ? item : -1; sLoc[m] = valid ? f * a.L + q : 0; }
         for (int t = wave; t < ntaps; t += GW_WAVES) {
             const GemmTap tp = a.tap[t];
             const int rr = r + tp.dr, cc = c + tp.dc;
             float mv = 0.0f;
-            if (valid && rr >= 0 && rr < a.H && cc >= 0 && cc < a.W)
-                mv = tp.mask_row >= 0 ? a.mask[(size_t)f * a.mask_fstride + (size_t)tp.mask_row * a.L + q] : 1.0f;
+            if (valid) {
+                if (tp.mask_row < 0) mv = 1.0f;                                   // (nin_skip: the location itself, unmasked)
+                else if (!frac) mv = (pat >> tp.mask_row) & 1 ? 1.0f : 0.0f;      // 0 / 1 masks: the tap set says it all
+                else if (rr >= 0 && rr < a.H && cc >= 0 && cc < a.W) mv = a.mask[(size_t)f * a.mask_fstride + (size_t)tp.mask_row * a.L + q];
+            }
             if (lane < MI) {
                 sRow[t * MI + m] = mv != 0.0f ? (f * a.L + rr * a.W + cc) : -1;
                 sMv[t * MI + m] = mv;
@@ -1039,7 +1053,8 @@ __global__ __launch_bounds__(1024) void k_prefix_starts(StartsArgs a)
 // Order inside a tap set: frame, then rank (neighbouring ranks are neighbouring locations: their input rows are the same lines).
 // `nparts` > 1: one sort per share of the frames, so that the contiguous range of tiles an XCD takes (k_gemm / k_gemm_wg) reads
 // the rows of ITS frames only.  Three small launches per pass and mask kind (dilation 1, dilation 2):
-//   k_perm_sort     per frame: (tap set << 12 | rank) of its items, sorted (bitonic, LDS), and the run length of every tap set
+//   k_perm_sort     per frame: (tap set's place << 13 | rank << 1 | fractional masks) of its items, sorted (bitonic, LDS), and the run
+//                   length of every tap set
 //   k_perm_scan     first position of every (share, tap set, frame) run: exclusive scan over [share][tap set][frame], in tiles of
 //                   1024 entries (the tiles' totals are scanned by every block of the next launch for itself)
 //   k_perm_scatter  per frame: perm[first + index in the run] = item
@@ -1052,6 +1067,7 @@ struct PermArgs {
     int32_t *cnt[2];                    // [nparts][512][frames per share]
     int32_t *tsum[2];                   // totals of the table's tiles of 1024 entries
     int32_t *perm[2];                   // [nf * npre]
+    int2 *permq[2];                     // the same as (item, location) pairs
 };
 constexpr int PERM_KEYS = 512;
 // Sort key of a tap set: its place in the order (number of open taps, descending; then the 9-bit set).  The workgroups of a launch
@@ -1069,6 +1085,13 @@ constexpr PermBins make_perm_bins()
     return t;
 }
 __device__ const PermBins g_perm_bin = make_perm_bins();
+constexpr PermBins make_perm_pats()   // the inverse: place -> tap set
+{
+    PermBins t{}, b = make_perm_bins();
+    for (int p = 0; p < PERM_KEYS; ++p) t.v[b.v[p]] = (unsigned short)p;
+    return t;
+}
+__device__ const PermBins g_perm_pat = make_perm_pats();
 __device__ __forceinline__ int perm_fpp(const PermArgs &a) { return (a.nf + a.nparts - 1) / a.nparts; }   // frames per share
 __device__ __forceinline__ size_t perm_cnt_index(const PermArgs &a, int fl, int key)
 {
@@ -1087,16 +1110,20 @@ __global__ __launch_bounds__(1024) void k_perm_sort(PermArgs a)
         uint32_t v = 0xFFFFFFFFu;
         if (r < a.npre) {
             const int q = a.order ? a.order[(size_t)f * a.L + r] : r, y = q / a.W, x = q - y * a.W;
-            uint32_t key = 0;
+            uint32_t key = 0, frac = 0;   // frac: a mask value that is neither 0 nor 1 (the reference's never are): the products load them
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const int yy = y + (tap / 3 - 1) * dil, xx = x + (tap % 3 - 1) * dil;
-                if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W && mask[((size_t)f * 9 + tap) * a.L + q] != 0.0f) key |= 1u << tap;
+                if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) {
+                    const float mvv = mask[((size_t)f * 9 + tap) * a.L + q];
+                    if (mvv != 0.0f) key |= 1u << tap;
+                    if (mvv != 0.0f && mvv != 1.0f) frac = 1;
+                }
             }
 #ifdef PS_PERM_PLAIN_BINS   // (tuning builds: the tap sets in the order of their 9-bit value)
-            v = key << 12 | (uint32_t)r;
+            v = key << 13 | (uint32_t)r << 1 | frac;
 #else
-            v = (uint32_t)g_perm_bin.v[key] << 12 | (uint32_t)r;
+            v = (uint32_t)g_perm_bin.v[key] << 13 | (uint32_t)r << 1 | frac;
 #endif
         }
         s[r] = v;
@@ -1116,7 +1143,7 @@ __global__ __launch_bounds__(1024) void k_perm_sort(PermArgs a)
         }
     for (int i = t; i < a.npre; i += 1024) {
         a.sorted[kind][(size_t)fl * a.npre + i] = s[i];
-        atomicAdd(&hist[s[i] >> 12], 1);
+        atomicAdd(&hist[s[i] >> 13], 1);
     }
     __syncthreads();
     for (int k = t; k < PERM_KEYS; k += 1024) a.cnt[kind][perm_cnt_index(a, fl, k)] = hist[k];
@@ -1159,14 +1186,22 @@ __global__ __launch_bounds__(1024) void k_perm_scatter(PermArgs a)
     tbase[t] = block_exscan_1024(t < ntiles ? a.tsum[kind][t] : 0, sh, &total);
     const uint32_t *s = a.sorted[kind] + (size_t)fl * a.npre;
     for (int i = t; i < a.npre; i += 1024) {
-        const uint32_t key = s[i] >> 12;
-        if (i == 0 || (s[i - 1] >> 12) != key) first[key] = i;
+        const uint32_t key = s[i] >> 13;
+        if (i == 0 || (s[i - 1] >> 13) != key) first[key] = i;
     }
     __syncthreads();
     for (int i = t; i < a.npre; i += 1024) {
-        const uint32_t v = s[i], key = v >> 12;
+        const uint32_t v = s[i], key = v >> 13;
         const size_t e = perm_cnt_index(a, fl, (int)key);
-        a.perm[kind][a.cnt[kind][e] + tbase[e >> 10] + i - first[key]] = fl * a.npre + (int)(v & 4095u);
+        const int r = (int)((v >> 1) & 4095u), pos = a.cnt[kind][e] + tbase[e >> 10] + i - first[key];
+        const int q = a.order ? a.order[(size_t)(a.f0 + fl) * a.L + r] : r;
+#ifdef PS_PERM_PLAIN_BINS
+        const int pat = (int)key;
+#else
+        const int pat = g_perm_pat.v[key];
+#endif
+        a.perm[kind][pos] = fl * a.npre + r;
+        a.permq[kind][pos] = int2{fl * a.npre + r, q | pat << 12 | (int)(v & 1u) << 21};   // (item, location | tap set | fractional masks)
     }
 }
 
@@ -1348,6 +1383,7 @@ void run_grid(ps_pixelcnn *h, int F, const int32_t *codes, const Masks &m, float
     }
     // the products' item lists, grouped by open-tap set (one per mask kind); the frame range's own part of the scratch
     const int32_t *perm[2] = {nullptr, nullptr};
+    const int2 *permq[2] = {nullptr, nullptr};
     if (h->tune.item_sort && h->L <= STARTS_MAXL && all_items.npre >= 2 && nf <= 2048) {
         PermArgs pa{};
         pa.order = order; pa.mask[0] = m.und; pa.mask[1] = m.dil;
@@ -1357,6 +1393,8 @@ void run_grid(ps_pixelcnn *h, int F, const int32_t *codes, const Masks &m, float
         for (int k = 0; k < 2; ++k) {
             pa.sorted[k] = h->perm_sorted + k * locs + (size_t)f0 * h->L;
             pa.perm[k] = h->perm + k * locs + (size_t)f0 * h->L;
+            pa.permq[k] = h->permq + k * locs + (size_t)f0 * h->L;
+            permq[k] = pa.permq[k];
             pa.cnt[k] = h->perm_cnt + ((size_t)k * h->maxF + f0) * PERM_KEYS;
             pa.tsum[k] = h->perm_tsum + (size_t)k * h->maxF + f0;
             perm[k] = pa.perm[k];
@@ -1372,6 +1410,7 @@ void run_grid(ps_pixelcnn *h, int F, const int32_t *codes, const Masks &m, float
     auto gemm = [&](GemmArgs &a, const float *mask, const float *sum_bias = nullptr, const PostArgs *post = nullptr) {
         a.items = items;
         a.items.perm = mask == m.und ? perm[0] : mask == m.dil ? perm[1] : nullptr;
+        a.items.permq = mask == m.und ? permq[0] : mask == m.dil ? permq[1] : nullptr;
         a.H = h->H; a.W = h->W; a.L = h->L; a.nitems = nitems;
         a.mask = mask; a.mask_fstride = (size_t)9 * h->L; a.tiles_per_block = 1;
         a.partial = h->partial + (size_t)4 * f0 * h->L * (2 * NF);   // (the frame range's own part of the scratch: passes over disjoint ranges may run side by side)

@@ -124,6 +124,7 @@ struct ps_pixelcnn {
     int32_t *pstart = nullptr;      // (N_EVAL, F) first rank of the prefix anyone reads, per stage and frame (k_prefix_starts)
     // items of a whole-grid pass grouped by open-tap set (k_perm_*, lmconv_grid.hip): [2 mask kinds][maxF * L] each
     int32_t *perm = nullptr;        // position -> natural item index (frame-local: fl * npre + rank)
+    int2 *permq = nullptr;          // the same as (item, location) pairs
     uint32_t *perm_sorted = nullptr;   // scratch: (key << 12 | rank) of every frame, sorted
     int32_t *perm_cnt = nullptr;    // scratch: [2][512 * maxF] run lengths -> first positions
     int32_t *perm_tsum = nullptr;   // scratch: [2][maxF] totals of that table's tiles of 1024 entries
