@@ -310,18 +310,56 @@ class ZbufferModelPts(nn.Module):
         eng = self.outpaint2.engine(self.obs[1], self.obs[2], V)
         if forced is None and uniforms is None:
             uniforms = torch.rand(V, L, device=gen_fs.device, dtype=torch.float32)
-        if between is None or plan.waves[0].shape[0] == 0:
+        nsplit = self._prefix_split(V)
+        if (between is None and nsplit == 1) or plan.waves[0].shape[0] == 0:
             eng.ar_run(c32, plan.order_loc, plan.region, plan.mask_init, plan.mask_undilated, plan.mask_dilated,
                        temperature=temperature, uniforms=uniforms, forced=forced, first_step=plan.first_step, waves=plan.waves)
             if between is not None:
                 between()
         else:
-            eng.ar_prefix(c32, plan.order_loc, plan.region, plan.mask_init, plan.mask_undilated, plan.mask_dilated, plan.first_step)
-            between()
+            args = (c32, plan.order_loc, plan.region, plan.mask_init, plan.mask_undilated, plan.mask_dilated, plan.first_step)
+            if nsplit == 1:
+                eng.ar_prefix(*args)
+            else:
+                # The whole-grid prefix pass of disjoint frame ranges on streams of their own (ps_pixelcnn_ar_prefix is built for it: every
+                # range has its part of the scratch): a launch empties over its last tenth, and the next stage's launch cannot start
+                # before it has -- with a second range's launches in flight, their workgroups take the places as they fall free.
+                main = torch.cuda.current_stream()
+                ready = torch.cuda.Event()
+                ready.record(main)
+                per = V // nsplit
+                for k, st in enumerate(self._prefix_streams(nsplit - 1, c32.device)):
+                    st.wait_event(ready)
+                    with torch.cuda.stream(st):
+                        eng.ar_prefix(*args, frame_begin=(k + 1) * per, frame_end=(k + 2) * per if k + 2 < nsplit else V)
+                    for t in (c32,) + args[1:6]:
+                        t.record_stream(st)
+                eng.ar_prefix(*args, frame_begin=0, frame_end=per)
+                for st in self._prefix_streams(nsplit - 1, c32.device):
+                    main.wait_stream(st)
+            if between is not None:
+                between()
             eng.ar_columns(c32, plan.order_loc, plan.region, plan.mask_init, plan.mask_undilated, plan.mask_dilated, plan.waves,
                            temperature=temperature, uniforms=uniforms, forced=forced, first_step=plan.first_step)
         planned["codes"] = c32.view(V, self.obs[1], self.obs[2])
         return planned
+
+    PREFIX_SPLIT_MIN_VIEWS = 64   # below this a launch of half the frames no longer fills the chip
+
+    def _prefix_split(self, V):
+        """Frame ranges the prefix pass of a V-view batch is dealt to (each on a stream of its own): PS_PREFIX_STREAMS, default 1."""
+        import os
+        n = int(os.environ.get("PS_PREFIX_STREAMS", "1"))
+        return n if n > 1 and V >= self.PREFIX_SPLIT_MIN_VIEWS and V % (8 * n) == 0 else 1
+
+    def _prefix_streams(self, n, device):
+        """n side streams for the prefix pass, created once per model and device (which hardware queue a stream lands on is dealt at
+        creation: docs/LAB_NOTEBOOK.md, "Which stream the side stream is")."""
+        key = (str(device), n)
+        cache = self.__dict__.setdefault("_pfx_streams", {})
+        if key not in cache:
+            cache[key] = [torch.cuda.Stream(device=device) for _ in range(n)]
+        return cache[key]
 
     def outpaint_views(self, fs, depth, K, K_inv, input_RT, input_RTinv, output_RT, output_RTinv, codes,
                        temperature=0.7, uniforms=None, forced=None, check=True):

@@ -202,6 +202,36 @@ def test_whole_grid_launch_forms_agree_bit_for_bit():
     np.testing.assert_allclose(merged[0].numpy(), ref[0].numpy(), rtol=1e-4, atol=1e-4)
 
 
+def test_workgroup_form_with_fractional_masks_loads_them():
+    """The sorted item list carries every item's SET of open taps, and the workgroup form takes a 0 / 1 mask's values from it
+    instead of loading them.  Masks with values that are neither 0 nor 1 (the generic layer supports them; the reference never
+    produces them) are flagged per item and loaded: k_gemm_wg / k_gemm_ws against k_gemm, which always loads, bit for bit."""
+    net = make_net(4)
+    dmaps = dict(syn.distance_maps())
+    eng = net.engine(32, 32, 2)
+    codes = syn.codes(19, 2).reshape(2, 1024).astype(np.int32)
+    orders = [c_oracle.custom_idx(32, 32, dmaps[n])[0] for n in ("rand2", "corner")]
+    ms = [np.concatenate([c_oracle.unfolded_masks(o, 32, 32, 3, dil, typ) for o in orders]) for dil, typ in
+          ((1, "A"), (1, "B"), (2, "B"))]
+    rs = np.random.RandomState(3)
+    for m_ in ms[1:]:                                   # a third of the open taps of frame 1 get a fractional value; frame 0 stays 0 / 1
+        scale = np.where(rs.rand(*m_[1].shape) < 0.33, 0.25 + 0.5 * rs.rand(*m_[1].shape), 1.0).astype(np.float32)
+        m_[1] = m_[1] * scale
+    run = lambda: eng.forward(tt(codes), *[tt(m) for m in ms]).cpu()
+    big = 1 << 30
+    eng.set_tuning(gemm_merge_min=0, gemm_wg_min=big)
+    ref = run()
+    eng.set_tuning(gemm_wg_min=1, gemm_ws=0)
+    assert torch.equal(run(), ref)
+    eng.set_tuning(gemm_ws=1)
+    assert torch.equal(run(), ref)
+    eng.set_tuning(gemm_ws=0, item_sort=0)
+    assert torch.equal(run(), ref)
+    eng.set_tuning(gemm_merge_min=8192, gemm_wg_min=1024, item_sort=2)
+    frac = ms[1][1][ms[1][1] > 0]
+    assert ((frac != 1.0).mean() > 0.2) and torch.isfinite(ref).all()
+
+
 @pytest.mark.parametrize("F_,first", [(7, 600), (3, 905), (33, 333), (16, 500)])
 def test_workgroup_gemm_form_under_the_prefix_cone_is_bit_identical(F_, first):
     """k_gemm_wg (the whole-grid products with the receptive-field rows staged in LDS once per workgroup) against k_gemm on
