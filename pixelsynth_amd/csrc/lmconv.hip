@@ -152,6 +152,7 @@ const TuningEntry tuning_table[] = {
     {"prefix_full", &Tuning::prefix_full, 0, 1}, {"prefix_cone_force", &Tuning::prefix_cone_force, 0, 1},
     {"tp_ahead", &Tuning::tp_ahead, 0, NST - 2}, {"col_ahead", &Tuning::col_ahead, 0, NST - 4},
     {"tp_min_cols", &Tuning::tp_min_cols, 1, 1 << 30}, {"tp_xcds", &Tuning::tp_xcds, -1, 7}, {"tp_fill", &Tuning::tp_fill, 0, 1},
+    {"tp_affine", &Tuning::tp_affine, 0, 1},
     {"col_cap", &Tuning::col_cap, 1, COL_CAP}, {"chain_xcds", &Tuning::chain_xcds, 0, 8}, {"nbr_groups", &Tuning::nbr_groups, 0, NBR_MAX_GROUPS},
 #ifdef PS_TUNING_BUILD   // timing experiments whose results are INVALID (1: chains do not wait for the neighbour slots, 2: no chains, 3: no
     {"column_debug", &Tuning::column_debug, 0, 1 << 20},   // neighbour role and no waiting; + 256 x the traced wave): tuning builds only
@@ -189,6 +190,36 @@ void apply_look_ahead(ps_pixelcnn *h)
     while (h->col_wsplit < h->nwork && h->work_stage[h->col_wsplit] < h->tune.col_ahead) ++h->col_wsplit;
     h->tp_wsplit = 0;
     while (h->tp_wsplit < h->nwork_tp && h->work_tp_stage[h->tp_wsplit] < h->tune.tp_ahead) ++h->tp_wsplit;
+    // Stage-affine neighbour XCDs: the stages dealt to nx XCDs, heaviest first to the least loaded, separately below and above the
+    // look-ahead depth (a launch computes the stages >= tp_ahead for itself and the stages below it for the next launch: both parts
+    // should be even); an XCD's entries stay in table order, so it still walks its stages in the order the chain tiles need them.
+    if (h->tp_xent && h->nwork_tp <= TP_XENT_MAX) {
+        std::vector<int> tab((size_t)9 * 8 * TP_XENT_MAX, 0);
+        std::vector<double> cost(NST, 0.0);
+        for (int e = 0; e < h->nwork_tp; ++e) cost[h->work_tp_stage[e]] += h->work_tp_cost[e];
+        for (int nx = 1; nx <= 8; ++nx) {
+            std::vector<int> owner(NST, 0);
+            for (int part = 0; part < 2; ++part) {
+                std::vector<int> st;
+                for (int k = 0; k < NST; ++k)
+                    if (cost[k] > 0.0 && (k < h->tune.tp_ahead) == (part == 0)) st.push_back(k);
+                std::stable_sort(st.begin(), st.end(), [&](int x, int y) { return cost[x] > cost[y]; });
+                std::vector<double> load(nx, 0.0);
+                for (int k : st) {
+                    const int x = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+                    owner[k] = x;
+                    load[x] += cost[k];
+                }
+            }
+            for (int x = 0; x < 8; ++x) { h->tp_xlen[nx][x] = 0; h->tp_xlo[nx][x] = 0; }
+            for (int e = 0; e < h->nwork_tp; ++e) {
+                const int x = owner[h->work_tp_stage[e]];
+                tab[((size_t)nx * 8 + x) * TP_XENT_MAX + h->tp_xlen[nx][x]++] = e;
+                if (e < h->tp_wsplit) h->tp_xlo[nx][x] += 1;
+            }
+        }
+        (void)hipMemcpy(h->tp_xent, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -314,7 +345,8 @@ int build_stage_table(ps_pixelcnn *h)
     if (int rc = dev_alloc(h, &h->work_tp, work_tp.size())) return rc;
     PS_HIP_CHECK(hipMemcpy(h->work_tp, work_tp.data(), work_tp.size() * sizeof(NbrWorkTp), hipMemcpyHostToDevice));
     h->nwork_tp = (int)work_tp.size();
-    for (const NbrWorkTp &w : work_tp) h->work_tp_stage.push_back(w.stage);
+    for (const NbrWorkTp &w : work_tp) { h->work_tp_stage.push_back(w.stage); h->work_tp_cost.push_back((double)w.T * w.NG); }
+    if (int rc = dev_alloc(h, &h->tp_xent, (size_t)9 * 8 * TP_XENT_MAX)) return rc;
     apply_look_ahead(h);
     return PS_OK;
 }

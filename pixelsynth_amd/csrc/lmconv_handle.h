@@ -44,6 +44,8 @@ static_assert(sizeof(NbrWorkTp) == 48, "three 16-byte loads");
 // Stage types of the throughput chain role (what fixes a stage's unit list): conv_input, conv_input + nin_skip, conv_out, dilated conv
 enum { TPT_CONVIN = 0, TPT_CONVIN_SKIP = 1, TPT_CONVOUT = 2, TPT_DIL = 3 };
 
+constexpr int TP_XENT_MAX = 256;   // work-table entries of the throughput form (this network: 248)
+
 struct ChainArgs {
     const int *ctl1;          // the chain role's per-stage control records (C1_CTL_DWORDS dwords each), read with scalar loads
     const float *nbr;         // neighbour slots of this launch, from the neighbour role
@@ -96,6 +98,9 @@ struct Tuning {
     int tp_min_cols = 2 * COL_CAP + 1;   // a wavefront of up to 256 columns is two latency-form launches rather than one throughput-form launch
     int tp_xcds = -1;            // 0 = chain tiles anywhere, -1 = on as few XCDs as hold them, n = on at least n XCDs
     int tp_fill = 0;             // neighbour workgroups on the spare CUs of the chain XCDs
+    int tp_affine = 1;           // throughput form: every neighbour XCD owns a fixed share of the STAGES (its ~3 MB of their weights stay in its L2
+                                 // from launch to launch) instead of all XCDs walking all stages together: 378 -> 162 MB per launch at the L2's memory
+                                 // side, the launch as long as before (122 us at 128 views; 151 -> 155 us at 256, where the neighbour role is the bound)
     int col_cap = COL_CAP;       // columns per latency-form launch
     int chain_xcds = 0;          // latency form: XCDs that hold chain workgroups (0 = automatic)
     int nbr_groups = 0;          // latency form: work items a neighbour workgroup runs at a time (0 = automatic)
@@ -138,6 +143,7 @@ struct ps_pixelcnn {
     pslm::NbrWorkTp *work_tp = nullptr;
     int nwork_tp = 0;
     std::vector<int> work_tp_stage;
+    std::vector<double> work_tp_cost;   // relative MFMA work of every entry (output tiles x channel groups)
     float *nbr_tp = nullptr;        // neighbour slots [2][NST][2][TP_COL_CAP][160]
     unsigned *cnt_tp = nullptr;     // [2][NST][TP_MAX_TILES] padded completion counters, never reset
     // look-ahead of the neighbour role (nbr_role_tp): slots, counters and their targets are double-buffered by launch parity
@@ -145,6 +151,10 @@ struct ps_pixelcnn {
     unsigned *done_tp = nullptr;    // [NST] padded: chain tiles that have published the input of stage k, never reset
     unsigned done_total = 0;        // what they stand at when every publishing launch so far is through
     int tp_wsplit = 0;              // first entry of work_tp whose stage is >= tune.tp_ahead
+    // stage-affine neighbour XCDs (tune.tp_affine): for every count nx of neighbour XCDs, the work-table entries of XCD xi in table
+    // order -- device [9][8][TP_XENT_MAX]; how many there are and how many of them lie below tp_wsplit (host)
+    int *tp_xent = nullptr;
+    int tp_xlen[9][8] = {}, tp_xlo[9][8] = {};
     const pslm::StepCtx *ahead_rec = nullptr;   // the launch the last one prepared: its first record, its columns, the parity it wrote to
     int ahead_n = 0, ahead_parity = 0;
     int tp_launch_no = 0;           // throughput-form launches of the current run so far (tuning builds: which launch is traced)

@@ -45,6 +45,11 @@ struct TpArgs {
     unsigned *cnt;            // [NST][TP_MAX_TILES] padded completion counters (tp_cnt_index), never reset
     int nwork, tiles, nbr_wgs;
     int chain_xcds, fill_nbr;   // placement (k_column_tp): XCDs that hold the chain tiles; first neighbour index of their spare CUs or -1
+    // stage-affine neighbour XCDs (0: all XCDs walk all stages): nx neighbour XCDs; XCD xi owns entries xent[xi * TP_XENT_MAX + k], k < xlen[xi],
+    // of which the first xlo[xi] lie below the look-ahead depth
+    int affine_nx;
+    const int *xent;
+    int xlen[8], xlo[8];
     // chain role (fields as in ChainArgs)
     const int *ctl1;
     const float *uinit_w, *uinit_b;
@@ -160,9 +165,16 @@ __device__ __forceinline__ void nbr_item_tp(const NbrWorkTp &wk, const TpArgs &a
 __device__ __forceinline__ void nbr_role_tp(const TpArgs &a, int nb)
 {
     const int wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int gw = nb * TP_WAVES + wave, nw = a.nbr_wgs * TP_WAVES;   // (the waves of a workgroup take consecutive items: they share the weights in L1 / L2)
-    const int n_own = (a.nwork - a.w_from) * a.tiles;
-    const int nitems = n_own + a.w_upto * a.tiles_next;
+    // all XCDs together: wave gw of nw takes items gw, gw + nw, ... of (entries [w_from, nwork) x tiles, then [0, w_upto) x tiles_next);
+    // stage-affine: the waves of neighbour XCD xi do the same over the entries that XCD owns (the waves of a workgroup take consecutive
+    // items either way: they share the weights in L1 / L2)
+    const int nx = a.affine_nx, xi = nx ? nb % nx : 0;
+    const int gw = (nx ? nb / nx : nb) * TP_WAVES + wave, nw = (nx ? a.nbr_wgs / nx : a.nbr_wgs) * TP_WAVES;
+    const int e_own0 = nx ? (a.w_from ? a.xlo[xi] : 0) : a.w_from, e_own1 = nx ? a.xlen[xi] : a.nwork;
+    const int e_ahead1 = nx ? (a.w_upto ? a.xlo[xi] : 0) : a.w_upto;
+    const int *xe = nx ? a.xent + (size_t)xi * TP_XENT_MAX : nullptr;
+    const int n_own = (e_own1 - e_own0) * a.tiles;
+    const int nitems = n_own + e_ahead1 * a.tiles_next;
     __shared__ unsigned sReadyTp;   // look-ahead stages some wave of this workgroup has seen published, + 1
     if (threadIdx.x == 0) sReadyTp = 0;
     __syncthreads();
@@ -172,11 +184,12 @@ __device__ __forceinline__ void nbr_role_tp(const TpArgs &a, int nb)
         int witem, ctile;
         if (!ahead) {
             const int q = item / a.tiles;
-            witem = a.w_from + q; ctile = item - q * a.tiles;
+            witem = e_own0 + q; ctile = item - q * a.tiles;
         } else {
             const int j = item - n_own;
             witem = j / a.tiles_next; ctile = j - witem * a.tiles_next;
         }
+        if (nx) witem = xe[witem];
         NbrWorkTp wk;
         {   // wave-uniform record: scalar loads
             typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -771,9 +784,16 @@ void run_columns_tp(ps_pixelcnn *h, const StepCtx *rec, int ncols, const ChainAr
                 ta.nbr_wgs = (8 - ta.chain_xcds) * use_rows;
                 ta.fill_nbr = -1;
                 if (h->tune.tp_fill && spare > 0 && use_rows == rows) { ta.fill_nbr = ta.nbr_wgs; ta.nbr_wgs += spare; }
+                ta.affine_nx = 0;
+                if (h->tune.tp_affine && ta.fill_nbr < 0 && h->tp_xent) {   // (neighbour block nb sits on neighbour XCD nb % nx)
+                    const int nx = 8 - ta.chain_xcds;
+                    ta.affine_nx = nx;
+                    ta.xent = h->tp_xent + (size_t)nx * 8 * TP_XENT_MAX;
+                    for (int x = 0; x < 8; ++x) { ta.xlen[x] = h->tp_xlen[nx][x]; ta.xlo[x] = h->tp_xlo[nx][x]; }
+                }
                 grid = use_rows * 8;
             } else {
-                ta.chain_xcds = 0; ta.fill_nbr = -1;
+                ta.chain_xcds = 0; ta.fill_nbr = -1; ta.affine_nx = 0;
                 ta.nbr_wgs = std::max(1, std::min(h->n_cus - tiles, (h->nwork_tp * tiles + TP_WAVES - 1) / TP_WAVES));
                 grid = ta.nbr_wgs + tiles;
             }

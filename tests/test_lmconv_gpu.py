@@ -603,6 +603,14 @@ def test_throughput_form_look_ahead_depths_are_bit_identical_to_the_walk(ahead):
             eng.check()
             assert torch.equal(c_walk, c_wave), (F_, first, cap, rep)
             assert torch.equal(l_walk, l_wave), (F_, first, cap, rep)
+        # stage-affine neighbour XCDs (every neighbour XCD owns a fixed share of the stages; the default) against all XCDs walking all
+        # stages: scheduling only -- the same items, the same counters -- so it can be switched on a live handle, and nothing may change
+        eng.set_tuning(tp_affine=1 - eng.get_tuning("tp_affine"))   # (the other setting than the default's)
+        c_aff = tt(codes0.copy())
+        l_aff = eng.ar_run(c_aff, tt(order_loc), tt(reg), *ms, temperature=0.7, uniforms=u, first_step=first, want_logits=True, waves=waves)
+        eng.check()
+        eng.set_tuning(tp_affine=1 - eng.get_tuning("tp_affine"))
+        assert torch.equal(c_walk, c_aff) and torch.equal(l_walk, l_aff), (F_, first, cap, "affine")
 
 
 @pytest.mark.parametrize("ahead", ["0", "5", "28"])
