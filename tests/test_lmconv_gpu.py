@@ -489,10 +489,11 @@ def test_ar_many_frames_layouts(F_):
     assert np.array_equal(c1.cpu().numpy()[0], codes[3])
 
 
-@pytest.mark.parametrize("H,W", [(16, 16), (8, 12)])
+@pytest.mark.parametrize("H,W", [(16, 16), (8, 12), (64, 64)])
 def test_other_grid_sizes(H, W):
     """The engine is not tied to PixelSynth's 32x32 code grid: whole-grid logits against the torch-fp32 oracle and
-    incremental == whole-grid (bit for bit) on a square and a non-square grid, random generation order."""
+    incremental == whole-grid (bit for bit) on a square and a non-square grid, random generation order.  64 x 64 = 4096
+    locations is the largest grid the item sort and the prefix cone take (ranks and locations in 12 bits)."""
     net = make_net(5)
     F_, L = 2, H * W
     eng = net.engine(H, W, F_)
