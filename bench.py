@@ -219,6 +219,9 @@ def measure_roofline(model, d, out, V):
             "flops_per_column": round(fpc.value), "columns_per_launch": round(cols_per_launch, 2),
             "launches_per_ar_run": launches.value, "wavefronts": len(wave_start) - 1, "columns": ncols,
             "kernel_table": kernel_table,
+            "kernel_table_note": "every kernel alone on the chip (PMC and trace passes with PS_PREFIX_STREAMS=1); the default step deals "
+                                 "the prefix pass to two frame ranges on two streams: twice the k_gemm_wg launches at half the items, "
+                                 "overlapping (z_buffermodel.PREFIX_STREAMS)",
             "walk_positions_without_wavefronts": 1024 - plan.first_step,
             "reference_definition": {
                 "what": "the same launch priced at what the reference schedules for its columns (SURVEY 8d): one whole-grid "

@@ -562,3 +562,41 @@ def test_sharded_sample_ranking_two_ranks_equals_one(tmp_path):
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-3000:]
 
 
+
+
+def test_prefix_pass_dealt_to_two_streams_gives_the_codes_of_one_stream(monkeypatch):
+    """outpaint_planned deals the whole-grid prefix pass of a batch of >= 64 views to PREFIX_STREAMS frame ranges, each on a stream
+    of its own (ps_pixelcnn_ar_prefix with a frame range; every range has its part of the engine's scratch and of the item sort's
+    buffers).  64 views, three times over to give a race between the ranges its chance: the codes are those of one range on one
+    stream, and a batch that does not divide (72 = 2 x 36 frames, not 8 per XCD) falls back to one range."""
+    m = make_model()
+    assert m.PREFIX_STREAMS == 2 and m._prefix_split(64) == 2 and m._prefix_split(72) == 1 and m._prefix_split(32) == 1
+    V = 64
+    cam = syn.demo_cameras(V)
+    img, depth = tt(syn.image(71, V, 3, 256)), tt(syn.depth_smooth(72, V, 256, 1.0, 100.0))
+    yaws = np.linspace(-0.7, 0.7, V)
+    rts = [syn.yaw_pose(cam["P"][v:v + 1], float(y)) for v, y in enumerate(yaws)]
+    RT2, RT2inv = tt(np.concatenate([r[1] for r in rts])), tt(np.concatenate([r[0] for r in rts]))
+    codes, uni = tt(syn.codes(73, V)), tt(np.random.RandomState(74).rand(V, 1024).astype(np.float32))
+    args = (img, depth, tt(cam["K"]), tt(cam["Kinv"]), tt(cam["P"]), tt(cam["Pinv"]), RT2, RT2inv)
+    eng = m.outpaint2.engine(32, 32, V)
+    ranges = []
+    real_prefix = eng.ar_prefix
+
+    def prefix(*a, **k):
+        ranges.append((k.get("frame_begin"), k.get("frame_end"), torch.cuda.current_stream().cuda_stream))
+        return real_prefix(*a, **k)
+    monkeypatch.setenv("PS_PREFIX_STREAMS", "1")
+    ref = m.outpaint_planned(m.plan_views(*args), codes, temperature=0.7, uniforms=uni)["codes"].clone()
+    monkeypatch.delenv("PS_PREFIX_STREAMS")
+    eng.ar_prefix = prefix
+    try:
+        for _ in range(3):
+            del ranges[:]
+            out = m.outpaint_planned(m.plan_views(*args), codes, temperature=0.7, uniforms=uni)
+            torch.cuda.synchronize()
+            eng.check()
+            assert sorted(r[:2] for r in ranges) == [(0, 32), (32, 64)] and ranges[0][2] != ranges[1][2]
+            assert torch.equal(out["codes"], ref)
+    finally:
+        eng.ar_prefix = real_prefix
