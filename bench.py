@@ -54,6 +54,7 @@ VIEWS_PER_SOURCE = 16   # config C5: 8 source images x 16 novel views each
 # PS_BENCH_FORCE_COLLECTIVE=1: a single-rank run creates the RCCL process group all the same and sends its gathers, barrier and
 # max-over-ranks through it -- the multi-GPU code path (`world > 1` in back()) executed on the one GPU a test box has
 FORCE_COLLECTIVE = os.environ.get("PS_BENCH_FORCE_COLLECTIVE") == "1"
+HOST_TIMES = [] if os.environ.get("PS_BENCH_HOST_TIMES") == "1" else None   # run_steps: host stamps per step, summarised on stderr
 
 
 def make_inputs(rank, V, device, smooth=True, cameras="mp3d", ids=None, trajectory="sweep"):
@@ -157,8 +158,10 @@ def run_steps(model, d, world, n, side):
         # stream any more.
         gate = torch.cuda.Event()
         gate.record(main)
+        t0 = time.perf_counter()
         prev, out = out, back(model, d, planned, world, prev=out)
         finish_gathers(prev)      # (a step without column launches has not collected them)
+        t1 = time.perf_counter()
         planned = None
         if i + 1 < n:
             if not os.environ.get("PS_BENCH_NO_GATE"):
@@ -167,6 +170,8 @@ def run_steps(model, d, world, n, side):
                 planned = front(model, d)
             model.adopt_planned(planned, main)
             main.wait_stream(side)
+        if HOST_TIMES is not None:   # PS_BENCH_HOST_TIMES=1: where the host thread spends a step (enqueueing the AR run; the next step's front)
+            HOST_TIMES.append((t0, t1, time.perf_counter()))
     return finish_gathers(out)
 
 
@@ -655,6 +660,10 @@ def main():
     out = steps_fn(args.steps)
     barrier()
     dt = time.perf_counter() - t0
+    if HOST_TIMES:   # the timed steps' host side: enqueueing the AR run (back), the next step's front, both in ms from the step's start
+        for (a0, a1, a2), nxt in zip(HOST_TIMES[-args.steps:], HOST_TIMES[-args.steps + 1:] + [None]):
+            print(f"host: back {1e3 * (a1 - a0):6.2f} ms, front of the next step {1e3 * (a2 - a1):6.2f} ms"
+                  + (f", iteration {1e3 * (nxt[0] - a0):6.2f} ms" if nxt else ""), file=sys.stderr)
     model.outpaint2.engine(32, 32, V).check()  # (outside the timed region) no column launch gave up on an in-launch wait
     elapsed = D.max_over_ranks(dt, None if dry else device, force_collective=FORCE_COLLECTIVE)
 

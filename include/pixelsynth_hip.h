@@ -333,6 +333,24 @@ int ps_upsample_add_nhwc_f32(const float *a, const float *b, const float *bias, 
 int ps_add_bias_nhwc_f32(const float *a, const float *b, const float *bias, int B, int HW, int C, float *out,
                          void *stream);
 
+/* ---- 3 x 3 convolutions of the refinement decoder on the fp16 matrix pipe (csrc/conv_f16x3.hip) ------------------------------
+ * Replaces, for the decoder's wide layers, torch.nn.Conv2d(Ci, Co, 3, 1, 1) as ResNet_Block calls it (models/layers/blocks.py:34-73,
+ * models/networks/architectures.py:126-167), WITHOUT the bias (the caller folds it into the next pass, as for the MIOpen path).
+ * fp32 in, fp32 out; every product is three fp16 MFMAs on split operands (v = hi + lo), sums in fp32: see the unit's header.
+ *
+ * ps_conv3x3_f16x3_packed_bytes: size of the packed weights of a (Co, Ci, 3, 3) convolution.
+ * ps_conv3x3_f16x3_pack: w (Co, 3, 3, Ci) fp32 contiguous -- torch's channels_last storage of a (Co, Ci, 3, 3) weight -- into
+ *   `packed` (device, ps_conv3x3_f16x3_packed_bytes).  Co a multiple of 128, Ci a multiple of 32.
+ * ps_conv3x3_f16x3_nhwc: y (B, H, W, Co) = conv3x3(act(x), w), zero padding 1, stride 1; x (B, H, W, Ci); H, W multiples of 16.
+ *   scale, shift: (B, Ci) or both NULL: act(x) = max(x * scale[b][c] - shift[b][c], 0) -- the LinearNoiseLayer + ReLU in front of the
+ *   convolution (models/layers/normalization.py:21-47), applied on the way in; NULL: act(x) = x.
+ *   overflow: device int the kernel sets to 1 when an activation lies beyond fp16's range (|v| > 65000) or is not a number;
+ *   never cleared by the library. */
+size_t ps_conv3x3_f16x3_packed_bytes(int Co, int Ci);
+int ps_conv3x3_f16x3_pack(const float *w, int Co, int Ci, void *packed, void *stream);
+int ps_conv3x3_f16x3_nhwc(const float *x, const float *scale, const float *shift, const void *packed, int B, int H, int W,
+                          int Ci, int Co, float *y, int *overflow, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -25,6 +25,7 @@ UNITS = [
     ("lmconv_tp.hip", ["-ffp-contract=off"]),
     ("vq.hip", ["-ffp-contract=off"]),
     ("nets.hip", ["-ffp-contract=off"]),
+    ("conv_f16x3.hip", ["-ffp-contract=off", "-Wno-inline-asm"]),
     ("host_order.cpp", []),
 ]
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]

@@ -17,6 +17,8 @@ Same constructor arguments, attribute / parameter names and shapes as the refere
 Training-mode batch statistics are supported for the plain BatchNorm2d layers (torch's own); the noise-conditioned
 layers implement the stored-statistics (eval) form only -- this repository does not train.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -149,24 +151,82 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
+def _plain_conv_weight(conv, x):
+    """The weight of `conv` as its forward would use it on `x`, for callers that take the convolution apart -- or None when that
+    is not safe.  Only a plain Conv2d, or one whose single extra is the legacy torch.nn.utils.spectral_norm pre-hook (it recomputes
+    .weight from weight_orig / u / v and returns nothing), is taken apart; anything else -- forward hooks, the parametrizations
+    API, a pre-hook that edits the input, another padding mode -- goes through Module.__call__ untouched."""
+    from torch.nn.utils.spectral_norm import SpectralNorm
+    pre = list(conv._forward_pre_hooks.values())
+    plain = (type(conv) is nn.Conv2d and not conv._forward_hooks and not getattr(conv, "parametrizations", None)
+             and conv.padding_mode == "zeros" and all(isinstance(h, SpectralNorm) for h in pre))
+    if not plain:
+        return None
+    for hook in pre:
+        hook(conv, (x,))
+    return conv.weight
+
+
 def _conv_split(conv, x):
     """conv(x) as (output WITHOUT the bias, bias) on the inference GPU path -- torch adds a convolution's bias in a pass
     of its own; here the per-channel constant rides along in whatever pass consumes the output (csrc/nets.hip).  Elsewhere
     (CPU, autograd, channel counts the kernels do not take): (conv(x), None)."""
     if conv.bias is None or torch.is_grad_enabled() or not _is_nhwc_cuda(x) or conv.out_channels % 4:
         return conv(x), None
-    # Only a plain Conv2d, or one whose single extra is the legacy torch.nn.utils.spectral_norm pre-hook (it recomputes
-    # .weight from weight_orig / u / v and returns nothing), is taken apart here; anything else -- forward hooks, the
-    # parametrizations API, a pre-hook that edits the input, another padding mode -- goes through Module.__call__ untouched.
-    from torch.nn.utils.spectral_norm import SpectralNorm
-    pre = list(conv._forward_pre_hooks.values())
-    plain = (type(conv) is nn.Conv2d and not conv._forward_hooks and not getattr(conv, "parametrizations", None)
-             and conv.padding_mode == "zeros" and all(isinstance(h, SpectralNorm) for h in pre))
-    if not plain:
+    weight = _plain_conv_weight(conv, x)
+    if weight is None:
         return conv(x), None
-    for hook in pre:
-        hook(conv, (x,))
-    return F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups), conv.bias
+    return F.conv2d(x, weight, None, conv.stride, conv.padding, conv.dilation, conv.groups), conv.bias
+
+
+# ---- the wide 3 x 3 convolutions on the fp16 matrix pipe (csrc/conv_f16x3.hip) ------------------------------------------------
+DECODER_CONV = os.environ.get("PS_DECODER_CONV", "f16x3")   # "f16x3" | "fp32" (everything through torch / MIOpen)
+_overflow_flags = {}
+
+
+def _overflow_flag(device):
+    key = str(device)
+    if key not in _overflow_flags:
+        _overflow_flags[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return _overflow_flags[key]
+
+
+def check_f16x3_overflow(device):
+    """Synchronises.  Raises if a split-fp16 convolution met an activation beyond fp16's range since the last call (its output is
+    then wrong); callers that can sit such activations out set PS_DECODER_CONV=fp32 / opt.decoder_conv = "fp32"."""
+    flag = _overflow_flags.get(str(device))
+    if flag is not None and int(flag.item()):
+        flag.zero_()
+        raise RuntimeError("refinement decoder: an activation beyond fp16's range (|v| > 65000, or not a number) reached a split-fp16 "
+                           "convolution; rerun with PS_DECODER_CONV=fp32")
+
+
+def _f16x3_takes(conv, x):
+    return (conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1)
+            and conv.groups == 1 and conv.in_channels % 32 == 0 and conv.out_channels % 128 == 0
+            and _is_nhwc_cuda(x) and x.size(2) % 16 == 0 and x.size(3) % 16 == 0 and x.size(2) * x.size(3) * x.size(1) < 2 ** 31
+            and not torch.is_grad_enabled())
+
+
+def _f16x3_conv(conv, x, scale=None, shift=None):
+    """conv(act(x)) WITHOUT the bias through ps_conv3x3_f16x3_nhwc, act = max(x * scale - shift, 0) with scale / shift (B, C)
+    contiguous, or the identity; None when the kernel does not take this convolution (the caller then goes through torch)."""
+    if not _f16x3_takes(conv, x):
+        return None
+    weight = _plain_conv_weight(conv, x)
+    if weight is None:
+        return None
+    from .. import _lib
+    L = _lib.lib()
+    Co, Ci = conv.out_channels, conv.in_channels
+    wl = weight.detach().permute(0, 2, 3, 1).contiguous()          # (Co, 3, 3, Ci): no copy for a channels_last weight
+    packed = torch.empty(L.ps_conv3x3_f16x3_packed_bytes(Co, Ci), dtype=torch.uint8, device=x.device)
+    _lib.check(L.ps_conv3x3_f16x3_pack(wl.data_ptr(), Co, Ci, packed.data_ptr(), _stream()), "ps_conv3x3_f16x3_pack")
+    B, _, H, W = x.shape
+    y = _empty_nhwc(B, Co, H, W, x)
+    _lib.check(L.ps_conv3x3_f16x3_nhwc(x.data_ptr(), _ptr(scale), _ptr(shift), packed.data_ptr(), B, H, W, Ci, Co, y.data_ptr(),
+                                       _overflow_flag(x.device).data_ptr(), _stream()), "ps_conv3x3_f16x3_nhwc")
+    return y
 
 
 def _sum_bias(*bs):
@@ -211,6 +271,7 @@ class ResNet_Block(nn.Module):
 
     def __init__(self, in_c, in_o, opt, downsample=None):
         super().__init__()
+        self.opt = opt
         self.resample = downsample
         self.ch_a = _Slots(_0=LinearNoiseLayer(opt, output_sz=in_c), _2=_conv(opt, in_c, in_o, 3, 1, 1),
                            _3=LinearNoiseLayer(opt, output_sz=in_o), _5=_conv(opt, in_o, in_o, 3, 1, 1))
@@ -236,9 +297,24 @@ class ResNet_Block(nn.Module):
             return y
         return torch.clamp_min(torch.addcmul(-shift, x, scale), 0)
 
+    def _norm_relu_conv(self, layer, conv, x, noise, bias=None):
+        """conv(relu(norm(x + bias))) as (output without the convolution's own bias, that bias).  The decoder's wide 3 x 3 layers:
+        ONE kernel, norm + ReLU applied as the patch is staged (csrc/conv_f16x3.hip); the others: the affine pass, then torch."""
+        mode = getattr(self.opt, "decoder_conv", None) or DECODER_CONV
+        if mode == "f16x3" and conv.bias is not None and _f16x3_takes(conv, x):
+            scale, shift = layer.affine(x, noise)
+            if bias is not None:
+                shift = shift - bias.view(1, -1, 1, 1) * scale
+            B, C = x.size(0), x.size(1)
+            if scale.numel() in (C, B * C):
+                y = _f16x3_conv(conv, x, scale.reshape(-1, C).expand(B, C).contiguous(), shift.reshape(-1, C).expand(B, C).contiguous())
+                if y is not None:
+                    return y, conv.bias
+        return _conv_split(conv, self._noise_affine(layer, x, noise, bias))
+
     def forward(self, x, noise=(None, None)):
-        a, ba = _conv_split(self.ch_a[2], self._noise_affine(self.ch_a[0], x, noise[0]))
-        a, ba = _conv_split(self.ch_a[5], self._noise_affine(self.ch_a[3], a, noise[1], ba))
+        a, ba = self._norm_relu_conv(self.ch_a[0], self.ch_a[2], x, noise[0])
+        a, ba = self._norm_relu_conv(self.ch_a[3], self.ch_a[5], a, noise[1], ba)
         if not self.projected:
             return _resample_sum(None, a, x, ba)
         b, bb = _conv_split(self.ch_b[0], x)

@@ -22,6 +22,7 @@ from . import _lib
 from .lmconv.layers import PONO
 from .lmconv.model import OurPixelCNN
 from .lmconv.sample import sample
+from .networks.architectures import check_f16x3_overflow
 from .projection.z_buffer_manipulator import PtsManipulator
 
 
@@ -395,6 +396,7 @@ class ZbufferModelPts(nn.Module):
         pred = self._decode_candidate(out["gen_fs"], out["background_mask"], out["codes"])
         if check:
             self.outpaint2.engine(self.obs[1], self.obs[2], K.shape[0]).check()
+            check_f16x3_overflow(pred.device)   # (the decoder's split-fp16 convolutions: no activation beyond fp16's range)
         return dict(PredImg=pred, FeaturesImg=out["gen_fs"], background_mask=out["background_mask"], codes=out["codes"],
                     depth=depth_src, plan=out["plan"])
 
@@ -444,6 +446,7 @@ class ZbufferModelPts(nn.Module):
         outputs["PredCodes"] = codes
         if self.vqvae is not None:  # :250-252 (without a refinement net the blend itself is the prediction)
             outputs["PredImg"] = self._decode_candidate(gen_fs, background_mask, codes.to(torch.int64))
+            check_f16x3_overflow(gen_fs.device)
         return None, outputs
 
     # ---------------------------------------------------------------- sample ranking (8f.3, host logic)

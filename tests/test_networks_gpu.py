@@ -84,3 +84,93 @@ def test_block_elementwise_kernels_against_torch():
     np.testing.assert_allclose(_resample_sum("Up", a3, a3).cpu().numpy(), (2 * _resample("Up", a3)).cpu().numpy(), rtol=1e-6)
     rc = _lib.lib().ps_pool_add_nhwc_f32(a3.data_ptr(), None, None, 1, 4, 4, 3, a3.data_ptr(), st)
     assert rc != 0 and b"multiple of 4" in _lib.lib().ps_last_error()
+
+
+def _f16x3(x_nchw, w, scale=None, shift=None):
+    """ps_conv3x3_f16x3_pack + ps_conv3x3_f16x3_nhwc through the C ABI; returns (y as NCHW view, overflow flag tensor)."""
+    from pixelsynth_amd import _lib
+    L, st = _lib.lib(), torch.cuda.current_stream().cuda_stream
+    B, Ci, H, W = x_nchw.shape
+    Co = w.shape[0]
+    xl, wl = x_nchw.permute(0, 2, 3, 1).contiguous(), w.permute(0, 2, 3, 1).contiguous()
+    packed = torch.empty(L.ps_conv3x3_f16x3_packed_bytes(Co, Ci), dtype=torch.uint8, device=DEV)
+    assert packed.numel() == 9 * Co * Ci * 4
+    _lib.check(L.ps_conv3x3_f16x3_pack(wl.data_ptr(), Co, Ci, packed.data_ptr(), st), "pack")
+    y = torch.empty(B, H, W, Co, device=DEV)
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    _lib.check(L.ps_conv3x3_f16x3_nhwc(xl.data_ptr(), None if scale is None else scale.data_ptr(), None if shift is None else shift.data_ptr(),
+                                       packed.data_ptr(), B, H, W, Ci, Co, y.data_ptr(), flag.data_ptr(), st), "conv")
+    return y.permute(0, 3, 1, 2), flag
+
+
+@pytest.mark.parametrize("B,H,W,Ci,Co,fuse", [(2, 32, 32, 64, 128, False), (2, 32, 48, 128, 128, True), (1, 16, 16, 256, 256, True),
+                                               (3, 48, 16, 32, 128, False), (5, 16, 32, 96, 256, True)])
+def test_conv3x3_on_the_fp16_pipe_against_an_fp64_convolution(B, H, W, Ci, Co, fuse):
+    """csrc/conv_f16x3.hip: fp32 in and out, every product three fp16 MFMAs on split operands.  Against torch's convolution in
+    fp64 (the definition; F.conv2d(relu(norm(x)), w, None, 1, 1), models/layers/blocks.py:41-47): the error stays within 3e-6 of the output's
+    largest magnitude -- an fp32 convolution (MIOpen, same inputs) sits at 2-4e-7 -- and within ten times the fp32 convolution's own.
+    Tiles on every border (one-tile images, 1 x 3 and 3 x 1 tile grids), block counts that are and are not multiples of eight
+    (the XCD mapping), the norm + ReLU on the way in with per-sample (B, C) scale / shift."""
+    g = torch.Generator().manual_seed(Ci + Co + H)
+    x = (torch.randn(B, Ci, H, W, generator=g) * 1.5).to(DEV)
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) / (3 * Ci ** 0.5)).to(DEV)
+    sc = (torch.rand(B, Ci, generator=g) + 0.5).to(DEV) if fuse else None
+    sh = (torch.randn(B, Ci, generator=g) * 0.3).to(DEV) if fuse else None
+    xa = torch.clamp_min(x * sc.view(B, Ci, 1, 1) - sh.view(B, Ci, 1, 1), 0) if fuse else x
+    ref = torch.nn.functional.conv2d(xa.double(), w.double(), None, 1, 1)
+    y32 = torch.nn.functional.conv2d(xa, w, None, 1, 1)
+    y, flag = _f16x3(x, w, sc, sh)
+    top = ref.abs().max().item()
+    e16, e32 = (y.double() - ref).abs().max().item() / top, (y32.double() - ref).abs().max().item() / top
+    assert int(flag.item()) == 0
+    assert e16 < 3e-6 and e16 < 10 * e32, (e16, e32)
+
+
+def test_conv3x3_on_the_fp16_pipe_flags_what_fp16_cannot_hold_and_rejects_what_it_does_not_take():
+    from pixelsynth_amd import _lib
+    x = torch.ones(1, 32, 16, 16, device=DEV)
+    w = torch.full((128, 32, 3, 3), 0.01, device=DEV)
+    y, flag = _f16x3(x, w)
+    assert int(flag.item()) == 0 and abs(y[0, 0, 8, 8].item() - 2.88) < 1e-5 and abs(y[0, 0, 0, 0].item() - 1.28) < 1e-5
+    x[0, 5, 3, 3] = 7.0e4                      # beyond fp16's largest finite value
+    _, flag = _f16x3(x, w)
+    assert int(flag.item()) == 1
+    x[0, 5, 3, 3] = float("nan")
+    _, flag = _f16x3(x, w)
+    assert int(flag.item()) == 1
+    L, st = _lib.lib(), torch.cuda.current_stream().cuda_stream
+    buf = torch.empty(1 << 20, dtype=torch.uint8, device=DEV)
+    for Co, Ci, H in ((64, 32, 16), (128, 24, 16), (128, 32, 24)):
+        rc = (L.ps_conv3x3_f16x3_pack(buf.data_ptr(), Co, Ci, buf.data_ptr(), st) if H == 16 else
+              L.ps_conv3x3_f16x3_nhwc(buf.data_ptr(), None, None, buf.data_ptr(), 1, H, H, Ci, Co, buf.data_ptr(), buf.data_ptr(), st))
+        assert rc != 0 and b"multiple" in L.ps_last_error()
+
+
+def test_decoder_with_split_fp16_convolutions_equals_the_fp32_decoder(monkeypatch):
+    """The refinement decoder's wide 3 x 3 layers run through csrc/conv_f16x3.hip by default (norm + ReLU fused into the staging);
+    PS_DECODER_CONV=fp32 / opt.decoder_conv = "fp32" sends everything through torch (MIOpen fp32).  Same weights, image and noise:
+    the two images agree to 2e-5 (the output is a tanh in [-1, 1]); the default path really takes the kernel; an overflowing
+    activation is reported by check_f16x3_overflow."""
+    from pixelsynth_amd.networks import architectures as A
+    dec = _filled(get_decoder(syn.network_opts()), 7)
+    x = torch.from_numpy(syn.image(3, 2, 3, 256)).to(DEV)
+    bgm = torch.from_numpy(syn.background_masks(256)["ragged"])[None].expand(2, -1, -1).to(DEV)
+    noise = [torch.randn(2, 20, generator=torch.Generator().manual_seed(i)).to(DEV) for i in range(dec.n_noise())]
+    calls = []
+    real = A._f16x3_conv
+    monkeypatch.setattr(A, "_f16x3_conv", lambda *a, **k: (calls.append(a[0].in_channels), real(*a, **k))[1])
+    with torch.no_grad():
+        got = dec(x, bgm, noise=noise)
+        assert len(calls) == 12 and A.DECODER_CONV == "f16x3"        # every 3 x 3 layer with Ci % 32 == 0 and Co % 128 == 0
+        A.check_f16x3_overflow(x.device)
+        monkeypatch.setattr(A, "DECODER_CONV", "fp32")
+        del calls[:]
+        want = dec(x, bgm, noise=noise)
+        assert not calls
+    assert (got - want).abs().max().item() < 2e-5
+    with torch.no_grad():
+        monkeypatch.setattr(A, "DECODER_CONV", "f16x3")
+        dec(x * 1e6, bgm, noise=noise)
+    with pytest.raises(RuntimeError, match="fp16's range"):
+        A.check_f16x3_overflow(x.device)
+    A.check_f16x3_overflow(x.device)   # (the flag is cleared by the report)
