@@ -340,7 +340,8 @@ int ps_add_bias_nhwc_f32(const float *a, const float *b, const float *bias, int 
  *
  * ps_conv3x3_f16x3_packed_bytes: size of the packed weights of a (Co, Ci, 3, 3) convolution.
  * ps_conv3x3_f16x3_pack: w (Co, 3, 3, Ci) fp32 contiguous -- torch's channels_last storage of a (Co, Ci, 3, 3) weight -- into
- *   `packed` (device, ps_conv3x3_f16x3_packed_bytes).  Co a multiple of 128, Ci a multiple of 32.
+ *   `packed` (device, ps_conv3x3_f16x3_packed_bytes).  Co a multiple of 64 (128 is the kernel's block: 64 runs half empty), Ci a
+ *   multiple of 32.
  * ps_conv3x3_f16x3_nhwc: y (B, H, W, Co) = conv3x3(act(x), w), zero padding 1, stride 1; x (B, H, W, Ci); H, W multiples of 16.
  *   scale, shift: (B, Ci) or both NULL: act(x) = max(x * scale[b][c] - shift[b][c], 0) -- the LinearNoiseLayer + ReLU in front of the
  *   convolution (models/layers/normalization.py:21-47), applied on the way in; NULL: act(x) = x.

@@ -18,8 +18,11 @@
 //     convolutions, models/layers/normalization.py:21-47 -- fused here instead of a round trip through memory) split and written to LDS
 //     as planes [hi | lo][k / 8][pixel][8 fp16]: an A fragment of any tap is one conflict-free ds_read_b128 at a shifted pixel;
 //   * the weights come packed in fragment order (ps_conv3x3_f16x3_pack) and reach LDS by LDS-DMA (global_load_lds_dwordx4), 16 KB
-//     per tap, two taps ahead in a ring of three buffers, waited for with counted s_waitcnt vmcnt; one raw barrier per tap.
+//     per tap, three taps ahead in a ring of four buffers, waited for with counted s_waitcnt vmcnt; one raw barrier per tap.
 #include "ps_common.h"
+
+#include <algorithm>
+#include <cstdlib>
 
 namespace psconv {
 
@@ -37,7 +40,7 @@ constexpr int A_PLANE = PP * 16;           // bytes: [pixel][8 fp16]
 constexpr int A_BUF = 8 * A_PLANE;         // planes [part 2][ks 2][kb 2]
 constexpr int B_TAP = CK * COT * 4;        // 16 KB: [ks 2][ct 4][part 2][lane 64][8 fp16]
 constexpr int LDS_B = 2 * A_BUF;
-constexpr int LDS_TOTAL = LDS_B + 3 * B_TAP;   // 132 096 bytes
+constexpr int LDS_TOTAL = LDS_B + 4 * B_TAP;   // 148 480 bytes
 constexpr int NA = (PP + 63) / 64;         // patch pixels per thread: 6 (8 threads = 32 channels per pixel, 64 pixels per sweep)
 
 #define PS_GCP(p) ((const __attribute__((address_space(1))) void *)(p))
@@ -45,6 +48,9 @@ constexpr int NA = (PP + 63) / 64;         // patch pixels per thread: 6 (8 thre
 // LDS-DMA by hand (the builtin makes the compiler wait vmcnt(0) in front of the next read of the array, which is the ring being consumed)
 __device__ __forceinline__ void dma16(const void *gsrc, unsigned lds_base)
 {
+#if defined(PS_CONV_EXP) && (PS_CONV_EXP & 8)   // tuning build: no weight traffic (results invalid)
+    return;
+#endif
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(PS_GCP(gsrc)), "s"(lds_base) : "memory", "m0");
 }
 __device__ __forceinline__ f32x4 load16_async(const void *g)   // the result is there after a vmcnt wait the CALLER places
@@ -55,11 +61,19 @@ __device__ __forceinline__ f32x4 load16_async(const void *g)   // the result is 
 }
 template <int N> __device__ __forceinline__ void wait_vm()
 {
+#if defined(PS_CONV_EXP) && (PS_CONV_EXP & 8)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+#endif
     asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory");
 }
 __device__ __forceinline__ void lds_barrier()
 {
+#if defined(PS_CONV_EXP) && (PS_CONV_EXP & 4)   // tuning build: no barrier (results invalid)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
 }
 
 struct ConvArgs {
@@ -72,41 +86,67 @@ struct ConvArgs {
     int H, W, Ci, Co, tiles_x, tiles_per_frame, ncb, nblocks;
 };
 
-// FUSE: norm + ReLU on the way in
+// One (tile, output-channel block) of the launch: which patch, which weights, where the results go.
+struct Item {
+    const float *xb;      // the frame
+    const char *w;        // the channel block's packed weights (+ this wave's piece)
+    int b, cb, ty0, tx0;
+};
+
+// FUSE: norm + ReLU on the way in.  PERSISTENT workgroups: one per compute unit (148 KB of LDS), each walking its share of the
+// launch's (tile, channel block) items with the chunk pipeline running ACROSS items -- the first patch of the next item is fetched
+// and stashed during the last chunk of this one, the weight ring never drains, and an item's results are stored behind its last
+// MFMA while the next item's first taps multiply.  Worth 1-2 % over one workgroup per item (PS_CONV_WGS=0), more on the two-chunk
+// layers: the kernel is bound by its MFMA stream (with the fragment reads switched off it takes as long), and that stream by the
+// chip's power -- every SIMD issuing v_mfma_f32_32x32x16_f16 on random operands and nothing else holds 1.72 GHz = 1.77 PFLOP/s,
+// 0.71 of the nominal 2.5 (tools/mfma_f16_clock_probe.hip; 2.39 GHz on constant operands); this kernel reaches 1.1-1.3.
 template <bool FUSE> __global__ __launch_bounds__(NT) void k_conv3x3_f16x3(ConvArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // block -> (tile, output-channel block): block b runs on XCD b % 8; an XCD takes a contiguous run of (tile, cb) pairs, cb fastest,
-    // so that neighbouring patches and the two channel blocks of one patch meet in one L2
-    int L = blockIdx.x;
-    if ((a.nblocks & 7) == 0) L = (L & 7) * (a.nblocks >> 3) + (L >> 3);
-    const int cb = L % a.ncb, tile = L / a.ncb;
-    const int b = tile / a.tiles_per_frame, tf = tile - b * a.tiles_per_frame;
-    const int ty0 = (tf / a.tiles_x) * TH, tx0 = (tf % a.tiles_x) * TW;
     const int H = a.H, W = a.W, Ci = a.Ci, nchunk = Ci / CK, G = nchunk * 9;
-    const float *xb = a.x + (size_t)b * H * W * Ci;
+    // block -> items: block b runs on XCD b % 8; an XCD takes a contiguous run of (tile, cb) pairs, cb fastest, so that neighbouring
+    // patches and the two channel blocks of one patch meet in one L2; the XCD's workgroups deal that run among themselves
+    const int xcd = blockIdx.x & 7, j0 = blockIdx.x >> 3, J = gridDim.x >> 3;
+    const int lo_x = (int)(((long long)a.nblocks * xcd) >> 3), hi_x = (int)(((long long)a.nblocks * (xcd + 1)) >> 3);
+    const int nitems = lo_x + j0 < hi_x ? (hi_x - lo_x - j0 + J - 1) / J : 0;
+    if (nitems == 0) return;
+    auto item_at = [&](int i) {
+        const int L = lo_x + j0 + i * J;
+        Item it;
+        it.cb = L % a.ncb;
+        const int tile = L / a.ncb;
+        it.b = tile / a.tiles_per_frame;
+        const int tf = tile - it.b * a.tiles_per_frame;
+        it.ty0 = (tf / a.tiles_x) * TH;
+        it.tx0 = (tf % a.tiles_x) * TW;
+        it.xb = a.x + (size_t)it.b * H * W * Ci;
+        it.w = a.wp + (size_t)it.cb * G * B_TAP + (size_t)wave * 1024 + lane * 16;
+        return it;
+    };
 
     // ---- staging role of this thread: channels 4 c4 .. 4 c4 + 3 of the chunk, patch pixels s, s + 64, ...
     const int c4 = tid & 7, s = tid >> 3;
-    unsigned xoff[NA];
+    unsigned xoff[NA];       // of the item whose patch is fetched next
     unsigned valid = 0;
+    auto aim = [&](const Item &it) {
 #pragma unroll
-    for (int i = 0; i < NA; ++i) {
-        const int p = s + 64 * i, pr = p / PW, pc = p - pr * PW, iy = ty0 + pr - 1, ix = tx0 + pc - 1;
-        const bool ok = p < PP && iy >= 0 && iy < H && ix >= 0 && ix < W;
-        xoff[i] = ok ? (unsigned)((iy * W + ix) * Ci + 4 * c4) : 0u;
-        valid |= (unsigned)ok << i;
-    }
+        for (int i = 0; i < NA; ++i) {
+            const int p = s + 64 * i, pr = p / PW, pc = p - pr * PW, iy = it.ty0 + pr - 1, ix = it.tx0 + pc - 1;
+            const bool ok = p < PP && iy >= 0 && iy < H && ix >= 0 && ix < W;
+            xoff[i] = ok ? (unsigned)((iy * W + ix) * Ci + 4 * c4) : 0u;
+            valid = (valid & ~(1u << i)) | ((unsigned)ok << i);
+        }
+    };
     const unsigned a_wr = (unsigned)(((c4 >> 1) & 1) + 2 * (c4 >> 2)) * A_PLANE + (c4 & 1) * 8 + s * 16;   // + 64 * 16 per sweep; lo: + 4 planes
     f32x4 ra[NA], rsc, rsh;
     int over = 0;
-    auto fetch = [&](int c) {   // chunk c of the patch into registers (asynchronous)
+    auto fetch = [&](const Item &it, int c) {   // chunk c of the item's patch into registers (asynchronous)
 #pragma unroll
-        for (int i = 0; i < NA; ++i) ra[i] = load16_async(xb + xoff[i] + c * CK);
+        for (int i = 0; i < NA; ++i) ra[i] = load16_async(it.xb + xoff[i] + c * CK);
         if (FUSE) {
-            rsc = load16_async(a.scale + (size_t)b * Ci + c * CK + 4 * c4);
-            rsh = load16_async(a.shift + (size_t)b * Ci + c * CK + 4 * c4);
+            rsc = load16_async(a.scale + (size_t)it.b * Ci + c * CK + 4 * c4);
+            rsh = load16_async(a.shift + (size_t)it.b * Ci + c * CK + 4 * c4);
         }
     };
     constexpr int NFETCH = NA + (FUSE ? 2 : 0);
@@ -134,90 +174,158 @@ template <bool FUSE> __global__ __launch_bounds__(NT) void k_conv3x3_f16x3(ConvA
             *(h4 *)(dst + 4 * A_PLANE) = lo;
         }
     };
-    // ---- weight ring: tap g of the (chunk, tap) sequence -> buffer g % 3; this wave copies pieces `wave` and `wave + 8` of its 16 KB
-    const char *wsrc = a.wp + (size_t)cb * G * B_TAP + (size_t)wave * 1024 + lane * 16;
-    auto dma_tap = [&](int g, int buf) {
-        const unsigned dst = (unsigned)(LDS_B + buf * B_TAP + wave * 1024);
-        dma16(wsrc + (size_t)g * B_TAP, dst);
-        dma16(wsrc + (size_t)g * B_TAP + 8 * 1024, dst + 8 * 1024);
+    // ---- weight ring: the workgroup's taps in the order it multiplies them, tap number gg -> buffer gg & 3; this wave copies pieces
+    // `wave` and `wave + 8` of a tap's 16 KB
+    auto dma_tap = [&](const Item &it, int g, int gg) {   // tap g = 9 chunk + tap of the item
+        const unsigned dst = (unsigned)(LDS_B + (gg & 3) * B_TAP + wave * 1024);
+        dma16(it.w + (size_t)g * B_TAP, dst);
+        dma16(it.w + (size_t)g * B_TAP + 8 * 1024, dst + 8 * 1024);
     };
     // ---- MFMA role: rows 4 pg .. 4 pg + 3 of the tile (two M tiles of 2 rows x 16 pixels), channel tiles 2 chh, 2 chh + 1
     const int pg = wave & 3, chh = wave >> 2, m = lane & 31, kb = lane >> 5;
     const unsigned a_rd = (unsigned)(((4 * pg + (m >> 4)) * PW + (m & 15)) * 16 + kb * A_PLANE);
     const unsigned b_rd = (unsigned)(LDS_B + lane * 16 + chh * 2 * 2048);
     f32x16 acc[2][2];
+    auto clear = [&]() {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    };
+    // D[row][col]: col = lane & 31 = channel, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) = pixel of the M tile
+    auto store = [&](const Item &it) {
+        const int co = it.cb * COT + chh * 64 + m;
+        float *yb = a.y + ((size_t)it.b * H * W) * a.Co + co;
+        const bool ok0 = co < a.Co, ok1 = co + 32 < a.Co;   // (Co = 64: the block's upper half is padding)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * kb;
+                const int oy = it.ty0 + 4 * pg + 2 * mt + (row >> 4), ox = it.tx0 + (row & 15);
+                float *yp = yb + ((size_t)oy * W + ox) * a.Co;
+                if (ok0) yp[0] = acc[mt][0][r];
+                if (ok1) yp[32] = acc[mt][1][r];
+            }
+    };
 
-    fetch(0);
-    dma_tap(0, 0);
-    if (G > 1) dma_tap(1, 1);
-    wait_vm<4>();   // (G >= 9: two taps of two copies each are newer than the patch)
+    // The MFMA steps (tap, 16-channel half) run as a software pipeline: while a step's twelve MFMAs execute, the wave reads the NEXT
+    // step's eight fragments into the other register set.  So tap t + 1's weights are resident when tap t starts (ring of four,
+    // requested three taps ahead) and the next chunk's patch is stashed during tap 6.
+    struct Frag { h8 ah[2], al[2], bh[2], bl[2]; };
+    Frag F[2];
+    [[maybe_unused]] bool first_load = true;
+    auto load_frags = [&](Frag &f, const char *Ab, const char *Bb, int tap, int ks) {
+#if defined(PS_CONV_EXP) && (PS_CONV_EXP & 2)   // tuning build: fragments read once
+        if (!first_load) return;
+#endif
+        const int ky = tap / 3, kx = tap % 3;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const char *p = Ab + ks * 2 * A_PLANE + ((2 * mt + ky) * PW + kx) * 16;
+            f.ah[mt] = *(const h8 *)p;
+            f.al[mt] = *(const h8 *)(p + 4 * A_PLANE);
+        }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const char *p = Bb + ks * 8192 + nt * 2048;
+            f.bh[nt] = *(const h8 *)p;
+            f.bl[nt] = *(const h8 *)(p + 1024);
+        }
+    };
+    auto mfma_step = [&](const Frag &f) {
+#if defined(PS_CONV_EXP) && (PS_CONV_EXP & 1)   // tuning build: no MFMAs (the fragments still have to arrive)
+        asm volatile("" : : "v"(f.ah[0]), "v"(f.ah[1]), "v"(f.al[0]), "v"(f.al[1]), "v"(f.bh[0]), "v"(f.bh[1]), "v"(f.bl[0]), "v"(f.bl[1]));
+        return;
+#endif
+        // term by term over the four accumulators: an MFMA never waits for the result of the one in front of it
+#pragma unroll
+        for (int term = 0; term < 3; ++term)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(term == 0 ? f.al[mt] : f.ah[mt], term == 1 ? f.bl[nt] : f.bh[nt],
+                                                                         acc[mt][nt], 0, 0, 0);
+#ifndef PS_CONV_NO_SCHED
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {   // one fragment read behind each of the first eight MFMAs
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+#endif
+    };
+
+    Item cur = item_at(0), nxt = cur;
+    const int Q = nitems * nchunk, GG = Q * 9;   // chunk instances and taps of this workgroup
+    aim(cur);
+    fetch(cur, 0);
+    dma_tap(cur, 0, 0);
+    dma_tap(cur, 1, 1);
+    dma_tap(cur, 2, 2);
+    wait_vm<6>();   // (three taps of two copies each are newer than the patch)
     pin();
     stash(0);
+    clear();
+    bool stored = false;   // the previous item's results are on their way out
 
-    for (int c = 0; c < nchunk; ++c) {
-        const bool more = c + 1 < nchunk;
-        const char *Ab = lds + (c & 1) * A_BUF + a_rd;
+    int c = 0, item = 0;   // chunk of the current item; q = chunk instance
+    for (int q = 0; q < Q; ++q) {
+        const bool last = c + 1 == nchunk, more = q + 1 < Q;
+        if (last && more) nxt = item_at(item + 1);
+        const Item &nx = last ? nxt : cur;       // the item of the next chunk instance
+        const int cn = last ? 0 : c + 1;          // and its chunk
+        const char *Ab = lds + (q & 1) * A_BUF + a_rd, *An = lds + ((q + 1) & 1) * A_BUF + a_rd;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            const int g = c * 9 + tap;
-            // tap g's weights have landed: everything older than the requests that may still be in flight
-            // (tap g + 1's two copies; the next chunk's patch, requested at tap 0 behind tap 2's copies)
-            if (g + 1 >= G) wait_vm<0>();
+            const int gg = q * 9 + tap;
+            // tap gg + 1's weights have landed: everything older than the requests that may still be in flight (tap gg + 2's two
+            // copies; the next chunk's patch, requested at tap 0 behind tap 3's copies)
+            if (gg + 2 >= GG) wait_vm<0>();
+            else if (stored && tap < 2) ;                      // (landed before the stores went out, see below)
             else if ((tap == 1 || tap == 2) && more) wait_vm<2 + NFETCH>();
             else wait_vm<2>();
+            if (tap == 1) stored = false;
             lds_barrier();
-            if (g + 2 < G) dma_tap(g + 2, (tap + 2) % 3);
-            if (tap == 0 && more) fetch(c + 1);
-            const char *Bb = lds + b_rd + (tap % 3) * B_TAP;
-            const int ky = tap / 3, kx = tap % 3;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                h8 ah[2], al[2], bh[2], bl[2];
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    const char *p = Ab + ks * 2 * A_PLANE + ((2 * mt + ky) * PW + kx) * 16;
-                    ah[mt] = *(const h8 *)p;
-                    al[mt] = *(const h8 *)(p + 4 * A_PLANE);
-                }
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    const char *p = Bb + ks * 8192 + nt * 2048;
-                    bh[nt] = *(const h8 *)p;
-                    bl[nt] = *(const h8 *)(p + 1024);
-                }
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) {
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
-                    }
+            if (gg + 3 < GG) {
+                if (tap < 6) dma_tap(cur, c * 9 + tap + 3, gg + 3);
+                else dma_tap(nx, cn * 9 + tap - 6, gg + 3);
             }
-            if (tap == 8 && more) {   // (the patch was waited for at tap 3: tap 3's weights were requested behind it)
+            if (tap == 0 && more) {
+                if (last) aim(nx);
+                fetch(nx, cn);
+            }
+            const char *Bb = lds + b_rd + (gg & 3) * B_TAP, *Bn = lds + b_rd + ((gg + 1) & 3) * B_TAP;
+            if (gg == 0) load_frags(F[0], Ab, Bb, 0, 0);
+            load_frags(F[1], Ab, Bb, tap, 1);
+            first_load = false;
+            mfma_step(F[0]);
+            if (tap < 8) load_frags(F[0], Ab, Bn, tap + 1, 0);
+            else if (more) load_frags(F[0], An, Bn, 0, 0);
+            mfma_step(F[1]);
+            if (tap == 6 && more) {   // (the patch was waited for at tap 3, whose wait covers tap 1's copies, requested behind it)
                 pin();
-                stash((c + 1) & 1);
+                stash((q + 1) & 1);
             }
+        }
+        if (last) {
+            // Stores and loads retire in no fixed order, so a counted wait behind 64 stores would wait for all of them.  Instead:
+            // everything requested so far (the next item's taps 0 .. 2) is waited for HERE, the next two taps then need no wait, and
+            // tap 2's counts only the loads behind it (a store still in flight makes that wait longer, never shorter).
+            if (more) wait_vm<0>();
+            store(cur);
+            clear();
+            stored = more;
+            cur = nxt;
+            ++item;
+            c = 0;
+        } else {
+            ++c;
         }
     }
-    // ---- out: D[row][col]: col = lane & 31 = channel, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) = pixel of the M tile
-    float *yb = a.y + ((size_t)b * H * W) * a.Co + cb * COT + chh * 64 + m;
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * kb;
-            const int oy = ty0 + 4 * pg + 2 * mt + (row >> 4), ox = tx0 + (row & 15);
-            float *yp = yb + ((size_t)oy * W + ox) * a.Co;
-            yp[0] = acc[mt][0][r];
-            yp[32] = acc[mt][1][r];
-        }
     if (over) *a.overflow = 1;
 }
 
@@ -234,11 +342,10 @@ __global__ __launch_bounds__(256) void k_pack(const float *__restrict__ w, int C
     const int tap = q % 9; q /= 9;
     const int nchunk = Ci / CK, chunk = q % nchunk, cb = q / nchunk;
     const int co = cb * COT + ct * 32 + (lane & 31), ci = chunk * CK + ks * 16 + (lane >> 5) * 8;
-    const float *src = w + ((size_t)co * 9 + tap) * Ci + ci;
     h8 hi, lo;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const float v = src[j];
+        const float v = co < Co ? w[((size_t)co * 9 + tap) * Ci + ci + j] : 0.f;   // (Co = 64: the block's upper half is zeros)
         hi[j] = (_Float16)v;
         lo[j] = (_Float16)(v - (float)hi[j]);
     }
@@ -251,14 +358,14 @@ __global__ __launch_bounds__(256) void k_pack(const float *__restrict__ w, int C
 
 extern "C" {
 
-size_t ps_conv3x3_f16x3_packed_bytes(int Co, int Ci) { return (size_t)9 * Co * Ci * 4; }
+size_t ps_conv3x3_f16x3_packed_bytes(int Co, int Ci) { return (size_t)9 * ((Co + psconv::COT - 1) / psconv::COT * psconv::COT) * Ci * 4; }
 
 int ps_conv3x3_f16x3_pack(const float *w, int Co, int Ci, void *packed, void *stream)
 {
     PS_REQUIRE(w && packed, "conv3x3_f16x3_pack: null pointer");
-    PS_REQUIRE(Co > 0 && Co % psconv::COT == 0 && Ci > 0 && Ci % psconv::CK == 0,
-               "conv3x3_f16x3_pack: Co a multiple of 128 and Ci a multiple of 32 required (Co = %d, Ci = %d)", Co, Ci);
-    const int total = (Co / psconv::COT) * (Ci / psconv::CK) * 9 * 2 * 4 * 64;
+    PS_REQUIRE(Co > 0 && Co % 64 == 0 && Ci > 0 && Ci % psconv::CK == 0,
+               "conv3x3_f16x3_pack: Co a multiple of 64 and Ci a multiple of 32 required (Co = %d, Ci = %d)", Co, Ci);
+    const int total = ((Co + psconv::COT - 1) / psconv::COT) * (Ci / psconv::CK) * 9 * 2 * 4 * 64;
     hipLaunchKernelGGL(psconv::k_pack, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, Co, Ci, (psconv::h8 *)packed, total);
     PS_LAUNCH_CHECK();
     return PS_OK;
@@ -271,23 +378,39 @@ int ps_conv3x3_f16x3_nhwc(const float *x, const float *scale, const float *shift
     PS_REQUIRE(x && packed && y && overflow, "conv3x3_f16x3: null pointer");
     PS_REQUIRE((scale == nullptr) == (shift == nullptr), "conv3x3_f16x3: scale and shift come together");
     PS_REQUIRE(B > 0 && H > 0 && W > 0 && H % TH == 0 && W % TW == 0, "conv3x3_f16x3: H and W multiples of 16 required (H = %d, W = %d)", H, W);
-    PS_REQUIRE(Co > 0 && Co % COT == 0 && Ci > 0 && Ci % CK == 0,
-               "conv3x3_f16x3: Co a multiple of 128 and Ci a multiple of 32 required (Co = %d, Ci = %d)", Co, Ci);
+    PS_REQUIRE(Co > 0 && Co % 64 == 0 && Ci > 0 && Ci % CK == 0,
+               "conv3x3_f16x3: Co a multiple of 64 and Ci a multiple of 32 required (Co = %d, Ci = %d)", Co, Ci);
     PS_REQUIRE((size_t)H * W * Ci < ((size_t)1 << 31), "conv3x3_f16x3: a frame of %d x %d x %d does not fit 32-bit offsets", H, W, Ci);
     ConvArgs a;
     a.x = x; a.scale = scale; a.shift = shift; a.wp = (const char *)packed; a.y = y; a.overflow = overflow;
     a.H = H; a.W = W; a.Ci = Ci; a.Co = Co;
-    a.tiles_x = W / TW; a.tiles_per_frame = (H / TH) * a.tiles_x; a.ncb = Co / COT;
+    a.tiles_x = W / TW; a.tiles_per_frame = (H / TH) * a.tiles_x; a.ncb = (Co + COT - 1) / COT;
     const size_t nb = (size_t)B * a.tiles_per_frame * a.ncb;
-    PS_REQUIRE(nb < ((size_t)1 << 31), "conv3x3_f16x3: too many tiles");
+    PS_REQUIRE(nb < ((size_t)1 << 30), "conv3x3_f16x3: too many tiles");
     a.nblocks = (int)nb;
+    // one persistent workgroup per compute unit (148 KB of LDS each), a multiple of the eight XCDs
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        PS_HIP_CHECK(hipGetDevice(&dev));
+        PS_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+        cus = prop.multiProcessorCount >= 8 ? prop.multiProcessorCount / 8 * 8 : 8;
+    }
+    static int wgs = -2;     // PS_CONV_WGS (tuning): workgroups per launch; 0 = one per item (no persistence); default: one per compute unit
+    if (wgs == -2) {
+        const char *e = getenv("PS_CONV_WGS");
+        wgs = e ? atoi(e) : -1;
+    }
+    const int want = wgs < 0 ? cus : wgs == 0 ? (int)((nb + 7) / 8 * 8) : (wgs + 7) / 8 * 8;
+    const int grid = (int)std::min<size_t>((size_t)want, (nb + 7) / 8 * 8);
     static bool attr_set[2] = {false, false};   // (per process; the attribute is per function)
     if (scale) {
         if (!attr_set[1]) { PS_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv3x3_f16x3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL)); attr_set[1] = true; }
-        hipLaunchKernelGGL(k_conv3x3_f16x3<true>, dim3(a.nblocks), dim3(NT), LDS_TOTAL, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(k_conv3x3_f16x3<true>, dim3(grid), dim3(NT), LDS_TOTAL, (hipStream_t)stream, a);
     } else {
         if (!attr_set[0]) { PS_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv3x3_f16x3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL)); attr_set[0] = true; }
-        hipLaunchKernelGGL(k_conv3x3_f16x3<false>, dim3(a.nblocks), dim3(NT), LDS_TOTAL, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(k_conv3x3_f16x3<false>, dim3(grid), dim3(NT), LDS_TOTAL, (hipStream_t)stream, a);
     }
     PS_LAUNCH_CHECK();
     return PS_OK;

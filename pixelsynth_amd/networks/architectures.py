@@ -167,16 +167,33 @@ def _plain_conv_weight(conv, x):
     return conv.weight
 
 
+_MIOPEN_SAFE_BYTES = 2 ** 31
+
+
+def _conv2d_batches(fn, x, out_channels, stride=1):
+    """fn(x) -- a convolution through torch (MIOpen) -- with the batch cut so that neither the input nor the output of a call
+    reaches 2 GiB: MIOpen's fp32 NHWC kernels index with 32 bits, and a (128, 128, 256, 256) activation -- 4 GiB, the decoder's
+    widest layer at C5's 128 views -- comes back WRONG, silently (8e-2 of the output's scale against an fp64 convolution,
+    tools/conv_f16x3_big_check.py; at 64 views, 2 GiB, it is right).  The split-fp16 kernel indexes frames with 64 bits."""
+    B = x.size(0)
+    per = max(x[0].numel(), out_channels * (x.size(2) // stride) * (x.size(3) // stride)) * x.element_size()
+    n = max(1, min(B, (_MIOPEN_SAFE_BYTES - 1) // max(per, 1)))
+    if not x.is_cuda or n >= B:
+        return fn(x)
+    return torch.cat([fn(x[i:i + n]) for i in range(0, B, n)])
+
+
 def _conv_split(conv, x):
     """conv(x) as (output WITHOUT the bias, bias) on the inference GPU path -- torch adds a convolution's bias in a pass
     of its own; here the per-channel constant rides along in whatever pass consumes the output (csrc/nets.hip).  Elsewhere
     (CPU, autograd, channel counts the kernels do not take): (conv(x), None)."""
     if conv.bias is None or torch.is_grad_enabled() or not _is_nhwc_cuda(x) or conv.out_channels % 4:
-        return conv(x), None
+        return _conv2d_batches(conv, x, conv.out_channels, conv.stride[0]), None
     weight = _plain_conv_weight(conv, x)
     if weight is None:
-        return conv(x), None
-    return F.conv2d(x, weight, None, conv.stride, conv.padding, conv.dilation, conv.groups), conv.bias
+        return _conv2d_batches(conv, x, conv.out_channels, conv.stride[0]), None
+    return _conv2d_batches(lambda t: F.conv2d(t, weight, None, conv.stride, conv.padding, conv.dilation, conv.groups), x,
+                           conv.out_channels, conv.stride[0]), conv.bias
 
 
 # ---- the wide 3 x 3 convolutions on the fp16 matrix pipe (csrc/conv_f16x3.hip) ------------------------------------------------
@@ -203,7 +220,7 @@ def check_f16x3_overflow(device):
 
 def _f16x3_takes(conv, x):
     return (conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1)
-            and conv.groups == 1 and conv.in_channels % 32 == 0 and conv.out_channels % 128 == 0
+            and conv.groups == 1 and conv.in_channels % 32 == 0 and conv.out_channels % 64 == 0
             and _is_nhwc_cuda(x) and x.size(2) % 16 == 0 and x.size(3) % 16 == 0 and x.size(2) * x.size(3) * x.size(1) < 2 ** 31
             and not torch.is_grad_enabled())
 

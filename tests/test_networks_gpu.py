@@ -94,7 +94,7 @@ def _f16x3(x_nchw, w, scale=None, shift=None):
     Co = w.shape[0]
     xl, wl = x_nchw.permute(0, 2, 3, 1).contiguous(), w.permute(0, 2, 3, 1).contiguous()
     packed = torch.empty(L.ps_conv3x3_f16x3_packed_bytes(Co, Ci), dtype=torch.uint8, device=DEV)
-    assert packed.numel() == 9 * Co * Ci * 4
+    assert packed.numel() == 9 * ((Co + 127) // 128 * 128) * Ci * 4
     _lib.check(L.ps_conv3x3_f16x3_pack(wl.data_ptr(), Co, Ci, packed.data_ptr(), st), "pack")
     y = torch.empty(B, H, W, Co, device=DEV)
     flag = torch.zeros(1, dtype=torch.int32, device=DEV)
@@ -104,13 +104,14 @@ def _f16x3(x_nchw, w, scale=None, shift=None):
 
 
 @pytest.mark.parametrize("B,H,W,Ci,Co,fuse", [(2, 32, 32, 64, 128, False), (2, 32, 48, 128, 128, True), (1, 16, 16, 256, 256, True),
-                                               (3, 48, 16, 32, 128, False), (5, 16, 32, 96, 256, True)])
+                                               (3, 48, 16, 32, 128, False), (5, 16, 32, 96, 256, True), (2, 32, 32, 64, 64, True),
+                                               (37, 16, 16, 32, 192, False)])
 def test_conv3x3_on_the_fp16_pipe_against_an_fp64_convolution(B, H, W, Ci, Co, fuse):
     """csrc/conv_f16x3.hip: fp32 in and out, every product three fp16 MFMAs on split operands.  Against torch's convolution in
     fp64 (the definition; F.conv2d(relu(norm(x)), w, None, 1, 1), models/layers/blocks.py:41-47): the error stays within 3e-6 of the output's
     largest magnitude -- an fp32 convolution (MIOpen, same inputs) sits at 2-4e-7 -- and within ten times the fp32 convolution's own.
-    Tiles on every border (one-tile images, 1 x 3 and 3 x 1 tile grids), block counts that are and are not multiples of eight
-    (the XCD mapping), the norm + ReLU on the way in with per-sample (B, C) scale / shift."""
+    Tiles on every border (one-tile images, 1 x 3 and 3 x 1 tile grids), more and fewer (tile, channel block) items than persistent
+    workgroups and counts the eight XCDs do not divide, 64 output channels (a half-empty channel block), the norm + ReLU on the way in with per-sample (B, C) scale / shift."""
     g = torch.Generator().manual_seed(Ci + Co + H)
     x = (torch.randn(B, Ci, H, W, generator=g) * 1.5).to(DEV)
     w = (torch.randn(Co, Ci, 3, 3, generator=g) / (3 * Ci ** 0.5)).to(DEV)
@@ -140,7 +141,7 @@ def test_conv3x3_on_the_fp16_pipe_flags_what_fp16_cannot_hold_and_rejects_what_i
     assert int(flag.item()) == 1
     L, st = _lib.lib(), torch.cuda.current_stream().cuda_stream
     buf = torch.empty(1 << 20, dtype=torch.uint8, device=DEV)
-    for Co, Ci, H in ((64, 32, 16), (128, 24, 16), (128, 32, 24)):
+    for Co, Ci, H in ((96, 32, 16), (128, 24, 16), (128, 32, 24)):
         rc = (L.ps_conv3x3_f16x3_pack(buf.data_ptr(), Co, Ci, buf.data_ptr(), st) if H == 16 else
               L.ps_conv3x3_f16x3_nhwc(buf.data_ptr(), None, None, buf.data_ptr(), 1, H, H, Ci, Co, buf.data_ptr(), buf.data_ptr(), st))
         assert rc != 0 and b"multiple" in L.ps_last_error()
@@ -161,7 +162,7 @@ def test_decoder_with_split_fp16_convolutions_equals_the_fp32_decoder(monkeypatc
     monkeypatch.setattr(A, "_f16x3_conv", lambda *a, **k: (calls.append(a[0].in_channels), real(*a, **k))[1])
     with torch.no_grad():
         got = dec(x, bgm, noise=noise)
-        assert len(calls) == 12 and A.DECODER_CONV == "f16x3"        # every 3 x 3 layer with Ci % 32 == 0 and Co % 128 == 0
+        assert len(calls) == 13 and A.DECODER_CONV == "f16x3"        # every 3 x 3 layer with Ci % 32 == 0 and Co % 64 == 0
         A.check_f16x3_overflow(x.device)
         monkeypatch.setattr(A, "DECODER_CONV", "fp32")
         del calls[:]
@@ -174,3 +175,50 @@ def test_decoder_with_split_fp16_convolutions_equals_the_fp32_decoder(monkeypatc
     with pytest.raises(RuntimeError, match="fp16's range"):
         A.check_f16x3_overflow(x.device)
     A.check_f16x3_overflow(x.device)   # (the flag is cleared by the report)
+
+
+def test_conv3x3_on_the_fp16_pipe_indexes_activations_beyond_4_gib():
+    """C5's 128 views put 4 GiB through the decoder's 128-channel layers at 256 x 256.  MIOpen's fp32 NHWC kernels come back wrong
+    there (32-bit indexing; tools/conv_f16x3_big_check.py: 8e-2 of the output's scale) -- which is why networks/architectures.py
+    cuts the batch for what still goes through torch (next test); the split-fp16 kernel indexes frames with 64 bits: frames 0, 63,
+    64 and 127 of a 128-view batch against an fp64 convolution of those frames alone."""
+    g = torch.Generator().manual_seed(11)
+    V, H, C = 128, 256, 128
+    x = torch.empty(V, C, H, H, device=DEV).contiguous(memory_format=torch.channels_last)
+    for v in range(0, V, 16):
+        x[v:v + 16] = torch.randn(16, C, H, H, generator=g).to(DEV)
+    w = (torch.randn(C, C, 3, 3, generator=g) * 0.03).to(DEV)
+    y, flag = _f16x3(x, w)
+    assert x.numel() * 4 == 2 ** 32 and int(flag.item()) == 0
+    for v in (0, 63, 64, 127):
+        ref = torch.nn.functional.conv2d(x[v:v + 1].double(), w.double(), None, 1, 1)
+        err = (y[v:v + 1].double() - ref).abs().max().item() / ref.abs().max().item()
+        assert err < 3e-6, (v, err)
+
+
+def test_convolutions_through_torch_are_cut_below_2_gib_per_call(monkeypatch):
+    """_conv2d_batches: the decoder's convolutions that still go through torch (MIOpen) see at most _MIOPEN_SAFE_BYTES of input or
+    output per call.  With the limit lowered so that a 5-view batch is cut into calls of 2, 2 and 1 views: the same image as uncut (1e-5),
+    channels_last preserved, and the calls are the expected ones."""
+    from pixelsynth_amd.networks import architectures as A
+    monkeypatch.setattr(A, "DECODER_CONV", "fp32")
+    dec = _filled(get_decoder(syn.network_opts()), 9)
+    x = torch.from_numpy(syn.image(5, 5, 3, 256)).to(DEV)
+    bgm = torch.from_numpy(syn.background_masks(256)["ragged"])[None].expand(5, -1, -1).to(DEV)
+    noise = [torch.randn(5, 20, generator=torch.Generator().manual_seed(i)).to(DEV) for i in range(dec.n_noise())]
+    with torch.no_grad():
+        want = dec(x, bgm, noise=noise)
+        sizes = []
+        real = A._conv2d_batches
+
+        def spy(fn, t, *a, **k):
+            return real(lambda u: (sizes.append(u.size(0)), fn(u))[1], t, *a, **k)
+        monkeypatch.setattr(A, "_conv2d_batches", spy)
+        monkeypatch.setattr(A, "_MIOPEN_SAFE_BYTES", 2 * 128 * 256 * 256 * 4 + 1)   # two views of the widest layer
+        got = dec(x, bgm, noise=noise)
+    assert 2 in sizes and 1 in sizes and max(sizes) <= 5 and sizes.count(5) > 0    # (narrow layers still go in one call)
+    assert (got - want).abs().max().item() < 1e-5      # (MIOpen may pick another algorithm for another batch size: not bit-equal)
+    t = torch.randn(5, 8, 16, 16, device=DEV).contiguous(memory_format=torch.channels_last)
+    monkeypatch.setattr(A, "_MIOPEN_SAFE_BYTES", 2 * 8 * 16 * 16 * 4 + 1)
+    out = real(lambda u: u * 2, t, 8)
+    assert out.is_contiguous(memory_format=torch.channels_last) and torch.equal(out, t * 2)

@@ -43,7 +43,7 @@ def timeit(fn, n=10):
 
 torch.manual_seed(0)
 # ---- accuracy: small case, fp64 reference
-for (B, H, Ci, Co, fuse) in [(2, 32, 64, 128, False), (2, 32, 128, 128, True), (1, 16, 256, 256, True), (3, 48, 32, 128, False)]:
+for (B, H, Ci, Co, fuse) in [(2, 32, 64, 128, False), (2, 32, 128, 128, True), (1, 16, 256, 256, True), (3, 48, 32, 128, False), (40, 32, 64, 64, True)]:
     x = torch.randn(B, Ci, H, H, device=dev) * 1.5
     w = torch.randn(Co, Ci, 3, 3, device=dev) * (1.0 / (3 * Ci ** 0.5))
     sc = (torch.rand(B, Ci, device=dev) + 0.5) if fuse else None
@@ -62,7 +62,7 @@ for (B, H, Ci, Co, fuse) in [(2, 32, 64, 128, False), (2, 32, 128, 128, True), (
 # ---- speed: the decoder's layers at V views
 V = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 tot16 = tot32 = 0.0
-for (H, Ci, Co, n) in [(256, 64, 128, 1), (256, 128, 128, 3), (128, 128, 256, 1), (128, 256, 256, 1), (64, 256, 256, 2), (64, 256, 128, 1),
+for (H, Ci, Co, n) in [(256, 64, 64, 1), (256, 64, 128, 1), (256, 128, 128, 3), (128, 128, 256, 1), (128, 256, 256, 1), (64, 256, 256, 2), (64, 256, 128, 1),
                        (64, 128, 128, 1), (128, 128, 128, 2)]:
     x = torch.randn(V, H, H, Ci, device=dev)
     w = torch.randn(Co, Ci, 3, 3, device=dev) * 0.05
