@@ -26,6 +26,7 @@ UNITS = [
     ("vq.hip", ["-ffp-contract=off"]),
     ("nets.hip", ["-ffp-contract=off"]),
     ("conv_f16x3.hip", ["-ffp-contract=off", "-Wno-inline-asm"]),
+    ("conv_thin.hip", ["-ffp-contract=off"]),
     ("host_order.cpp", []),
 ]
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]

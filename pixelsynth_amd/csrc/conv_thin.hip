@@ -1,0 +1,159 @@
+// conv_thin.hip -- the two THIN 3 x 3 convolutions at either end of the refinement decoder (SURVEY 8f row 2;
+// models/networks/architectures.py:126-167, models/layers/blocks.py:34-73) for gfx950 (MI355X), fp32 throughout:
+//   ps_conv3x3_thin_in_nhwc_f32    4 input channels -> Co (block 0: the reprojected RGB + mask into 64 channels)
+//   ps_conv3x3_thin_out_nhwc_f32   Ci -> at most 4 output channels (block 7: 128 channels into RGB)
+// Neither is a matrix product worth the name (K = 36; N = 3): through MIOpen's implicit GEMM they take 0.5 and 0.9 ms per 16 views,
+// as long as the decoder's 128 -> 128 layers do on the fp16 pipe (csrc/conv_f16x3.hip), while their arithmetic is 2 % of those.
+// Here they are what they are -- one pass over the wide side of the layer (the 64-channel output / the 128-channel input) at memory
+// speed, fp32 FMAs on the vector ALU, weights through the scalar cache (uniform addresses) -- with the block's norm + ReLU,
+// y = max(x * scale[b][c] - shift[b][c], 0) (models/layers/normalization.py:21-47), applied on the way in.  No bias: the caller
+// folds it into the next pass, as for every convolution of the decoder.
+#include "ps_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TW = 32, TH = 8;                   // output pixels per 256-thread workgroup
+constexpr int PW = TW + 2, PP = (TH + 2) * PW;   // the patch: 10 x 34 = 340 pixels
+
+// ---- 4 -> Co.  A thread owns one output pixel: its 3 x 3 x 4 inputs in registers, four output channels at a time.
+// w: [tap 9][ci 4][Co]
+template <bool FUSE> __global__ __launch_bounds__(256) void k_thin_in(const f32x4 *__restrict__ x, const f32x4 *__restrict__ scale,
+                                                                       const f32x4 *__restrict__ shift, const float *__restrict__ w,
+                                                                       float *__restrict__ y, int H, int W, int Co, int tiles_x,
+                                                                       int tiles_per_frame)
+{
+    const int b = blockIdx.x / tiles_per_frame, tf = blockIdx.x - b * tiles_per_frame;
+    const int oy = (tf / tiles_x) * TH + (threadIdx.x >> 5), ox = (tf % tiles_x) * TW + (threadIdx.x & 31);
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 sc = zero, sh = zero;
+    if (FUSE) { sc = scale[b]; sh = shift[b]; }
+    f32x4 in[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int iy = oy + t / 3 - 1, ix = ox + t % 3 - 1;
+        f32x4 v = zero;
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+            v = x[((size_t)b * H + iy) * W + ix];
+            if (FUSE) v = __builtin_elementwise_max(v * sc - sh, zero);
+        }
+        in[t] = v;
+    }
+    float *yp = y + (((size_t)b * H + oy) * W + ox) * Co;
+    for (int c = 0; c < Co; c += 4) {
+        f32x4 acc = zero;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 wv = *(const f32x4 *)(w + (size_t)(t * 4 + j) * Co + c);   // (uniform: scalar loads)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[k] = __builtin_fmaf(in[t][j], wv[k], acc[k]);
+            }
+        *(f32x4 *)(yp + c) = acc;
+    }
+}
+
+// ---- Ci -> CO <= 4.  The workgroup's 10 x 34 patch of 32 input channels in LDS as [c / 4][pixel] float4s (a wave's reads are
+// consecutive), normalised on the way in; a thread owns one output pixel and CO accumulators.  w: [tap 9][Ci][CO]
+template <int CO, bool FUSE> __global__ __launch_bounds__(256) void k_thin_out(const float *__restrict__ x, const float *__restrict__ scale,
+                                                                               const float *__restrict__ shift, const float *__restrict__ w,
+                                                                               float *__restrict__ y, int H, int W, int Ci, int tiles_x,
+                                                                               int tiles_per_frame)
+{
+    __shared__ f32x4 patch[8][PP];
+    const int b = blockIdx.x / tiles_per_frame, tf = blockIdx.x - b * tiles_per_frame;
+    const int ty0 = (tf / tiles_x) * TH, tx0 = (tf % tiles_x) * TW, ty = threadIdx.x >> 5, tx = threadIdx.x & 31;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    const float *xb = x + (size_t)b * H * W * Ci;
+    float acc[CO];
+#pragma unroll
+    for (int k = 0; k < CO; ++k) acc[k] = 0.f;
+    for (int c0 = 0; c0 < Ci; c0 += 32) {
+        for (int i = threadIdx.x; i < PP * 8; i += 256) {
+            const int p = i >> 3, c4 = i & 7, pr = p / PW, pc = p - pr * PW, iy = ty0 + pr - 1, ix = tx0 + pc - 1;
+            f32x4 v = zero;
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+                v = *(const f32x4 *)(xb + ((size_t)iy * W + ix) * Ci + c0 + 4 * c4);
+                if (FUSE) {
+                    const f32x4 sc = *(const f32x4 *)(scale + (size_t)b * Ci + c0 + 4 * c4), sh = *(const f32x4 *)(shift + (size_t)b * Ci + c0 + 4 * c4);
+                    v = __builtin_elementwise_max(v * sc - sh, zero);
+                }
+            }
+            patch[c4][p] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int pp = (ty + t / 3) * PW + tx + t % 3;
+#pragma unroll
+            for (int c4 = 0; c4 < 8; ++c4) {
+                const f32x4 v = patch[c4][pp];
+                const float *wv = w + ((size_t)t * Ci + c0 + 4 * c4) * CO;   // (uniform: scalar loads)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int k = 0; k < CO; ++k) acc[k] = __builtin_fmaf(v[j], wv[j * CO + k], acc[k]);
+            }
+        }
+        __syncthreads();
+    }
+    float *yp = y + (((size_t)b * H + ty0 + ty) * W + tx0 + tx) * CO;
+#pragma unroll
+    for (int k = 0; k < CO; ++k) yp[k] = acc[k];
+}
+
+}  // namespace
+
+extern "C" {
+
+int ps_conv3x3_thin_in_nhwc_f32(const float *x, const float *scale, const float *shift, const float *w, int B, int H, int W, int Co,
+                                float *y, void *stream)
+{
+    PS_REQUIRE(x && w && y, "conv3x3_thin_in: null pointer");
+    PS_REQUIRE((scale == nullptr) == (shift == nullptr), "conv3x3_thin_in: scale and shift come together");
+    PS_REQUIRE(B > 0 && H > 0 && W > 0 && H % TH == 0 && W % TW == 0 && Co > 0 && Co % 4 == 0,
+               "conv3x3_thin_in: H a multiple of 8, W of 32, Co of 4 required (H = %d, W = %d, Co = %d)", H, W, Co);
+    const int tiles_x = W / TW, tpf = (H / TH) * tiles_x;
+    PS_REQUIRE((size_t)B * tpf < ((size_t)1 << 31), "conv3x3_thin_in: too many tiles");
+    if (scale)
+        hipLaunchKernelGGL(k_thin_in<true>, dim3(B * tpf), dim3(256), 0, (hipStream_t)stream, (const f32x4 *)x, (const f32x4 *)scale,
+                           (const f32x4 *)shift, w, y, H, W, Co, tiles_x, tpf);
+    else
+        hipLaunchKernelGGL(k_thin_in<false>, dim3(B * tpf), dim3(256), 0, (hipStream_t)stream, (const f32x4 *)x, (const f32x4 *)nullptr,
+                           (const f32x4 *)nullptr, w, y, H, W, Co, tiles_x, tpf);
+    PS_LAUNCH_CHECK();
+    return PS_OK;
+}
+
+int ps_conv3x3_thin_out_nhwc_f32(const float *x, const float *scale, const float *shift, const float *w, int B, int H, int W, int Ci,
+                                 int Co, float *y, void *stream)
+{
+    PS_REQUIRE(x && w && y, "conv3x3_thin_out: null pointer");
+    PS_REQUIRE((scale == nullptr) == (shift == nullptr), "conv3x3_thin_out: scale and shift come together");
+    PS_REQUIRE(B > 0 && H > 0 && W > 0 && H % TH == 0 && W % TW == 0 && Ci > 0 && Ci % 32 == 0 && Co >= 1 && Co <= 4,
+               "conv3x3_thin_out: H a multiple of 8, W of 32, Ci of 32 and 1 <= Co <= 4 required (H = %d, W = %d, Ci = %d, Co = %d)", H, W, Ci, Co);
+    const int tiles_x = W / TW, tpf = (H / TH) * tiles_x;
+    PS_REQUIRE((size_t)B * tpf < ((size_t)1 << 31), "conv3x3_thin_out: too many tiles");
+#define PS_THIN_OUT(CO)                                                                                                                  \
+    do {                                                                                                                                 \
+        if (scale)                                                                                                                       \
+            hipLaunchKernelGGL((k_thin_out<CO, true>), dim3(B * tpf), dim3(256), 0, (hipStream_t)stream, x, scale, shift, w, y, H, W, Ci, \
+                               tiles_x, tpf);                                                                                            \
+        else                                                                                                                             \
+            hipLaunchKernelGGL((k_thin_out<CO, false>), dim3(B * tpf), dim3(256), 0, (hipStream_t)stream, x, scale, shift, w, y, H, W, Ci, \
+                               tiles_x, tpf);                                                                                            \
+    } while (0)
+    switch (Co) {
+    case 1: PS_THIN_OUT(1); break;
+    case 2: PS_THIN_OUT(2); break;
+    case 3: PS_THIN_OUT(3); break;
+    default: PS_THIN_OUT(4); break;
+    }
+#undef PS_THIN_OUT
+    PS_LAUNCH_CHECK();
+    return PS_OK;
+}
+
+}  // extern "C"

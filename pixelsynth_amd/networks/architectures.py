@@ -104,7 +104,7 @@ class LinearNoiseLayer(nn.Module):
         if noise is None:
             noise = torch.randn(x.size(0), self.noise_sz).to(x.device)
         B = noise.size(0)
-        return self.bn.scale_shift((1 + self.gain(noise)).view(B, -1, 1, 1), self.bias(noise).view(B, -1, 1, 1))
+        return self.bn.scale_shift((1 + _sn_linear(self.gain, noise)).view(B, -1, 1, 1), _sn_linear(self.bias, noise).view(B, -1, 1, 1))
 
     def forward(self, x, noise=None):
         scale, shift = self.affine(x, noise)
@@ -162,9 +162,38 @@ def _plain_conv_weight(conv, x):
              and conv.padding_mode == "zeros" and all(isinstance(h, SpectralNorm) for h in pre))
     if not plain:
         return None
-    for hook in pre:
-        hook(conv, (x,))
-    return conv.weight
+    return _normalised_weight(conv, pre, x)
+
+
+def _normalised_weight(mod, pre, x):
+    """mod.weight as mod's spectral-norm pre-hooks leave it.  In eval mode the hook does no power iteration -- weight_orig / sigma with
+    sigma from the stored u, v is a constant of the checkpoint, yet torch recomputes it at every forward (a matrix-vector product, a
+    dot and a division: ~270 launches of a few microseconds per decoder pass, a tenth of its time once the convolutions are
+    fast).  Here it is computed once and kept until weight_orig / u / v change (their storage or version counters)."""
+    if not pre:
+        return mod.weight
+    if mod.training or torch.is_grad_enabled():
+        for hook in pre:
+            hook(mod, (x,))
+        return mod.weight
+    key = tuple((t.data_ptr(), t._version) for t in (mod.weight_orig, mod.weight_u, mod.weight_v))
+    cache = mod.__dict__.get("_ps_sn_cache")
+    if cache is None or cache[0] != key:
+        for hook in pre:
+            hook(mod, (x,))
+        cache = (key, mod.weight.detach())
+        mod.__dict__["_ps_sn_cache"] = cache
+    return cache[1]
+
+
+def _sn_linear(lin, x):
+    """lin(x) for the bias-free, possibly spectral-normalised Linear layers of LinearNoiseLayer, the normalised weight cached as above."""
+    from torch.nn.utils.spectral_norm import SpectralNorm
+    pre = list(lin._forward_pre_hooks.values())
+    if (type(lin) is not nn.Linear or lin.bias is not None or lin._forward_hooks or getattr(lin, "parametrizations", None)
+            or not all(isinstance(h, SpectralNorm) for h in pre)):
+        return lin(x)
+    return F.linear(x, _normalised_weight(lin, pre, x))
 
 
 _MIOPEN_SAFE_BYTES = 2 ** 31
@@ -225,6 +254,39 @@ def _f16x3_takes(conv, x):
             and not torch.is_grad_enabled())
 
 
+def _thin_conv(conv, x, scale=None, shift=None):
+    """conv(act(x)) WITHOUT the bias for the decoder's two thin 3 x 3 layers (4 -> Co, Ci -> <= 4 channels) through csrc/conv_thin.hip
+    (fp32 FMAs), or None when `conv` is not one of them."""
+    Ci, Co = conv.in_channels, conv.out_channels
+    thin_in, thin_out = Ci == 4 and Co % 4 == 0, Ci % 32 == 0 and 1 <= Co <= 4
+    if not (conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1
+            and (thin_in or thin_out) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+            and x.is_contiguous(memory_format=torch.channels_last) and x.size(2) % 8 == 0 and x.size(3) % 32 == 0
+            and not torch.is_grad_enabled()):
+        return None
+    weight = _plain_conv_weight(conv, x)
+    if weight is None:
+        return None
+    from .. import _lib
+    L = _lib.lib()
+    key = (weight.data_ptr(), weight._version, str(weight.device))
+    cache = conv.__dict__.get("_ps_thin_cache")
+    if cache is None or cache[0] != key:
+        cache = (key, weight.detach().permute(2, 3, 1, 0).contiguous(), weight)      # [ky][kx][ci][co]
+        conv.__dict__["_ps_thin_cache"] = cache
+    B, _, H, W = x.shape
+    y = torch.empty((B, Co, H, W), dtype=x.dtype, device=x.device).contiguous(memory_format=torch.channels_last)
+    if Co == 1:   # (channels_last of one channel is ambiguous to torch; the kernel writes (B, H, W, Co))
+        y = torch.empty((B, H, W, Co), dtype=x.dtype, device=x.device).permute(0, 3, 1, 2)
+    if thin_in:
+        _lib.check(L.ps_conv3x3_thin_in_nhwc_f32(x.data_ptr(), _ptr(scale), _ptr(shift), cache[1].data_ptr(), B, H, W, Co, y.data_ptr(),
+                                                 _stream()), "ps_conv3x3_thin_in_nhwc_f32")
+    else:
+        _lib.check(L.ps_conv3x3_thin_out_nhwc_f32(x.data_ptr(), _ptr(scale), _ptr(shift), cache[1].data_ptr(), B, H, W, Ci, Co,
+                                                  y.data_ptr(), _stream()), "ps_conv3x3_thin_out_nhwc_f32")
+    return y
+
+
 def _f16x3_conv(conv, x, scale=None, shift=None):
     """conv(act(x)) WITHOUT the bias through ps_conv3x3_f16x3_nhwc, act = max(x * scale - shift, 0) with scale / shift (B, C)
     contiguous, or the identity; None when the kernel does not take this convolution (the caller then goes through torch)."""
@@ -236,9 +298,15 @@ def _f16x3_conv(conv, x, scale=None, shift=None):
     from .. import _lib
     L = _lib.lib()
     Co, Ci = conv.out_channels, conv.in_channels
-    wl = weight.detach().permute(0, 2, 3, 1).contiguous()          # (Co, 3, 3, Ci): no copy for a channels_last weight
-    packed = torch.empty(L.ps_conv3x3_f16x3_packed_bytes(Co, Ci), dtype=torch.uint8, device=x.device)
-    _lib.check(L.ps_conv3x3_f16x3_pack(wl.data_ptr(), Co, Ci, packed.data_ptr(), _stream()), "ps_conv3x3_f16x3_pack")
+    key = (weight.data_ptr(), weight._version, str(weight.device))
+    cache = conv.__dict__.get("_ps_f16x3_cache")
+    if cache is None or cache[0] != key:     # packed once per weight (with spectral norm in eval mode: per checkpoint, see _normalised_weight)
+        wl = weight.detach().permute(0, 2, 3, 1).contiguous()          # (Co, 3, 3, Ci): no copy for a channels_last weight
+        packed = torch.empty(L.ps_conv3x3_f16x3_packed_bytes(Co, Ci), dtype=torch.uint8, device=x.device)
+        _lib.check(L.ps_conv3x3_f16x3_pack(wl.data_ptr(), Co, Ci, packed.data_ptr(), _stream()), "ps_conv3x3_f16x3_pack")
+        cache = (key, packed, weight)      # (the weight is kept alive: its address is the key)
+        conv.__dict__["_ps_f16x3_cache"] = cache
+    packed = cache[1]
     B, _, H, W = x.shape
     y = _empty_nhwc(B, Co, H, W, x)
     _lib.check(L.ps_conv3x3_f16x3_nhwc(x.data_ptr(), _ptr(scale), _ptr(shift), packed.data_ptr(), B, H, W, Ci, Co, y.data_ptr(),
@@ -297,12 +365,15 @@ class ResNet_Block(nn.Module):
             self.ch_b = _Slots(_0=_conv(opt, in_c, in_o, 1, 1, 0))
 
     @staticmethod
-    def _noise_affine(layer, x, noise, bias=None):
+    def _noise_affine(layer, x, noise, bias=None, affine=None):
         """norm + ReLU of (x + bias): y = max(x * scale[b][c] - shift[b][c], 0), a pending conv bias folded into shift --
         one HIP pass on the GPU (ps_affine_relu_nhwc_f32)."""
-        scale, shift = layer.affine(x, noise)
-        if bias is not None:
-            shift = shift - bias.view(1, -1, 1, 1) * scale
+        if affine is not None:   # (computed by the caller, bias already folded in; as (B, C) or broadcastable to (B, C, 1, 1))
+            scale, shift = (t.view(t.size(0), -1, 1, 1) if t.dim() == 2 else t for t in affine)
+        else:
+            scale, shift = layer.affine(x, noise)
+            if bias is not None:
+                shift = shift - bias.view(1, -1, 1, 1) * scale
         B, C = x.size(0), x.size(1)
         if _is_nhwc_cuda(x) and scale.numel() in (C, B * C) and not torch.is_grad_enabled():
             from .. import _lib
@@ -318,15 +389,17 @@ class ResNet_Block(nn.Module):
         """conv(relu(norm(x + bias))) as (output without the convolution's own bias, that bias).  The decoder's wide 3 x 3 layers:
         ONE kernel, norm + ReLU applied as the patch is staged (csrc/conv_f16x3.hip); the others: the affine pass, then torch."""
         mode = getattr(self.opt, "decoder_conv", None) or DECODER_CONV
-        if mode == "f16x3" and conv.bias is not None and _f16x3_takes(conv, x):
+        if mode == "f16x3" and conv.bias is not None and x.is_cuda and not torch.is_grad_enabled():
             scale, shift = layer.affine(x, noise)
             if bias is not None:
                 shift = shift - bias.view(1, -1, 1, 1) * scale
             B, C = x.size(0), x.size(1)
             if scale.numel() in (C, B * C):
-                y = _f16x3_conv(conv, x, scale.reshape(-1, C).expand(B, C).contiguous(), shift.reshape(-1, C).expand(B, C).contiguous())
+                scale, shift = scale.reshape(-1, C).expand(B, C).contiguous(), shift.reshape(-1, C).expand(B, C).contiguous()
+                y = _f16x3_conv(conv, x, scale, shift) if _f16x3_takes(conv, x) else _thin_conv(conv, x, scale, shift)
                 if y is not None:
                     return y, conv.bias
+            return _conv_split(conv, self._noise_affine(layer, x, None, None, affine=(scale, shift)))
         return _conv_split(conv, self._noise_affine(layer, x, noise, bias))
 
     def forward(self, x, noise=(None, None)):

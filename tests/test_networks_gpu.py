@@ -162,7 +162,7 @@ def test_decoder_with_split_fp16_convolutions_equals_the_fp32_decoder(monkeypatc
     monkeypatch.setattr(A, "_f16x3_conv", lambda *a, **k: (calls.append(a[0].in_channels), real(*a, **k))[1])
     with torch.no_grad():
         got = dec(x, bgm, noise=noise)
-        assert len(calls) == 13 and A.DECODER_CONV == "f16x3"        # every 3 x 3 layer with Ci % 32 == 0 and Co % 64 == 0
+        assert len(calls) == 13 and A.DECODER_CONV == "f16x3"        # every 3 x 3 layer with Ci % 32 == 0 and Co % 64 == 0 (4 -> 64 and 128 -> 3: conv_thin)
         A.check_f16x3_overflow(x.device)
         monkeypatch.setattr(A, "DECODER_CONV", "fp32")
         del calls[:]
@@ -222,3 +222,30 @@ def test_convolutions_through_torch_are_cut_below_2_gib_per_call(monkeypatch):
     monkeypatch.setattr(A, "_MIOPEN_SAFE_BYTES", 2 * 8 * 16 * 16 * 4 + 1)
     out = real(lambda u: u * 2, t, 8)
     assert out.is_contiguous(memory_format=torch.channels_last) and torch.equal(out, t * 2)
+
+
+@pytest.mark.parametrize("B,H,W,Ci,Co,fuse", [(2, 16, 32, 4, 64, True), (3, 8, 64, 4, 8, False), (2, 16, 32, 128, 3, True), (1, 24, 96, 32, 4, False),
+                                               (5, 8, 32, 64, 1, True)])
+def test_thin_convolutions_against_an_fp64_convolution(B, H, W, Ci, Co, fuse):
+    """csrc/conv_thin.hip: the decoder's 4 -> 64 and 128 -> 3 layers (and their neighbours in shape) as fp32 FMA passes, norm + ReLU
+    on the way in, against torch's convolution in fp64: within 2e-6 of the output's largest magnitude (fp32 summation noise)."""
+    from pixelsynth_amd import _lib
+    L, st = _lib.lib(), torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(3 * Ci + Co)
+    x = torch.randn(B, Ci, H, W, generator=g).to(DEV)
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) / (3 * Ci ** 0.5)).to(DEV)
+    sc = (torch.rand(B, Ci, generator=g) + 0.5).to(DEV) if fuse else None
+    sh = (torch.randn(B, Ci, generator=g) * 0.3).to(DEV) if fuse else None
+    xa = torch.clamp_min(x * sc.view(B, Ci, 1, 1) - sh.view(B, Ci, 1, 1), 0) if fuse else x
+    ref = torch.nn.functional.conv2d(xa.double(), w.double(), None, 1, 1)
+    xl, wl = x.permute(0, 2, 3, 1).contiguous(), w.permute(2, 3, 1, 0).contiguous()
+    y = torch.empty(B, H, W, Co, device=DEV)
+    p = lambda t: None if t is None else t.data_ptr()
+    if Ci == 4:
+        _lib.check(L.ps_conv3x3_thin_in_nhwc_f32(xl.data_ptr(), p(sc), p(sh), wl.data_ptr(), B, H, W, Co, y.data_ptr(), st), "thin_in")
+    else:
+        _lib.check(L.ps_conv3x3_thin_out_nhwc_f32(xl.data_ptr(), p(sc), p(sh), wl.data_ptr(), B, H, W, Ci, Co, y.data_ptr(), st), "thin_out")
+    err = (y.permute(0, 3, 1, 2).double() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 2e-6, err
+    assert L.ps_conv3x3_thin_out_nhwc_f32(xl.data_ptr(), None, None, wl.data_ptr(), B, H, W, 32, 5, y.data_ptr(), st) != 0
+    assert L.ps_conv3x3_thin_in_nhwc_f32(xl.data_ptr(), None, None, wl.data_ptr(), B, 12, W, 8, y.data_ptr(), st) != 0

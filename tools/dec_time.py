@@ -1,4 +1,4 @@
-"""The refinement decoder on V views (default 16): PS_DECODER_CONV=f16x3 against fp32 (MIOpen).  usage: python tools/dec_time.py [V]"""
+"""The refinement decoder on V views (default 16): PS_DECODER_CONV=f16x3 against fp32 (MIOpen).  usage: python tools/dec_time.py [V [mode ...]]"""
 import sys, time
 import torch
 sys.path.insert(0, ".")
@@ -21,9 +21,10 @@ def t(fn, n=10):
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
 with torch.no_grad():
     out = {}
-    for mode in ("fp32", "f16x3"):
+    for mode in (sys.argv[2:] or ("fp32", "f16x3")):
         A.DECODER_CONV = mode
         out[mode] = dec(x, bg, noise=noise)
         print(f"{mode}: {t(lambda: dec(x, bg, noise=noise)):.2f} ms per {V} views", flush=True)
     A.check_f16x3_overflow(dev)
-    print("max |difference| of the two images:", (out["fp32"] - out["f16x3"]).abs().max().item())
+    if len(out) == 2:
+        print("max |difference| of the two images:", (out["fp32"] - out["f16x3"]).abs().max().item())
