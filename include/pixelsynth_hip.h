@@ -333,6 +333,14 @@ int ps_upsample_add_nhwc_f32(const float *a, const float *b, const float *bias, 
 int ps_add_bias_nhwc_f32(const float *a, const float *b, const float *bias, int B, int HW, int C, float *out,
                          void *stream);
 
+/* ps_noise_affine_f32: the per-(sample, channel) affine of LinearNoiseLayer + stored-statistics batch norm
+ * (models/layers/normalization.py:21-47, :170-184): scale[b][c] = rsqrt(var[c] + eps) * (1 + <noise[b], Wg[c]>),
+ * shift[b][c] = mean[c] * scale[b][c] - <noise[b], Wb[c]> - pend[c] * scale[b][c].  noise (B, K); Wg, Wb (C, K): the (spectral-
+ * normalised) weights of the layer's gain / bias Linear; mean, var (C); pend (C) or NULL: a convolution bias still missing from
+ * the tensor to be normalised.  scale, shift (B, C): what ps_affine_relu_nhwc_f32 and the fused convolutions take. */
+int ps_noise_affine_f32(const float *noise, const float *wg, const float *wb, const float *mean, const float *var, const float *pend,
+                        float eps, int B, int C, int K, float *scale, float *shift, void *stream);
+
 /* ---- 3 x 3 convolutions of the refinement decoder on the fp16 matrix pipe (csrc/conv_f16x3.hip) ------------------------------
  * Replaces, for the decoder's wide layers, torch.nn.Conv2d(Ci, Co, 3, 1, 1) as ResNet_Block calls it (models/layers/blocks.py:34-73,
  * models/networks/architectures.py:126-167), WITHOUT the bias (the caller folds it into the next pass, as for the MIOpen path).

@@ -9,6 +9,7 @@
 //   ps_pool_add_nhwc_f32         out = avg_pool2d(a, 3, 2, 1) + avg_pool2d(b, 3, 2, 1)       (count_include_pad, as torch's default)
 //   ps_upsample_add_nhwc_f32     out = bilinear_x2(a) + bilinear_x2(b)                       (align_corners = False)
 //   ps_add_bias_nhwc_f32         out = a + b + bias[c]
+//   ps_noise_affine_f32          the (B, C) scale / shift of a LinearNoiseLayer from its noise draw: one launch instead of eight
 // (b may be NULL: the resampled branch alone.)  The bias of a convolution is a pass of its own in torch; here the convolutions
 // run without it and the per-channel constant rides along in the pass that consumes their output: folded into `shift` of the
 // next norm (host), or the `bias` argument of the resampling / residual kernels.  The convolutions themselves stay on MIOpen: at 16 views they run at ~70 % of the
@@ -119,6 +120,29 @@ __global__ __launch_bounds__(256) void k_add_bias(const f32x4 *__restrict__ a, c
     }
 }
 
+// LinearNoiseLayer + stored-statistics batch norm as ONE (sample, channel) affine (normalization.py:21-47, :170-184):
+//   scale[b][c] = rsqrt(var[c] + eps) * (1 + <noise[b], Wg[c]>),   shift[b][c] = mean[c] * scale[b][c] - <noise[b], Wb[c]> - pend[c] * scale[b][c]
+// noise (B, K), Wg / Wb (C, K); pend: the bias of the convolution in front, not yet added to the normalised tensor (may be null).
+__global__ __launch_bounds__(256) void k_noise_affine(const float *__restrict__ noise, const float *__restrict__ wg, const float *__restrict__ wb,
+                                                      const float *__restrict__ mean, const float *__restrict__ var, const float *__restrict__ pend,
+                                                      float eps, int B, int C, int K, float *__restrict__ scale, float *__restrict__ shift)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * C) return;
+    const int b = i / C, c = i - b * C;
+    float g = 0.f, h = 0.f;
+    for (int k = 0; k < K; ++k) {
+        const float n = noise[b * K + k];
+        g = __builtin_fmaf(n, wg[c * K + k], g);
+        h = __builtin_fmaf(n, wb[c * K + k], h);
+    }
+    const float sc = (1.0f / __builtin_sqrtf(var[c] + eps)) * (1.0f + g);
+    float sh = mean[c] * sc - h;
+    if (pend) sh -= pend[c] * sc;
+    scale[i] = sc;
+    shift[i] = sh;
+}
+
 unsigned grid_for(size_t total4) { return (unsigned)std::min<size_t>((total4 + 255) / 256, 256 * 32); }
 
 }  // namespace
@@ -166,6 +190,17 @@ int ps_add_bias_nhwc_f32(const float *a, const float *b, const float *bias, int 
     const size_t total4 = (size_t)B * HW * (C / 4);
     hipLaunchKernelGGL(k_add_bias, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, (const f32x4 *)a, (const f32x4 *)b,
                        (const f32x4 *)bias, C / 4, total4, (f32x4 *)out);
+    PS_LAUNCH_CHECK();
+    return PS_OK;
+}
+
+int ps_noise_affine_f32(const float *noise, const float *wg, const float *wb, const float *mean, const float *var, const float *pend,
+                        float eps, int B, int C, int K, float *scale, float *shift, void *stream)
+{
+    PS_REQUIRE(noise && wg && wb && mean && var && scale && shift, "noise_affine: null pointer");
+    PS_REQUIRE(B > 0 && C > 0 && K > 0, "noise_affine: B, C, K > 0 required");
+    hipLaunchKernelGGL(k_noise_affine, dim3((B * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, noise, wg, wb, mean, var, pend, eps, B, C, K,
+                       scale, shift);
     PS_LAUNCH_CHECK();
     return PS_OK;
 }

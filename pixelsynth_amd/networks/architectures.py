@@ -106,6 +106,38 @@ class LinearNoiseLayer(nn.Module):
         B = noise.size(0)
         return self.bn.scale_shift((1 + _sn_linear(self.gain, noise)).view(B, -1, 1, 1), _sn_linear(self.bias, noise).view(B, -1, 1, 1))
 
+    def affine_bc(self, x, noise=None, pend=None):
+        """affine() as contiguous (B, C) scale / shift -- what the HIP passes take -- with `pend` (C), a convolution bias still missing
+        from x, folded into shift.  On the inference GPU path ONE launch (ps_noise_affine_f32) instead of two matrix products and six
+        elementwise kernels; elsewhere composed from affine()."""
+        if noise is None:
+            noise = torch.randn(x.size(0), self.noise_sz).to(x.device)
+        B, C = noise.size(0), self.bn.stored_mean.numel()
+        if (x.is_cuda and not torch.is_grad_enabled() and not self.training and not self.bn.accumulate_standing and B == x.size(0)
+                and noise.dtype == torch.float32 and all(type(m) is nn.Linear and m.bias is None for m in (self.gain, self.bias))):
+            from torch.nn.utils.spectral_norm import SpectralNorm
+            ws = []
+            for lin in (self.gain, self.bias):
+                pre = list(lin._forward_pre_hooks.values())
+                if lin._forward_hooks or getattr(lin, "parametrizations", None) or not all(isinstance(h, SpectralNorm) for h in pre):
+                    ws = None
+                    break
+                ws.append(_normalised_weight(lin, pre, noise).contiguous())
+            if ws is not None:
+                from .. import _lib
+                noise = noise.contiguous()
+                scale = torch.empty(B, C, dtype=torch.float32, device=x.device)
+                shift = torch.empty_like(scale)
+                _lib.check(_lib.lib().ps_noise_affine_f32(noise.data_ptr(), ws[0].data_ptr(), ws[1].data_ptr(), self.bn.stored_mean.data_ptr(),
+                                                          self.bn.stored_var.data_ptr(), _ptr(pend), float(self.bn.eps), B, C, noise.size(1),
+                                                          scale.data_ptr(), shift.data_ptr(), _stream()), "ps_noise_affine_f32")
+                return scale, shift
+        scale, shift = self.affine(x, noise)
+        if pend is not None:
+            shift = shift - pend.view(1, -1, 1, 1) * scale
+        Bx = x.size(0)
+        return scale.reshape(-1, C).expand(Bx, C).contiguous(), shift.reshape(-1, C).expand(Bx, C).contiguous()
+
     def forward(self, x, noise=None):
         scale, shift = self.affine(x, noise)
         return x * scale - shift
@@ -368,7 +400,9 @@ class ResNet_Block(nn.Module):
     def _noise_affine(layer, x, noise, bias=None, affine=None):
         """norm + ReLU of (x + bias): y = max(x * scale[b][c] - shift[b][c], 0), a pending conv bias folded into shift --
         one HIP pass on the GPU (ps_affine_relu_nhwc_f32)."""
-        if affine is not None:   # (computed by the caller, bias already folded in; as (B, C) or broadcastable to (B, C, 1, 1))
+        if affine is None and _is_nhwc_cuda(x) and not torch.is_grad_enabled() and hasattr(layer, "affine_bc"):
+            affine = layer.affine_bc(x, noise, bias)
+        if affine is not None:   # (bias already folded in; as (B, C) or broadcastable to (B, C, 1, 1))
             scale, shift = (t.view(t.size(0), -1, 1, 1) if t.dim() == 2 else t for t in affine)
         else:
             scale, shift = layer.affine(x, noise)
@@ -390,15 +424,10 @@ class ResNet_Block(nn.Module):
         ONE kernel, norm + ReLU applied as the patch is staged (csrc/conv_f16x3.hip); the others: the affine pass, then torch."""
         mode = getattr(self.opt, "decoder_conv", None) or DECODER_CONV
         if mode == "f16x3" and conv.bias is not None and x.is_cuda and not torch.is_grad_enabled():
-            scale, shift = layer.affine(x, noise)
-            if bias is not None:
-                shift = shift - bias.view(1, -1, 1, 1) * scale
-            B, C = x.size(0), x.size(1)
-            if scale.numel() in (C, B * C):
-                scale, shift = scale.reshape(-1, C).expand(B, C).contiguous(), shift.reshape(-1, C).expand(B, C).contiguous()
-                y = _f16x3_conv(conv, x, scale, shift) if _f16x3_takes(conv, x) else _thin_conv(conv, x, scale, shift)
-                if y is not None:
-                    return y, conv.bias
+            scale, shift = layer.affine_bc(x, noise, bias)
+            y = _f16x3_conv(conv, x, scale, shift) if _f16x3_takes(conv, x) else _thin_conv(conv, x, scale, shift)
+            if y is not None:
+                return y, conv.bias
             return _conv_split(conv, self._noise_affine(layer, x, None, None, affine=(scale, shift)))
         return _conv_split(conv, self._noise_affine(layer, x, noise, bias))
 
@@ -431,6 +460,10 @@ class ResNetDecoder(nn.Module):
     def forward(self, x, background_mask=None, noise=None):
         h = x if background_mask is None else torch.cat((x, (~background_mask).unsqueeze(1).float()), 1)
         h = _nhwc(self, h)
+        if noise is None and h.is_cuda:
+            # the reference draws each layer's noise on the host and sends it over (normalization.py:36-37): sixteen small blocking
+            # copies per pass.  The same sixteen draws, in the same order from the same generator, in ONE copy.
+            noise = torch.stack([torch.randn(h.size(0), NOISE_SZ) for _ in range(self.n_noise())]).to(h.device).unbind(0)
         for i, blk in enumerate(self.eblocks):
             h = blk(h, (None, None) if noise is None else (noise[2 * i], noise[2 * i + 1]))
         if getattr(self.opt, "predict_residual", False):

@@ -249,3 +249,29 @@ def test_thin_convolutions_against_an_fp64_convolution(B, H, W, Ci, Co, fuse):
     assert err < 2e-6, err
     assert L.ps_conv3x3_thin_out_nhwc_f32(xl.data_ptr(), None, None, wl.data_ptr(), B, H, W, 32, 5, y.data_ptr(), st) != 0
     assert L.ps_conv3x3_thin_in_nhwc_f32(xl.data_ptr(), None, None, wl.data_ptr(), B, 12, W, 8, y.data_ptr(), st) != 0
+
+
+def test_noise_affine_in_one_launch_equals_the_composed_form():
+    """ps_noise_affine_f32 (LinearNoiseLayer.affine_bc on the GPU): the (B, C) scale / shift of a noise-conditioned norm layer, a
+    pending convolution bias folded in, against affine() composed from torch ops on the CPU (normalization.py:21-47, :170-184)."""
+    from pixelsynth_amd.networks.architectures import LinearNoiseLayer
+    g = torch.Generator().manual_seed(5)
+    for C, B in ((64, 3), (4, 1), (256, 16)):
+        layer = LinearNoiseLayer(syn.network_opts(), output_sz=C).eval()
+        with torch.no_grad():
+            layer.bn.stored_mean.copy_(torch.randn(C, generator=g))
+            layer.bn.stored_var.copy_(torch.rand(C, generator=g) + 0.2)
+            for lin in (layer.gain, layer.bias):
+                lin.weight_orig.copy_(torch.randn(C, 20, generator=g) * 0.3)
+        noise, pend = torch.randn(B, 20, generator=g), torch.randn(C, generator=g)
+        x = torch.zeros(B, C, 8, 8)
+        with torch.no_grad():
+            sc, sh = layer.affine(x, noise)
+            want = sc.reshape(B, C), (sh - pend.view(1, -1, 1, 1) * sc).reshape(B, C)
+            layer = layer.to(DEV)
+            got = layer.affine_bc(x.to(DEV), noise.to(DEV), pend.to(DEV))
+            plain = layer.affine_bc(x.to(DEV), noise.to(DEV))
+        assert got[0].shape == (B, C) and got[0].is_contiguous()
+        np.testing.assert_allclose(got[0].cpu().numpy(), want[0].numpy(), rtol=2e-6, atol=2e-6)
+        np.testing.assert_allclose(got[1].cpu().numpy(), want[1].numpy(), rtol=2e-6, atol=4e-6)
+        np.testing.assert_allclose(plain[1].cpu().numpy(), sh.reshape(B, C).numpy(), rtol=2e-6, atol=4e-6)
