@@ -5,10 +5,14 @@
 Same constructor arguments, attribute / parameter names and shapes as the reference, so its checkpoints load with
 `load_state_dict(strict=True)`; the bodies are written for inference on one MI355X:
 
-  * the convolutions run through torch (MIOpen) for now -- "Torch/MIOpen first" in SURVEY 8f -- in NHWC
-    (channels_last) on the GPU: measured on 16 views, 3.3 ms instead of 12.6 ms for the Unet and 27 ms instead of
-    31 ms for the decoder (MIOpen's NHWC implicit-GEMM / CK kernels, no layout shuffles between layers); inputs are
-    converted on entry, results handed back NCHW-contiguous because the HIP kernels downstream take raw NCHW pointers;
+  * NHWC (channels_last) on the GPU; inputs are converted on entry, results handed back NCHW-contiguous because the HIP kernels
+    downstream take raw NCHW pointers;
+  * the DECODER's 3 x 3 convolutions are hand-written (csrc/conv_f16x3.hip: split-fp16 MFMA, fp32 in / out, the norm + ReLU in
+    front of them applied as the input is staged; csrc/conv_thin.hip for the 4 -> 64 and 128 -> 3 layers): 8.3 instead of 20 ms
+    per 16 views.  PS_DECODER_CONV=fp32 / opt.decoder_conv = "fp32" sends them through torch.  The Unet's convolutions, the
+    decoder's 1 x 1 and 3 -> 3 layers run through torch (MIOpen), the batch cut so that no call sees 2 GiB (MIOpen's fp32 NHWC
+    kernels are silently wrong on 4 GiB activations -- 128 views of the decoder's widest layer);
+  * spectral-normalised weights are computed once per checkpoint in eval mode, not at every forward (_normalised_weight);
   * `LinearNoiseLayer` + stored-statistics batch norm + ReLU is ONE per-(sample, channel) affine and a clamp
     (`_noise_affine`), not four elementwise passes;
   * `ResNetDecoder.forward(..., noise=)` takes the noise draws explicitly (a list of (B,20) tensors, two per block) so
