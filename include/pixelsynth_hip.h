@@ -353,12 +353,14 @@ int ps_noise_affine_f32(const float *noise, const float *wg, const float *wb, co
  * ps_conv3x3_f16x3_nhwc: y (B, H, W, Co) = conv3x3(act(x), w), zero padding 1, stride 1; x (B, H, W, Ci); H, W multiples of 16.
  *   scale, shift: (B, Ci) or both NULL: act(x) = max(x * scale[b][c] - shift[b][c], 0) -- the LinearNoiseLayer + ReLU in front of the
  *   convolution (models/layers/normalization.py:21-47), applied on the way in; NULL: act(x) = x.
+ *   bias (Co) and res (B, H, W, Co), each may be NULL, are added to the results on the way out: y = conv + bias + res -- the sum a
+ *   ResNet_Block forms of its two branches (blocks.py:61-73), without a pass of its own.
  *   overflow: device int the kernel sets to 1 when an activation lies beyond fp16's range (|v| > 65000) or is not a number;
  *   never cleared by the library. */
 size_t ps_conv3x3_f16x3_packed_bytes(int Co, int Ci);
 int ps_conv3x3_f16x3_pack(const float *w, int Co, int Ci, void *packed, void *stream);
-int ps_conv3x3_f16x3_nhwc(const float *x, const float *scale, const float *shift, const void *packed, int B, int H, int W,
-                          int Ci, int Co, float *y, int *overflow, void *stream);
+int ps_conv3x3_f16x3_nhwc(const float *x, const float *scale, const float *shift, const void *packed, const float *bias,
+                          const float *res, int B, int H, int W, int Ci, int Co, float *y, int *overflow, void *stream);
 
 /* ---- the decoder's two thin 3 x 3 convolutions (csrc/conv_thin.hip), fp32 FMAs, same contract as above (no bias; optional
  * act(x) = max(x * scale[b][c] - shift[b][c], 0) on the way in; zero padding 1, stride 1; NHWC):

@@ -82,6 +82,8 @@ struct ConvArgs {
     const float *shift;
     const char *wp;        // packed weights
     float *y;              // (B, H, W, Co)
+    const float *bias;     // (Co) or null: added to the results
+    const float *res;      // (B, H, W, Co) or null: added to the results (the block's other branch)
     int *overflow;
     int H, W, Ci, Co, tiles_x, tiles_per_frame, ncb, nblocks;
 };
@@ -197,18 +199,41 @@ template <bool FUSE> __global__ __launch_bounds__(NT) void k_conv3x3_f16x3(ConvA
     // D[row][col]: col = lane & 31 = channel, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) = pixel of the M tile
     auto store = [&](const Item &it) {
         const int co = it.cb * COT + chh * 64 + m;
-        float *yb = a.y + ((size_t)it.b * H * W) * a.Co + co;
+        const size_t base = ((size_t)it.b * H * W) * a.Co + co;
+        float *yb = a.y + base;
         const bool ok0 = co < a.Co, ok1 = co + 32 < a.Co;   // (Co = 64: the block's upper half is padding)
+        float b0 = 0.f, b1 = 0.f;
+        if (a.bias) {
+            if (ok0) b0 = a.bias[co];
+            if (ok1) b1 = a.bias[co + 32];
+        }
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < 2; ++mt) {
+            // all of an M tile's residual values first, then its stores: load / store pairs one by one would each wait for the store in
+            // front of them (one counter, in order) -- 20 us per item instead of 2
+            float rv[16][2];
+            if (a.res) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * kb;
+                    const int oy = it.ty0 + 4 * pg + 2 * mt + (row >> 4), ox = it.tx0 + (row & 15);
+                    const float *rp = a.res + base + ((size_t)oy * W + ox) * a.Co;
+                    rv[r][0] = ok0 ? rp[0] : 0.f;
+                    rv[r][1] = ok1 ? rp[32] : 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rv[r][0] = rv[r][1] = 0.f;
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * kb;
                 const int oy = it.ty0 + 4 * pg + 2 * mt + (row >> 4), ox = it.tx0 + (row & 15);
-                float *yp = yb + ((size_t)oy * W + ox) * a.Co;
-                if (ok0) yp[0] = acc[mt][0][r];
-                if (ok1) yp[32] = acc[mt][1][r];
+                const size_t off = ((size_t)oy * W + ox) * a.Co;
+                if (ok0) yb[off] = acc[mt][0][r] + b0 + rv[r][0];
+                if (ok1) yb[off + 32] = acc[mt][1][r] + b1 + rv[r][1];
             }
+        }
     };
 
     // The MFMA steps (tap, 16-channel half) run as a software pipeline: while a step's twelve MFMAs execute, the wave reads the NEXT
@@ -371,8 +396,8 @@ int ps_conv3x3_f16x3_pack(const float *w, int Co, int Ci, void *packed, void *st
     return PS_OK;
 }
 
-int ps_conv3x3_f16x3_nhwc(const float *x, const float *scale, const float *shift, const void *packed, int B, int H, int W, int Ci, int Co,
-                          float *y, int *overflow, void *stream)
+int ps_conv3x3_f16x3_nhwc(const float *x, const float *scale, const float *shift, const void *packed, const float *bias, const float *res,
+                          int B, int H, int W, int Ci, int Co, float *y, int *overflow, void *stream)
 {
     using namespace psconv;
     PS_REQUIRE(x && packed && y && overflow, "conv3x3_f16x3: null pointer");
@@ -382,7 +407,7 @@ int ps_conv3x3_f16x3_nhwc(const float *x, const float *scale, const float *shift
                "conv3x3_f16x3: Co a multiple of 64 and Ci a multiple of 32 required (Co = %d, Ci = %d)", Co, Ci);
     PS_REQUIRE((size_t)H * W * Ci < ((size_t)1 << 31), "conv3x3_f16x3: a frame of %d x %d x %d does not fit 32-bit offsets", H, W, Ci);
     ConvArgs a;
-    a.x = x; a.scale = scale; a.shift = shift; a.wp = (const char *)packed; a.y = y; a.overflow = overflow;
+    a.x = x; a.scale = scale; a.shift = shift; a.wp = (const char *)packed; a.y = y; a.bias = bias; a.res = res; a.overflow = overflow;
     a.H = H; a.W = W; a.Ci = Ci; a.Co = Co;
     a.tiles_x = W / TW; a.tiles_per_frame = (H / TH) * a.tiles_x; a.ncb = (Co + COT - 1) / COT;
     const size_t nb = (size_t)B * a.tiles_per_frame * a.ncb;

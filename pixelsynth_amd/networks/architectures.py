@@ -323,9 +323,10 @@ def _thin_conv(conv, x, scale=None, shift=None):
     return y
 
 
-def _f16x3_conv(conv, x, scale=None, shift=None):
-    """conv(act(x)) WITHOUT the bias through ps_conv3x3_f16x3_nhwc, act = max(x * scale - shift, 0) with scale / shift (B, C)
-    contiguous, or the identity; None when the kernel does not take this convolution (the caller then goes through torch)."""
+def _f16x3_conv(conv, x, scale=None, shift=None, bias=None, res=None):
+    """conv(act(x)) WITHOUT the convolution's own bias through ps_conv3x3_f16x3_nhwc, act = max(x * scale - shift, 0) with scale /
+    shift (B, C) contiguous, or the identity; `bias` (Co) and `res` (an NHWC tensor of the output's shape) are added on the way out.
+    None when the kernel does not take this convolution (the caller then goes through torch)."""
     if not _f16x3_takes(conv, x):
         return None
     weight = _plain_conv_weight(conv, x)
@@ -345,8 +346,10 @@ def _f16x3_conv(conv, x, scale=None, shift=None):
     packed = cache[1]
     B, _, H, W = x.shape
     y = _empty_nhwc(B, Co, H, W, x)
-    _lib.check(L.ps_conv3x3_f16x3_nhwc(x.data_ptr(), _ptr(scale), _ptr(shift), packed.data_ptr(), B, H, W, Ci, Co, y.data_ptr(),
-                                       _overflow_flag(x.device).data_ptr(), _stream()), "ps_conv3x3_f16x3_nhwc")
+    if res is not None and not (_is_nhwc_cuda(res) and res.shape == y.shape):
+        return None
+    _lib.check(L.ps_conv3x3_f16x3_nhwc(x.data_ptr(), _ptr(scale), _ptr(shift), packed.data_ptr(), _ptr(bias), _ptr(res), B, H, W, Ci, Co,
+                                       y.data_ptr(), _overflow_flag(x.device).data_ptr(), _stream()), "ps_conv3x3_f16x3_nhwc")
     return y
 
 
@@ -357,12 +360,14 @@ def _sum_bias(*bs):
 
 def _resample_sum(kind, a, b, bias=None):
     """_resample(kind, a + bias) + _resample(kind, b) -- blocks.py:61-73 -- as ONE pass through csrc/nets.hip on the GPU
-    (`bias`: per-channel constant still missing from the inputs, see _conv_split)."""
+    (`bias`: per-channel constant still missing from the inputs, see _conv_split).  b = None: a alone -- resampling is linear, so
+    a caller that already holds the SUM of the two branches resamples once."""
     from .. import _lib
-    if not _is_nhwc_cuda(a, b) or a.shape != b.shape or (kind and kind != "Up" and (a.size(2) % 2 or a.size(3) % 2)):
+    if (not (_is_nhwc_cuda(a) if b is None else _is_nhwc_cuda(a, b)) or (b is not None and a.shape != b.shape)
+            or (kind and kind != "Up" and (a.size(2) % 2 or a.size(3) % 2)) or (b is None and not kind)):
         if bias is not None:
             a = a + bias.view(1, -1, 1, 1)
-        return _resample(kind, a) + _resample(kind, b)
+        return _resample(kind, a) if b is None else _resample(kind, a) + _resample(kind, b)
     B, C, H, W = a.shape
     if not kind:
         out = torch.empty_like(a)
@@ -370,11 +375,11 @@ def _resample_sum(kind, a, b, bias=None):
                    "ps_add_bias_nhwc_f32")
     elif kind == "Up":
         out = _empty_nhwc(B, C, 2 * H, 2 * W, a)
-        _lib.check(_lib.lib().ps_upsample_add_nhwc_f32(a.data_ptr(), b.data_ptr(), _ptr(bias), B, H, W, C, out.data_ptr(), _stream()),
+        _lib.check(_lib.lib().ps_upsample_add_nhwc_f32(a.data_ptr(), _ptr(b), _ptr(bias), B, H, W, C, out.data_ptr(), _stream()),
                    "ps_upsample_add_nhwc_f32")
     else:
         out = _empty_nhwc(B, C, H // 2, W // 2, a)
-        _lib.check(_lib.lib().ps_pool_add_nhwc_f32(a.data_ptr(), b.data_ptr(), _ptr(bias), B, H, W, C, out.data_ptr(), _stream()),
+        _lib.check(_lib.lib().ps_pool_add_nhwc_f32(a.data_ptr(), _ptr(b), _ptr(bias), B, H, W, C, out.data_ptr(), _stream()),
                    "ps_pool_add_nhwc_f32")
     return out
 
@@ -423,25 +428,38 @@ class ResNet_Block(nn.Module):
             return y
         return torch.clamp_min(torch.addcmul(-shift, x, scale), 0)
 
-    def _norm_relu_conv(self, layer, conv, x, noise, bias=None):
-        """conv(relu(norm(x + bias))) as (output without the convolution's own bias, that bias).  The decoder's wide 3 x 3 layers:
-        ONE kernel, norm + ReLU applied as the patch is staged (csrc/conv_f16x3.hip); the others: the affine pass, then torch."""
+    def _norm_relu_conv(self, layer, conv, x, noise, bias=None, res=None, out_bias=None):
+        """conv(relu(norm(x + bias))) as (output without the convolution's own bias, that bias, fused).  The decoder's 3 x 3 layers:
+        ONE kernel, norm + ReLU applied as the patch is staged (csrc/conv_f16x3.hip, conv_thin.hip); the others: the affine pass, then
+        torch.  res / out_bias: the block's other branch and the biases still pending, which the split-fp16 kernel adds on its way out
+        (`fused` says whether it did: the output is then conv + res + out_bias)."""
         mode = getattr(self.opt, "decoder_conv", None) or DECODER_CONV
         if mode == "f16x3" and conv.bias is not None and x.is_cuda and not torch.is_grad_enabled():
             scale, shift = layer.affine_bc(x, noise, bias)
-            y = _f16x3_conv(conv, x, scale, shift) if _f16x3_takes(conv, x) else _thin_conv(conv, x, scale, shift)
+            if _f16x3_takes(conv, x):
+                y = _f16x3_conv(conv, x, scale, shift, out_bias, res)
+                if y is not None:
+                    return y, conv.bias, res is not None or out_bias is not None
+                y = _f16x3_conv(conv, x, scale, shift)
+            else:
+                y = _thin_conv(conv, x, scale, shift)
             if y is not None:
-                return y, conv.bias
-            return _conv_split(conv, self._noise_affine(layer, x, None, None, affine=(scale, shift)))
-        return _conv_split(conv, self._noise_affine(layer, x, noise, bias))
+                return y, conv.bias, False
+            return _conv_split(conv, self._noise_affine(layer, x, None, None, affine=(scale, shift))) + (False,)
+        return _conv_split(conv, self._noise_affine(layer, x, noise, bias)) + (False,)
 
     def forward(self, x, noise=(None, None)):
-        a, ba = self._norm_relu_conv(self.ch_a[0], self.ch_a[2], x, noise[0])
-        a, ba = self._norm_relu_conv(self.ch_a[3], self.ch_a[5], a, noise[1], ba)
-        if not self.projected:
-            return _resample_sum(None, a, x, ba)
-        b, bb = _conv_split(self.ch_b[0], x)
-        return _resample_sum(self.resample, a, b, _sum_bias(ba, bb))
+        a, ba, _ = self._norm_relu_conv(self.ch_a[0], self.ch_a[2], x, noise[0])
+        b, bb = _conv_split(self.ch_b[0], x) if self.projected else (x, None)
+        # The second convolution adds the other branch on its way out where it can (resampling is linear: resample(a) + resample(b) =
+        # resample(a + b)); without resampling the biases go in as well and its output is the block's.
+        conv2 = self.ch_a[5]
+        own = conv2.bias if conv2.bias is not None and not self.resample else None
+        a, ba2, fused = self._norm_relu_conv(self.ch_a[3], conv2, a, noise[1], ba, res=b,
+                                             out_bias=None if self.resample else _sum_bias(own, bb))
+        if fused:
+            return a if not self.resample else _resample_sum(self.resample, a, None, _sum_bias(ba2, bb))
+        return _resample_sum(self.resample if self.projected else None, a, b, _sum_bias(ba2, bb))
 
 
 class ResNetDecoder(nn.Module):

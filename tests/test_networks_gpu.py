@@ -99,7 +99,7 @@ def _f16x3(x_nchw, w, scale=None, shift=None):
     y = torch.empty(B, H, W, Co, device=DEV)
     flag = torch.zeros(1, dtype=torch.int32, device=DEV)
     _lib.check(L.ps_conv3x3_f16x3_nhwc(xl.data_ptr(), None if scale is None else scale.data_ptr(), None if shift is None else shift.data_ptr(),
-                                       packed.data_ptr(), B, H, W, Ci, Co, y.data_ptr(), flag.data_ptr(), st), "conv")
+                                       packed.data_ptr(), None, None, B, H, W, Ci, Co, y.data_ptr(), flag.data_ptr(), st), "conv")
     return y.permute(0, 3, 1, 2), flag
 
 
@@ -143,7 +143,7 @@ def test_conv3x3_on_the_fp16_pipe_flags_what_fp16_cannot_hold_and_rejects_what_i
     buf = torch.empty(1 << 20, dtype=torch.uint8, device=DEV)
     for Co, Ci, H in ((96, 32, 16), (128, 24, 16), (128, 32, 24)):
         rc = (L.ps_conv3x3_f16x3_pack(buf.data_ptr(), Co, Ci, buf.data_ptr(), st) if H == 16 else
-              L.ps_conv3x3_f16x3_nhwc(buf.data_ptr(), None, None, buf.data_ptr(), 1, H, H, Ci, Co, buf.data_ptr(), buf.data_ptr(), st))
+              L.ps_conv3x3_f16x3_nhwc(buf.data_ptr(), None, None, buf.data_ptr(), None, None, 1, H, H, Ci, Co, buf.data_ptr(), buf.data_ptr(), st))
         assert rc != 0 and b"multiple" in L.ps_last_error()
 
 
@@ -272,6 +272,6 @@ def test_noise_affine_in_one_launch_equals_the_composed_form():
             got = layer.affine_bc(x.to(DEV), noise.to(DEV), pend.to(DEV))
             plain = layer.affine_bc(x.to(DEV), noise.to(DEV))
         assert got[0].shape == (B, C) and got[0].is_contiguous()
-        np.testing.assert_allclose(got[0].cpu().numpy(), want[0].numpy(), rtol=2e-6, atol=2e-6)
-        np.testing.assert_allclose(got[1].cpu().numpy(), want[1].numpy(), rtol=2e-6, atol=4e-6)
-        np.testing.assert_allclose(plain[1].cpu().numpy(), sh.reshape(B, C).numpy(), rtol=2e-6, atol=4e-6)
+        np.testing.assert_allclose(got[0].cpu().numpy(), want[0].numpy(), rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(got[1].cpu().numpy(), want[1].numpy(), rtol=1e-5, atol=2e-5)
+        np.testing.assert_allclose(plain[1].cpu().numpy(), sh.reshape(B, C).numpy(), rtol=1e-5, atol=2e-5)

@@ -11,7 +11,7 @@ for (V, H, Ci, Co) in [(16, 256, 128, 128), (64, 256, 128, 128), (128, 256, 128,
     wp = torch.empty(L.ps_conv3x3_f16x3_packed_bytes(Co, Ci), dtype=torch.uint8, device=dev)
     _lib.check(L.ps_conv3x3_f16x3_pack(wl.data_ptr(), Co, Ci, wp.data_ptr(), st()), "pack")
     y = torch.empty(V, H, H, Co, device=dev)
-    _lib.check(L.ps_conv3x3_f16x3_nhwc(x.data_ptr(), None, None, wp.data_ptr(), V, H, H, Ci, Co, y.data_ptr(), flag.data_ptr(), st()), "conv")
+    _lib.check(L.ps_conv3x3_f16x3_nhwc(x.data_ptr(), None, None, wp.data_ptr(), None, None, V, H, H, Ci, Co, y.data_ptr(), flag.data_ptr(), st()), "conv")
     y32 = F.conv2d(x.permute(0, 3, 1, 2), w.contiguous(memory_format=torch.channels_last), None, 1, 1)
     worst16 = worst32 = 0.0
     bad = []

@@ -24,7 +24,7 @@ def conv(x_nhwc, wp, Co, scale=None, shift=None):   # x (B, H, W, Ci) contiguous
     B, H, W, Ci = x_nhwc.shape
     y = torch.empty(B, H, W, Co, dtype=torch.float32, device=dev)
     _lib.check(L.ps_conv3x3_f16x3_nhwc(x_nhwc.data_ptr(), None if scale is None else scale.data_ptr(), None if shift is None else shift.data_ptr(),
-                                       wp.data_ptr(), B, H, W, Ci, Co, y.data_ptr(), flag.data_ptr(), st()), "conv")
+                                       wp.data_ptr(), None, None, B, H, W, Ci, Co, y.data_ptr(), flag.data_ptr(), st()), "conv")
     return y
 
 

@@ -7,7 +7,7 @@ dev = torch.device("cuda:0")
 L = _lib.lib()
 st = lambda: torch.cuda.current_stream().cuda_stream
 flag = torch.zeros(1, dtype=torch.int32, device=dev)
-V = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+V = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 16
 out = []
 for (H, Ci, Co) in [(256, 64, 128), (256, 128, 128), (128, 256, 256), (64, 256, 256)]:
     x = torch.randn(V, H, H, Ci, device=dev)
@@ -15,7 +15,9 @@ for (H, Ci, Co) in [(256, 64, 128), (256, 128, 128), (128, 256, 256), (64, 256, 
     wp = torch.empty(L.ps_conv3x3_f16x3_packed_bytes(Co, Ci), dtype=torch.uint8, device=dev)
     _lib.check(L.ps_conv3x3_f16x3_pack(w.data_ptr(), Co, Ci, wp.data_ptr(), st()), "pack")
     y = torch.empty(V, H, H, Co, device=dev)
-    fn = lambda: _lib.check(L.ps_conv3x3_f16x3_nhwc(x.data_ptr(), None, None, wp.data_ptr(), V, H, H, Ci, Co, y.data_ptr(), flag.data_ptr(), st()), "conv")
+    res = torch.randn(V, H, H, Co, device=dev) if "--res" in sys.argv else None
+    fn = lambda: _lib.check(L.ps_conv3x3_f16x3_nhwc(x.data_ptr(), None, None, wp.data_ptr(), None, None if res is None else res.data_ptr(), V, H, H, Ci, Co,
+                                                    y.data_ptr(), flag.data_ptr(), st()), "conv")
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
