@@ -325,6 +325,10 @@ int ps_affine_relu_nhwc_f32(const float *x, const float *scale, const float *shi
  *   to be added to every INPUT pixel (the bias of the convolutions that produced a and b, which ran without it). */
 int ps_pool_add_nhwc_f32(const float *a, const float *b, const float *bias, int B, int H, int W, int C, float *out,
                          void *stream);
+/* ps_pool_add_post_nhwc_f32: ps_pool_add_nhwc_f32 plus `post` (B, H/2, W/2, C) or NULL, added AFTER the pooling: the projected
+ * branch of a down-sampling block whose 1 x 1 convolution ran on the pooled input (avg_pool2d and a 1 x 1 convolution commute). */
+int ps_pool_add_post_nhwc_f32(const float *a, const float *b, const float *bias, const float *post, int B, int H, int W, int C,
+                              float *out, void *stream);
 /* ps_upsample_add_nhwc_f32: blocks.py:61-73 with 'Up': out (B, 2H, 2W, C) = bilinear x2 (align_corners = False) of a,
  *   plus the same of b unless b is NULL; bias as above. */
 int ps_upsample_add_nhwc_f32(const float *a, const float *b, const float *bias, int B, int H, int W, int C, float *out,

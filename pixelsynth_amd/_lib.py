@@ -57,6 +57,7 @@ _PROTOS = {
     "ps_vq_embed_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ps_affine_relu_nhwc_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ps_pool_add_nhwc_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "ps_pool_add_post_nhwc_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ps_upsample_add_nhwc_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ps_add_bias_nhwc_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ps_noise_affine_f32": (c_int, [c_void_p] * 6 + [ctypes.c_float, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),

@@ -37,9 +37,11 @@ __global__ __launch_bounds__(256) void k_affine_relu(const f32x4 *__restrict__ x
 // 3x3 window sums of a (and b) around input pixel (2 yo, 2 xo), zero padding, divisor 9
 // `bias` (per channel, may be null) is a constant that belongs to every INPUT pixel of the pooled tensors (the bias of the
 // convolutions that produced them, not yet added): it reaches the output with the share of the window inside the image
+// `post` (may be null): a tensor of the OUTPUT's shape added after the pooling -- the other branch of a down-sampling block when its
+// 1 x 1 convolution was run on the pooled input instead (pooling and a 1 x 1 convolution commute; the convolution then costs a quarter)
 __global__ __launch_bounds__(256) void k_pool_add(const f32x4 *__restrict__ a, const f32x4 *__restrict__ b,
-                                                  const f32x4 *__restrict__ bias, int H, int W, int C4, size_t total4,
-                                                  f32x4 *__restrict__ out)
+                                                  const f32x4 *__restrict__ bias, const f32x4 *__restrict__ post, int H, int W, int C4,
+                                                  size_t total4, f32x4 *__restrict__ out)
 {
     const int Ho = H / 2, Wo = W / 2;
     const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -69,6 +71,7 @@ __global__ __launch_bounds__(256) void k_pool_add(const f32x4 *__restrict__ a, c
         const float ninth = 1.0f / 9.0f;
         f32x4 v = b ? sa * ninth + sb * ninth : sa * ninth;
         if (bias) v += bias[c4] * ((float)inside * ninth);
+        if (post) v += post[i];
         out[i] = v;
     }
 }
@@ -160,16 +163,22 @@ int ps_affine_relu_nhwc_f32(const float *x, const float *scale, const float *shi
     return PS_OK;
 }
 
-int ps_pool_add_nhwc_f32(const float *a, const float *b, const float *bias, int B, int H, int W, int C, float *out, void *stream)
+int ps_pool_add_post_nhwc_f32(const float *a, const float *b, const float *bias, const float *post, int B, int H, int W, int C, float *out,
+                              void *stream)
 {
     PS_REQUIRE(a && out, "pool_add: null pointer");
     PS_REQUIRE(B > 0 && H > 1 && W > 1 && H % 2 == 0 && W % 2 == 0 && C > 0 && C % 4 == 0,
                "pool_add: even H, W and C a multiple of 4 required (H = %d, W = %d, C = %d)", H, W, C);
     const size_t total4 = (size_t)B * (H / 2) * (W / 2) * (C / 4);
     hipLaunchKernelGGL(k_pool_add, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, (const f32x4 *)a, (const f32x4 *)b,
-                       (const f32x4 *)bias, H, W, C / 4, total4, (f32x4 *)out);
+                       (const f32x4 *)bias, (const f32x4 *)post, H, W, C / 4, total4, (f32x4 *)out);
     PS_LAUNCH_CHECK();
     return PS_OK;
+}
+
+int ps_pool_add_nhwc_f32(const float *a, const float *b, const float *bias, int B, int H, int W, int C, float *out, void *stream)
+{
+    return ps_pool_add_post_nhwc_f32(a, b, bias, nullptr, B, H, W, C, out, stream);
 }
 
 int ps_upsample_add_nhwc_f32(const float *a, const float *b, const float *bias, int B, int H, int W, int C, float *out, void *stream)

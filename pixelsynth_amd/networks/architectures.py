@@ -358,16 +358,18 @@ def _sum_bias(*bs):
     return None if not bs else bs[0] if len(bs) == 1 else (bs[0] + bs[1]).contiguous()
 
 
-def _resample_sum(kind, a, b, bias=None):
+def _resample_sum(kind, a, b, bias=None, post=None):
     """_resample(kind, a + bias) + _resample(kind, b) -- blocks.py:61-73 -- as ONE pass through csrc/nets.hip on the GPU
     (`bias`: per-channel constant still missing from the inputs, see _conv_split).  b = None: a alone -- resampling is linear, so
-    a caller that already holds the SUM of the two branches resamples once."""
+    a caller that already holds the SUM of the two branches resamples once.  post ('Down' only): a tensor of the output's shape added
+    after the pooling."""
     from .. import _lib
     if (not (_is_nhwc_cuda(a) if b is None else _is_nhwc_cuda(a, b)) or (b is not None and a.shape != b.shape)
             or (kind and kind != "Up" and (a.size(2) % 2 or a.size(3) % 2)) or (b is None and not kind)):
         if bias is not None:
             a = a + bias.view(1, -1, 1, 1)
-        return _resample(kind, a) if b is None else _resample(kind, a) + _resample(kind, b)
+        out = _resample(kind, a) if b is None else _resample(kind, a) + _resample(kind, b)
+        return out if post is None else out + post
     B, C, H, W = a.shape
     if not kind:
         out = torch.empty_like(a)
@@ -379,8 +381,13 @@ def _resample_sum(kind, a, b, bias=None):
                    "ps_upsample_add_nhwc_f32")
     else:
         out = _empty_nhwc(B, C, H // 2, W // 2, a)
-        _lib.check(_lib.lib().ps_pool_add_nhwc_f32(a.data_ptr(), _ptr(b), _ptr(bias), B, H, W, C, out.data_ptr(), _stream()),
-                   "ps_pool_add_nhwc_f32")
+        if post is not None and not (_is_nhwc_cuda(post) and post.shape == out.shape):
+            raise ValueError("_resample_sum: post must be a channels_last tensor of the pooled shape")
+        _lib.check(_lib.lib().ps_pool_add_post_nhwc_f32(a.data_ptr(), _ptr(b), _ptr(bias), _ptr(post), B, H, W, C, out.data_ptr(), _stream()),
+                   "ps_pool_add_post_nhwc_f32")
+        return out
+    if post is not None:
+        raise ValueError("_resample_sum: post goes with 'Down' only")
     return out
 
 
@@ -450,6 +457,14 @@ class ResNet_Block(nn.Module):
 
     def forward(self, x, noise=(None, None)):
         a, ba, _ = self._norm_relu_conv(self.ch_a[0], self.ch_a[2], x, noise[0])
+        mode = getattr(self.opt, "decoder_conv", None) or DECODER_CONV
+        if (self.resample and self.resample != "Up" and mode == "f16x3" and _is_nhwc_cuda(x) and not torch.is_grad_enabled()
+                and x.size(2) % 2 == 0 and x.size(3) % 2 == 0 and self.ch_b[0].kernel_size == (1, 1) and self.ch_b[0].stride == (1, 1)):
+            # Down: avg_pool2d and the 1 x 1 convolution of the other branch commute -- pool first, convolve a quarter of the pixels,
+            # and hand the result to the pooling of this branch as its `post` term (both biases ride through the pooling: bias=)
+            b, bb = _conv_split(self.ch_b[0], _resample_sum(self.resample, x, None))
+            a, ba2, _ = self._norm_relu_conv(self.ch_a[3], self.ch_a[5], a, noise[1], ba)
+            return _resample_sum(self.resample, a, None, _sum_bias(ba2, bb), post=b)
         b, bb = _conv_split(self.ch_b[0], x) if self.projected else (x, None)
         # The second convolution adds the other branch on its way out where it can (resampling is linear: resample(a) + resample(b) =
         # resample(a + b)); without resampling the biases go in as well and its output is the block's.

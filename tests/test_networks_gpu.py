@@ -86,8 +86,9 @@ def test_block_elementwise_kernels_against_torch():
     assert rc != 0 and b"multiple of 4" in _lib.lib().ps_last_error()
 
 
-def _f16x3(x_nchw, w, scale=None, shift=None):
-    """ps_conv3x3_f16x3_pack + ps_conv3x3_f16x3_nhwc through the C ABI; returns (y as NCHW view, overflow flag tensor)."""
+def _f16x3(x_nchw, w, scale=None, shift=None, bias=None, res=None):
+    """ps_conv3x3_f16x3_pack + ps_conv3x3_f16x3_nhwc through the C ABI; returns (y as NCHW view, overflow flag tensor).
+    res: (B, H, W, Co) contiguous."""
     from pixelsynth_amd import _lib
     L, st = _lib.lib(), torch.cuda.current_stream().cuda_stream
     B, Ci, H, W = x_nchw.shape
@@ -99,7 +100,8 @@ def _f16x3(x_nchw, w, scale=None, shift=None):
     y = torch.empty(B, H, W, Co, device=DEV)
     flag = torch.zeros(1, dtype=torch.int32, device=DEV)
     _lib.check(L.ps_conv3x3_f16x3_nhwc(xl.data_ptr(), None if scale is None else scale.data_ptr(), None if shift is None else shift.data_ptr(),
-                                       packed.data_ptr(), None, None, B, H, W, Ci, Co, y.data_ptr(), flag.data_ptr(), st), "conv")
+                                       packed.data_ptr(), None if bias is None else bias.data_ptr(), None if res is None else res.data_ptr(),
+                                       B, H, W, Ci, Co, y.data_ptr(), flag.data_ptr(), st), "conv")
     return y.permute(0, 3, 1, 2), flag
 
 
@@ -125,6 +127,26 @@ def test_conv3x3_on_the_fp16_pipe_against_an_fp64_convolution(B, H, W, Ci, Co, f
     e16, e32 = (y.double() - ref).abs().max().item() / top, (y32.double() - ref).abs().max().item() / top
     assert int(flag.item()) == 0
     assert e16 < 3e-6 and e16 < 10 * e32, (e16, e32)
+
+
+@pytest.mark.parametrize("Co", [64, 128, 256])
+def test_conv3x3_on_the_fp16_pipe_adds_bias_and_the_other_branch_on_the_way_out(Co):
+    """bias (Co) and res (B, H, W, Co): y = conv + bias + res, what a ResNet_Block's second convolution hands on (blocks.py:61-73);
+    each alone and both, several items per workgroup (B = 70: 280 tiles), against the plain result plus the torch ops."""
+    g = torch.Generator().manual_seed(Co)
+    B, H, Ci = 70, 32, 32
+    x = torch.randn(B, Ci, H, H, generator=g).to(DEV)
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) * 0.1).to(DEV)
+    bias, res = torch.randn(Co, generator=g).to(DEV), torch.randn(B, H, H, Co, generator=g).to(DEV)
+    plain, _ = _f16x3(x, w)
+    for bb, rr in ((bias, None), (None, res), (bias, res)):
+        got, _ = _f16x3(x, w, None, None, bb, rr)
+        want = plain.clone()
+        if bb is not None:
+            want = want + bb.view(1, -1, 1, 1)
+        if rr is not None:
+            want = want + rr.permute(0, 3, 1, 2)
+        assert (got - want).abs().max().item() < 1e-5
 
 
 def test_conv3x3_on_the_fp16_pipe_flags_what_fp16_cannot_hold_and_rejects_what_it_does_not_take():
