@@ -88,6 +88,10 @@ struct ConvArgs {
     int H, W, Ci, Co, tiles_x, tiles_per_frame, ncb, nblocks;
 };
 
+#if defined(PS_CONV_EXP) && (PS_CONV_EXP & 16)   // tuning build: shader cycles and 100 MHz ticks of every workgroup's first wave, summed
+__device__ unsigned long long g_conv_clk[2];
+#endif
+
 // One (tile, output-channel block) of the launch: which patch, which weights, where the results go.
 struct Item {
     const float *xb;      // the frame
@@ -284,6 +288,9 @@ template <bool FUSE> __global__ __launch_bounds__(NT) void k_conv3x3_f16x3(ConvA
 #endif
     };
 
+#if defined(PS_CONV_EXP) && (PS_CONV_EXP & 16)
+    const unsigned long long clk0 = clock64(), wall0 = wall_clock64();
+#endif
     Item cur = item_at(0), nxt = cur;
     const int Q = nitems * nchunk, GG = Q * 9;   // chunk instances and taps of this workgroup
     aim(cur);
@@ -332,7 +339,7 @@ template <bool FUSE> __global__ __launch_bounds__(NT) void k_conv3x3_f16x3(ConvA
             else if (more) load_frags(F[0], An, Bn, 0, 0);
             mfma_step(F[1]);
             if (tap == 6 && more) {   // (the patch was waited for at tap 3, whose wait covers tap 1's copies, requested behind it)
-                pin();
+                pin();                // (the two waves of a SIMD stashing at different taps, 5 and 6: 1-3 % slower)
                 stash((q + 1) & 1);
             }
         }
@@ -352,6 +359,12 @@ template <bool FUSE> __global__ __launch_bounds__(NT) void k_conv3x3_f16x3(ConvA
         }
     }
     if (over) *a.overflow = 1;
+#if defined(PS_CONV_EXP) && (PS_CONV_EXP & 16)
+    if (tid == 0) {
+        atomicAdd(&g_conv_clk[0], clock64() - clk0);
+        atomicAdd(&g_conv_clk[1], wall_clock64() - wall0);
+    }
+#endif
 }
 
 // (Co, 3, 3, Ci) fp32 -> [cb][chunk][tap][ks][ct][part][lane][8] fp16: B[k][n] of the MFMA: n = lane & 31 = channel 32 ct + n of block cb,
@@ -382,6 +395,18 @@ __global__ __launch_bounds__(256) void k_pack(const float *__restrict__ w, int C
 }  // namespace psconv
 
 extern "C" {
+
+#if defined(PS_CONV_EXP) && (PS_CONV_EXP & 16)
+// tuning build: (shader cycles, 100 MHz ticks) summed over the workgroups since the last call; resets
+int ps_conv_debug_clock(unsigned long long *out)
+{
+    unsigned long long zero[2] = {0, 0};
+    PS_HIP_CHECK(hipDeviceSynchronize());
+    PS_HIP_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(psconv::g_conv_clk), 16));
+    PS_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(psconv::g_conv_clk), zero, 16));
+    return PS_OK;
+}
+#endif
 
 size_t ps_conv3x3_f16x3_packed_bytes(int Co, int Ci) { return (size_t)9 * ((Co + psconv::COT - 1) / psconv::COT * psconv::COT) * Ci * 4; }
 

@@ -28,5 +28,12 @@ for (H, Ci, Co) in [(256, 64, 128), (256, 128, 128), (128, 256, 256), (64, 256, 
     e1.record()
     torch.cuda.synchronize()
     t = e0.elapsed_time(e1) / 10
-    out.append(f"{H}^2 {Ci}->{Co}: {t:.3f} ms ({3 * 2 * 9 * Ci * Co * H * H * V / t / 1e9:.0f} TF fp16)")
+    clk = ""
+    if "--clock" in sys.argv:   # a -DPS_CONV_EXP=16 build: the shader clock and the wave-time of the launches just timed
+        import ctypes
+        raw = ctypes.CDLL(_lib.LIB_PATH)
+        buf = (ctypes.c_ulonglong * 2)()
+        raw.ps_conv_debug_clock(buf)          # (13 launches: 3 warm-up + 10 timed; every workgroup's first wave)
+        clk = f", clock {buf[0] / (buf[1] * 10.0):.3f} GHz"
+    out.append(f"{H}^2 {Ci}->{Co}: {t:.3f} ms ({3 * 2 * 9 * Ci * Co * H * H * V / t / 1e9:.0f} TF fp16{clk})")
 print(" | ".join(out))
