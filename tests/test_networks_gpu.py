@@ -278,6 +278,7 @@ def test_noise_affine_in_one_launch_equals_the_composed_form():
     pending convolution bias folded in, against affine() composed from torch ops on the CPU (normalization.py:21-47, :170-184)."""
     from pixelsynth_amd.networks.architectures import LinearNoiseLayer
     g = torch.Generator().manual_seed(5)
+    torch.manual_seed(5)     # (spectral_norm draws its u, v from the global generator: sigma, hence the size of the numbers, depends on it)
     for C, B in ((64, 3), (4, 1), (256, 16)):
         layer = LinearNoiseLayer(syn.network_opts(), output_sz=C).eval()
         with torch.no_grad():
@@ -294,6 +295,7 @@ def test_noise_affine_in_one_launch_equals_the_composed_form():
             got = layer.affine_bc(x.to(DEV), noise.to(DEV), pend.to(DEV))
             plain = layer.affine_bc(x.to(DEV), noise.to(DEV))
         assert got[0].shape == (B, C) and got[0].is_contiguous()
-        np.testing.assert_allclose(got[0].cpu().numpy(), want[0].numpy(), rtol=1e-5, atol=1e-5)
-        np.testing.assert_allclose(got[1].cpu().numpy(), want[1].numpy(), rtol=1e-5, atol=2e-5)
-        np.testing.assert_allclose(plain[1].cpu().numpy(), sh.reshape(B, C).numpy(), rtol=1e-5, atol=2e-5)
+        top = max(float(want[0].abs().max()), float(want[1].abs().max()), float(sh.abs().max()), 1.0)    # (shift is a difference of products of scale)
+        np.testing.assert_allclose(got[0].cpu().numpy(), want[0].numpy(), rtol=1e-5, atol=1e-5 * top)
+        np.testing.assert_allclose(got[1].cpu().numpy(), want[1].numpy(), rtol=1e-5, atol=2e-5 * top)
+        np.testing.assert_allclose(plain[1].cpu().numpy(), sh.reshape(B, C).numpy(), rtol=1e-5, atol=2e-5 * top)
