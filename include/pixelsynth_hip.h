@@ -370,7 +370,7 @@ int ps_conv3x3_f16x3_nhwc(const float *x, const float *scale, const float *shift
  * act(x) = max(x * scale[b][c] - shift[b][c], 0) on the way in; zero padding 1, stride 1; NHWC):
  * ps_conv3x3_thin_in_nhwc_f32:  x (B, H, W, 4) -> y (B, H, W, Co), Co a multiple of 4; w [3][3][4][Co] (= weight.permute(2, 3, 1, 0)).
  * ps_conv3x3_thin_out_nhwc_f32: x (B, H, W, Ci) -> y (B, H, W, Co), Ci a multiple of 32, 1 <= Co <= 4; w [3][3][Ci][Co].
- * H a multiple of 8, W of 32.  Replace torch.nn.Conv2d(4, 64, 3, 1, 1) / Conv2d(128, 3, 3, 1, 1) of the decoder's first and last
+ * H a multiple of 8; W a multiple of 64 (thin_in; Co <= 256) / 32 (thin_out).  Replace torch.nn.Conv2d(4, 64, 3, 1, 1) / Conv2d(128, 3, 3, 1, 1) of the decoder's first and last
  * blocks (models/networks/architectures.py:126-167). */
 int ps_conv3x3_thin_in_nhwc_f32(const float *x, const float *scale, const float *shift, const float *w, int B, int H, int W,
                                 int Co, float *y, void *stream);

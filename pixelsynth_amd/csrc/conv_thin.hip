@@ -5,7 +5,9 @@
 // Neither is a matrix product worth the name (K = 36; N = 3): through MIOpen's implicit GEMM they take 0.5 and 0.9 ms per 16 views,
 // as long as the decoder's 128 -> 128 layers do on the fp16 pipe (csrc/conv_f16x3.hip), while their arithmetic is 2 % of those.
 // Here they are what they are -- one pass over the wide side of the layer (the 64-channel output / the 128-channel input) at memory
-// speed, fp32 FMAs on the vector ALU, weights through the scalar cache (uniform addresses) -- with the block's norm + ReLU,
+// speed, fp32 FMAs on the vector ALU (thin_in: two neighbouring pixels per thread, weights by broadcast LDS reads; thin_out: the patch
+// in LDS, weights through the scalar cache -- two pixels per thread with the weights in LDS too was SLOWER, 394 against 338 us: a
+// broadcast ds_read_b128 costs what any other does, and every weight read feeds only 6 CO FMAs) -- with the block's norm + ReLU,
 // y = max(x * scale[b][c] - shift[b][c], 0) (models/layers/normalization.py:21-47), applied on the way in.  No bias: the caller
 // folds it into the next pass, as for every convolution of the decoder.
 #include "ps_common.h"
@@ -13,45 +15,59 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int TW = 32, TH = 8;                   // output pixels per 256-thread workgroup
-constexpr int PW = TW + 2, PP = (TH + 2) * PW;   // the patch: 10 x 34 = 340 pixels
+constexpr int TW = 64, TH = 8;                   // output pixels per 256-thread workgroup: a thread owns two neighbours in a row
+constexpr int OTW = 32, OTH = 8;                 // thin_out: one pixel per thread
+constexpr int OPW = OTW + 2, OPP = (OTH + 2) * OPW;   // its patch: 10 x 34 = 340 pixels
 
-// ---- 4 -> Co.  A thread owns one output pixel: its 3 x 3 x 4 inputs in registers, four output channels at a time.
-// w: [tap 9][ci 4][Co]
+// ---- 4 -> Co.  A thread owns two neighbouring output pixels: their 3 x 4 x 4 inputs in registers, four output channels at a time;
+// the weights in LDS ([tap][ci][Co], read as broadcast float4s: one read feeds eight FMAs of every lane).
 template <bool FUSE> __global__ __launch_bounds__(256) void k_thin_in(const f32x4 *__restrict__ x, const f32x4 *__restrict__ scale,
                                                                        const f32x4 *__restrict__ shift, const float *__restrict__ w,
                                                                        float *__restrict__ y, int H, int W, int Co, int tiles_x,
                                                                        int tiles_per_frame)
 {
+    extern __shared__ f32x4 wl[];   // 36 * Co floats
+    for (int i = threadIdx.x; i < 9 * Co; i += 256) wl[i] = ((const f32x4 *)w)[i];
     const int b = blockIdx.x / tiles_per_frame, tf = blockIdx.x - b * tiles_per_frame;
-    const int oy = (tf / tiles_x) * TH + (threadIdx.x >> 5), ox = (tf % tiles_x) * TW + (threadIdx.x & 31);
+    const int oy = (tf / tiles_x) * TH + (threadIdx.x >> 5), ox = (tf % tiles_x) * TW + 2 * (threadIdx.x & 31);
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     f32x4 sc = zero, sh = zero;
     if (FUSE) { sc = scale[b]; sh = shift[b]; }
-    f32x4 in[9];
+    f32x4 in[3][4];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        const int iy = oy + t / 3 - 1, ix = ox + t % 3 - 1;
-        f32x4 v = zero;
-        if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
-            v = x[((size_t)b * H + iy) * W + ix];
-            if (FUSE) v = __builtin_elementwise_max(v * sc - sh, zero);
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int iy = oy + r - 1, ix = ox + c - 1;
+            f32x4 v = zero;
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+                v = x[((size_t)b * H + iy) * W + ix];
+                if (FUSE) v = __builtin_elementwise_max(v * sc - sh, zero);
+            }
+            in[r][c] = v;
         }
-        in[t] = v;
-    }
+    __syncthreads();
     float *yp = y + (((size_t)b * H + oy) * W + ox) * Co;
-    for (int c = 0; c < Co; c += 4) {
-        f32x4 acc = zero;
+    const int Co4 = Co >> 2;
+    for (int c = 0; c < Co4; ++c) {
+        f32x2 a0l = {0.f, 0.f}, a0h = a0l, a1l = a0l, a1h = a0l;   // pairs: v_pk_fma_f32, two FMAs per lane and issue slot
 #pragma unroll
         for (int t = 0; t < 9; ++t)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const f32x4 wv = *(const f32x4 *)(w + (size_t)(t * 4 + j) * Co + c);   // (uniform: scalar loads)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) acc[k] = __builtin_fmaf(in[t][j], wv[k], acc[k]);
+                const f32x4 wv = wl[(t * 4 + j) * Co4 + c];
+                const f32x2 wlo = {wv[0], wv[1]}, whi = {wv[2], wv[3]};
+                const float u0 = in[t / 3][t % 3][j], u1 = in[t / 3][t % 3 + 1][j];
+                const f32x2 uu0 = {u0, u0}, uu1 = {u1, u1};
+                a0l = __builtin_elementwise_fma(uu0, wlo, a0l);
+                a0h = __builtin_elementwise_fma(uu0, whi, a0h);
+                a1l = __builtin_elementwise_fma(uu1, wlo, a1l);
+                a1h = __builtin_elementwise_fma(uu1, whi, a1h);
             }
-        *(f32x4 *)(yp + c) = acc;
+        *(f32x4 *)(yp + 4 * c) = (f32x4){a0l[0], a0l[1], a0h[0], a0h[1]};
+        *(f32x4 *)(yp + Co + 4 * c) = (f32x4){a1l[0], a1l[1], a1h[0], a1h[1]};
     }
 }
 
@@ -62,17 +78,17 @@ template <int CO, bool FUSE> __global__ __launch_bounds__(256) void k_thin_out(c
                                                                                float *__restrict__ y, int H, int W, int Ci, int tiles_x,
                                                                                int tiles_per_frame)
 {
-    __shared__ f32x4 patch[8][PP];
+    __shared__ f32x4 patch[8][OPP];
     const int b = blockIdx.x / tiles_per_frame, tf = blockIdx.x - b * tiles_per_frame;
-    const int ty0 = (tf / tiles_x) * TH, tx0 = (tf % tiles_x) * TW, ty = threadIdx.x >> 5, tx = threadIdx.x & 31;
+    const int ty0 = (tf / tiles_x) * OTH, tx0 = (tf % tiles_x) * OTW, ty = threadIdx.x >> 5, tx = threadIdx.x & 31;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     const float *xb = x + (size_t)b * H * W * Ci;
     float acc[CO];
 #pragma unroll
     for (int k = 0; k < CO; ++k) acc[k] = 0.f;
     for (int c0 = 0; c0 < Ci; c0 += 32) {
-        for (int i = threadIdx.x; i < PP * 8; i += 256) {
-            const int p = i >> 3, c4 = i & 7, pr = p / PW, pc = p - pr * PW, iy = ty0 + pr - 1, ix = tx0 + pc - 1;
+        for (int i = threadIdx.x; i < OPP * 8; i += 256) {
+            const int p = i >> 3, c4 = i & 7, pr = p / OPW, pc = p - pr * OPW, iy = ty0 + pr - 1, ix = tx0 + pc - 1;
             f32x4 v = zero;
             if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
                 v = *(const f32x4 *)(xb + ((size_t)iy * W + ix) * Ci + c0 + 4 * c4);
@@ -86,7 +102,7 @@ template <int CO, bool FUSE> __global__ __launch_bounds__(256) void k_thin_out(c
         __syncthreads();
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            const int pp = (ty + t / 3) * PW + tx + t % 3;
+            const int pp = (ty + t / 3) * OPW + tx + t % 3;
 #pragma unroll
             for (int c4 = 0; c4 < 8; ++c4) {
                 const f32x4 v = patch[c4][pp];
@@ -113,15 +129,15 @@ int ps_conv3x3_thin_in_nhwc_f32(const float *x, const float *scale, const float 
 {
     PS_REQUIRE(x && w && y, "conv3x3_thin_in: null pointer");
     PS_REQUIRE((scale == nullptr) == (shift == nullptr), "conv3x3_thin_in: scale and shift come together");
-    PS_REQUIRE(B > 0 && H > 0 && W > 0 && H % TH == 0 && W % TW == 0 && Co > 0 && Co % 4 == 0,
-               "conv3x3_thin_in: H a multiple of 8, W of 32, Co of 4 required (H = %d, W = %d, Co = %d)", H, W, Co);
+    PS_REQUIRE(B > 0 && H > 0 && W > 0 && H % TH == 0 && W % TW == 0 && Co > 0 && Co % 4 == 0 && Co <= 256,
+               "conv3x3_thin_in: H a multiple of 8, W of 64, Co of 4 (at most 256) required (H = %d, W = %d, Co = %d)", H, W, Co);
     const int tiles_x = W / TW, tpf = (H / TH) * tiles_x;
     PS_REQUIRE((size_t)B * tpf < ((size_t)1 << 31), "conv3x3_thin_in: too many tiles");
     if (scale)
-        hipLaunchKernelGGL(k_thin_in<true>, dim3(B * tpf), dim3(256), 0, (hipStream_t)stream, (const f32x4 *)x, (const f32x4 *)scale,
+        hipLaunchKernelGGL(k_thin_in<true>, dim3(B * tpf), dim3(256), 36 * Co * sizeof(float), (hipStream_t)stream, (const f32x4 *)x, (const f32x4 *)scale,
                            (const f32x4 *)shift, w, y, H, W, Co, tiles_x, tpf);
     else
-        hipLaunchKernelGGL(k_thin_in<false>, dim3(B * tpf), dim3(256), 0, (hipStream_t)stream, (const f32x4 *)x, (const f32x4 *)nullptr,
+        hipLaunchKernelGGL(k_thin_in<false>, dim3(B * tpf), dim3(256), 36 * Co * sizeof(float), (hipStream_t)stream, (const f32x4 *)x, (const f32x4 *)nullptr,
                            (const f32x4 *)nullptr, w, y, H, W, Co, tiles_x, tpf);
     PS_LAUNCH_CHECK();
     return PS_OK;
@@ -132,9 +148,9 @@ int ps_conv3x3_thin_out_nhwc_f32(const float *x, const float *scale, const float
 {
     PS_REQUIRE(x && w && y, "conv3x3_thin_out: null pointer");
     PS_REQUIRE((scale == nullptr) == (shift == nullptr), "conv3x3_thin_out: scale and shift come together");
-    PS_REQUIRE(B > 0 && H > 0 && W > 0 && H % TH == 0 && W % TW == 0 && Ci > 0 && Ci % 32 == 0 && Co >= 1 && Co <= 4,
+    PS_REQUIRE(B > 0 && H > 0 && W > 0 && H % OTH == 0 && W % OTW == 0 && Ci > 0 && Ci % 32 == 0 && Co >= 1 && Co <= 4,
                "conv3x3_thin_out: H a multiple of 8, W of 32, Ci of 32 and 1 <= Co <= 4 required (H = %d, W = %d, Ci = %d, Co = %d)", H, W, Ci, Co);
-    const int tiles_x = W / TW, tpf = (H / TH) * tiles_x;
+    const int tiles_x = W / OTW, tpf = (H / OTH) * tiles_x;
     PS_REQUIRE((size_t)B * tpf < ((size_t)1 << 31), "conv3x3_thin_out: too many tiles");
 #define PS_THIN_OUT(CO)                                                                                                                  \
     do {                                                                                                                                 \

@@ -294,10 +294,10 @@ def _thin_conv(conv, x, scale=None, shift=None):
     """conv(act(x)) WITHOUT the bias for the decoder's two thin 3 x 3 layers (4 -> Co, Ci -> <= 4 channels) through csrc/conv_thin.hip
     (fp32 FMAs), or None when `conv` is not one of them."""
     Ci, Co = conv.in_channels, conv.out_channels
-    thin_in, thin_out = Ci == 4 and Co % 4 == 0, Ci % 32 == 0 and 1 <= Co <= 4
+    thin_in, thin_out = Ci == 4 and Co % 4 == 0 and Co <= 256, Ci % 32 == 0 and 1 <= Co <= 4
     if not (conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1
             and (thin_in or thin_out) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
-            and x.is_contiguous(memory_format=torch.channels_last) and x.size(2) % 8 == 0 and x.size(3) % 32 == 0
+            and x.is_contiguous(memory_format=torch.channels_last) and x.size(2) % 8 == 0 and x.size(3) % (64 if thin_in else 32) == 0
             and not torch.is_grad_enabled()):
         return None
     weight = _plain_conv_weight(conv, x)

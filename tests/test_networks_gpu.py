@@ -246,8 +246,8 @@ def test_convolutions_through_torch_are_cut_below_2_gib_per_call(monkeypatch):
     assert out.is_contiguous(memory_format=torch.channels_last) and torch.equal(out, t * 2)
 
 
-@pytest.mark.parametrize("B,H,W,Ci,Co,fuse", [(2, 16, 32, 4, 64, True), (3, 8, 64, 4, 8, False), (2, 16, 32, 128, 3, True), (1, 24, 96, 32, 4, False),
-                                               (5, 8, 32, 64, 1, True)])
+@pytest.mark.parametrize("B,H,W,Ci,Co,fuse", [(2, 16, 64, 4, 64, True), (3, 8, 128, 4, 8, False), (2, 16, 64, 128, 3, True), (1, 24, 128, 32, 4, False),
+                                               (5, 8, 32, 64, 1, True), (1, 8, 96, 256, 2, True)])
 def test_thin_convolutions_against_an_fp64_convolution(B, H, W, Ci, Co, fuse):
     """csrc/conv_thin.hip: the decoder's 4 -> 64 and 128 -> 3 layers (and their neighbours in shape) as fp32 FMA passes, norm + ReLU
     on the way in, against torch's convolution in fp64: within 2e-6 of the output's largest magnitude (fp32 summation noise)."""
