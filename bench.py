@@ -424,7 +424,7 @@ def extra_configs(device):
                                  "decode_code_ms": round(timings["decode_code"] * 1e3, 3),
                                  "note": "next-row component (SURVEY 8f.1), outside the headline metric"}
     # SURVEY 8f row 2, also outside the metric: depth Unet on the 16 source images and refinement decoder on the 16 blended
-    # views (torch / MIOpen convolutions, fused noise-affine normalisation), synthetic weights
+    # views (fused noise-affine normalisation; the decoder's 3 x 3 convolutions through csrc/conv_f16x3.hip / conv_thin.hip), synthetic weights
     from pixelsynth_amd.networks import Unet, get_decoder
     nets = {}
     for name, mod in (("unet", Unet(channels_in=3, channels_out=1, opt=syn.network_opts())), ("decoder", get_decoder(syn.network_opts()))):
@@ -444,9 +444,50 @@ def extra_configs(device):
                 fn()
             torch.cuda.synchronize()
             timings[name] = (time.perf_counter() - t0) / n
+    # the decoder once more with every convolution through torch / MIOpen fp32, and its widest layer (128 -> 128 channels at 256 x 256,
+    # three of the thirteen split-fp16 layers, a third of the decoder's arithmetic) alone on the fp16 pipe with HIP events
+    from pixelsynth_amd.networks import architectures as arch
+    mode = arch.DECODER_CONV
+    conv_rec = None
+    with torch.no_grad():
+        arch.DECODER_CONV = "fp32"
+        for _ in range(3):
+            nets["decoder"](gen16, bg16)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            nets["decoder"](gen16, bg16)
+        torch.cuda.synchronize()
+        timings["refine_decoder_miopen"] = (time.perf_counter() - t0) / 5
+        arch.DECODER_CONV = mode
+        arch.check_f16x3_overflow(device)
+        if mode == "f16x3":
+            conv = nets["decoder"].eblocks[6].ch_a[5]
+            xx = torch.randn(16, 128, 256, 256, device=device).contiguous(memory_format=torch.channels_last)
+            for _ in range(3):
+                arch._f16x3_conv(conv, xx)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                arch._f16x3_conv(conv, xx)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 10
+            fl = 2 * 9 * 128 * 128 * 256 * 256 * 16
+            conv_rec = {"kernel": "k_conv3x3_f16x3 (csrc/conv_f16x3.hip): 128 -> 128 channels, 16 x 256 x 256, fp32 in / out, three fp16 MFMAs per product",
+                        "ms": round(ms, 4), "fp32_equivalent_tflops": round(fl / ms / 1e9, 1), "mfma_tflops": round(3 * fl / ms / 1e9, 1),
+                        "bound": "mfma", "peak": 2500.0, "unit": "TFLOP/s", "frac": round(3 * fl / ms / 1e9 / 2500.0, 4),
+                        "sustained_peak_on_random_operands": 1774.0,
+                        "note": "peak = dense fp16 MFMA at 2.4 GHz; under a pure stream of these MFMAs on random operands the chip holds "
+                                "1.72 GHz = 1774 TFLOP/s (tools/mfma_f16_clock_probe.hip); MIOpen's fp32 implicit GEMM runs this layer at "
+                                "~125 TFLOP/s"}
+            del xx
     res["depth_and_refinement_16_views"] = {"depth_unet_ms": round(timings["depth_unet"] * 1e3, 3),
                                             "refine_decoder_ms": round(timings["refine_decoder"] * 1e3, 3),
-                                            "note": "next-row components (SURVEY 8f.2), outside the headline metric"}
+                                            "refine_decoder_through_miopen_fp32_ms": round(timings["refine_decoder_miopen"] * 1e3, 3),
+                                            "decoder_conv": mode, "widest_layer": conv_rec,
+                                            "note": "next-row components (SURVEY 8f.2), outside the headline metric; the decoder's 3 x 3 "
+                                                    "convolutions hand-written on the fp16 matrix pipe (split operands, fp32-grade results)"}
     # the whole pipeline as ONE timed configuration: what a user gets per frame
     res["end_to_end_16_views"] = end_to_end_config(device, 16)
     res["end_to_end_128_views"] = end_to_end_config(device, 128, steps=2)
@@ -535,7 +576,7 @@ def end_to_end_config(device, V, steps=3):
             "sampled_codes_per_view_mean": round(float(np.mean(out["plan"].n_sampled)), 1), "parts_ms": parts,
             "hot_path_ms": round(parts["reproject_splat_plan_ms"] + parts["ar_outpaint_ms"], 3),
             "note": "every network of forward_image in the loop; depth from the (random-init) Unet, so the outpainting region is not "
-                    "the headline's; convolutions of the Unet / VQ-VAE / decoder through MIOpen (SURVEY 8f next rows)"}
+                    "the headline's; convolutions of the Unet / VQ-VAE through MIOpen, the decoder's 3 x 3 layers hand-written on the fp16 pipe (SURVEY 8f next rows)"}
 
 
 def cpu_baseline(host, out, V, budget_s=20.0):

@@ -31,7 +31,10 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int TH = 16, TW = 16;            // output pixels per workgroup
+constexpr int TH = 16, TW = 16;            // output pixels per workgroup.  (An MFMA tile = two rows of 16 pixels, 288 bytes apart in LDS: under
+                                           // ds_read_b128's lane groups every A read is a 2-way bank conflict, SQ_LDS_BANK_CONFLICT = 35 % of the
+                                           // LDS cycles.  8 x 32 tiles -- one image row per MFMA tile, conflict-free -- measured equal to 2 %
+                                           // slower: the larger halo costs what the conflicts did; the kernel is not bound by LDS.)
 constexpr int PW = TW + 2, PP = (TH + 2) * PW;   // the patch: 18 x 18 = 324 pixels
 constexpr int CK = 32;                     // input channels per chunk (two MFMA steps of 16)
 constexpr int COT = 128;                   // output channels per workgroup
