@@ -263,7 +263,31 @@ def _conv_split(conv, x):
 
 # ---- the wide 3 x 3 convolutions on the fp16 matrix pipe (csrc/conv_f16x3.hip) ------------------------------------------------
 DECODER_CONV = os.environ.get("PS_DECODER_CONV", "f16x3")   # "f16x3" | "fp32" (everything through torch / MIOpen)
+_FORCED_CONV = []    # decoder_conv(mode) in effect
 _overflow_flags = {}
+
+
+def _conv_mode(opt):
+    """Which convolutions a decoder block takes: decoder_conv(...) in effect, else opt.decoder_conv, else PS_DECODER_CONV."""
+    return _FORCED_CONV[-1] if _FORCED_CONV else (getattr(opt, "decoder_conv", None) or DECODER_CONV)
+
+
+class decoder_conv:
+    """with decoder_conv("fp32"): ... -- every decoder convolution inside through torch (MIOpen fp32), whatever the options say: how the
+    model reruns a pass whose split-fp16 convolutions met an activation beyond fp16's range."""
+
+    def __init__(self, mode):
+        if mode not in ("f16x3", "fp32"):
+            raise ValueError("decoder_conv: 'f16x3' or 'fp32'")
+        self.mode = mode
+
+    def __enter__(self):
+        _FORCED_CONV.append(self.mode)
+        return self
+
+    def __exit__(self, *exc):
+        _FORCED_CONV.pop()
+        return False
 
 
 def _overflow_flag(device):
@@ -440,7 +464,7 @@ class ResNet_Block(nn.Module):
         ONE kernel, norm + ReLU applied as the patch is staged (csrc/conv_f16x3.hip, conv_thin.hip); the others: the affine pass, then
         torch.  res / out_bias: the block's other branch and the biases still pending, which the split-fp16 kernel adds on its way out
         (`fused` says whether it did: the output is then conv + res + out_bias)."""
-        mode = getattr(self.opt, "decoder_conv", None) or DECODER_CONV
+        mode = _conv_mode(self.opt)
         if mode == "f16x3" and conv.bias is not None and x.is_cuda and not torch.is_grad_enabled():
             scale, shift = layer.affine_bc(x, noise, bias)
             if _f16x3_takes(conv, x):
@@ -457,7 +481,7 @@ class ResNet_Block(nn.Module):
 
     def forward(self, x, noise=(None, None)):
         a, ba, _ = self._norm_relu_conv(self.ch_a[0], self.ch_a[2], x, noise[0])
-        mode = getattr(self.opt, "decoder_conv", None) or DECODER_CONV
+        mode = _conv_mode(self.opt)
         if (self.resample and self.resample != "Up" and mode == "f16x3" and _is_nhwc_cuda(x) and not torch.is_grad_enabled()
                 and x.size(2) % 2 == 0 and x.size(3) % 2 == 0 and self.ch_b[0].kernel_size == (1, 1) and self.ch_b[0].stride == (1, 1)):
             # Down: avg_pool2d and the 1 x 1 convolution of the other branch commute -- pool first, convolve a quarter of the pixels,

@@ -22,7 +22,7 @@ from . import _lib
 from .lmconv.layers import PONO
 from .lmconv.model import OurPixelCNN
 from .lmconv.sample import sample
-from .networks.architectures import check_f16x3_overflow
+from .networks.architectures import check_f16x3_overflow, decoder_conv
 from .projection.z_buffer_manipulator import PtsManipulator
 
 
@@ -393,10 +393,9 @@ class ZbufferModelPts(nn.Module):
         planned = self.plan_views(fs_src[view_src].contiguous(), depth_src[view_src].contiguous(), K, K_inv, input_RT, input_RTinv,
                                   output_RT, output_RTinv)
         out = self.outpaint_planned(planned, None, self.opt.temperature if temperature is None else temperature, uniforms)
-        pred = self._decode_candidate(out["gen_fs"], out["background_mask"], out["codes"])
         if check:
             self.outpaint2.engine(self.obs[1], self.obs[2], K.shape[0]).check()
-            check_f16x3_overflow(pred.device)   # (the decoder's split-fp16 convolutions: no activation beyond fp16's range)
+        pred = (self._decode_checked if check else self._decode_candidate)(out["gen_fs"], out["background_mask"], out["codes"])
         return dict(PredImg=pred, FeaturesImg=out["gen_fs"], background_mask=out["background_mask"], codes=out["codes"],
                     depth=depth_src, plan=out["plan"])
 
@@ -445,8 +444,7 @@ class ZbufferModelPts(nn.Module):
         codes = torch.argmax(autoreg_output, dim=1)
         outputs["PredCodes"] = codes
         if self.vqvae is not None:  # :250-252 (without a refinement net the blend itself is the prediction)
-            outputs["PredImg"] = self._decode_candidate(gen_fs, background_mask, codes.to(torch.int64))
-            check_f16x3_overflow(gen_fs.device)
+            outputs["PredImg"] = self._decode_checked(gen_fs, background_mask, codes.to(torch.int64))
         return None, outputs
 
     # ---------------------------------------------------------------- sample ranking (8f.3, host logic)
@@ -467,6 +465,21 @@ class ZbufferModelPts(nn.Module):
         """codes (B,32,32) -> image: decode, blend with the reprojected features (a14), refine if a projector exists."""
         combined = self.get_combined(gen_fs, self.vqvae.decode_code(codes), background_mask)
         return combined if self.projector is None else self.projector(combined, background_mask)
+
+    def _decode_checked(self, gen_fs, background_mask, codes):
+        """_decode_candidate, then (synchronising) the question whether a split-fp16 convolution of the refinement decoder met an
+        activation beyond fp16's range (csrc/conv_f16x3.hip raises a flag; the image is then wrong): if so the pass is run again
+        with every convolution through torch in fp32, with a warning.  Weights under spectral norm behind normalisation layers do
+        not get there; a checkpoint that does should set opt.decoder_conv = "fp32" and save itself the first attempt."""
+        pred = self._decode_candidate(gen_fs, background_mask, codes)
+        try:
+            check_f16x3_overflow(gen_fs.device)
+        except RuntimeError as err:
+            import warnings
+            warnings.warn(f"{err}: the decoder pass is run again in fp32")
+            with decoder_conv("fp32"):
+                pred = self._decode_candidate(gen_fs, background_mask, codes)
+        return pred
 
     @torch.no_grad()
     def get_best_sample(self, *args, uniforms=None, shard=False):

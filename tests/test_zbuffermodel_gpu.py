@@ -383,6 +383,39 @@ def test_forward_image_with_every_network_in_the_loop():
     assert 0.2 < float(bg.float().mean()) < 0.9
 
 
+def test_a_decoder_pass_that_overflowed_fp16_is_run_again_in_fp32():
+    """_decode_checked: when a split-fp16 convolution of the refinement decoder raised its overflow flag (an activation beyond
+    65000: csrc/conv_f16x3.hip), the model warns and runs the pass again with every convolution through torch; without the flag the
+    split-fp16 kernels are what ran."""
+    from pixelsynth_amd.networks import architectures as A
+    o = vars(syn.network_opts())
+    m = make_model(vqvae=True, **o)
+    for mod, seed in ((m.pts_regressor, 5), (m.projector, 5)):
+        shapes = {k: tuple(v.shape) for k, v in mod.state_dict().items()}
+        mod.load_state_dict({k: torch.from_numpy(v) for k, v in syn.fill_state_dict(shapes, seed).items()}, strict=True)
+    m.vqvae.load_state_dict({k: torch.from_numpy(v) for k, v in syn.vqvae_state_dict(0).items()}, strict=True)
+    m = m.to(DEV).eval()
+    gen_fs = tt(syn.image(8, 2, 3, 256))
+    bgm = tt(syn.background_masks(256)["ragged"])[None].expand(2, -1, -1).contiguous()
+    codes = tt(syn.codes(9, 2)).to(torch.int64)
+    calls = []
+    real = A._f16x3_conv
+    A._f16x3_conv = lambda *a, **k: (calls.append(A._conv_mode(None)), real(*a, **k))[1]
+    try:
+        with torch.no_grad():
+            img = m._decode_checked(gen_fs, bgm, codes)
+            assert len(calls) == 13 and torch.isfinite(img).all()
+            del calls[:]
+            A._overflow_flag(gen_fs.device).fill_(1)          # as the kernel would
+            with pytest.warns(UserWarning, match="run again in fp32"):
+                img2 = m._decode_checked(gen_fs, bgm, codes)
+            assert len(calls) == 13                           # the first attempt only: the rerun went through torch
+            assert torch.isfinite(img2).all() and img2.shape == img.shape
+            A.check_f16x3_overflow(gen_fs.device)              # (cleared)
+    finally:
+        A._f16x3_conv = real
+
+
 def test_plan_views_then_outpaint_planned_equals_outpaint_views_also_across_streams():
     """The two halves of outpaint_views (host planning / device AR run) are what bench.py and the driver overlap across
     batches: planning on a side stream while another AR run is in flight must give the same views."""
