@@ -342,7 +342,8 @@ template <bool FUSE> __global__ __launch_bounds__(NT) void k_conv3x3_f16x3(ConvA
             else if (more) load_frags(F[0], An, Bn, 0, 0);
             mfma_step(F[1]);
             if (tap == 6 && more) {   // (the patch was waited for at tap 3, whose wait covers tap 1's copies, requested behind it)
-                pin();                // (the two waves of a SIMD stashing at different taps, 5 and 6: 1-3 % slower)
+                pin();                // (the two waves of a SIMD stashing at different taps, 5 and 6: 1-3 % slower; the stash spread a
+                                      // piece per step over taps 3 .. 5 with its conversions scheduled behind the MFMAs: 2 % slower)
                 stash((q + 1) & 1);
             }
         }
