@@ -442,15 +442,20 @@ int ps_conv3x3_f16x3_nhwc(const float *x, const float *scale, const float *shift
     const size_t nb = (size_t)B * a.tiles_per_frame * a.ncb;
     PS_REQUIRE(nb < ((size_t)1 << 30), "conv3x3_f16x3: too many tiles");
     a.nblocks = (int)nb;
-    // one persistent workgroup per compute unit (148 KB of LDS each), a multiple of the eight XCDs
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
+    // one persistent workgroup per compute unit (148 KB of LDS each), a multiple of the eight XCDs; per DEVICE, as is the functions'
+    // dynamic-LDS limit (a process may drive several GPUs, one per thread)
+    constexpr int MAX_DEV = 64;
+    static int cus_of[MAX_DEV] = {};
+    static bool attr_set[MAX_DEV][2] = {};
+    int dev = 0;
+    PS_HIP_CHECK(hipGetDevice(&dev));
+    PS_REQUIRE(dev >= 0 && dev < MAX_DEV, "conv3x3_f16x3: device %d", dev);
+    if (!cus_of[dev]) {
         hipDeviceProp_t prop;
-        PS_HIP_CHECK(hipGetDevice(&dev));
         PS_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
-        cus = prop.multiProcessorCount >= 8 ? prop.multiProcessorCount / 8 * 8 : 8;
+        cus_of[dev] = prop.multiProcessorCount >= 8 ? prop.multiProcessorCount / 8 * 8 : 8;
     }
+    const int cus = cus_of[dev];
     static int wgs = -2;     // PS_CONV_WGS (tuning): workgroups per launch; 0 = one per item (no persistence); default: one per compute unit
     if (wgs == -2) {
         const char *e = getenv("PS_CONV_WGS");
@@ -458,12 +463,17 @@ int ps_conv3x3_f16x3_nhwc(const float *x, const float *scale, const float *shift
     }
     const int want = wgs < 0 ? cus : wgs == 0 ? (int)((nb + 7) / 8 * 8) : (wgs + 7) / 8 * 8;
     const int grid = (int)std::min<size_t>((size_t)want, (nb + 7) / 8 * 8);
-    static bool attr_set[2] = {false, false};   // (per process; the attribute is per function)
     if (scale) {
-        if (!attr_set[1]) { PS_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv3x3_f16x3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL)); attr_set[1] = true; }
+        if (!attr_set[dev][1]) {
+            PS_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv3x3_f16x3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
+            attr_set[dev][1] = true;
+        }
         hipLaunchKernelGGL(k_conv3x3_f16x3<true>, dim3(grid), dim3(NT), LDS_TOTAL, (hipStream_t)stream, a);
     } else {
-        if (!attr_set[0]) { PS_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv3x3_f16x3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL)); attr_set[0] = true; }
+        if (!attr_set[dev][0]) {
+            PS_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv3x3_f16x3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
+            attr_set[dev][0] = true;
+        }
         hipLaunchKernelGGL(k_conv3x3_f16x3<false>, dim3(grid), dim3(NT), LDS_TOTAL, (hipStream_t)stream, a);
     }
     PS_LAUNCH_CHECK();
