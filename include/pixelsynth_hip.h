@@ -337,6 +337,11 @@ int ps_upsample_add_nhwc_f32(const float *a, const float *b, const float *bias, 
 int ps_add_bias_nhwc_f32(const float *a, const float *b, const float *bias, int B, int HW, int C, float *out,
                          void *stream);
 
+/* ps_cat_mask_nhwc_f32: the refinement decoder's input (models/networks/architectures.py:153-156: torch.cat((x, ~background_mask), 1)):
+ * x (B, 3, H, W) fp32 NCHW, background_mask (B, H, W) bytes (non-zero = background) -> out (B, H, W, 4) fp32 NHWC, channel 3 =
+ * 1 - background. */
+int ps_cat_mask_nhwc_f32(const float *x, const unsigned char *background_mask, int B, int H, int W, float *out, void *stream);
+
 /* ps_noise_affine_f32: the per-(sample, channel) affine of LinearNoiseLayer + stored-statistics batch norm
  * (models/layers/normalization.py:21-47, :170-184): scale[b][c] = rsqrt(var[c] + eps) * (1 + <noise[b], Wg[c]>),
  * shift[b][c] = mean[c] * scale[b][c] - <noise[b], Wb[c]> - pend[c] * scale[b][c].  noise (B, K); Wg, Wb (C, K): the (spectral-

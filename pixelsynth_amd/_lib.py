@@ -60,6 +60,7 @@ _PROTOS = {
     "ps_pool_add_post_nhwc_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ps_upsample_add_nhwc_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ps_add_bias_nhwc_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "ps_cat_mask_nhwc_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ps_noise_affine_f32": (c_int, [c_void_p] * 6 + [ctypes.c_float, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "ps_conv3x3_thin_in_nhwc_f32": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p, c_void_p]),
     "ps_conv3x3_thin_out_nhwc_f32": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p, c_void_p]),

@@ -335,7 +335,7 @@ def _thin_conv(conv, x, scale=None, shift=None):
         cache = (key, weight.detach().permute(2, 3, 1, 0).contiguous(), weight)      # [ky][kx][ci][co]
         conv.__dict__["_ps_thin_cache"] = cache
     B, _, H, W = x.shape
-    y = torch.empty((B, Co, H, W), dtype=x.dtype, device=x.device).contiguous(memory_format=torch.channels_last)
+    y = _empty_nhwc(B, Co, H, W, x)
     if Co == 1:   # (channels_last of one channel is ambiguous to torch; the kernel writes (B, H, W, Co))
         y = torch.empty((B, H, W, Co), dtype=x.dtype, device=x.device).permute(0, 3, 1, 2)
     if thin_in:
@@ -519,8 +519,18 @@ class ResNetDecoder(nn.Module):
         return 2 * len(self.eblocks)
 
     def forward(self, x, background_mask=None, noise=None):
-        h = x if background_mask is None else torch.cat((x, (~background_mask).unsqueeze(1).float()), 1)
-        h = _nhwc(self, h)
+        if (background_mask is not None and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.size(1) == 3 and x.is_contiguous()
+                and background_mask.dtype == torch.bool and background_mask.is_contiguous()
+                and background_mask.shape == (x.size(0), x.size(2), x.size(3)) and not torch.is_grad_enabled()):
+            from .. import _lib
+            B, _, H, W = x.shape
+            h = _empty_nhwc(B, 4, H, W, x)          # cat + NCHW -> NHWC in one pass
+            _lib.check(_lib.lib().ps_cat_mask_nhwc_f32(x.data_ptr(), background_mask.data_ptr(), B, H, W, h.data_ptr(), _stream()),
+                       "ps_cat_mask_nhwc_f32")
+            _nhwc(self, h)                            # (the weights, once)
+        else:
+            h = x if background_mask is None else torch.cat((x, (~background_mask).unsqueeze(1).float()), 1)
+            h = _nhwc(self, h)
         if noise is None and h.is_cuda:
             # the reference draws each layer's noise on the host and sends it over (normalization.py:36-37): sixteen small blocking
             # copies per pass.  The same sixteen draws, in the same order from the same generator, in ONE copy.

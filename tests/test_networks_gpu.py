@@ -299,3 +299,17 @@ def test_noise_affine_in_one_launch_equals_the_composed_form():
         np.testing.assert_allclose(got[0].cpu().numpy(), want[0].numpy(), rtol=1e-5, atol=1e-5 * top)
         np.testing.assert_allclose(got[1].cpu().numpy(), want[1].numpy(), rtol=1e-5, atol=2e-5 * top)
         np.testing.assert_allclose(plain[1].cpu().numpy(), sh.reshape(B, C).numpy(), rtol=1e-5, atol=2e-5 * top)
+
+
+def test_decoder_input_is_packed_in_one_pass():
+    """ps_cat_mask_nhwc_f32: torch.cat((x, ~background_mask), 1) (models/networks/architectures.py:153-156) of an NCHW image and a
+    bool mask, written as the NHWC tensor the first block reads -- bit for bit the cat, in channels_last storage."""
+    from pixelsynth_amd import _lib
+    g = torch.Generator().manual_seed(2)
+    for B, H, W in ((3, 8, 40), (1, 256, 256)):
+        x = torch.randn(B, 3, H, W, generator=g).to(DEV)
+        bg = (torch.rand(B, H, W, generator=g) > 0.4).to(DEV)
+        out = torch.empty(B, H, W, 4, device=DEV)
+        _lib.check(_lib.lib().ps_cat_mask_nhwc_f32(x.data_ptr(), bg.data_ptr(), B, H, W, out.data_ptr(), torch.cuda.current_stream().cuda_stream), "cat")
+        want = torch.cat((x, (~bg).unsqueeze(1).float()), 1)
+        assert torch.equal(out.permute(0, 3, 1, 2), want)
