@@ -1,3 +1,5 @@
+"""The first N rows of a rocprofv3 kernel_stats.csv (find-mode reference kernels left out) with their share and total time.
+usage: python tools/kernel_stats_top.py <kernel_stats.csv> <N>"""
 import csv, sys
 rows=list(csv.DictReader(open(sys.argv[1])))
 rows=[r for r in rows if 'naive' not in r['Name']]
