@@ -735,7 +735,8 @@ def main():
                        "ar_steps_walked": 1024 - plan.first_step,
                        "sampled_codes_per_view_mean": round(float(np.mean(plan.n_sampled)), 1),
                        "parallelism": f"views sharded over {world} GPU(s), RCCL all_gather of the reprojected views (8-bit) + completed code grids",
-                       "step_pipeline": "one stream; host half of step i + 1 on an unmasked side stream"},
+                       "step_pipeline": "the AR run on one stream, its whole-grid prefix pass dealt to two frame ranges on two streams; the host half of "
+                                        "step i + 1 (splat, planning, uploads) on a side stream"},
         }
         if torch.distributed.is_available() and torch.distributed.is_initialized():   # what the backend itself reports (tools/scale.sh)
             res["collective"] = {"backend": torch.distributed.get_backend(), "world_size": torch.distributed.get_world_size(),
