@@ -175,7 +175,7 @@ def run_steps(model, d, world, n, side):
     return finish_gathers(out)
 
 
-def measure_roofline(model, d, out, V):
+def measure_roofline(model, d, out, V, live_pmc=False):
     """Average column launch -- the dominant kernel: one launch per WAVEFRONT of independent columns (one column = one order
     position of one frame) -- over a whole AR run of this step's views, measured with HIP events on the stream the launches go to
     (ps_pixelcnn_time_ar_run_waves, median of three runs), against the dense algorithmic fp32 work of its columns:
@@ -183,7 +183,8 @@ def measure_roofline(model, d, out, V):
     k_column_tp, fp32 FMA chains on the vector ALU in the latency form k_column_la) plus the neighbour-tap partial sums of all 32
     masked convs (fp32 MFMA in both forms, masked taps skipped) -- the u_init product is a gather and is not priced.  fp32 MFMA and
     packed fp32 FMA share gfx950's dense fp32 peak (157.3 TFLOP/s).  A launch is bounded by the LATENCY of its 33 dependent stages,
-    not by throughput; `traffic`, `mfma_counters` and `kernel_table` come from the newest committed PMC record
+    not by throughput; `traffic` is measured in the run itself when live_pmc is set (live_pmc_traffic: two rocprofv3
+    --pmc passes of this command), otherwise it, and always `mfma_counters` and `kernel_table`, come from the newest committed PMC record
     of the same workload (profiles/README.md names it) -- counter passes cannot run inside a timed bench."""
     plan = out["plan"]
     eng = model.outpaint2.engine(32, 32, V)
@@ -210,6 +211,9 @@ def measure_roofline(model, d, out, V):
     if pmc:
         traffic, traffic_src, mfma_util = pmc.get("traffic_bytes_per_launch"), pmc.get("source"), pmc.get("mfma")
         kernel_table = pmc.get("kernel_table")
+    live = live_pmc_traffic() if live_pmc else None
+    if live:   # the driver's own run vouches for the traffic; MFMA counters and the per-kernel table stay the committed record's
+        traffic, traffic_src = live["traffic_bytes_per_launch"], live["source"]
     tp = cols_per_launch > 128
     kernel = ("k_column_tp (throughput form of the column launch, one launch per wavefront of up to 1024 independent AR columns: "
               "16-column MFMA chain tiles + one wave per neighbour item, the neighbour role a launch ahead of the chain tiles; "
@@ -223,6 +227,7 @@ def measure_roofline(model, d, out, V):
             "algorithmic_flops_per_launch": round(fl), "avg_launch_us": round(us, 3),
             "flops_per_column": round(fpc.value), "columns_per_launch": round(cols_per_launch, 2),
             "launches_per_ar_run": launches.value, "wavefronts": len(wave_start) - 1, "columns": ncols,
+            "traffic_live": live, "traffic_committed_record": (pmc or {}).get("traffic_bytes_per_launch"),
             "kernel_table": kernel_table,
             "kernel_table_note": "every kernel alone on the chip (PMC and trace passes with PS_PREFIX_STREAMS=1); the default step deals "
                                  "the prefix pass to two frame ranges on two streams: twice the k_gemm_wg launches at half the items, "
@@ -233,6 +238,65 @@ def measure_roofline(model, d, out, V):
                         "forward, 11.43095 GFLOP, per frame and order position -- skipped redundant work is NOT utilisation, "
                         "this is shown for comparison only",
                 "equivalent_tflops": round(11.43095e9 * cols_per_launch / (us * 1e-6) / 1e12, 1)}}
+
+
+def live_pmc_traffic():
+    """The column launches' FETCH_SIZE / WRITE_SIZE measured in THIS run (review, round 4: a committed record is reproducible but the
+    driver's run cannot vouch for it): two `rocprofv3 --pmc` passes -- one counter each, no trace beside them -- over a short run of this
+    same command (2 steps + 1 warm-up, no side measurements), parsed like tools/pmc_record.py does: the average over ALL column launches
+    (k_column_tp and k_column_la, weighted by dispatches), FETCH_SIZE doubled (gfx950 reports half of the bytes of wide coalesced
+    reads, MI355X_MICROARCH.md).  None when rocprofv3 is missing, a pass fails or takes more than four minutes, PS_BENCH_NO_LIVE_PMC=1,
+    or inside such a pass."""
+    import csv
+    import glob
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    if os.environ.get("PS_BENCH_NO_LIVE_PMC") == "1" or os.environ.get("PS_BENCH_PMC_CHILD") == "1":
+        return None
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    acc = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        tmp = tempfile.mkdtemp(prefix="ps_pmc_", dir="/tmp")
+        cmd = ([exe, "--pmc", counter, "--output-format", "csv", "-d", tmp, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__)]
+               + sys.argv[1:] + ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extra"])
+        proc = None
+        try:
+            proc = subprocess.Popen(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp", PS_BENCH_PMC_CHILD="1"), stdout=subprocess.DEVNULL,
+                                    stderr=subprocess.DEVNULL, start_new_session=True)
+            if proc.wait(timeout=240) != 0:
+                raise RuntimeError("rocprofv3 pass failed")
+            for path in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
+                with open(path) as fh:
+                    for row in csv.DictReader(fh):
+                        name = row.get("Kernel_Name") or row.get("Kernel Name") or ""
+                        kern = "k_column_tp" if "k_column_tp" in name else "k_column_la" if "k_column_la" in name else None
+                        if kern and (row.get("Counter_Name") or row.get("Counter Name")) == counter:
+                            a = acc.setdefault((kern, counter), [0.0, 0])
+                            a[0] += float(row.get("Counter_Value") or row.get("Counter Value") or 0)
+                            a[1] += 1
+        except Exception:
+            if proc is not None and proc.poll() is None:
+                try:
+                    os.killpg(proc.pid, signal.SIGKILL)   # (the session this call started, nothing else)
+                except OSError:
+                    pass
+            shutil.rmtree(tmp, ignore_errors=True)
+            return None
+        shutil.rmtree(tmp, ignore_errors=True)
+    kernels = sorted({k for k, _ in acc})
+    if not kernels or any((k, c) not in acc for k in kernels for c in ("FETCH_SIZE", "WRITE_SIZE")):
+        return None
+    per = {k: {"dispatches": acc[(k, "FETCH_SIZE")][1], "FETCH_SIZE_KB_mean": round(acc[(k, "FETCH_SIZE")][0] / acc[(k, "FETCH_SIZE")][1], 1),
+               "WRITE_SIZE_KB_mean": round(acc[(k, "WRITE_SIZE")][0] / acc[(k, "WRITE_SIZE")][1], 1)} for k in kernels}
+    n = sum(v["dispatches"] for v in per.values())
+    total = sum((2 * v["FETCH_SIZE_KB_mean"] + v["WRITE_SIZE_KB_mean"]) * 1024 * v["dispatches"] for v in per.values())
+    return {"traffic_bytes_per_launch": int(round(total / n)), "per_kernel": per,
+            "source": "measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, one pass each over this command with --steps 2 "
+                      "--warmup 1 (no trace beside the counters); average over all column launches; FETCH_SIZE x 2 (gfx950 correction)"}
 
 
 def latest_pmc_record(V):
@@ -648,6 +712,7 @@ def main():
     ap.add_argument("--cameras", choices=["mp3d", "demo"], default=None, help="Matterport-shaped (C5, default) or demo / RealEstate10K-shaped inputs (default for the circle)")
     ap.add_argument("--depth", choices=["smooth", "uniform"], default="smooth")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-live-pmc", action="store_true", help="roofline.traffic from the committed PMC record only (no rocprofv3 --pmc passes)")
     ap.add_argument("--no-extra", action="store_true", help="skip the C3 single-view / C2 splat-only side measurements")
     ap.add_argument("--dump-gather", metavar="NPZ", help="rank 0 saves what the last step gathered from all ranks (tests)")
     args = ap.parse_args()
@@ -743,7 +808,7 @@ def main():
                                  "forced_on_one_rank": bool(FORCE_COLLECTIVE and world == 1)}
         if world == 1:
             try:
-                res["roofline"] = measure_roofline(model, d, out, V)
+                res["roofline"] = measure_roofline(model, d, out, V, live_pmc=not args.no_extra and not args.no_live_pmc)
                 # the step as a whole against the same peak: every view is ONE whole-grid forward's worth of matrix work (SURVEY 8d:
                 # 11.43095 GFLOP, prefix pass + columns), whatever it is scheduled as; splat, planning and launch gaps count as time
                 step_tf = V * 11.43095e9 / (elapsed / args.steps) / 1e12
