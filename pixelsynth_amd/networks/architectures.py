@@ -363,11 +363,16 @@ def _f16x3_conv(conv, x, scale=None, shift=None, bias=None, res=None):
     cache = conv.__dict__.get("_ps_f16x3_cache")
     if cache is None or cache[0] != key:     # packed once per weight (with spectral norm in eval mode: per checkpoint, see _normalised_weight)
         wl = weight.detach().permute(0, 2, 3, 1).contiguous()          # (Co, 3, 3, Ci): no copy for a channels_last weight
-        packed = torch.empty(L.ps_conv3x3_f16x3_packed_bytes(Co, Ci), dtype=torch.uint8, device=x.device)
-        _lib.check(L.ps_conv3x3_f16x3_pack(wl.data_ptr(), Co, Ci, packed.data_ptr(), _stream()), "ps_conv3x3_f16x3_pack")
+        top = float(wl.abs().max())       # (synchronises -- once per weight) a weight fp16 cannot hold: this layer stays on torch
+        packed = None
+        if top == top and top < 6.0e4:
+            packed = torch.empty(L.ps_conv3x3_f16x3_packed_bytes(Co, Ci), dtype=torch.uint8, device=x.device)
+            _lib.check(L.ps_conv3x3_f16x3_pack(wl.data_ptr(), Co, Ci, packed.data_ptr(), _stream()), "ps_conv3x3_f16x3_pack")
         cache = (key, packed, weight)      # (the weight is kept alive: its address is the key)
         conv.__dict__["_ps_f16x3_cache"] = cache
     packed = cache[1]
+    if packed is None:
+        return None
     B, _, H, W = x.shape
     y = _empty_nhwc(B, Co, H, W, x)
     if res is not None and not (_is_nhwc_cuda(res) and res.shape == y.shape):

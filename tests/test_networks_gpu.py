@@ -197,6 +197,15 @@ def test_decoder_with_split_fp16_convolutions_equals_the_fp32_decoder(monkeypatc
     with pytest.raises(RuntimeError, match="fp16's range"):
         A.check_f16x3_overflow(x.device)
     A.check_f16x3_overflow(x.device)   # (the flag is cleared by the report)
+    # a WEIGHT fp16 cannot hold: that layer goes through torch (decided once, when the weight is packed), the others stay
+    conv = dec.eblocks[6].ch_a[5]
+    with torch.no_grad():
+        conv.weight_orig[0, 0, 0, 0] = 3.0e9      # (spectral norm divides by sigma ~ 3e9 * |u0 v0|: still a huge entry against the rest)
+        conv.weight_u.zero_(); conv.weight_u[0] = 1e-6; conv.weight_v.zero_(); conv.weight_v[0] = 1e-6
+        del calls[:]
+        out = dec(x, bgm, noise=noise)
+        A.check_f16x3_overflow(x.device)
+        assert len(calls) == 14 and conv.__dict__["_ps_f16x3_cache"][1] is None and out.shape == want.shape   # (asked twice: with and without the branch sum)
 
 
 def test_conv3x3_on_the_fp16_pipe_indexes_activations_beyond_4_gib():
