@@ -19,6 +19,10 @@
 //     as planes [hi | lo][k / 8][pixel][8 fp16]: an A fragment of any tap is one conflict-free ds_read_b128 at a shifted pixel;
 //   * the weights come packed in fragment order (ps_conv3x3_f16x3_pack) and reach LDS by LDS-DMA (global_load_lds_dwordx4), 16 KB
 //     per tap, three taps ahead in a ring of four buffers, waited for with counted s_waitcnt vmcnt; one raw barrier per tap.
+// Tuning builds (never the product library): -DPS_CONV_EXP=<bits> -- 1: no MFMAs, 2: fragments read once, 4: no barriers, 8: no weight
+// copies (1-8: results invalid, for timing what the rest costs), 16: every workgroup's shader cycles and 100 MHz ticks summed
+// (ps_conv_debug_clock; tools/conv_f16x3_time.py --clock); -DPS_CONV_NO_SCHED: no sched_group_barrier pattern.  PS_CONV_WGS (environment):
+// workgroups per launch.
 #include "ps_common.h"
 
 #include <algorithm>
