@@ -311,7 +311,7 @@ class ZbufferModelPts(nn.Module):
         eng = self.outpaint2.engine(self.obs[1], self.obs[2], V)
         if forced is None and uniforms is None:
             uniforms = torch.rand(V, L, device=gen_fs.device, dtype=torch.float32)
-        nsplit = self._prefix_split(V)
+        nsplit = self._prefix_split(V, busy=between is not None)
         if (between is None and nsplit == 1) or plan.waves[0].shape[0] == 0:
             eng.ar_run(c32, plan.order_loc, plan.region, plan.mask_init, plan.mask_undilated, plan.mask_dilated,
                        temperature=temperature, uniforms=uniforms, forced=forced, first_step=plan.first_step, waves=plan.waves)
@@ -348,12 +348,17 @@ class ZbufferModelPts(nn.Module):
     PREFIX_SPLIT_MIN_VIEWS = 64   # below this a launch of half the frames no longer fills the chip
     PREFIX_STREAMS = 2            # 128 views: 18.16 -> 17.95 ms per step (three alternating pairs); 4 ranges lose (18.59)
 
-    def _prefix_split(self, V):
+    def _prefix_split(self, V, busy=False):
         """Frame ranges the prefix pass of a V-view batch is dealt to (each on a stream of its own): PREFIX_STREAMS, or
         PS_PREFIX_STREAMS from the environment; 1 for batches too small to fill the chip twice over or not a multiple of 8 frames
-        per range (a range's frames are dealt to the 8 XCDs)."""
+        per range (a range's frames are dealt to the 8 XCDs).  busy: collectives are in flight beside the AR run (the caller passed
+        between=) -- with the runtime's default of four hardware queues one more stream then shares a queue with another and the step
+        gets SLOWER (19.5 against 18.4 ms), so the pass is split only when the process runs with GPU_MAX_HW_QUEUES >= 8 (18.1 ms;
+        bench.py sets it, tools/hwq_ab.sh measured it)."""
         import os
         n = int(os.environ.get("PS_PREFIX_STREAMS", self.PREFIX_STREAMS))
+        if busy and "PS_PREFIX_STREAMS" not in os.environ and int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) < 8:
+            n = 1
         return n if n > 1 and V >= self.PREFIX_SPLIT_MIN_VIEWS and V % (8 * n) == 0 else 1
 
     def _prefix_streams(self, n, device):
@@ -362,6 +367,9 @@ class ZbufferModelPts(nn.Module):
         key = (str(device), n)
         cache = self.__dict__.setdefault("_pfx_streams", {})
         if key not in cache:
+            import os
+            skip = int(os.environ.get("PS_PREFIX_STREAM_SKIP", "0"))    # tuning: streams created (and kept) in front of them
+            cache[("skip",) + key] = [torch.cuda.Stream(device=device) for _ in range(skip)]
             cache[key] = [torch.cuda.Stream(device=device) for _ in range(n)]
         return cache[key]
 
