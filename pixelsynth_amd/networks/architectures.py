@@ -574,7 +574,12 @@ class Unet(nn.Module):
             if self._DEC_NORM[i]:
                 setattr(self, self._DEC_NORM[i], norm(dec_out[i]))
 
+    MAX_BATCH = 64   # images per call on the GPU: dconv8 reads 64 channels at the input's size -- 2 GiB, where MIOpen's fp32 kernels start
+    #                  to index wrongly (_conv2d_batches), at 128 images of 256 x 256
+
     def forward(self, input):
+        if input.is_cuda and input.size(0) > self.MAX_BATCH and not torch.is_grad_enabled() and not self.training:
+            return torch.cat([self.forward(input[i:i + self.MAX_BATCH]) for i in range(0, input.size(0), self.MAX_BATCH)])
         skips, h = [], _nhwc(self, input)
         for i in range(8):
             h = getattr(self, f"conv{i + 1}")(h if i == 0 else F.leaky_relu(h, 0.2))

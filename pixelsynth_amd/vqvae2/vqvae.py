@@ -127,9 +127,14 @@ class VQVAETop(nn.Module):
         self.dec = Decoder(embed_dim, in_channel, channel, n_res_block, n_res_channel, stride=4)
 
     # ---------------------------------------------------------------- the novel-view path
+    MAX_BATCH = 256   # views per call on the GPU: the widest activation (64 channels at half the input's size) stays below the 2 GiB at
+    #                   which MIOpen's fp32 kernels start to index wrongly (networks/architectures.py:_conv2d_batches; 256 x 256 inputs)
+
     @torch.no_grad()
     def encode_codes(self, input):
         """(B,3,256,256) -> top codes (B,32,32) int32, on the device (= ``encode(input)[3]``, z_buffermodel.py:345)."""
+        if input.is_cuda and input.size(0) > self.MAX_BATCH:
+            return torch.cat([self.encode_codes(input[i:i + self.MAX_BATCH]) for i in range(0, input.size(0), self.MAX_BATCH)])
         lat = self.quantize_conv_t(self.enc_t(self.enc_b(input)))  # (B,64,32,32)
         B, _, H, W = lat.shape
         return self.quantize_t.nearest(lat.float(), 1, H * W).view(B, H, W)
@@ -137,6 +142,8 @@ class VQVAETop(nn.Module):
     @torch.no_grad()
     def decode_code(self, code_t):
         """codes (B,32,32) int -> image (B,3,256,256) (vqvae.py:305-311, z_buffermodel.py:250)."""
+        if code_t.is_cuda and code_t.size(0) > self.MAX_BATCH:
+            return torch.cat([self.decode_code(code_t[i:i + self.MAX_BATCH]) for i in range(0, code_t.size(0), self.MAX_BATCH)])
         return self.decode(self.quantize_t.embed_grid(code_t))
 
     # ---------------------------------------------------------------- reference-shaped surface
