@@ -381,6 +381,10 @@ int ps_conv3x3_thin_in_nhwc_f32(const float *x, const float *scale, const float 
                                 int Co, float *y, void *stream);
 int ps_conv3x3_thin_out_nhwc_f32(const float *x, const float *scale, const float *shift, const float *w, int B, int H, int W,
                                  int Ci, int Co, float *y, void *stream);
+/* ps_conv3x3_thin_in_f16x3_nhwc: the 4 -> 64 layer on the fp16 matrix pipe (split operands, three MFMAs per product, as
+ * ps_conv3x3_f16x3_nhwc; `overflow` likewise).  Co = 64, W a multiple of 16; w [3][3][4][64]. */
+int ps_conv3x3_thin_in_f16x3_nhwc(const float *x, const float *scale, const float *shift, const float *w, int B, int H, int W,
+                                  int Co, float *y, int *overflow, void *stream);
 
 #ifdef __cplusplus
 }

@@ -63,6 +63,7 @@ _PROTOS = {
     "ps_cat_mask_nhwc_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ps_noise_affine_f32": (c_int, [c_void_p] * 6 + [ctypes.c_float, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "ps_conv3x3_thin_in_nhwc_f32": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p, c_void_p]),
+    "ps_conv3x3_thin_in_f16x3_nhwc": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p, c_void_p, c_void_p]),
     "ps_conv3x3_thin_out_nhwc_f32": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p, c_void_p]),
     "ps_conv3x3_f16x3_packed_bytes": (ctypes.c_size_t, [c_int, c_int]),
     "ps_conv3x3_f16x3_pack": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),

@@ -12,6 +12,8 @@
 // folds it into the next pass, as for every convolution of the decoder.
 #include "ps_common.h"
 
+#include <algorithm>
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -120,9 +122,104 @@ template <int CO, bool FUSE> __global__ __launch_bounds__(256) void k_thin_out(c
     for (int k = 0; k < CO; ++k) yp[k] = acc[k];
 }
 
+// ---- 4 -> 64 on the fp16 matrix pipe (split operands as in csrc/conv_f16x3.hip: v = hi + lo, three MFMAs per product, fp32 sums).
+// K = 9 taps x 4 channels = 36, padded to two steps of v_mfma_f32_16x16x32_f16; a wave takes 16 consecutive pixels of a row per
+// tile: lane (m, kb) = (lane & 15, lane >> 4) holds A[m][8 kb .. 8 kb + 7] = the four channels of taps 2 kb and 2 kb + 1 at pixel m
+// (second step: tap 8 in kb = 0, zeros elsewhere), and, for each of the four 16-channel output tiles, B[8 kb ..][n] = the weights of
+// those (tap, channel) pairs for output channel n -- loaded and split once per wave, 64 registers.  D: column = lane & 15 = channel,
+// row = 4 (lane >> 4) + register = pixel.  w: [tap 9][ci 4][64].
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+template <bool FUSE> __global__ __launch_bounds__(256) void k_thin_in_mfma(const f32x4 *__restrict__ x, const f32x4 *__restrict__ scale,
+                                                                            const f32x4 *__restrict__ shift, const float *__restrict__ w,
+                                                                            float *__restrict__ y, int H, int W, int tiles_per_row, int ntiles,
+                                                                            int *__restrict__ overflow)
+{
+    constexpr int CO = 64;
+    const int lane = threadIdx.x & 63, m = lane & 15, kb = lane >> 4;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    int over = 0;
+    auto split = [&](const float (&v)[8], h8 &hi, h8 &lo) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            over |= !(__builtin_fabsf(v[j]) <= 65000.f);
+            hi[j] = (_Float16)v[j];
+            lo[j] = (_Float16)(v[j] - (float)hi[j]);
+        }
+    };
+    // the weights of this lane's (tap, channel) pairs, every output tile, both steps
+    h8 bh[4][2], bl[4][2];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = ks * 32 + kb * 8 + j;
+                v[j] = k < 36 ? w[(size_t)k * CO + nt * 16 + m] : 0.f;
+            }
+            split(v, bh[nt][ks], bl[nt][ks]);
+        }
+    for (int tile = wave; tile < ntiles; tile += nwaves) {
+        const int x0 = (tile % tiles_per_row) * 16, rowid = tile / tiles_per_row, b = rowid / H, oy = rowid - b * H, ox = x0 + m;
+        f32x4 sc = zero, sh = zero;
+        if (FUSE) { sc = scale[b]; sh = shift[b]; }
+        auto pixel = [&](int t) {   // the (normalised) input of tap t at this lane's pixel; zeros outside the image and beyond tap 8
+            f32x4 v = zero;
+            const int iy = oy + t / 3 - 1, ix = ox + t % 3 - 1;
+            if (t < 9 && iy >= 0 && iy < H && ix >= 0 && ix < W) {
+                v = x[((size_t)b * H + iy) * W + ix];
+                if (FUSE) v = __builtin_elementwise_max(v * sc - sh, zero);
+            }
+            return v;
+        };
+        const f32x4 p0 = pixel(2 * kb), p1 = pixel(2 * kb + 1), p2 = pixel(kb == 0 ? 8 : 9);
+        const float v0[8] = {p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3]};
+        const float v1[8] = {p2[0], p2[1], p2[2], p2[3], 0.f, 0.f, 0.f, 0.f};
+        h8 a0h, a0l, a1h, a1l;
+        split(v0, a0h, a0l);
+        split(v1, a1h, a1l);
+        float *yp = y + (((size_t)b * H + oy) * W + x0 + 4 * kb) * CO + m;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            f32x4 acc = zero;
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0l, bh[nt][0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0h, bl[nt][0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1l, bh[nt][1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1h, bl[nt][1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1h, bh[nt][1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0h, bh[nt][0], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) yp[(size_t)r * CO + nt * 16] = acc[r];
+        }
+    }
+    if (over) *overflow = 1;
+}
+
 }  // namespace
 
 extern "C" {
+
+int ps_conv3x3_thin_in_f16x3_nhwc(const float *x, const float *scale, const float *shift, const float *w, int B, int H, int W, int Co,
+                                  float *y, int *overflow, void *stream)
+{
+    PS_REQUIRE(x && w && y && overflow, "conv3x3_thin_in_f16x3: null pointer");
+    PS_REQUIRE((scale == nullptr) == (shift == nullptr), "conv3x3_thin_in_f16x3: scale and shift come together");
+    PS_REQUIRE(B > 0 && H > 0 && W > 0 && W % 16 == 0 && Co == 64, "conv3x3_thin_in_f16x3: W a multiple of 16 and Co = 64 required (W = %d, Co = %d)", W, Co);
+    const size_t nt = (size_t)B * H * (W / 16);
+    PS_REQUIRE(nt < ((size_t)1 << 31), "conv3x3_thin_in_f16x3: too many tiles");
+    const int grid = (int)std::min<size_t>((nt + 3) / 4, 256 * 8);
+    if (scale)
+        hipLaunchKernelGGL(k_thin_in_mfma<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const f32x4 *)x, (const f32x4 *)scale,
+                           (const f32x4 *)shift, w, y, H, W, W / 16, (int)nt, overflow);
+    else
+        hipLaunchKernelGGL(k_thin_in_mfma<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const f32x4 *)x, (const f32x4 *)nullptr,
+                           (const f32x4 *)nullptr, w, y, H, W, W / 16, (int)nt, overflow);
+    PS_LAUNCH_CHECK();
+    return PS_OK;
+}
 
 int ps_conv3x3_thin_in_nhwc_f32(const float *x, const float *scale, const float *shift, const float *w, int B, int H, int W, int Co,
                                 float *y, void *stream)

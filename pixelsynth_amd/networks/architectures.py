@@ -321,7 +321,8 @@ def _thin_conv(conv, x, scale=None, shift=None):
     thin_in, thin_out = Ci == 4 and Co % 4 == 0 and Co <= 256, Ci % 32 == 0 and 1 <= Co <= 4
     if not (conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1
             and (thin_in or thin_out) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
-            and x.is_contiguous(memory_format=torch.channels_last) and x.size(2) % 8 == 0 and x.size(3) % (64 if thin_in else 32) == 0
+            and x.is_contiguous(memory_format=torch.channels_last)
+            and ((thin_in and Co == 64 and x.size(3) % 16 == 0) or (x.size(2) % 8 == 0 and x.size(3) % (64 if thin_in else 32) == 0))
             and not torch.is_grad_enabled()):
         return None
     weight = _plain_conv_weight(conv, x)
@@ -338,7 +339,10 @@ def _thin_conv(conv, x, scale=None, shift=None):
     y = _empty_nhwc(B, Co, H, W, x)
     if Co == 1:   # (channels_last of one channel is ambiguous to torch; the kernel writes (B, H, W, Co))
         y = torch.empty((B, H, W, Co), dtype=x.dtype, device=x.device).permute(0, 3, 1, 2)
-    if thin_in:
+    if thin_in and Co == 64 and W % 16 == 0:   # on the fp16 matrix pipe (split operands): 82 instead of 270 us per 16 views
+        _lib.check(L.ps_conv3x3_thin_in_f16x3_nhwc(x.data_ptr(), _ptr(scale), _ptr(shift), cache[1].data_ptr(), B, H, W, Co, y.data_ptr(),
+                                                   _overflow_flag(x.device).data_ptr(), _stream()), "ps_conv3x3_thin_in_f16x3_nhwc")
+    elif thin_in:
         _lib.check(L.ps_conv3x3_thin_in_nhwc_f32(x.data_ptr(), _ptr(scale), _ptr(shift), cache[1].data_ptr(), B, H, W, Co, y.data_ptr(),
                                                  _stream()), "ps_conv3x3_thin_in_nhwc_f32")
     else:

@@ -322,3 +322,29 @@ def test_decoder_input_is_packed_in_one_pass():
         _lib.check(_lib.lib().ps_cat_mask_nhwc_f32(x.data_ptr(), bg.data_ptr(), B, H, W, out.data_ptr(), torch.cuda.current_stream().cuda_stream), "cat")
         want = torch.cat((x, (~bg).unsqueeze(1).float()), 1)
         assert torch.equal(out.permute(0, 3, 1, 2), want)
+
+
+@pytest.mark.parametrize("B,H,W,fuse", [(2, 16, 64, True), (3, 9, 48, False), (1, 256, 256, True)])
+def test_thin_in_on_the_fp16_pipe_against_an_fp64_convolution(B, H, W, fuse):
+    """ps_conv3x3_thin_in_f16x3_nhwc: the decoder's 4 -> 64 layer as split-fp16 MFMAs (K = 36 in two steps of v_mfma_f32_16x16x32_f16,
+    16 pixels of a row per tile) against torch's convolution in fp64: within 2e-6 of the output's largest magnitude, every border."""
+    from pixelsynth_amd import _lib
+    L, st = _lib.lib(), torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(H + W)
+    x = torch.randn(B, 4, H, W, generator=g).to(DEV)
+    w = (torch.randn(64, 4, 3, 3, generator=g) / 6).to(DEV)
+    sc = (torch.rand(B, 4, generator=g) + 0.5).to(DEV) if fuse else None
+    sh = (torch.randn(B, 4, generator=g) * 0.3).to(DEV) if fuse else None
+    xa = torch.clamp_min(x * sc.view(B, 4, 1, 1) - sh.view(B, 4, 1, 1), 0) if fuse else x
+    ref = torch.nn.functional.conv2d(xa.double(), w.double(), None, 1, 1)
+    xl, wl = x.permute(0, 2, 3, 1).contiguous(), w.permute(2, 3, 1, 0).contiguous()
+    y = torch.empty(B, H, W, 64, device=DEV)
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    p = lambda t: None if t is None else t.data_ptr()
+    _lib.check(L.ps_conv3x3_thin_in_f16x3_nhwc(xl.data_ptr(), p(sc), p(sh), wl.data_ptr(), B, H, W, 64, y.data_ptr(), flag.data_ptr(), st), "thin_in_f16x3")
+    err = (y.permute(0, 3, 1, 2).double() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 2e-6 and int(flag.item()) == 0, err
+    xl[0, 0, 0, 0] = 1e5
+    _lib.check(L.ps_conv3x3_thin_in_f16x3_nhwc(xl.data_ptr(), None, None, wl.data_ptr(), B, H, W, 64, y.data_ptr(), flag.data_ptr(), st), "thin_in_f16x3")
+    assert int(flag.item()) == 1
+    assert L.ps_conv3x3_thin_in_f16x3_nhwc(xl.data_ptr(), None, None, wl.data_ptr(), B, H, W, 32, y.data_ptr(), flag.data_ptr(), st) != 0
