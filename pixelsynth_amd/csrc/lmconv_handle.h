@@ -101,6 +101,9 @@ struct Tuning {
     int tp_affine = 1;           // throughput form: every neighbour XCD owns a fixed share of the STAGES (its ~3 MB of their weights stay in its L2
                                  // from launch to launch) instead of all XCDs walking all stages together: 378 -> 162 MB per launch at the L2's memory
                                  // side, the launch as long as before (122 us at 128 views; 151 -> 155 us at 256, where the neighbour role is the bound)
+    int tp_ct8_xcds = 3;         // throughput form: chain tiles of 8 columns (k_column_tp8) for launches whose tiles then fit this many XCDs (0: never)
+    int tp_pipe = 0;             // throughput form: the neighbour items request their operands a chunk ahead of their MFMAs (nbr_item_tp_pl)
+    int tp_pair = 1;             // throughput form: column tiles per neighbour item (2: every weight fragment feeds two tiles' MFMAs)
     int col_cap = COL_CAP;       // columns per latency-form launch
     int chain_xcds = 0;          // latency form: XCDs that hold chain workgroups (0 = automatic)
     int nbr_groups = 0;          // latency form: work items a neighbour workgroup runs at a time (0 = automatic)

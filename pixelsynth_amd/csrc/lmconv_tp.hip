@@ -23,7 +23,6 @@ namespace pslm {
 // The hand-off (write-through stores -> device-scope counter -> device-scope loads, bounded waits) is the one of k_column.
 // ==========================================================================================
 constexpr int TP_WAVES = 8, TP_THREADS = 64 * TP_WAVES;   // 8 waves: 256 registers per thread
-constexpr int TP_NPC = TP_COLS / TP_WAVES;   // columns a wave does the post op of
 constexpr int TP_MAXU = (50 + TP_WAVES - 1) / TP_WAVES;   // units per wave and stage at most: 7
 constexpr int TP_MINU = (25 + TP_WAVES - 1) / TP_WAVES;   // ... of a 25-unit stage: 4
 constexpr int XB_LD = 68;             // B-operand layout: dwords per 4-channel group (16 columns x 4 + 4 pad: conflict-free
@@ -43,11 +42,14 @@ struct TpArgs {
     const ColTaps *taps;      // records of this launch's columns
     float *nbr;               // [NST][2][TP_COL_CAP][NBR_LD]
     unsigned *cnt;            // [NST][TP_MAX_TILES] padded completion counters (tp_cnt_index), never reset
-    int nwork, tiles, nbr_wgs;
+    int nwork, tiles, nbr_wgs;   // (tiles: the neighbour role's 16-column tiles)
+    int ctiles;                 // chain tiles: of 16 columns (k_column_tp) or of 8 (k_column_tp8)
     int chain_xcds, fill_nbr;   // placement (k_column_tp): XCDs that hold the chain tiles; first neighbour index of their spare CUs or -1
     // stage-affine neighbour XCDs (0: all XCDs walk all stages): nx neighbour XCDs; XCD xi owns entries xent[xi * TP_XENT_MAX + k], k < xlen[xi],
     // of which the first xlo[xi] lie below the look-ahead depth
     int affine_nx;
+    int pair;                   // column tiles per neighbour item: 1 or 2 (tuning value tp_pair)
+    int pipe;                   // 1: nbr_item_tp_pl (operand loads a chunk ahead; one tile per item)
     const int *xent;
     int xlen[8], xlo[8];
     // chain role (fields as in ChainArgs)
@@ -92,9 +94,115 @@ struct TpArgs {
 #ifndef PS_TP_POLL_SLEEP
 #define PS_TP_POLL_SLEEP 100
 #endif
-template <int T, int NG, bool AHEAD>
+template <int T, int NG, bool AHEAD, int TC>
 __device__ __forceinline__ void nbr_item_tp(const NbrWorkTp &wk, const TpArgs &a, int ctile, int lane)
 {
+    // TC column tiles (ctile, ctile + 1) share every weight fragment: per (tap, five channel groups) TC x 5 row loads and T x 5 weight
+    // loads feed TC x T x 20 MFMAs -- at TC = 2 a third fewer vector-memory instructions per MFMA than one tile at a time (the CU's
+    // vector-memory path, ~41 B/clk whoever issues, is what the role runs against).  Same chains, same order: the same bits.
+    const int i = lane & 15, kk = lane >> 4;
+    const ColTaps *const taps = AHEAD ? a.taps_next : a.taps;
+    const int ncols = AHEAD ? a.ncols_next : a.ncols;
+    const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    int col[TC];
+    bool valid[TC];
+    i32x4 rows[TC];
+#pragma unroll
+    for (int c = 0; c < TC; ++c) {
+        col[c] = (ctile + c) * TP_COLS + i;
+        valid[c] = col[c] < ncols;
+        rows[c] = i32x4{-1, -1, -1, -1};
+        if (valid[c]) rows[c] = *PS_GC(i32x4, &taps[col[c]].row[wk.kind][wk.half * 4]);
+    }
+    const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc((void *)wk.in, 0, 0x7fffffff, 0x00020000);
+    f32x4 tot[TC][T];
+#pragma unroll
+    for (int c = 0; c < TC; ++c)
+#pragma unroll
+        for (int u = 0; u < T; ++u) tot[c][u] = zero;
+    const size_t gstride = (size_t)16 * wk.Co_pad;   // floats between channel groups of the packed weights
+#pragma unroll
+    for (int tq = 0; tq < 4; ++tq) {
+        int row[TC];
+        bool live[TC];
+        unsigned long long open[TC], any = 0ull;
+#pragma unroll
+        for (int c = 0; c < TC; ++c) {
+            row[c] = rows[c][tq];
+            live[c] = row[c] >= 0;
+            open[c] = __builtin_amdgcn_ballot_w64(live[c]);
+            any |= open[c];
+        }
+        if (any == 0ull) continue;   // (a closed tap is an exact zero)
+        // closed lanes read (and drop) a row that is being read anyway
+        int safe[TC];
+#pragma unroll
+        for (int c = 0; c < TC; ++c) {
+            const int src_c = open[c] != 0ull ? c : (TC - 1 - c);
+            safe[c] = __shfl(row[src_c], __builtin_ctzll(open[src_c]), 64);
+        }
+        const int t = wk.half * 5 + tq;
+        const float *wbase = wk.w + (size_t)t * NG * gstride + ((size_t)kk * wk.Co_pad + wk.o0 + i) * 4;
+        Acc5 acc[TC][T];
+#pragma unroll
+        for (int c = 0; c < TC; ++c)
+#pragma unroll
+            for (int u = 0; u < T; ++u) acc[c][u] = acc5_zero();
+#pragma unroll
+        for (int g0 = 0; g0 < NG; g0 += 5) {
+            f32x4 bv[TC][5];
+#pragma unroll
+            for (int c = 0; c < TC; ++c) {
+                const int r = live[c] ? row[c] : safe[c];
+                if (AHEAD && NG == 5) {
+                    const int voff = (r * wk.in_ld + 4 * kk) * 4;
+#pragma unroll
+                    for (int g = 0; g < 5; ++g)
+                        bv[c][g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(irs, voff + 64 * (g0 + g), 0, 16 /* sc1 */));
+                } else {
+                    const float *src = wk.in + (size_t)r * wk.in_ld + 4 * kk;
+#pragma unroll
+                    for (int g = 0; g < 5; ++g) bv[c][g] = *PS_GC(f32x4, src + 16 * (g0 + g));
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < TC; ++c)
+#pragma unroll
+                for (int g = 0; g < 5; ++g) bv[c][g] = live[c] ? bv[c][g] : zero;   // (mask values are 0 / 1: no multiply needed)
+#pragma unroll
+            for (int u = 0; u < T; ++u) {
+                f32x4 av[5];
+#pragma unroll
+                for (int g = 0; g < 5; ++g) av[g] = *PS_GC(f32x4, wbase + (size_t)(g0 + g) * gstride + 64 * u);
+#pragma unroll
+                for (int c = 0; c < TC; ++c) mfma_chunk5(av, bv[c], acc[c][u]);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < TC; ++c)
+#pragma unroll
+            for (int u = 0; u < T; ++u) tot[c][u] = tot[c][u] + chunk_total(acc[c][u]);
+    }
+#pragma unroll
+    for (int c = 0; c < TC; ++c) {
+        if (!valid[c]) continue;
+        float *dst = (AHEAD ? a.nbr_next : a.nbr) + (((size_t)wk.stage * 2 + wk.half) * TP_COL_CAP + col[c]) * NBR_LD + wk.o0 + kk * 4;
+#pragma unroll
+        for (int u = 0; u < T; ++u) store_through(dst + 16 * u, tot[c][u]);
+    }
+}
+
+// The same item with its operand loads a CHUNK AHEAD of its MFMAs.  A chunk = (open tap, five channel groups): 5 row loads + T x 5
+// weight loads for T x 20 MFMAs.  nbr_item_tp issues a chunk's loads and waits for them on the spot -- ~700 cycles of L2 latency in
+// front of 640-1280 cycles of MFMAs, hidden only by the other wave of the SIMD.  Here two register sets alternate: the loads of
+// chunk c + 1 go out before the MFMAs of chunk c.  Static wait counts need the same number of loads on every path, so
+// the last chunk "prefetches" itself again (L1 / L2 hits, dropped) and the loop has no conditional loads.  Chains, channel order and
+// the order of the taps are nbr_item_tp's: the same bits.
+template <int T, int NG, bool AHEAD>
+__device__ __forceinline__ void nbr_item_tp_pl(const NbrWorkTp &wk, const TpArgs &a, int ctile, int lane)
+{
+    constexpr int CPT = NG / 5;   // chunks per tap
     const int i = lane & 15, kk = lane >> 4;
     const int col = ctile * TP_COLS + i;
     const bool valid = col < (AHEAD ? a.ncols_next : a.ncols);
@@ -104,52 +212,103 @@ __device__ __forceinline__ void nbr_item_tp(const NbrWorkTp &wk, const TpArgs &a
     i32x4 rows = {-1, -1, -1, -1};
     if (valid) rows = *PS_GC(i32x4, &taps[col].row[wk.kind][wk.half * 4]);
     const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc((void *)wk.in, 0, 0x7fffffff, 0x00020000);
+    // the open taps of the tile, in tap order (wave-uniform)
+    int ot[4] = {0, 0, 0, 0}, nopen = 0;
+#pragma unroll
+    for (int tq = 0; tq < 4; ++tq) {
+        const bool o = __builtin_amdgcn_ballot_w64(rows[tq] >= 0) != 0ull;
+        if (o) {
+            if (nopen == 0) ot[0] = tq; else if (nopen == 1) ot[1] = tq; else if (nopen == 2) ot[2] = tq; else ot[3] = tq;
+            ++nopen;
+        }
+    }
+    nopen = uni(nopen);
     f32x4 tot[T];
 #pragma unroll
     for (int u = 0; u < T; ++u) tot[u] = zero;
-    const size_t gstride = (size_t)16 * wk.Co_pad;   // floats between channel groups of the packed weights
-#pragma unroll
-    for (int tq = 0; tq < 4; ++tq) {
-        const int row = rows[tq];
-        const bool live = row >= 0;
-        const unsigned long long open = __builtin_amdgcn_ballot_w64(live);
-        if (open == 0ull) continue;   // (a closed tap is an exact zero)
-        const int safe = __shfl(row, __builtin_ctzll(open), 64);   // closed lanes read (and drop) a row that is being read anyway
-        const int t = wk.half * 5 + tq;
-        const float *src = wk.in + (size_t)(live ? row : safe) * wk.in_ld + 4 * kk;
-        const float *wbase = wk.w + (size_t)t * NG * gstride + ((size_t)kk * wk.Co_pad + wk.o0 + i) * 4;
-        Acc5 acc[T];
-#pragma unroll
-        for (int u = 0; u < T; ++u) acc[u] = acc5_zero();
-#pragma unroll
-        for (int g0 = 0; g0 < NG; g0 += 5) {
-            f32x4 bv[5];
+    if (nopen > 0) {
+        const size_t gstride = (size_t)16 * wk.Co_pad;   // floats between channel groups of the packed weights
+        const int nch = nopen * CPT;
+        struct Chunk { f32x4 bv[5]; f32x4 av[T][5]; bool live; };
+        auto request = [&](Chunk &ck, int c) {   // chunk c (clamped to the last one), always 5 + 5 T loads
+            c = min(c, nch - 1);
+            const int k = c / CPT, g0 = 5 * (c - k * CPT);
+            const int tq = uni(k == 0 ? ot[0] : k == 1 ? ot[1] : k == 2 ? ot[2] : ot[3]);
+            const int row = tq == 0 ? rows[0] : tq == 1 ? rows[1] : tq == 2 ? rows[2] : rows[3];
+            ck.live = row >= 0;
+            const unsigned long long open = __builtin_amdgcn_ballot_w64(ck.live);
+            const int safe = __shfl(row, __builtin_ctzll(open), 64);   // closed lanes read (and drop) a row that is being read anyway
+            const int r = ck.live ? row : safe;
             if (AHEAD && NG == 5) {
-                const int voff = ((live ? row : safe) * wk.in_ld + 4 * kk) * 4;
+                const int voff = (r * wk.in_ld + 4 * kk) * 4;
 #pragma unroll
                 for (int g = 0; g < 5; ++g)
-                    bv[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(irs, voff + 64 * (g0 + g), 0, 16 /* sc1 */));
+                    ck.bv[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(irs, voff + 64 * (g0 + g), 0, 16 /* sc1 */));
             } else {
+                const float *src = wk.in + (size_t)r * wk.in_ld + 4 * kk + 16 * g0;
 #pragma unroll
-                for (int g = 0; g < 5; ++g) bv[g] = *PS_GC(f32x4, src + 16 * (g0 + g));
+                for (int g = 0; g < 5; ++g) ck.bv[g] = *PS_GC(f32x4, src + 16 * g);
             }
+            const float *wb = wk.w + ((size_t)(wk.half * 5 + tq) * NG + g0) * gstride + ((size_t)kk * wk.Co_pad + wk.o0 + i) * 4;
 #pragma unroll
-            for (int g = 0; g < 5; ++g) bv[g] = live ? bv[g] : zero;   // (mask values are 0 / 1: no multiply needed)
+            for (int u = 0; u < T; ++u)
 #pragma unroll
-            for (int u = 0; u < T; ++u) {
-                f32x4 av[5];
+                for (int g = 0; g < 5; ++g) ck.av[u][g] = *PS_GC(f32x4, wb + (size_t)g * gstride + 64 * u);
+            __builtin_amdgcn_sched_barrier(0);   // (the requests stay in front of the MFMAs that follow)
+        };
+        Acc5 acc[T];
+        auto products = [&](Chunk &ck, int c) {
+            if (c % CPT == 0) {
 #pragma unroll
-                for (int g = 0; g < 5; ++g) av[g] = *PS_GC(f32x4, wbase + (size_t)(g0 + g) * gstride + 64 * u);
-                mfma_chunk5(av, bv, acc[u]);
+                for (int u = 0; u < T; ++u) acc[u] = acc5_zero();
             }
+            f32x4 b[5];
+#pragma unroll
+            for (int g = 0; g < 5; ++g) b[g] = ck.live ? ck.bv[g] : zero;   // (mask values are 0 / 1: no multiply needed)
+#pragma unroll
+            for (int u = 0; u < T; ++u) mfma_chunk5(ck.av[u], b, acc[u]);
+            if (c % CPT == CPT - 1) {
+#pragma unroll
+                for (int u = 0; u < T; ++u) tot[u] = tot[u] + chunk_total(acc[u]);
+            }
+        };
+        Chunk c0, c1;
+        request(c0, 0);
+        for (int c = 0; c < nch; c += 2) {
+            request(c1, c + 1);
+            products(c0, c);
+            request(c0, c + 2);
+            if (c + 1 < nch) products(c1, c + 1);
         }
-#pragma unroll
-        for (int u = 0; u < T; ++u) tot[u] = tot[u] + chunk_total(acc[u]);
     }
     if (valid) {
         float *dst = (AHEAD ? a.nbr_next : a.nbr) + (((size_t)wk.stage * 2 + wk.half) * TP_COL_CAP + col) * NBR_LD + wk.o0 + kk * 4;
 #pragma unroll
         for (int u = 0; u < T; ++u) store_through(dst + 16 * u, tot[u]);
+    }
+}
+
+template <bool AHEAD>
+__device__ __forceinline__ void nbr_item_dispatch(const NbrWorkTp &wk, const TpArgs &a, int ctile, int lane, bool two)
+{
+    if (a.pipe) {
+        if (wk.T == 2) {
+            if (wk.NG == 10) nbr_item_tp_pl<2, 10, AHEAD>(wk, a, ctile, lane); else nbr_item_tp_pl<2, 5, AHEAD>(wk, a, ctile, lane);
+        } else {
+            if (wk.NG == 10) nbr_item_tp_pl<1, 10, AHEAD>(wk, a, ctile, lane); else nbr_item_tp_pl<1, 5, AHEAD>(wk, a, ctile, lane);
+        }
+    } else if (two) {
+        if (wk.T == 2) {
+            if (wk.NG == 10) nbr_item_tp<2, 10, AHEAD, 2>(wk, a, ctile, lane); else nbr_item_tp<2, 5, AHEAD, 2>(wk, a, ctile, lane);
+        } else {
+            if (wk.NG == 10) nbr_item_tp<1, 10, AHEAD, 2>(wk, a, ctile, lane); else nbr_item_tp<1, 5, AHEAD, 2>(wk, a, ctile, lane);
+        }
+    } else {
+        if (wk.T == 2) {
+            if (wk.NG == 10) nbr_item_tp<2, 10, AHEAD, 1>(wk, a, ctile, lane); else nbr_item_tp<2, 5, AHEAD, 1>(wk, a, ctile, lane);
+        } else {
+            if (wk.NG == 10) nbr_item_tp<1, 10, AHEAD, 1>(wk, a, ctile, lane); else nbr_item_tp<1, 5, AHEAD, 1>(wk, a, ctile, lane);
+        }
     }
 }
 
@@ -173,8 +332,10 @@ __device__ __forceinline__ void nbr_role_tp(const TpArgs &a, int nb)
     const int e_own0 = nx ? (a.w_from ? a.xlo[xi] : 0) : a.w_from, e_own1 = nx ? a.xlen[xi] : a.nwork;
     const int e_ahead1 = nx ? (a.w_upto ? a.xlo[xi] : 0) : a.w_upto;
     const int *xe = nx ? a.xent + (size_t)xi * TP_XENT_MAX : nullptr;
-    const int n_own = (e_own1 - e_own0) * a.tiles;
-    const int nitems = n_own + e_ahead1 * a.tiles_next;
+    // an item = a work-table entry x `pair` consecutive column tiles (nbr_item_tp's TC; the last one of an odd count alone)
+    const int pair = a.pair, tgroups = (a.tiles + pair - 1) / pair, tgroups_next = (a.tiles_next + pair - 1) / pair;
+    const int n_own = (e_own1 - e_own0) * tgroups;
+    const int nitems = n_own + e_ahead1 * tgroups_next;
     __shared__ unsigned sReadyTp;   // look-ahead stages some wave of this workgroup has seen published, + 1
     if (threadIdx.x == 0) sReadyTp = 0;
     __syncthreads();
@@ -183,12 +344,13 @@ __device__ __forceinline__ void nbr_role_tp(const TpArgs &a, int nb)
         const bool ahead = item >= n_own;
         int witem, ctile;
         if (!ahead) {
-            const int q = item / a.tiles;
-            witem = e_own0 + q; ctile = item - q * a.tiles;
+            const int q = item / tgroups;
+            witem = e_own0 + q; ctile = (item - q * tgroups) * pair;
         } else {
             const int j = item - n_own;
-            witem = j / a.tiles_next; ctile = j - witem * a.tiles_next;
+            witem = j / tgroups_next; ctile = (j - witem * tgroups_next) * pair;
         }
+        const bool two = pair == 2 && ctile + 1 < (ahead ? a.tiles_next : a.tiles);
         if (nx) witem = xe[witem];
         NbrWorkTp wk;
         {   // wave-uniform record: scalar loads
@@ -225,25 +387,23 @@ __device__ __forceinline__ void nbr_role_tp(const TpArgs &a, int nb)
                 ready_upto = (int)val - 1;
             }
             asm volatile("" ::: "memory");
-            if (wk.T == 2) {
-                if (wk.NG == 10) nbr_item_tp<2, 10, true>(wk, a, ctile, lane); else nbr_item_tp<2, 5, true>(wk, a, ctile, lane);
-            } else {
-                if (wk.NG == 10) nbr_item_tp<1, 10, true>(wk, a, ctile, lane); else nbr_item_tp<1, 5, true>(wk, a, ctile, lane);
-            }
+            nbr_item_dispatch<true>(wk, a, ctile, lane, two);
             signal_done(a.cnt_next + tp_cnt_index(wk.stage, ctile), lane);
+            if (two && lane == 0) __hip_atomic_fetch_add(a.cnt_next + tp_cnt_index(wk.stage, ctile + 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
-            if (wk.T == 2) {
-                if (wk.NG == 10) nbr_item_tp<2, 10, false>(wk, a, ctile, lane); else nbr_item_tp<2, 5, false>(wk, a, ctile, lane);
-            } else {
-                if (wk.NG == 10) nbr_item_tp<1, 10, false>(wk, a, ctile, lane); else nbr_item_tp<1, 5, false>(wk, a, ctile, lane);
-            }
+            nbr_item_dispatch<false>(wk, a, ctile, lane, two);
             signal_done(a.cnt + tp_cnt_index(wk.stage, ctile), lane);
+            if (two && lane == 0) __hip_atomic_fetch_add(a.cnt + tp_cnt_index(wk.stage, ctile + 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
 
-__device__ __forceinline__ void chain_role_tp(const TpArgs &a, int tile)
+// NPC = columns a wave does the post op of: 2 = tiles of 16 columns, 1 = tiles of 8 (the MFMA phase is what it is for 16 -- the N of the
+// MFMA --, the post phase and the stores are half: for launches whose tiles then still fit three XCDs; run_columns_tp)
+template <int NPC>
+__device__ __forceinline__ void chain_role_tp(const TpArgs &a, int ctile)
 {
+    constexpr int CT = NPC * TP_WAVES;   // columns of a chain tile
     // (Both 16-byte-accessed buffers are DECLARED as 16-byte elements: behind a float array and a run-time index hipcc cannot
     // prove the alignment and splits every ds_read_b128 / ds_write_b128 into two ds_read2_b32 -- which, at a lane stride of
     // four dwords, is an 8-way bank conflict on every operand read: the MFMA phase took 2-3x its MFMA time.)
@@ -262,8 +422,9 @@ __device__ __forceinline__ void chain_role_tp(const TpArgs &a, int tile)
 #else
     constexpr bool dbg_nostore = false, dbg_noops = false, dbg_norefill = false, dbg_nopost = false;
 #endif
-    const int col0 = tile * TP_COLS;
-    const int ncl = min(TP_COLS, a.ncols - col0);   // columns of this tile (>= 1)
+    const int col0 = ctile * CT;
+    const int ncl = min(CT, a.ncols - col0);   // columns of this tile (>= 1)
+    const int tile = col0 / TP_COLS;           // the neighbour role's 16-column tile these columns lie in: its counters, its use counts
     {
         const int nq = (int)(sizeof(StepCtx) / 16);
         for (int k = t; k < TP_COLS * nq; k += TP_THREADS) {
@@ -288,14 +449,14 @@ __device__ __forceinline__ void chain_role_tp(const TpArgs &a, int tile)
     const bool own = lane < PONO_LANES;
     const int c2 = own ? 2 * lane : 0;
     const f32x2 zero2 = {0.0f, 0.0f};
-    bool pvalid[TP_NPC];
-    int pcol[TP_NPC], pfr[TP_NPC];
-    size_t ploc[TP_NPC];
-    f32x2 ucur[TP_NPC];
+    bool pvalid[NPC];
+    int pcol[NPC], pfr[NPC];
+    size_t ploc[NPC];
+    f32x2 ucur[NPC];
 #pragma unroll
-    for (int k = 0; k < TP_NPC; ++k) ucur[k] = zero2;
+    for (int k = 0; k < NPC; ++k) ucur[k] = zero2;
 #pragma unroll
-    for (int k = 0; k < TP_NPC; ++k) {
+    for (int k = 0; k < NPC; ++k) {
         pcol[k] = wave + TP_WAVES * k;
         pvalid[k] = pcol[k] < ncl;
         pfr[k] = uni(sC[pcol[k]].f);
@@ -332,21 +493,21 @@ __device__ __forceinline__ void chain_role_tp(const TpArgs &a, int tile)
     auto plain = [](const float *p) { return *PS_GC(f32x2, p); };
     // PONO + finish of BOTH columns of this wave (independent instruction streams, interleaved by the compiler) and the
     // hand-off: next stage's input into the B-operand layout, values to the caches.  KIND / HAS_SKIP are compile-time.
-    auto emit2 = [&](const f32x2 (&y)[TP_NPC], const f32x2 (&g)[TP_NPC], const f32x2 (&skip)[TP_NPC], auto KINDc, auto SKIPc, int in_form, int save_slot,
+    auto emit2 = [&](const f32x2 (&y)[NPC], const f32x2 (&g)[NPC], const f32x2 (&skip)[NPC], auto KINDc, auto SKIPc, int in_form, int save_slot,
                      const StoreCtl &sc) {
         constexpr int kind = decltype(KINDc)::value;
         constexpr bool has_skip = decltype(SKIPc)::value;
-        float mean[TP_NPC], inv[TP_NPC];
-        f32x2 d[TP_NPC];
+        float mean[NPC], inv[NPC];
+        f32x2 d[NPC];
 #pragma unroll
-        for (int k = 0; k < TP_NPC; ++k) mean[k] = pono_mean(pono_total(y[k], own));
+        for (int k = 0; k < NPC; ++k) mean[k] = pono_mean(pono_total(y[k], own));
 #pragma unroll
-        for (int k = 0; k < TP_NPC; ++k) d[k] = y[k] - mean[k];
+        for (int k = 0; k < NPC; ++k) d[k] = y[k] - mean[k];
 #pragma unroll
-        for (int k = 0; k < TP_NPC; ++k) inv[k] = pono_inv(pono_total(d[k] * d[k], own));
+        for (int k = 0; k < NPC; ++k) inv[k] = pono_inv(pono_total(d[k] * d[k], own));
         if (!own) return;
 #pragma unroll
-        for (int k = 0; k < TP_NPC; ++k) {
+        for (int k = 0; k < NPC; ++k) {
             const f32x2 n = d[k] * inv[k];
             f32x2 out;
             if (kind == PRO_CONVIN) out = post_finish<POST_CONVIN>(n, zero2, skip[k], has_skip, zero2);
@@ -380,7 +541,7 @@ __device__ __forceinline__ void chain_role_tp(const TpArgs &a, int tile)
     auto stage_skip_input = [&](int skip_slot) {
         if (skip_slot < 0 || !own) return;
 #pragma unroll
-        for (int k = 0; k < TP_NPC; ++k) {
+        for (int k = 0; k < NPC; ++k) {
             const int col = pcol[k];
             f32x2 ep, en;
             celu_pair2(*(const f32x2 *)(&sU[skip_slot][col][c2]), ep, en);
@@ -396,8 +557,8 @@ __device__ __forceinline__ void chain_role_tp(const TpArgs &a, int tile)
 #ifdef PS_TP_TRACE_BUILD
     int trace_s = 0;
     const int trace_wave = a.debug >> 8;   // column_debug = 256 * wave (+ mode): the wave whose stamps are kept
-#define TP_STAMP(slot) do { if (a.trace && tile == 0 && t == 64 * trace_wave) a.trace[s * 8 + (slot)] = clock64(); } while (0)
-#define TP_STAMP2(slot, dep) do { if (a.trace && tile == 0 && t == 64 * trace_wave && (dep)) a.trace[trace_s * 8 + (slot)] = clock64(); } while (0)
+#define TP_STAMP(slot) do { if (a.trace && ctile == 0 && t == 64 * trace_wave) a.trace[s * 8 + (slot)] = clock64(); } while (0)
+#define TP_STAMP2(slot, dep) do { if (a.trace && ctile == 0 && t == 64 * trace_wave && (dep)) a.trace[trace_s * 8 + (slot)] = clock64(); } while (0)
 #else
 #define TP_STAMP(slot) do { } while (0)
 #define TP_STAMP2(slot, dep) do { } while (0)
@@ -499,7 +660,7 @@ __device__ __forceinline__ void chain_role_tp(const TpArgs &a, int tile)
         const int nty = fi(cvB, CTL_TP_TYPE);
         const float *nbase = fpf(cvB, CTL_WTP) + ((size_t)wave * tpt_nu(nty) * 2 * 64 + lane) * 4;
         // operands of this stage's post op: y = ((bias + NA) + centre) + NB (+ gate half, + nin_skip bias); they land under the MFMAs
-        f32x2 ob = zero2, obg = zero2, ob2 = zero2, ona[TP_NPC], onb[TP_NPC], onag[TP_NPC], onbg[TP_NPC];
+        f32x2 ob = zero2, obg = zero2, ob2 = zero2, ona[NPC], onb[NPC], onag[NPC], onbg[NPC];
         auto request_operands = [&]() {
             wait_counter(cnt_have, s, items);
             cnt_have = counter(min(s + 1, NST - 2));             // looked at a stage later
@@ -509,7 +670,7 @@ __device__ __forceinline__ void chain_role_tp(const TpArgs &a, int tile)
             if (kind == PRO_GATE) obg = plain(pc.bias + NF + c2);
             if (has_skip) ob2 = plain(pc.bias2 + c2);
 #pragma unroll
-            for (int k = 0; k < TP_NPC; ++k) {
+            for (int k = 0; k < NPC; ++k) {
                 const float *nb = a.nbr + (size_t)s * nbr_stage + (size_t)(col0 + (pvalid[k] ? pcol[k] : 0)) * NBR_LD + c2;
                 ona[k] = fresh(nb);
                 onb[k] = fresh(nb + nbr_half);
@@ -543,12 +704,12 @@ __device__ __forceinline__ void chain_role_tp(const TpArgs &a, int tile)
             return chain_total(*(const f32x2 *)p, *(const f32x2 *)(p + stride), *(const f32x2 *)(p + 2 * stride),
                                *(const f32x2 *)(p + 3 * stride), *(const f32x2 *)(p + 4 * stride));
         };
-        f32x2 y[TP_NPC], g[TP_NPC], skip[TP_NPC];
+        f32x2 y[NPC], g[NPC], skip[NPC];
 #pragma unroll
-        for (int k = 0; k < TP_NPC; ++k) { g[k] = zero2; skip[k] = zero2; }
+        for (int k = 0; k < NPC; ++k) { g[k] = zero2; skip[k] = zero2; }
         if (dbg_nopost) { cvA = cvB; cvB = cvC; lds_barrier(); return; }
 #pragma unroll
-        for (int k = 0; k < TP_NPC; ++k) {
+        for (int k = 0; k < NPC; ++k) {
             const float *P = &sP[pcol[k] * SP_LD + c2];
             y[k] = slot_sum2(ob, ona[k], five(P, Co), onb[k]);
             if (kind == PRO_GATE) g[k] = slot_sum2(obg, onag[k], five(P + NF, Co), onbg[k]);
@@ -580,9 +741,9 @@ __device__ __forceinline__ void chain_role_tp(const TpArgs &a, int tile)
             for (int u = 0; u < TP_MINU; ++u) { WA[u].a0 = *PS_GC(f32x4, b0p + (size_t)(2 * u) * 256); WA[u].a1 = *PS_GC(f32x4, b0p + (size_t)(2 * u + 1) * 256); }
         }
         cnt_have = counter(0);
-        f32x2 y[TP_NPC];
+        f32x2 y[NPC];
 #pragma unroll
-        for (int k = 0; k < TP_NPC; ++k) {
+        for (int k = 0; k < NPC; ++k) {
             const StepCtx &cx = sC[pcol[k]];
             float mA[9];
             int ncode[9], nl[9];
@@ -594,9 +755,9 @@ __device__ __forceinline__ void chain_role_tp(const TpArgs &a, int tile)
             for (int tp = 0; tp < 9; ++tp) ncode[tp] = nl[tp] >= 0 ? ncode[tp] : UINIT_CLOSED;
             y[k] = uinit_from_codes<f32x2>(ncode, mA, a.uinit_w, a.uinit_b, c2);
         }
-        f32x2 z2[TP_NPC];
+        f32x2 z2[NPC];
 #pragma unroll
-        for (int k = 0; k < TP_NPC; ++k) z2[k] = zero2;
+        for (int k = 0; k < NPC; ++k) z2[k] = zero2;
         emit2(y, z2, z2, std::integral_constant<int, PRO_UINIT>{}, std::integral_constant<bool, false>{}, pc.in_form, pc.save_slot, sc);
         stage_skip_input(sc.skip_slot);
     }
@@ -627,7 +788,7 @@ __device__ __forceinline__ void chain_role_tp(const TpArgs &a, int tile)
     }
     lds_barrier();
 #pragma unroll
-    for (int k = 0; k < TP_NPC; ++k) {
+    for (int k = 0; k < NPC; ++k) {
         if (!pvalid[k]) continue;
         float lg[8];
         const float *Lp = &sP[pcol[k] * SLOG_LD + lane * 8];
@@ -656,24 +817,26 @@ __device__ __forceinline__ void chain_role_tp(const TpArgs &a, int tile)
 // chain_xcds = cx > 0 (speed only; block b runs on XCD b % 8): the chain tiles are the blocks on XCDs 0 .. cx-1, whose L2s then
 // hold the 2.8 MB of centre-tap weights instead of sharing their bandwidth with the neighbour role's operand stream; every
 // other block is a neighbour workgroup (the spare CUs of the chain XCDs too when fill is set).
-#define CHAIN_ROLE_TP chain_role_tp
-__global__ __launch_bounds__(TP_THREADS) void k_column_tp(TpArgs a)
+template <int NPC>
+__device__ __forceinline__ void column_tp_body(const TpArgs &a)
 {
     const int b = blockIdx.x, cx = a.chain_xcds;
     if (cx == 0) {
         if (b < a.nbr_wgs) { if ((a.debug & 3) != 3) nbr_role_tp(a, b); }
-        else if ((a.debug & 3) != 2) CHAIN_ROLE_TP(a, b - a.nbr_wgs);
+        else if ((a.debug & 3) != 2) chain_role_tp<NPC>(a, b - a.nbr_wgs);
         return;
     }
     const int x = b & 7, slot = b >> 3;
     if (x < cx) {
         const int tile = slot * cx + x;
-        if (tile < a.tiles) { if ((a.debug & 3) != 2) CHAIN_ROLE_TP(a, tile); }
-        else if (a.fill_nbr >= 0 && (a.debug & 3) != 3) nbr_role_tp(a, a.fill_nbr + (tile - a.tiles));
+        if (tile < a.ctiles) { if ((a.debug & 3) != 2) chain_role_tp<NPC>(a, tile); }
+        else if (a.fill_nbr >= 0 && (a.debug & 3) != 3) nbr_role_tp(a, a.fill_nbr + (tile - a.ctiles));
     } else if ((a.debug & 3) != 3) {
         nbr_role_tp(a, slot * (8 - cx) + (x - cx));
     }
 }
+__global__ __launch_bounds__(TP_THREADS) void k_column_tp(TpArgs a) { column_tp_body<2>(a); }    // chain tiles of 16 columns
+__global__ __launch_bounds__(TP_THREADS) void k_column_tp8(TpArgs a) { column_tp_body<1>(a); }   // chain tiles of 8 columns
 
 // (ot, j, nin_skip?) of unit n of a stage with Co output channels: main units tile-major, then nin_skip's
 __device__ __host__ __forceinline__ void tp_unit_of(int n, int Co, int &ot, int &j, bool &skip)
@@ -722,7 +885,7 @@ void run_columns_tp(ps_pixelcnn *h, const StepCtx *rec, int ncols, const ChainAr
         h->columns_launched = true;
         TpArgs ta{};
         ta.work = h->work_tp; ta.nwork = h->nwork_tp;
-        ta.done = h->done_tp; ta.split = tp_ahead;
+        ta.done = h->done_tp; ta.split = tp_ahead; ta.pipe = h->tune.tp_pipe; ta.pair = ta.pipe ? 1 : h->tune.tp_pair;
         const size_t nbr_half_buf = (size_t)NST * 2 * TP_COL_CAP * NBR_LD, cnt_half_buf = tp_cnt_index(NST, 0);
         ta.ctl1 = h->ctl1; ta.uinit_w = h->uinit_w; ta.uinit_b = h->uinit_b; ta.codes_in = ca.codes_in;
         ta.out_w = h->out_w; ta.out_b = h->out_b; ta.L = h->L;
@@ -740,7 +903,11 @@ void run_columns_tp(ps_pixelcnn *h, const StepCtx *rec, int ncols, const ChainAr
         for (int done = 0; done < ncols; done += cap) {
             const int n = std::min(cap, ncols - done);
             const int tiles = (n + TP_COLS - 1) / TP_COLS;
-            ta.taps = taps + done; ta.ctx = rec + done; ta.ncols = n; ta.tiles = tiles;
+            // chain tiles of 8 columns (k_column_tp8) while they fit tp_ct8_xcds XCDs: the post phase and the stores of a stage are half
+            const int rows_ = h->n_cus / 8;
+            const bool ct8 = h->tune.tp_ct8_xcds > 0 && h->tune.tp_xcds != 0 && h->xcd_even && (n + 7) / 8 <= h->tune.tp_ct8_xcds * rows_;
+            const int ctiles = ct8 ? (n + 7) / 8 : tiles;
+            ta.taps = taps + done; ta.ctx = rec + done; ta.ncols = n; ta.tiles = tiles; ta.ctiles = ctiles;
             // did the launch in front prepare this one?  then its slots of the stages [0, split) are in the buffers of `par`
             const bool prepared = tp_ahead > 0 && h->ahead_rec == rec + done && h->ahead_n == n;
             const int par = prepared ? h->ahead_parity : 0;
@@ -758,7 +925,7 @@ void run_columns_tp(ps_pixelcnn *h, const StepCtx *rec, int ncols, const ChainAr
             ta.ncols_next = ahead ? nn : 0;
             ta.tiles_next = ahead ? (nn + TP_COLS - 1) / TP_COLS : 1;
             ta.publish_upto = ahead ? tp_ahead : 0;
-            if (ahead) h->done_total += (unsigned)tiles;
+            if (ahead) h->done_total += (unsigned)ctiles;
             ta.done_target = h->done_total;
             for (int t = 0; t < tiles; ++t) {
                 if (!prepared) h->tile_uses_tp_lo[par][t] += 1;
@@ -776,10 +943,10 @@ void run_columns_tp(ps_pixelcnn *h, const StepCtx *rec, int ncols, const ChainAr
             // kernels of OTHER streams that hold CUs for a while (bench.py / driver.py overlap the next batch's ~2 ms of splat
             // kernels with this run) delay a launch, they cannot starve it past the bound.
             const int rows = h->n_cus / 8;   // CUs per XCD
-            if (h->tune.tp_xcds != 0 && h->xcd_even && tiles <= 4 * rows) {
-                const int cx = h->tune.tp_xcds > 0 ? std::max(h->tune.tp_xcds, (tiles + rows - 1) / rows) : (tiles + rows - 1) / rows;
+            if (h->tune.tp_xcds != 0 && h->xcd_even && ctiles <= 4 * rows) {
+                const int cx = h->tune.tp_xcds > 0 ? std::max(h->tune.tp_xcds, (ctiles + rows - 1) / rows) : (ctiles + rows - 1) / rows;
                 ta.chain_xcds = std::min(cx, 7);
-                const int spare = ta.chain_xcds * rows - tiles;
+                const int spare = ta.chain_xcds * rows - ctiles;
                 const int use_rows = rows;
                 ta.nbr_wgs = (8 - ta.chain_xcds) * use_rows;
                 ta.fill_nbr = -1;
@@ -794,12 +961,15 @@ void run_columns_tp(ps_pixelcnn *h, const StepCtx *rec, int ncols, const ChainAr
                 grid = use_rows * 8;
             } else {
                 ta.chain_xcds = 0; ta.fill_nbr = -1; ta.affine_nx = 0;
-                ta.nbr_wgs = std::max(1, std::min(h->n_cus - tiles, (h->nwork_tp * tiles + TP_WAVES - 1) / TP_WAVES));
-                grid = ta.nbr_wgs + tiles;
+                ta.nbr_wgs = std::max(1, std::min(h->n_cus - ctiles, (h->nwork_tp * tiles + TP_WAVES - 1) / TP_WAVES));
+                grid = ta.nbr_wgs + ctiles;
             }
             ta.trace = (trace_sel < 0 || trace_sel == h->tp_launch_no) ? h->tp_trace : nullptr;
             h->tp_launch_no += 1;
-            timed(h, st, TAG_CHAIN, [&]() { hipLaunchKernelGGL(k_column_tp, dim3(grid), dim3(TP_THREADS), 0, st, ta); });
+            timed(h, st, TAG_CHAIN, [&]() {
+                if (ct8) hipLaunchKernelGGL(k_column_tp8, dim3(grid), dim3(TP_THREADS), 0, st, ta);
+                else hipLaunchKernelGGL(k_column_tp, dim3(grid), dim3(TP_THREADS), 0, st, ta);
+            });
         }
     }
 }
