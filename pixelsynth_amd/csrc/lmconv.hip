@@ -152,7 +152,7 @@ const TuningEntry tuning_table[] = {
     {"prefix_full", &Tuning::prefix_full, 0, 1}, {"prefix_cone_force", &Tuning::prefix_cone_force, 0, 1},
     {"tp_ahead", &Tuning::tp_ahead, 0, NST - 2}, {"col_ahead", &Tuning::col_ahead, 0, NST - 4},
     {"tp_min_cols", &Tuning::tp_min_cols, 1, 1 << 30}, {"tp_xcds", &Tuning::tp_xcds, -1, 7}, {"tp_fill", &Tuning::tp_fill, 0, 1},
-    {"tp_affine", &Tuning::tp_affine, 0, 1}, {"tp_pair", &Tuning::tp_pair, 1, 2}, {"tp_pipe", &Tuning::tp_pipe, 0, 1}, {"tp_ct8_xcds", &Tuning::tp_ct8_xcds, 0, 4},
+    {"tp_affine", &Tuning::tp_affine, 0, 1}, {"tp_ct8_xcds", &Tuning::tp_ct8_xcds, 0, 4},
     {"col_cap", &Tuning::col_cap, 1, COL_CAP}, {"chain_xcds", &Tuning::chain_xcds, 0, 8}, {"nbr_groups", &Tuning::nbr_groups, 0, NBR_MAX_GROUPS},
 #ifdef PS_TUNING_BUILD   // timing experiments whose results are INVALID (1: chains do not wait for the neighbour slots, 2: no chains, 3: no
     {"column_debug", &Tuning::column_debug, 0, 1 << 20},   // neighbour role and no waiting; + 256 x the traced wave): tuning builds only
@@ -246,7 +246,7 @@ int build_stage_table(ps_pixelcnn *h)
             for (int half = 0; half < 2; ++half)
                 for (int cog = 0; cog < Co / 16; ++cog) work.push_back(NbrWork{w, in, s, half, cog, NG, Co, in_ld, dil, mask_kind});
         if (has_nbr) {   // throughput form: two output tiles per item where the stage has them
-            const int step = 32;   // (one output tile per item in the first stages was measured no faster)
+            const int step = 32;   // (one output tile per item in the first stages, and all 80 channels of a half per item, were measured slower)
             for (int half = 0; half < 2; ++half)
                 for (int o0 = 0; o0 < Co; o0 += step)
                     work_tp.push_back(NbrWorkTp{w, in, s, half, o0, (step == 32 && o0 + 32 <= Co) ? 2 : 1, NG, Co, in_ld, mask_kind - 1});

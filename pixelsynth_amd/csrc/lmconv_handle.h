@@ -93,7 +93,7 @@ struct Tuning {
                                  // order, 1 = one sort over all frames, 2 = one per XCD share of the frames (the rows of a frame stay in one L2)
     int prefix_full = 0;         // 1: the prefix pass evaluates every item (no dependency-cone elimination)
     int prefix_cone_force = 0;   // 1: keep the elimination on when the caller asks for logits (parity tests: walked locations only)
-    int tp_ahead = 12;           // stages [0, tp_ahead) of a throughput-form launch are computed by the launch in front of it (0: off)
+    int tp_ahead = 16;           // stages [0, tp_ahead) of a throughput-form launch are computed by the launch in front of it (0: off)
     int col_ahead = 16;          // the same for the latency form (0: off -- k_column as before)
     int tp_min_cols = 2 * COL_CAP + 1;   // a wavefront of up to 256 columns is two latency-form launches rather than one throughput-form launch
     int tp_xcds = -1;            // 0 = chain tiles anywhere, -1 = on as few XCDs as hold them, n = on at least n XCDs
@@ -102,8 +102,6 @@ struct Tuning {
                                  // from launch to launch) instead of all XCDs walking all stages together: 378 -> 162 MB per launch at the L2's memory
                                  // side, the launch as long as before (122 us at 128 views; 151 -> 155 us at 256, where the neighbour role is the bound)
     int tp_ct8_xcds = 3;         // throughput form: chain tiles of 8 columns (k_column_tp8) for launches whose tiles then fit this many XCDs (0: never)
-    int tp_pipe = 0;             // throughput form: the neighbour items request their operands a chunk ahead of their MFMAs (nbr_item_tp_pl)
-    int tp_pair = 1;             // throughput form: column tiles per neighbour item (2: every weight fragment feeds two tiles' MFMAs)
     int col_cap = COL_CAP;       // columns per latency-form launch
     int chain_xcds = 0;          // latency form: XCDs that hold chain workgroups (0 = automatic)
     int nbr_groups = 0;          // latency form: work items a neighbour workgroup runs at a time (0 = automatic)

@@ -612,6 +612,16 @@ def test_throughput_form_look_ahead_depths_are_bit_identical_to_the_walk(ahead):
         eng.check()
         eng.set_tuning(tp_affine=1 - eng.get_tuning("tp_affine"))
         assert torch.equal(c_walk, c_aff) and torch.equal(l_walk, l_aff), (F_, first, cap, "affine")
+        # chain tiles of 8 columns (k_column_tp8: a wave's post phase is one column; launches whose tiles fit tp_ct8_xcds XCDs) against
+        # tiles of 16 (k_column_tp) -- and both with the spare compute units of the chain XCDs dealt to the neighbour shares (tp_fill)
+        ct8 = eng.get_tuning("tp_ct8_xcds")
+        for other, fill in ((0 if ct8 else 3, 0), (3, 1), (4, 0)):
+            eng.set_tuning(tp_ct8_xcds=other, tp_fill=fill)
+            c_ct = tt(codes0.copy())
+            l_ct = eng.ar_run(c_ct, tt(order_loc), tt(reg), *ms, temperature=0.7, uniforms=u, first_step=first, want_logits=True, waves=waves)
+            eng.check()
+            assert torch.equal(c_walk, c_ct) and torch.equal(l_walk, l_ct), (F_, first, cap, "tiles of 8 columns", other, fill)
+        eng.set_tuning(tp_ct8_xcds=ct8, tp_fill=0)
 
 
 @pytest.mark.parametrize("ahead", ["0", "5", "28"])
