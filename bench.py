@@ -111,13 +111,20 @@ def front(model, d):
     return model.plan_views(d["img"], d["depth"], d["K"], d["Kinv"], d["P"], d["Pinv"], d["RT2"], d["RT2inv"])
 
 
-def back(model, d, planned, world, prev=None):
+def back(model, d, planned, world, prev=None, pipelined=False):
     """Second half: the AR run (asynchronous), then the path's only collective.
     prev: the previous step's result, whose gathers are still in flight: the stream waits for them between this step's prefix
     pass and its first column launch (see finish_gathers)."""
-    out = model.outpaint_planned(planned, d["codes"], temperature=0.7, uniforms=d["uniforms"],
-                                 between=(lambda: finish_gathers(prev)) if prev is not None and "_gathers" in prev else None)
-    if world > 1 or FORCE_COLLECTIVE:  # what the path produced on every rank -- the reprojected views as 8-bit images (the byte volume of finished
+    between = (lambda: finish_gathers(prev)) if prev is not None and "_gathers" in prev else None
+    if pipelined:   # the result is the PREVIOUS step's batch, whose last wavefronts ran inside this step's first launches (None: first step)
+        out = model.outpaint_pipelined(planned, d["codes"], temperature=0.7, uniforms=d["uniforms"], between=between)
+    else:
+        out = model.outpaint_planned(planned, d["codes"], temperature=0.7, uniforms=d["uniforms"], between=between)
+    return start_gathers(out, world)
+
+
+def start_gathers(out, world):
+    if out is not None and (world > 1 or FORCE_COLLECTIVE):  # what the path produced on every rank -- the reprojected views as 8-bit images (the byte volume of finished
         # frames: the VQ-VAE decode that turns codes into pixels is a next-row component, timed under end_to_end_*) and the
         # completed 32x32 code grids -- RCCL all_gather over xGMI.  Started here as asynchronous collectives, collected by
         # finish_gathers() in the NEXT step, between its whole-grid prefix pass and its first column launch: 25 MB per rank and
@@ -151,6 +158,7 @@ def run_steps(model, d, world, n, side):
     """
     main = torch.cuda.current_stream()
     planned, out = None, None
+    pipelined = ar_pipelined(d["codes"].shape[0])
     for i in range(n):
         if planned is None:
             planned = front(model, d)
@@ -164,7 +172,7 @@ def run_steps(model, d, world, n, side):
         gate = torch.cuda.Event()
         gate.record(main)
         t0 = time.perf_counter()
-        prev, out = out, back(model, d, planned, world, prev=out)
+        prev, out = out, back(model, d, planned, world, prev=out, pipelined=pipelined)
         finish_gathers(prev)      # (a step without column launches has not collected them)
         t1 = time.perf_counter()
         planned = None
@@ -177,7 +185,17 @@ def run_steps(model, d, world, n, side):
             main.wait_stream(side)
         if HOST_TIMES is not None:   # PS_BENCH_HOST_TIMES=1: where the host thread spends a step (enqueueing the AR run; the next step's front)
             HOST_TIMES.append((t0, t1, time.perf_counter()))
+    if pipelined:   # the last batch's tail wavefronts, as launches of their own: the n steps are complete when this call returns
+        finish_gathers(out)
+        out = start_gathers(model.outpaint_flush(), world)
     return finish_gathers(out)
+
+
+def ar_pipelined(V):
+    """The AR runs of consecutive steps overlapped (z_buffermodel.outpaint_pipelined) -- batches that take the throughput form of the
+    column launch; PS_BENCH_AR_PIPELINE=0 runs every step's AR run on its own."""
+    from pixelsynth_amd.lmconv.model import TP_MIN_FRAMES
+    return os.environ.get("PS_BENCH_AR_PIPELINE", "1") != "0" and V >= TP_MIN_FRAMES
 
 
 def measure_roofline(model, d, out, V, live_pmc=False):
@@ -192,21 +210,49 @@ def measure_roofline(model, d, out, V, live_pmc=False):
     --pmc passes of this command), otherwise it, and always `mfma_counters` and `kernel_table`, come from the newest committed PMC record
     of the same workload (profiles/README.md names it) -- counter passes cannot run inside a timed bench."""
     plan = out["plan"]
-    eng = model.outpaint2.engine(32, 32, V)
+    pipelined = ar_pipelined(V)
     cols, wave_start = plan.waves
     ncols = int(cols.shape[0])
     launches, total_ms, fpc = ctypes.c_int(0), ctypes.c_float(0.0), ctypes.c_double(0.0)
     us_list = []
-    for _ in range(3):
-        c32 = d["codes"].reshape(V, 1024).to(torch.int32).contiguous().clone()
-        rc = _lib.lib().ps_pixelcnn_time_ar_run_waves(
-            eng.handle, _lib.ptr(c32), _lib.ptr(plan.order_loc), _lib.ptr(plan.region), _lib.ptr(plan.mask_init),
-            _lib.ptr(plan.mask_undilated), _lib.ptr(plan.mask_dilated), _lib.ptr(d["uniforms"]), 0.7, V, plan.first_step,
-            _lib.ptr(cols), _lib.ptr(wave_start), len(wave_start) - 1, ctypes.cast(ctypes.byref(launches), ctypes.c_void_p),
-            ctypes.cast(ctypes.byref(total_ms), ctypes.c_void_p), ctypes.cast(ctypes.byref(fpc), ctypes.c_void_p),
-            _lib.current_stream())
-        _lib.check(rc, "ps_pixelcnn_time_ar_run_waves")
-        us_list.append(total_ms.value * 1e3 / max(1, launches.value))
+    byref = lambda v: ctypes.cast(ctypes.byref(v), ctypes.c_void_p)
+    if pipelined:
+        # The column launches of ONE STEADY-STATE STEP of the pipelined form: the tail wavefronts of one batch inside the launches of
+        # the next batch's head wavefronts.  Timed inside a two-batch run of the same views in a 2 V-frame handle (batch B = batch A):
+        # head A | tail A + head B | tail B -- only the middle section's launches count: exactly one batch's columns.
+        from pixelsynth_amd.lmconv.model import merge_schedules, split_tail
+        eng = model.outpaint2.engine(32, 32, 2 * V)
+        hc, ws = plan.waves_host, plan.waves[1]
+        cut = split_tail(ws, model.PIPE_MERGE_MAX)
+        off = np.array([V, 0], np.int32)
+        mid_c, mid_w = merge_schedules(hc[ws[cut]:], ws[cut:] - ws[cut], hc[:ws[cut]] + off, ws[:cut + 1], model.PIPE_CAP)
+        all_c = np.ascontiguousarray(np.concatenate([hc[:ws[cut]], mid_c, hc[ws[cut]:] + off]), np.int32)
+        all_w = np.ascontiguousarray(np.concatenate([ws[:cut + 1], ws[cut] + mid_w[1:], ws[cut] + mid_w[-1] + (ws[cut + 1:] - ws[cut])]), np.int32)
+        assert all_w[-1] == 2 * ncols and mid_w[-1] == ncols
+        dcols = torch.from_numpy(all_c).to(d["codes"].device)
+        two = lambda t: torch.cat([t, t]).contiguous()
+        arrs = [two(plan.order_loc), two(plan.region), two(plan.mask_init), two(plan.mask_undilated), two(plan.mask_dilated), two(d["uniforms"])]
+        w0, w1 = cut, cut + len(mid_w) - 1
+        for _ in range(3):
+            c32 = two(d["codes"].reshape(V, 1024).to(torch.int32))
+            rc = _lib.lib().ps_pixelcnn_time_ar_run_waves_range(
+                eng.handle, _lib.ptr(c32), *[_lib.ptr(a) for a in arrs[:5]], _lib.ptr(arrs[5]), 0.7, 2 * V, plan.first_step,
+                _lib.ptr(dcols), _lib.ptr(all_w), len(all_w) - 1, w0, w1, byref(launches), byref(total_ms), byref(fpc), _lib.current_stream())
+            _lib.check(rc, "ps_pixelcnn_time_ar_run_waves_range")
+            us_list.append(total_ms.value * 1e3 / max(1, launches.value))
+        assert torch.equal(c32[:V], c32[V:])     # (the staggered batch drew what the other did)
+        n_wavefronts = len(mid_w) - 1
+    else:
+        eng = model.outpaint2.engine(32, 32, V)
+        for _ in range(3):
+            c32 = d["codes"].reshape(V, 1024).to(torch.int32).contiguous().clone()
+            rc = _lib.lib().ps_pixelcnn_time_ar_run_waves(
+                eng.handle, _lib.ptr(c32), _lib.ptr(plan.order_loc), _lib.ptr(plan.region), _lib.ptr(plan.mask_init),
+                _lib.ptr(plan.mask_undilated), _lib.ptr(plan.mask_dilated), _lib.ptr(d["uniforms"]), 0.7, V, plan.first_step,
+                _lib.ptr(cols), _lib.ptr(wave_start), len(wave_start) - 1, byref(launches), byref(total_ms), byref(fpc), _lib.current_stream())
+            _lib.check(rc, "ps_pixelcnn_time_ar_run_waves")
+            us_list.append(total_ms.value * 1e3 / max(1, launches.value))
+        n_wavefronts = len(wave_start) - 1
     us = sorted(us_list)[1]
     cols_per_launch = ncols / max(1, launches.value)
     fl = fpc.value * cols_per_launch
@@ -225,7 +271,10 @@ def measure_roofline(model, d, out, V, live_pmc=False):
     kernel = ("k_column_tp (throughput form of the column launch, one launch per wavefront of up to 1024 independent AR columns: "
               "16-column MFMA chain tiles + one wave per neighbour item, the neighbour role a launch ahead of the chain tiles; "
               "wavefronts of up to 256 columns as two launches of the latency form k_column_la -- the average is over all "
-              "column launches of the AR run)" if tp else
+              "column launches of the AR run"
+              + ("; the AR runs of consecutive steps overlap -- the narrow last wavefronts of a batch run inside the launches of the next "
+                 "batch's first ones (z_buffermodel.outpaint_pipelined): the launches timed are those of one steady-state step)" if pipelined else ")")
+              if tp else
               "k_column (one launch per wavefront of independent AR columns: per-column centre-tap chains + "
               "neighbour-tap slots of all 32 masked convs)")
     return {"bound": "mfma", "kernel": kernel,
@@ -233,7 +282,8 @@ def measure_roofline(model, d, out, V, live_pmc=False):
             "frac": round(tf / FP32_MFMA_PEAK_TF, 6), "traffic": traffic, "traffic_source": traffic_src, "mfma_counters": mfma_util,
             "algorithmic_flops_per_launch": round(fl), "avg_launch_us": round(us, 3),
             "flops_per_column": round(fpc.value), "columns_per_launch": round(cols_per_launch, 2),
-            "launches_per_ar_run": launches.value, "wavefronts": len(wave_start) - 1, "columns": ncols,
+            "launches_per_ar_run": launches.value, "wavefronts": n_wavefronts, "columns": ncols,
+            "ar_runs_overlapped": bool(pipelined), "wavefronts_of_a_batch_alone": len(wave_start) - 1,
             "pmc_live": live, "traffic_committed_record": (pmc or {}).get("traffic_bytes_per_launch"),
             "kernel_table": kernel_table,
             "kernel_table_note": "every kernel alone on the chip (PMC and trace passes with PS_PREFIX_STREAMS=1); the default step deals "
@@ -811,7 +861,10 @@ def main():
                        "sampled_codes_per_view_mean": round(float(np.mean(plan.n_sampled)), 1),
                        "parallelism": f"views sharded over {world} GPU(s), RCCL all_gather of the reprojected views (8-bit) + completed code grids",
                        "step_pipeline": "the AR run on one stream, its whole-grid prefix pass dealt to two frame ranges on two streams; the host half of "
-                                        "step i + 1 (splat, planning, uploads) on a side stream"},
+                                        "step i + 1 (splat, planning, uploads) on a side stream"
+                                        + ("; the narrow last wavefronts of step i's AR run inside the launches of step i + 1's first wavefronts (both "
+                                           "batches resident in one engine handle; the timed region ends with the last step's tail flushed: exactly "
+                                           "`steps` complete steps)" if ar_pipelined(V) else "")},
         }
         if torch.distributed.is_available() and torch.distributed.is_initialized():   # what the backend itself reports (tools/scale.sh)
             res["collective"] = {"backend": torch.distributed.get_backend(), "world_size": torch.distributed.get_world_size(),

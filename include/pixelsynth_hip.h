@@ -236,7 +236,12 @@ int ps_pixelcnn_ar_run_waves(ps_pixelcnn *h, int32_t *codes, const int32_t *orde
  *                           Disjoint frame ranges are independent -- they may be issued on different streams;
  *   ps_pixelcnn_ar_columns  the column launches of all F frames (schedule as for ps_pixelcnn_ar_run_waves), after every frame's
  *                           prefix pass has completed (the caller orders the streams).
- * Together they do exactly what ps_pixelcnn_ar_run_waves(..., out_logits = NULL, ...) does. */
+ * Together they do exactly what ps_pixelcnn_ar_run_waves(..., out_logits = NULL, ...) does.
+ * ps_pixelcnn_ar_columns also takes a schedule that holds only PART of the run's columns (any (frame, position) pairs with position >=
+ * first_step, wave by wave): the caller then answers for the dependencies -- every column a column reads (earlier positions of its
+ * frame) was walked by an earlier wave or call.  Callers use it to run the narrow last wavefronts of one batch of frames inside the
+ * launches of the next batch's first wavefronts (both batches resident in one handle: pixelsynth_amd/z_buffermodel.py,
+ * outpaint_pipelined). */
 int ps_pixelcnn_ar_prefix(ps_pixelcnn *h, int32_t *codes, const int32_t *order, const uint8_t *sample_region,
                           const float *mask_init, const float *mask_undilated, const float *mask_dilated, int F,
                           int first_step, int frame_begin, int frame_end, void *stream);

@@ -32,6 +32,15 @@ int ps_pixelcnn_time_ar_run_waves(ps_pixelcnn *h, int32_t *codes, const int32_t 
                                   const float *uniforms, float temperature, int F, int first_step,
                                   const int32_t *wave_cols, const int32_t *wave_start, int n_waves,
                                   int *launches, float *total_ms, double *flops_per_column, void *stream);
+/* ... counting only the launches of the wavefronts [wave_from, wave_to) of the schedule (bench.py: one steady-state step of the
+ * pipelined form -- the last wavefronts of one batch inside the launches of the next batch's first ones -- within a two-batch run). */
+int ps_pixelcnn_time_ar_run_waves_range(ps_pixelcnn *h, int32_t *codes, const int32_t *order,
+                                        const uint8_t *sample_region, const float *mask_init,
+                                        const float *mask_undilated, const float *mask_dilated,
+                                        const float *uniforms, float temperature, int F, int first_step,
+                                        const int32_t *wave_cols, const int32_t *wave_start, int n_waves,
+                                        int wave_from, int wave_to, int *launches, float *total_ms,
+                                        double *flops_per_column, void *stream);
 
 /* Debugging aid (tools/tp_debug.py): device address of one of the handle's
  * activation caches -- what 0: raw u of node idx (19 nodes, row stride 96 floats), 1: concat_elu(u) of node idx (160),

@@ -44,6 +44,7 @@ _PROTOS = {
     "ps_stream_create_cu_range": (c_int, [c_int, c_int, c_void_p]),
     "ps_stream_destroy": (c_int, [c_void_p]),
     "ps_pixelcnn_time_ar_run_waves": (c_int, [c_void_p] * 8 + [c_float, c_int, c_int, c_void_p, c_void_p, c_int] + [c_void_p] * 4),
+    "ps_pixelcnn_time_ar_run_waves_range": (c_int, [c_void_p] * 8 + [c_float, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int] + [c_void_p] * 4),
     "ps_ar_wavefronts": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "ps_ar_wavefronts_capped": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "ps_pixelcnn_status": (c_int, [c_void_p, c_void_p]),

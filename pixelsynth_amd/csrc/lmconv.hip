@@ -152,7 +152,7 @@ const TuningEntry tuning_table[] = {
     {"prefix_full", &Tuning::prefix_full, 0, 1}, {"prefix_cone_force", &Tuning::prefix_cone_force, 0, 1},
     {"tp_ahead", &Tuning::tp_ahead, 0, NST - 2}, {"col_ahead", &Tuning::col_ahead, 0, NST - 4},
     {"tp_min_cols", &Tuning::tp_min_cols, 1, 1 << 30}, {"tp_xcds", &Tuning::tp_xcds, -1, 7}, {"tp_fill", &Tuning::tp_fill, 0, 1},
-    {"tp_affine", &Tuning::tp_affine, 0, 1}, {"tp_ct8_xcds", &Tuning::tp_ct8_xcds, 0, 4},
+    {"tp_affine", &Tuning::tp_affine, 0, 1}, {"tp_ct8_xcds", &Tuning::tp_ct8_xcds, 0, 4}, {"tp_ct8_cols", &Tuning::tp_ct8_cols, 0, 1024},
     {"col_cap", &Tuning::col_cap, 1, COL_CAP}, {"chain_xcds", &Tuning::chain_xcds, 0, 8}, {"nbr_groups", &Tuning::nbr_groups, 0, NBR_MAX_GROUPS},
 #ifdef PS_TUNING_BUILD   // timing experiments whose results are INVALID (1: chains do not wait for the neighbour slots, 2: no chains, 3: no
     {"column_debug", &Tuning::column_debug, 0, 1 << 20},   // neighbour role and no waiting; + 256 x the traced wave): tuning builds only
@@ -578,8 +578,10 @@ static int ar_run_impl(ps_pixelcnn *h, int32_t *codes, const int32_t *order, con
         PS_REQUIRE(wave_start && n_waves >= 0 && wave_start[0] == 0, "pixelcnn_ar_run_waves: bad schedule");
         for (int w = 0; w < n_waves; ++w)
             PS_REQUIRE(wave_start[w + 1] >= wave_start[w], "pixelcnn_ar_run_waves: wave_start must not decrease");
-        PS_REQUIRE(wave_start[n_waves] == F * nsteps, "pixelcnn_ar_run_waves: the schedule holds %d columns, the run has %d",
-                   wave_start[n_waves], F * nsteps);
+        // (a whole run walks every column once; ps_pixelcnn_ar_columns alone also takes PART of them -- callers that run the narrow last
+        // wavefronts of one batch inside the launches of the next batch's first ones)
+        PS_REQUIRE(phases == AR_COLUMNS ? wave_start[n_waves] <= F * nsteps : wave_start[n_waves] == F * nsteps,
+                   "pixelcnn_ar_run_waves: the schedule holds %d columns, the run has %d", wave_start[n_waves], F * nsteps);
     }
     hipStream_t st = (hipStream_t)stream;
     const Masks m{mask_init, mask_undilated, mask_dilated};
@@ -595,7 +597,7 @@ static int ar_run_impl(ps_pixelcnn *h, int32_t *codes, const int32_t *order, con
     ChainArgs ca{};
     ca.codes = codes; ca.region = sample_region; ca.forced = forced; ca.uniforms = uniforms;
     ca.out_logits = out_logits; ca.temperature = temperature;
-    const int total = F * nsteps;
+    const int total = wave_cols ? wave_start[n_waves] : F * nsteps;
     if (total > 0)
         hipLaunchKernelGGL(k_ctx_build, dim3(total), dim3(32), 0, st, make_ctx_args(h, order, m, F), wave_cols, total, first_step,
                            h->H, h->W, h->err);
@@ -609,6 +611,7 @@ static int ar_run_impl(ps_pixelcnn *h, int32_t *codes, const int32_t *order, con
             int nx = w + 1;
             while (nx < n_waves && wave_start[nx + 1] <= wave_start[nx]) ++nx;
             const int nnext = nx < n_waves ? wave_start[nx + 1] - wave_start[nx] : 0;
+            h->prof_wave = w;
             run_columns(h, h->ctx + wave_start[w], wave_start[w + 1] - wave_start[w], codes, ca, st,
                         nnext > 0 ? h->ctx + wave_start[nx] : nullptr, nnext);
         }
@@ -701,6 +704,18 @@ int ps_pixelcnn_time_ar_run_waves(ps_pixelcnn *h, int32_t *codes, const int32_t 
                                   const int32_t *wave_start, int n_waves, int *launches, float *total_ms,
                                   double *flops_per_column, void *stream)
 {
+    return ps_pixelcnn_time_ar_run_waves_range(h, codes, order, sample_region, mask_init, mask_undilated, mask_dilated, uniforms, temperature, F,
+                                               first_step, wave_cols, wave_start, n_waves, 0, n_waves, launches, total_ms, flops_per_column, stream);
+}
+
+// ... counting only the launches of the wavefronts [wave_from, wave_to) (bench.py: the launches of one steady-state step of the
+// pipelined form inside a two-batch run)
+int ps_pixelcnn_time_ar_run_waves_range(ps_pixelcnn *h, int32_t *codes, const int32_t *order, const uint8_t *sample_region,
+                                        const float *mask_init, const float *mask_undilated, const float *mask_dilated,
+                                        const float *uniforms, float temperature, int F, int first_step, const int32_t *wave_cols,
+                                        const int32_t *wave_start, int n_waves, int wave_from, int wave_to, int *launches,
+                                        float *total_ms, double *flops_per_column, void *stream)
+{
     PS_REQUIRE(h && launches && total_ms, "pixelcnn_time_ar_run_waves: null pointer");
     std::vector<ps_pixelcnn::ProfRec> recs;
     h->prof = &recs;
@@ -713,7 +728,7 @@ int ps_pixelcnn_time_ar_run_waves(ps_pixelcnn *h, int32_t *codes, const int32_t 
     for (auto &r : recs) {
         float ms = 0.0f;
         (void)hipEventElapsedTime(&ms, r.e0, r.e1);
-        if (r.tag == TAG_CHAIN) { *launches += 1; *total_ms += ms; }
+        if (r.tag == TAG_CHAIN && r.wave >= wave_from && r.wave < wave_to) { *launches += 1; *total_ms += ms; }
         (void)hipEventDestroy(r.e0);
         (void)hipEventDestroy(r.e1);
     }

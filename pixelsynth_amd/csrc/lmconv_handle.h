@@ -101,6 +101,7 @@ struct Tuning {
     int tp_affine = 1;           // throughput form: every neighbour XCD owns a fixed share of the STAGES (its ~3 MB of their weights stay in its L2
                                  // from launch to launch) instead of all XCDs walking all stages together: 378 -> 162 MB per launch at the L2's memory
                                  // side, the launch as long as before (122 us at 128 views; 151 -> 155 us at 256, where the neighbour role is the bound)
+    int tp_ct8_cols = 1024;      // ... and that have at most this many columns (beyond, the neighbour role on the fewer CUs left to it is the bound)
     int tp_ct8_xcds = 3;         // throughput form: chain tiles of 8 columns (k_column_tp8) for launches whose tiles then fit this many XCDs (0: never)
     int col_cap = COL_CAP;       // columns per latency-form launch
     int chain_xcds = 0;          // latency form: XCDs that hold chain workgroups (0 = automatic)
@@ -174,8 +175,9 @@ struct ps_pixelcnn {
     pslm::Tuning tune;
     int env_col_cap = 0;            // col_cap as asked for (environment at creation or set_tuning); re-applied when the compute-unit count changes
     // bench.py profiling aid (ps_pixelcnn_time_column_step): event pair around every launch, by kernel tag
-    struct ProfRec { int tag; hipEvent_t e0, e1; };
+    struct ProfRec { int tag; hipEvent_t e0, e1; int wave; };
     std::vector<ProfRec> *prof = nullptr;
+    int prof_wave = 0;            // the wavefront whose launches are being enqueued (timed runs)
     double flops_nbr = 0.0, flops_chain = 0.0, wbytes_nbr = 0.0, wbytes_chain = 0.0;  // dense work of one step, per frame
 };
 
@@ -206,7 +208,7 @@ template <typename Fn>
 inline void timed(ps_pixelcnn *h, hipStream_t st, int tag, Fn &&launch)
 {
     if (!h->prof) { launch(); return; }
-    ps_pixelcnn::ProfRec r{tag, nullptr, nullptr};
+    ps_pixelcnn::ProfRec r{tag, nullptr, nullptr, h->prof_wave};
     (void)hipEventCreate(&r.e0);
     (void)hipEventCreate(&r.e1);
     (void)hipEventRecord(r.e0, st);

@@ -761,7 +761,7 @@ void run_columns_tp(ps_pixelcnn *h, const StepCtx *rec, int ncols, const ChainAr
             const int tiles = (n + TP_COLS - 1) / TP_COLS;
             // chain tiles of 8 columns (k_column_tp8) while they fit tp_ct8_xcds XCDs: the post phase and the stores of a stage are half
             const int rows_ = h->n_cus / 8;
-            const bool ct8 = h->tune.tp_ct8_xcds > 0 && h->tune.tp_xcds != 0 && h->xcd_even && (n + 7) / 8 <= h->tune.tp_ct8_xcds * rows_;
+            const bool ct8 = h->tune.tp_ct8_xcds > 0 && h->tune.tp_xcds != 0 && h->xcd_even && (n + 7) / 8 <= h->tune.tp_ct8_xcds * rows_ && n <= h->tune.tp_ct8_cols;
             const int ctiles = ct8 ? (n + 7) / 8 : tiles;
             ta.taps = taps + done; ta.ctx = rec + done; ta.ncols = n; ta.tiles = tiles; ta.ctiles = ctiles;
             // did the launch in front prepare this one?  then its slots of the stages [0, split) are in the buffers of `par`

@@ -400,20 +400,72 @@ def launch_capacity(frames):
     return COLUMNS_PER_LAUNCH_TP if frames >= TP_MIN_FRAMES else COLUMNS_PER_LAUNCH
 
 
-def wavefronts(order_host, H, W, first_step, device=None, max_cols=None):
+def wavefronts(order_host, H, W, first_step, device=None, max_cols=None, keep_host=False):
     """Wavefront schedule of an AR run (ps_ar_wavefronts_capped): order_host (F,L) int32 numpy array ->
     (cols int32 (n,2) tensor on `device`, wave_start int32 numpy array of n_waves + 1 entries).
-    max_cols: columns per wave (0 = the pure dependency levels; None = what a launch takes for this many frames)."""
+    max_cols: columns per wave (0 = the pure dependency levels; None = what a launch takes for this many frames).
+    keep_host: a third value, the (n,2) columns as a numpy array of the caller's own (split_tail / merge_schedules work on it)."""
     import ctypes
     order_host = np.ascontiguousarray(order_host, np.int32)
     F_, L = order_host.shape
     if max_cols is None:
         max_cols = launch_capacity(F_)
     with _COLS_LOCK:     # the staging buffer is shared state: one schedule is staged at a time
-        return _wavefronts(order_host, F_, L, H, W, first_step, device, max_cols)
+        return _wavefronts(order_host, F_, L, H, W, first_step, device, max_cols, keep_host)
 
 
-def _wavefronts(order_host, F_, L, H, W, first_step, device, max_cols):
+def split_tail(wave_start, merge_max):
+    """Where the TAIL of a wavefront schedule starts: the first wave behind the widest one from which on every wave has at most
+    merge_max columns (len(wave_start) - 1 = no tail).  A batch's waves grow to the launch capacity and shrink to a handful of columns
+    (C5: 392 ... 1024 x 22 ... 544, 464, ... 16, 8): the narrow last ones cost a launch each for next to no work -- a pipelined caller
+    leaves them for the launches of the NEXT batch's first waves (merge_schedules, z_buffermodel.outpaint_pipelined)."""
+    sizes = np.diff(wave_start)
+    n = len(sizes)
+    if n == 0:
+        return 0
+    s = n
+    while s > 0 and sizes[s - 1] <= merge_max:
+        s -= 1
+    return max(s, n - int(np.argmax(sizes[::-1])))   # (behind the LAST of the widest waves)
+
+
+def merge_schedules(tail_cols, tail_start, head_cols, head_start, cap):
+    """One schedule out of the TAIL waves of one batch and the HEAD waves of the next (frame indices already those of the shared
+    handle): launch j holds head wave j and, while there are any, as many columns of the current tail wave as fit under `cap` (the
+    columns of a wave are independent: a wave may be dealt to several launches; the NEXT tail wave starts in the launch after the one
+    that took the last of this one) -- each batch's waves keep their order, so every dependency is met.  Tail columns left over when
+    the head runs out follow as launches of their own.
+    The columns as numpy arrays or as (device) tensors -> (cols (n,2) int32 of the same kind, wave_start int32 numpy)."""
+    nt, nh = len(tail_start) - 1, len(head_start) - 1
+    parts, starts, total = [], [0], 0
+    t, at = 0, int(tail_start[0]) if nt else 0          # the current tail wave and how far it has been dealt
+    for j in range(nh):
+        a, b = int(head_start[j]), int(head_start[j + 1])
+        parts.append(head_cols[a:b])
+        total += b - a
+        if t < nt:
+            k = min(cap - (b - a), int(tail_start[t + 1]) - at)
+            if k > 0:
+                parts.append(tail_cols[at:at + k])
+                total += k
+                at += k
+            if at == int(tail_start[t + 1]):
+                t += 1
+        starts.append(total)
+    while t < nt:
+        parts.append(tail_cols[at:int(tail_start[t + 1])])
+        total += int(tail_start[t + 1]) - at
+        starts.append(total)
+        t += 1
+        at = int(tail_start[t]) if t < nt else at
+    if torch.is_tensor(head_cols):    # (device tensors: one concatenation on the device)
+        cols = torch.cat(parts) if parts else head_cols[:0]
+    else:
+        cols = np.ascontiguousarray(np.concatenate(parts) if parts else np.zeros((0, 2), np.int32), np.int32)
+    return cols, np.asarray(starts, np.int32)
+
+
+def _wavefronts(order_host, F_, L, H, W, first_step, device, max_cols, keep_host=False):
     import ctypes
     nsteps = L - first_step
     n = F_ * nsteps
@@ -430,10 +482,12 @@ def _wavefronts(order_host, F_, L, H, W, first_step, device, max_cols):
     rc = _lib.lib().ps_ar_wavefronts_capped(_lib.ptr(order_host), F_, H, W, int(first_step), int(max_cols), _lib.ptr(cols),
                                             _lib.ptr(wave_start), ctypes.cast(ctypes.byref(nw), ctypes.c_void_p))
     _lib.check(rc, "ps_ar_wavefronts_capped")
+    host = cols[:n].copy() if keep_host else None
     if device is not None:
         cols_t = stage[:n].to(device, non_blocking=True)
         if cols_t.is_cuda:
             torch.cuda.current_stream().synchronize()             # the staging buffer is free again
     else:
         cols_t = torch.from_numpy(cols[:n].copy() if n else cols[:0].copy())
-    return cols_t, np.ascontiguousarray(wave_start[:nw.value + 1])
+    ws = np.ascontiguousarray(wave_start[:nw.value + 1])
+    return (cols_t, ws, host) if keep_host else (cols_t, ws)

@@ -103,7 +103,8 @@ def _build_ar_plan(background_mask, G, device):
     plan = ARPlan(d_order, d_region, masks[0], masks[1], masks[2], int(first.value), order_host, G)
     plan._n_sampled = region.sum(1).astype(int)
     from .lmconv.model import wavefronts
-    plan.waves = wavefronts(order_host, G, G, plan.first_step, device)   # (cols on the device, wave_start on the host)
+    w = wavefronts(order_host, G, G, plan.first_step, device, keep_host=True)   # (cols on the device, wave_start on the host)
+    plan.waves, plan.waves_host = w[:2], w[2]
     _lib.read_status("ps_order_masks_f32", device)   # synchronises: the staging buffers are free again, and a bad order is an error
     return plan
 
@@ -344,6 +345,124 @@ class ZbufferModelPts(nn.Module):
                            temperature=temperature, uniforms=uniforms, forced=forced, first_step=plan.first_step)
         planned["codes"] = c32.view(V, self.obs[1], self.obs[2])
         return planned
+
+    # ---------------------------------------------------------------- the AR runs of consecutive batches, overlapped
+    PIPE_MERGE_MAX = int(__import__('os').environ.get('PS_PIPE_MERGE_MAX', '640'))    # wavefronts of at most this many columns behind a schedule's widest are left for the next batch's launches
+    PIPE_CAP = 1024         # columns a merged launch takes (lmconv.model.COLUMNS_PER_LAUNCH_TP)
+
+    def _pipe_buffers(self, V, device):
+        """Both batches of the pipelined form live in ONE engine handle of 2 V frames: batch i in frames [V (i % 2), V (i % 2) + V).
+        The per-frame arrays of the C ABI (codes, order, region, the three masks, uniforms) are persistent (2 V, ...) tensors; a batch's
+        plan is copied into its half on the stream of the AR run (14 MB, ~10 us), so that planning on a side stream never writes
+        under a launch that still reads the other batch's half."""
+        st = self.__dict__.get("_pipe")
+        if st is not None and (st["V"] != V or st["device"] != device):
+            if st["pending"] is not None:
+                raise RuntimeError("outpaint_pipelined: a batch of another size is still in flight (call outpaint_flush first)")
+            st = None
+        if st is None:
+            L = self.obs[1] * self.obs[2]
+            z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=device)
+            st = self.__dict__["_pipe"] = dict(
+                V=V, device=device, slot=0, pending=None, codes=z((2 * V, L), torch.int32), order=z((2 * V, L), torch.int32),
+                region=z((2 * V, L), torch.uint8), masks=[z((2 * V, 9, L), torch.float32) for _ in range(3)],
+                uniforms=z((2 * V, L), torch.float32), offset=torch.tensor([V, 0], dtype=torch.int32, device=device))
+            st["order"][:] = torch.arange(L, device=device, dtype=torch.int32)   # (a frame nobody has planned yet still holds a permutation)
+        return st
+
+    @torch.no_grad()
+    def outpaint_pipelined(self, planned, codes, temperature=0.7, uniforms=None, between=None):
+        """outpaint_planned for callers with a STREAM of batches of V views (bench.py, driver.py): the narrow last wavefronts of a
+        batch's AR run -- a launch each for a few hundred columns down to eight, 1.5 of C5's 10.3 ms of column launches -- are not run
+        with their batch but inside the launches of the NEXT batch's first wavefronts (merge_schedules: both batches are resident in
+        one 2 V-frame handle; every column still runs behind the columns it reads, so the codes are those of outpaint_planned, bit
+        for bit -- tests/test_zbuffermodel_gpu.py).  Asynchronous on the current stream.
+        -> the PREVIOUS call's `planned` dict, complete (codes added), or None for the first batch; outpaint_flush() runs what is left
+        of the last one.  between: as for outpaint_planned."""
+        from .lmconv.model import merge_schedules, split_tail
+        gen_fs, plan = planned["gen_fs"], planned["plan"]
+        V, G = gen_fs.shape[0], self.obs[1]
+        L = G * self.obs[2]
+        st = self._pipe_buffers(V, gen_fs.device)
+        if codes is None:
+            codes = self.vqvae.encode_codes(gen_fs)
+        if uniforms is None:
+            uniforms = torch.rand(V, L, device=gen_fs.device, dtype=torch.float32)
+        h = st["slot"]
+        lo, hi = h * V, (h + 1) * V
+        # (as elementwise kernels, not Tensor.copy_: same-type copies go through hipMemcpyAsync, which on the stream of the AR run stalled
+        # for ~60 ms every few steps)
+        put = lambda dst, src: torch.add(src, 0, out=dst) if src.dtype == dst.dtype else dst.copy_(src)
+        put(st["codes"][lo:hi], codes.reshape(V, L))
+        put(st["order"][lo:hi], plan.order_loc)
+        put(st["region"][lo:hi], plan.region)
+        for dst, src in zip(st["masks"], (plan.mask_init, plan.mask_undilated, plan.mask_dilated)):
+            put(dst[lo:hi], src.expand(V, -1, -1) if src.size(0) == 1 else src)
+        put(st["uniforms"][lo:hi], uniforms)
+        eng = self.outpaint2.engine(G, self.obs[2], 2 * V)
+        args = (st["codes"], st["order"], st["region"], st["masks"][0], st["masks"][1], st["masks"][2])
+        # the prefix pass of this batch's frames (two ranges on two streams, as in outpaint_planned)
+        nsplit = self._prefix_split(V, busy=between is not None)
+        if nsplit == 1:
+            eng.ar_prefix(*args, plan.first_step, frame_begin=lo, frame_end=hi)
+        else:
+            main = torch.cuda.current_stream()
+            ready = torch.cuda.Event()
+            ready.record(main)
+            per = V // nsplit
+            for k, side in enumerate(self._prefix_streams(nsplit - 1, gen_fs.device)):
+                side.wait_event(ready)
+                with torch.cuda.stream(side):
+                    eng.ar_prefix(*args, plan.first_step, frame_begin=lo + (k + 1) * per, frame_end=lo + (k + 2) * per if k + 2 < nsplit else hi)
+            eng.ar_prefix(*args, plan.first_step, frame_begin=lo, frame_end=lo + per)
+            for side in self._prefix_streams(nsplit - 1, gen_fs.device):
+                main.wait_stream(side)
+        if between is not None:
+            between()
+        # this batch's schedule, in the handle's frame numbering: head now, tail with the next batch.  The columns are on the device
+        # already (the plan's upload); the merged schedule is put together THERE, launch by launch, from slices of the two batches'
+        # columns (one concatenation) -- nothing crosses PCIe on the stream of the AR run.
+        ws = plan.waves[1]
+        dcols = plan.waves[0] + st["offset"] if h else plan.waves[0]
+        cut = split_tail(ws, self.PIPE_MERGE_MAX)
+        head = (dcols[:ws[cut]], ws[:cut + 1])
+        tail = (dcols[ws[cut]:], ws[cut:] - ws[cut])
+        prev = st["pending"]
+        if prev is None:
+            mcols, mws, first = head[0], head[1], plan.first_step
+        else:
+            mcols, mws = merge_schedules(prev["tail"][0], prev["tail"][1], head[0], head[1], self.PIPE_CAP)
+            first = min(plan.first_step, prev["first_step"])
+        self._pipe_columns(eng, st, args, mcols, mws, first, temperature)
+        st["pending"] = dict(planned=planned, tail=tail, first_step=plan.first_step, slot=h, temperature=temperature)
+        st["slot"] = 1 - h
+        return self._pipe_done(st, prev)
+
+    def _pipe_columns(self, eng, st, args, cols, ws, first, temperature):
+        if len(ws) > 1 and ws[-1] > 0:
+            eng.ar_columns(*args, (cols.contiguous(), np.ascontiguousarray(ws, np.int32)), temperature=temperature, uniforms=st["uniforms"],
+                           first_step=int(first))
+
+    def _pipe_done(self, st, prev):
+        """The batch whose last columns the call just queued: its codes out of the handle's half."""
+        if prev is None:
+            return None
+        V, lo = st["V"], prev["slot"] * st["V"]
+        out = prev["planned"]
+        out["codes"] = st["codes"][lo:lo + V].clone().view(V, self.obs[1], self.obs[2])
+        return out
+
+    @torch.no_grad()
+    def outpaint_flush(self):
+        """What outpaint_pipelined left of its last batch (the tail wavefronts, as launches of their own) -> that batch's dict, or None."""
+        st = self.__dict__.get("_pipe")
+        if st is None or st["pending"] is None:
+            return None
+        prev, st["pending"] = st["pending"], None
+        eng = self.outpaint2.engine(self.obs[1], self.obs[2], 2 * st["V"])
+        args = (st["codes"], st["order"], st["region"], st["masks"][0], st["masks"][1], st["masks"][2])
+        self._pipe_columns(eng, st, args, prev["tail"][0], prev["tail"][1], prev["first_step"], prev["temperature"])
+        return self._pipe_done(st, prev)
 
     PREFIX_SPLIT_MIN_VIEWS = 64   # below this a launch of half the frames no longer fills the chip
     PREFIX_STREAMS = 2            # 128 views: 18.16 -> 17.95 ms per step (three alternating pairs); 4 ranges lose (18.59)

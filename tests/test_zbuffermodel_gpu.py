@@ -633,3 +633,47 @@ def test_prefix_pass_dealt_to_two_streams_gives_the_codes_of_one_stream(monkeypa
             assert torch.equal(out["codes"], ref)
     finally:
         eng.ar_prefix = real_prefix
+
+
+def test_outpaint_pipelined_gives_the_codes_of_outpaint_planned_batch_by_batch():
+    """outpaint_pipelined leaves the narrow last wavefronts of a batch's AR run for the launches of the NEXT batch's first wavefronts
+    (both batches resident in one 2 V-frame handle, merge_schedules); outpaint_flush runs what is left of the last batch.  Three
+    different batches of 64 views in a row (the frame halves of the handle alternate: the third batch reuses the first one's), twice over:
+    every batch's codes are those of outpaint_planned, bit for bit, and a batch comes back exactly one call late."""
+    from pixelsynth_amd.lmconv.model import split_tail
+    m = make_model()
+    V = 64
+    cam = syn.demo_cameras(V)
+    K, Kinv, P, Pinv = (tt(cam[k]) for k in ("K", "Kinv", "P", "Pinv"))
+    batches = []
+    for b in range(3):
+        img, depth = tt(syn.image(81 + b, V, 3, 256)), tt(syn.depth_smooth(91 + b, V, 256, 1.0, 100.0))
+        yaws = np.linspace(-0.7 + 0.1 * b, 0.5 + 0.1 * b, V)
+        rts = [syn.yaw_pose(cam["P"][v:v + 1], float(y)) for v, y in enumerate(yaws)]
+        RT2, RT2inv = tt(np.concatenate([r[1] for r in rts])), tt(np.concatenate([r[0] for r in rts]))
+        codes, uni = tt(syn.codes(101 + b, V)), tt(np.random.RandomState(111 + b).rand(V, 1024).astype(np.float32))
+        batches.append(((img, depth, K, Kinv, P, Pinv, RT2, RT2inv), codes, uni))
+    ref = []
+    for args, codes, uni in batches:
+        out = m.outpaint_planned(m.plan_views(*args), codes, temperature=0.7, uniforms=uni)
+        ref.append(out["codes"].clone())
+        ws = out["plan"].waves[1]
+        cut = split_tail(ws, m.PIPE_MERGE_MAX)
+        assert 0 < cut < len(ws) - 1 and np.diff(ws)[cut:].max() <= m.PIPE_MERGE_MAX    # there is a tail to leave behind
+    torch.cuda.synchronize()
+    assert not torch.equal(ref[0], ref[1]) and not torch.equal(ref[1], ref[2])
+    for rep in range(2):
+        got = []
+        for args, codes, uni in batches:
+            planned = m.plan_views(*args)
+            done = m.outpaint_pipelined(planned, codes, temperature=0.7, uniforms=uni)
+            assert (done is None) == (len(got) == 0 and True) or done is not None
+            if done is not None:
+                got.append(done["codes"].clone())
+        got.append(m.outpaint_flush()["codes"].clone())
+        assert m.outpaint_flush() is None
+        torch.cuda.synchronize()
+        m.outpaint2.engine(32, 32, 2 * V).check()
+        assert len(got) == 3
+        for b in range(3):
+            assert torch.equal(got[b], ref[b]), (rep, b, int((got[b] != ref[b]).sum()))

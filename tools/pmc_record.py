@@ -16,10 +16,22 @@ for line in open(os.path.join(root, "pmc_summary.txt")):
     m = re.match(r"\s+(\S.*?)\s+(\w+)\s+dispatches\s+(\d+)\s+mean\s+([\d.]+)\s+total", line)
     if m:
         pmc[m.group(1).replace("pslm::", "")][m.group(2)] = (int(m.group(3)), float(m.group(4)))
-avg_us = {}
+avg_us, calls = {}, {}
 for r in csv.DictReader(open(os.path.join(root, "kernel_stats.csv"))):
     n = r["Name"].replace("(anonymous namespace)::", "").replace("void ", "").replace("pslm::", "")
     avg_us[n.split("(")[0]] = float(r["AverageNs"]) / 1e3
+    calls[n.split("(")[0]] = int(r["Calls"])
+# the throughput form is two kernels since round 5 (chain tiles of 16 columns: k_column_tp, of 8: k_column_tp8): one row, weighted by dispatches
+forms = {k: dict(pmc.pop(k)) for k in ("k_column_tp", "k_column_tp8") if k in pmc}
+if forms:
+    merged = {}
+    for c in set().union(*[set(v) for v in forms.values()]):
+        n = sum(v[c][0] for v in forms.values() if c in v)
+        merged[c] = (n, sum(v[c][0] * v[c][1] for v in forms.values() if c in v) / n)
+    pmc["k_column_tp"] = merged
+    n = sum(calls.get(k, 0) for k in forms)
+    tp_forms_us = {k: round(avg_us[k], 1) for k in forms if k in avg_us}
+    avg_us["k_column_tp"] = sum(avg_us[k] * calls[k] for k in forms if k in avg_us) / max(1, n)
 CLK = 2.4e3   # shader cycles per us
 SIMDS = 1024
 
@@ -70,6 +82,11 @@ rec = {
 # where a step's time is: every kernel of the profiled command that takes more than 0.5 % of it.  The command runs 3 pipelined steps
 # and the 3 extra AR runs of measure_roofline: the AR kernels (namespace pslm) are dispatched 6 times per "step's worth", the splat
 # kernels 3 times.
+if forms:   # the table shows the two throughput kernels apart
+    rec["mfma"][tp]["forms_avg_us_under_trace"] = tp_forms_us
+    for k, v in forms.items():
+        pmc[k] = v
+        avg_us[k] = tp_forms_us.get(k, avg_us[tp])
 stats = {}
 for r in csv.DictReader(open(os.path.join(root, "kernel_stats.csv"))):
     raw = r["Name"].replace("(anonymous namespace)::", "").replace("void ", "")
