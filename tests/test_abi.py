@@ -19,7 +19,7 @@ def header_symbols(name="pixelsynth_hip.h"):
     return sorted(set(re.findall(r"\b(ps_[a-z0-9_]+)\s*\(", txt)))
 
 
-DEBUG_ONLY = {"ps_pixelcnn_set_tuning", "ps_pixelcnn_get_tuning", "ps_pixelcnn_time_ar_run_waves", "ps_pixelcnn_time_column_step",
+DEBUG_ONLY = {"ps_pixelcnn_set_tuning", "ps_pixelcnn_get_tuning", "ps_pixelcnn_time_ar_run_waves", "ps_pixelcnn_time_ar_run_waves_range", "ps_pixelcnn_time_column_step",
               "ps_pixelcnn_debug_cache"}
 
 
