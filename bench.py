@@ -222,7 +222,9 @@ def measure_roofline(model, d, out, V, live_pmc=False):
         # head A | tail A + head B | tail B -- only the middle section's launches count: exactly one batch's columns.
         from pixelsynth_amd.lmconv.model import merge_schedules, split_tail
         eng = model.outpaint2.engine(32, 32, 2 * V)
-        hc, ws = plan.waves_host, plan.waves[1]
+        frames = getattr(plan, "waves_frames", None) if model.PER_FRAME_PREFIX else None   # per-frame prefixes: their own schedule
+        hc, ws = (frames[0].cpu().numpy(), frames[1]) if frames is not None else (plan.waves_host, plan.waves[1])
+        ncols = int(hc.shape[0])
         cut = split_tail(ws, model.PIPE_MERGE_MAX)
         off = np.array([V, 0], np.int32)
         mid_c, mid_w = merge_schedules(hc[ws[cut]:], ws[cut:] - ws[cut], hc[:ws[cut]] + off, ws[:cut + 1], model.PIPE_CAP)
@@ -233,11 +235,14 @@ def measure_roofline(model, d, out, V, live_pmc=False):
         two = lambda t: torch.cat([t, t]).contiguous()
         arrs = [two(plan.order_loc), two(plan.region), two(plan.mask_init), two(plan.mask_undilated), two(plan.mask_dilated), two(d["uniforms"])]
         w0, w1 = cut, cut + len(mid_w) - 1
+        fs_dev = two(plan.first_steps_dev) if frames is not None else None
+        fs_max = int(plan.first_steps.max()) if frames is not None else -1
         for _ in range(3):
             c32 = two(d["codes"].reshape(V, 1024).to(torch.int32))
             rc = _lib.lib().ps_pixelcnn_time_ar_run_waves_range(
                 eng.handle, _lib.ptr(c32), *[_lib.ptr(a) for a in arrs[:5]], _lib.ptr(arrs[5]), 0.7, 2 * V, plan.first_step,
-                _lib.ptr(dcols), _lib.ptr(all_w), len(all_w) - 1, w0, w1, byref(launches), byref(total_ms), byref(fpc), _lib.current_stream())
+                _lib.ptr(dcols), _lib.ptr(all_w), len(all_w) - 1, w0, w1, _lib.ptr(fs_dev), fs_max, byref(launches), byref(total_ms),
+                byref(fpc), _lib.current_stream())
             _lib.check(rc, "ps_pixelcnn_time_ar_run_waves_range")
             us_list.append(total_ms.value * 1e3 / max(1, launches.value))
         assert torch.equal(c32[:V], c32[V:])     # (the staggered batch drew what the other did)
@@ -284,6 +289,8 @@ def measure_roofline(model, d, out, V, live_pmc=False):
             "flops_per_column": round(fpc.value), "columns_per_launch": round(cols_per_launch, 2),
             "launches_per_ar_run": launches.value, "wavefronts": n_wavefronts, "columns": ncols,
             "ar_runs_overlapped": bool(pipelined), "wavefronts_of_a_batch_alone": len(wave_start) - 1,
+            "per_frame_prefixes": bool(pipelined and getattr(plan, "waves_frames", None) is not None and model.PER_FRAME_PREFIX),
+            "columns_with_one_prefix_for_the_batch": int(cols.shape[0]),
             "pmc_live": live, "traffic_committed_record": (pmc or {}).get("traffic_bytes_per_launch"),
             "kernel_table": kernel_table,
             "kernel_table_note": "every kernel alone on the chip (PMC and trace passes with PS_PREFIX_STREAMS=1); the default step deals "

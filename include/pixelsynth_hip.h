@@ -148,6 +148,11 @@ int ps_ar_wavefronts(const int32_t *order_loc, int B, int H, int W, int first_st
  * the pure levels of ps_ar_wavefronts.  wave_start needs (L-first_step) + ceil(B*(L-first_step)/max_cols) + 1 entries. */
 int ps_ar_wavefronts_capped(const int32_t *order_loc, int B, int H, int W, int first_step, int max_cols,
                             int32_t *cols, int32_t *wave_start, int32_t *n_waves);
+/* The same with a first walked position PER FRAME (first_steps (B) int32, host): frame b's columns are its positions from
+ * first_steps[b] on -- everything in front of a frame's own first sampled location belongs to its whole-grid pass
+ * (ps_pixelcnn_ar_prefix_frames).  cols holds sum_b (L - first_steps[b]) columns. */
+int ps_ar_wavefronts_frames(const int32_t *order_loc, int B, int H, int W, const int32_t *first_steps, int max_cols,
+                            int32_t *cols, int32_t *wave_start, int32_t *n_waves);
 
 /* ------------------------------------------------------------------------------------------
  * Locally masked convolution / PixelCNN (models/lmconv)
@@ -245,6 +250,16 @@ int ps_pixelcnn_ar_run_waves(ps_pixelcnn *h, int32_t *codes, const int32_t *orde
 int ps_pixelcnn_ar_prefix(ps_pixelcnn *h, int32_t *codes, const int32_t *order, const uint8_t *sample_region,
                           const float *mask_init, const float *mask_undilated, const float *mask_dilated, int F,
                           int first_step, int frame_begin, int frame_end, void *stream);
+/* ps_pixelcnn_ar_prefix with PER-FRAME prefixes: frame f's whole-grid pass covers its order positions [0, first_steps[f]) -- the
+ * observed locations in front of ITS first sampled one, not only those in front of the batch's (first_steps: device, (F) int32,
+ * min_first_step <= first_steps[f] <= max_first_step; both bounds from the host).  The whole-grid pass evaluates a location for about
+ * half of what a column costs and every form produces the same bits, so nothing changes but the time.  The column
+ * schedule then holds frame f's positions from first_steps[f] on (ps_ar_wavefronts_frames) and goes to ps_pixelcnn_ar_columns with
+ * first_step = min_first_step. */
+int ps_pixelcnn_ar_prefix_frames(ps_pixelcnn *h, int32_t *codes, const int32_t *order, const uint8_t *sample_region,
+                                 const float *mask_init, const float *mask_undilated, const float *mask_dilated, int F,
+                                 const int32_t *first_steps, int min_first_step, int max_first_step, int frame_begin,
+                                 int frame_end, void *stream);
 int ps_pixelcnn_ar_columns(ps_pixelcnn *h, int32_t *codes, const int32_t *order, const uint8_t *sample_region,
                            const float *mask_init, const float *mask_undilated, const float *mask_dilated,
                            const int32_t *forced, const float *uniforms, float temperature, int F, int first_step,

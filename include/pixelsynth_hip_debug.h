@@ -33,14 +33,15 @@ int ps_pixelcnn_time_ar_run_waves(ps_pixelcnn *h, int32_t *codes, const int32_t 
                                   const int32_t *wave_cols, const int32_t *wave_start, int n_waves,
                                   int *launches, float *total_ms, double *flops_per_column, void *stream);
 /* ... counting only the launches of the wavefronts [wave_from, wave_to) of the schedule (bench.py: one steady-state step of the
- * pipelined form -- the last wavefronts of one batch inside the launches of the next batch's first ones -- within a two-batch run). */
+ * pipelined form -- the last wavefronts of one batch inside the launches of the next batch's first ones -- within a two-batch run).
+ * first_steps (device, (F)) / max_first_step: per-frame prefixes as for ps_pixelcnn_ar_prefix_frames, or NULL / -1. */
 int ps_pixelcnn_time_ar_run_waves_range(ps_pixelcnn *h, int32_t *codes, const int32_t *order,
                                         const uint8_t *sample_region, const float *mask_init,
                                         const float *mask_undilated, const float *mask_dilated,
                                         const float *uniforms, float temperature, int F, int first_step,
                                         const int32_t *wave_cols, const int32_t *wave_start, int n_waves,
-                                        int wave_from, int wave_to, int *launches, float *total_ms,
-                                        double *flops_per_column, void *stream);
+                                        int wave_from, int wave_to, const int32_t *first_steps, int max_first_step,
+                                        int *launches, float *total_ms, double *flops_per_column, void *stream);
 
 /* Debugging aid (tools/tp_debug.py): device address of one of the handle's
  * activation caches -- what 0: raw u of node idx (19 nodes, row stride 96 floats), 1: concat_elu(u) of node idx (160),

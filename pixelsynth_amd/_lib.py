@@ -39,14 +39,16 @@ _PROTOS = {
     "ps_pixelcnn_ar_run": (c_int, [c_void_p] * 9 + [c_float, c_int, c_int, c_void_p, c_void_p]),
     "ps_pixelcnn_ar_run_waves": (c_int, [c_void_p] * 9 + [c_float, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "ps_pixelcnn_ar_prefix": (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_int, c_void_p]),
+    "ps_pixelcnn_ar_prefix_frames": (c_int, [c_void_p] * 7 + [c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "ps_pixelcnn_ar_columns": (c_int, [c_void_p] * 9 + [c_float, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "ps_pixelcnn_set_compute_units": (c_int, [c_void_p, c_int]),
     "ps_stream_create_cu_range": (c_int, [c_int, c_int, c_void_p]),
     "ps_stream_destroy": (c_int, [c_void_p]),
     "ps_pixelcnn_time_ar_run_waves": (c_int, [c_void_p] * 8 + [c_float, c_int, c_int, c_void_p, c_void_p, c_int] + [c_void_p] * 4),
-    "ps_pixelcnn_time_ar_run_waves_range": (c_int, [c_void_p] * 8 + [c_float, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int] + [c_void_p] * 4),
+    "ps_pixelcnn_time_ar_run_waves_range": (c_int, [c_void_p] * 8 + [c_float, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int] + [c_void_p] * 4),
     "ps_ar_wavefronts": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "ps_ar_wavefronts_capped": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "ps_ar_wavefronts_frames": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "ps_pixelcnn_status": (c_int, [c_void_p, c_void_p]),
     "ps_pixelcnn_debug_cache": (c_void_p, [c_void_p, c_int, c_int]),
     "ps_pixelcnn_set_tuning": (c_int, [c_void_p, ctypes.c_char_p, c_int]),

@@ -189,14 +189,20 @@ int ps_ar_plan(const uint8_t *bg, int B, int S, int G, int32_t *order_loc, uint8
     return PS_OK;
 }
 
-int ps_ar_wavefronts_capped(const int32_t *order_loc, int B, int H, int W, int first_step, int max_cols, int32_t *cols,
-                            int32_t *wave_start, int32_t *n_waves)
+// fs[b]: the first order position of frame b that is walked as a column (everything before it is the whole-grid pass's)
+static int wavefronts_impl(const int32_t *order_loc, int B, int H, int W, const int32_t *fs, int max_cols, int32_t *cols,
+                           int32_t *wave_start, int32_t *n_waves)
 {
-    PS_REQUIRE(order_loc && cols && wave_start && n_waves, "ar_wavefronts: null pointer");
+    PS_REQUIRE(order_loc && cols && wave_start && n_waves && fs, "ar_wavefronts: null pointer");
     PS_REQUIRE(B > 0 && H > 0 && W > 0 && max_cols >= 0, "ar_wavefronts: bad sizes");
     const int L = H * W;
-    PS_REQUIRE(first_step >= 0 && first_step <= L, "ar_wavefronts: first_step out of range");
-    const int nsteps = L - first_step;
+    size_t ncolumns = 0;
+    std::vector<size_t> base((size_t)B + 1, 0);   // columns of the frames in front of frame b
+    for (int b = 0; b < B; ++b) {
+        PS_REQUIRE(fs[b] >= 0 && fs[b] <= L, "ar_wavefronts: first_step out of range");
+        ncolumns += (size_t)(L - fs[b]);
+        base[(size_t)b + 1] = ncolumns;
+    }
     // A column reads the columns of the locations that are a 3x3 tap neighbour at dilation 1 or 2 AND earlier in the
     // order (exactly the open taps of the three kernel masks); columns before first_step are done by the whole-grid pass.
     std::vector<int32_t> rank((size_t)B * L);
@@ -220,16 +226,16 @@ int ps_ar_wavefronts_capped(const int32_t *order_loc, int B, int H, int W, int f
     };
     if (max_cols == 0) {
         // pure dependency levels: wave of a column = 1 + the latest wave among the columns it reads
-        std::vector<int32_t> wave((size_t)B * nsteps), lvl((size_t)L);
+        std::vector<int32_t> wave(ncolumns), lvl((size_t)L);
         int deepest = 0;
         for (int b = 0; b < B; ++b) {
             const int32_t *ol = order_loc + (size_t)b * L, *rk = rank.data() + (size_t)b * L;
             std::fill(lvl.begin(), lvl.end(), 0);
-            for (int i = first_step; i < L; ++i) {
+            for (int i = fs[b]; i < L; ++i) {
                 int dep = 0;
                 for_neighbours(ol[i], [&](int p) { if (rk[p] < i) dep = std::max(dep, lvl[p]); });
                 lvl[ol[i]] = dep + 1;
-                wave[(size_t)b * nsteps + (i - first_step)] = dep;  // 0-based wave index
+                wave[base[b] + (size_t)(i - fs[b])] = dep;  // 0-based wave index
                 deepest = std::max(deepest, dep + 1);
             }
         }
@@ -239,10 +245,10 @@ int ps_ar_wavefronts_capped(const int32_t *order_loc, int B, int H, int W, int f
         for (int w = 0; w < deepest; ++w) count[(size_t)w + 1] += count[w];
         for (int w = 0; w <= deepest; ++w) wave_start[w] = count[w];
         for (int b = 0; b < B; ++b)
-            for (int k = 0; k < nsteps; ++k) {
-                const int32_t at = count[wave[(size_t)b * nsteps + k]]++;
+            for (int k = 0; k < L - fs[b]; ++k) {
+                const int32_t at = count[wave[base[b] + (size_t)k]]++;
                 cols[2 * (size_t)at] = b;
-                cols[2 * (size_t)at + 1] = first_step + k;
+                cols[2 * (size_t)at + 1] = fs[b] + k;
             }
         *n_waves = deepest;
         return PS_OK;
@@ -263,11 +269,11 @@ int ps_ar_wavefronts_capped(const int32_t *order_loc, int B, int H, int W, int f
     auto frame_graph = [&](int b) {  // heights (longest chain of dependants) and in-degrees of one frame's columns
         const int32_t *ol = order_loc + (size_t)b * L, *rk = rank.data() + (size_t)b * L;
         int32_t *hb = height.data() + (size_t)b * L, *db = indeg.data() + (size_t)b * L;
-        for (int i = L - 1; i >= first_step; --i) {
+        for (int i = L - 1; i >= fs[b]; --i) {
             int h = 0, d = 0;
             for_neighbours(ol[i], [&](int p) {
                 if (rk[p] > i) h = std::max(h, (int)hb[p]);
-                else if (rk[p] >= first_step) ++d;
+                else if (rk[p] >= fs[b]) ++d;
             });
             hb[ol[i]] = h + 1;
             db[ol[i]] = d;
@@ -277,7 +283,7 @@ int ps_ar_wavefronts_capped(const int32_t *order_loc, int B, int H, int W, int f
     for (int b = 0; b < B; ++b) {
         const int32_t *ol = order_loc + (size_t)b * L;
         const int32_t *hb = height.data() + (size_t)b * L, *db = indeg.data() + (size_t)b * L;
-        for (int i = first_step; i < L; ++i)
+        for (int i = fs[b]; i < L; ++i)
             if (db[ol[i]] == 0) push(hb[ol[i]], b, i);
     }
     size_t at = 0;
@@ -329,9 +335,23 @@ int ps_ar_wavefronts_capped(const int32_t *order_loc, int B, int H, int W, int f
         }
         wave_start[++nw] = (int32_t)at;
     }
-    PS_REQUIRE(at == (size_t)B * nsteps, "ar_wavefronts: internal error, %zu of %zu columns scheduled", at, (size_t)B * nsteps);
+    PS_REQUIRE(at == ncolumns, "ar_wavefronts: internal error, %zu of %zu columns scheduled", at, ncolumns);
     *n_waves = nw;
     return PS_OK;
+}
+
+int ps_ar_wavefronts_capped(const int32_t *order_loc, int B, int H, int W, int first_step, int max_cols, int32_t *cols,
+                            int32_t *wave_start, int32_t *n_waves)
+{
+    PS_REQUIRE(B > 0, "ar_wavefronts: bad sizes");
+    const std::vector<int32_t> fs((size_t)B, first_step);
+    return wavefronts_impl(order_loc, B, H, W, fs.data(), max_cols, cols, wave_start, n_waves);
+}
+
+int ps_ar_wavefronts_frames(const int32_t *order_loc, int B, int H, int W, const int32_t *first_steps, int max_cols, int32_t *cols,
+                            int32_t *wave_start, int32_t *n_waves)
+{
+    return wavefronts_impl(order_loc, B, H, W, first_steps, max_cols, cols, wave_start, n_waves);
 }
 
 int ps_ar_wavefronts(const int32_t *order_loc, int B, int H, int W, int first_step, int32_t *cols, int32_t *wave_start,

@@ -564,8 +564,12 @@ static int ar_run_impl(ps_pixelcnn *h, int32_t *codes, const int32_t *order, con
                        const float *mask_init, const float *mask_undilated, const float *mask_dilated,
                        const int32_t *forced, const float *uniforms, float temperature, int F, int first_step,
                        const int32_t *wave_cols, const int32_t *wave_start, int n_waves, float *out_logits, void *stream,
-                       int phases = AR_PREFIX | AR_COLUMNS, int f0 = 0, int nf = AR_ALL_FRAMES)
+                       int phases = AR_PREFIX | AR_COLUMNS, int f0 = 0, int nf = AR_ALL_FRAMES,
+                       const int32_t *first_steps = nullptr, int max_first_step = -1)
 {
+    // first_steps (device, (F)) / max_first_step: PER-FRAME prefixes -- frame f's whole-grid pass covers its ranks [0, first_steps[f]),
+    // first_step <= first_steps[f] <= max_first_step, and the schedule holds its columns from first_steps[f] on (ps_ar_wavefronts_frames)
+    const bool per_frame = first_steps != nullptr;
     if (int rc = check_handle(h, F)) return rc;
     if (nf == AR_ALL_FRAMES) nf = F;
     PS_REQUIRE(codes && order && sample_region && mask_init && mask_undilated && mask_dilated, "pixelcnn_ar_run: null pointer");
@@ -580,7 +584,7 @@ static int ar_run_impl(ps_pixelcnn *h, int32_t *codes, const int32_t *order, con
             PS_REQUIRE(wave_start[w + 1] >= wave_start[w], "pixelcnn_ar_run_waves: wave_start must not decrease");
         // (a whole run walks every column once; ps_pixelcnn_ar_columns alone also takes PART of them -- callers that run the narrow last
         // wavefronts of one batch inside the launches of the next batch's first ones)
-        PS_REQUIRE(phases == AR_COLUMNS ? wave_start[n_waves] <= F * nsteps : wave_start[n_waves] == F * nsteps,
+        PS_REQUIRE(phases == AR_COLUMNS || per_frame ? wave_start[n_waves] <= F * nsteps : wave_start[n_waves] == F * nsteps,
                    "pixelcnn_ar_run_waves: the schedule holds %d columns, the run has %d", wave_start[n_waves], F * nsteps);
     }
     hipStream_t st = (hipStream_t)stream;
@@ -590,7 +594,9 @@ static int ar_run_impl(ps_pixelcnn *h, int32_t *codes, const int32_t *order, con
         if (n > 0) hipLaunchKernelGGL(k_mask_codes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, codes + off, sample_region + off, n);
         // whole-grid pass: exact for every location that precedes the first sampled one; with out_logits it also
         // yields their logits, by location (the walked positions are overwritten by the column steps)
-        run_grid(h, F, codes, m, out_logits, false, st, order, first_step, f0, nf);
+        PS_REQUIRE(!per_frame || (max_first_step >= first_step && max_first_step <= h->L && !out_logits),
+                   "pixelcnn_ar_prefix: per-frame first steps need first_step <= max_first_step <= L (and no logits)");
+        run_grid(h, F, codes, m, out_logits, false, st, order, per_frame ? max_first_step : first_step, f0, nf, first_steps);
         PS_LAUNCH_CHECK();
     }
     if (!(phases & AR_COLUMNS)) return PS_OK;
@@ -652,6 +658,17 @@ int ps_pixelcnn_ar_prefix(ps_pixelcnn *h, int32_t *codes, const int32_t *order, 
                        nullptr, 0, nullptr, stream, AR_PREFIX, frame_begin, frame_end - frame_begin);
 }
 
+int ps_pixelcnn_ar_prefix_frames(ps_pixelcnn *h, int32_t *codes, const int32_t *order, const uint8_t *sample_region, const float *mask_init,
+                                 const float *mask_undilated, const float *mask_dilated, int F, const int32_t *first_steps, int min_first_step,
+                                 int max_first_step, int frame_begin, int frame_end, void *stream)
+{
+    PS_REQUIRE(first_steps, "pixelcnn_ar_prefix_frames: null first_steps");
+    PS_REQUIRE(frame_begin >= 0 && frame_begin <= frame_end && frame_end <= F, "pixelcnn_ar_prefix: frames [%d, %d) are not a range of the run's %d",
+               frame_begin, frame_end, F);
+    return ar_run_impl(h, codes, order, sample_region, mask_init, mask_undilated, mask_dilated, nullptr, nullptr, 1.0f, F, min_first_step, nullptr,
+                       nullptr, 0, nullptr, stream, AR_PREFIX, frame_begin, frame_end - frame_begin, first_steps, max_first_step);
+}
+
 int ps_pixelcnn_ar_columns(ps_pixelcnn *h, int32_t *codes, const int32_t *order, const uint8_t *sample_region, const float *mask_init,
                            const float *mask_undilated, const float *mask_dilated, const int32_t *forced, const float *uniforms,
                            float temperature, int F, int first_step, const int32_t *wave_cols, const int32_t *wave_start, int n_waves,
@@ -705,7 +722,7 @@ int ps_pixelcnn_time_ar_run_waves(ps_pixelcnn *h, int32_t *codes, const int32_t 
                                   double *flops_per_column, void *stream)
 {
     return ps_pixelcnn_time_ar_run_waves_range(h, codes, order, sample_region, mask_init, mask_undilated, mask_dilated, uniforms, temperature, F,
-                                               first_step, wave_cols, wave_start, n_waves, 0, n_waves, launches, total_ms, flops_per_column, stream);
+                                               first_step, wave_cols, wave_start, n_waves, 0, n_waves, nullptr, -1, launches, total_ms, flops_per_column, stream);
 }
 
 // ... counting only the launches of the wavefronts [wave_from, wave_to) (bench.py: the launches of one steady-state step of the
@@ -713,14 +730,15 @@ int ps_pixelcnn_time_ar_run_waves(ps_pixelcnn *h, int32_t *codes, const int32_t 
 int ps_pixelcnn_time_ar_run_waves_range(ps_pixelcnn *h, int32_t *codes, const int32_t *order, const uint8_t *sample_region,
                                         const float *mask_init, const float *mask_undilated, const float *mask_dilated,
                                         const float *uniforms, float temperature, int F, int first_step, const int32_t *wave_cols,
-                                        const int32_t *wave_start, int n_waves, int wave_from, int wave_to, int *launches,
-                                        float *total_ms, double *flops_per_column, void *stream)
+                                        const int32_t *wave_start, int n_waves, int wave_from, int wave_to, const int32_t *first_steps,
+                                        int max_first_step, int *launches, float *total_ms, double *flops_per_column, void *stream)
 {
     PS_REQUIRE(h && launches && total_ms, "pixelcnn_time_ar_run_waves: null pointer");
     std::vector<ps_pixelcnn::ProfRec> recs;
     h->prof = &recs;
     const int rc = ar_run_impl(h, codes, order, sample_region, mask_init, mask_undilated, mask_dilated, nullptr, uniforms,
-                               temperature, F, first_step, wave_cols, wave_start, n_waves, nullptr, stream);
+                               temperature, F, first_step, wave_cols, wave_start, n_waves, nullptr, stream, AR_PREFIX | AR_COLUMNS, 0,
+                               AR_ALL_FRAMES, first_steps, max_first_step);
     h->prof = nullptr;
     (void)hipStreamSynchronize((hipStream_t)stream);
     *launches = 0;

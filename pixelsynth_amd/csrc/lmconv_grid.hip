@@ -32,6 +32,8 @@ struct ItemMap {
     const int32_t *perm;   // or null: position p of the products' item list holds item perm[p] -- the items grouped by their set of
                            // open taps (k_perm_*), so that a tile of 16 / 32 items shares its taps; the post ops walk the items as they are
     const int2 *permq;     // the same list as (item, location) pairs: one load instead of the chain position -> item -> order -> location
+    const int32_t *end;    // (F) or null: frame f's prefix ends at rank end[f] <= npre (per-frame prefixes: the ranks from there on are
+                           // its columns'); only with an order
 };
 // item at position `pos` of the products' item list, -1 past its end
 __device__ __forceinline__ int item_at(const ItemMap &m, int pos, int nitems)
@@ -49,9 +51,9 @@ __device__ __forceinline__ void item_loc(const ItemMap &m, int item, int L, int 
 // is the item evaluated at this stage?
 __device__ __forceinline__ bool item_wanted(const ItemMap &m, int item)
 {
-    if (!m.start) return true;
-    const int fl = item / m.npre;
-    return item - fl * m.npre >= m.start[m.f0 + fl];
+    if (!m.start && !m.end) return true;
+    const int fl = item / m.npre, r = item - fl * m.npre;
+    return (!m.start || r >= m.start[m.f0 + fl]) && (!m.end || r < m.end[m.f0 + fl]);
 }
 
 struct GemmArgs {
@@ -962,6 +964,7 @@ struct StartsArgs {
     int g_in[NGATED], g_out[NGATED], g_skip[NGATED], d_in[4], d_out[4];
     int32_t *starts;        // (N_EVAL, F)
     int f0;                 // frames [f0, f0 + gridDim.x) of the F
+    const int32_t *pend;    // (F) or null: the prefix of frame f is its ranks [0, pend[f]) instead of [0, npre)
 };
 constexpr int STARTS_MAXL = 4096;
 __global__ __launch_bounds__(1024) void k_prefix_starts(StartsArgs a)
@@ -970,7 +973,7 @@ __global__ __launch_bounds__(1024) void k_prefix_starts(StartsArgs a)
     __shared__ int s1[STARTS_MAXL];     // by rank < npre: min rank among the open dilation-1 taps of ranks >= r (suffix minimum)
     __shared__ int s2[STARTS_MAXL];     //                 the same, dilation-2 taps of the dilated mask
     __shared__ int cmin[2];             // min rank the COLUMNS (ranks >= npre) read through dilation-1 / dilation-2 taps
-    const int f = a.f0 + blockIdx.x, t = threadIdx.x, L = a.L, npre = a.npre;
+    const int f = a.f0 + blockIdx.x, t = threadIdx.x, L = a.L, npre = a.pend ? a.pend[f] : a.npre;
     const int32_t *ord = a.order + (size_t)f * L;
     for (int r = t; r < L; r += 1024) rank[ord[r]] = r;
     if (t < 2) cmin[t] = npre;
@@ -1068,6 +1071,7 @@ struct PermArgs {
     int32_t *tsum[2];                   // totals of the table's tiles of 1024 entries
     int32_t *perm[2];                   // [nf * npre]
     int2 *permq[2];                     // the same as (item, location) pairs
+    const int32_t *pend;                // (F) or null: ranks >= pend[f] of frame f are not part of its prefix (they sort behind everything)
 };
 constexpr int PERM_KEYS = 512;
 // Sort key of a tap set: its place in the order (number of open taps, descending; then the 9-bit set).  The workgroups of a launch
@@ -1125,6 +1129,9 @@ __global__ __launch_bounds__(1024) void k_perm_sort(PermArgs a)
 #else
             v = (uint32_t)g_perm_bin.v[key] << 13 | (uint32_t)r << 1 | frac;
 #endif
+            // (per-frame prefixes: the ranks behind a frame's own end keep their place in the item space -- nobody evaluates them,
+            // item_wanted -- and are put together behind every tap set, so that they fill whole tiles, which leave at once)
+            if (a.pend && r >= a.pend[f]) v = (uint32_t)(PERM_KEYS - 1) << 13 | (uint32_t)r << 1;
         }
         s[r] = v;
     }
@@ -1364,10 +1371,12 @@ bool launch_gemm(GemmArgs &a, int item_blocks, hipStream_t st, const Tuning &tun
 // (with an order: the pass can be restricted to frames [f0, f0 + nf) of the F -- independent passes over disjoint frame ranges
 // may run on different streams)
 void run_grid(ps_pixelcnn *h, int F, const int32_t *codes, const Masks &m, float *logits, bool nchw, hipStream_t st,
-              const int32_t *order, int npre, int f0, int nf)
+              const int32_t *order, int npre, int f0, int nf, const int32_t *pend)
 {
     if (nf < 0) nf = F;
-    const ItemMap all_items{order, order ? npre : h->L, nullptr, f0};
+    if (!order) pend = nullptr;
+    ItemMap all_items{order, order ? npre : h->L, nullptr, f0};
+    all_items.end = pend;
     const int nitems = nf * all_items.npre;
     if (nitems <= 0) return;  // an AR run that starts at rank 0 has no prefix
     const int pblocks = (nitems + 3) / 4;
@@ -1376,7 +1385,7 @@ void run_grid(ps_pixelcnn *h, int F, const int32_t *codes, const Masks &m, float
     // keeps the elimination on for the parity test, which compares the logits of the WALKED locations only.)
     const bool cone = order && (!logits || h->tune.prefix_cone_force) && h->L <= STARTS_MAXL && !h->tune.prefix_full;
     if (cone) {
-        StartsArgs sa{order, m.und, m.dil, h->H, h->W, h->L, npre, F, {}, {}, {}, {}, {}, h->pstart, f0};
+        StartsArgs sa{order, m.und, m.dil, h->H, h->W, h->L, npre, F, {}, {}, {}, {}, {}, h->pstart, f0, pend};
         for (int g = 0; g < NGATED; ++g) { sa.g_in[g] = h->gated[g].node_in; sa.g_out[g] = h->gated[g].node_out; sa.g_skip[g] = h->gated[g].node_skip; }
         for (int d = 0; d < 4; ++d) { sa.d_in[d] = h->dil[d].node_in; sa.d_out[d] = h->dil[d].node_out; }
         hipLaunchKernelGGL(k_prefix_starts, dim3(nf), dim3(1024), 0, st, sa);
@@ -1387,7 +1396,7 @@ void run_grid(ps_pixelcnn *h, int F, const int32_t *codes, const Masks &m, float
     if (h->tune.item_sort && h->L <= STARTS_MAXL && all_items.npre >= 2 && nf <= 2048) {
         PermArgs pa{};
         pa.order = order; pa.mask[0] = m.und; pa.mask[1] = m.dil;
-        pa.H = h->H; pa.W = h->W; pa.L = h->L; pa.npre = all_items.npre; pa.f0 = f0; pa.nf = nf;
+        pa.H = h->H; pa.W = h->W; pa.L = h->L; pa.npre = all_items.npre; pa.f0 = f0; pa.nf = nf; pa.pend = pend;
         pa.nparts = h->tune.item_sort == 2 && nf >= 2 * N_XCD && nf % N_XCD == 0 ? N_XCD : 1;   // (even shares only: the table is [share][tap set][frame])
         const size_t locs = (size_t)h->maxF * h->L;
         for (int k = 0; k < 2; ++k) {

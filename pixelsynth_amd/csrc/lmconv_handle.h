@@ -221,9 +221,10 @@ inline int pad16(int v) { return (v + 15) / 16 * 16; }
 
 // ---- what the translation units export to each other (all in namespace pslm) ----
 // lmconv_grid.hip: whole-grid evaluation (reference-faithful forward; cache build before the column steps).  logits: null (caches only),
-// (F,512,H,W) when nchw, else (F*L,512) by location.  With an order the pass covers ranks [0, npre) of frames [f0, f0 + nf).
+// (F,512,H,W) when nchw, else (F*L,512) by location.  With an order the pass covers ranks [0, npre) of frames [f0, f0 + nf) -- with
+// pend (device, (F)) ranks [0, pend[f]) of frame f, pend[f] <= npre (per-frame prefixes).
 void run_grid(ps_pixelcnn *h, int F, const int32_t *codes, const Masks &m, float *logits, bool nchw, hipStream_t st,
-              const int32_t *order = nullptr, int npre = -1, int f0 = 0, int nf = -1);
+              const int32_t *order = nullptr, int npre = -1, int f0 = 0, int nf = -1, const int32_t *pend = nullptr);
 // lmconv_column.hip: `ncols` independent columns (records rec[0 .. ncols)) as latency-form launches of at most col_cap columns;
 // next_rec / next_ncols: the columns of the launch that FOLLOWS on this stream, when the caller knows it (look-ahead)
 void run_columns_la(ps_pixelcnn *h, const StepCtx *rec, int ncols, ChainArgs ca, hipStream_t st, const StepCtx *next_rec, int next_ncols);

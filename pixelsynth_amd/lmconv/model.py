@@ -159,10 +159,21 @@ class PixelCNNEngine:
             self._frame_arg(F_, name, t, dt)
         return F_, masks
 
-    def ar_prefix(self, codes, order, region, mask_init, mask_undilated, mask_dilated, first_step, frame_begin=0, frame_end=None):
+    def ar_prefix(self, codes, order, region, mask_init, mask_undilated, mask_dilated, first_step, frame_begin=0, frame_end=None,
+                  first_steps=None, max_first_step=None):
         """First half of ar_run for frames [frame_begin, frame_end): sampled codes masked out, whole-grid pass over their observed
-        prefix.  Asynchronous on the current stream; disjoint frame ranges may go to different streams (ps_pixelcnn_ar_prefix)."""
+        prefix.  Asynchronous on the current stream; disjoint frame ranges may go to different streams (ps_pixelcnn_ar_prefix).
+        first_steps (F,) int32 device tensor + max_first_step: PER-FRAME prefixes (ps_pixelcnn_ar_prefix_frames) -- frame f's pass
+        covers its positions [0, first_steps[f]), first_step <= first_steps[f] <= max_first_step."""
         F_, (mi, mu, md) = self._ar_args(codes, order, region, mask_init, mask_undilated, mask_dilated)
+        if first_steps is not None:
+            _lib.require_cuda(first_steps)
+            assert first_steps.dtype == torch.int32 and first_steps.shape == (F_,) and first_steps.is_contiguous()
+            rc = _lib.lib().ps_pixelcnn_ar_prefix_frames(self.handle, _lib.ptr(codes), _lib.ptr(order), _lib.ptr(region), _lib.ptr(mi), _lib.ptr(mu),
+                                                         _lib.ptr(md), F_, _lib.ptr(first_steps), int(first_step), int(max_first_step), int(frame_begin),
+                                                         int(F_ if frame_end is None else frame_end), _lib.current_stream())
+            _lib.check(rc, "ps_pixelcnn_ar_prefix_frames")
+            return
         rc = _lib.lib().ps_pixelcnn_ar_prefix(self.handle, _lib.ptr(codes), _lib.ptr(order), _lib.ptr(region), _lib.ptr(mi), _lib.ptr(mu),
                                               _lib.ptr(md), F_, int(first_step), int(frame_begin), int(F_ if frame_end is None else frame_end),
                                               _lib.current_stream())
@@ -400,18 +411,19 @@ def launch_capacity(frames):
     return COLUMNS_PER_LAUNCH_TP if frames >= TP_MIN_FRAMES else COLUMNS_PER_LAUNCH
 
 
-def wavefronts(order_host, H, W, first_step, device=None, max_cols=None, keep_host=False):
+def wavefronts(order_host, H, W, first_step, device=None, max_cols=None, keep_host=False, first_steps=None):
     """Wavefront schedule of an AR run (ps_ar_wavefronts_capped): order_host (F,L) int32 numpy array ->
     (cols int32 (n,2) tensor on `device`, wave_start int32 numpy array of n_waves + 1 entries).
     max_cols: columns per wave (0 = the pure dependency levels; None = what a launch takes for this many frames).
-    keep_host: a third value, the (n,2) columns as a numpy array of the caller's own (split_tail / merge_schedules work on it)."""
+    keep_host: a third value, the (n,2) columns as a numpy array of the caller's own (split_tail / merge_schedules work on it).
+    first_steps: (F,) int32 numpy array, a first walked position PER FRAME (ps_ar_wavefronts_frames; first_step = their minimum)."""
     import ctypes
     order_host = np.ascontiguousarray(order_host, np.int32)
     F_, L = order_host.shape
     if max_cols is None:
         max_cols = launch_capacity(F_)
     with _COLS_LOCK:     # the staging buffer is shared state: one schedule is staged at a time
-        return _wavefronts(order_host, F_, L, H, W, first_step, device, max_cols, keep_host)
+        return _wavefronts(order_host, F_, L, H, W, first_step, device, max_cols, keep_host, first_steps)
 
 
 def split_tail(wave_start, merge_max):
@@ -465,10 +477,14 @@ def merge_schedules(tail_cols, tail_start, head_cols, head_start, cap):
     return cols, np.asarray(starts, np.int32)
 
 
-def _wavefronts(order_host, F_, L, H, W, first_step, device, max_cols, keep_host=False):
+def _wavefronts(order_host, F_, L, H, W, first_step, device, max_cols, keep_host=False, first_steps=None):
     import ctypes
     nsteps = L - first_step
     n = F_ * nsteps
+    if first_steps is not None:
+        first_steps = np.ascontiguousarray(first_steps, np.int32)
+        assert first_steps.shape == (F_,) and int(first_steps.min()) >= first_step
+        n = int((L - first_steps.astype(np.int64)).sum())
     cap = 1 << max(10, int(max(n, 1) - 1).bit_length())          # page-locked staging, kept per power-of-two capacity
     stage = _COLS_STAGE.get(cap) if device is not None else None
     if device is not None and stage is None:
@@ -479,8 +495,12 @@ def _wavefronts(order_host, F_, L, H, W, first_step, device, max_cols, keep_host
     cols = stage.numpy() if stage is not None else np.empty((max(n, 1), 2), np.int32)
     wave_start = np.zeros(nsteps + (n + max_cols - 1) // max_cols + 2 if max_cols else nsteps + 1, np.int32)
     nw = ctypes.c_int32(0)
-    rc = _lib.lib().ps_ar_wavefronts_capped(_lib.ptr(order_host), F_, H, W, int(first_step), int(max_cols), _lib.ptr(cols),
-                                            _lib.ptr(wave_start), ctypes.cast(ctypes.byref(nw), ctypes.c_void_p))
+    if first_steps is not None:
+        rc = _lib.lib().ps_ar_wavefronts_frames(_lib.ptr(order_host), F_, H, W, _lib.ptr(first_steps), int(max_cols), _lib.ptr(cols),
+                                                _lib.ptr(wave_start), ctypes.cast(ctypes.byref(nw), ctypes.c_void_p))
+    else:
+        rc = _lib.lib().ps_ar_wavefronts_capped(_lib.ptr(order_host), F_, H, W, int(first_step), int(max_cols), _lib.ptr(cols),
+                                                _lib.ptr(wave_start), ctypes.cast(ctypes.byref(nw), ctypes.c_void_p))
     _lib.check(rc, "ps_ar_wavefronts_capped")
     host = cols[:n].copy() if keep_host else None
     if device is not None:

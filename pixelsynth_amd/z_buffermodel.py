@@ -47,7 +47,10 @@ class ARPlan:
 
 
 import collections
+import os
 import threading
+
+PER_FRAME_PREFIX = os.environ.get("PS_PER_FRAME_PREFIX", "1") != "0"   # plans also carry the schedule of per-frame prefixes (waves_frames)
 
 _PINNED = collections.OrderedDict()
 _PINNED_MAX = 12                       # staging buffers kept (four per batch shape): the oldest shapes are released
@@ -105,6 +108,15 @@ def _build_ar_plan(background_mask, G, device):
     from .lmconv.model import wavefronts
     w = wavefronts(order_host, G, G, plan.first_step, device, keep_host=True)   # (cols on the device, wave_start on the host)
     plan.waves, plan.waves_host = w[:2], w[2]
+    # per-frame prefixes: a frame's first SAMPLED position (L: none) -- the observed positions in front of it need no column
+    sampled = np.take_along_axis(region, order_loc.astype(np.int64), 1) != 0
+    plan.first_steps = np.where(sampled.any(1), sampled.argmax(1), L).astype(np.int32)
+    if PER_FRAME_PREFIX and int(plan.first_steps.min()) >= plan.first_step and int(plan.first_steps.max()) > plan.first_step:
+        fs_t = _pinned("first_steps", (B,), torch.int32)
+        fs_t.numpy()[:] = plan.first_steps
+        plan.first_steps_dev = fs_t.to(device, non_blocking=True)
+        w = wavefronts(order_host, G, G, plan.first_step, device, keep_host=True, first_steps=plan.first_steps)
+        plan.waves_frames = w[:2]
     _lib.read_status("ps_order_masks_f32", device)   # synchronises: the staging buffers are free again, and a bad order is an error
     return plan
 
@@ -349,6 +361,7 @@ class ZbufferModelPts(nn.Module):
     # ---------------------------------------------------------------- the AR runs of consecutive batches, overlapped
     PIPE_MERGE_MAX = int(__import__('os').environ.get('PS_PIPE_MERGE_MAX', '640'))    # wavefronts of at most this many columns behind a schedule's widest are left for the next batch's launches
     PIPE_CAP = 1024         # columns a merged launch takes (lmconv.model.COLUMNS_PER_LAUNCH_TP)
+    PER_FRAME_PREFIX = True  # outpaint_pipelined: per-frame prefixes where the plan carries their schedule (build_ar_plan, PS_PER_FRAME_PREFIX)
 
     def _pipe_buffers(self, V, device):
         """Both batches of the pipelined form live in ONE engine handle of 2 V frames: batch i in frames [V (i % 2), V (i % 2) + V).
@@ -366,7 +379,7 @@ class ZbufferModelPts(nn.Module):
             st = self.__dict__["_pipe"] = dict(
                 V=V, device=device, slot=0, pending=None, codes=z((2 * V, L), torch.int32), order=z((2 * V, L), torch.int32),
                 region=z((2 * V, L), torch.uint8), masks=[z((2 * V, 9, L), torch.float32) for _ in range(3)],
-                uniforms=z((2 * V, L), torch.float32), offset=torch.tensor([V, 0], dtype=torch.int32, device=device))
+                uniforms=z((2 * V, L), torch.float32), first_steps=z((2 * V,), torch.int32), offset=torch.tensor([V, 0], dtype=torch.int32, device=device))
             st["order"][:] = torch.arange(L, device=device, dtype=torch.int32)   # (a frame nobody has planned yet still holds a permutation)
         return st
 
@@ -401,10 +414,19 @@ class ZbufferModelPts(nn.Module):
         put(st["uniforms"][lo:hi], uniforms)
         eng = self.outpaint2.engine(G, self.obs[2], 2 * V)
         args = (st["codes"], st["order"], st["region"], st["masks"][0], st["masks"][1], st["masks"][2])
+        # PER-FRAME prefixes (plans that carry their schedule): the whole-grid pass takes every frame up to ITS first sampled position --
+        # a location costs it half of what a column costs, and the bits are the same
+        waves = getattr(plan, "waves_frames", None) if self.PER_FRAME_PREFIX else None
+        pf = {}
+        if waves is not None:
+            put(st["first_steps"][lo:hi], plan.first_steps_dev)
+            pf = dict(first_steps=st["first_steps"], max_first_step=int(plan.first_steps.max()))
+        else:
+            waves = plan.waves
         # the prefix pass of this batch's frames (two ranges on two streams, as in outpaint_planned)
         nsplit = self._prefix_split(V, busy=between is not None)
         if nsplit == 1:
-            eng.ar_prefix(*args, plan.first_step, frame_begin=lo, frame_end=hi)
+            eng.ar_prefix(*args, plan.first_step, frame_begin=lo, frame_end=hi, **pf)
         else:
             main = torch.cuda.current_stream()
             ready = torch.cuda.Event()
@@ -413,8 +435,8 @@ class ZbufferModelPts(nn.Module):
             for k, side in enumerate(self._prefix_streams(nsplit - 1, gen_fs.device)):
                 side.wait_event(ready)
                 with torch.cuda.stream(side):
-                    eng.ar_prefix(*args, plan.first_step, frame_begin=lo + (k + 1) * per, frame_end=lo + (k + 2) * per if k + 2 < nsplit else hi)
-            eng.ar_prefix(*args, plan.first_step, frame_begin=lo, frame_end=lo + per)
+                    eng.ar_prefix(*args, plan.first_step, frame_begin=lo + (k + 1) * per, frame_end=lo + (k + 2) * per if k + 2 < nsplit else hi, **pf)
+            eng.ar_prefix(*args, plan.first_step, frame_begin=lo, frame_end=lo + per, **pf)
             for side in self._prefix_streams(nsplit - 1, gen_fs.device):
                 main.wait_stream(side)
         if between is not None:
@@ -422,8 +444,8 @@ class ZbufferModelPts(nn.Module):
         # this batch's schedule, in the handle's frame numbering: head now, tail with the next batch.  The columns are on the device
         # already (the plan's upload); the merged schedule is put together THERE, launch by launch, from slices of the two batches'
         # columns (one concatenation) -- nothing crosses PCIe on the stream of the AR run.
-        ws = plan.waves[1]
-        dcols = plan.waves[0] + st["offset"] if h else plan.waves[0]
+        ws = waves[1]
+        dcols = waves[0] + st["offset"] if h else waves[0]
         cut = split_tail(ws, self.PIPE_MERGE_MAX)
         head = (dcols[:ws[cut]], ws[:cut + 1])
         tail = (dcols[ws[cut]:], ws[cut:] - ws[cut])

@@ -662,10 +662,15 @@ def test_outpaint_pipelined_gives_the_codes_of_outpaint_planned_batch_by_batch()
         assert 0 < cut < len(ws) - 1 and np.diff(ws)[cut:].max() <= m.PIPE_MERGE_MAX    # there is a tail to leave behind
     torch.cuda.synchronize()
     assert not torch.equal(ref[0], ref[1]) and not torch.equal(ref[1], ref[2])
-    for rep in range(2):
+    for rep in range(3):
+        # per-frame prefixes (the whole-grid pass takes every frame up to ITS first sampled position, ps_pixelcnn_ar_prefix_frames; the
+        # schedule of ps_ar_wavefronts_frames) twice, then one prefix for the batch: the same codes
+        m.PER_FRAME_PREFIX = rep < 2
         got = []
         for args, codes, uni in batches:
             planned = m.plan_views(*args)
+            fs = planned["plan"].first_steps
+            assert fs.min() == planned["plan"].first_step and fs.max() > fs.min() and planned["plan"].waves_frames[0].shape[0] == int((1024 - fs).sum())
             done = m.outpaint_pipelined(planned, codes, temperature=0.7, uniforms=uni)
             assert (done is None) == (len(got) == 0 and True) or done is not None
             if done is not None:
