@@ -359,7 +359,7 @@ class ZbufferModelPts(nn.Module):
         return planned
 
     # ---------------------------------------------------------------- the AR runs of consecutive batches, overlapped
-    PIPE_MERGE_MAX = int(__import__('os').environ.get('PS_PIPE_MERGE_MAX', '640'))    # wavefronts of at most this many columns behind a schedule's widest are left for the next batch's launches
+    PIPE_MERGE_MAX = int(__import__('os').environ.get('PS_PIPE_MERGE_MAX', '720'))    # wavefronts of at most this many columns behind a schedule's widest are left for the next batch's launches
     PIPE_CAP = 1024         # columns a merged launch takes (lmconv.model.COLUMNS_PER_LAUNCH_TP)
     PER_FRAME_PREFIX = True  # outpaint_pipelined: per-frame prefixes where the plan carries their schedule (build_ar_plan, PS_PER_FRAME_PREFIX)
 
