@@ -302,8 +302,9 @@ class ZbufferModelPts(nn.Module):
         """A plan made on a side stream is about to be consumed on `stream`: tell the caching allocator, so that the
         plan's buffers are not recycled on the side stream while work queued on `stream` still reads them."""
         plan = planned["plan"]
+        more = (plan.waves_frames[0], plan.first_steps_dev) if getattr(plan, "waves_frames", None) is not None else ()
         for t in (planned["gen_fs"], planned["background_mask"], plan.order_loc, plan.region, plan.mask_init,
-                  plan.mask_undilated, plan.mask_dilated, plan.waves[0]):
+                  plan.mask_undilated, plan.mask_dilated, plan.waves[0]) + more:
             if t.numel():
                 t.record_stream(stream)
 
@@ -325,7 +326,15 @@ class ZbufferModelPts(nn.Module):
         if forced is None and uniforms is None:
             uniforms = torch.rand(V, L, device=gen_fs.device, dtype=torch.float32)
         nsplit = self._prefix_split(V, busy=between is not None)
-        if (between is None and nsplit == 1) or plan.waves[0].shape[0] == 0:
+        # per-frame prefixes where the plan carries their schedule (build_ar_plan): the whole-grid pass takes every frame up to ITS first
+        # sampled position, the columns start there (ps_pixelcnn_ar_prefix_frames / ps_ar_wavefronts_frames: the same codes)
+        # (batches of the throughput form only: the launches of a small batch are bound by their latency, not by their columns --
+        # 16 views: 5.55 ms per step with one prefix for the batch, 5.66 with per-frame ones)
+        from .lmconv.model import TP_MIN_FRAMES
+        waves_f = getattr(plan, "waves_frames", None) if self.PER_FRAME_PREFIX and V >= TP_MIN_FRAMES else None
+        pf = dict(first_steps=plan.first_steps_dev, max_first_step=int(plan.first_steps.max())) if waves_f is not None else {}
+        waves = waves_f if waves_f is not None else plan.waves
+        if (between is None and nsplit == 1 and waves_f is None) or plan.waves[0].shape[0] == 0:
             eng.ar_run(c32, plan.order_loc, plan.region, plan.mask_init, plan.mask_undilated, plan.mask_dilated,
                        temperature=temperature, uniforms=uniforms, forced=forced, first_step=plan.first_step, waves=plan.waves)
             if between is not None:
@@ -333,7 +342,7 @@ class ZbufferModelPts(nn.Module):
         else:
             args = (c32, plan.order_loc, plan.region, plan.mask_init, plan.mask_undilated, plan.mask_dilated, plan.first_step)
             if nsplit == 1:
-                eng.ar_prefix(*args)
+                eng.ar_prefix(*args, **pf)
             else:
                 # The whole-grid prefix pass of disjoint frame ranges on streams of their own (ps_pixelcnn_ar_prefix is built for it: every
                 # range has its part of the scratch): a launch empties over its last tenth, and the next stage's launch cannot start
@@ -345,15 +354,15 @@ class ZbufferModelPts(nn.Module):
                 for k, st in enumerate(self._prefix_streams(nsplit - 1, c32.device)):
                     st.wait_event(ready)
                     with torch.cuda.stream(st):
-                        eng.ar_prefix(*args, frame_begin=(k + 1) * per, frame_end=(k + 2) * per if k + 2 < nsplit else V)
-                    for t in (c32,) + args[1:6]:
+                        eng.ar_prefix(*args, frame_begin=(k + 1) * per, frame_end=(k + 2) * per if k + 2 < nsplit else V, **pf)
+                    for t in (c32,) + args[1:6] + ((pf["first_steps"],) if pf else ()):
                         t.record_stream(st)
-                eng.ar_prefix(*args, frame_begin=0, frame_end=per)
+                eng.ar_prefix(*args, frame_begin=0, frame_end=per, **pf)
                 for st in self._prefix_streams(nsplit - 1, c32.device):
                     main.wait_stream(st)
             if between is not None:
                 between()
-            eng.ar_columns(c32, plan.order_loc, plan.region, plan.mask_init, plan.mask_undilated, plan.mask_dilated, plan.waves,
+            eng.ar_columns(c32, plan.order_loc, plan.region, plan.mask_init, plan.mask_undilated, plan.mask_dilated, waves,
                            temperature=temperature, uniforms=uniforms, forced=forced, first_step=plan.first_step)
         planned["codes"] = c32.view(V, self.obs[1], self.obs[2])
         return planned

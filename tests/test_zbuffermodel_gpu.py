@@ -655,8 +655,11 @@ def test_outpaint_pipelined_gives_the_codes_of_outpaint_planned_batch_by_batch()
         batches.append(((img, depth, K, Kinv, P, Pinv, RT2, RT2inv), codes, uni))
     ref = []
     for args, codes, uni in batches:
+        m.PER_FRAME_PREFIX = False      # the reference: one prefix for the batch, one AR run per batch
         out = m.outpaint_planned(m.plan_views(*args), codes, temperature=0.7, uniforms=uni)
         ref.append(out["codes"].clone())
+        m.PER_FRAME_PREFIX = True       # ... and outpaint_planned with per-frame prefixes
+        assert torch.equal(m.outpaint_planned(m.plan_views(*args), codes, temperature=0.7, uniforms=uni)["codes"], ref[-1])
         ws = out["plan"].waves[1]
         cut = split_tail(ws, m.PIPE_MERGE_MAX)
         assert 0 < cut < len(ws) - 1 and np.diff(ws)[cut:].max() <= m.PIPE_MERGE_MAX    # there is a tail to leave behind
