@@ -200,8 +200,9 @@ def ar_pipelined(V):
 
 def measure_roofline(model, d, out, V, live_pmc=False):
     """Average column launch -- the dominant kernel: one launch per WAVEFRONT of independent columns (one column = one order
-    position of one frame) -- over a whole AR run of this step's views, measured with HIP events on the stream the launches go to
-    (ps_pixelcnn_time_ar_run_waves, median of three runs), against the dense algorithmic fp32 work of its columns:
+    position of one frame) -- over the column launches of one steady-state step (pipelined form: inside a two-batch run,
+    ps_pixelcnn_time_ar_run_waves_range; otherwise a whole AR run of this step's views, ps_pixelcnn_time_ar_run_waves), measured with
+    HIP events on the stream the launches go to (median of three runs), against the dense algorithmic fp32 work of its columns:
     10.42 MFLOP per column = the 32 matrix stages' centre taps (the chain role: 16-column MFMA tiles in the throughput form
     k_column_tp, fp32 FMA chains on the vector ALU in the latency form k_column_la) plus the neighbour-tap partial sums of all 32
     masked convs (fp32 MFMA in both forms, masked taps skipped) -- the u_init product is a gather and is not priced.  fp32 MFMA and
@@ -871,7 +872,8 @@ def main():
                                         "step i + 1 (splat, planning, uploads) on a side stream"
                                         + ("; the narrow last wavefronts of step i's AR run inside the launches of step i + 1's first wavefronts (both "
                                            "batches resident in one engine handle; the timed region ends with the last step's tail flushed: exactly "
-                                           "`steps` complete steps)" if ar_pipelined(V) else "")},
+                                           "`steps` complete steps); the whole-grid pass takes every frame up to ITS first sampled position "
+                                           "(per-frame prefixes), the columns start there" if ar_pipelined(V) else "")},
         }
         if torch.distributed.is_available() and torch.distributed.is_initialized():   # what the backend itself reports (tools/scale.sh)
             res["collective"] = {"backend": torch.distributed.get_backend(), "world_size": torch.distributed.get_world_size(),
