@@ -192,10 +192,10 @@ def run_steps(model, d, world, n, side):
 
 
 def ar_pipelined(V):
-    """The AR runs of consecutive steps overlapped (z_buffermodel.outpaint_pipelined) -- batches that take the throughput form of the
-    column launch; PS_BENCH_AR_PIPELINE=0 runs every step's AR run on its own."""
-    from pixelsynth_amd.lmconv.model import TP_MIN_FRAMES
-    return os.environ.get("PS_BENCH_AR_PIPELINE", "1") != "0" and V >= TP_MIN_FRAMES
+    """The AR runs of consecutive steps overlapped (z_buffermodel.outpaint_pipelined): batches of at least two views (16 views: 5.55 ->
+    4.30 ms per step, 64-frame circle 10.9 -> 9.1, 128 views 16.9 -> 12.8 with the per-frame prefixes); PS_BENCH_AR_PIPELINE=0 runs every
+    step's AR run on its own."""
+    return os.environ.get("PS_BENCH_AR_PIPELINE", "1") != "0" and V >= int(os.environ.get("PS_BENCH_AR_PIPELINE_MIN", "2"))
 
 
 def measure_roofline(model, d, out, V, live_pmc=False):
@@ -228,7 +228,9 @@ def measure_roofline(model, d, out, V, live_pmc=False):
         ncols = int(hc.shape[0])
         cut = split_tail(ws, model.PIPE_MERGE_MAX)
         off = np.array([V, 0], np.int32)
-        mid_c, mid_w = merge_schedules(hc[ws[cut]:], ws[cut:] - ws[cut], hc[:ws[cut]] + off, ws[:cut + 1], model.PIPE_CAP)
+        from pixelsynth_amd.lmconv.model import launch_capacity
+        cut = split_tail(ws, min(model.PIPE_MERGE_MAX, launch_capacity(V) * 45 // 64))
+        mid_c, mid_w = merge_schedules(hc[ws[cut]:], ws[cut:] - ws[cut], hc[:ws[cut]] + off, ws[:cut + 1], min(model.PIPE_CAP, launch_capacity(V)))
         all_c = np.ascontiguousarray(np.concatenate([hc[:ws[cut]], mid_c, hc[ws[cut]:] + off]), np.int32)
         all_w = np.ascontiguousarray(np.concatenate([ws[:cut + 1], ws[cut] + mid_w[1:], ws[cut] + mid_w[-1] + (ws[cut + 1:] - ws[cut])]), np.int32)
         assert all_w[-1] == 2 * ncols and mid_w[-1] == ncols

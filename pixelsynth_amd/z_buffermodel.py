@@ -401,7 +401,7 @@ class ZbufferModelPts(nn.Module):
         for bit -- tests/test_zbuffermodel_gpu.py).  Asynchronous on the current stream.
         -> the PREVIOUS call's `planned` dict, complete (codes added), or None for the first batch; outpaint_flush() runs what is left
         of the last one.  between: as for outpaint_planned."""
-        from .lmconv.model import merge_schedules, split_tail
+        from .lmconv.model import launch_capacity, merge_schedules, split_tail
         gen_fs, plan = planned["gen_fs"], planned["plan"]
         V, G = gen_fs.shape[0], self.obs[1]
         L = G * self.obs[2]
@@ -455,14 +455,14 @@ class ZbufferModelPts(nn.Module):
         # columns (one concatenation) -- nothing crosses PCIe on the stream of the AR run.
         ws = waves[1]
         dcols = waves[0] + st["offset"] if h else waves[0]
-        cut = split_tail(ws, self.PIPE_MERGE_MAX)
+        cut = split_tail(ws, min(self.PIPE_MERGE_MAX, launch_capacity(V) * 45 // 64))
         head = (dcols[:ws[cut]], ws[:cut + 1])
         tail = (dcols[ws[cut]:], ws[cut:] - ws[cut])
         prev = st["pending"]
         if prev is None:
             mcols, mws, first = head[0], head[1], plan.first_step
         else:
-            mcols, mws = merge_schedules(prev["tail"][0], prev["tail"][1], head[0], head[1], self.PIPE_CAP)
+            mcols, mws = merge_schedules(prev["tail"][0], prev["tail"][1], head[0], head[1], min(self.PIPE_CAP, launch_capacity(V)))
             first = min(plan.first_step, prev["first_step"])
         self._pipe_columns(eng, st, args, mcols, mws, first, temperature)
         st["pending"] = dict(planned=planned, tail=tail, first_step=plan.first_step, slot=h, temperature=temperature)
