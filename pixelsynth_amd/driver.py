@@ -132,6 +132,14 @@ def render_pipelined(model, img, depth, cam, chunks, seeds, temperature=0.7):
                 torch.cat([p[2] for p in chunk]).contiguous(), torch.cat([p[1] for p in chunk]).contiguous())
 
     frames, planned = [], None
+    # batches of one size (a trajectory cut into equal chunks): their AR runs overlap -- the narrow last wavefronts of a batch inside the
+    # launches of the next batch's first ones (outpaint_pipelined; the same codes); a batch then comes back one call late
+    overlap = len(chunks) > 1 and len({len(c) for c in chunks}) == 1 and len(chunks[0]) >= 2
+
+    def finish(out):
+        if out is not None:
+            sample = model.vqvae.decode_code(out["codes"])
+            frames.append(model.get_combined(out["gen_fs"], sample, out["background_mask"]))
     for k, chunk in enumerate(chunks):
         if planned is None:
             planned = model.plan_views(*inputs(chunk))
@@ -139,7 +147,7 @@ def render_pipelined(model, img, depth, cam, chunks, seeds, temperature=0.7):
         # the draws of a view are seeded by the VIEW (its index in the trajectory), not by where the sharding put it: a frame is
         # the same picture on one GPU or eight
         uniforms = torch.stack([torch.rand(1024, generator=torch.Generator(device="cpu").manual_seed(int(sd))) for sd in seeds[k]]).to(img.device)
-        out = model.outpaint_planned(planned, None, temperature=temperature, uniforms=uniforms)
+        out = (model.outpaint_pipelined if overlap else model.outpaint_planned)(planned, None, temperature=temperature, uniforms=uniforms)
         planned = None
         if k + 1 < len(chunks):
             if k == 0:
@@ -148,8 +156,9 @@ def render_pipelined(model, img, depth, cam, chunks, seeds, temperature=0.7):
                 planned = model.plan_views(*inputs(chunks[k + 1]))
             model.adopt_planned(planned, main)
             main.wait_stream(side)
-        sample = model.vqvae.decode_code(out["codes"])
-        frames.append(model.get_combined(out["gen_fs"], sample, out["background_mask"]))
+        finish(out)
+    if overlap:
+        finish(model.outpaint_flush())
     if chunks:
         model.outpaint2.engine(32, 32, len(chunks[-1])).check()
     return frames

@@ -341,6 +341,11 @@ def test_driver_renders_a_trajectory_and_writes_the_video_layout(tmp_path):
     src = ((np.clip(syn.image(1000, 1, 3, 256)[0], -1, 1) * 0.5 + 0.5) * 255.0 + 0.5).astype(np.uint8).transpose(1, 2, 0)
     assert np.array_equal(frames[0], src)
     assert not np.array_equal(frames[1], frames[3])                       # different poses give different views
+    # equal chunks: their AR runs overlap (outpaint_pipelined) -- the pictures are those of one batch of all six views
+    for batch, sub in ((3, "a"), (6, "b")):
+        driver.main(["--trajectory", "circle", "--frames", "6", "--batch", str(batch), "--out", str(tmp_path / sub)])
+    pics = [[np.asarray(Image.open(tmp_path / sub / "video" / f"{i}.png")).astype(np.int32) for i in range(7)] for sub in ("a", "b")]
+    assert all(np.abs(x - y).max() <= 2 for x, y in zip(*pics)) and not np.array_equal(pics[0][2], pics[0][5])
     m = driver.build_model(torch.device(DEV))
     P = tt(syn.demo_cameras(1)["P"])
     poses = driver.trajectory(m, P, "circle", 8)
