@@ -148,7 +148,7 @@ struct TuningEntry { const char *key; int Tuning::*field; int lo, hi; };
 const TuningEntry tuning_table[] = {
     {"gemm_merge_min", &Tuning::gemm_merge_min, 0, 1 << 30}, {"gemm_wg_min", &Tuning::gemm_wg_min, 1, 1 << 30},
     {"wg_ti_out", &Tuning::wg_ti_out, 1, 2}, {"wg_ti_in", &Tuning::wg_ti_in, 2, 4}, {"wg_ti_dil", &Tuning::wg_ti_dil, 2, 4},
-    {"item_sort", &Tuning::item_sort, 0, 2}, {"gemm_ws", &Tuning::gemm_ws, 0, 1},
+    {"item_sort", &Tuning::item_sort, 0, 2}, {"gemm_ws", &Tuning::gemm_ws, 0, 7},
     {"prefix_full", &Tuning::prefix_full, 0, 1}, {"prefix_cone_force", &Tuning::prefix_cone_force, 0, 1},
     {"tp_ahead", &Tuning::tp_ahead, 0, NST - 2}, {"col_ahead", &Tuning::col_ahead, 0, NST - 4},
     {"tp_min_cols", &Tuning::tp_min_cols, 1, 1 << 30}, {"tp_xcds", &Tuning::tp_xcds, -1, 7}, {"tp_fill", &Tuning::tp_fill, 0, 1},

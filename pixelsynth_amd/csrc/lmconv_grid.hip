@@ -1337,7 +1337,7 @@ bool launch_gemm(GemmArgs &a, int item_blocks, hipStream_t st, const Tuning &tun
         const int per_pass = kind == GW_DIL ? 4 : 14;
         a.trace_on = a.ny >= 2048 && seen[kind]++ % per_pass == (sel < per_pass ? sel : per_pass - 1);
 #endif
-        if (tune.gemm_ws && post != nullptr) {   // weights shared through LDS, 64 items per workgroup (round 5)
+        if ((tune.gemm_ws >> kind & 1) && post != nullptr) {   // weights shared through LDS, 64 items per workgroup (round 5); one bit per kind
             a.ny = (a.nitems + WS_MI - 1) / WS_MI;
             a.tpx = (a.ny + N_XCD - 1) / N_XCD;
             PostArgs pw = *post;

@@ -87,7 +87,7 @@ struct Tuning {
     int gemm_merge_min = 8192;   // (tile, channel block) pairs from which one k_gemm wave walks all slots of its tile
     int gemm_wg_min = 1024;      // item tiles from which the whole-grid products take the workgroup form (k_gemm_wg)
     int wg_ti_out = 1, wg_ti_in = 2, wg_ti_dil = 2;   // item tiles per k_gemm_wg workgroup: conv_out / conv_input / dilated
-    int gemm_ws = 1;             // the workgroup form with the WEIGHTS shared through LDS (k_gemm_ws, 64 items per workgroup) instead of k_gemm_wg (0) --
+    int gemm_ws = 7;             // bits 0 / 1 / 2 = conv_out / conv_input / dilated: the workgroup form with the WEIGHTS shared through LDS (k_gemm_ws, 64 items per workgroup) instead of k_gemm_wg --
                                  // bit-identical; slower on the round-5 prefix of one first step per batch (236 / 157 / 93 us against 219 / 146 / 89),
                                  // faster once the pass takes every frame up to ITS first sampled position (13.7 -> 12.9 ms per step): the default since
     int item_sort = 2;           // whole-grid products: items grouped by their set of open taps (round 5).  0 = natural (frame, rank)

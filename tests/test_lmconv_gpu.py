@@ -178,7 +178,7 @@ def test_whole_grid_launch_forms_agree_bit_for_bit():
     eng.set_tuning(gemm_merge_min=0, gemm_wg_min=1, gemm_ws=0)   # k_gemm_wg: four-wave workgroups, input rows shared through LDS, post op fused (large launches)
     wg = run()
     assert torch.equal(wg, split)
-    eng.set_tuning(gemm_ws=1)                         # k_gemm_ws: 64 items per workgroup, the WEIGHTS shared through LDS
+    eng.set_tuning(gemm_ws=7)                         # k_gemm_ws: 64 items per workgroup, the WEIGHTS shared through LDS
     assert torch.equal(run(), split)
     eng.set_tuning(gemm_ws=0)
     for ti in ((2, 2, 2), (1, 4, 4), (2, 4, 2)):      # item tiles per workgroup: conv_out / conv_input / dilated
@@ -192,9 +192,9 @@ def test_whole_grid_launch_forms_agree_bit_for_bit():
     assert torch.equal(run(), split)
     eng.set_tuning(item_sort=1)
     assert torch.equal(run(), split)
-    eng.set_tuning(gemm_wg_min=1, gemm_ws=1)
+    eng.set_tuning(gemm_wg_min=1, gemm_ws=7)
     assert torch.equal(run(), split)                  # (k_gemm_ws over one sort of all frames)
-    eng.set_tuning(gemm_merge_min=8192, gemm_wg_min=1024, wg_ti_out=1, wg_ti_in=2, wg_ti_dil=2, item_sort=2, gemm_ws=1)   # (the defaults)
+    eng.set_tuning(gemm_merge_min=8192, gemm_wg_min=1024, wg_ti_out=1, wg_ti_in=2, wg_ti_dil=2, item_sort=2, gemm_ws=7)   # (the defaults)
     x = torch.zeros(1, 512, 1024)
     x[0, codes[0], np.arange(1024)] = 1
     with torch.no_grad():
@@ -223,11 +223,13 @@ def test_workgroup_form_with_fractional_masks_loads_them():
     ref = run()
     eng.set_tuning(gemm_wg_min=1, gemm_ws=0)
     assert torch.equal(run(), ref)
-    eng.set_tuning(gemm_ws=1)
+    eng.set_tuning(gemm_ws=7)
+    assert torch.equal(run(), ref)
+    eng.set_tuning(gemm_ws=2)   # (one kind through k_gemm_ws, the others through k_gemm_wg)
     assert torch.equal(run(), ref)
     eng.set_tuning(gemm_ws=0, item_sort=0)
     assert torch.equal(run(), ref)
-    eng.set_tuning(gemm_merge_min=8192, gemm_wg_min=1024, item_sort=2, gemm_ws=1)   # (the defaults)
+    eng.set_tuning(gemm_merge_min=8192, gemm_wg_min=1024, item_sort=2, gemm_ws=7)   # (the defaults)
     frac = ms[1][1][ms[1][1] > 0]
     assert ((frac != 1.0).mean() > 0.2) and torch.isfinite(ref).all()
 
