@@ -45,6 +45,30 @@ class ARPlan:
     def n_sampled(self):
         return self._n_sampled
 
+    # The wavefront schedule of ONE first step for the whole batch: (cols on the device, wave_start on the host) and the columns on the
+    # host.  A plan that carries the schedule of per-frame prefixes (waves_frames: what the batched paths run) builds this one on first
+    # use -- 3.6 of the 9.8 ms of host work per 128-view plan, and only the measurement / parity callers ask for it.
+    def _schedule(self):
+        if self._waves is None:
+            from .lmconv.model import wavefronts
+            w = wavefronts(self._order_host, self._G, self._G, self.first_step, self.order_loc.device, keep_host=True)
+            self._waves, self._waves_host = w[:2], w[2]
+        return self._waves, self._waves_host
+
+    _waves = _waves_host = None
+
+    @property
+    def waves(self):
+        return self._schedule()[0]
+
+    @waves.setter
+    def waves(self, value):
+        self._waves = value
+
+    @property
+    def waves_host(self):
+        return self._schedule()[1]
+
 
 import collections
 import os
@@ -106,8 +130,6 @@ def _build_ar_plan(background_mask, G, device):
     plan = ARPlan(d_order, d_region, masks[0], masks[1], masks[2], int(first.value), order_host, G)
     plan._n_sampled = region.sum(1).astype(int)
     from .lmconv.model import wavefronts
-    w = wavefronts(order_host, G, G, plan.first_step, device, keep_host=True)   # (cols on the device, wave_start on the host)
-    plan.waves, plan.waves_host = w[:2], w[2]
     # per-frame prefixes: a frame's first SAMPLED position (L: none) -- the observed positions in front of it need no column
     sampled = np.take_along_axis(region, order_loc.astype(np.int64), 1) != 0
     plan.first_steps = np.where(sampled.any(1), sampled.argmax(1), L).astype(np.int32)
@@ -117,6 +139,9 @@ def _build_ar_plan(background_mask, G, device):
         plan.first_steps_dev = fs_t.to(device, non_blocking=True)
         w = wavefronts(order_host, G, G, plan.first_step, device, keep_host=True, first_steps=plan.first_steps)
         plan.waves_frames = w[:2]
+    from .lmconv.model import TP_MIN_FRAMES
+    if getattr(plan, "waves_frames", None) is None or B < TP_MIN_FRAMES:
+        plan._schedule()   # (no per-frame schedule, or a small batch, whose outpaint_planned runs this one: built here, off the AR stream)
     _lib.read_status("ps_order_masks_f32", device)   # synchronises: the staging buffers are free again, and a bad order is an error
     return plan
 
@@ -304,7 +329,7 @@ class ZbufferModelPts(nn.Module):
         plan = planned["plan"]
         more = (plan.waves_frames[0], plan.first_steps_dev) if getattr(plan, "waves_frames", None) is not None else ()
         for t in (planned["gen_fs"], planned["background_mask"], plan.order_loc, plan.region, plan.mask_init,
-                  plan.mask_undilated, plan.mask_dilated, plan.waves[0]) + more:
+                  plan.mask_undilated, plan.mask_dilated) + ((plan._waves[0],) if plan._waves is not None else ()) + more:
             if t.numel():
                 t.record_stream(stream)
 
@@ -334,7 +359,7 @@ class ZbufferModelPts(nn.Module):
         waves_f = getattr(plan, "waves_frames", None) if self.PER_FRAME_PREFIX and V >= TP_MIN_FRAMES else None
         pf = dict(first_steps=plan.first_steps_dev, max_first_step=int(plan.first_steps.max())) if waves_f is not None else {}
         waves = waves_f if waves_f is not None else plan.waves
-        if (between is None and nsplit == 1 and waves_f is None) or plan.waves[0].shape[0] == 0:
+        if (between is None and nsplit == 1 and waves_f is None) or plan.first_step >= L:   # (nothing to walk: only the whole-grid pass runs)
             eng.ar_run(c32, plan.order_loc, plan.region, plan.mask_init, plan.mask_undilated, plan.mask_dilated,
                        temperature=temperature, uniforms=uniforms, forced=forced, first_step=plan.first_step, waves=plan.waves)
             if between is not None:
