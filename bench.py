@@ -152,6 +152,15 @@ def run_step(model, d, world):
 
 
 def run_steps(model, d, world, n, side):
+    """_run_steps; a run that dies on the way leaves no batch in flight for the next run to merge (z_buffermodel.outpaint_reset)."""
+    try:
+        return _run_steps(model, d, world, n, side)
+    except BaseException:
+        model.outpaint_reset()
+        raise
+
+
+def _run_steps(model, d, world, n, side):
     """n steps, software-pipelined: while the device runs the AR loop of step i (main stream), the host half of step
     i + 1 -- splat on the side stream, masks back, planning, uploads -- is already under way.  Same work per step, the
     steps are independent; results identical to n x run_step.

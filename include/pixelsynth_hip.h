@@ -33,6 +33,9 @@ enum { PS_ACC_ALPHACOMPOSITE = 0, PS_ACC_WSUM = 1, PS_ACC_WSUMNORM = 2 }; /* opt
 enum { PS_STATUS_BAD_ORDER = 1, PS_STATUS_BAD_PIXEL = 2 };
 
 int ps_abi_version(void);
+/* What the library was built from: ABI version, target, flags, and whether any tuning / trace / experiment macro was passed to the
+ * build ("product build" or "NON-PRODUCT build, extra flags: ..."; pixelsynth_amd/build.py).  A static string. */
+const char *ps_build_info(void);
 const char *ps_last_error(void);
 /* Synchronises `stream`, reads the caller's status word and clears it: PS_OK when no asynchronous call that was handed this
  * word has raised a bit since the last read, otherwise PS_ERR_STATE with the decoded bits in ps_last_error().  (The library

@@ -43,6 +43,21 @@ int ps_pixelcnn_time_ar_run_waves_range(ps_pixelcnn *h, int32_t *codes, const in
                                         int wave_from, int wave_to, const int32_t *first_steps, int max_first_step,
                                         int *launches, float *total_ms, double *flops_per_column, void *stream);
 
+/* Which kernels carried the matrix work (tests: "the forms the headline takes really ran"; bench.py: `roofline.kernels`).
+ * Kinds 0 .. ps_pixelcnn_launch_kinds() - 1, named by ps_pixelcnn_launch_kind_name: k_column, k_column_la, k_column_tp, k_column_tp8
+ * (column launches: one-position walk, latency form, throughput form with chain tiles of 16 / 8 columns), k_gemm, k_gemm_wg,
+ * k_gemm_ws<0> / <1> / <2> (whole-grid products: one wave per tile; rows through LDS; weights through LDS for conv_out /
+ * conv_input / dilated).  ps_pixelcnn_launch_counts: cumulative launches of the handle since its creation, by kind (host counters,
+ * no synchronisation).  ps_pixelcnn_profile_begin / _end: between the two calls every such launch -- whichever entry point
+ * enqueues it, on whichever stream -- is bracketed by a HIP event pair on ITS stream; _end synchronises the device and returns
+ * launches and summed kernel time by kind (launches[n], total_ms[n]).  The kernels of two streams overlap: the sums can exceed
+ * the wall time. */
+int ps_pixelcnn_launch_kinds(void);
+const char *ps_pixelcnn_launch_kind_name(int kind);
+int ps_pixelcnn_launch_counts(ps_pixelcnn *h, long long *counts, int n);
+int ps_pixelcnn_profile_begin(ps_pixelcnn *h);
+int ps_pixelcnn_profile_end(ps_pixelcnn *h, int n, int *launches, float *total_ms);
+
 /* Debugging aid (tools/tp_debug.py): device address of one of the handle's
  * activation caches -- what 0: raw u of node idx (19 nodes, row stride 96 floats), 1: concat_elu(u) of node idx (160),
  * 2: the activation inside gated resnet idx (14 blocks, 160); rows are frame * L + location; 5: the (33, F) int32 table of

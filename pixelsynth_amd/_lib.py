@@ -17,6 +17,12 @@ c_void_p, c_int, c_float, c_double, c_size_t = (ctypes.c_void_p, ctypes.c_int, c
 _PROTOS = {
     "ps_abi_version": (c_int, []),
     "ps_last_error": (ctypes.c_char_p, []),
+    "ps_build_info": (ctypes.c_char_p, []),
+    "ps_pixelcnn_launch_kinds": (c_int, []),
+    "ps_pixelcnn_launch_kind_name": (ctypes.c_char_p, [c_int]),
+    "ps_pixelcnn_launch_counts": (c_int, [c_void_p, c_void_p, c_int]),
+    "ps_pixelcnn_profile_begin": (c_int, [c_void_p]),
+    "ps_pixelcnn_profile_end": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "ps_project_pts_f32": (c_int, [c_void_p] * 5 + [c_int, c_int, c_void_p, c_void_p]),
     "ps_project_pts_cumulative_f32": (c_int, [c_void_p] * 8 + [c_int] * 4 + [c_void_p] * 3),
     "ps_splat_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_double]),

@@ -30,7 +30,10 @@ UNITS = [
     ("host_order.cpp", []),
 ]
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
-COMMON += os.environ.get("PS_EXTRA_HIPCC_FLAGS", "").split()  # tuning builds, e.g. -DPS_TUNING_BUILD -DPS_CHAIN_TRACE_BUILD
+EXTRA = os.environ.get("PS_EXTRA_HIPCC_FLAGS", "").split()  # tuning builds, e.g. -DPS_TUNING_BUILD -DPS_CHAIN_TRACE_BUILD
+COMMON += EXTRA
+if EXTRA:   # ps_build_info() (csrc/host_order.cpp) names them: a number measured through such a library carries its provenance
+    COMMON += ['-DPS_BUILD_EXTRA_FLAGS="%s"' % " ".join(EXTRA).replace('"', "'")]
 
 
 def _deps():
@@ -40,7 +43,7 @@ def _deps():
 
 
 def build(force=False, verbose=True):
-    objs = []
+    objs, todo = [], []
     dep_m = max(os.path.getmtime(d) for d in _deps())
     for src, flags in UNITS:
         sp = os.path.join(CSRC, src)
@@ -48,11 +51,17 @@ def build(force=False, verbose=True):
             continue
         obj = os.path.join(CSRC, os.path.splitext(src)[0] + os.environ.get("PS_OBJ_SUFFIX", "") + ".o")
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(sp), dep_m):
-            cmd = [HIPCC, "-x", "hip", "-c", sp, "-o", obj] + COMMON + flags
+            todo.append([HIPCC, "-x", "hip", "-c", sp, "-o", obj] + COMMON + flags)
+        objs.append(obj)
+    if todo:   # the units are independent: compiled side by side (a full build is the longest unit, not the sum)
+        from concurrent.futures import ThreadPoolExecutor
+
+        def run(cmd):
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
-        objs.append(obj)
+        with ThreadPoolExecutor(max_workers=min(len(todo), max(1, (os.cpu_count() or 2) // 2))) as pool:
+            list(pool.map(run, todo))
     if force or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
         cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs
         if verbose:

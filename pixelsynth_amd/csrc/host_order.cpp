@@ -86,6 +86,23 @@ void custom_order(int rows, int cols, int64_t *d, int32_t *order)
 extern "C" {
 
 int ps_abi_version(void) { return PS_ABI_VERSION; }
+// What this library was built from, for whoever reports a number measured through it (bench.py prints it): pixelsynth_amd/build.py
+// passes its extra flags in (-DPS_BUILD_EXTRA_FLAGS="..."); a product build has none.  Tuning / trace / experiment builds
+// (-DPS_TUNING_BUILD, -DPS_*_TRACE_BUILD, -DPS_WS_EXP=..., ...: results INVALID or timing perturbed) say so here.
+#ifndef PS_BUILD_EXTRA_FLAGS
+#define PS_BUILD_EXTRA_FLAGS ""
+#endif
+#define PS_STR2(x) #x
+#define PS_STR(x) PS_STR2(x)
+const char *ps_build_info(void)
+{
+    static const std::string info = [] {
+        const std::string extra = PS_BUILD_EXTRA_FLAGS;
+        return std::string("libpixelsynth_hip abi ") + PS_STR(PS_ABI_VERSION) + "; hipcc --offload-arch=gfx950 -O3 -ffp-contract=off; "
+               + (extra.empty() ? "product build (no extra flags)" : "NON-PRODUCT build, extra flags: " + extra);
+    }();
+    return info.c_str();
+}
 const char *ps_last_error(void) { return ps::last_error_ref().c_str(); }
 
 int ps_custom_order(int rows, int cols, int64_t *distances, int32_t *order)

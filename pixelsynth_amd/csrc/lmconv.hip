@@ -754,6 +754,45 @@ int ps_pixelcnn_time_ar_run_waves_range(ps_pixelcnn *h, int32_t *codes, const in
     return rc;
 }
 
+// Which kernels carried a run's matrix work: cumulative launch counts of the handle by kind (pslm::LaunchKind), always on ...
+static const char *const launch_kind_names[LK_N] = {"k_column", "k_column_la", "k_column_tp", "k_column_tp8", "k_gemm", "k_gemm_wg",
+                                                    "k_gemm_ws<0>", "k_gemm_ws<1>", "k_gemm_ws<2>"};
+int ps_pixelcnn_launch_kinds(void) { return LK_N; }
+const char *ps_pixelcnn_launch_kind_name(int kind) { return kind >= 0 && kind < LK_N ? launch_kind_names[kind] : nullptr; }
+int ps_pixelcnn_launch_counts(ps_pixelcnn *h, long long *counts, int n)
+{
+    PS_REQUIRE(h && counts && n >= 0, "pixelcnn_launch_counts: null pointer");
+    for (int k = 0; k < n; ++k) counts[k] = k < LK_N ? h->launch_count[k] : 0;
+    return PS_OK;
+}
+// ... and, between _begin and _end, a HIP event pair around every such launch on the stream it goes to (whatever entry point enqueues
+// it, on whatever stream): _end synchronises the device and returns launches and summed duration by kind.
+int ps_pixelcnn_profile_begin(ps_pixelcnn *h)
+{
+    PS_REQUIRE(h, "pixelcnn_profile_begin: null pointer");
+    if (h->prof) return ps::fail(PS_ERR_STATE, "pixelcnn_profile_begin: a timed run is in progress");
+    h->prof_own.clear();
+    h->prof = &h->prof_own;
+    return PS_OK;
+}
+int ps_pixelcnn_profile_end(ps_pixelcnn *h, int n, int *launches, float *total_ms)
+{
+    PS_REQUIRE(h && launches && total_ms && n >= 0, "pixelcnn_profile_end: null pointer");
+    if (h->prof != &h->prof_own) return ps::fail(PS_ERR_STATE, "pixelcnn_profile_end: no profile was begun");
+    h->prof = nullptr;
+    PS_HIP_CHECK(hipDeviceSynchronize());
+    for (int k = 0; k < n; ++k) { launches[k] = 0; total_ms[k] = 0.0f; }
+    for (auto &r : h->prof_own) {
+        float ms = 0.0f;
+        (void)hipEventElapsedTime(&ms, r.e0, r.e1);
+        if (r.kind >= 0 && r.kind < n) { launches[r.kind] += 1; total_ms[r.kind] += ms; }
+        (void)hipEventDestroy(r.e0);
+        (void)hipEventDestroy(r.e1);
+    }
+    h->prof_own.clear();
+    return PS_OK;
+}
+
 // tuning / debugging aid (tools/tp_debug.py): device address of an activation cache -- what 0: R[idx] (raw u of node idx,
 // row stride 96), 1: E[idx] (concat_elu(u), 160), 2: X[idx] (inside gated resnet idx, 160); rows are (frame * L + location)
 void *ps_pixelcnn_debug_cache(ps_pixelcnn *h, int what, int idx)

@@ -928,12 +928,12 @@ void run_columns_la(ps_pixelcnn *h, const StepCtx *rec, int ncols, ChainArgs ca,
             if (ahead) for (int t = 0; t < tiles_next; ++t) h->col_uses_lo[par ^ 1][t] += 1;
             ca.la_split = col_ahead; ca.done = h->done_col; ca.publish_upto = ahead ? col_ahead : 0;
             h->col_ahead_rec = ahead ? nrec : nullptr; h->col_ahead_n = nn; h->col_ahead_parity = par ^ 1;
-            timed(h, st, TAG_CHAIN, [&]() { hipLaunchKernelGGL(k_column_la, dim3(rows * 8), dim3(C1_THREADS), 0, st, na, ca); });
+            timed(h, st, TAG_CHAIN, LK_COLUMN_LA, [&]() { hipLaunchKernelGGL(k_column_la, dim3(rows * 8), dim3(C1_THREADS), 0, st, na, ca); });
         } else {   // a launch nobody prepared and that prepares nobody (a walk position by position): one set of use counts for all stages
             h->col_ahead_rec = nullptr;
             for (int t = 0; t < tiles; ++t) { h->col_uses_lo[0][t] += 1; h->col_uses_hi[0][t] += 1; }
             for (int t = 0; t < MAX_TILES; ++t) ca.tile_uses[t] = h->col_uses_hi[0][t];
-            timed(h, st, TAG_CHAIN, [&]() { hipLaunchKernelGGL(k_column, dim3(rows * 8), dim3(C1_THREADS), 0, st, na, ca); });
+            timed(h, st, TAG_CHAIN, LK_COLUMN, [&]() { hipLaunchKernelGGL(k_column, dim3(rows * 8), dim3(C1_THREADS), 0, st, na, ca); });
         }
     }
 }

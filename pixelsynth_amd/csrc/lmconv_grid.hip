@@ -1309,7 +1309,7 @@ void conv_taps(GemmArgs &a, const float *in, int ld, const float *wp, int Cin, i
 
 // grid of k_gemm: (channel blocks x item blocks x slots) laid out XCD by XCD, see the kernel
 // -> true when the post op `post` was done in the same launch (k_gemm_wg)
-bool launch_gemm(GemmArgs &a, int item_blocks, hipStream_t st, const Tuning &tune, const PostArgs *post = nullptr)
+bool launch_gemm(GemmArgs &a, int item_blocks, hipStream_t st, const Tuning &tune, const PostArgs *post = nullptr, ps_pixelcnn *h = nullptr)
 {
     a.nx = (a.Co_pad + 16 * GEMM_T - 1) / (16 * GEMM_T);
     a.ny = item_blocks;
@@ -1343,24 +1343,28 @@ bool launch_gemm(GemmArgs &a, int item_blocks, hipStream_t st, const Tuning &tun
             PostArgs pw = *post;
             pw.summed = 1;
             const dim3 gws((unsigned)(N_XCD * a.tpx)), bws(WS_THREADS);
-            if (kind == GW_CONVOUT) hipLaunchKernelGGL((k_gemm_ws<GW_CONVOUT>), gws, bws, 0, st, a, pw);
-            else if (kind == GW_CONVIN) hipLaunchKernelGGL((k_gemm_ws<GW_CONVIN>), gws, bws, 0, st, a, pw);
-            else hipLaunchKernelGGL((k_gemm_ws<GW_DIL>), gws, bws, 0, st, a, pw);
+            timed(h, st, TAG_GRID, kind == GW_CONVOUT ? LK_GEMM_WS_OUT : kind == GW_CONVIN ? LK_GEMM_WS_IN : LK_GEMM_WS_DIL, [&]() {
+                if (kind == GW_CONVOUT) hipLaunchKernelGGL((k_gemm_ws<GW_CONVOUT>), gws, bws, 0, st, a, pw);
+                else if (kind == GW_CONVIN) hipLaunchKernelGGL((k_gemm_ws<GW_CONVIN>), gws, bws, 0, st, a, pw);
+                else hipLaunchKernelGGL((k_gemm_ws<GW_DIL>), gws, bws, 0, st, a, pw);
+            });
             return true;
         }
         const bool fuse = post != nullptr;
         PostArgs pp{};
         if (fuse) { pp = *post; pp.summed = 1; }
         const int fz = fuse ? 1 : 0;
-        if (kind == GW_CONVOUT && TI == 1) hipLaunchKernelGGL((k_gemm_wg<GW_CONVOUT, 1>), grid, block, 0, st, a, pp, fz);
-        else if (kind == GW_CONVOUT) hipLaunchKernelGGL((k_gemm_wg<GW_CONVOUT, 2>), grid, block, 0, st, a, pp, fz);
-        else if (kind == GW_CONVIN && TI == 2) hipLaunchKernelGGL((k_gemm_wg<GW_CONVIN, 2>), grid, block, 0, st, a, pp, fz);
-        else if (kind == GW_CONVIN) hipLaunchKernelGGL((k_gemm_wg<GW_CONVIN, 4>), grid, block, 0, st, a, pp, fz);
-        else if (TI == 2) hipLaunchKernelGGL((k_gemm_wg<GW_DIL, 2>), grid, block, 0, st, a, pp, fz);
-        else hipLaunchKernelGGL((k_gemm_wg<GW_DIL, 4>), grid, block, 0, st, a, pp, fz);
+        timed(h, st, TAG_GRID, LK_GEMM_WG, [&]() {
+            if (kind == GW_CONVOUT && TI == 1) hipLaunchKernelGGL((k_gemm_wg<GW_CONVOUT, 1>), grid, block, 0, st, a, pp, fz);
+            else if (kind == GW_CONVOUT) hipLaunchKernelGGL((k_gemm_wg<GW_CONVOUT, 2>), grid, block, 0, st, a, pp, fz);
+            else if (kind == GW_CONVIN && TI == 2) hipLaunchKernelGGL((k_gemm_wg<GW_CONVIN, 2>), grid, block, 0, st, a, pp, fz);
+            else if (kind == GW_CONVIN) hipLaunchKernelGGL((k_gemm_wg<GW_CONVIN, 4>), grid, block, 0, st, a, pp, fz);
+            else if (TI == 2) hipLaunchKernelGGL((k_gemm_wg<GW_DIL, 2>), grid, block, 0, st, a, pp, fz);
+            else hipLaunchKernelGGL((k_gemm_wg<GW_DIL, 4>), grid, block, 0, st, a, pp, fz);
+        });
         return fuse;
     }
-    hipLaunchKernelGGL(k_gemm, dim3((unsigned)(N_XCD * a.nx * a.tpx * a.zgrid)), dim3(64), 0, st, a);
+    timed(h, st, TAG_GRID, LK_GEMM, [&]() { hipLaunchKernelGGL(k_gemm, dim3((unsigned)(N_XCD * a.nx * a.tpx * a.zgrid)), dim3(64), 0, st, a); });
     return false;
 }
 
@@ -1425,7 +1429,7 @@ void run_grid(ps_pixelcnn *h, int F, const int32_t *codes, const Masks &m, float
         a.partial = h->partial + (size_t)4 * f0 * h->L * (2 * NF);   // (the frame range's own part of the scratch: passes over disjoint ranges may run side by side)
         a.sum_bias = sum_bias;
         const int tiles = (nitems + 15) / 16;
-        if (launch_gemm(a, tiles, st, h->tune, post)) return 2;
+        if (launch_gemm(a, tiles, st, h->tune, post, h)) return 2;
         return a.sum_bias != nullptr ? 1 : 0;
     };
     {   // u_init + norm_init  (model.py:132)

@@ -176,9 +176,13 @@ struct ps_pixelcnn {
     pslm::Tuning tune;
     int env_col_cap = 0;            // col_cap as asked for (environment at creation or set_tuning); re-applied when the compute-unit count changes
     // bench.py profiling aid (ps_pixelcnn_time_column_step): event pair around every launch, by kernel tag
-    struct ProfRec { int tag; hipEvent_t e0, e1; int wave; };
+    struct ProfRec { int tag; hipEvent_t e0, e1; int wave; int kind; };
     std::vector<ProfRec> *prof = nullptr;
     int prof_wave = 0;            // the wavefront whose launches are being enqueued (timed runs)
+    // which kernel a launch was (pslm::LaunchKind): counted always (ps_pixelcnn_launch_counts: tests assert which forms a run took),
+    // event-timed between ps_pixelcnn_profile_begin / _end (bench.py: `roofline.kernels`)
+    long long launch_count[16] = {};
+    std::vector<ProfRec> prof_own;
     double flops_nbr = 0.0, flops_chain = 0.0, wbytes_nbr = 0.0, wbytes_chain = 0.0;  // dense work of one step, per frame
 };
 
@@ -203,13 +207,16 @@ inline int upload(ps_pixelcnn *h, float **p, const float *src, size_t count)
 
 struct Masks { const float *init, *und, *dil; };
 
-enum { TAG_NBR = 0, TAG_CHAIN = 1 };
+enum { TAG_NBR = 0, TAG_CHAIN = 1, TAG_GRID = 2 };
+// the kernels that carry the matrix work of the path, as launch_count / the profile see them (names: lmconv.hip launch_kind_name)
+enum LaunchKind { LK_COLUMN = 0, LK_COLUMN_LA, LK_COLUMN_TP, LK_COLUMN_TP8, LK_GEMM, LK_GEMM_WG, LK_GEMM_WS_OUT, LK_GEMM_WS_IN, LK_GEMM_WS_DIL, LK_N };
 
 template <typename Fn>
-inline void timed(ps_pixelcnn *h, hipStream_t st, int tag, Fn &&launch)
+inline void timed(ps_pixelcnn *h, hipStream_t st, int tag, int kind, Fn &&launch)
 {
-    if (!h->prof) { launch(); return; }
-    ps_pixelcnn::ProfRec r{tag, nullptr, nullptr, h->prof_wave};
+    if (h) h->launch_count[kind] += 1;
+    if (!h || !h->prof) { launch(); return; }
+    ps_pixelcnn::ProfRec r{tag, nullptr, nullptr, h->prof_wave, kind};
     (void)hipEventCreate(&r.e0);
     (void)hipEventCreate(&r.e1);
     (void)hipEventRecord(r.e0, st);

@@ -806,7 +806,7 @@ void run_columns_tp(ps_pixelcnn *h, const StepCtx *rec, int ncols, const ChainAr
                 const int use_rows = rows;
                 ta.nbr_wgs = (8 - ta.chain_xcds) * use_rows;
                 ta.fill_nbr = -1; ta.fill_cnt = 0;
-                const bool affine = h->tune.tp_affine && h->tp_xent;
+                const bool affine = h->tune.tp_affine && h->tp_xent && h->nwork_tp <= TP_XENT_MAX;   // (a longer work table never filled tp_xent)
                 // spare CUs of the chain XCDs as neighbour workgroups; stage-affine: as many as deal evenly to the neighbour XCDs' shares
                 // (workgroup nb works for share nb % nx wherever it runs -- these fetch their weights through a chain XCD's L2)
                 const int fill = !h->tune.tp_fill || use_rows != rows ? 0 : affine ? spare / (8 - ta.chain_xcds) * (8 - ta.chain_xcds) : spare;
@@ -826,7 +826,7 @@ void run_columns_tp(ps_pixelcnn *h, const StepCtx *rec, int ncols, const ChainAr
             }
             ta.trace = (trace_sel < 0 || trace_sel == h->tp_launch_no) ? h->tp_trace : nullptr;
             h->tp_launch_no += 1;
-            timed(h, st, TAG_CHAIN, [&]() {
+            timed(h, st, TAG_CHAIN, ct8 ? LK_COLUMN_TP8 : LK_COLUMN_TP, [&]() {
                 if (ct8) hipLaunchKernelGGL(k_column_tp8, dim3(grid), dim3(TP_THREADS), 0, st, ta);
                 else hipLaunchKernelGGL(k_column_tp, dim3(grid), dim3(TP_THREADS), 0, st, ta);
             });

@@ -140,25 +140,29 @@ def render_pipelined(model, img, depth, cam, chunks, seeds, temperature=0.7):
         if out is not None:
             sample = model.vqvae.decode_code(out["codes"])
             frames.append(model.get_combined(out["gen_fs"], sample, out["background_mask"]))
-    for k, chunk in enumerate(chunks):
-        if planned is None:
-            planned = model.plan_views(*inputs(chunk))
-        V = len(chunk)
-        # the draws of a view are seeded by the VIEW (its index in the trajectory), not by where the sharding put it: a frame is
-        # the same picture on one GPU or eight
-        uniforms = torch.stack([torch.rand(1024, generator=torch.Generator(device="cpu").manual_seed(int(sd))) for sd in seeds[k]]).to(img.device)
-        out = (model.outpaint_pipelined if overlap else model.outpaint_planned)(planned, None, temperature=temperature, uniforms=uniforms)
-        planned = None
-        if k + 1 < len(chunks):
-            if k == 0:
-                side.wait_stream(main)      # (the shared inputs were produced on the main stream)
-            with torch.cuda.stream(side):
-                planned = model.plan_views(*inputs(chunks[k + 1]))
-            model.adopt_planned(planned, main)
-            main.wait_stream(side)
-        finish(out)
-    if overlap:
-        finish(model.outpaint_flush())
+    try:
+        for k, chunk in enumerate(chunks):
+            if planned is None:
+                planned = model.plan_views(*inputs(chunk))
+            V = len(chunk)
+            # the draws of a view are seeded by the VIEW (its index in the trajectory), not by where the sharding put it: a frame is
+            # the same picture on one GPU or eight
+            uniforms = torch.stack([torch.rand(1024, generator=torch.Generator(device="cpu").manual_seed(int(sd))) for sd in seeds[k]]).to(img.device)
+            out = (model.outpaint_pipelined if overlap else model.outpaint_planned)(planned, None, temperature=temperature, uniforms=uniforms)
+            planned = None
+            if k + 1 < len(chunks):
+                if k == 0:
+                    side.wait_stream(main)      # (the shared inputs were produced on the main stream)
+                with torch.cuda.stream(side):
+                    planned = model.plan_views(*inputs(chunks[k + 1]))
+                model.adopt_planned(planned, main)
+                main.wait_stream(side)
+            finish(out)
+        if overlap:
+            finish(model.outpaint_flush())
+    except BaseException:
+        model.outpaint_reset()      # (a batch left in flight must not be merged into the next sequence's launches)
+        raise
     if chunks:
         model.outpaint2.engine(32, 32, len(chunks[-1])).check()
     return frames

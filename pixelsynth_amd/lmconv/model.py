@@ -78,6 +78,30 @@ class PixelCNNEngine:
                    f"ps_pixelcnn_get_tuning({key})")
         return v.value
 
+    # ---- which kernels carried the matrix work (include/pixelsynth_hip_debug.h; tests and bench.py, not the product path)
+    @staticmethod
+    def launch_kind_names():
+        L = _lib.lib()
+        return [L.ps_pixelcnn_launch_kind_name(k).decode() for k in range(L.ps_pixelcnn_launch_kinds())]
+
+    def launch_counts(self):
+        """{kernel: launches of this engine since its creation} (host counters)."""
+        names = self.launch_kind_names()
+        buf = (ctypes.c_longlong * len(names))()
+        _lib.check(_lib.lib().ps_pixelcnn_launch_counts(self.handle, ctypes.cast(buf, ctypes.c_void_p), len(names)), "ps_pixelcnn_launch_counts")
+        return dict(zip(names, (int(v) for v in buf)))
+
+    def profile_begin(self):
+        _lib.check(_lib.lib().ps_pixelcnn_profile_begin(self.handle), "ps_pixelcnn_profile_begin")
+
+    def profile_end(self):
+        """Synchronises -> {kernel: (launches, summed ms)} of the launches since profile_begin (HIP events on the launches' own streams)."""
+        names = self.launch_kind_names()
+        n, ms = (ctypes.c_int * len(names))(), (ctypes.c_float * len(names))()
+        _lib.check(_lib.lib().ps_pixelcnn_profile_end(self.handle, len(names), ctypes.cast(n, ctypes.c_void_p), ctypes.cast(ms, ctypes.c_void_p)),
+                   "ps_pixelcnn_profile_end")
+        return {k: (int(a), float(b)) for k, a, b in zip(names, n, ms)}
+
     def close(self):
         if getattr(self, "handle", None):
             _lib.lib().ps_pixelcnn_destroy(self.handle)

@@ -117,8 +117,13 @@ class LinearNoiseLayer(nn.Module):
         if noise is None:
             noise = torch.randn(x.size(0), self.noise_sz).to(x.device)
         B, C = noise.size(0), self.bn.stored_mean.numel()
+        bufs = (self.bn.stored_mean, self.bn.stored_var)
         if (x.is_cuda and not torch.is_grad_enabled() and not self.training and not self.bn.accumulate_standing and B == x.size(0)
-                and noise.dtype == torch.float32 and all(type(m) is nn.Linear and m.bias is None for m in (self.gain, self.bias))):
+                and noise.dtype == torch.float32 and noise.is_cuda and noise.device == x.device   # (the kernel takes raw pointers: a host
+                # tensor or one of another device must go the torch way, where it raises the usual device-mismatch error)
+                and all(t.is_cuda and t.device == x.device and t.dtype == torch.float32 and t.is_contiguous() for t in bufs)
+                and (pend is None or (pend.is_cuda and pend.device == x.device and pend.dtype == torch.float32 and pend.is_contiguous()))
+                and all(type(m) is nn.Linear and m.bias is None for m in (self.gain, self.bias))):
             from torch.nn.utils.spectral_norm import SpectralNorm
             ws = []
             for lin in (self.gain, self.bias):
@@ -295,6 +300,13 @@ def _overflow_flag(device):
     if key not in _overflow_flags:
         _overflow_flags[key] = torch.zeros(1, dtype=torch.int32, device=device)
     return _overflow_flags[key]
+
+
+def clear_f16x3_overflow(device):
+    """Asynchronous: forget what earlier passes left in the flag, so that the next check_f16x3_overflow speaks of the pass in between only."""
+    flag = _overflow_flags.get(str(device))
+    if flag is not None:
+        flag.zero_()
 
 
 def check_f16x3_overflow(device):
@@ -492,7 +504,10 @@ class ResNet_Block(nn.Module):
         a, ba, _ = self._norm_relu_conv(self.ch_a[0], self.ch_a[2], x, noise[0])
         mode = _conv_mode(self.opt)
         if (self.resample and self.resample != "Up" and mode == "f16x3" and _is_nhwc_cuda(x) and not torch.is_grad_enabled()
-                and x.size(2) % 2 == 0 and x.size(3) % 2 == 0 and self.ch_b[0].kernel_size == (1, 1) and self.ch_b[0].stride == (1, 1)):
+                and x.size(2) % 2 == 0 and x.size(3) % 2 == 0 and self.ch_b[0].kernel_size == (1, 1) and self.ch_b[0].stride == (1, 1)
+                # (the 1 x 1 conv's bias must come back SEPARATE from _conv_split, to go through the pool's bias * inside / 9 term: a
+                # convolution that cannot be taken apart returns conv(x) + bias, whose border pixels would then differ from the reference's)
+                and (self.ch_b[0].bias is None or (self.ch_b[0].out_channels % 4 == 0 and _plain_conv_weight(self.ch_b[0], x) is not None))):
             # Down: avg_pool2d and the 1 x 1 convolution of the other branch commute -- pool first, convolve a quarter of the pixels,
             # and hand the result to the pooling of this branch as its `post` term (both biases ride through the pooling: bias=)
             b, bb = _conv_split(self.ch_b[0], _resample_sum(self.resample, x, None))
@@ -578,12 +593,19 @@ class Unet(nn.Module):
             if self._DEC_NORM[i]:
                 setattr(self, self._DEC_NORM[i], norm(dec_out[i]))
 
-    MAX_BATCH = 64   # images per call on the GPU: dconv8 reads 64 channels at the input's size -- 2 GiB, where MIOpen's fp32 kernels start
-    #                  to index wrongly (_conv2d_batches), at 128 images of 256 x 256
+    MAX_BATCH = 64   # images per call on the GPU, at most
+
+    def _images_per_call(self, H, W):
+        """dconv8 reads 2 f channels at the input's size: the call's batch keeps that activation below the 2 GiB at which MIOpen's fp32
+        kernels start to index wrongly (_conv2d_batches) -- by bytes, so at 512 x 512 it is a quarter of what it is at 256 x 256."""
+        per = self.dconv8.in_channels * H * W * 4
+        return max(1, min(self.MAX_BATCH, (_MIOPEN_SAFE_BYTES - 1) // per))
 
     def forward(self, input):
-        if input.is_cuda and input.size(0) > self.MAX_BATCH and not torch.is_grad_enabled() and not self.training:
-            return torch.cat([self.forward(input[i:i + self.MAX_BATCH]) for i in range(0, input.size(0), self.MAX_BATCH)])
+        if input.is_cuda and not torch.is_grad_enabled() and not self.training:
+            n = self._images_per_call(input.size(2), input.size(3))
+            if input.size(0) > n:
+                return torch.cat([self.forward(input[i:i + n]) for i in range(0, input.size(0), n)])
         skips, h = [], _nhwc(self, input)
         for i in range(8):
             h = getattr(self, f"conv{i + 1}")(h if i == 0 else F.leaky_relu(h, 0.2))

@@ -127,14 +127,23 @@ class VQVAETop(nn.Module):
         self.dec = Decoder(embed_dim, in_channel, channel, n_res_block, n_res_channel, stride=4)
 
     # ---------------------------------------------------------------- the novel-view path
-    MAX_BATCH = 256   # views per call on the GPU: the widest activation (64 channels at half the input's size) stays below the 2 GiB at
-    #                   which MIOpen's fp32 kernels start to index wrongly (networks/architectures.py:_conv2d_batches; 256 x 256 inputs)
+    MAX_BATCH = 256   # views per call on the GPU, at most
+    _MIOPEN_SAFE_BYTES = 2 ** 31   # where MIOpen's fp32 kernels start to index wrongly (networks/architectures.py:_conv2d_batches)
+
+    def _views_per_call(self, H, W):
+        """Views per call on the GPU for (H, W) IMAGES: the widest activation on either side of the codes -- channel / 2 maps at half the
+        image's size (enc_b's first convolution, dec's last but one), channel maps at a quarter -- stays below the 2 GiB at which MIOpen's
+        fp32 kernels index wrongly, whatever the image size (256 x 256, 64 maps: 512 views; capped at MAX_BATCH)."""
+        c = self.enc_b.blocks[0].out_channels          # channel // 2
+        per = max(c * (H // 2) * (W // 2), 2 * c * (H // 4) * (W // 4), 3 * H * W) * 4
+        return max(1, min(self.MAX_BATCH, (self._MIOPEN_SAFE_BYTES - 1) // per))
 
     @torch.no_grad()
     def encode_codes(self, input):
         """(B,3,256,256) -> top codes (B,32,32) int32, on the device (= ``encode(input)[3]``, z_buffermodel.py:345)."""
-        if input.is_cuda and input.size(0) > self.MAX_BATCH:
-            return torch.cat([self.encode_codes(input[i:i + self.MAX_BATCH]) for i in range(0, input.size(0), self.MAX_BATCH)])
+        n = self._views_per_call(input.size(2), input.size(3)) if input.is_cuda else input.size(0)
+        if input.size(0) > n:
+            return torch.cat([self.encode_codes(input[i:i + n]) for i in range(0, input.size(0), n)])
         lat = self.quantize_conv_t(self.enc_t(self.enc_b(input)))  # (B,64,32,32)
         B, _, H, W = lat.shape
         return self.quantize_t.nearest(lat.float(), 1, H * W).view(B, H, W)
@@ -142,8 +151,9 @@ class VQVAETop(nn.Module):
     @torch.no_grad()
     def decode_code(self, code_t):
         """codes (B,32,32) int -> image (B,3,256,256) (vqvae.py:305-311, z_buffermodel.py:250)."""
-        if code_t.is_cuda and code_t.size(0) > self.MAX_BATCH:
-            return torch.cat([self.decode_code(code_t[i:i + self.MAX_BATCH]) for i in range(0, code_t.size(0), self.MAX_BATCH)])
+        n = self._views_per_call(8 * code_t.size(-2), 8 * code_t.size(-1)) if code_t.is_cuda else code_t.size(0)
+        if code_t.size(0) > n:
+            return torch.cat([self.decode_code(code_t[i:i + n]) for i in range(0, code_t.size(0), n)])
         return self.decode(self.quantize_t.embed_grid(code_t))
 
     # ---------------------------------------------------------------- reference-shaped surface

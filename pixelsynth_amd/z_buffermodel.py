@@ -22,7 +22,7 @@ from . import _lib
 from .lmconv.layers import PONO
 from .lmconv.model import OurPixelCNN
 from .lmconv.sample import sample
-from .networks.architectures import check_f16x3_overflow, decoder_conv
+from .networks.architectures import check_f16x3_overflow, clear_f16x3_overflow, decoder_conv
 from .projection.z_buffer_manipulator import PtsManipulator
 
 
@@ -483,7 +483,12 @@ class ZbufferModelPts(nn.Module):
         cut = split_tail(ws, min(self.PIPE_MERGE_MAX, launch_capacity(V) * 45 // 64))
         head = (dcols[:ws[cut]], ws[:cut + 1])
         tail = (dcols[ws[cut]:], ws[cut:] - ws[cut])
-        prev = st["pending"]
+        prev, early = st["pending"], None
+        if prev is not None and prev["temperature"] != temperature:
+            # the tail of the batch in flight was planned with ANOTHER temperature: it cannot ride in this batch's launches (a launch has
+            # one temperature), so it runs now as launches of its own, with its own -- the codes stay those of outpaint_planned
+            self._pipe_columns(eng, st, args, prev["tail"][0], prev["tail"][1], prev["first_step"], prev["temperature"])
+            prev, early = None, prev
         if prev is None:
             mcols, mws, first = head[0], head[1], plan.first_step
         else:
@@ -492,7 +497,7 @@ class ZbufferModelPts(nn.Module):
         self._pipe_columns(eng, st, args, mcols, mws, first, temperature)
         st["pending"] = dict(planned=planned, tail=tail, first_step=plan.first_step, slot=h, temperature=temperature)
         st["slot"] = 1 - h
-        return self._pipe_done(st, prev)
+        return self._pipe_done(st, prev if early is None else early)
 
     def _pipe_columns(self, eng, st, args, cols, ws, first, temperature):
         if len(ws) > 1 and ws[-1] > 0:
@@ -519,6 +524,15 @@ class ZbufferModelPts(nn.Module):
         args = (st["codes"], st["order"], st["region"], st["masks"][0], st["masks"][1], st["masks"][2])
         self._pipe_columns(eng, st, args, prev["tail"][0], prev["tail"][1], prev["first_step"], prev["temperature"])
         return self._pipe_done(st, prev)
+
+    def outpaint_reset(self):
+        """Forget a batch outpaint_pipelined still holds (its tail wavefronts never run; its codes are lost).  For a caller whose
+        sequence of batches was cut short by an exception: without this the NEXT sequence of the same batch size would merge the stale
+        tail into its first launches and get the stale batch's dict back as its first result (driver.render_pipelined and bench.py
+        call it on their way out of a failed run)."""
+        st = self.__dict__.get("_pipe")
+        if st is not None:
+            st["pending"] = None
 
     PREFIX_SPLIT_MIN_VIEWS = 64   # below this a launch of half the frames no longer fills the chip
     PREFIX_STREAMS = 2            # 128 views: 18.16 -> 17.95 ms per step (three alternating pairs); 4 ranges lose (18.59)
@@ -607,7 +621,7 @@ class ZbufferModelPts(nn.Module):
         if paired:
             outputs["OutputImg"] = output_img
         if getattr(self.opt, "no_outpainting", False):   # :383-384
-            outputs["PredImg"] = gen_fs if self.projector is None else self.projector(gen_fs, None)
+            outputs["PredImg"] = self._project_checked(gen_fs, None)
             return None, outputs
         if self.vqvae is not None:
             enc = getattr(self.vqvae, "encode_codes", None)      # our mirror: top codes only, int32, on the device
@@ -649,20 +663,34 @@ class ZbufferModelPts(nn.Module):
         combined = self.get_combined(gen_fs, self.vqvae.decode_code(codes), background_mask)
         return combined if self.projector is None else self.projector(combined, background_mask)
 
-    def _decode_checked(self, gen_fs, background_mask, codes):
-        """_decode_candidate, then (synchronising) the question whether a split-fp16 convolution of the refinement decoder met an
-        activation beyond fp16's range (csrc/conv_f16x3.hip raises a flag; the image is then wrong): if so the pass is run again
-        with every convolution through torch in fp32, with a warning.  Weights under spectral norm behind normalisation layers do
-        not get there; a checkpoint that does should set opt.decoder_conv = "fp32" and save itself the first attempt."""
-        pred = self._decode_candidate(gen_fs, background_mask, codes)
+    def _run_checked(self, device, fn):
+        """fn() -- any pass through the refinement decoder -- then (synchronising) the question whether one of ITS split-fp16 convolutions
+        met an activation beyond fp16's range (csrc/conv_f16x3.hip raises a device flag; the image is then wrong): if so the pass is run
+        again with every convolution through torch in fp32, with a warning.  The flag is cleared BEFORE the pass (what an earlier,
+        unchecked pass left there is not this one's) and by the check.  Weights under spectral norm behind normalisation layers do not
+        get there; a checkpoint that does should set opt.decoder_conv = "fp32" and save itself the first attempt."""
+        clear_f16x3_overflow(device)
+        out = fn()
         try:
-            check_f16x3_overflow(gen_fs.device)
+            check_f16x3_overflow(device)
         except RuntimeError as err:
             import warnings
             warnings.warn(f"{err}: the decoder pass is run again in fp32")
             with decoder_conv("fp32"):
-                pred = self._decode_candidate(gen_fs, background_mask, codes)
-        return pred
+                out = fn()
+        return out
+
+    def _decode_checked(self, gen_fs, background_mask, codes):
+        """_decode_candidate behind the overflow check of _run_checked: every image that is returned, ranked or fed into the next frame
+        of a chain goes through here."""
+        return self._run_checked(gen_fs.device, lambda: self._decode_candidate(gen_fs, background_mask, codes))
+
+    def _project_checked(self, gen_fs, *mask):
+        """The no_outpainting form: the refinement decoder on the reprojected features alone (z_buffermodel.py:383-384; the chained mode
+        calls it without the mask argument), checked likewise."""
+        if self.projector is None:
+            return gen_fs
+        return self._run_checked(gen_fs.device, lambda: self.projector(gen_fs, *mask))
 
     @torch.no_grad()
     def get_best_sample(self, *args, uniforms=None, shard=False):
@@ -715,7 +743,7 @@ class ZbufferModelPts(nn.Module):
                        uniforms=uniforms[idx].reshape(k * B, L).contiguous(), first_step=plan.first_step, waves=waves)
             eng.check()
             for j, i in enumerate(idx):
-                img = self._decode_candidate(gen_fs, background_mask, c[j * B:(j + 1) * B].view(B, G, self.obs[2]))
+                img = self._decode_checked(gen_fs, background_mask, c[j * B:(j + 1) * B].view(B, G, self.obs[2]))
                 imgs[i] = img
                 if n > 1:
                     disc.append(float(netD.run_discriminator_one_step(img, input_img)["D_Fake"].mean().cpu()))
@@ -750,7 +778,7 @@ class ZbufferModelPts(nn.Module):
             plan = build_ar_plan(background_mask, self.obs[1])
             gen_img = self.get_best_sample(plan, self.vqvae.encode_codes(gen_fs), background_mask, gen_fs, netD, input_img)
         else:
-            gen_img = gen_fs if self.projector is None else self.projector(gen_fs)
+            gen_img = self._project_checked(gen_fs)
         st.img, st.cloud, st.feats, st.background, st.out_RTinv = gen_img, cloud, feats, background_mask, out_RTinv
         return gen_img, gen_fs, depth, background_mask
 

@@ -20,7 +20,8 @@ def header_symbols(name="pixelsynth_hip.h"):
 
 
 DEBUG_ONLY = {"ps_pixelcnn_set_tuning", "ps_pixelcnn_get_tuning", "ps_pixelcnn_time_ar_run_waves", "ps_pixelcnn_time_ar_run_waves_range", "ps_pixelcnn_time_column_step",
-              "ps_pixelcnn_debug_cache"}
+              "ps_pixelcnn_debug_cache", "ps_pixelcnn_launch_kinds", "ps_pixelcnn_launch_kind_name", "ps_pixelcnn_launch_counts",
+              "ps_pixelcnn_profile_begin", "ps_pixelcnn_profile_end"}
 
 
 def test_library_exports_every_declared_symbol():
@@ -37,6 +38,10 @@ def test_library_exports_every_declared_symbol():
     exported = {ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith("ps_")}
     assert exported == set(names) | set(debug), exported ^ (set(names) | set(debug))
     assert L.ps_abi_version() == 2
+    # the library says what it was built from: the in-tree one is a product build (no tuning / trace / experiment macro)
+    info = L.ps_build_info().decode()
+    assert "abi 2" in info and "gfx950" in info and ("product build" in info) == (not os.environ.get("PS_HIP_LIB")), info
+    assert [L.ps_pixelcnn_launch_kind_name(k).decode() for k in range(L.ps_pixelcnn_launch_kinds())][-3:] == ["k_gemm_ws<0>", "k_gemm_ws<1>", "k_gemm_ws<2>"]
 
 
 def test_error_channel():
