@@ -215,8 +215,10 @@ def measure_roofline(model, d, out, V, live_pmc=False):
     10.42 MFLOP per column = the 32 matrix stages' centre taps (the chain role: 16-column MFMA tiles in the throughput form
     k_column_tp, fp32 FMA chains on the vector ALU in the latency form k_column_la) plus the neighbour-tap partial sums of all 32
     masked convs (fp32 MFMA in both forms, masked taps skipped) -- the u_init product is a gather and is not priced.  fp32 MFMA and
-    packed fp32 FMA share gfx950's dense fp32 peak (157.3 TFLOP/s).  A launch is bounded by the LATENCY of its 33 dependent stages,
-    not by throughput; `traffic` is measured in the run itself when live_pmc is set (live_pmc_traffic: two rocprofv3
+    packed fp32 FMA share gfx950's dense fp32 peak (157.3 TFLOP/s).  At C5's size every phase of the step is throughput-bound (the
+    launches are full) -- the small batches under other_single_gpu_configs are bound by the latency of a launch's 33
+    dependent stages; which kernel is the LARGEST phase of the step is `roofline.kernel` / `roofline.kernels` (measure_kernels), the
+    top-level achieved / frac stay the column launch's for comparability with earlier rounds; `traffic` is measured in the run itself when live_pmc is set (live_pmc_traffic: two rocprofv3
     --pmc passes of this command), otherwise it, and always `mfma_counters` and `kernel_table`, come from the newest committed PMC record
     of the same workload (profiles/README.md names it) -- counter passes cannot run inside a timed bench."""
     plan = out["plan"]
@@ -294,7 +296,7 @@ def measure_roofline(model, d, out, V, live_pmc=False):
               if tp else
               "k_column (one launch per wavefront of independent AR columns: per-column centre-tap chains + "
               "neighbour-tap slots of all 32 masked convs)")
-    return {"bound": "mfma", "kernel": kernel,
+    return {"bound": "mfma", "column_launch_kernel": kernel,
             "achieved": round(tf, 4), "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
             "frac": round(tf / FP32_MFMA_PEAK_TF, 6), "traffic": traffic, "traffic_source": traffic_src, "mfma_counters": mfma_util,
             "algorithmic_flops_per_launch": round(fl), "avg_launch_us": round(us, 3),
@@ -305,9 +307,10 @@ def measure_roofline(model, d, out, V, live_pmc=False):
             "columns_with_one_prefix_for_the_batch": int(cols.shape[0]),
             "pmc_live": live, "traffic_committed_record": (pmc or {}).get("traffic_bytes_per_launch"),
             "kernel_table": kernel_table,
-            "kernel_table_note": "every kernel alone on the chip (PMC and trace passes with PS_PREFIX_STREAMS=1); the default step deals "
-                                 "the prefix pass to two frame ranges on two streams: twice the k_gemm_wg launches at half the items, "
-                                 "overlapping (z_buffermodel.PREFIX_STREAMS)",
+            "kernel_table_note": "the committed PMC record's table (every kernel alone on the chip: PMC and trace passes with "
+                                 "PS_PREFIX_STREAMS=1; the default step deals the prefix pass to two frame ranges on two streams: twice the "
+                                 "k_gemm_ws launches at half the items, overlapping -- z_buffermodel.PREFIX_STREAMS); THIS run's own table is "
+                                 "`kernels`",
             "walk_positions_without_wavefronts": 1024 - plan.first_step,
             "reference_definition": {
                 "what": "the same launch priced at what the reference schedules for its columns (SURVEY 8d): one whole-grid "
@@ -334,11 +337,11 @@ def live_pmc_traffic():
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None
-    acc = {}
+    acc, by_kind = {}, {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_MFMA"):
         tmp = tempfile.mkdtemp(prefix="ps_pmc_", dir="/tmp")
         cmd = ([exe, "--pmc", counter, "--output-format", "csv", "-d", tmp, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__)]
-               + sys.argv[1:] + ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extra"])
+               + sys.argv[1:] + ["--steps", "6", "--warmup", "1", "--no-cpu-baseline", "--no-extra"])
         proc = None
         try:
             proc = subprocess.Popen(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp", PS_BENCH_PMC_CHILD="1"), stdout=subprocess.DEVNULL,
@@ -349,10 +352,18 @@ def live_pmc_traffic():
                 with open(path) as fh:
                     for row in csv.DictReader(fh):
                         name = row.get("Kernel_Name") or row.get("Kernel Name") or ""
+                        if (row.get("Counter_Name") or row.get("Counter Name")) != counter:
+                            continue
+                        val = float(row.get("Counter_Value") or row.get("Counter Value") or 0)
                         kern = "k_column_tp" if "k_column_tp" in name else "k_column_la" if "k_column_la" in name else None
-                        if kern and (row.get("Counter_Name") or row.get("Counter Name")) == counter:
+                        if kern:
                             a = acc.setdefault((kern, counter), [0.0, 0])
-                            a[0] += float(row.get("Counter_Value") or row.get("Counter Value") or 0)
+                            a[0] += val
+                            a[1] += 1
+                        kind = kernel_kind_of(name)     # (every kernel that carries matrix work, by launch kind: roofline.kernels)
+                        if kind:
+                            a = by_kind.setdefault((kind, counter), [0.0, 0])
+                            a[0] += val
                             a[1] += 1
         except Exception:
             if proc is not None and proc.poll() is None:
@@ -371,11 +382,133 @@ def live_pmc_traffic():
                "SQ_INSTS_MFMA_mean": round(acc[(k, "SQ_INSTS_MFMA")][0] / acc[(k, "SQ_INSTS_MFMA")][1])} for k in kernels}
     n = sum(v["dispatches"] for v in per.values())
     total = sum((2 * v["FETCH_SIZE_KB_mean"] + v["WRITE_SIZE_KB_mean"]) * 1024 * v["dispatches"] for v in per.values())
+    kinds = {}
+    for (kind, counter), (tot, cnt) in by_kind.items():
+        kinds.setdefault(kind, {})[counter + "_mean"] = tot / max(1, cnt)
+        kinds[kind]["dispatches"] = cnt
     return {"traffic_bytes_per_launch": int(round(total / n)),
             "SQ_INSTS_MFMA_per_launch": int(round(sum(v["SQ_INSTS_MFMA_mean"] * v["dispatches"] for v in per.values()) / n)), "per_kernel": per,
+            "by_launch_kind": kinds,
             "source": "measured in this run: rocprofv3 --pmc FETCH_SIZE, --pmc WRITE_SIZE and --pmc SQ_INSTS_MFMA, one pass each over this command "
-                      "with --steps 2 --warmup 1 (no trace beside the counters); average over all column launches; FETCH_SIZE x 2 (gfx950 "
-                      "correction)"}
+                      "with --steps 6 --warmup 1 and nothing but the timed steps in it (no trace beside the counters; the child skips "
+                      "the roofline's own measurement runs); average over all column launches; FETCH_SIZE x 2 (gfx950 correction)"}
+
+
+def kernel_kind_of(name):
+    """rocprofv3 kernel name -> the engine's launch kind (PixelCNNEngine.launch_kind_names), or None."""
+    import re
+    m = re.search(r"k_gemm_ws<\(?[^0-9>]*(\d)", name)
+    if m:
+        return f"k_gemm_ws<{m.group(1)}>"
+    for k in ("k_column_tp8", "k_column_tp", "k_column_la", "k_gemm_wg"):
+        if k in name:
+            return k
+    if re.search(r"\bk_column\b", name):
+        return "k_column"
+    if re.search(r"\bk_gemm\b", name):
+        return "k_gemm"
+    return None
+
+
+# dense fp32 work of one (frame, location) at one stage of the network (SURVEY 8d: 2 x taps x Cin x Cout; the 8 gated blocks of the down
+# pass add their nin_skip product, 2 x 160 x 80): what `roofline.kernels[].dense_flops_per_launch` prices an EVALUATED item at
+STAGE_FLOPS = {"conv_out": 2 * 9 * 160 * 160, "conv_in": 2 * 9 * 160 * 80, "nin_skip": 2 * 160 * 80, "dilated": 2 * 9 * 80 * 80}
+MFMA_FLOP = 2 * 16 * 16 * 4          # one v_mfma_f32_16x16x4_f32
+N_SIMD, NOMINAL_MHZ = 1024, 2400.0
+
+
+def measure_kernels(model, d, V, world, side, plan, live, ms_per_step, steps=4):
+    """`roofline.kernels`: every kernel that carries matrix work, as the timed region runs it -- `steps` more pipelined steps with a HIP
+    event pair around each such launch on the stream it goes to (ps_pixelcnn_profile_begin / _end): launches per step, event-timed
+    average, ms per step (the prefix pass runs on two streams: its kernels overlap each other and the splat, so the column sums to more than
+    the step), dense-equivalent flops (column launches: SURVEY 8d's 10.42 MFLOP per column; whole-grid launches: the items the pass
+    really evaluates at that stage -- read back from the engine's dependency-cone table -- x the stage's dense flops), EXECUTED flops
+    (SQ_INSTS_MFMA of this run's own --pmc pass x 2048; closed taps are skipped, so executed < dense) and both as fractions of the fp32
+    matrix peak (`frac_executed` = the share of all SIMD cycles the matrix pipes are busy at the nominal 2.4 GHz).
+    -> (kernels, dominant kernel name, executed flops per step)."""
+    pipelined = ar_pipelined(V)
+    eng = model.outpaint2.engine(32, 32, 2 * V if pipelined else V)
+    run_steps(model, d, world, 2, side)
+    torch.cuda.synchronize()
+    # the two phases of a step on the main stream: [prefix pass + the small kernels around it | column launches]; events around the
+    # column launches of every step (outpaint_pipelined -> _pipe_columns; outpaint_planned has no such seam and reports none)
+    marks = []
+    real_cols = getattr(model, "_pipe_columns")
+
+    def cols(*a, **k):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        real_cols(*a, **k)
+        e1.record()
+        marks.append((e0, e1))
+    model._pipe_columns = cols
+    eng.profile_begin()
+    try:
+        run_steps(model, d, world, steps, side)
+    finally:
+        prof = eng.profile_end()
+        del model._pipe_columns          # (the instance attribute: the class's method is back)
+    phases = None
+    if pipelined and len(marks) >= steps + 1:     # (steps merged launches + the flush)
+        col_ms = [a.elapsed_time(b) for a, b in marks[1:steps]]                       # steady-state steps only (not the first, not the flush)
+        pre_ms = [marks[i][1].elapsed_time(marks[i + 1][0]) for i in range(0, steps - 1)]
+        phases = {"column_launches_ms": round(float(np.mean(col_ms)), 3), "prefix_pass_and_small_kernels_ms": round(float(np.mean(pre_ms)), 3),
+                  "what": "main-stream event marks around the column launches of the steady-state steps of this profile run: the step is the "
+                          "prefix phase (whole-grid pass on two streams, the next step's splat beside it, item sort / cone / context kernels) "
+                          "followed by the column phase"}
+    # items the whole-grid pass evaluates per stage: ranks [start[stage][f], end[f]) of every frame
+    N_EVAL = 33
+    F = eng.max_frames
+    _lib.lib().ps_pixelcnn_debug_cache.restype = ctypes.c_void_p
+    ptr = _lib.lib().ps_pixelcnn_debug_cache(eng.handle, 5, 0)
+    raw = type("Raw", (), {"__cuda_array_interface__": {"shape": (N_EVAL, F), "typestr": "<i4", "data": (ptr, False), "version": 2}})()
+    starts = torch.as_tensor(raw, device=d["codes"].device).cpu().numpy()[:, :V].astype(np.int64)
+    per_frame = pipelined and getattr(plan, "waves_frames", None) is not None and model.PER_FRAME_PREFIX
+    ends = np.asarray(plan.first_steps, np.int64)[:V] if per_frame else np.full(V, plan.first_step, np.int64)
+    items = np.maximum(ends[None, :] - np.minimum(starts, ends[None, :]), 0).sum(1)          # (33,) per prefix pass of V frames
+    dense_grid = {"k_gemm_ws<0>": sum(items[15 + g] * STAGE_FLOPS["conv_out"] for g in range(14)),
+                  "k_gemm_ws<1>": sum(items[1 + g] * (STAGE_FLOPS["conv_in"] + (STAGE_FLOPS["nin_skip"] if g >= 6 else 0)) for g in range(14)),
+                  "k_gemm_ws<2>": sum(items[29 + k] * STAGE_FLOPS["dilated"] for k in range(4))}
+    n_items = {"k_gemm_ws<0>": int(items[15:29].sum()), "k_gemm_ws<1>": int(items[1:15].sum()), "k_gemm_ws<2>": int(items[29:33].sum())}
+    ncols = int((plan.waves_frames[0] if per_frame else plan.waves[0]).shape[0])
+    col_launches = sum(prof[k][0] for k in prof if k.startswith("k_column"))
+    kinds = (live or {}).get("by_launch_kind", {})
+    rows, executed_step = [], 0.0
+    for name, (n, ms) in prof.items():
+        if n == 0:
+            continue
+        per_step, us = n / steps, ms * 1e3 / n
+        row = {"kernel": name, "launches_per_step": round(per_step, 2), "avg_launch_us": round(us, 2), "ms_per_step": round(ms / steps, 3)}
+        if name.startswith("k_column"):
+            # (a step's columns over its column launches of every form: the forms are not priced apart -- a schedule's wide wavefronts
+            # take the throughput forms, its narrow ones the latency form)
+            dense = 10424320.0 * ncols / max(1.0, col_launches / steps)
+            row["columns_per_launch_mean_over_all_forms"] = round(ncols / max(1.0, col_launches / steps), 1)
+        elif name in dense_grid:
+            dense = float(dense_grid[name]) / max(1.0, per_step)      # (one pass per step; its launches are per stage AND per frame range)
+            row["items_evaluated_per_step"] = n_items[name]
+        else:
+            dense = None
+        if dense is not None:
+            row["dense_flops_per_launch"] = round(dense)
+            row["frac_dense"] = round(dense / (us * 1e-6) / 1e12 / FP32_MFMA_PEAK_TF, 4)
+        k = kinds.get(name)
+        if k and "SQ_INSTS_MFMA_mean" in k:
+            mf = k["SQ_INSTS_MFMA_mean"]
+            row["mfma_instructions_per_launch"] = round(mf)
+            row["executed_flops_per_launch"] = round(mf * MFMA_FLOP)
+            row["frac_executed"] = round(mf * 32.0 / N_SIMD / (us * NOMINAL_MHZ), 4)
+            executed_step += mf * MFMA_FLOP * per_step
+        rows.append(row)
+    rows.sort(key=lambda r: -r["ms_per_step"])
+    if phases is not None and kinds:
+        ex = {"column": 0.0, "prefix": 0.0}
+        for r in rows:
+            if "executed_flops_per_launch" in r:
+                ex["column" if r["kernel"].startswith("k_column") else "prefix"] += r["executed_flops_per_launch"] * r["launches_per_step"]
+        phases["column_launches_executed_frac"] = round(ex["column"] / (phases["column_launches_ms"] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF, 4)
+        phases["prefix_pass_executed_frac"] = round(ex["prefix"] / (phases["prefix_pass_and_small_kernels_ms"] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF, 4)
+    return rows, (rows[0]["kernel"] if rows else None), (executed_step if kinds else None), phases
 
 
 def latest_pmc_record(V):
@@ -793,6 +926,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-live-pmc", action="store_true", help="roofline.traffic from the committed PMC record only (no rocprofv3 --pmc passes)")
     ap.add_argument("--no-extra", action="store_true", help="skip the C3 single-view / C2 splat-only side measurements")
+    ap.add_argument("--live-pmc", action="store_true", help="the rocprofv3 --pmc passes of this command even with --no-extra")
     ap.add_argument("--dump-gather", metavar="NPZ", help="rank 0 saves what the last step gathered from all ranks (tests)")
     args = ap.parse_args()
 
@@ -886,18 +1020,44 @@ def main():
                                            "`steps` complete steps); the whole-grid pass takes every frame up to ITS first sampled position "
                                            "(per-frame prefixes), the columns start there" if ar_pipelined(V) else "")},
         }
+        # which library and which switches produced the number: a tuning / trace / experiment build (PS_HIP_LIB=...) says so itself
+        res["library"] = {"path": os.path.relpath(_lib.LIB_PATH, os.path.dirname(os.path.abspath(__file__))), "build": _lib.lib().ps_build_info().decode(),
+                          "env_overrides": {k: v for k, v in sorted(os.environ.items()) if k.startswith("PS_") and k not in ("PS_BENCH_PMC_CHILD",)}}
         if torch.distributed.is_available() and torch.distributed.is_initialized():   # what the backend itself reports (tools/scale.sh)
             res["collective"] = {"backend": torch.distributed.get_backend(), "world_size": torch.distributed.get_world_size(),
                                  "forced_on_one_rank": bool(FORCE_COLLECTIVE and world == 1)}
-        if world == 1:
+        if world == 1 and os.environ.get("PS_BENCH_PMC_CHILD") == "1":
+            pass      # (a counter pass of live_pmc_traffic: only the timed steps' kernels are wanted in it)
+        elif world == 1:
             try:
-                res["roofline"] = measure_roofline(model, d, out, V, live_pmc=not args.no_extra and not args.no_live_pmc)
+                res["roofline"] = measure_roofline(model, d, out, V, live_pmc=(not args.no_extra or args.live_pmc) and not args.no_live_pmc)
                 # the step as a whole against the same peak: every view is ONE whole-grid forward's worth of matrix work (SURVEY 8d:
                 # 11.43095 GFLOP, prefix pass + columns), whatever it is scheduled as; splat, planning and launch gaps count as time
                 step_tf = V * 11.43095e9 / (elapsed / args.steps) / 1e12
-                res["roofline"]["step"] = {"what": "views x 11.43095 GFLOP (one whole-grid forward's worth per view) / ms_per_step, the "
-                                                   "timed step with everything in it", "achieved": round(step_tf, 3), "peak": FP32_MFMA_PEAK_TF,
+                res["roofline"]["step"] = {"what": "views x 11.43095 GFLOP (one whole-grid forward's worth per view: SURVEY 8d's DENSE definition -- closed "
+                                                   "taps, the prefix cone and the u_init gather are work the kernels legitimately skip, so this is a "
+                                                   "dense-equivalent rate, NOT a utilisation; `executed_frac` is) / ms_per_step, the timed step with "
+                                                   "everything in it", "achieved": round(step_tf, 3), "peak": FP32_MFMA_PEAK_TF,
                                            "unit": "TFLOP/s", "frac": round(step_tf / FP32_MFMA_PEAK_TF, 4)}
+                try:
+                    rows, dominant, executed, phases = measure_kernels(model, d, V, world, side, plan, res["roofline"].get("pmc_live"),
+                                                               elapsed / args.steps * 1e3)
+                    res["roofline"]["kernels"] = rows
+                    res["roofline"]["kernels_note"] = ("event-timed per launch on the launch's own stream; the whole-grid pass runs as two frame ranges on two "
+                                                       "streams, so two k_gemm_ws launches share the chip and stretch each other: their ms_per_step sum to more "
+                                                       "than the phase's wall time and their frac_* are per-launch figures under that sharing -- the phase's own "
+                                                       "busy fraction is `phases.prefix_pass_executed_frac`")
+                    res["roofline"]["phases"] = phases
+                    res["roofline"]["kernel"] = (f"{dominant}: the largest phase of the step by summed kernel time (`kernels`, sorted); the top-level "
+                                                 "achieved / frac / avg_launch_us are the COLUMN launch's (`column_launch_kernel`), as in every round")
+                    if executed is not None:
+                        ex_tf = executed / (elapsed / args.steps) / 1e12
+                        res["roofline"]["step"]["executed_frac"] = round(ex_tf / FP32_MFMA_PEAK_TF, 4)
+                        res["roofline"]["step"]["executed_what"] = ("MFMA instructions of all matrix kernels of a step (this run's SQ_INSTS_MFMA pass x launches "
+                                                                    "per step) x 2048 flop / ms_per_step / peak: the share of the fp32 matrix peak the step "
+                                                                    "really keeps busy (the latency form's centre taps run on the vector ALU and are not in it)")
+                except Exception as e:
+                    res["roofline"]["kernels"] = {"error": repr(e)}
             except Exception as e:  # measurement aid must not sink the headline number
                 res["roofline"] = {"error": repr(e)}
             if not args.no_cpu_baseline:

@@ -308,6 +308,106 @@ __device__ __forceinline__ void post_item(const PostArgs &a, int item, int lane,
     post_item_at<KIND>(a, loc, lane, Pbase, ss, Sbase, rin, b2);
 }
 
+// FOUR items per wave pass (round 6): the workgroup forms run the post op of 16 to 64 items per workgroup, and one item per pass
+// keeps 40 of 64 lanes busy and makes a wave's 4 to 16 items one dependent chain after the other (two cross-lane reductions, an
+// exponential, a reciprocal square root each).  Here item j of the pass sits in row j of the wave (lanes 16 j .. 16 j + 15) and lane l
+// of the row carries the channel pairs l, l + 16 and l + 32 (< 40) -- the three ROWS of the canonical one-item layout (pono_total:
+// lane p < 40 owns channels 2 p, 2 p + 1; butterfly over each row of 16 lanes; T = R2 + (R1 + R0)) held as three slots of one lane.
+// The butterflies are the same DPP steps on the same positions within a row and the rows are added in the same order, so the
+// statistics -- and with them every output -- are the canonical bits; the totals are row-local (no readlane).
+// row: the item's y tile in LDS (y at [0, 80), the gate half or the nin_skip slot at [80, 160)); item_ok: the lane's item is evaluated
+// (lane-level: the four items of a pass differ); rin / b2: the residual input (POST_GATE) and the nin_skip bias at the lane's three pairs.
+__device__ __forceinline__ float pono_total_rows(const f32x2 (&v)[3], const bool (&ok)[3])
+{
+    float x[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        x[s] = ok[s] ? v[s].x + v[s].y : 0.0f;
+        x[s] = dpp_xadd<0xB1>(x[s]);
+        x[s] = dpp_xadd<0x4E>(x[s]);
+        x[s] = dpp_xadd<0x141>(x[s]);
+        x[s] = dpp_xadd<0x140>(x[s]);      // every lane of the row: R_s of ITS item
+    }
+    return x[2] + (x[1] + x[0]);
+}
+template <int KIND>
+__device__ __forceinline__ void post_items4(const PostArgs &a, int lane, const float *row, bool item_ok, size_t loc, const f32x2 (&rin)[3],
+                                            const f32x2 (&b2)[3])
+{
+    const int l = lane & 15;
+    const f32x2 zero = {0.0f, 0.0f};
+    auto ld = [](const float *p) { return *(const f32x2 *)p; };
+    f32x2 y[3], g[3], skip[3], d[3], dd[3];
+    bool ok[3];
+    int c[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        ok[s] = l + 16 * s < PONO_LANES;
+        c[s] = ok[s] ? 2 * (l + 16 * s) : 0;
+        y[s] = ld(row + c[s]);
+        g[s] = KIND == POST_GATE ? ld(row + NF + c[s]) : zero;
+        skip[s] = KIND == POST_CONVIN && a.has_skip ? ld(row + NF + c[s]) + b2[s] : zero;
+    }
+    const float mean = pono_mean(pono_total_rows(y, ok));
+#pragma unroll
+    for (int s = 0; s < 3; ++s) { d[s] = y[s] - mean; dd[s] = d[s] * d[s]; }
+    const float inv = pono_inv(pono_total_rows(dd, ok));
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        if (!ok[s] || !item_ok) continue;
+        const f32x2 out = post_finish<KIND>(d[s] * inv, g[s], skip[s], a.has_skip != 0, rin[s]);
+        if (KIND == POST_CONVIN) {
+            f32x2 ep, en;
+            celu_pair2(out, ep, en);
+            *(f32x2 *)(a.Xout + loc * (2 * NF) + c[s]) = ep;
+            *(f32x2 *)(a.Xout + loc * (2 * NF) + NF + c[s]) = en;
+        } else {
+            store_raw_celu2(a.Rout, a.Eout, loc, c[s], out);
+        }
+    }
+}
+// the post op of a workgroup's items parked in LDS (sY: a row of YLD floats per item), wave w taking items w, w + WAVES, ...: four
+// per pass.  sItem / sLoc: item index (-1: not evaluated) and cache row per item.  Called by every thread of the workgroup BEFORE the
+// barrier that publishes sY: the residual rows of all of a wave's items are requested first (post_prefetch), the passes run behind
+// the barrier (post_run).
+template <int KIND, int NPI, int WAVES>
+struct Post4 {
+    static_assert(NPI % 4 == 0, "four items per pass");
+    static constexpr int NG = NPI / 4;
+    f32x2 rin[NG][3], b2[3];
+    int loc[NG], m[NG];
+    bool ok[NG];
+    __device__ __forceinline__ void prefetch(const PostArgs &pa, int wave, int lane, const int *sItem, const int *sLoc)
+    {
+        const int r = lane >> 4, l = lane & 15;
+        const f32x2 z2 = {0.0f, 0.0f};
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int c = l + 16 * s < PONO_LANES ? 2 * (l + 16 * s) : 0;
+            b2[s] = KIND == POST_CONVIN && pa.has_skip ? *(const f32x2 *)(pa.bias2 + c) : z2;
+        }
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi) {
+            m[gi] = wave + WAVES * (4 * gi + r);
+            loc[gi] = sLoc[m[gi]];
+            ok[gi] = sItem[m[gi]] >= 0;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const int c = l + 16 * s < PONO_LANES ? 2 * (l + 16 * s) : 0;
+                rin[gi][s] = KIND == POST_GATE ? *(const f32x2 *)(pa.Rin + (size_t)loc[gi] * R_LD + c) : z2;   // (row 0 for an absent item: loaded, dropped)
+            }
+        }
+    }
+    __device__ __forceinline__ void run(const PostArgs &pa, int lane, const float *sY, int yld) const
+    {
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi) {
+            if (!__any(ok[gi])) continue;     // (wave-uniform: none of the pass's four items is evaluated)
+            post_items4<KIND>(pa, lane, sY + m[gi] * yld, ok[gi], (size_t)loc[gi], rin[gi], b2);
+        }
+    }
+};
+
 // whole-grid post op: one wave per item, 4 items per 256-thread block
 template <int KIND>
 __global__ __launch_bounds__(256) void k_post_grid(PostArgs a)
@@ -703,28 +803,14 @@ __global__ __launch_bounds__(GW_THREADS) void k_gemm_wg(GemmArgs a, PostArgs pa,
         // the wave's items are m = wave, wave + 4, ...: what their post ops read from memory -- the residual input of a gate, a row
         // per item -- is requested for ALL of them here, ahead of the parking and the barrier (fetched item by item inside the loop,
         // each was a dependent round trip -- order look-up, then the row -- in front of its item: 9-19 k cycles of a workgroup's life)
-        constexpr int NPI = MI / GW_WAVES;
-        const int pc = lane < PONO_LANES ? 2 * lane : 0;
-        const f32x2 z2 = {0.0f, 0.0f};
-        f32x2 rin[NPI], b2 = z2;
-        int ploc[NPI];
-#pragma unroll
-        for (int k = 0; k < NPI; ++k) {
-            ploc[k] = sLoc[wave + GW_WAVES * k];
-            rin[k] = POSTK == POST_GATE ? *(const f32x2 *)(pa.Rin + (size_t)ploc[k] * R_LD + pc) : z2;   // (row 0 for an absent item: loaded, dropped)
-        }
-        if (POSTK == POST_CONVIN && pa.has_skip) b2 = *(const f32x2 *)(pa.bias2 + pc);
+        Post4<POSTK, MI / GW_WAVES, GW_WAVES> post;
+        post.prefetch(pa, wave, lane, sItem, sLoc);
         // (conv_input with nin_skip: the skip slot was parked above, after the barrier of the last tap; here the taps are done too)
 #pragma unroll
         for (int k = 0; k < NTL; ++k)
             if (k < NT4 || has5) *(f32x4 *)(sY + m_of(k) * YLD + o_of(k) + kk * 4) = ysum[k];
         __syncthreads();
-#pragma unroll
-        for (int k = 0; k < NPI; ++k) {
-            const int m = wave + GW_WAVES * k;
-            if (sItem[m] < 0) continue;   // (wave-uniform)
-            post_item_at<POSTK>(pa, (size_t)ploc[k], lane, sY + m * YLD, 0, sY + m * YLD + NF, rin[k], b2);
-        }
+        post.run(pa, lane, sY, YLD);
     }
     WG_STAMP(15);
 #ifdef PS_WG_TRACE_BUILD
@@ -922,26 +1008,12 @@ __global__ __launch_bounds__(WS_THREADS) void k_gemm_ws(GemmArgs a, PostArgs pa)
     // ---- the post op of the stage on the workgroup's 64 items, 16 per wave (as in k_gemm_wg)
     {
         float *sY = (float *)sA;
-        constexpr int NPI = MI / WS_WAVES;
-        const int pc = lane < PONO_LANES ? 2 * lane : 0;
-        const f32x2 z2 = {0.0f, 0.0f};
-        f32x2 rin[NPI], b2 = z2;
-        int ploc[NPI];
-#pragma unroll
-        for (int k = 0; k < NPI; ++k) {
-            ploc[k] = sLoc[wave + WS_WAVES * k];
-            rin[k] = POSTK == POST_GATE ? *(const f32x2 *)(pa.Rin + (size_t)ploc[k] * R_LD + pc) : z2;
-        }
-        if (POSTK == POST_CONVIN && pa.has_skip) b2 = *(const f32x2 *)(pa.bias2 + pc);
+        Post4<POSTK, MI / WS_WAVES, WS_WAVES> post;
+        post.prefetch(pa, wave, lane, sItem, sLoc);
 #pragma unroll
         for (int k = 0; k < NOT; ++k) *(f32x4 *)(sY + (wave * 16 + i) * YLD + 16 * k + kk * 4) = ysum[k];
         __syncthreads();
-#pragma unroll
-        for (int k = 0; k < NPI; ++k) {
-            const int m = wave + WS_WAVES * k;
-            if (sItem[m] < 0 || (PS_WS_EXP & 16)) continue;   // (wave-uniform)
-            post_item_at<POSTK>(pa, (size_t)ploc[k], lane, sY + m * YLD, 0, sY + m * YLD + NF, rin[k], b2);
-        }
+        if (!(PS_WS_EXP & 16)) post.run(pa, lane, sY, YLD);
     }
 }
 

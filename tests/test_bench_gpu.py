@@ -32,6 +32,48 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
     assert abs(r["achieved"] - r["algorithmic_flops_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e12) / r["achieved"] < 1e-3
+    # which library produced the number, and every matrix kernel of the step with its own event-timed figures, largest phase first
+    assert "product build" in d["library"]["build"] and d["library"]["path"].endswith("libpixelsynth_hip.so")
+    rows = r["kernels"]
+    names = [row["kernel"] for row in rows]
+    assert {"k_gemm_ws<0>", "k_gemm_ws<1>", "k_gemm_ws<2>"} <= set(names) and any(n.startswith("k_column_tp") for n in names), names
+    assert [row["ms_per_step"] for row in rows] == sorted((row["ms_per_step"] for row in rows), reverse=True)
+    assert r["kernel"].startswith(names[0] + ":")
+    for row in rows:
+        assert row["launches_per_step"] > 0 and row["avg_launch_us"] > 0
+        assert abs(row["ms_per_step"] - row["launches_per_step"] * row["avg_launch_us"] * 1e-3) <= 0.02 * row["ms_per_step"] + 2e-3, row
+        if "dense_flops_per_launch" in row:
+            assert abs(row["frac_dense"] - row["dense_flops_per_launch"] / (row["avg_launch_us"] * 1e-6) / 1e12 / r["peak"]) < 2e-3, row
+    ws = {row["kernel"]: row for row in rows}
+    assert ws["k_gemm_ws<0>"]["launches_per_step"] == 28 and ws["k_gemm_ws<2>"]["launches_per_step"] == 8      # 14 / 4 stages x two frame ranges
+    assert 0 < ws["k_gemm_ws<0>"]["items_evaluated_per_step"] <= 14 * 128 * 1024
+    assert "executed_frac" not in r["step"]          # (no counter pass in this short run: nothing is made up)
+
+
+def test_bench_line_with_the_counter_passes_says_what_is_executed():
+    """With the run's own rocprofv3 --pmc passes (what the default `python bench.py` does): executed MFMA flops per kernel, both
+    fractions, and the step's executed fraction beside the dense-equivalent one -- executed <= dense everywhere (closed taps and the
+    prefix cone are skipped work)."""
+    import shutil
+    if not (shutil.which("rocprofv3") or os.path.exists("/opt/rocm/bin/rocprofv3")):
+        pytest.skip("rocprofv3 not installed")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2",
+                          "--no-cpu-baseline", "--no-extra", "--live-pmc"], capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    r = d["roofline"]
+    if r.get("pmc_live") is None:
+        pytest.skip("the counter passes did not run on this box")
+    step = r["step"]
+    assert 0 < step["executed_frac"] < step["frac"] < 1
+    ph = r["phases"]
+    assert 0 < ph["column_launches_executed_frac"] < 1 and 0 < ph["prefix_pass_executed_frac"] < 1
+    assert abs(ph["column_launches_ms"] + ph["prefix_pass_and_small_kernels_ms"] - d["ms_per_step"]) < 0.25 * d["ms_per_step"]
+    for row in r["kernels"]:
+        if row["kernel"].startswith("k_gemm_ws") or row["kernel"].startswith("k_column_tp"):
+            assert 0 < row["frac_executed"] <= 1 and abs(row["executed_flops_per_launch"] - row["mfma_instructions_per_launch"] * 2048) <= 2048, row
+        if row["kernel"].startswith("k_gemm_ws"):
+            assert row["executed_flops_per_launch"] <= row["dense_flops_per_launch"] * 1.02, row      # per tile a tap is computed for all 16 items
 
 
 def _torchrun(script_args, env_extra, nproc=2, timeout=900):

@@ -85,6 +85,56 @@ def test_c5_teacher_forced_logits_of_three_views_vs_the_torch_twin(c5):
         np.testing.assert_allclose(logits[v].cpu().numpy(), ref, rtol=1e-4, atol=1e-4, err_msg=f"view {v}")
 
 
+def test_c5_the_path_the_headline_times_at_its_size(c5):
+    """bench.py's timed region runs z_buffermodel.outpaint_pipelined: two 128-view batches resident in one 256-frame handle, the narrow
+    last wavefronts of a batch inside the launches of the next batch's first ones, per-frame prefixes, the prefix pass on two streams,
+    `between=` set (where bench.py collects the previous step's gathers).  Three DIFFERENT C5 batches (bench.make_inputs, ranks 0 .. 2)
+    through it at C5's size: every batch's codes equal outpaint_planned's bit for bit, batch 0's are the fixture's -- the codes whose
+    logits test_c5_teacher_forced_logits_of_three_views_vs_the_torch_twin holds against the torch twin and whose splat the oracle
+    checks -- and the kernels the bench line's roofline names are the ones that ran (launch counters of the 256-frame engine)."""
+    import bench
+    model, d0, host0, out0 = c5
+    V = 128
+    batches = [d0] + [bench.make_inputs(r, V, DEV)[0] for r in (1, 2)]
+    front = lambda d: model.plan_views(d["img"], d["depth"], d["K"], d["Kinv"], d["P"], d["Pinv"], d["RT2"], d["RT2inv"])
+    ref = []
+    for d in batches:
+        ref.append(model.outpaint_planned(front(d), d["codes"], temperature=0.7, uniforms=d["uniforms"])["codes"].clone())
+    model.outpaint2.engine(32, 32, V).check()
+    assert torch.equal(ref[0], out0["codes"])                      # (outpaint_views is plan_views + outpaint_planned)
+    assert not torch.equal(ref[0], ref[1]) and not torch.equal(ref[1], ref[2])
+    eng = model.outpaint2.engine(32, 32, 2 * V)
+    before = eng.launch_counts()
+    streams, between_calls = set(), []
+    real_prefix = eng.ar_prefix
+
+    def prefix(*a, **k):
+        streams.add(torch.cuda.current_stream().cuda_stream)
+        return real_prefix(*a, **k)
+    eng.ar_prefix = prefix
+    try:
+        for rep in range(2):      # twice: the second time every half of the handle has held another batch before
+            got = []
+            for d in batches:
+                done = model.outpaint_pipelined(front(d), d["codes"], temperature=0.7, uniforms=d["uniforms"],
+                                                between=lambda: between_calls.append(torch.cuda.current_stream().cuda_stream))
+                if done is not None:
+                    got.append(done["codes"].clone())
+            got.append(model.outpaint_flush()["codes"].clone())
+            torch.cuda.synchronize()
+            eng.check()
+            assert len(got) == 3
+            for b in range(3):
+                assert torch.equal(got[b], ref[b]), (rep, b, int((got[b] != ref[b]).sum()))
+    finally:
+        eng.ar_prefix = real_prefix
+    assert len(streams) == 2 and len(between_calls) == 6           # two frame ranges on two streams; between= ran in every step
+    ran = {k: v - before[k] for k, v in eng.launch_counts().items()}
+    assert ran["k_column_tp8"] > 0 and ran["k_column_tp"] > 0, ran                                 # both throughput forms of the column launch
+    assert ran["k_gemm_ws<0>"] == ran["k_gemm_ws<1>"] == 6 * 2 * 14 and ran["k_gemm_ws<2>"] == 6 * 2 * 4, ran   # 6 prefix passes x 2 ranges
+    assert ran["k_gemm_wg"] == 0 and ran["k_gemm"] == 0 and ran["k_column"] == 0, ran
+
+
 def test_c2_idx_emitting_mode_at_batch_32_vs_the_oracle():
     """BASELINE config 2 at its size: 32 clouds of 65 536 points through the splatter with the PyTorch3D-shaped debug tensors
     (B,S,S,K=128): idx / zbuf / dist of four frames bit-exact against the oracle's rasterizer fed the same projected points

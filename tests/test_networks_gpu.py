@@ -348,3 +348,22 @@ def test_thin_in_on_the_fp16_pipe_against_an_fp64_convolution(B, H, W, fuse):
     _lib.check(L.ps_conv3x3_thin_in_f16x3_nhwc(xl.data_ptr(), None, None, wl.data_ptr(), B, H, W, 64, y.data_ptr(), flag.data_ptr(), st), "thin_in_f16x3")
     assert int(flag.item()) == 1
     assert L.ps_conv3x3_thin_in_f16x3_nhwc(xl.data_ptr(), None, None, wl.data_ptr(), B, H, W, 32, y.data_ptr(), flag.data_ptr(), st) != 0
+
+
+def test_affine_bc_refuses_pointers_it_cannot_hand_to_the_kernel():
+    """LinearNoiseLayer.affine_bc hands raw device pointers to ps_noise_affine_f32: a caller-supplied noise tensor that lives on the host
+    (the documented noise= argument) must take the torch path -- where it fails with torch's device-mismatch error, as it always did --
+    not reach the kernel as a host address (a GPU memory fault).  Device noise takes the kernel and equals the torch composition."""
+    from pixelsynth_amd.networks import architectures as A
+    opt = syn.network_opts()
+    layer = A.LinearNoiseLayer(opt, output_sz=64).to(DEV).eval()
+    x = torch.randn(3, 64, 8, 8, device=DEV).contiguous(memory_format=torch.channels_last)
+    noise = torch.randn(3, A.NOISE_SZ)
+    with torch.no_grad():
+        with pytest.raises(RuntimeError):
+            layer.affine_bc(x, noise)                       # host noise: torch's own error, no kernel launch
+        torch.cuda.synchronize()                            # (the device is still alive)
+        sc, sh = layer.affine_bc(x, noise.to(DEV))
+        sc_ref, sh_ref = layer.affine(x, noise.to(DEV))
+    torch.testing.assert_close(sc, sc_ref.reshape(3, 64), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(sh, sh_ref.reshape(3, 64).expand(3, 64), rtol=1e-5, atol=1e-6)

@@ -403,22 +403,88 @@ def test_a_decoder_pass_that_overflowed_fp16_is_run_again_in_fp32():
     gen_fs = tt(syn.image(8, 2, 3, 256))
     bgm = tt(syn.background_masks(256)["ragged"])[None].expand(2, -1, -1).contiguous()
     codes = tt(syn.codes(9, 2)).to(torch.int64)
-    calls = []
+    calls, raise_at = [], [None]
     real = A._f16x3_conv
-    A._f16x3_conv = lambda *a, **k: (calls.append(A._conv_mode(None)), real(*a, **k))[1]
+
+    def spy(*a, **k):
+        calls.append(A._conv_mode(None))
+        y = real(*a, **k)
+        if raise_at[0] is not None and len(calls) == raise_at[0]:
+            A._overflow_flag(gen_fs.device).fill_(1)          # as the kernel would, in the middle of the pass
+        return y
+    A._f16x3_conv = spy
     try:
         with torch.no_grad():
             img = m._decode_checked(gen_fs, bgm, codes)
             assert len(calls) == 13 and torch.isfinite(img).all()
             del calls[:]
-            A._overflow_flag(gen_fs.device).fill_(1)          # as the kernel would
+            raise_at[0] = 5
             with pytest.warns(UserWarning, match="run again in fp32"):
                 img2 = m._decode_checked(gen_fs, bgm, codes)
             assert len(calls) == 13                           # the first attempt only: the rerun went through torch
             assert torch.isfinite(img2).all() and img2.shape == img.shape
-            A.check_f16x3_overflow(gen_fs.device)              # (cleared)
+            A.check_f16x3_overflow(gen_fs.device)              # (cleared by the report)
+            # a flag an earlier, UNCHECKED pass left behind is not this pass's: cleared before the pass, no rerun, no warning
+            del calls[:]
+            raise_at[0] = None
+            A._overflow_flag(gen_fs.device).fill_(1)
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("error")
+                img3 = m._decode_checked(gen_fs, bgm, codes)
+            assert len(calls) == 13 and torch.isfinite(img3).all()
+            # get_best_sample's candidates (forward_image with num_samples, every frame of forward_scene) and the no_outpainting
+            # projector call go through the same check: an overflow in the middle of a candidate's pass reruns THAT candidate
+            plan = m.get_masks_for_batch(None, None, bgm[:1], compact=True)
+            del calls[:]
+            raise_at[0] = 7
+            with pytest.warns(UserWarning, match="run again in fp32"):
+                best = m.get_best_sample(plan, codes[:1], bgm[:1], gen_fs[:1], None, gen_fs[:1])
+            assert len(calls) == 13 and tuple(best.shape) == (1, 3, 256, 256) and torch.isfinite(best).all()
+            A.check_f16x3_overflow(gen_fs.device)
     finally:
         A._f16x3_conv = real
+
+
+def test_pipelined_batches_with_different_temperatures_and_a_reset():
+    """outpaint_pipelined when the temperature changes from one batch to the next: the tail wavefronts of the batch in flight run as
+    launches of their own with THEIR temperature (a merged launch has one), so every batch's codes are still outpaint_planned's at its
+    own temperature; outpaint_reset drops a batch in flight (a sequence cut short must not leak into the next one)."""
+    m = make_model()
+    V = 16
+    cam = syn.demo_cameras(V)
+    K, Kinv, P, Pinv = (tt(cam[k]) for k in ("K", "Kinv", "P", "Pinv"))
+    batches = []
+    for b, temp in enumerate((0.7, 1.0, 1.0)):
+        img, depth = tt(syn.image(181 + b, V, 3, 256)), tt(syn.depth_smooth(191 + b, V, 256, 1.0, 100.0))
+        yaws = np.linspace(-0.7 + 0.1 * b, 0.5 + 0.1 * b, V)
+        rts = [syn.yaw_pose(cam["P"][v:v + 1], float(y)) for v, y in enumerate(yaws)]
+        RT2, RT2inv = tt(np.concatenate([r[1] for r in rts])), tt(np.concatenate([r[0] for r in rts]))
+        codes, uni = tt(syn.codes(201 + b, V)), tt(np.random.RandomState(211 + b).rand(V, 1024).astype(np.float32))
+        batches.append(((img, depth, K, Kinv, P, Pinv, RT2, RT2inv), codes, uni, temp))
+    ref = [m.outpaint_planned(m.plan_views(*a), c, temperature=t, uniforms=u)["codes"].clone() for a, c, u, t in batches]
+    other = m.outpaint_planned(m.plan_views(*batches[0][0]), batches[0][1], temperature=1.0, uniforms=batches[0][2])["codes"]
+    assert not torch.equal(other, ref[0])        # (the temperature matters for these draws)
+    got = []
+    for a, c, u, t in batches:
+        done = m.outpaint_pipelined(m.plan_views(*a), c, temperature=t, uniforms=u)
+        if done is not None:
+            got.append(done["codes"].clone())
+    got.append(m.outpaint_flush()["codes"].clone())
+    torch.cuda.synchronize()
+    m.outpaint2.engine(32, 32, 2 * V).check()
+    assert len(got) == 3
+    for b in range(3):
+        assert torch.equal(got[b], ref[b]), (b, int((got[b] != ref[b]).sum()))
+    # a sequence cut short: the batch in flight is dropped, the next sequence starts clean
+    a, c, u, t = batches[0]
+    assert m.outpaint_pipelined(m.plan_views(*a), c, temperature=t, uniforms=u) is None
+    m.outpaint_reset()
+    assert m.outpaint_flush() is None
+    a, c, u, t = batches[1]
+    assert m.outpaint_pipelined(m.plan_views(*a), c, temperature=t, uniforms=u) is None      # (not the dropped batch's dict)
+    assert torch.equal(m.outpaint_flush()["codes"], ref[1])
+    m.outpaint2.engine(32, 32, 2 * V).check()
 
 
 def test_plan_views_then_outpaint_planned_equals_outpaint_views_also_across_streams():
