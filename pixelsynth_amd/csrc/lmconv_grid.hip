@@ -852,8 +852,8 @@ __global__ __launch_bounds__(WS_THREADS) void k_gemm_ws(GemmArgs a, PostArgs pa)
     constexpr int HALF = 4 * CO;                 // f32x4 of one 16-channel group of a tap's weights: [kk][o]
     constexpr int CHUNK = NGH * HALF;            // one (tap, chain) chunk: groups j and j + 5
     constexpr int SVN = (CHUNK + WS_THREADS - 1) / WS_THREADS;   // staging elements per thread (the last one may be absent)
-    constexpr int NB4 = 2 * CHUNK > MI * YLD / 4 ? 2 * CHUNK : MI * YLD / 4;   // (the post op's tile reuses the weight buffers)
     constexpr int NQ = NGH * NOT;                // A fragments of a chain, in the order they are used: q = h * NOT + tile
+    constexpr int NB4 = 2 * CHUNK > MI * YLD / 4 ? 2 * CHUNK : MI * YLD / 4;   // (the post op's tile reuses the weight buffers)
     __shared__ f32x4 sA[NB4];
     __shared__ int sRow[MAX_TAPS * MI];
     __shared__ float sMv[MAX_TAPS * MI];
