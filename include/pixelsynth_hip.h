@@ -76,7 +76,11 @@ size_t ps_splat_workspace_bytes(int B, int N, int S, double radius_px);
  *     out_idx int32 (packed index b*N+n, -1 padded), out_zbuf f32, out_dist f32 (dist^2, NDC)
  *   radius_px = opts.radius, K = opts.pp_pixel, tau, rad_pow, accumulation (PS_ACC_*),
  *   bg_ksize = opts.background_smoothing_kernel_size (odd).
- *   workspace: >= ps_splat_workspace_bytes(B,N,S,radius_px) bytes of device memory. */
+ *   workspace: >= ps_splat_workspace_bytes(B,N,S,radius_px) bytes of device memory.
+ *   Numerics: out_bg and the debug outputs are exact (the K nearest hits per pixel in (z, index) order).  out_feat under
+ *   PS_ACC_ALPHACOMPOSITE WITHOUT debug outputs: a pixel's front-to-back walk stops once its transmittance prod(1 - alpha) is below
+ *   2^-23 -- the hits behind can add at most that times max |feature| (below one ulp of a unit-magnitude result; the parity tests
+ *   state 1e-6); with debug outputs, and in the other accumulation modes, every one of the K hits is walked. */
 int ps_splat_f32(float *pts, const float *feat, int B, int N, int C, int S, double radius_px, int K,
                  float tau, int rad_pow, int accumulation, int bg_ksize, float *out_feat,
                  uint8_t *out_bg, int32_t *out_idx, float *out_zbuf, float *out_dist,

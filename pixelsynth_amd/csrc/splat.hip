@@ -525,6 +525,14 @@ __global__ __launch_bounds__(64) void k_composite(
     for (int c = 0; c < NC; ++c) acc[c] = 0.0f;
     float cum = 1.0f, tsum = 0.0f;
     int cnt = 0;
+    // Alpha compositing front to back: what the hits behind the current one can still add is bounded by the transmittance,
+    // sum_i cum_i a_i |f_i| <= cum * max|f| (the weights telescope to cum - cum_end).  Once cum < 2^-23 that is below one ulp of a
+    // unit-magnitude result, and a lane stops walking (round 6: ~40 instead of ~50 hits per pixel at r = 4 px, where a hit's mean alpha
+    // is 1/3).  Only the features are affected, within the 1e-6 the parity tests state for them; the background mask needs ONE hit, and
+    // the mode that emits idx / zbuf / dist (DEBUG_OUT: the bit-exact K-nearest lists) walks everything.
+    constexpr bool EARLY = MODE == PS_ACC_ALPHACOMPOSITE && !DEBUG_OUT;
+    constexpr float CUM_EPS = 1.1920929e-07f;   // 2^-23
+    auto open_lane = [&]() { return cnt < K && (!EARLY || cum >= CUM_EPS); };
 
     for (int pass = (MODE == PS_ACC_WSUMNORM ? 0 : 1); pass < 2; ++pass) {
         cnt = 0;
@@ -561,7 +569,7 @@ __global__ __launch_bounds__(64) void k_composite(
             __syncthreads();
             // phase 1: hit bits
             uint64_t hits = 0;
-            if (valid && cnt < K) {
+            if (valid && open_lane()) {
 #if PS_COMPOSITE_PK
                 // Two records per packed instruction (v_pk_add / v_pk_mul: the same IEEE operations, two at a time), and the mask
                 // built by the carry chain: v_cmp writes vcc, v_addc computes h + h + vcc = (h << 1) | hit -- one instruction per
@@ -605,7 +613,7 @@ __global__ __launch_bounds__(64) void k_composite(
 #endif
             }
             // phase 2: this pixel's hits, front to back
-            while (hits && cnt < K) {
+            while (hits && open_lane()) {
                 const int j = __builtin_ctzll(hits);
                 hits &= hits - 1;
                 SplatRec h;
@@ -637,7 +645,7 @@ __global__ __launch_bounds__(64) void k_composite(
                 }
                 ++cnt;
             }
-            if (__all((cnt >= K) || !valid)) break;
+            if (__all(!open_lane() || !valid)) break;
         }
     }
     if (!valid) return;
