@@ -59,6 +59,7 @@ VIEWS_PER_SOURCE = 16   # config C5: 8 source images x 16 novel views each
 # PS_BENCH_FORCE_COLLECTIVE=1: a single-rank run creates the RCCL process group all the same and sends its gathers, barrier and
 # max-over-ranks through it -- the multi-GPU code path (`world > 1` in back()) executed on the one GPU a test box has
 FORCE_COLLECTIVE = os.environ.get("PS_BENCH_FORCE_COLLECTIVE") == "1"
+GATE_MIN_VIEWS = 60     # (lmconv.model.TP_MIN_FRAMES: batches of the throughput form)
 HOST_TIMES = [] if os.environ.get("PS_BENCH_HOST_TIMES") == "1" else None   # run_steps: host stamps per step, summarised on stderr
 
 
@@ -186,7 +187,9 @@ def _run_steps(model, d, world, n, side):
         t1 = time.perf_counter()
         planned = None
         if i + 1 < n:
-            if not os.environ.get("PS_BENCH_NO_GATE"):
+            # (batches of the latency form -- a few ms per step -- are not gated: the chain gate -> splat -> masks to the host -> planning
+            # -> enqueueing is then as long as the step itself and the host falls behind: 16 views 4.2 -> 4.0 ms per step without it)
+            if not os.environ.get("PS_BENCH_NO_GATE") and d["codes"].shape[0] >= GATE_MIN_VIEWS:
                 side.wait_event(gate)
             with torch.cuda.stream(side):
                 planned = front(model, d)
@@ -194,9 +197,10 @@ def _run_steps(model, d, world, n, side):
             main.wait_stream(side)
         if HOST_TIMES is not None:   # PS_BENCH_HOST_TIMES=1: where the host thread spends a step (enqueueing the AR run; the next step's front)
             HOST_TIMES.append((t0, t1, time.perf_counter()))
-    if pipelined:   # the last batch's tail wavefronts, as launches of their own: the n steps are complete when this call returns
-        finish_gathers(out)
-        out = start_gathers(model.outpaint_flush(), world)
+    if pipelined:   # what is left of the batches in flight, as launches of their own: the n steps are complete when this call returns
+        for o in model.outpaint_flush():
+            finish_gathers(out)
+            out = start_gathers(o, world)
     return finish_gathers(out)
 
 
@@ -228,7 +232,28 @@ def measure_roofline(model, d, out, V, live_pmc=False):
     launches, total_ms, fpc = ctypes.c_int(0), ctypes.c_float(0.0), ctypes.c_double(0.0)
     us_list = []
     byref = lambda v: ctypes.cast(ctypes.byref(v), ctypes.c_void_p)
-    if pipelined:
+    deep = pipelined and model.pipe_depth(V) != 2
+    if deep:
+        # more than two batches in flight (small batches: z_buffermodel.pipe_depth): the column launches of steady-state steps as the
+        # timed region runs them, event-timed through the engine's launch profile (ps_pixelcnn_profile_begin / _end)
+        eng = model.outpaint2.engine(32, 32, model.pipe_frames(V))
+        frames = getattr(plan, "waves_frames", None) if model.PER_FRAME_PREFIX else None
+        ncols = int((frames[0] if frames is not None else cols).shape[0])
+        nst = 8
+        for _ in range(3):
+            run_steps(model, d, 1, 2, side_stream())
+            torch.cuda.synchronize()
+            eng.profile_begin()
+            try:
+                run_steps(model, d, 1, nst, side_stream())
+            finally:
+                prof = eng.profile_end()
+            n_launch = sum(v[0] for k, v in prof.items() if k.startswith("k_column"))
+            us_list.append(sum(v[1] for k, v in prof.items() if k.startswith("k_column")) * 1e3 / max(1, n_launch))
+        launches.value = int(round(n_launch / nst))
+        fpc.value = 10424320.0
+        n_wavefronts = launches.value
+    elif pipelined:
         # The column launches of ONE STEADY-STATE STEP of the pipelined form: the tail wavefronts of one batch inside the launches of
         # the next batch's head wavefronts.  Timed inside a two-batch run of the same views in a 2 V-frame handle (batch B = batch A):
         # head A | tail A + head B | tail B -- only the middle section's launches count: exactly one batch's columns.
@@ -302,7 +327,8 @@ def measure_roofline(model, d, out, V, live_pmc=False):
             "algorithmic_flops_per_launch": round(fl), "avg_launch_us": round(us, 3),
             "flops_per_column": round(fpc.value), "columns_per_launch": round(cols_per_launch, 2),
             "launches_per_ar_run": launches.value, "wavefronts": n_wavefronts, "columns": ncols,
-            "ar_runs_overlapped": bool(pipelined), "wavefronts_of_a_batch_alone": len(wave_start) - 1,
+            "ar_runs_overlapped": bool(pipelined), "batches_in_flight": model.pipe_depth(V) if pipelined else 1,
+            "wavefronts_of_a_batch_alone": len(wave_start) - 1,
             "per_frame_prefixes": bool(pipelined and getattr(plan, "waves_frames", None) is not None and model.PER_FRAME_PREFIX),
             "columns_with_one_prefix_for_the_batch": int(cols.shape[0]),
             "pmc_live": live, "traffic_committed_record": (pmc or {}).get("traffic_bytes_per_launch"),
@@ -427,7 +453,7 @@ def measure_kernels(model, d, V, world, side, plan, live, ms_per_step, steps=4):
     matrix peak (`frac_executed` = the share of all SIMD cycles the matrix pipes are busy at the nominal 2.4 GHz).
     -> (kernels, dominant kernel name, executed flops per step)."""
     pipelined = ar_pipelined(V)
-    eng = model.outpaint2.engine(32, 32, 2 * V if pipelined else V)
+    eng = model.outpaint2.engine(32, 32, model.pipe_frames(V) if pipelined else V)
     run_steps(model, d, world, 2, side)
     torch.cuda.synchronize()
     # the two phases of a step on the main stream: [prefix pass + the small kernels around it | column launches]; events around the
@@ -458,7 +484,7 @@ def measure_kernels(model, d, V, world, side, plan, live, ms_per_step, steps=4):
                           "followed by the column phase"}
     # items the whole-grid pass evaluates per stage: ranks [start[stage][f], end[f]) of every frame
     N_EVAL = 33
-    F = eng.max_frames
+    F = model.pipe_frames(V) if pipelined else V     # (the frame count of the run that filled the table: its row stride)
     _lib.lib().ps_pixelcnn_debug_cache.restype = ctypes.c_void_p
     ptr = _lib.lib().ps_pixelcnn_debug_cache(eng.handle, 5, 0)
     raw = type("Raw", (), {"__cuda_array_interface__": {"shape": (N_EVAL, F), "typestr": "<i4", "data": (ptr, False), "version": 2}})()

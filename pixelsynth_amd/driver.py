@@ -159,7 +159,8 @@ def render_pipelined(model, img, depth, cam, chunks, seeds, temperature=0.7):
                 main.wait_stream(side)
             finish(out)
         if overlap:
-            finish(model.outpaint_flush())
+            for out in model.outpaint_flush():
+                finish(out)
     except BaseException:
         model.outpaint_reset()      # (a batch left in flight must not be merged into the next sequence's launches)
         raise

@@ -97,7 +97,7 @@ class RasterizePointsXYsBlending(nn.Module):
         _lib.check(rc, "ps_splat_f32")
         if pts is not caller_pts:  # keep the reference's visible side effect on the caller's tensor
             caller_pts[:, :, 0:2] = pts[:, :, 0:2].to(caller_pts.dtype)
-        background_mask = bg.bool()
+        background_mask = bg.view(torch.bool)    # (k_dilate writes 0 / 1: the same bytes are the boolean mask)
         if return_debug:
             return out, background_mask, idx, zbuf, dist
         return out, background_mask

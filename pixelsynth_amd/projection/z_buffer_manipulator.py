@@ -74,7 +74,7 @@ class PtsManipulator(nn.Module):
                 int(sp._opt("background_smoothing_kernel_size", 13)), _lib.ptr(out), _lib.ptr(bg), _lib.ptr(ws),
                 ws.numel(), _lib.current_stream())
             _lib.check(rc, "ps_project_splat_f32")
-            return out, bg.bool()
+            return out, bg.view(torch.bool)    # (k_dilate writes 0 / 1: the same bytes are the boolean mask -- no conversion pass)
         if len(pred_pts.size()) > 3:
             pred_pts = pred_pts.view(bs, 1, -1)
             src = src.view(bs, c, -1)

@@ -110,7 +110,9 @@ def _build_ar_plan(background_mask, G, device):
     L = G * G
     if background_mask.is_cuda:
         stage = _pinned("bg", (B, S, S), torch.uint8)
-        stage.copy_(background_mask.to(torch.uint8), non_blocking=True)
+        as_u8 = (background_mask.view(torch.uint8) if background_mask.dtype == torch.bool and background_mask.is_contiguous()
+                 else background_mask.to(torch.uint8))      # (a bool mask IS bytes of 0 / 1: no conversion pass in front of the copy)
+        stage.copy_(as_u8, non_blocking=True)
         torch.cuda.current_stream().synchronize()
         bg = stage.numpy()
     else:
@@ -396,24 +398,44 @@ class ZbufferModelPts(nn.Module):
     PIPE_MERGE_MAX = int(__import__('os').environ.get('PS_PIPE_MERGE_MAX', '720'))    # wavefronts of at most this many columns behind a schedule's widest are left for the next batch's launches
     PIPE_CAP = 1024         # columns a merged launch takes (lmconv.model.COLUMNS_PER_LAUNCH_TP)
     PER_FRAME_PREFIX = True  # outpaint_pipelined: per-frame prefixes where the plan carries their schedule (build_ar_plan, PS_PER_FRAME_PREFIX)
+    PIPE_DEPTH_SMALL = 4    # batches in flight for batches of fewer than PIPE_DEEP_BELOW views: their wavefronts leave a launch far from
+    PIPE_DEEP_BELOW = 96    # full (64 views: waves of 300-500 columns in launches that take 1024; 16 views: ~50 in launches of the latency
+    #                         form, which cost their 33 dependent stages whatever they hold up to 128), so four batches share the launches
+    #                         (round 6: C4's 64-frame circle on one GPU 8.8 -> 6.9 ms per step, 16 views 4.2 -> 4.0); from C5's 128 views on
+    #                         the waves reach the capacity by themselves and a launch is bound by its columns: two in flight (12.45 ms
+    #                         per step with two, 12.69 with three, 12.44 with four)
+
+    def pipe_depth(self, V):
+        """Batches of V views that outpaint_pipelined keeps in flight (PS_PIPE_DEPTH overrides): a batch's schedule is cut into that many
+        consecutive parts, and a call runs part p of the batch p calls ago, all in the same launches; a batch's result comes back
+        depth - 1 calls late."""
+        import os
+        d = os.environ.get("PS_PIPE_DEPTH")
+        return max(2, min(8, int(d))) if d else (2 if V >= self.PIPE_DEEP_BELOW else self.PIPE_DEPTH_SMALL)
+
+    def pipe_frames(self, V):
+        """Frames of the engine handle outpaint_pipelined runs batches of V views in."""
+        return self.pipe_depth(V) * V
 
     def _pipe_buffers(self, V, device):
-        """Both batches of the pipelined form live in ONE engine handle of 2 V frames: batch i in frames [V (i % 2), V (i % 2) + V).
-        The per-frame arrays of the C ABI (codes, order, region, the three masks, uniforms) are persistent (2 V, ...) tensors; a batch's
-        plan is copied into its half on the stream of the AR run (14 MB, ~10 us), so that planning on a side stream never writes
-        under a launch that still reads the other batch's half."""
+        """The batches in flight live in ONE engine handle of depth x V frames: batch i in frames [V (i % depth), ...).  The per-frame
+        arrays of the C ABI (codes, order, region, the three masks, uniforms) are persistent (depth x V, ...) tensors; a batch's plan is
+        copied into its share on the stream of the AR run (14 MB, ~10 us), so that planning on a side stream never writes under a
+        launch that still reads another batch's share."""
         st = self.__dict__.get("_pipe")
-        if st is not None and (st["V"] != V or st["device"] != device):
-            if st["pending"] is not None:
+        D = self.pipe_depth(V)
+        if st is not None and (st["V"] != V or st["device"] != device or st["depth"] != D):
+            if st["inflight"] or st["done"]:
                 raise RuntimeError("outpaint_pipelined: a batch of another size is still in flight (call outpaint_flush first)")
             st = None
         if st is None:
             L = self.obs[1] * self.obs[2]
             z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=device)
             st = self.__dict__["_pipe"] = dict(
-                V=V, device=device, slot=0, pending=None, codes=z((2 * V, L), torch.int32), order=z((2 * V, L), torch.int32),
-                region=z((2 * V, L), torch.uint8), masks=[z((2 * V, 9, L), torch.float32) for _ in range(3)],
-                uniforms=z((2 * V, L), torch.float32), first_steps=z((2 * V,), torch.int32), offset=torch.tensor([V, 0], dtype=torch.int32, device=device))
+                V=V, depth=D, device=device, slot=0, inflight=[], done=[], codes=z((D * V, L), torch.int32), order=z((D * V, L), torch.int32),
+                region=z((D * V, L), torch.uint8), masks=[z((D * V, 9, L), torch.float32) for _ in range(3)],
+                uniforms=z((D * V, L), torch.float32), first_steps=z((D * V,), torch.int32),
+                offset=[torch.tensor([k * V, 0], dtype=torch.int32, device=device) for k in range(D)])
             st["order"][:] = torch.arange(L, device=device, dtype=torch.int32)   # (a frame nobody has planned yet still holds a permutation)
         return st
 
@@ -421,20 +443,29 @@ class ZbufferModelPts(nn.Module):
     def outpaint_pipelined(self, planned, codes, temperature=0.7, uniforms=None, between=None):
         """outpaint_planned for callers with a STREAM of batches of V views (bench.py, driver.py): the narrow last wavefronts of a
         batch's AR run -- a launch each for a few hundred columns down to eight, 1.5 of C5's 10.3 ms of column launches -- are not run
-        with their batch but inside the launches of the NEXT batch's first wavefronts (merge_schedules: both batches are resident in
-        one 2 V-frame handle; every column still runs behind the columns it reads, so the codes are those of outpaint_planned, bit
-        for bit -- tests/test_zbuffermodel_gpu.py).  Asynchronous on the current stream.
-        -> the PREVIOUS call's `planned` dict, complete (codes added), or None for the first batch; outpaint_flush() runs what is left
-        of the last one.  between: as for outpaint_planned."""
-        from .lmconv.model import launch_capacity, merge_schedules, split_tail
+        with their batch but inside the launches of the NEXT batch's first wavefronts (merge_schedules: the batches are resident in
+        one handle of pipe_frames(V) frames; every column still runs behind the columns it reads, so the codes are those of
+        outpaint_planned, bit for bit -- tests/test_zbuffermodel_gpu.py).  Small batches, whose launches are bound by their latency,
+        are cut into pipe_depth(V) parts and as many batches share a launch.  Asynchronous on the current stream.
+        -> the dict (codes added) of the oldest batch that is complete and has not been handed back yet -- in the steady state the batch
+        of pipe_depth(V) - 1 calls ago -- or None; outpaint_flush() runs what is left.  between: as for outpaint_planned."""
+        from .lmconv.model import launch_capacity, split_tail
         gen_fs, plan = planned["gen_fs"], planned["plan"]
         V, G = gen_fs.shape[0], self.obs[1]
         L = G * self.obs[2]
         st = self._pipe_buffers(V, gen_fs.device)
+        D = st["depth"]
         if codes is None:
             codes = self.vqvae.encode_codes(gen_fs)
         if uniforms is None:
             uniforms = torch.rand(V, L, device=gen_fs.device, dtype=torch.float32)
+        eng = self.outpaint2.engine(G, self.obs[2], D * V)
+        args = (st["codes"], st["order"], st["region"], st["masks"][0], st["masks"][1], st["masks"][2])
+        if st["inflight"] and st["inflight"][0]["temperature"] != temperature:
+            # what is in flight was planned with ANOTHER temperature: it cannot ride in this batch's launches (a launch has one
+            # temperature), so it is finished now, as launches of its own, with its own -- the codes stay those of outpaint_planned
+            while st["inflight"]:
+                self._pipe_step(eng, st, args, V)
         h = st["slot"]
         lo, hi = h * V, (h + 1) * V
         # (as elementwise kernels, not Tensor.copy_: same-type copies go through hipMemcpyAsync, which on the stream of the AR run stalled
@@ -446,8 +477,6 @@ class ZbufferModelPts(nn.Module):
         for dst, src in zip(st["masks"], (plan.mask_init, plan.mask_undilated, plan.mask_dilated)):
             put(dst[lo:hi], src.expand(V, -1, -1) if src.size(0) == 1 else src)
         put(st["uniforms"][lo:hi], uniforms)
-        eng = self.outpaint2.engine(G, self.obs[2], 2 * V)
-        args = (st["codes"], st["order"], st["region"], st["masks"][0], st["masks"][1], st["masks"][2])
         # PER-FRAME prefixes (plans that carry their schedule): the whole-grid pass takes every frame up to ITS first sampled position --
         # a location costs it half of what a column costs, and the bits are the same
         waves = getattr(plan, "waves_frames", None) if self.PER_FRAME_PREFIX else None
@@ -475,64 +504,74 @@ class ZbufferModelPts(nn.Module):
                 main.wait_stream(side)
         if between is not None:
             between()
-        # this batch's schedule, in the handle's frame numbering: head now, tail with the next batch.  The columns are on the device
-        # already (the plan's upload); the merged schedule is put together THERE, launch by launch, from slices of the two batches'
-        # columns (one concatenation) -- nothing crosses PCIe on the stream of the AR run.
+        # this batch's schedule, in the handle's frame numbering, cut into `depth` consecutive parts: the first runs now, part p with the
+        # p-th batch from now.  The columns are on the device already (the plan's upload); the merged schedule is put together THERE,
+        # launch by launch, from slices of the batches' columns (one concatenation) -- nothing crosses PCIe on the stream of the AR run.
         ws = waves[1]
-        dcols = waves[0] + st["offset"] if h else waves[0]
-        cut = split_tail(ws, min(self.PIPE_MERGE_MAX, launch_capacity(V) * 45 // 64))
-        head = (dcols[:ws[cut]], ws[:cut + 1])
-        tail = (dcols[ws[cut]:], ws[cut:] - ws[cut])
-        prev, early = st["pending"], None
-        if prev is not None and prev["temperature"] != temperature:
-            # the tail of the batch in flight was planned with ANOTHER temperature: it cannot ride in this batch's launches (a launch has
-            # one temperature), so it runs now as launches of its own, with its own -- the codes stay those of outpaint_planned
-            self._pipe_columns(eng, st, args, prev["tail"][0], prev["tail"][1], prev["first_step"], prev["temperature"])
-            prev, early = None, prev
-        if prev is None:
-            mcols, mws, first = head[0], head[1], plan.first_step
-        else:
-            mcols, mws = merge_schedules(prev["tail"][0], prev["tail"][1], head[0], head[1], min(self.PIPE_CAP, launch_capacity(V)))
-            first = min(plan.first_step, prev["first_step"])
-        self._pipe_columns(eng, st, args, mcols, mws, first, temperature)
-        st["pending"] = dict(planned=planned, tail=tail, first_step=plan.first_step, slot=h, temperature=temperature)
-        st["slot"] = 1 - h
-        return self._pipe_done(st, prev if early is None else early)
+        dcols = waves[0] + st["offset"][h] if h else waves[0]
+        n = len(ws) - 1
+        if D == 2:   # head / tail: the tail = the narrow last waves behind the widest one
+            bounds = [0, split_tail(ws, min(self.PIPE_MERGE_MAX, launch_capacity(V) * 45 // 64)), n]
+        else:        # (more than two in flight: equal numbers of waves)
+            bounds = [(n * p + D // 2) // D for p in range(D + 1)]
+        parts = [(dcols[ws[a]:ws[b]], ws[a:b + 1] - ws[a]) for a, b in zip(bounds[:-1], bounds[1:])]
+        st["inflight"].append(dict(planned=planned, parts=parts, first_step=plan.first_step, slot=h, temperature=temperature))
+        st["slot"] = (h + 1) % D
+        self._pipe_step(eng, st, args, V)
+        return st["done"].pop(0) if st["done"] else None
+
+    def _pipe_step(self, eng, st, args, V):
+        """One set of merged launches: the next part of every batch in flight, oldest first -- launch j holds wave j of the newest
+        batch's part and, folded in from the oldest on, as many columns of the older batches' current waves as fit (merge_schedules).
+        Batches whose last part this was are complete: their codes are taken out of the handle behind the launches."""
+        from .lmconv.model import launch_capacity, merge_schedules
+        cap = min(self.PIPE_CAP, launch_capacity(V))
+        merged, first = None, None
+        for b in st["inflight"]:
+            cols, ws = b["parts"].pop(0)
+            first = b["first_step"] if first is None else min(first, b["first_step"])
+            merged = (cols, ws) if merged is None else merge_schedules(merged[0], merged[1], cols, ws, cap)
+        if merged is not None:
+            self._pipe_columns(eng, st, args, merged[0], merged[1], first, st["inflight"][0]["temperature"])
+        finished = [b for b in st["inflight"] if not b["parts"]]
+        st["inflight"] = [b for b in st["inflight"] if b["parts"]]
+        st["done"] += [self._pipe_done(st, b) for b in finished]
 
     def _pipe_columns(self, eng, st, args, cols, ws, first, temperature):
         if len(ws) > 1 and ws[-1] > 0:
             eng.ar_columns(*args, (cols.contiguous(), np.ascontiguousarray(ws, np.int32)), temperature=temperature, uniforms=st["uniforms"],
                            first_step=int(first))
 
-    def _pipe_done(self, st, prev):
-        """The batch whose last columns the call just queued: its codes out of the handle's half."""
-        if prev is None:
-            return None
-        V, lo = st["V"], prev["slot"] * st["V"]
-        out = prev["planned"]
+    def _pipe_done(self, st, b):
+        """The batch whose last columns have just been queued: its codes out of the handle's share."""
+        V, lo = st["V"], b["slot"] * st["V"]
+        out = b["planned"]
         out["codes"] = st["codes"][lo:lo + V].clone().view(V, self.obs[1], self.obs[2])
         return out
 
     @torch.no_grad()
     def outpaint_flush(self):
-        """What outpaint_pipelined left of its last batch (the tail wavefronts, as launches of their own) -> that batch's dict, or None."""
+        """What outpaint_pipelined still holds: the remaining parts of the batches in flight, as launches of their own
+        -> the dicts of the batches not handed back yet, oldest first ([] when there is none)."""
         st = self.__dict__.get("_pipe")
-        if st is None or st["pending"] is None:
-            return None
-        prev, st["pending"] = st["pending"], None
-        eng = self.outpaint2.engine(self.obs[1], self.obs[2], 2 * st["V"])
-        args = (st["codes"], st["order"], st["region"], st["masks"][0], st["masks"][1], st["masks"][2])
-        self._pipe_columns(eng, st, args, prev["tail"][0], prev["tail"][1], prev["first_step"], prev["temperature"])
-        return self._pipe_done(st, prev)
+        if st is None:
+            return []
+        if st["inflight"]:
+            eng = self.outpaint2.engine(self.obs[1], self.obs[2], st["depth"] * st["V"])
+            args = (st["codes"], st["order"], st["region"], st["masks"][0], st["masks"][1], st["masks"][2])
+            while st["inflight"]:
+                self._pipe_step(eng, st, args, st["V"])
+        out, st["done"] = st["done"], []
+        return out
 
     def outpaint_reset(self):
-        """Forget a batch outpaint_pipelined still holds (its tail wavefronts never run; its codes are lost).  For a caller whose
-        sequence of batches was cut short by an exception: without this the NEXT sequence of the same batch size would merge the stale
-        tail into its first launches and get the stale batch's dict back as its first result (driver.render_pipelined and bench.py
-        call it on their way out of a failed run)."""
+        """Forget the batches outpaint_pipelined still holds (their remaining wavefronts never run; their codes are lost).  For a caller
+        whose sequence of batches was cut short by an exception: without this the NEXT sequence of the same batch size would merge the
+        stale batches into its first launches and get their dicts back as its first results (driver.render_pipelined and bench.py call
+        it on their way out of a failed run)."""
         st = self.__dict__.get("_pipe")
         if st is not None:
-            st["pending"] = None
+            st["inflight"], st["done"] = [], []
 
     PREFIX_SPLIT_MIN_VIEWS = 64   # below this a launch of half the frames no longer fills the chip
     PREFIX_STREAMS = 2            # 128 views: 18.16 -> 17.95 ms per step (three alternating pairs); 4 ranges lose (18.59)

@@ -446,6 +446,47 @@ def test_a_decoder_pass_that_overflowed_fp16_is_run_again_in_fp32():
         A._f16x3_conv = real
 
 
+@pytest.mark.parametrize("depth", [4, 3])
+def test_small_batches_pipelined_four_and_three_deep(monkeypatch, depth):
+    """Batches of fewer than 96 views (here 8) keep pipe_depth = 4 batches in flight (3 with PS_PIPE_DEPTH): a batch's schedule is
+    cut into as many parts, a call runs part p of the batch p calls ago in the same launches, and a batch comes back depth - 1 calls
+    late.  Six different batches: every batch's codes are outpaint_planned's bit for bit, in order, and the merged launches are fewer
+    than the batches' own."""
+    if depth != 4:
+        monkeypatch.setenv("PS_PIPE_DEPTH", str(depth))
+    m = make_model()
+    V = 8
+    assert m.pipe_depth(V) == depth and m.pipe_frames(V) == depth * V and m.pipe_depth(128) == (2 if depth == 4 else depth)
+    cam = syn.demo_cameras(V)
+    K, Kinv, P, Pinv = (tt(cam[k]) for k in ("K", "Kinv", "P", "Pinv"))
+    batches = []
+    for b in range(6):
+        img, depth_ = tt(syn.image(281 + b, V, 3, 256)), tt(syn.depth_smooth(291 + b, V, 256, 1.0, 100.0))
+        yaws = np.linspace(-0.7 + 0.05 * b, 0.5 + 0.05 * b, V)
+        rts = [syn.yaw_pose(cam["P"][v:v + 1], float(y)) for v, y in enumerate(yaws)]
+        RT2, RT2inv = tt(np.concatenate([r[1] for r in rts])), tt(np.concatenate([r[0] for r in rts]))
+        batches.append(((img, depth_, K, Kinv, P, Pinv, RT2, RT2inv), tt(syn.codes(301 + b, V)), tt(np.random.RandomState(311 + b).rand(V, 1024).astype(np.float32))))
+    eng1 = m.outpaint2.engine(32, 32, V)
+    n0 = sum(eng1.launch_counts().values())
+    ref = [m.outpaint_planned(m.plan_views(*a), c, temperature=0.7, uniforms=u)["codes"].clone() for a, c, u in batches]
+    own = sum(eng1.launch_counts().values()) - n0
+    eng = m.outpaint2.engine(32, 32, depth * V)
+    n0 = sum(eng.launch_counts().values())
+    got, late = [], []
+    for k, (a, c, u) in enumerate(batches):
+        done = m.outpaint_pipelined(m.plan_views(*a), c, temperature=0.7, uniforms=u)
+        late.append(done is None)
+        if done is not None:
+            got.append(done["codes"].clone())
+    got += [o["codes"].clone() for o in m.outpaint_flush()]
+    torch.cuda.synchronize()
+    eng.check()
+    assert late == [True] * (depth - 1) + [False] * (6 - depth + 1) and len(got) == 6 and m.outpaint_flush() == []
+    for b in range(6):
+        assert torch.equal(got[b], ref[b]), (b, int((got[b] != ref[b]).sum()))
+    assert sum(eng.launch_counts().values()) - n0 < 0.8 * own
+
+
 def test_pipelined_batches_with_different_temperatures_and_a_reset():
     """outpaint_pipelined when the temperature changes from one batch to the next: the tail wavefronts of the batch in flight run as
     launches of their own with THEIR temperature (a merged launch has one), so every batch's codes are still outpaint_planned's at its
@@ -470,9 +511,9 @@ def test_pipelined_batches_with_different_temperatures_and_a_reset():
         done = m.outpaint_pipelined(m.plan_views(*a), c, temperature=t, uniforms=u)
         if done is not None:
             got.append(done["codes"].clone())
-    got.append(m.outpaint_flush()["codes"].clone())
+    got += [o["codes"].clone() for o in m.outpaint_flush()]
     torch.cuda.synchronize()
-    m.outpaint2.engine(32, 32, 2 * V).check()
+    m.outpaint2.engine(32, 32, m.pipe_frames(V)).check()
     assert len(got) == 3
     for b in range(3):
         assert torch.equal(got[b], ref[b]), (b, int((got[b] != ref[b]).sum()))
@@ -480,11 +521,12 @@ def test_pipelined_batches_with_different_temperatures_and_a_reset():
     a, c, u, t = batches[0]
     assert m.outpaint_pipelined(m.plan_views(*a), c, temperature=t, uniforms=u) is None
     m.outpaint_reset()
-    assert m.outpaint_flush() is None
+    assert m.outpaint_flush() == []
     a, c, u, t = batches[1]
     assert m.outpaint_pipelined(m.plan_views(*a), c, temperature=t, uniforms=u) is None      # (not the dropped batch's dict)
-    assert torch.equal(m.outpaint_flush()["codes"], ref[1])
-    m.outpaint2.engine(32, 32, 2 * V).check()
+    left = m.outpaint_flush()
+    assert len(left) == 1 and torch.equal(left[0]["codes"], ref[1])
+    m.outpaint2.engine(32, 32, m.pipe_frames(V)).check()
 
 
 def test_plan_views_then_outpaint_planned_equals_outpaint_views_also_across_streams():
@@ -706,14 +748,16 @@ def test_prefix_pass_dealt_to_two_streams_gives_the_codes_of_one_stream(monkeypa
         eng.ar_prefix = real_prefix
 
 
-def test_outpaint_pipelined_gives_the_codes_of_outpaint_planned_batch_by_batch():
+def test_outpaint_pipelined_gives_the_codes_of_outpaint_planned_batch_by_batch(monkeypatch):
     """outpaint_pipelined leaves the narrow last wavefronts of a batch's AR run for the launches of the NEXT batch's first wavefronts
     (both batches resident in one 2 V-frame handle, merge_schedules); outpaint_flush runs what is left of the last batch.  Three
     different batches of 64 views in a row (the frame halves of the handle alternate: the third batch reuses the first one's), twice over:
     every batch's codes are those of outpaint_planned, bit for bit, and a batch comes back exactly one call late."""
     from pixelsynth_amd.lmconv.model import split_tail
+    monkeypatch.setenv("PS_PIPE_DEPTH", "2")      # the head / tail form C5's 128 views take, at half the size (64 views alone: four in flight)
     m = make_model()
     V = 64
+    assert m.pipe_depth(V) == 2
     cam = syn.demo_cameras(V)
     K, Kinv, P, Pinv = (tt(cam[k]) for k in ("K", "Kinv", "P", "Pinv"))
     batches = []
@@ -746,11 +790,11 @@ def test_outpaint_pipelined_gives_the_codes_of_outpaint_planned_batch_by_batch()
             fs = planned["plan"].first_steps
             assert fs.min() == planned["plan"].first_step and fs.max() > fs.min() and planned["plan"].waves_frames[0].shape[0] == int((1024 - fs).sum())
             done = m.outpaint_pipelined(planned, codes, temperature=0.7, uniforms=uni)
-            assert (done is None) == (len(got) == 0 and True) or done is not None
+            assert (done is None) == (len(got) == 0 and done is None)      # (two batches in flight: a batch comes back one call late)
             if done is not None:
                 got.append(done["codes"].clone())
-        got.append(m.outpaint_flush()["codes"].clone())
-        assert m.outpaint_flush() is None
+        got += [o["codes"].clone() for o in m.outpaint_flush()]
+        assert m.outpaint_flush() == []
         torch.cuda.synchronize()
         m.outpaint2.engine(32, 32, 2 * V).check()
         assert len(got) == 3

@@ -7,7 +7,7 @@ mkdir -p gpurun_out
 for r in $(seq 1 $rounds); do
   for cfg in "$@"; do
     name=${cfg%%=*}; envs=${cfg#*=}; [ "$envs" = "$cfg" ] && envs=""
-    env $(echo $envs | tr '+' ' ') python bench.py --no-extra --no-cpu-baseline --no-live-pmc --steps $steps --warmup 5 \
+    env $(echo $envs | tr '+' ' ') python bench.py --no-extra --no-cpu-baseline --no-live-pmc --steps $steps --warmup 5 $PS_AB_ARGS \
         > gpurun_out/ab_${name}_${r}.json 2> gpurun_out/ab_${name}_${r}.err || tail -5 gpurun_out/ab_${name}_${r}.err
   done
 done
