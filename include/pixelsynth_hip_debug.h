@@ -15,7 +15,7 @@ extern "C" {
 #endif
 
 /* Tuning values of a handle, by name (pixelsynth_amd/csrc/lmconv_handle.h: struct Tuning; lmconv.hip: tuning_table): which launch
- * form the whole-grid pass takes from which size on (gemm_merge_min, gemm_wg_min, wg_ti_out / _in / _dil), whether the prefix
+ * form the whole-grid pass takes from which size on (gemm_merge_min, gemm_wg_min, gemm_ws_min, gemm_ws, wg_ti_out / _in / _dil), whether the prefix
  * pass skips the items nobody reads (prefix_full, prefix_cone_force), the look-ahead depths of the column launches (tp_ahead,
  * col_ahead: only before the handle's first column launch), the form and placement of a column launch (tp_min_cols, tp_xcds,
  * tp_fill, col_cap, chain_xcds, nbr_groups).  No value changes results: every form is bit-identical (tests/test_lmconv_gpu.py).

@@ -146,7 +146,7 @@ std::vector<float> pack_nin_host(const float *v, const float *g, int Co, int Ci)
 // ------------------------------------------------------------------------------------------
 struct TuningEntry { const char *key; int Tuning::*field; int lo, hi; };
 const TuningEntry tuning_table[] = {
-    {"gemm_merge_min", &Tuning::gemm_merge_min, 0, 1 << 30}, {"gemm_wg_min", &Tuning::gemm_wg_min, 1, 1 << 30},
+    {"gemm_merge_min", &Tuning::gemm_merge_min, 0, 1 << 30}, {"gemm_wg_min", &Tuning::gemm_wg_min, 1, 1 << 30}, {"gemm_ws_min", &Tuning::gemm_ws_min, 1, 1 << 30},
     {"wg_ti_out", &Tuning::wg_ti_out, 1, 2}, {"wg_ti_in", &Tuning::wg_ti_in, 2, 4}, {"wg_ti_dil", &Tuning::wg_ti_dil, 2, 4},
     {"item_sort", &Tuning::item_sort, 0, 2}, {"gemm_ws", &Tuning::gemm_ws, 0, 7},
     {"prefix_full", &Tuning::prefix_full, 0, 1}, {"prefix_cone_force", &Tuning::prefix_cone_force, 0, 1},

@@ -864,22 +864,36 @@ __global__ __launch_bounds__(WS_THREADS) void k_gemm_ws(GemmArgs a, PostArgs pa)
     if (tb >= a.tpx || y >= a.ny) return;
     const int item0 = y * MI, ntaps = a.slot_first[a.nslots];
     const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
-    {   // ---- set-up: rows and mask values of every (tap, item): lane = item, wave w does taps w, w + 4, w + 8
-        const int item = item_at(a.items, item0 + lane, a.nitems);
-        const bool valid = item >= 0 && item_wanted(a.items, item);
-        int f = 0, q = 0, r = 0, c = 0;
-        if (valid) {
-            item_loc(a.items, item, a.L, f, q);
-            r = q / a.W;
-            c = q - r * a.W;
+    {   // ---- set-up: rows and mask values of every (tap, item): lane = item, wave w does taps w, w + 4, w + 8.
+        // Where the items were sorted, k_perm_scatter left (item, location | tap set << 12 | fractional-masks flag << 21) pairs: ONE load
+        // per lane instead of the chain position -> item -> order -> location -> mask values (three dependent round trips at the head of a
+        // workgroup whose partner on the compute unit starts at the same moment); with 0 / 1 masks the tap set says what the values are
+        // (k_gemm_wg's set-up, round 5)
+        const int pos = item0 + lane;
+        int item = -1, q = 0, pat = 0x1ff;
+        bool frac = true;
+        if (pos < a.nitems) {
+            if (a.items.permq) {
+                const int2 v = a.items.permq[pos];
+                item = v.x; q = v.y & 4095; pat = (v.y >> 12) & 0x1ff; frac = (v.y >> 21) & 1;
+            } else {
+                int fq;
+                item = item_at(a.items, pos, a.nitems);
+                item_loc(a.items, item, a.L, fq, q);
+            }
         }
+        const bool valid = item >= 0 && item_wanted(a.items, item);
+        const int f = a.items.f0 + (item >= 0 ? item / a.items.npre : 0), r = q / a.W, c = q - r * a.W;
         if (wave == 0) { sItem[lane] = valid ? item : -1; sLoc[lane] = valid ? f * a.L + q : 0; }
         for (int t = wave; t < ntaps; t += WS_WAVES) {
             const GemmTap tp = a.tap[t];
             const int rr = r + tp.dr, cc = c + tp.dc;
             float mv = 0.0f;
-            if (valid && rr >= 0 && rr < a.H && cc >= 0 && cc < a.W)
-                mv = tp.mask_row >= 0 ? a.mask[(size_t)f * a.mask_fstride + (size_t)tp.mask_row * a.L + q] : 1.0f;
+            if (valid) {
+                if (tp.mask_row < 0) mv = 1.0f;                                   // (nin_skip: the location itself, unmasked)
+                else if (!frac) mv = (pat >> tp.mask_row) & 1 ? 1.0f : 0.0f;      // 0 / 1 masks: the tap set says it all
+                else if (rr >= 0 && rr < a.H && cc >= 0 && cc < a.W) mv = a.mask[(size_t)f * a.mask_fstride + (size_t)tp.mask_row * a.L + q];
+            }
             sRow[t * MI + lane] = mv != 0.0f ? (f * a.L + rr * a.W + cc) : -1;
             sMv[t * MI + lane] = mv;
         }
@@ -1409,7 +1423,7 @@ bool launch_gemm(GemmArgs &a, int item_blocks, hipStream_t st, const Tuning &tun
         const int per_pass = kind == GW_DIL ? 4 : 14;
         a.trace_on = a.ny >= 2048 && seen[kind]++ % per_pass == (sel < per_pass ? sel : per_pass - 1);
 #endif
-        if ((tune.gemm_ws >> kind & 1) && post != nullptr) {   // weights shared through LDS, 64 items per workgroup (round 5); one bit per kind
+        if ((tune.gemm_ws >> kind & 1) && post != nullptr && item_blocks >= tune.gemm_ws_min) {   // weights shared through LDS, 64 items per workgroup (round 5); one bit per kind
             a.ny = (a.nitems + WS_MI - 1) / WS_MI;
             a.tpx = (a.ny + N_XCD - 1) / N_XCD;
             PostArgs pw = *post;

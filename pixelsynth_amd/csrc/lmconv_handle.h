@@ -85,7 +85,9 @@ struct ChainArgs {
 // form of the whole-grid pass inside one process.  Nothing here changes results -- every form is bit-identical (tested).
 struct Tuning {
     int gemm_merge_min = 8192;   // (tile, channel block) pairs from which one k_gemm wave walks all slots of its tile
-    int gemm_wg_min = 1024;      // item tiles from which the whole-grid products take the workgroup form (k_gemm_wg)
+    int gemm_wg_min = 256;       // item tiles from which the whole-grid products take a workgroup form: k_gemm_wg (rows through LDS, post op fused --
+                                 // 16 views: 4.06 against 4.16 ms per step through k_gemm + k_post_grid, round 6) ...
+    int gemm_ws_min = 1024;      // ... and from which on the forms of `gemm_ws` (weights through LDS, 64 items per workgroup; 16 views: 4.42 ms)
     int wg_ti_out = 1, wg_ti_in = 2, wg_ti_dil = 2;   // item tiles per k_gemm_wg workgroup: conv_out / conv_input / dilated
     int gemm_ws = 7;             // bits 0 / 1 / 2 = conv_out / conv_input / dilated: the workgroup form with the WEIGHTS shared through LDS (k_gemm_ws, 64 items per workgroup) instead of k_gemm_wg --
                                  // bit-identical; slower on the round-5 prefix of one first step per batch (236 / 157 / 93 us against 219 / 146 / 89),

@@ -178,8 +178,12 @@ def test_whole_grid_launch_forms_agree_bit_for_bit():
     eng.set_tuning(gemm_merge_min=0, gemm_wg_min=1, gemm_ws=0)   # k_gemm_wg: four-wave workgroups, input rows shared through LDS, post op fused (large launches)
     wg = run()
     assert torch.equal(wg, split)
-    eng.set_tuning(gemm_ws=7)                         # k_gemm_ws: 64 items per workgroup, the WEIGHTS shared through LDS
+    eng.set_tuning(gemm_ws=7, gemm_ws_min=1)          # k_gemm_ws: 64 items per workgroup, the WEIGHTS shared through LDS
+    n0 = eng.launch_counts()
     assert torch.equal(run(), split)
+    n1 = eng.launch_counts()
+    assert n1["k_gemm_ws<0>"] - n0["k_gemm_ws<0>"] == 14 and n1["k_gemm_ws<1>"] - n0["k_gemm_ws<1>"] == 14 and n1["k_gemm_ws<2>"] - n0["k_gemm_ws<2>"] == 4
+    assert n1["k_gemm_wg"] == n0["k_gemm_wg"] > 0     # (the form under test is the one that ran; k_gemm_wg ran for `wg` above)
     eng.set_tuning(gemm_ws=0)
     for ti in ((2, 2, 2), (1, 4, 4), (2, 4, 2)):      # item tiles per workgroup: conv_out / conv_input / dilated
         eng.set_tuning(wg_ti_out=ti[0], wg_ti_in=ti[1], wg_ti_dil=ti[2])
@@ -194,7 +198,7 @@ def test_whole_grid_launch_forms_agree_bit_for_bit():
     assert torch.equal(run(), split)
     eng.set_tuning(gemm_wg_min=1, gemm_ws=7)
     assert torch.equal(run(), split)                  # (k_gemm_ws over one sort of all frames)
-    eng.set_tuning(gemm_merge_min=8192, gemm_wg_min=1024, wg_ti_out=1, wg_ti_in=2, wg_ti_dil=2, item_sort=2, gemm_ws=7)   # (the defaults)
+    eng.set_tuning(gemm_merge_min=8192, gemm_wg_min=256, gemm_ws_min=1024, wg_ti_out=1, wg_ti_in=2, wg_ti_dil=2, item_sort=2, gemm_ws=7)   # (the defaults)
     x = torch.zeros(1, 512, 1024)
     x[0, codes[0], np.arange(1024)] = 1
     with torch.no_grad():
@@ -221,7 +225,7 @@ def test_workgroup_form_with_fractional_masks_loads_them():
     big = 1 << 30
     eng.set_tuning(gemm_merge_min=0, gemm_wg_min=big)
     ref = run()
-    eng.set_tuning(gemm_wg_min=1, gemm_ws=0)
+    eng.set_tuning(gemm_wg_min=1, gemm_ws=0, gemm_ws_min=1)
     assert torch.equal(run(), ref)
     eng.set_tuning(gemm_ws=7)
     assert torch.equal(run(), ref)
@@ -229,7 +233,7 @@ def test_workgroup_form_with_fractional_masks_loads_them():
     assert torch.equal(run(), ref)
     eng.set_tuning(gemm_ws=0, item_sort=0)
     assert torch.equal(run(), ref)
-    eng.set_tuning(gemm_merge_min=8192, gemm_wg_min=1024, item_sort=2, gemm_ws=7)   # (the defaults)
+    eng.set_tuning(gemm_merge_min=8192, gemm_wg_min=256, gemm_ws_min=1024, item_sort=2, gemm_ws=7)   # (the defaults)
     frac = ms[1][1][ms[1][1] > 0]
     assert ((frac != 1.0).mean() > 0.2) and torch.isfinite(ref).all()
 
@@ -256,7 +260,7 @@ def test_workgroup_gemm_form_under_the_prefix_cone_is_bit_identical(F_, first):
     codes0 = syn.codes(23, F_).reshape(F_, 1024).astype(np.int32)
     u = tt(np.random.RandomState(5).rand(F_, 1024).astype(np.float32))
     waves = wavefronts(order_loc, 32, 32, first, DEV)
-    eng.set_tuning(prefix_cone_force=1, gemm_merge_min=0)
+    eng.set_tuning(prefix_cone_force=1, gemm_merge_min=0, gemm_ws_min=1)
 
     def run(wg_min, item_sort=2, gemm_ws=0):
         eng.set_tuning(gemm_wg_min=wg_min, item_sort=item_sort, gemm_ws=gemm_ws)
@@ -269,7 +273,7 @@ def test_workgroup_gemm_form_under_the_prefix_cone_is_bit_identical(F_, first):
     c_nat, l_nat = run(1, item_sort=0)        # items in natural order / one sort over all frames (16 frames: default = one per XCD share)
     c_one, l_one = run(1 << 30, item_sort=1)
     c_old, l_old = run(1, gemm_ws=1)          # k_gemm_ws (weights through LDS, 64 items per workgroup) instead of k_gemm_wg (rows through LDS)
-    eng.set_tuning(prefix_cone_force=0, gemm_merge_min=8192, gemm_wg_min=1024, item_sort=2, gemm_ws=0)
+    eng.set_tuning(prefix_cone_force=0, gemm_merge_min=8192, gemm_wg_min=256, gemm_ws_min=1024, item_sort=2, gemm_ws=0)
     assert torch.equal(c_wg, c_ref) and torch.equal(c_nat, c_ref) and torch.equal(c_one, c_ref) and torch.equal(c_old, c_ref)
     walked = np.zeros((F_, 1024), bool)
     for b in range(F_):
