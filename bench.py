@@ -262,10 +262,10 @@ def measure_roofline(model, d, out, V, live_pmc=False):
         frames = getattr(plan, "waves_frames", None) if model.PER_FRAME_PREFIX else None   # per-frame prefixes: their own schedule
         hc, ws = (frames[0].cpu().numpy(), frames[1]) if frames is not None else (plan.waves_host, plan.waves[1])
         ncols = int(hc.shape[0])
-        cut = split_tail(ws, model.PIPE_MERGE_MAX)
+        cut = split_tail(ws, model.pipe_merge_max())
         off = np.array([V, 0], np.int32)
         from pixelsynth_amd.lmconv.model import launch_capacity
-        cut = split_tail(ws, min(model.PIPE_MERGE_MAX, launch_capacity(V) * 45 // 64))
+        cut = split_tail(ws, min(model.pipe_merge_max(), launch_capacity(V) * 45 // 64))
         mid_c, mid_w = merge_schedules(hc[ws[cut]:], ws[cut:] - ws[cut], hc[:ws[cut]] + off, ws[:cut + 1], min(model.PIPE_CAP, launch_capacity(V)))
         all_c = np.ascontiguousarray(np.concatenate([hc[:ws[cut]], mid_c, hc[ws[cut]:] + off]), np.int32)
         all_w = np.ascontiguousarray(np.concatenate([ws[:cut + 1], ws[cut] + mid_w[1:], ws[cut] + mid_w[-1] + (ws[cut + 1:] - ws[cut])]), np.int32)

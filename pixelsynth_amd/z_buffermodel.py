@@ -395,7 +395,7 @@ class ZbufferModelPts(nn.Module):
         return planned
 
     # ---------------------------------------------------------------- the AR runs of consecutive batches, overlapped
-    PIPE_MERGE_MAX = int(__import__('os').environ.get('PS_PIPE_MERGE_MAX', '720'))    # wavefronts of at most this many columns behind a schedule's widest are left for the next batch's launches
+    PIPE_MERGE_MAX = 720    # wavefronts of at most this many columns behind a schedule's widest are left for the next batch's launches (PS_PIPE_MERGE_MAX, read per call: pipe_merge_max)
     PIPE_CAP = 1024         # columns a merged launch takes (lmconv.model.COLUMNS_PER_LAUNCH_TP)
     PER_FRAME_PREFIX = True  # outpaint_pipelined: per-frame prefixes where the plan carries their schedule (build_ar_plan, PS_PER_FRAME_PREFIX)
     PIPE_DEPTH_SMALL = 4    # batches in flight for batches of fewer than PIPE_DEEP_BELOW views: their wavefronts leave a launch far from
@@ -412,6 +412,10 @@ class ZbufferModelPts(nn.Module):
         import os
         d = os.environ.get("PS_PIPE_DEPTH")
         return max(2, min(8, int(d))) if d else (2 if V >= self.PIPE_DEEP_BELOW else self.PIPE_DEPTH_SMALL)
+
+    def pipe_merge_max(self):
+        import os
+        return int(os.environ.get("PS_PIPE_MERGE_MAX", self.PIPE_MERGE_MAX))
 
     def pipe_frames(self, V):
         """Frames of the engine handle outpaint_pipelined runs batches of V views in."""
@@ -511,7 +515,7 @@ class ZbufferModelPts(nn.Module):
         dcols = waves[0] + st["offset"][h] if h else waves[0]
         n = len(ws) - 1
         if D == 2:   # head / tail: the tail = the narrow last waves behind the widest one
-            bounds = [0, split_tail(ws, min(self.PIPE_MERGE_MAX, launch_capacity(V) * 45 // 64)), n]
+            bounds = [0, split_tail(ws, min(self.pipe_merge_max(), launch_capacity(V) * 45 // 64)), n]
         else:        # (more than two in flight: equal numbers of waves)
             bounds = [(n * p + D // 2) // D for p in range(D + 1)]
         parts = [(dcols[ws[a]:ws[b]], ws[a:b + 1] - ws[a]) for a, b in zip(bounds[:-1], bounds[1:])]
