@@ -7,7 +7,10 @@ tag=$1; shift
 out=gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-B="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra $*"
+# (PS_BENCH_PMC_CHILD=1: nothing but the timed steps in the profiled command -- bench.py then skips the roofline's own measurement runs,
+# whose two-batch launches of twice the frames used to be averaged into every per-kernel figure)
+export PS_BENCH_PMC_CHILD=1
+B="python bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-extra $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o bench -- $B > $out/bench_under_trace.json 2> $out/stats.log
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
   name=$(echo $grp | cut -d' ' -f1)
@@ -15,7 +18,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES
 done
 find $out -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/kernel_stats.csv
 for f in $(find $out -name "*counter_collection.csv"); do python tools/pmc_summary.py $f; done > $out/pmc_summary.txt 2>&1
-python $* bench.py > /dev/null 2>&1 || true
+unset PS_BENCH_PMC_CHILD
 ls -la $out | head -30
 head -12 $out/kernel_stats.csv
 cat $out/pmc_summary.txt | head -80
