@@ -443,7 +443,7 @@ MFMA_FLOP = 2 * 16 * 16 * 4          # one v_mfma_f32_16x16x4_f32
 N_SIMD, NOMINAL_MHZ = 1024, 2400.0
 
 
-def measure_kernels(model, d, V, world, side, plan, live, ms_per_step, steps=4):
+def measure_kernels(model, d, V, world, side, plan, live, ms_per_step, steps=12):
     """`roofline.kernels`: every kernel that carries matrix work, as the timed region runs it -- `steps` more pipelined steps with a HIP
     event pair around each such launch on the stream it goes to (ps_pixelcnn_profile_begin / _end): launches per step, event-timed
     average, ms per step (the prefix pass runs on two streams: its kernels overlap each other and the splat, so the column sums to more than
@@ -467,6 +467,16 @@ def measure_kernels(model, d, V, world, side, plan, live, ms_per_step, steps=4):
         real_cols(*a, **k)
         e1.record()
         marks.append((e0, e1))
+    # a run of n steps is the pipeline's fill, n steady-state steps' worth of launches and the flush of what is left (narrow launches of
+    # their own): a SHORT run is profiled first and taken off the long one -- what remains are `steps - short` steady-state steps
+    short = 4 if pipelined and steps > 6 else 0
+    prof0 = None
+    if short:
+        eng.profile_begin()
+        try:
+            run_steps(model, d, world, short, side)
+        finally:
+            prof0 = eng.profile_end()
     model._pipe_columns = cols
     eng.profile_begin()
     try:
@@ -474,10 +484,14 @@ def measure_kernels(model, d, V, world, side, plan, live, ms_per_step, steps=4):
     finally:
         prof = eng.profile_end()
         del model._pipe_columns          # (the instance attribute: the class's method is back)
+    if prof0 is not None:
+        prof = {k: (prof[k][0] - prof0[k][0], prof[k][1] - prof0[k][1]) for k in prof}
+    nsteps = steps - short
     phases = None
-    if pipelined and len(marks) >= steps + 1:     # (steps merged launches + the flush)
-        col_ms = [a.elapsed_time(b) for a, b in marks[1:steps]]                       # steady-state steps only (not the first, not the flush)
-        pre_ms = [marks[i][1].elapsed_time(marks[i + 1][0]) for i in range(0, steps - 1)]
+    D = model.pipe_depth(V) if pipelined else 1
+    if pipelined and len(marks) >= steps + 1 and steps > D + 1:     # (steps merged launches + the flush's)
+        col_ms = [a.elapsed_time(b) for a, b in marks[D:steps]]                       # steady-state steps only (pipeline full, not the flush)
+        pre_ms = [marks[i][1].elapsed_time(marks[i + 1][0]) for i in range(D - 1, steps - 1)]
         phases = {"column_launches_ms": round(float(np.mean(col_ms)), 3), "prefix_pass_and_small_kernels_ms": round(float(np.mean(pre_ms)), 3),
                   "what": "main-stream event marks around the column launches of the steady-state steps of this profile run: the step is the "
                           "prefix phase (whole-grid pass on two streams, the next step's splat beside it, item sort / cone / context kernels) "
@@ -497,6 +511,7 @@ def measure_kernels(model, d, V, world, side, plan, live, ms_per_step, steps=4):
                   "k_gemm_ws<2>": sum(items[29 + k] * STAGE_FLOPS["dilated"] for k in range(4))}
     n_items = {"k_gemm_ws<0>": int(items[15:29].sum()), "k_gemm_ws<1>": int(items[1:15].sum()), "k_gemm_ws<2>": int(items[29:33].sum())}
     ncols = int((plan.waves_frames[0] if per_frame else plan.waves[0]).shape[0])
+    steps = nsteps
     col_launches = sum(prof[k][0] for k in prof if k.startswith("k_column"))
     kinds = (live or {}).get("by_launch_kind", {})
     rows, executed_step = [], 0.0
@@ -625,7 +640,7 @@ def extra_configs(device):
     # round-robin (rank 0 renders views 0, 8, 16, ...: two of every source's sweep); C4 = the 64-frame circle -> 8 frames per GPU.
     c5 = small_batch_config(device, 16, "mp3d", total=128)
     c4 = small_batch_config(device, 8, "demo", total=64, trajectory="circle")
-    c4_1gpu = small_batch_config(device, 64, "demo", total=None, trajectory="circle")
+    c4_1gpu = small_batch_config(device, 64, "demo", total=None, trajectory="circle", steps=40)   # (four batches in flight: the fill and the flush weigh on a short run)
     res["C4_circle_64_frames_one_gpu"] = c4_1gpu
     res["projected_per_gpu"] = {
         "note": "what ONE of eight GPUs runs in the strong-scaling forms of C5 / C4 (python bench.py --total-views 128 | "
