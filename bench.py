@@ -483,7 +483,7 @@ def measure_kernels(model, d, V, world, side, plan, live, ms_per_step, steps=12)
         run_steps(model, d, world, steps, side)
     finally:
         prof = eng.profile_end()
-        del model._pipe_columns          # (the instance attribute: the class's method is back)
+        model.__dict__.pop("_pipe_columns", None)          # (the instance attribute: the class's method is back)
     if prof0 is not None:
         prof = {k: (prof[k][0] - prof0[k][0], prof[k][1] - prof0[k][1]) for k in prof}
     nsteps = steps - short

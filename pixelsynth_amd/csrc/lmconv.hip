@@ -522,6 +522,10 @@ int ps_pixelcnn_create(const float *const *params, int n_params, int H, int W, i
 void ps_pixelcnn_destroy(ps_pixelcnn *h)
 {
     if (!h) return;
+    for (auto &r : h->prof_own) {   // (a launch profile that was begun and never ended: its events go with the handle)
+        (void)hipEventDestroy(r.e0);
+        (void)hipEventDestroy(r.e1);
+    }
     for (void *p : h->allocs) (void)hipFree(p);
     delete h;
 }
