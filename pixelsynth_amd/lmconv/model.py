@@ -501,6 +501,26 @@ def merge_schedules(tail_cols, tail_start, head_cols, head_start, cap):
     return cols, np.asarray(starts, np.int32)
 
 
+def split_parts(wave_start, depth, merge_max):
+    """Wave indices [b_0 = 0, ..., b_depth = n] at which a schedule of n waves is cut into `depth` consecutive parts for
+    z_buffermodel.outpaint_pipelined: two parts = head and tail (split_tail: the narrow waves behind the widest one), more = equal
+    numbers of waves."""
+    n = len(wave_start) - 1
+    if depth == 2:
+        return [0, split_tail(wave_start, merge_max), n]
+    return [(n * p + depth // 2) // depth for p in range(depth + 1)]
+
+
+def fold_schedules(parts, cap):
+    """One schedule out of the current parts of several batches in flight, OLDEST FIRST (each (cols, wave_start), frame indices already
+    those of the shared handle): merge_schedules folded from the oldest on -- launch j holds wave j of the newest batch's part and as many
+    columns of the older batches' current waves as fit under `cap`; every batch's waves keep their order.  -> (cols, wave_start) or None."""
+    merged = None
+    for cols, ws in parts:
+        merged = (cols, ws) if merged is None else merge_schedules(merged[0], merged[1], cols, ws, cap)
+    return merged
+
+
 def _wavefronts(order_host, F_, L, H, W, first_step, device, max_cols, keep_host=False, first_steps=None):
     import ctypes
     nsteps = L - first_step

@@ -453,7 +453,7 @@ class ZbufferModelPts(nn.Module):
         are cut into pipe_depth(V) parts and as many batches share a launch.  Asynchronous on the current stream.
         -> the dict (codes added) of the oldest batch that is complete and has not been handed back yet -- in the steady state the batch
         of pipe_depth(V) - 1 calls ago -- or None; outpaint_flush() runs what is left.  between: as for outpaint_planned."""
-        from .lmconv.model import launch_capacity, split_tail
+        from .lmconv.model import launch_capacity, split_parts
         gen_fs, plan = planned["gen_fs"], planned["plan"]
         V, G = gen_fs.shape[0], self.obs[1]
         L = G * self.obs[2]
@@ -513,11 +513,8 @@ class ZbufferModelPts(nn.Module):
         # launch by launch, from slices of the batches' columns (one concatenation) -- nothing crosses PCIe on the stream of the AR run.
         ws = waves[1]
         dcols = waves[0] + st["offset"][h] if h else waves[0]
-        n = len(ws) - 1
-        if D == 2:   # head / tail: the tail = the narrow last waves behind the widest one
-            bounds = [0, split_tail(ws, min(self.pipe_merge_max(), launch_capacity(V) * 45 // 64)), n]
-        else:        # (more than two in flight: equal numbers of waves)
-            bounds = [(n * p + D // 2) // D for p in range(D + 1)]
+        # (two in flight: head / tail, the tail = the narrow last waves behind the widest one; more: equal numbers of waves)
+        bounds = split_parts(ws, D, min(self.pipe_merge_max(), launch_capacity(V) * 45 // 64))
         parts = [(dcols[ws[a]:ws[b]], ws[a:b + 1] - ws[a]) for a, b in zip(bounds[:-1], bounds[1:])]
         st["inflight"].append(dict(planned=planned, parts=parts, first_step=plan.first_step, slot=h, temperature=temperature))
         st["slot"] = (h + 1) % D
@@ -528,13 +525,9 @@ class ZbufferModelPts(nn.Module):
         """One set of merged launches: the next part of every batch in flight, oldest first -- launch j holds wave j of the newest
         batch's part and, folded in from the oldest on, as many columns of the older batches' current waves as fit (merge_schedules).
         Batches whose last part this was are complete: their codes are taken out of the handle behind the launches."""
-        from .lmconv.model import launch_capacity, merge_schedules
-        cap = min(self.PIPE_CAP, launch_capacity(V))
-        merged, first = None, None
-        for b in st["inflight"]:
-            cols, ws = b["parts"].pop(0)
-            first = b["first_step"] if first is None else min(first, b["first_step"])
-            merged = (cols, ws) if merged is None else merge_schedules(merged[0], merged[1], cols, ws, cap)
+        from .lmconv.model import fold_schedules, launch_capacity
+        first = min((b["first_step"] for b in st["inflight"]), default=None)
+        merged = fold_schedules([b["parts"].pop(0) for b in st["inflight"]], min(self.PIPE_CAP, launch_capacity(V)))
         if merged is not None:
             self._pipe_columns(eng, st, args, merged[0], merged[1], first, st["inflight"][0]["temperature"])
         finished = [b for b in st["inflight"] if not b["parts"]]
