@@ -152,7 +152,7 @@ const TuningEntry tuning_table[] = {
     {"prefix_full", &Tuning::prefix_full, 0, 1}, {"prefix_cone_force", &Tuning::prefix_cone_force, 0, 1},
     {"tp_ahead", &Tuning::tp_ahead, 0, NST - 2}, {"col_ahead", &Tuning::col_ahead, 0, NST - 4},
     {"tp_min_cols", &Tuning::tp_min_cols, 1, 1 << 30}, {"tp_xcds", &Tuning::tp_xcds, -1, 7}, {"tp_fill", &Tuning::tp_fill, 0, 1},
-    {"tp_affine", &Tuning::tp_affine, 0, 1}, {"tp_ct8_xcds", &Tuning::tp_ct8_xcds, 0, 4}, {"tp_ct8_cols", &Tuning::tp_ct8_cols, 0, 1024},
+    {"tp_affine", &Tuning::tp_affine, 0, 1}, {"tp_dequeue", &Tuning::tp_dequeue, 0, 1}, {"tp_ct8_xcds", &Tuning::tp_ct8_xcds, 0, 4}, {"tp_ct8_cols", &Tuning::tp_ct8_cols, 0, 1024},
     {"col_cap", &Tuning::col_cap, 1, COL_CAP}, {"chain_xcds", &Tuning::chain_xcds, 0, 8}, {"nbr_groups", &Tuning::nbr_groups, 0, NBR_MAX_GROUPS},
 #ifdef PS_TUNING_BUILD   // timing experiments whose results are INVALID (1: chains do not wait for the neighbour slots, 2: no chains, 3: no
     {"column_debug", &Tuning::column_debug, 0, 1 << 20},   // neighbour role and no waiting; + 256 x the traced wave): tuning builds only
@@ -503,7 +503,8 @@ int ps_pixelcnn_create(const float *const *params, int n_params, int H, int W, i
     if ((rc = dev_alloc(h, &h->nbr_tp, (size_t)2 * NST * 2 * TP_COL_CAP * NBR_LD))) return fail_out(rc);
     if ((rc = dev_alloc(h, &h->cnt_tp, 2 * tp_cnt_index(NST, 0)))) return fail_out(rc);
     if ((rc = dev_alloc(h, &h->done_tp, (size_t)NST * CNT_PAD))) return fail_out(rc);
-    if (hipMemset(h->cnt_tp, 0, 2 * tp_cnt_index(NST, 0) * sizeof(unsigned)) != hipSuccess ||
+    if ((rc = dev_alloc(h, &h->dq_tp, (size_t)8 * CNT_PAD))) return fail_out(rc);
+    if (hipMemset(h->cnt_tp, 0, 2 * tp_cnt_index(NST, 0) * sizeof(unsigned)) != hipSuccess || hipMemset(h->dq_tp, 0, (size_t)8 * CNT_PAD * sizeof(unsigned)) != hipSuccess ||
         hipMemset(h->done_tp, 0, (size_t)NST * CNT_PAD * sizeof(unsigned)) != hipSuccess) {
         ps::fail(PS_ERR_HIP, "pixelcnn_create: hipMemset failed");
         return fail_out(PS_ERR_HIP);

@@ -104,6 +104,8 @@ struct Tuning {
     int tp_affine = 1;           // throughput form: every neighbour XCD owns a fixed share of the STAGES (its ~3 MB of their weights stay in its L2
                                  // from launch to launch) instead of all XCDs walking all stages together: 378 -> 162 MB per launch at the L2's memory
                                  // side, the launch as long as before (122 us at 128 views; 151 -> 155 us at 256, where the neighbour role is the bound)
+    int tp_dequeue = 1;          // throughput form, neighbour role: items taken on demand from a device counter per share instead of dealt round-robin
+                                 // (round 6: k_column_tp8 115.5 -> 113.7 us per launch, 12.31 -> 12.23 ms per step; scheduling only, bit-identical)
     int tp_ct8_cols = 1024;      // ... and that have at most this many columns (beyond, the neighbour role on the fewer CUs left to it is the bound)
     int tp_ct8_xcds = 3;         // throughput form: chain tiles of 8 columns (k_column_tp8) for launches whose tiles then fit this many XCDs (0: never)
     int col_cap = COL_CAP;       // columns per latency-form launch
@@ -154,6 +156,8 @@ struct ps_pixelcnn {
     // look-ahead of the neighbour role (nbr_role_tp): slots, counters and their targets are double-buffered by launch parity
     unsigned tile_uses_tp_lo[2][pslm::TP_MAX_TILES] = {}, tile_uses_tp_hi[2][pslm::TP_MAX_TILES] = {};
     unsigned *done_tp = nullptr;    // [NST] padded: chain tiles that have published the input of stage k, never reset
+    unsigned *dq_tp = nullptr;      // [8] padded: items the neighbour role's shares have taken (tune.tp_dequeue), never reset
+    unsigned dq_total[8] = {};      // what they will stand at when every launch enqueued so far is through
     unsigned done_total = 0;        // what they stand at when every publishing launch so far is through
     int tp_wsplit = 0;              // first entry of work_tp whose stage is >= tune.tp_ahead
     // stage-affine neighbour XCDs (tune.tp_affine): for every count nx of neighbour XCDs, the work-table entries of XCD xi in table

@@ -78,6 +78,10 @@ struct TpArgs {
     int publish_upto;         // stages whose input the chain tiles publish (0: nobody looks)
     int *err;
     int debug;
+    // neighbour role, items dealt on demand (round 6): one never-reset device counter per share (stage-affine XCD, or [0] for all), each on
+    // its own line; dq_base[x] = what counter x stood at when this launch was enqueued (null: items dealt round-robin, as before)
+    unsigned *dq;
+    unsigned dq_base[8];
     unsigned long long *trace;   // tuning builds (-DPS_TP_TRACE_BUILD): [NST][8] shader-clock stamps of tile 0, wave 0
 };
 
@@ -191,7 +195,22 @@ __device__ __forceinline__ void nbr_role_tp(const TpArgs &a, int nb)
     if (threadIdx.x == 0) sReadyTp = 0;
     __syncthreads();
     int ready_upto = -1;
-    for (int item = gw; item < nitems; item += nw) {
+    // Which items a wave takes: round-robin (wave gw of nw takes gw, gw + nw, ...), or ON DEMAND -- the items differ by a factor of ten
+    // (0 to 4 open taps, 5 or 10 channel groups, one or two output tiles), a wave gets about nine of them, and the launch is as long as
+    // the unluckiest wave's share; with a device-scope counter per share every wave takes the next item when it is through with its own
+    // (the next index is requested while the current item runs, so the round trip is hidden).  The order in which items START is the
+    // table's either way: stage-major, own entries before the next launch's.  Every wave requests exactly one index past the end: the
+    // host knows what the counter stands at afterwards (run_columns_tp).
+    unsigned *const dq = a.dq ? a.dq + (size_t)xi * CNT_PAD : nullptr;
+    const unsigned dq_base = a.dq_base[xi];
+    auto dq_next = [&]() {
+        unsigned v = 0;
+        if (lane == 0) v = __hip_atomic_fetch_add(dq, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return v;      // (lane 0's value; made uniform where it is consumed)
+    };
+    unsigned fetched = dq ? dq_next() : 0u;
+    for (int item = dq ? (int)((unsigned)uni((int)fetched) - dq_base) : gw; item < nitems;) {
+        if (dq) fetched = dq_next();
         const bool ahead = item >= n_own;
         int witem, ctile;
         if (!ahead) {
@@ -251,6 +270,7 @@ __device__ __forceinline__ void nbr_role_tp(const TpArgs &a, int nb)
             }
             signal_done(a.cnt + tp_cnt_index(wk.stage, ctile), lane);
         }
+        item = dq ? (int)((unsigned)uni((int)fetched) - dq_base) : item + nw;
     }
 }
 
@@ -823,6 +843,22 @@ void run_columns_tp(ps_pixelcnn *h, const StepCtx *rec, int ncols, const ChainAr
                 ta.chain_xcds = 0; ta.fill_nbr = -1; ta.fill_cnt = 0; ta.affine_nx = 0;
                 ta.nbr_wgs = std::max(1, std::min(h->n_cus - ctiles, (h->nwork_tp * tiles + TP_WAVES - 1) / TP_WAVES));
                 grid = ta.nbr_wgs + ctiles;
+            }
+            // items on demand (tune.tp_dequeue): where every share's counter stands now, and where it will stand when this launch is through --
+            // a share's items + one request past the end by each of its waves (exactly what nbr_role_tp does)
+            ta.dq = nullptr;
+            if (h->tune.tp_dequeue && h->dq_tp) {
+                ta.dq = h->dq_tp;
+                const int nx = ta.affine_nx;
+                for (int x = 0; x < (nx ? nx : 1); ++x) {
+                    const int e_own0 = nx ? (ta.w_from ? ta.xlo[x] : 0) : ta.w_from, e_own1 = nx ? ta.xlen[x] : ta.nwork;
+                    const int e_ahead1 = nx ? (ta.w_upto ? ta.xlo[x] : 0) : ta.w_upto;
+                    const int nitems = (e_own1 - e_own0) * ta.tiles + e_ahead1 * ta.tiles_next;
+                    int wgs = ta.nbr_wgs;
+                    if (nx) { wgs = 0; for (int nb = 0; nb < ta.nbr_wgs; ++nb) wgs += nb % nx == x; }
+                    ta.dq_base[x] = h->dq_total[x];
+                    h->dq_total[x] += (unsigned)(nitems + wgs * TP_WAVES);
+                }
             }
             ta.trace = (trace_sel < 0 || trace_sel == h->tp_launch_no) ? h->tp_trace : nullptr;
             h->tp_launch_no += 1;
