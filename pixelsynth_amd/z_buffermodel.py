@@ -74,6 +74,7 @@ import collections
 import os
 import threading
 
+_PREFIX_STREAMS = {}    # (device, n) -> the prefix pass's side streams (ZbufferModelPts._prefix_streams)
 PER_FRAME_PREFIX = os.environ.get("PS_PER_FRAME_PREFIX", "1") != "0"   # plans also carry the schedule of per-frame prefixes (waves_frames)
 
 _PINNED = collections.OrderedDict()
@@ -587,10 +588,12 @@ class ZbufferModelPts(nn.Module):
         return n if n > 1 and V >= self.PREFIX_SPLIT_MIN_VIEWS and V % (8 * n) == 0 else 1
 
     def _prefix_streams(self, n, device):
-        """n side streams for the prefix pass, created once per model and device (which hardware queue a stream lands on is dealt at
-        creation: docs/LAB_NOTEBOOK.md, "Which stream the side stream is")."""
+        """n side streams for the prefix pass, created once per PROCESS and device: which hardware queue a stream lands on is dealt at
+        creation, one in eight shares the main stream's (docs/LAB_NOTEBOOK.md, "Which stream the side stream is") -- a process that
+        builds several models one after the other (bench.py's side configurations) must not draw a new lot with each of them
+        (round 6: C4's 64-frame circle 8.8 ms per step inside the long default bench run, 6.9 as a run of its own)."""
         key = (str(device), n)
-        cache = self.__dict__.setdefault("_pfx_streams", {})
+        cache = _PREFIX_STREAMS
         if key not in cache:
             import os
             skip = int(os.environ.get("PS_PREFIX_STREAM_SKIP", "0"))    # tuning: streams created (and kept) in front of them
