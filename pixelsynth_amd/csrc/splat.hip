@@ -700,6 +700,43 @@ __global__ __launch_bounds__(256) void k_dilate(const uint8_t *__restrict__ bg0,
     }
 }
 
+// The same dilation on BIT ROWS (round 6; S a multiple of 64, at most 2048): a wave's 64 one-byte loads of a row segment are one coalesced
+// 64-byte request and its ballot is the segment as a 64-bit word; a band of 64 output rows keeps its 64 + 2 h input rows as words in LDS,
+// the horizontal pass is shifts across word boundaries (OR over -h .. h), the vertical one an OR over 2 h + 1 rows, and a word goes back
+// out as 64 coalesced bytes.  k_dilate moved every byte through LDS twice, a byte per access (57 us alone per 128 frames of 256 x 256,
+// ~110 beside the prefix pass: the splat's kernels add to the step one for one).
+constexpr int DB_ROWS = 64, DB_MAXW = 2048 / 64;
+__global__ __launch_bounds__(256) void k_dilate_bits(const uint8_t *__restrict__ bg0, int S, int h, uint8_t *__restrict__ bg)
+{
+    __shared__ unsigned long long m[DB_ROWS + 2 * DMAXH][DB_MAXW], mh[DB_ROWS + 2 * DMAXH][DB_MAXW];
+    const int b = blockIdx.y, y0 = blockIdx.x * DB_ROWS, W64 = S >> 6, R = DB_ROWS + 2 * h;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint8_t *src = bg0 + (size_t)b * S * S;
+    for (int q = wave; q < R * W64; q += 4) {          // (row, word) pairs: one 64-byte load and one ballot each
+        const int r = q / W64, k = q - r * W64, y = y0 + r - h;
+        const uint8_t v = (y >= 0 && y < S) ? src[(size_t)y * S + 64 * k + lane] : 0;
+        const unsigned long long bits = __ballot(v != 0);
+        if (lane == 0) m[r][k] = bits;
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < R * W64; q += 256) {  // horizontal: bit i = pixel 64 k + i; out bit i = OR of the bits i - h .. i + h
+        const int r = q / W64, k = q - r * W64;
+        const unsigned long long x = m[r][k], left = k > 0 ? m[r][k - 1] : 0ull, right = k + 1 < W64 ? m[r][k + 1] : 0ull;
+        unsigned long long o = x;
+        for (int d = 1; d <= h; ++d) o |= (x >> d) | (right << (64 - d)) | (x << d) | (left >> (64 - d));
+        mh[r][k] = o;
+    }
+    __syncthreads();
+    uint8_t *dst = bg + (size_t)b * S * S;
+    for (int q = wave; q < DB_ROWS * W64; q += 4) {     // vertical, and a word back out as 64 bytes
+        const int r = q / W64, k = q - r * W64, y = y0 + r;
+        if (y >= S) continue;                           // (wave-uniform)
+        unsigned long long o = 0;
+        for (int d = 0; d <= 2 * h; ++d) o |= mh[r + d][k];
+        dst[(size_t)y * S + 64 * k + lane] = (uint8_t)((o >> lane) & 1ull);
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
@@ -794,8 +831,12 @@ int splat_core(const float *pts, const float *feat, int B, int N, int C, int S, 
                                           r2, denom_arg, tau, K, out_feat, bg0, out_idx, out_zbuf, out_dist);
         break;
     }
-    const dim3 gd((S + DT - 1) / DT, (S + DT - 1) / DT, B);
-    hipLaunchKernelGGL(k_dilate, gd, dim3(256), 0, st, bg0, S, bg_ksize / 2, out_bg);
+    if (S % 64 == 0 && S <= 64 * DB_MAXW) {
+        hipLaunchKernelGGL(k_dilate_bits, dim3((S + DB_ROWS - 1) / DB_ROWS, B), dim3(256), 0, st, bg0, S, bg_ksize / 2, out_bg);
+    } else {
+        const dim3 gd((S + DT - 1) / DT, (S + DT - 1) / DT, B);
+        hipLaunchKernelGGL(k_dilate, gd, dim3(256), 0, st, bg0, S, bg_ksize / 2, out_bg);
+    }
     PS_LAUNCH_CHECK();
     return PS_OK;
 }
