@@ -701,11 +701,11 @@ __global__ __launch_bounds__(256) void k_dilate(const uint8_t *__restrict__ bg0,
 }
 
 // The same dilation on BIT ROWS (round 6; S a multiple of 64, at most 2048): a wave's 64 one-byte loads of a row segment are one coalesced
-// 64-byte request and its ballot is the segment as a 64-bit word; a band of 64 output rows keeps its 64 + 2 h input rows as words in LDS,
+// 64-byte request and its ballot is the segment as a 64-bit word; a band of 16 output rows keeps its 16 + 2 h input rows as words in LDS,
 // the horizontal pass is shifts across word boundaries (OR over -h .. h), the vertical one an OR over 2 h + 1 rows, and a word goes back
 // out as 64 coalesced bytes.  k_dilate moved every byte through LDS twice, a byte per access (57 us alone per 128 frames of 256 x 256,
 // ~110 beside the prefix pass: the splat's kernels add to the step one for one).
-constexpr int DB_ROWS = 64, DB_MAXW = 2048 / 64;
+constexpr int DB_ROWS = 16, DB_MAXW = 2048 / 64;   // (bands of 16 rows: 16 x B workgroups fill the chip from 16 frames on; 64-row bands ran 32 frames on 128 workgroups: C2 0.407 -> 0.442 ms)
 __global__ __launch_bounds__(256) void k_dilate_bits(const uint8_t *__restrict__ bg0, int S, int h, uint8_t *__restrict__ bg)
 {
     __shared__ unsigned long long m[DB_ROWS + 2 * DMAXH][DB_MAXW], mh[DB_ROWS + 2 * DMAXH][DB_MAXW];
