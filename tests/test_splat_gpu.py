@@ -124,6 +124,28 @@ def test_product_route_stops_a_walk_below_2_to_the_minus_23_transmittance(scale)
     assert (ref["idx"][..., K - 1] >= 0).mean() > 0.1      # (there really are pixels with K hits: walks the early-out cuts short)
 
 
+@pytest.mark.parametrize("S,ksize", [(64, 9), (128, 31), (128, 1), (192, 13), (96, 13)])
+def test_mask_dilation_on_bit_rows_vs_oracle(S, ksize):
+    """The background mask's k x k dilation (z_buffer_layers.py:100-110): sizes that are a multiple of 64 take k_dilate_bits (bit rows,
+    bands of 16 rows, shifts across 64-pixel words), the others k_dilate -- the widest kernel (31), the identity (1), three words per
+    row (192) and a size that is no multiple of 64 (96), a sparse cloud so that the mask has holes and islands at every word boundary."""
+    rs = np.random.RandomState(S + ksize)
+    N = 3 * S * S
+    pts = np.empty((2, N, 3), np.float32)
+    pts[..., :2] = rs.rand(2, N, 2) * 2.2 - 1.1
+    pts[..., 2] = rs.rand(2, N) * 3 + 0.5
+    for b in range(2):                      # a dense cloud with a few holes: the "no hit" mask is the holes, the dilation grows them
+        for cx, cy, rad in rs.rand(5, 3) * [1.8, 1.8, 0.12] + [-0.9, -0.9, 0.03]:
+            inside = (pts[b, :, 0] - cx) ** 2 + (pts[b, :, 1] - cy) ** 2 < rad ** 2
+            pts[b, inside, 2] = -1.0        # (behind the camera: culled)
+    feat = rs.rand(2, 3, N).astype(np.float32)
+    sp = make_splatter(S, 8, radius=1.5, background_smoothing_kernel_size=ksize)
+    bg = sp(torch.from_numpy(pts).to(dev()), torch.from_numpy(feat).to(dev()))[1]
+    ref = c_oracle.splat_forward(pts, feat, S, radius_px=1.5, K=8, bg_ksize=ksize)
+    assert np.array_equal(bg.cpu().numpy(), ref["bg"])
+    assert 0.005 < ref["bg"].mean() < 0.995
+
+
 @pytest.mark.parametrize("acc,tau,tol", [("wsum", 1.0, 1e-5), ("wsumnorm", 1.0, 1e-6), ("alphacomposite", 0.5, 1e-5),
                                          ("wsumnorm", 2.0, 1e-5)])
 def test_accumulation_modes(acc, tau, tol):
