@@ -232,60 +232,32 @@ def measure_roofline(model, d, out, V, live_pmc=False):
     launches, total_ms, fpc = ctypes.c_int(0), ctypes.c_float(0.0), ctypes.c_double(0.0)
     us_list = []
     byref = lambda v: ctypes.cast(ctypes.byref(v), ctypes.c_void_p)
-    deep = pipelined and model.pipe_depth(V) != 2
-    if deep:
-        # more than two batches in flight (small batches: z_buffermodel.pipe_depth): the column launches of steady-state steps as the
-        # timed region runs them, event-timed through the engine's launch profile (ps_pixelcnn_profile_begin / _end)
+    if pipelined:
+        # The column launches of steady-state steps as the timed region runs them (several batches in flight, every launch as full as they
+        # make it: z_buffermodel.outpaint_pipelined), event-timed through the engine's launch profile (ps_pixelcnn_profile_begin / _end):
+        # a long run minus a short one -- the pipeline's fill and the flush cancel.
         eng = model.outpaint2.engine(32, 32, model.pipe_frames(V))
         frames = getattr(plan, "waves_frames", None) if model.PER_FRAME_PREFIX else None
         ncols = int((frames[0] if frames is not None else cols).shape[0])
-        nst = 8
+        n_short, n_long = 4, 12
+        n_launch = 0
         for _ in range(3):
             run_steps(model, d, 1, 2, side_stream())
             torch.cuda.synchronize()
-            eng.profile_begin()
-            try:
-                run_steps(model, d, 1, nst, side_stream())
-            finally:
-                prof = eng.profile_end()
-            n_launch = sum(v[0] for k, v in prof.items() if k.startswith("k_column"))
-            us_list.append(sum(v[1] for k, v in prof.items() if k.startswith("k_column")) * 1e3 / max(1, n_launch))
-        launches.value = int(round(n_launch / nst))
+            profs = []
+            for n_ in (n_short, n_long):
+                eng.profile_begin()
+                try:
+                    run_steps(model, d, 1, n_, side_stream())
+                finally:
+                    profs.append(eng.profile_end())
+            n_launch = sum(profs[1][k][0] - profs[0][k][0] for k in profs[1] if k.startswith("k_column"))
+            ms = sum(profs[1][k][1] - profs[0][k][1] for k in profs[1] if k.startswith("k_column"))
+            us_list.append(ms * 1e3 / max(1, n_launch))
+        launches.value = int(round(n_launch / (n_long - n_short)))
         fpc.value = 10424320.0
         n_wavefronts = launches.value
-    elif pipelined:
-        # The column launches of ONE STEADY-STATE STEP of the pipelined form: the tail wavefronts of one batch inside the launches of
-        # the next batch's head wavefronts.  Timed inside a two-batch run of the same views in a 2 V-frame handle (batch B = batch A):
-        # head A | tail A + head B | tail B -- only the middle section's launches count: exactly one batch's columns.
-        from pixelsynth_amd.lmconv.model import merge_schedules, split_tail
-        eng = model.outpaint2.engine(32, 32, 2 * V)
-        frames = getattr(plan, "waves_frames", None) if model.PER_FRAME_PREFIX else None   # per-frame prefixes: their own schedule
-        hc, ws = (frames[0].cpu().numpy(), frames[1]) if frames is not None else (plan.waves_host, plan.waves[1])
-        ncols = int(hc.shape[0])
-        cut = split_tail(ws, model.pipe_merge_max())
-        off = np.array([V, 0], np.int32)
-        from pixelsynth_amd.lmconv.model import launch_capacity
-        cut = split_tail(ws, min(model.pipe_merge_max(), launch_capacity(V) * 45 // 64))
-        mid_c, mid_w = merge_schedules(hc[ws[cut]:], ws[cut:] - ws[cut], hc[:ws[cut]] + off, ws[:cut + 1], min(model.PIPE_CAP, launch_capacity(V)))
-        all_c = np.ascontiguousarray(np.concatenate([hc[:ws[cut]], mid_c, hc[ws[cut]:] + off]), np.int32)
-        all_w = np.ascontiguousarray(np.concatenate([ws[:cut + 1], ws[cut] + mid_w[1:], ws[cut] + mid_w[-1] + (ws[cut + 1:] - ws[cut])]), np.int32)
-        assert all_w[-1] == 2 * ncols and mid_w[-1] == ncols
-        dcols = torch.from_numpy(all_c).to(d["codes"].device)
-        two = lambda t: torch.cat([t, t]).contiguous()
-        arrs = [two(plan.order_loc), two(plan.region), two(plan.mask_init), two(plan.mask_undilated), two(plan.mask_dilated), two(d["uniforms"])]
-        w0, w1 = cut, cut + len(mid_w) - 1
-        fs_dev = two(plan.first_steps_dev) if frames is not None else None
-        fs_max = int(plan.first_steps.max()) if frames is not None else -1
-        for _ in range(3):
-            c32 = two(d["codes"].reshape(V, 1024).to(torch.int32))
-            rc = _lib.lib().ps_pixelcnn_time_ar_run_waves_range(
-                eng.handle, _lib.ptr(c32), *[_lib.ptr(a) for a in arrs[:5]], _lib.ptr(arrs[5]), 0.7, 2 * V, plan.first_step,
-                _lib.ptr(dcols), _lib.ptr(all_w), len(all_w) - 1, w0, w1, _lib.ptr(fs_dev), fs_max, byref(launches), byref(total_ms),
-                byref(fpc), _lib.current_stream())
-            _lib.check(rc, "ps_pixelcnn_time_ar_run_waves_range")
-            us_list.append(total_ms.value * 1e3 / max(1, launches.value))
-        assert torch.equal(c32[:V], c32[V:])     # (the staggered batch drew what the other did)
-        n_wavefronts = len(mid_w) - 1
+        launches_exact = n_launch / (n_long - n_short)
     else:
         eng = model.outpaint2.engine(32, 32, V)
         for _ in range(3):
@@ -298,7 +270,7 @@ def measure_roofline(model, d, out, V, live_pmc=False):
             us_list.append(total_ms.value * 1e3 / max(1, launches.value))
         n_wavefronts = len(wave_start) - 1
     us = sorted(us_list)[1]
-    cols_per_launch = ncols / max(1, launches.value)
+    cols_per_launch = ncols / max(1e-9, launches_exact if pipelined else launches.value)
     fl = fpc.value * cols_per_launch
     tf = fl / (us * 1e-6) / 1e12
     traffic, traffic_src, mfma_util, kernel_table = None, None, None, None
@@ -316,8 +288,9 @@ def measure_roofline(model, d, out, V, live_pmc=False):
               "16-column MFMA chain tiles + one wave per neighbour item, the neighbour role a launch ahead of the chain tiles; "
               "wavefronts of up to 256 columns as two launches of the latency form k_column_la -- the average is over all "
               "column launches of the AR run"
-              + ("; the AR runs of consecutive steps overlap -- the narrow last wavefronts of a batch run inside the launches of the next "
-                 "batch's first ones (z_buffermodel.outpaint_pipelined): the launches timed are those of one steady-state step)" if pipelined else ")")
+              + ("; the AR runs of consecutive steps share their launches -- up to four batches in flight, every launch taking what is left of "
+                 "each batch's current wavefront (z_buffermodel.outpaint_pipelined, lmconv.model.pack_launches): the launches timed are those "
+                 "of steady-state steps)" if pipelined else ")")
               if tp else
               "k_column (one launch per wavefront of independent AR columns: per-column centre-tap chains + "
               "neighbour-tap slots of all 32 masked convs)")
@@ -1056,10 +1029,10 @@ def main():
                        "parallelism": f"views sharded over {world} GPU(s), RCCL all_gather of the reprojected views (8-bit) + completed code grids",
                        "step_pipeline": "the AR run on one stream, its whole-grid prefix pass dealt to two frame ranges on two streams; the host half of "
                                         "step i + 1 (splat, planning, uploads) on a side stream"
-                                        + ("; the narrow last wavefronts of step i's AR run inside the launches of step i + 1's first wavefronts (both "
-                                           "batches resident in one engine handle; the timed region ends with the last step's tail flushed: exactly "
-                                           "`steps` complete steps); the whole-grid pass takes every frame up to ITS first sampled position "
-                                           "(per-frame prefixes), the columns start there" if ar_pipelined(V) else "")},
+                                        + ("; up to four steps' AR runs in flight in one engine handle, every column launch taking what is left of each "
+                                           "batch's current wavefront (the timed region ends with everything flushed: exactly `steps` complete steps); "
+                                           "the whole-grid pass takes every frame up to ITS first sampled position (per-frame prefixes), the columns "
+                                           "start there" if ar_pipelined(V) else "")},
         }
         # which library and which switches produced the number: a tuning / trace / experiment build (PS_HIP_LIB=...) says so itself
         res["library"] = {"path": os.path.relpath(_lib.LIB_PATH, os.path.dirname(os.path.abspath(__file__))), "build": _lib.lib().ps_build_info().decode(),

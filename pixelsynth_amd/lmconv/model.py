@@ -439,7 +439,7 @@ def wavefronts(order_host, H, W, first_step, device=None, max_cols=None, keep_ho
     """Wavefront schedule of an AR run (ps_ar_wavefronts_capped): order_host (F,L) int32 numpy array ->
     (cols int32 (n,2) tensor on `device`, wave_start int32 numpy array of n_waves + 1 entries).
     max_cols: columns per wave (0 = the pure dependency levels; None = what a launch takes for this many frames).
-    keep_host: a third value, the (n,2) columns as a numpy array of the caller's own (split_tail / merge_schedules work on it).
+    keep_host: a third value, the (n,2) columns as a numpy array of the caller's own (schedule surgery on the host).
     first_steps: (F,) int32 numpy array, a first walked position PER FRAME (ps_ar_wavefronts_frames; first_step = their minimum)."""
     import ctypes
     order_host = np.ascontiguousarray(order_host, np.int32)
@@ -450,75 +450,41 @@ def wavefronts(order_host, H, W, first_step, device=None, max_cols=None, keep_ho
         return _wavefronts(order_host, F_, L, H, W, first_step, device, max_cols, keep_host, first_steps)
 
 
-def split_tail(wave_start, merge_max):
-    """Where the TAIL of a wavefront schedule starts: the first wave behind the widest one from which on every wave has at most
-    merge_max columns (len(wave_start) - 1 = no tail).  A batch's waves grow to the launch capacity and shrink to a handful of columns
-    (C5: 392 ... 1024 x 22 ... 544, 464, ... 16, 8): the narrow last ones cost a launch each for next to no work -- a pipelined caller
-    leaves them for the launches of the NEXT batch's first waves (merge_schedules, z_buffermodel.outpaint_pipelined)."""
-    sizes = np.diff(wave_start)
-    n = len(sizes)
-    if n == 0:
-        return 0
-    s = n
-    while s > 0 and sizes[s - 1] <= merge_max:
-        s -= 1
-    return max(s, n - int(np.argmax(sizes[::-1])))   # (behind the LAST of the widest waves)
-
-
-def merge_schedules(tail_cols, tail_start, head_cols, head_start, cap):
-    """One schedule out of the TAIL waves of one batch and the HEAD waves of the next (frame indices already those of the shared
-    handle): launch j holds head wave j and, while there are any, as many columns of the current tail wave as fit under `cap` (the
-    columns of a wave are independent: a wave may be dealt to several launches; the NEXT tail wave starts in the launch after the one
-    that took the last of this one) -- each batch's waves keep their order, so every dependency is met.  Tail columns left over when
-    the head runs out follow as launches of their own.
-    The columns as numpy arrays or as (device) tensors -> (cols (n,2) int32 of the same kind, wave_start int32 numpy)."""
-    nt, nh = len(tail_start) - 1, len(head_start) - 1
-    parts, starts, total = [], [0], 0
-    t, at = 0, int(tail_start[0]) if nt else 0          # the current tail wave and how far it has been dealt
-    for j in range(nh):
-        a, b = int(head_start[j]), int(head_start[j + 1])
-        parts.append(head_cols[a:b])
-        total += b - a
-        if t < nt:
-            k = min(cap - (b - a), int(tail_start[t + 1]) - at)
-            if k > 0:
-                parts.append(tail_cols[at:at + k])
-                total += k
-                at += k
-            if at == int(tail_start[t + 1]):
-                t += 1
+def pack_launches(batches, cap, until_oldest_done=True, budget=None):
+    """Launch after launch out of the batches in flight (round 6; z_buffermodel.outpaint_pipelined): `batches`, OLDEST FIRST, are dicts
+    with 'ws' (a schedule's wave boundaries, numpy), 'w' (the wave the batch stands at) and 'off' (columns of that wave already
+    launched) -- advanced in place.  A launch takes, from the oldest batch on, what is left of each batch's CURRENT wave while there is
+    room under `cap` (the columns of a wave are independent: a wave may be dealt to several launches); a batch moves on to its next wave
+    only in the launch AFTER the one that took the last of the current one, so every batch's waves keep their order and every
+    dependency is met -- and a launch is as full as the batches in flight can make it (the older scheme cut every schedule into
+    `depth` parts and merged part p of the batch p calls ago: 44-50 launches per step where 33 hold the columns).
+    Stops when the batch that was oldest at the start is complete (until_oldest_done), after `budget` launches, or when nothing is left.
+    -> (slices, starts): slices = [(index into `batches`, begin, end)] column ranges in launch order, starts = launch boundaries."""
+    slices, starts, total, n = [], [0], 0, 0
+    live = [k for k, b in enumerate(batches) if b["w"] < len(b["ws"]) - 1]
+    oldest = live[0] if live else None
+    while live and (budget is None or n < budget) and not (until_oldest_done and budget is None and oldest not in live):
+        room, adv = cap, []
+        for k in live:
+            b = batches[k]
+            if room == 0:
+                break          # (the younger batches wait)
+            a0 = int(b["ws"][b["w"]]) + b["off"]
+            take = min(room, int(b["ws"][b["w"] + 1]) - a0)
+            if take > 0:
+                slices.append((k, a0, a0 + take))
+                total += take
+                room -= take
+                b["off"] += take
+            if a0 + take == int(b["ws"][b["w"] + 1]):
+                adv.append(k)
+        for k in adv:
+            batches[k]["w"] += 1
+            batches[k]["off"] = 0
+        live = [k for k in live if batches[k]["w"] < len(batches[k]["ws"]) - 1]
         starts.append(total)
-    while t < nt:
-        parts.append(tail_cols[at:int(tail_start[t + 1])])
-        total += int(tail_start[t + 1]) - at
-        starts.append(total)
-        t += 1
-        at = int(tail_start[t]) if t < nt else at
-    if torch.is_tensor(head_cols):    # (device tensors: one concatenation on the device)
-        cols = torch.cat(parts) if parts else head_cols[:0]
-    else:
-        cols = np.ascontiguousarray(np.concatenate(parts) if parts else np.zeros((0, 2), np.int32), np.int32)
-    return cols, np.asarray(starts, np.int32)
-
-
-def split_parts(wave_start, depth, merge_max):
-    """Wave indices [b_0 = 0, ..., b_depth = n] at which a schedule of n waves is cut into `depth` consecutive parts for
-    z_buffermodel.outpaint_pipelined: two parts = head and tail (split_tail: the narrow waves behind the widest one), more = equal
-    numbers of waves."""
-    n = len(wave_start) - 1
-    if depth == 2:
-        return [0, split_tail(wave_start, merge_max), n]
-    return [(n * p + depth // 2) // depth for p in range(depth + 1)]
-
-
-def fold_schedules(parts, cap):
-    """One schedule out of the current parts of several batches in flight, OLDEST FIRST (each (cols, wave_start), frame indices already
-    those of the shared handle): merge_schedules folded from the oldest on -- launch j holds wave j of the newest batch's part and as many
-    columns of the older batches' current waves as fit under `cap`; every batch's waves keep their order.  -> (cols, wave_start) or None."""
-    merged = None
-    for cols, ws in parts:
-        merged = (cols, ws) if merged is None else merge_schedules(merged[0], merged[1], cols, ws, cap)
-    return merged
+        n += 1
+    return slices, np.asarray(starts, np.int32)
 
 
 def _wavefronts(order_host, F_, L, H, W, first_step, device, max_cols, keep_host=False, first_steps=None):

@@ -396,27 +396,19 @@ class ZbufferModelPts(nn.Module):
         return planned
 
     # ---------------------------------------------------------------- the AR runs of consecutive batches, overlapped
-    PIPE_MERGE_MAX = 720    # wavefronts of at most this many columns behind a schedule's widest are left for the next batch's launches (PS_PIPE_MERGE_MAX, read per call: pipe_merge_max)
     PIPE_CAP = 1024         # columns a merged launch takes (lmconv.model.COLUMNS_PER_LAUNCH_TP)
     PER_FRAME_PREFIX = True  # outpaint_pipelined: per-frame prefixes where the plan carries their schedule (build_ar_plan, PS_PER_FRAME_PREFIX)
-    PIPE_DEPTH_SMALL = 4    # batches in flight for batches of fewer than PIPE_DEEP_BELOW views: their wavefronts leave a launch far from
-    PIPE_DEEP_BELOW = 96    # full (64 views: waves of 300-500 columns in launches that take 1024; 16 views: ~50 in launches of the latency
-    #                         form, which cost their 33 dependent stages whatever they hold up to 128), so four batches share the launches
-    #                         (round 6: C4's 64-frame circle on one GPU 8.8 -> 6.9 ms per step, 16 views 4.2 -> 4.0); from C5's 128 views on
-    #                         the waves reach the capacity by themselves and a launch is bound by its columns: two in flight (12.45 ms
-    #                         per step with two, 12.69 with three, 12.44 with four)
+    PIPE_DEPTH = 4          # batches outpaint_pipelined keeps in flight at most: every launch takes what is left of each batch's current
+    #                         wavefront, oldest batch first, while there is room (lmconv.model.pack_launches) -- with three to four in
+    #                         flight the launches are full whatever the batch size (C5's 128 views: 33 launches of ~1 020 columns per step
+    #                         where head / tail merging ran 45 of 750; 16 views: 33 of 128 where equal parts ran 44)
 
     def pipe_depth(self, V):
-        """Batches of V views that outpaint_pipelined keeps in flight (PS_PIPE_DEPTH overrides): a batch's schedule is cut into that many
-        consecutive parts, and a call runs part p of the batch p calls ago, all in the same launches; a batch's result comes back
-        depth - 1 calls late."""
+        """Batches of V views that outpaint_pipelined keeps in flight at most (PS_PIPE_DEPTH overrides): the frames of its engine handle
+        are that many batches'; a batch's result comes back at most depth - 1 calls late."""
         import os
         d = os.environ.get("PS_PIPE_DEPTH")
-        return max(2, min(8, int(d))) if d else (2 if V >= self.PIPE_DEEP_BELOW else self.PIPE_DEPTH_SMALL)
-
-    def pipe_merge_max(self):
-        import os
-        return int(os.environ.get("PS_PIPE_MERGE_MAX", self.PIPE_MERGE_MAX))
+        return max(2, min(8, int(d))) if d else self.PIPE_DEPTH
 
     def pipe_frames(self, V):
         """Frames of the engine handle outpaint_pipelined runs batches of V views in."""
@@ -437,7 +429,7 @@ class ZbufferModelPts(nn.Module):
             L = self.obs[1] * self.obs[2]
             z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=device)
             st = self.__dict__["_pipe"] = dict(
-                V=V, depth=D, device=device, slot=0, inflight=[], done=[], codes=z((D * V, L), torch.int32), order=z((D * V, L), torch.int32),
+                V=V, depth=D, device=device, inflight=[], done=[], seq=0, next_out=0, codes=z((D * V, L), torch.int32), order=z((D * V, L), torch.int32),
                 region=z((D * V, L), torch.uint8), masks=[z((D * V, 9, L), torch.float32) for _ in range(3)],
                 uniforms=z((D * V, L), torch.float32), first_steps=z((D * V,), torch.int32),
                 offset=[torch.tensor([k * V, 0], dtype=torch.int32, device=device) for k in range(D)])
@@ -446,15 +438,16 @@ class ZbufferModelPts(nn.Module):
 
     @torch.no_grad()
     def outpaint_pipelined(self, planned, codes, temperature=0.7, uniforms=None, between=None):
-        """outpaint_planned for callers with a STREAM of batches of V views (bench.py, driver.py): the narrow last wavefronts of a
-        batch's AR run -- a launch each for a few hundred columns down to eight, 1.5 of C5's 10.3 ms of column launches -- are not run
-        with their batch but inside the launches of the NEXT batch's first wavefronts (merge_schedules: the batches are resident in
-        one handle of pipe_frames(V) frames; every column still runs behind the columns it reads, so the codes are those of
-        outpaint_planned, bit for bit -- tests/test_zbuffermodel_gpu.py).  Small batches, whose launches are bound by their latency,
-        are cut into pipe_depth(V) parts and as many batches share a launch.  Asynchronous on the current stream.
-        -> the dict (codes added) of the oldest batch that is complete and has not been handed back yet -- in the steady state the batch
-        of pipe_depth(V) - 1 calls ago -- or None; outpaint_flush() runs what is left.  between: as for outpaint_planned."""
-        from .lmconv.model import launch_capacity, split_parts
+        """outpaint_planned for callers with a STREAM of batches of V views (bench.py, driver.py).  A batch's wavefronts grow to the
+        launch capacity and shrink to a handful of columns, and a launch costs its 33 dependent stages whatever it holds: up to
+        pipe_depth(V) batches are resident in ONE engine handle of pipe_frames(V) frames, and every column launch takes what is left of
+        each batch's current wavefront, oldest batch first, while there is room (lmconv.model.pack_launches) -- C5's 128 views: 33
+        launches of ~1 020 columns per step instead of 45 of 750 (head / tail merging of two batches, round 5) or 91 of a batch alone.
+        Every column still runs behind the columns it reads (a batch moves on to its next wavefront only in the launch after the one
+        that took the last of the current one), so the codes are outpaint_planned's, bit for bit (tests/test_zbuffermodel_gpu.py,
+        tests/test_config_size_gpu.py).  Asynchronous on the current stream.
+        -> the dict (codes added) of the next batch, in submission order, that is complete -- at most pipe_depth(V) - 1 calls late -- or
+        None; outpaint_flush() runs what is left.  between: as for outpaint_planned."""
         gen_fs, plan = planned["gen_fs"], planned["plan"]
         V, G = gen_fs.shape[0], self.obs[1]
         L = G * self.obs[2]
@@ -469,9 +462,8 @@ class ZbufferModelPts(nn.Module):
         if st["inflight"] and st["inflight"][0]["temperature"] != temperature:
             # what is in flight was planned with ANOTHER temperature: it cannot ride in this batch's launches (a launch has one
             # temperature), so it is finished now, as launches of its own, with its own -- the codes stay those of outpaint_planned
-            while st["inflight"]:
-                self._pipe_step(eng, st, args, V)
-        h = st["slot"]
+            self._pipe_step(eng, st, args, V, drain=True)
+        h = min(set(range(D)) - {b["slot"] for b in st["inflight"]})      # a share of the handle nobody in flight lives in
         lo, hi = h * V, (h + 1) * V
         # (as elementwise kernels, not Tensor.copy_: same-type copies go through hipMemcpyAsync, which on the stream of the AR run stalled
         # for ~60 ms every few steps)
@@ -509,31 +501,48 @@ class ZbufferModelPts(nn.Module):
                 main.wait_stream(side)
         if between is not None:
             between()
-        # this batch's schedule, in the handle's frame numbering, cut into `depth` consecutive parts: the first runs now, part p with the
-        # p-th batch from now.  The columns are on the device already (the plan's upload); the merged schedule is put together THERE,
-        # launch by launch, from slices of the batches' columns (one concatenation) -- nothing crosses PCIe on the stream of the AR run.
-        ws = waves[1]
+        # this batch's schedule, in the handle's frame numbering, joins the batches in flight.  The columns are on the device already (the
+        # plan's upload); a call's launches are put together THERE, from slices of the batches' columns (one concatenation) -- nothing
+        # crosses PCIe on the stream of the AR run.
+        ws = np.asarray(waves[1])
         dcols = waves[0] + st["offset"][h] if h else waves[0]
-        # (two in flight: head / tail, the tail = the narrow last waves behind the widest one; more: equal numbers of waves)
-        bounds = split_parts(ws, D, min(self.pipe_merge_max(), launch_capacity(V) * 45 // 64))
-        parts = [(dcols[ws[a]:ws[b]], ws[a:b + 1] - ws[a]) for a, b in zip(bounds[:-1], bounds[1:])]
-        st["inflight"].append(dict(planned=planned, parts=parts, first_step=plan.first_step, slot=h, temperature=temperature))
-        st["slot"] = (h + 1) % D
+        st["inflight"].append(dict(planned=planned, cols=dcols, ws=ws, w=0, off=0, first_step=plan.first_step, slot=h, temperature=temperature,
+                                   seq=st["seq"]))
+        st["seq"] += 1
         self._pipe_step(eng, st, args, V)
-        return st["done"].pop(0) if st["done"] else None
+        return self._pipe_pop(st)
 
-    def _pipe_step(self, eng, st, args, V):
-        """One set of merged launches: the next part of every batch in flight, oldest first -- launch j holds wave j of the newest
-        batch's part and, folded in from the oldest on, as many columns of the older batches' current waves as fit (merge_schedules).
-        Batches whose last part this was are complete: their codes are taken out of the handle behind the launches."""
-        from .lmconv.model import fold_schedules, launch_capacity
-        first = min((b["first_step"] for b in st["inflight"]), default=None)
-        merged = fold_schedules([b["parts"].pop(0) for b in st["inflight"]], min(self.PIPE_CAP, launch_capacity(V)))
-        if merged is not None:
-            self._pipe_columns(eng, st, args, merged[0], merged[1], first, st["inflight"][0]["temperature"])
-        finished = [b for b in st["inflight"] if not b["parts"]]
-        st["inflight"] = [b for b in st["inflight"] if b["parts"]]
-        st["done"] += [self._pipe_done(st, b) for b in finished]
+    @staticmethod
+    def _pipe_pop(st):
+        """The next batch in SUBMISSION order, if it is complete (a short batch may be through before an older, longer one: it waits)."""
+        if st["done"] and st["done"][0][0] == st["next_out"]:
+            st["next_out"] += 1
+            return st["done"].pop(0)[1]
+        return None
+
+    def _pipe_step(self, eng, st, args, V, drain=False):
+        """One call's launches out of the batches in flight (lmconv.model.pack_launches: every launch takes what is left of each batch's
+        current wavefront, oldest first, under the launch capacity).  With the handle full -- `depth` batches in flight -- launches run
+        until the oldest batch is complete (one batch in, one out: the steady state); while it fills, a `depth`-th of the new batch's
+        wavefronts' worth; drain: until nothing is left.  Batches whose last column has been queued are complete: their codes are
+        taken out of the handle behind the launches."""
+        from .lmconv.model import launch_capacity, pack_launches
+        infl = st["inflight"]
+        cap = min(self.PIPE_CAP, launch_capacity(V))
+        while infl:
+            first = min(b["first_step"] for b in infl)
+            temperature = infl[0]["temperature"]
+            full = len(infl) >= st["depth"]
+            slices, starts = pack_launches(infl, cap, until_oldest_done=True,
+                                           budget=None if (drain or full) else -(-(len(infl[-1]["ws"]) - 1) // st["depth"]))
+            if slices:
+                cols = torch.cat([infl[k]["cols"][a:b] for k, a, b in slices])
+                self._pipe_columns(eng, st, args, cols, starts, first, temperature)
+            finished = [b for b in infl if b["w"] >= len(b["ws"]) - 1]
+            infl[:] = [b for b in infl if b["w"] < len(b["ws"]) - 1]
+            st["done"] = sorted(st["done"] + [(b["seq"], self._pipe_done(st, b)) for b in finished], key=lambda t: t[0])
+            if not drain:
+                break
 
     def _pipe_columns(self, eng, st, args, cols, ws, first, temperature):
         if len(ws) > 1 and ws[-1] > 0:
@@ -557,9 +566,9 @@ class ZbufferModelPts(nn.Module):
         if st["inflight"]:
             eng = self.outpaint2.engine(self.obs[1], self.obs[2], st["depth"] * st["V"])
             args = (st["codes"], st["order"], st["region"], st["masks"][0], st["masks"][1], st["masks"][2])
-            while st["inflight"]:
-                self._pipe_step(eng, st, args, st["V"])
-        out, st["done"] = st["done"], []
+            self._pipe_step(eng, st, args, st["V"], drain=True)
+        out, st["done"] = [d for _, d in st["done"]], []
+        st["next_out"] = st["seq"]
         return out
 
     def outpaint_reset(self):
@@ -569,7 +578,7 @@ class ZbufferModelPts(nn.Module):
         it on their way out of a failed run)."""
         st = self.__dict__.get("_pipe")
         if st is not None:
-            st["inflight"], st["done"] = [], []
+            st["inflight"], st["done"], st["next_out"] = [], [], st["seq"]
 
     PREFIX_SPLIT_MIN_VIEWS = 64   # below this a launch of half the frames no longer fills the chip
     PREFIX_STREAMS = 2            # 128 views: 18.16 -> 17.95 ms per step (three alternating pairs); 4 ranges lose (18.59)

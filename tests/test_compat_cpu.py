@@ -119,43 +119,6 @@ def test_rank_samples_follows_the_reference_rule():
     assert rank_samples([0.1, 0.9], [2.0, 1.0]) == 1     # highest discriminator score and lowest entropy wins
 
 
-def test_split_tail_and_merge_schedules_keep_every_wave_in_order():
-    """The schedule surgery of the pipelined AR runs (lmconv.model.split_tail / merge_schedules): the tail starts behind the widest
-    wave where the waves have shrunk for good; a merged schedule holds every column of both parts once, a launch takes a tail wave only
-    if it fits under the cap, and each part's waves keep their order."""
-    from pixelsynth_amd.lmconv.model import merge_schedules, split_tail
-    sizes = [392, 384, 472, 700, 1024, 1024, 1016, 600, 610, 544, 464, 300, 16, 8]
-    ws = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
-    cut = split_tail(ws, 560)
-    assert cut == 9 and split_tail(ws, 4) == len(sizes) and split_tail(ws, 2000) == 6     # behind 610 / no tail / right behind the peak
-    assert split_tail(np.array([0], np.int32), 560) == 0
-    cols = np.stack([np.repeat(np.arange(len(sizes)), sizes), np.arange(ws[-1])], 1).astype(np.int32)   # (wave, running number)
-    tail = (cols[ws[cut]:] + np.array([1000, 0], np.int32), ws[cut:] - ws[cut])
-    head = (cols[:ws[cut]], ws[:cut + 1])
-    mc, ms = merge_schedules(tail[0], tail[1], head[0], head[1], 1024)
-    assert ms[0] == 0 and ms[-1] == ws[-1] and len(ms) - 1 == cut                  # the tail's five waves found room in the head's launches
-    assert np.diff(ms).max() <= 1024
-    assert sorted(mc[:, 1].tolist()) == list(range(ws[-1]))                          # every column once
-    wave_of = np.repeat(np.arange(len(ms) - 1), np.diff(ms))
-    def in_order(cols_, starts_):     # every column of wave k runs in an earlier launch than any column of wave k + 1, in both parts
-        launch = np.repeat(np.arange(len(starts_) - 1), np.diff(starts_))
-        for part in (cols_[:, 0] < 1000, cols_[:, 0] >= 1000):
-            w, l = cols_[part, 0], launch[part]
-            ks = sorted(set(w.tolist()))
-            assert all(l[w == a].max() < l[w == b].min() for a, b in zip(ks, ks[1:]))
-    in_order(mc, ms)
-    # a tail wave wider than a launch's room is dealt to several launches (its columns are independent), the next one starts behind it
-    big = (np.concatenate([tail[0][:1].repeat(900, 0), tail[0]]), np.concatenate([[0], tail[1] + 900]).astype(np.int32))
-    big[0][:900, 0] = 999 + 1000      # (a wave of its own in front of the others, numbered below them)
-    big[0][:900, 1] = -1 - np.arange(900)
-    mc3, ms3 = merge_schedules(big[0], big[1], head[0], head[1], 1024)
-    assert np.diff(ms3).max() <= 1024 and ms3[-1] == ws[-1] + 900 and len(set(np.repeat(np.arange(len(ms3) - 1), np.diff(ms3))[mc3[:, 0] == 1999])) > 1
-    in_order(np.where(mc3[:, :1] == 1999, np.array([[1000, 0]], np.int32), mc3 + np.array([[1, 0]], np.int32) * (mc3[:, :1] >= 1000)), ms3)
-    # a head too short for the tail: the rest follows as launches of its own
-    mc2, ms2 = merge_schedules(tail[0], tail[1], head[0][:ws[2]], head[1][:3], 1024)
-    assert len(ms2) - 1 == 2 + (len(tail[1]) - 1) - 2 and ms2[-1] == ws[2] + tail[1][-1]
-
-
 def test_wavefronts_with_a_first_step_per_frame():
     """ps_ar_wavefronts_frames: a first walked position per frame.  With the same value for every frame it is ps_ar_wavefronts_capped;
     with different ones every frame's positions from its own first step on appear once, and a column runs in a later wave than every
