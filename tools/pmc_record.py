@@ -50,8 +50,9 @@ ntp, nla = pmc[tp]["FETCH_SIZE"][0], pmc[la]["FETCH_SIZE"][0]
 rec = {
     "kernel": f"k_column_tp ({ntp} dispatches) + k_column_la ({nla}: wavefronts of up to 256 columns as two latency-form launches)",
     "views": views,
-    "workload": "bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra (C5: 8 sources x 16 views = 128 views per GPU; 3 pipelined steps + "
-                "the 3 timed AR runs of measure_roofline -- two-batch runs when the AR runs of consecutive steps overlap)",
+    "workload": "PS_BENCH_PMC_CHILD=1 bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-extra (C5: 8 sources x 16 views = 128 views per GPU; the 7 "
+                "pipelined steps and nothing else -- the pipeline's fill and flush are in it: launches with fewer than four batches in flight are "
+                "narrower, which is where this record's k_column_la / k_column_tp8 dispatches come from)",
     "dispatches": ntp + nla,
     "FETCH_SIZE_KB_mean": round((pmc[tp]["FETCH_SIZE"][1] * ntp + pmc[la]["FETCH_SIZE"][1] * nla) / (ntp + nla), 3),
     "WRITE_SIZE_KB_mean": round((pmc[tp]["WRITE_SIZE"][1] * ntp + pmc[la]["WRITE_SIZE"][1] * nla) / (ntp + nla), 3),
