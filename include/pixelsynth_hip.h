@@ -397,6 +397,14 @@ size_t ps_conv3x3_f16x3_packed_bytes(int Co, int Ci);
 int ps_conv3x3_f16x3_pack(const float *w, int Co, int Ci, void *packed, void *stream);
 int ps_conv3x3_f16x3_nhwc(const float *x, const float *scale, const float *shift, const void *packed, const float *bias,
                           const float *res, int B, int H, int W, int Ci, int Co, float *y, int *overflow, void *stream);
+/* ps_conv3x3_f16x3_ex_nhwc: the same with a permutation folded into either end (the VQ-VAE's stride-2 layers, models/vqvae2/vqvae.py:107-161,
+ *   run as 3 x 3 convolutions over 2 x 2 blocks):  in_s2d != 0: x is (B, 2 H, 2 W, Ci / 4) and is read as its space-to-depth form
+ *   (B, H, W, Ci), channel (sy * 2 + sx) * Ci / 4 + c = pixel (2 y + sy, 2 x + sx) -- Ci / 4 a multiple of 32 (scale / shift stay (B, Ci));
+ *   out_d2s != 0: y is (B, 2 H, 2 W, Co / 4), written as the depth-to-space form of the (B, H, W, Co) result, channel
+ *   (py * 2 + px) * Co / 4 + c -> pixel (2 y + py, 2 x + px) -- Co / 4 a multiple of 64, res NULL. */
+int ps_conv3x3_f16x3_ex_nhwc(const float *x, const float *scale, const float *shift, const void *packed, const float *bias,
+                             const float *res, int B, int H, int W, int Ci, int Co, int in_s2d, int out_d2s, float *y, int *overflow,
+                             void *stream);
 
 /* ---- the decoder's two thin 3 x 3 convolutions (csrc/conv_thin.hip), fp32 FMAs, same contract as above (no bias; optional
  * act(x) = max(x * scale[b][c] - shift[b][c], 0) on the way in; zero padding 1, stride 1; NHWC):
@@ -412,6 +420,30 @@ int ps_conv3x3_thin_out_nhwc_f32(const float *x, const float *scale, const float
  * ps_conv3x3_f16x3_nhwc; `overflow` likewise).  Co = 64, W a multiple of 16; w [3][3][4][64]. */
 int ps_conv3x3_thin_in_f16x3_nhwc(const float *x, const float *scale, const float *shift, const float *w, int B, int H, int W,
                                   int Co, float *y, int *overflow, void *stream);
+
+/* ---- 1 x 1 convolutions (csrc/conv1x1.hip) on the fp32 matrix pipe: exact fp32 products, fp32 accumulation.
+ * ps_conv1x1_nhwc_f32: y (npix, Co) = x (npix, Ci) . w^T, w (Co, Ci) contiguous -- torch.nn.Conv2d(Ci, Co, 1) WITHOUT its bias on
+ *   channels-last activations, npix = B H W.  Ci in {4, 32, 64, 128, 256}, Co >= 1, ceil16(Co) * Ci <= 32768 (the weights stay in LDS);
+ *   buffers 16-byte aligned.  Replaces the projection branch of a ResNet_Block (models/layers/blocks.py:46-57) and the ResBlock /
+ *   quantize_conv_t projections of the VQ-VAE (models/vqvae2/vqvae.py:81-97, :262).
+ * ps_conv1x1_ex_nhwc_f32: the same with the passes around it folded in: x rows `ldx` floats apart (>= Ci, a multiple of 4: the first Ci
+ *   channels of a wider activation); flags bit 0: max(x, 0) on the way in; bias (Co) and res (npix, Co), each may be NULL, added on the
+ *   way out -- max(res, 0) instead of res with flags bit 1: y = act(x) . w^T + bias + res.  The tail of the VQ-VAE's ResBlock
+ *   (vqvae.py:81-97: ReLU, 1 x 1, + the in-place-ReLU'd input) in one launch.
+ * ps_conv1x1_takes: 1 when these take a (Co, Ci) weight, else 0. */
+int ps_conv1x1_takes(int Ci, int Co);
+int ps_conv1x1_nhwc_f32(const float *x, const float *w, size_t npix, int Ci, int Co, float *y, void *stream);
+int ps_conv1x1_ex_nhwc_f32(const float *x, int ldx, const float *w, const float *bias, const float *res, int flags, size_t npix, int Ci,
+                           int Co, float *y, void *stream);
+
+/* ---- the 3-channel ends of the VQ-VAE (csrc/vq_ends.hip; models/vqvae2/vqvae.py:107, :150), fp32 matrix pipe, exact fp32 products.
+ * ps_vq_stem_s2d_f32: Conv2d(3, 64, 4, stride 2, padding 1) of an image x (B, 3, H, W) NCHW, bias included, written in the
+ *   space-to-depth form the next layer reads: y (B, H / 4, W / 4, 256), channel (sy * 2 + sx) * 64 + co = output pixel (2 y + sy, 2 x + sx).
+ *   w (64, 3, 4, 4), bias (64); H a multiple of 4, W of 16.
+ * ps_vq_head_f32: image y (B, 3, 2 Hh, 2 Wh) NCHW = ConvTranspose2d(64, 3, 4, stride 2, padding 1)(relu(h)) + bias, h (B, Hh, Wh, 64)
+ *   channels-last; wt (64, 3, 4, 4) (torch's (in, out, kh, kw)), bias (3); Wh a multiple of 16. */
+int ps_vq_stem_s2d_f32(const float *x, const float *w, const float *bias, int B, int H, int W, float *y, void *stream);
+int ps_vq_head_f32(const float *h, const float *wt, const float *bias, int B, int Hh, int Wh, float *y, void *stream);
 
 #ifdef __cplusplus
 }

@@ -74,9 +74,15 @@ _PROTOS = {
     "ps_conv3x3_thin_in_nhwc_f32": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p, c_void_p]),
     "ps_conv3x3_thin_in_f16x3_nhwc": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p, c_void_p, c_void_p]),
     "ps_conv3x3_thin_out_nhwc_f32": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p, c_void_p]),
+    "ps_vq_stem_s2d_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "ps_vq_head_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "ps_conv1x1_takes": (c_int, [c_int, c_int]),
+    "ps_conv1x1_nhwc_f32": (c_int, [c_void_p, c_void_p, ctypes.c_size_t, c_int, c_int, c_void_p, c_void_p]),
+    "ps_conv1x1_ex_nhwc_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, ctypes.c_size_t, c_int, c_int, c_void_p, c_void_p]),
     "ps_conv3x3_f16x3_packed_bytes": (ctypes.c_size_t, [c_int, c_int]),
     "ps_conv3x3_f16x3_pack": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "ps_conv3x3_f16x3_nhwc": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p, c_void_p, c_void_p]),
+    "ps_conv3x3_f16x3_ex_nhwc": (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_void_p, c_void_p, c_void_p]),
     "ps_pixelcnn_time_column_step": (c_int, [c_void_p] * 6 + [c_int, c_int, c_int] + [c_void_p] * 5),
     "ps_pixelcnn_ar_step": (c_int, [c_void_p] * 6 + [c_int, c_int, c_int, c_void_p, c_void_p]),
 }

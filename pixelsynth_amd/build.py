@@ -27,6 +27,8 @@ UNITS = [
     ("nets.hip", ["-ffp-contract=off"]),
     ("conv_f16x3.hip", ["-ffp-contract=off", "-Wno-inline-asm"]),
     ("conv_thin.hip", ["-ffp-contract=off"]),
+    ("conv1x1.hip", ["-ffp-contract=off"]),
+    ("vq_ends.hip", ["-ffp-contract=off"]),
     ("host_order.cpp", []),
 ]
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]

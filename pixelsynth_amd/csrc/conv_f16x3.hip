@@ -93,6 +93,8 @@ struct ConvArgs {
     const float *res;      // (B, H, W, Co) or null: added to the results (the block's other branch)
     int *overflow;
     int H, W, Ci, Co, tiles_x, tiles_per_frame, ncb, nblocks;
+    int s2d_C;             // > 0: x is (B, 2 H, 2 W, s2d_C), read as its space-to-depth form (B, H, W, Ci = 4 s2d_C), channel (sy, sx, c)
+    int d2s_C;             // > 0: y is (B, 2 H, 2 W, d2s_C), written from the depth-to-space of (B, H, W, Co = 4 d2s_C), channel (py, px, c)
 };
 
 #if defined(PS_CONV_EXP) && (PS_CONV_EXP & 16)   // tuning build: shader cycles and 100 MHz ticks of every workgroup's first wave, summed
@@ -113,11 +115,14 @@ struct Item {
 // layers: the kernel is bound by its MFMA stream (with the fragment reads switched off it takes as long), and that stream by the
 // chip's power -- every SIMD issuing v_mfma_f32_32x32x16_f16 on random operands and nothing else holds 1.72 GHz = 1.77 PFLOP/s,
 // 0.71 of the nominal 2.5 (tools/mfma_f16_clock_probe.hip; 2.39 GHz on constant operands); this kernel reaches 1.1-1.3.
-template <bool FUSE> __global__ __launch_bounds__(NT) void k_conv3x3_f16x3(ConvArgs a)
+// PERM: the space-to-depth read / depth-to-space store of ps_conv3x3_f16x3_ex_nhwc compiled in (an instantiation of its own: the runtime
+// branches cost the plain form 1 % of the decoder's time).
+template <bool FUSE, bool PERM = false> __global__ __launch_bounds__(NT) void k_conv3x3_f16x3(ConvArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int H = a.H, W = a.W, Ci = a.Ci, nchunk = Ci / CK, G = nchunk * 9;
+    const int s2dC = PERM ? a.s2d_C : 0, d2sC = PERM ? a.d2s_C : 0;
     // block -> items: block b runs on XCD b % 8; an XCD takes a contiguous run of (tile, cb) pairs, cb fastest, so that neighbouring
     // patches and the two channel blocks of one patch meet in one L2; the XCD's workgroups deal that run among themselves
     const int xcd = blockIdx.x & 7, j0 = blockIdx.x >> 3, J = gridDim.x >> 3;
@@ -147,7 +152,7 @@ template <bool FUSE> __global__ __launch_bounds__(NT) void k_conv3x3_f16x3(ConvA
         for (int i = 0; i < NA; ++i) {
             const int p = s + 64 * i, pr = p / PW, pc = p - pr * PW, iy = it.ty0 + pr - 1, ix = it.tx0 + pc - 1;
             const bool ok = p < PP && iy >= 0 && iy < H && ix >= 0 && ix < W;
-            xoff[i] = ok ? (unsigned)((iy * W + ix) * Ci + 4 * c4) : 0u;
+            xoff[i] = ok ? (unsigned)((s2dC ? iy * W * Ci + ix * (Ci >> 1) : (iy * W + ix) * Ci) + 4 * c4) : 0u;
             valid = (valid & ~(1u << i)) | ((unsigned)ok << i);
         }
     };
@@ -155,8 +160,13 @@ template <bool FUSE> __global__ __launch_bounds__(NT) void k_conv3x3_f16x3(ConvA
     f32x4 ra[NA], rsc, rsh;
     int over = 0;
     auto fetch = [&](const Item &it, int c) {   // chunk c of the item's patch into registers (asynchronous)
+        int coff = c * CK;
+        if (s2dC) {   // chunk c of the space-to-depth channels = sub-position q of the 2 x 2 block, channels cc .. cc + 31 of the real tensor
+            const int q = coff / s2dC, cc = coff - q * s2dC;
+            coff = ((q >> 1) * 2 * W + (q & 1)) * s2dC + cc;
+        }
 #pragma unroll
-        for (int i = 0; i < NA; ++i) ra[i] = load16_async(it.xb + xoff[i] + c * CK);
+        for (int i = 0; i < NA; ++i) ra[i] = load16_async(it.xb + xoff[i] + coff);
         if (FUSE) {
             rsc = load16_async(a.scale + (size_t)it.b * Ci + c * CK + 4 * c4);
             rsh = load16_async(a.shift + (size_t)it.b * Ci + c * CK + 4 * c4);
@@ -210,7 +220,10 @@ template <bool FUSE> __global__ __launch_bounds__(NT) void k_conv3x3_f16x3(ConvA
     // D[row][col]: col = lane & 31 = channel, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) = pixel of the M tile
     auto store = [&](const Item &it) {
         const int co = it.cb * COT + chh * 64 + m;
-        const size_t base = ((size_t)it.b * H * W) * a.Co + co;
+        // depth-to-space on the way out: channel co = parity * d2s_C + c goes to pixel (2 oy + py, 2 ox + px), channel c (co and
+        // co + 32 share their parity: d2s_C is a multiple of 64)
+        const int par = d2sC ? co / d2sC : 0, py = par >> 1, px = par & 1;
+        const size_t base = ((size_t)it.b * H * W) * a.Co + (d2sC ? co - par * d2sC : co);
         float *yb = a.y + base;
         const bool ok0 = co < a.Co, ok1 = co + 32 < a.Co;   // (Co = 64: the block's upper half is padding)
         float b0 = 0.f, b1 = 0.f;
@@ -240,7 +253,7 @@ template <bool FUSE> __global__ __launch_bounds__(NT) void k_conv3x3_f16x3(ConvA
             for (int r = 0; r < 16; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * kb;
                 const int oy = it.ty0 + 4 * pg + 2 * mt + (row >> 4), ox = it.tx0 + (row & 15);
-                const size_t off = ((size_t)oy * W + ox) * a.Co;
+                const size_t off = d2sC ? ((size_t)(2 * oy + py) * (2 * W) + 2 * ox + px) * d2sC : ((size_t)oy * W + ox) * a.Co;
                 if (ok0) yb[off] = acc[mt][0][r] + b0 + rv[r][0];
                 if (ok1) yb[off + 32] = acc[mt][1][r] + b1 + rv[r][1];
             }
@@ -432,8 +445,17 @@ int ps_conv3x3_f16x3_pack(const float *w, int Co, int Ci, void *packed, void *st
 int ps_conv3x3_f16x3_nhwc(const float *x, const float *scale, const float *shift, const void *packed, const float *bias, const float *res,
                           int B, int H, int W, int Ci, int Co, float *y, int *overflow, void *stream)
 {
+    return ps_conv3x3_f16x3_ex_nhwc(x, scale, shift, packed, bias, res, B, H, W, Ci, Co, 0, 0, y, overflow, stream);
+}
+
+int ps_conv3x3_f16x3_ex_nhwc(const float *x, const float *scale, const float *shift, const void *packed, const float *bias, const float *res,
+                             int B, int H, int W, int Ci, int Co, int in_s2d, int out_d2s, float *y, int *overflow, void *stream)
+{
     using namespace psconv;
     PS_REQUIRE(x && packed && y && overflow, "conv3x3_f16x3: null pointer");
+    PS_REQUIRE(!in_s2d || (Ci % 4 == 0 && (Ci / 4) % CK == 0), "conv3x3_f16x3: space-to-depth input needs Ci / 4 a multiple of 32 (Ci = %d)", Ci);
+    PS_REQUIRE(!out_d2s || (Co % 4 == 0 && (Co / 4) % 64 == 0 && !res),
+               "conv3x3_f16x3: depth-to-space output needs Co / 4 a multiple of 64 and no res (Co = %d)", Co);
     PS_REQUIRE((scale == nullptr) == (shift == nullptr), "conv3x3_f16x3: scale and shift come together");
     PS_REQUIRE(B > 0 && H > 0 && W > 0 && H % TH == 0 && W % TW == 0, "conv3x3_f16x3: H and W multiples of 16 required (H = %d, W = %d)", H, W);
     PS_REQUIRE(Co > 0 && Co % 64 == 0 && Ci > 0 && Ci % CK == 0,
@@ -442,6 +464,7 @@ int ps_conv3x3_f16x3_nhwc(const float *x, const float *scale, const float *shift
     ConvArgs a;
     a.x = x; a.scale = scale; a.shift = shift; a.wp = (const char *)packed; a.y = y; a.bias = bias; a.res = res; a.overflow = overflow;
     a.H = H; a.W = W; a.Ci = Ci; a.Co = Co;
+    a.s2d_C = in_s2d ? Ci / 4 : 0; a.d2s_C = out_d2s ? Co / 4 : 0;
     a.tiles_x = W / TW; a.tiles_per_frame = (H / TH) * a.tiles_x; a.ncb = (Co + COT - 1) / COT;
     const size_t nb = (size_t)B * a.tiles_per_frame * a.ncb;
     PS_REQUIRE(nb < ((size_t)1 << 30), "conv3x3_f16x3: too many tiles");
@@ -450,7 +473,7 @@ int ps_conv3x3_f16x3_nhwc(const float *x, const float *scale, const float *shift
     // dynamic-LDS limit (a process may drive several GPUs, one per thread)
     constexpr int MAX_DEV = 64;
     static int cus_of[MAX_DEV] = {};
-    static bool attr_set[MAX_DEV][2] = {};
+    static bool attr_set[MAX_DEV][4] = {};
     int dev = 0;
     PS_HIP_CHECK(hipGetDevice(&dev));
     PS_REQUIRE(dev >= 0 && dev < MAX_DEV, "conv3x3_f16x3: device %d", dev);
@@ -467,19 +490,19 @@ int ps_conv3x3_f16x3_nhwc(const float *x, const float *scale, const float *shift
     }
     const int want = wgs < 0 ? cus : wgs == 0 ? (int)((nb + 7) / 8 * 8) : (wgs + 7) / 8 * 8;
     const int grid = (int)std::min<size_t>((size_t)want, (nb + 7) / 8 * 8);
-    if (scale) {
-        if (!attr_set[dev][1]) {
-            PS_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv3x3_f16x3<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
-            attr_set[dev][1] = true;
+    auto launch = [&](auto kernel, int slot) -> int {
+        if (!attr_set[dev][slot]) {
+            PS_HIP_CHECK(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
+            attr_set[dev][slot] = true;
         }
-        hipLaunchKernelGGL(k_conv3x3_f16x3<true>, dim3(grid), dim3(NT), LDS_TOTAL, (hipStream_t)stream, a);
-    } else {
-        if (!attr_set[dev][0]) {
-            PS_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv3x3_f16x3<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
-            attr_set[dev][0] = true;
-        }
-        hipLaunchKernelGGL(k_conv3x3_f16x3<false>, dim3(grid), dim3(NT), LDS_TOTAL, (hipStream_t)stream, a);
-    }
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(NT), LDS_TOTAL, (hipStream_t)stream, a);
+        return PS_OK;
+    };
+    const bool perm = a.s2d_C || a.d2s_C;
+    int rc;
+    if (scale) rc = perm ? launch(k_conv3x3_f16x3<true, true>, 3) : launch(k_conv3x3_f16x3<true, false>, 1);
+    else rc = perm ? launch(k_conv3x3_f16x3<false, true>, 2) : launch(k_conv3x3_f16x3<false, false>, 0);
+    if (rc != PS_OK) return rc;
     PS_LAUNCH_CHECK();
     return PS_OK;
 }

@@ -253,10 +253,42 @@ def _conv2d_batches(fn, x, out_channels, stride=1):
     return torch.cat([fn(x[i:i + n]) for i in range(0, B, n)])
 
 
-def _conv_split(conv, x):
+def conv1x1(conv, x):
+    """conv(x) WITHOUT the bias for a 1 x 1 convolution (stride 1, no padding) on a channels-last CUDA fp32 activation, through
+    csrc/conv1x1.hip (fp32 matrix pipe: exact fp32 products) -- or None when `conv` / `x` are not that (the caller goes through torch)."""
+    if not (type(conv) is nn.Conv2d and conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0)
+            and conv.dilation == (1, 1) and conv.groups == 1 and _is_nhwc_cuda(x) and not torch.is_grad_enabled()):
+        return None
+    from .. import _lib
+    L = _lib.lib()
+    Ci, Co = conv.in_channels, conv.out_channels
+    if not L.ps_conv1x1_takes(Ci, Co):
+        return None
+    weight = _plain_conv_weight(conv, x)
+    if weight is None or weight.dtype != torch.float32 or not weight.is_cuda or weight.device != x.device:
+        return None
+    key = (weight.data_ptr(), weight._version, str(weight.device))
+    cache = conv.__dict__.get("_ps_1x1_cache")
+    if cache is None or cache[0] != key:
+        cache = (key, weight.detach().reshape(Co, Ci).contiguous(), weight)       # (the weight is kept alive: its address is the key)
+        conv.__dict__["_ps_1x1_cache"] = cache
+    B, _, H, W = x.shape
+    y = _empty_nhwc(B, Co, H, W, x)
+    if Co == 1:   # (channels_last of one channel is ambiguous to torch; the kernel writes (B, H, W, Co))
+        y = torch.empty((B, H, W, Co), dtype=x.dtype, device=x.device).permute(0, 3, 1, 2)
+    _lib.check(L.ps_conv1x1_nhwc_f32(x.data_ptr(), cache[1].data_ptr(), B * H * W, Ci, Co, y.data_ptr(), _stream()), "ps_conv1x1_nhwc_f32")
+    return y
+
+
+def _conv_split(conv, x, mode=None):
     """conv(x) as (output WITHOUT the bias, bias) on the inference GPU path -- torch adds a convolution's bias in a pass
     of its own; here the per-channel constant rides along in whatever pass consumes the output (csrc/nets.hip).  Elsewhere
-    (CPU, autograd, channel counts the kernels do not take): (conv(x), None)."""
+    (CPU, autograd, channel counts the kernels do not take): (conv(x), None).  mode "f16x3": a 1 x 1 convolution through
+    csrc/conv1x1.hip instead of torch (MIOpen)."""
+    if mode == "f16x3":
+        y = conv1x1(conv, x)
+        if y is not None:
+            return y, conv.bias
     if conv.bias is None or torch.is_grad_enabled() or not _is_nhwc_cuda(x) or conv.out_channels % 4:
         return _conv2d_batches(conv, x, conv.out_channels, conv.stride[0]), None
     weight = _plain_conv_weight(conv, x)
@@ -510,10 +542,10 @@ class ResNet_Block(nn.Module):
                 and (self.ch_b[0].bias is None or (self.ch_b[0].out_channels % 4 == 0 and _plain_conv_weight(self.ch_b[0], x) is not None))):
             # Down: avg_pool2d and the 1 x 1 convolution of the other branch commute -- pool first, convolve a quarter of the pixels,
             # and hand the result to the pooling of this branch as its `post` term (both biases ride through the pooling: bias=)
-            b, bb = _conv_split(self.ch_b[0], _resample_sum(self.resample, x, None))
+            b, bb = _conv_split(self.ch_b[0], _resample_sum(self.resample, x, None), mode)
             a, ba2, _ = self._norm_relu_conv(self.ch_a[3], self.ch_a[5], a, noise[1], ba)
             return _resample_sum(self.resample, a, None, _sum_bias(ba2, bb), post=b)
-        b, bb = _conv_split(self.ch_b[0], x) if self.projected else (x, None)
+        b, bb = _conv_split(self.ch_b[0], x, mode) if self.projected else (x, None)
         # The second convolution adds the other branch on its way out where it can (resampling is linear: resample(a) + resample(b) =
         # resample(a + b)); without resampling the biases go in as well and its output is the block's.
         conv2 = self.ch_a[5]

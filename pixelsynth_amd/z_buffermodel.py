@@ -528,7 +528,7 @@ class ZbufferModelPts(nn.Module):
         taken out of the handle behind the launches."""
         from .lmconv.model import launch_capacity, pack_launches
         infl = st["inflight"]
-        cap = min(self.PIPE_CAP, launch_capacity(V))
+        cap = min(int(os.environ.get("PS_PIPE_CAP", self.PIPE_CAP)), self.PIPE_CAP, launch_capacity(V))
         while infl:
             first = min(b["first_step"] for b in infl)
             temperature = infl[0]["temperature"]

@@ -129,6 +129,63 @@ def test_conv3x3_on_the_fp16_pipe_against_an_fp64_convolution(B, H, W, Ci, Co, f
     assert e16 < 3e-6 and e16 < 10 * e32, (e16, e32)
 
 
+@pytest.mark.parametrize("B,H,W,C,Co,fuse", [(2, 16, 32, 64, 128, True), (1, 32, 16, 128, 64, True), (3, 16, 16, 32, 128, False)])
+def test_conv3x3_on_the_fp16_pipe_reads_space_to_depth_blocks_in_place(B, H, W, C, Co, fuse):
+    """ps_conv3x3_f16x3_ex_nhwc, in_s2d: x (B, 2 H, 2 W, C) read as its space-to-depth form (B, H, W, 4 C) -- a 4 x 4 stride-2 convolution as the
+    VQ-VAE runs it (vqvae.s2d_weight) against torch's strided layer in fp64, ReLU on the way in."""
+    from pixelsynth_amd import _lib
+    from pixelsynth_amd.vqvae2.vqvae import s2d_weight
+    L, st = _lib.lib(), torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(C + Co)
+    x = torch.randn(B, C, 2 * H, 2 * W, generator=g).to(DEV)
+    w = (torch.randn(Co, C, 4, 4, generator=g) / (4 * C ** 0.5)).to(DEV)
+    bias = torch.randn(Co, generator=g).to(DEV)
+    ref = torch.nn.functional.conv2d((torch.relu(x) if fuse else x).double(), w.double(), bias.double(), 2, 1)
+    wl = s2d_weight(w).permute(0, 2, 3, 1).contiguous()
+    packed = torch.empty(L.ps_conv3x3_f16x3_packed_bytes(Co, 4 * C), dtype=torch.uint8, device=DEV)
+    _lib.check(L.ps_conv3x3_f16x3_pack(wl.data_ptr(), Co, 4 * C, packed.data_ptr(), st), "pack")
+    xl = x.permute(0, 2, 3, 1).contiguous()
+    sc, sh = (torch.ones(B, 4 * C, device=DEV), torch.zeros(B, 4 * C, device=DEV)) if fuse else (None, None)
+    p = lambda t: None if t is None else t.data_ptr()
+    y = torch.full((B, H, W, Co), float("nan"), device=DEV)
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    _lib.check(L.ps_conv3x3_f16x3_ex_nhwc(xl.data_ptr(), p(sc), p(sh), packed.data_ptr(), bias.data_ptr(), None, B, H, W, 4 * C, Co, 1, 0,
+                                          y.data_ptr(), flag.data_ptr(), st), "conv")
+    err = (y.permute(0, 3, 1, 2).double() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 3e-6 and int(flag.item()) == 0, err
+    assert L.ps_conv3x3_f16x3_ex_nhwc(xl.data_ptr(), None, None, packed.data_ptr(), None, None, B, H, W, 64, Co, 1, 0, y.data_ptr(),
+                                      flag.data_ptr(), st) != 0                       # (Ci / 4 = 16: not a multiple of 32)
+
+
+@pytest.mark.parametrize("B,H,W,Ci,C,fuse", [(2, 16, 32, 64, 64, False), (1, 32, 32, 128, 64, True), (3, 16, 16, 32, 128, True)])
+def test_conv3x3_on_the_fp16_pipe_stores_depth_to_space(B, H, W, Ci, C, fuse):
+    """ps_conv3x3_f16x3_ex_nhwc, out_d2s: the (B, H, W, 4 C) result stored as (B, 2 H, 2 W, C) -- a 4 x 4 stride-2 TRANSPOSED convolution as the
+    VQ-VAE runs it (vqvae.convt_weight) against torch's layer in fp64."""
+    from pixelsynth_amd import _lib
+    from pixelsynth_amd.vqvae2.vqvae import convt_weight
+    L, st = _lib.lib(), torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(Ci + C)
+    x = torch.randn(B, Ci, H, W, generator=g).to(DEV)
+    wt = (torch.randn(Ci, C, 4, 4, generator=g) / (2 * Ci ** 0.5)).to(DEV)
+    bias = torch.randn(C, generator=g).to(DEV)
+    ref = torch.nn.functional.conv_transpose2d((torch.relu(x) if fuse else x).double(), wt.double(), bias.double(), 2, 1)
+    wl = convt_weight(wt).permute(0, 2, 3, 1).contiguous()
+    packed = torch.empty(L.ps_conv3x3_f16x3_packed_bytes(4 * C, Ci), dtype=torch.uint8, device=DEV)
+    _lib.check(L.ps_conv3x3_f16x3_pack(wl.data_ptr(), 4 * C, Ci, packed.data_ptr(), st), "pack")
+    xl = x.permute(0, 2, 3, 1).contiguous()
+    sc, sh = (torch.ones(B, Ci, device=DEV), torch.zeros(B, Ci, device=DEV)) if fuse else (None, None)
+    p = lambda t: None if t is None else t.data_ptr()
+    y = torch.full((B, 2 * H, 2 * W, C), float("nan"), device=DEV)
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    b4 = bias.repeat(4).contiguous()
+    _lib.check(L.ps_conv3x3_f16x3_ex_nhwc(xl.data_ptr(), p(sc), p(sh), packed.data_ptr(), b4.data_ptr(), None, B, H, W, Ci, 4 * C, 0, 1,
+                                          y.data_ptr(), flag.data_ptr(), st), "conv")
+    err = (y.permute(0, 3, 1, 2).double() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 3e-6 and int(flag.item()) == 0, err
+    assert L.ps_conv3x3_f16x3_ex_nhwc(xl.data_ptr(), None, None, packed.data_ptr(), None, y.data_ptr(), B, H, W, Ci, 4 * C, 0, 1, y.data_ptr(),
+                                      flag.data_ptr(), st) != 0                       # (res does not go with depth-to-space)
+
+
 @pytest.mark.parametrize("Co", [64, 128, 256])
 def test_conv3x3_on_the_fp16_pipe_adds_bias_and_the_other_branch_on_the_way_out(Co):
     """bias (Co) and res (B, H, W, Co): y = conv + bias + res, what a ResNet_Block's second convolution hands on (blocks.py:61-73);
@@ -280,6 +337,39 @@ def test_thin_convolutions_against_an_fp64_convolution(B, H, W, Ci, Co, fuse):
     assert err < 2e-6, err
     assert L.ps_conv3x3_thin_out_nhwc_f32(xl.data_ptr(), None, None, wl.data_ptr(), B, H, W, 32, 5, y.data_ptr(), st) != 0
     assert L.ps_conv3x3_thin_in_nhwc_f32(xl.data_ptr(), None, None, wl.data_ptr(), B, 12, W, 8, y.data_ptr(), st) != 0
+
+
+@pytest.mark.parametrize("B,H,W,Ci,Co", [(2, 16, 64, 4, 64), (3, 9, 31, 64, 128), (1, 64, 64, 128, 256), (2, 33, 17, 256, 128), (1, 128, 128, 128, 128),
+                                          (2, 40, 24, 128, 3), (3, 7, 5, 32, 128), (1, 32, 32, 128, 64), (1, 3, 3, 64, 1), (2, 5, 7, 32, 20)])
+def test_conv1x1_on_the_fp32_matrix_pipe_against_an_fp64_convolution(B, H, W, Ci, Co):
+    """csrc/conv1x1.hip: the projection branches of the decoder's blocks and the VQ-VAE's 1 x 1 layers (and neighbours in shape: pixel counts
+    that do not fill a workgroup's trip, output channels that do not fill a tile) against torch's convolution in fp64: within 2e-6 of the
+    output's largest magnitude (exact fp32 products, fp32 accumulation); through the module-level wrapper the decoder uses as well."""
+    from pixelsynth_amd import _lib
+    from pixelsynth_amd.networks import architectures as A
+    L, st = _lib.lib(), torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(5 * Ci + Co)
+    x = torch.randn(B, Ci, H, W, generator=g).to(DEV)
+    w = (torch.randn(Co, Ci, 1, 1, generator=g) / Ci ** 0.5).to(DEV)
+    ref = torch.nn.functional.conv2d(x.double(), w.double())
+    xl, wl = x.permute(0, 2, 3, 1).contiguous(), w.reshape(Co, Ci).contiguous()
+    y = torch.full((B, H, W, Co), float("nan"), device=DEV)
+    assert L.ps_conv1x1_takes(Ci, Co) == 1
+    _lib.check(L.ps_conv1x1_nhwc_f32(xl.data_ptr(), wl.data_ptr(), B * H * W, Ci, Co, y.data_ptr(), st), "conv1x1")
+    err = (y.permute(0, 3, 1, 2).double() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 2e-6, err
+    if Ci % 4 == 0:
+        conv = torch.nn.Conv2d(Ci, Co, 1).to(DEV)
+        with torch.no_grad():
+            conv.weight.copy_(w)
+            got = A.conv1x1(conv, x.contiguous(memory_format=torch.channels_last))
+        assert got is not None and got.shape == (B, Co, H, W) and (got.double() - ref).abs().max().item() / ref.abs().max().item() < 2e-6
+        with torch.no_grad():
+            assert A.conv1x1(conv, x) is None                                  # (NCHW storage: not taken)
+            assert A.conv1x1(torch.nn.Conv2d(Ci, Co, 1, stride=2).to(DEV), x.contiguous(memory_format=torch.channels_last)) is None
+    assert L.ps_conv1x1_takes(48, 64) == 0 and L.ps_conv1x1_takes(256, 256) == 0 and L.ps_conv1x1_takes(128, 0) == 0
+    assert L.ps_conv1x1_nhwc_f32(xl.data_ptr(), wl.data_ptr(), B * H * W, 48, Co, y.data_ptr(), st) != 0
+    assert L.ps_conv1x1_nhwc_f32(xl.data_ptr(), wl.data_ptr(), 0, Ci, Co, y.data_ptr(), st) != 0
 
 
 def test_noise_affine_in_one_launch_equals_the_composed_form():

@@ -132,6 +132,102 @@ def test_module_encode_decode_against_reference_outputs():
     np.testing.assert_allclose(dec.cpu().numpy(), want.numpy(), rtol=1e-3, atol=1e-4)
 
 
+def _module(seed=0):
+    from pixelsynth_amd.vqvae2 import VQVAETop
+    m = VQVAETop().eval()
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in syn.vqvae_state_dict(seed).items()}, strict=True)
+    return m.cuda()
+
+
+def test_hand_written_convolutions_against_the_fp32_module_and_an_fp64_one(monkeypatch):
+    """The inference GPU path of encode_codes / decode_code (vqvae._FastPath: the 3 x 3, 4 x 4 stride-2 and transposed convolutions through
+    csrc/conv_f16x3.hip, the ResBlock tails through csrc/conv1x1.hip) against the same module in fp64 on the host: the latent in front of
+    the arg-min within 3e-5 of its scale -- closer than the MIOpen fp32 path gets --, the codes equal except at near-ties, the decoded image within
+    1e-5 of the fp64 one's scale; PS_VQVAE_CONV=fp32 and a decoder_conv("fp32") block take the torch path (no split-fp16 launch)."""
+    from pixelsynth_amd.networks import architectures as A
+    from pixelsynth_amd.vqvae2 import vqvae as V
+    m = _module(1)
+    img = dev(syn.image(11, 3, 3, 256))
+    with torch.no_grad():
+        fast = m._fast(img, 256, 256)
+        assert fast is not None
+        lat = fast.encode_latent(m, img)                                   # (B, 32, 32, 64)
+        m64 = _module(1).cpu().double()
+        ref = m64.quantize_conv_t(m64.enc_t(m64.enc_b(img.cpu().double()))).permute(0, 2, 3, 1)
+        scale = ref.abs().max().item()
+        err = (lat.cpu().double() - ref).abs().max().item() / scale
+        assert err < 3e-5, err
+        codes = m.encode_codes(img)
+        emb = m64.quantize_t.embed
+        z = ref.reshape(-1, emb.shape[0])
+        d = (z * z).sum(1, keepdim=True) - 2 * z @ emb + (emb * emb).sum(0, keepdim=True)
+        two = torch.topk(d, 2, dim=1, largest=False)
+        gap = ((two.values[:, 1] - two.values[:, 0]) / two.values[:, 0].abs().clamp_min(1e-12)).numpy()
+        got = codes.cpu().numpy().reshape(-1)
+        assert np.all((got == two.indices[:, 0].numpy()) | (gap < 10 * TIE)) and (got != two.indices[:, 0].numpy()).sum() <= 8
+        image = m.decode_code(codes)
+        want = m64.decode(m64.quantize_t.embed_code(codes.cpu().long()).permute(0, 3, 1, 2))
+        assert image.shape == (3, 3, 256, 256) and image.is_contiguous()
+        assert (image.cpu().double() - want).abs().max().item() / want.abs().max().item() < 1e-5
+        A.check_f16x3_overflow(img.device)
+        # the switches
+        calls = []
+        real = V._FastPath.conv3
+        monkeypatch.setattr(V._FastPath, "conv3", lambda self, *a, **k: (calls.append(1), real(self, *a, **k))[1])
+        m.encode_codes(img)
+        assert calls
+        del calls[:]
+        with A.decoder_conv("fp32"):
+            slow = m.encode_codes(img)
+            m.decode_code(slow)
+        monkeypatch.setattr(V, "VQVAE_CONV", "fp32")
+        m.decode_code(m.encode_codes(img))
+        assert not calls
+        assert (slow.cpu().numpy().reshape(-1) != got).sum() <= 8
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 64, 64), (1, 12, 48), (3, 256, 256)])
+def test_three_channel_ends_against_fp64_layers(B, H, W):
+    """csrc/vq_ends.hip: the VQ-VAE's first convolution (3 -> 64, 4 x 4, stride 2; output in the space-to-depth blocks the next layer reads)
+    and its last transposed convolution (ReLU, 64 -> 3, 4 x 4, stride 2; the NCHW image) on the fp32 matrix pipe against torch's layers
+    in fp64: 2e-6 of the output's scale; borders (zero padding) included, a non-square image."""
+    from pixelsynth_amd.vqvae2.vqvae import _s2d
+    L, st = _lib.lib(), _lib.current_stream()
+    g = torch.Generator().manual_seed(H + W)
+    x = torch.randn(B, 3, H, W, generator=g).cuda()
+    w = (torch.randn(64, 3, 4, 4, generator=g) / 7).cuda()
+    b = torch.randn(64, generator=g).cuda()
+    y = torch.full((B, H // 4, W // 4, 256), float("nan"), device="cuda")
+    _lib.check(L.ps_vq_stem_s2d_f32(x.data_ptr(), w.data_ptr(), b.data_ptr(), B, H, W, y.data_ptr(), st), "ps_vq_stem_s2d_f32")
+    ref = _s2d(torch.nn.functional.conv2d(x.double(), w.double(), b.double(), 2, 1)).permute(0, 2, 3, 1)
+    assert (y.double() - ref).abs().max().item() / ref.abs().max().item() < 2e-6
+    Hh, Wh = H // 2, W // 2 if (W // 2) % 16 == 0 else 16
+    h = torch.randn(B, Hh, Wh, 64, generator=g).cuda()
+    wt = (torch.randn(64, 3, 4, 4, generator=g) / 16).cuda()
+    bt = torch.randn(3, generator=g).cuda()
+    img = torch.full((B, 3, 2 * Hh, 2 * Wh), float("nan"), device="cuda")
+    _lib.check(L.ps_vq_head_f32(h.data_ptr(), wt.data_ptr(), bt.data_ptr(), B, Hh, Wh, img.data_ptr(), st), "ps_vq_head_f32")
+    ref = torch.nn.functional.conv_transpose2d(torch.relu(h.double().permute(0, 3, 1, 2)), wt.double(), bt.double(), 2, 1)
+    assert (img.double() - ref).abs().max().item() / ref.abs().max().item() < 2e-6
+    assert L.ps_vq_stem_s2d_f32(x.data_ptr(), w.data_ptr(), b.data_ptr(), B, H, 40, y.data_ptr(), st) != 0
+    assert L.ps_vq_head_f32(h.data_ptr(), wt.data_ptr(), bt.data_ptr(), B, Hh, 24, img.data_ptr(), st) != 0
+
+
+def test_encoder_runs_again_in_fp32_when_an_activation_leaves_fp16s_range():
+    """An image scaled so that the first activations pass 65 000: the split-fp16 convolutions raise the device flag, encode_codes warns and
+    returns what the torch path computes."""
+    from pixelsynth_amd.networks import architectures as A
+    m = _module(2)
+    img = dev(syn.image(5, 1, 3, 256)) * 3.0e6
+    with torch.no_grad():
+        with pytest.warns(UserWarning, match="run again in fp32"):
+            got = m.encode_codes(img)
+        with A.decoder_conv("fp32"):
+            want = m.encode_codes(img)
+    assert (got != want).sum().item() <= 8
+    A.check_f16x3_overflow(img.device)          # (left clear)
+
+
 def test_large_batches_are_cut_per_call(monkeypatch):
     """VQVAETop.encode_codes / decode_code and Unet.forward cut a batch beyond MAX_BATCH into several calls (MIOpen's fp32 kernels
     index wrongly from 2 GiB activations on: networks/architectures.py:_conv2d_batches).  With MAX_BATCH lowered to 2, five views
