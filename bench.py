@@ -691,7 +691,7 @@ def extra_configs(device):
         "note": f"{n_s} sampled codes x one whole-grid forward each (what the reference schedules); the incremental "
                 "form above does the work of ONE such forward per frame"}
     # SURVEY 8f row 1, reported separately (not part of the metric): VQ-VAE-2 top level either side of the AR loop for the
-    # 16 views of a step -- reprojected view -> top codes (convs through MIOpen, quantiser = ps_vq_nearest_f32) and
+    # 16 views of a step -- reprojected view -> top codes (convolutions: csrc/conv_f16x3.hip / conv1x1.hip / vq_ends.hip, quantiser = ps_vq_nearest_f32) and
     # sampled codes -> 256x256 image (ps_vq_embed_f32 + transposed convs), random-init weights
     from pixelsynth_amd.vqvae2 import VQVAETop
     vq = VQVAETop().eval()
@@ -812,7 +812,7 @@ def end_to_end_config(device, V, steps=3):
     """What a user of the reference's demo gets per frame (models/z_buffermodel.py:291-419), V views in one pass: depth Unet on
     the source images -> reproject + splat -> VQ-VAE top codes -> AR outpainting -> decode_code -> get_combined -> refinement
     decoder, every network in the loop (random-init weights of the reference's shapes), inputs resident, wall clock around
-    synchronised passes.  The dense convolutions (Unet, VQ-VAE, decoder) are MIOpen's -- next-row components; the
+    synchronised passes.  The Unet's convolutions are MIOpen's, the VQ-VAE's and the decoder's hand-written -- next-row components; the
     hot path of the headline metric is the part `hot_path_ms` times inside this pass."""
     from pixelsynth_amd.z_buffermodel import ZbufferModelPts
     o = vars(make_opts()).copy()
@@ -866,7 +866,7 @@ def end_to_end_config(device, V, steps=3):
             "sampled_codes_per_view_mean": round(float(np.mean(out["plan"].n_sampled)), 1), "parts_ms": parts,
             "hot_path_ms": round(parts["reproject_splat_plan_ms"] + parts["ar_outpaint_ms"], 3),
             "note": "every network of forward_image in the loop; depth from the (random-init) Unet, so the outpainting region is not "
-                    "the headline's; convolutions of the Unet / VQ-VAE through MIOpen, the decoder's 3 x 3 layers hand-written on the fp16 pipe (SURVEY 8f next rows)"}
+                    "the headline's; the Unet's convolutions through MIOpen, the VQ-VAE's and the decoder's hand-written (3 x 3 and stride-2 layers on the fp16 pipe with split operands, 1 x 1 and 3-channel layers on the fp32 matrix pipe; SURVEY 8f next rows)"}
 
 
 def cpu_baseline(host, out, V, budget_s=20.0):

@@ -13,8 +13,8 @@
 //   ps_noise_affine_f32          the (B, C) scale / shift of a LinearNoiseLayer from its noise draw: one launch instead of eight
 // (b may be NULL: the resampled branch alone.)  The bias of a convolution is a pass of its own in torch; here the convolutions
 // run without it and the per-channel constant rides along in the pass that consumes their output: folded into `shift` of the
-// next norm (host), or the `bias` argument of the resampling / residual kernels.  The convolutions themselves stay on MIOpen: at 16 views they run at ~70 % of the
-// fp32 matrix peak.
+// next norm (host), or the `bias` argument of the resampling / residual kernels.  The convolutions themselves are csrc/conv_f16x3.hip,
+// conv_thin.hip and conv1x1.hip (rounds 5 and 6).
 #include "ps_common.h"
 
 namespace {

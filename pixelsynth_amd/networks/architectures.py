@@ -9,8 +9,8 @@ Same constructor arguments, attribute / parameter names and shapes as the refere
     downstream take raw NCHW pointers;
   * the DECODER's 3 x 3 convolutions are hand-written (csrc/conv_f16x3.hip: split-fp16 MFMA, fp32 in / out, the norm + ReLU in
     front of them applied as the input is staged; csrc/conv_thin.hip for the 4 -> 64 and 128 -> 3 layers): 8.3 instead of 20 ms
-    per 16 views.  PS_DECODER_CONV=fp32 / opt.decoder_conv = "fp32" sends them through torch.  The Unet's convolutions, the
-    decoder's 1 x 1 and 3 -> 3 layers run through torch (MIOpen), the batch cut so that no call sees 2 GiB (MIOpen's fp32 NHWC
+    per 16 views; its 1 x 1 projections run on the fp32 matrix pipe (csrc/conv1x1.hip, round 6).  PS_DECODER_CONV=fp32 /
+    opt.decoder_conv = "fp32" sends them through torch.  The Unet's convolutions and the decoder's 3 -> 3 layer run through torch (MIOpen), the batch cut so that no call sees 2 GiB (MIOpen's fp32 NHWC
     kernels are silently wrong on 4 GiB activations -- 128 views of the decoder's widest layer);
   * spectral-normalised weights are computed once per checkpoint in eval mode, not at every forward (_normalised_weight);
   * `LinearNoiseLayer` + stored-statistics batch norm + ReLU is ONE per-(sample, channel) affine and a clamp
