@@ -401,10 +401,12 @@ int ps_conv3x3_f16x3_nhwc(const float *x, const float *scale, const float *shift
  *   run as 3 x 3 convolutions over 2 x 2 blocks):  in_s2d != 0: x is (B, 2 H, 2 W, Ci / 4) and is read as its space-to-depth form
  *   (B, H, W, Ci), channel (sy * 2 + sx) * Ci / 4 + c = pixel (2 y + sy, 2 x + sx) -- Ci / 4 a multiple of 32 (scale / shift stay (B, Ci));
  *   out_d2s != 0: y is (B, 2 H, 2 W, Co / 4), written as the depth-to-space form of the (B, H, W, Co) result, channel
- *   (py * 2 + px) * Co / 4 + c -> pixel (2 y + py, 2 x + px) -- Co / 4 a multiple of 64, res NULL. */
+ *   (py * 2 + px) * Co / 4 + c -> pixel (2 y + py, 2 x + px) -- Co / 4 a multiple of 64, res NULL.
+ *   co_live (0 = Co): the caller's word that output channels [co_live, Co) carry all-zero weights (a 32-channel layer packed as 64): they
+ *   are not multiplied (speed only: they come out as bias + res either way). */
 int ps_conv3x3_f16x3_ex_nhwc(const float *x, const float *scale, const float *shift, const void *packed, const float *bias,
-                             const float *res, int B, int H, int W, int Ci, int Co, int in_s2d, int out_d2s, float *y, int *overflow,
-                             void *stream);
+                             const float *res, int B, int H, int W, int Ci, int Co, int co_live, int in_s2d, int out_d2s, float *y,
+                             int *overflow, void *stream);
 
 /* ---- the decoder's two thin 3 x 3 convolutions (csrc/conv_thin.hip), fp32 FMAs, same contract as above (no bias; optional
  * act(x) = max(x * scale[b][c] - shift[b][c], 0) on the way in; zero padding 1, stride 1; NHWC):

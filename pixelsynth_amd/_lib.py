@@ -82,7 +82,7 @@ _PROTOS = {
     "ps_conv3x3_f16x3_packed_bytes": (ctypes.c_size_t, [c_int, c_int]),
     "ps_conv3x3_f16x3_pack": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "ps_conv3x3_f16x3_nhwc": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p, c_void_p, c_void_p]),
-    "ps_conv3x3_f16x3_ex_nhwc": (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_void_p, c_void_p, c_void_p]),
+    "ps_conv3x3_f16x3_ex_nhwc": (c_int, [c_void_p] * 6 + [c_int] * 8 + [c_void_p, c_void_p, c_void_p]),
     "ps_pixelcnn_time_column_step": (c_int, [c_void_p] * 6 + [c_int, c_int, c_int] + [c_void_p] * 5),
     "ps_pixelcnn_ar_step": (c_int, [c_void_p] * 6 + [c_int, c_int, c_int, c_void_p, c_void_p]),
 }

@@ -94,6 +94,7 @@ struct ConvArgs {
     int *overflow;
     int H, W, Ci, Co, tiles_x, tiles_per_frame, ncb, nblocks;
     int s2d_C;             // > 0: x is (B, 2 H, 2 W, s2d_C), read as its space-to-depth form (B, H, W, Ci = 4 s2d_C), channel (sy, sx, c)
+    int co_live;           // output channels [co_live, Co) have all-zero weights (padding): 64-channel halves of a block that lie there are not multiplied
     int d2s_C;             // > 0: y is (B, 2 H, 2 W, d2s_C), written from the depth-to-space of (B, H, W, Co = 4 d2s_C), channel (py, px, c)
 };
 
@@ -265,6 +266,7 @@ template <bool FUSE, bool PERM = false> __global__ __launch_bounds__(NT) void k_
     // requested three taps ahead) and the next chunk's patch is stashed during tap 6.
     struct Frag { h8 ah[2], al[2], bh[2], bl[2]; };
     Frag F[2];
+    bool fresh = false;
     [[maybe_unused]] bool first_load = true;
     auto load_frags = [&](Frag &f, const char *Ab, const char *Bb, int tap, int ks) {
 #if defined(PS_CONV_EXP) && (PS_CONV_EXP & 2)   // tuning build: fragments read once
@@ -284,6 +286,17 @@ template <bool FUSE, bool PERM = false> __global__ __launch_bounds__(NT) void k_
             f.bl[nt] = *(const h8 *)(p + 1024);
         }
     };
+    // Does this wave's 64-channel half of the block carry weights at all (wave-uniform, per item)?  64 output channels leave the upper half of
+    // the 128-channel block as padding.  A wave's MFMAs on zero weights cost the SIMD it shares with a live wave as much as real ones -- the
+    // kernel is bound by its MFMA stream -- so a dead wave keeps the barriers, the copies and the staging and skips fragments and MFMAs.
+    // (Tried and dropped: also skipping the upper 32-channel tile INSIDE a live wave -- the branch inside the step costs the scheduler its
+    // interleaving: the decoder 53.9 -> 64.2 ms.)
+    bool lv = true;
+#ifdef PS_CONV_NO_SKIP   // tuning build: every wave multiplies, padding or not
+    auto live_of = [&](const Item &) { return true; };
+#else
+    auto live_of = [&](const Item &it) { return it.cb * COT + chh * 64 < a.co_live; };
+#endif
     auto mfma_step = [&](const Frag &f) {
 #if defined(PS_CONV_EXP) && (PS_CONV_EXP & 1)   // tuning build: no MFMAs (the fragments still have to arrive)
         asm volatile("" : : "v"(f.ah[0]), "v"(f.ah[1]), "v"(f.al[0]), "v"(f.al[1]), "v"(f.bh[0]), "v"(f.bh[1]), "v"(f.bl[0]), "v"(f.bl[1]));
@@ -312,6 +325,7 @@ template <bool FUSE, bool PERM = false> __global__ __launch_bounds__(NT) void k_
     const unsigned long long clk0 = clock64(), wall0 = wall_clock64();
 #endif
     Item cur = item_at(0), nxt = cur;
+    lv = live_of(cur);
     const int Q = nitems * nchunk, GG = Q * 9;   // chunk instances and taps of this workgroup
     aim(cur);
     fetch(cur, 0);
@@ -351,13 +365,18 @@ template <bool FUSE, bool PERM = false> __global__ __launch_bounds__(NT) void k_
                 fetch(nx, cn);
             }
             const char *Bb = lds + b_rd + (gg & 3) * B_TAP, *Bn = lds + b_rd + ((gg + 1) & 3) * B_TAP;
-            if (gg == 0) load_frags(F[0], Ab, Bb, 0, 0);
-            load_frags(F[1], Ab, Bb, tap, 1);
-            first_load = false;
-            mfma_step(F[0]);
-            if (tap < 8) load_frags(F[0], Ab, Bn, tap + 1, 0);
-            else if (more) load_frags(F[0], An, Bn, 0, 0);
-            mfma_step(F[1]);
+            if (lv) {
+                if (gg == 0 || fresh) load_frags(F[0], Ab, Bb, tap, 0);
+                fresh = false;
+                load_frags(F[1], Ab, Bb, tap, 1);
+                first_load = false;
+                mfma_step(F[0]);
+                if (tap < 8) load_frags(F[0], Ab, Bn, tap + 1, 0);
+                else if (more) load_frags(F[0], An, Bn, 0, 0);
+                mfma_step(F[1]);
+            } else {
+                fresh = true;      // (a wave that comes back to life at a later item reads its first fragments itself)
+            }
             if (tap == 6 && more) {   // (the patch was waited for at tap 3, whose wait covers tap 1's copies, requested behind it)
                 pin();                // (the two waves of a SIMD stashing at different taps, 5 and 6: 1-3 % slower; the stash spread a
                                       // piece per step over taps 3 .. 5 with its conversions scheduled behind the MFMAs: 2 % slower)
@@ -373,6 +392,7 @@ template <bool FUSE, bool PERM = false> __global__ __launch_bounds__(NT) void k_
             clear();
             stored = more;
             cur = nxt;
+            lv = live_of(cur);
             ++item;
             c = 0;
         } else {
@@ -445,14 +465,15 @@ int ps_conv3x3_f16x3_pack(const float *w, int Co, int Ci, void *packed, void *st
 int ps_conv3x3_f16x3_nhwc(const float *x, const float *scale, const float *shift, const void *packed, const float *bias, const float *res,
                           int B, int H, int W, int Ci, int Co, float *y, int *overflow, void *stream)
 {
-    return ps_conv3x3_f16x3_ex_nhwc(x, scale, shift, packed, bias, res, B, H, W, Ci, Co, 0, 0, y, overflow, stream);
+    return ps_conv3x3_f16x3_ex_nhwc(x, scale, shift, packed, bias, res, B, H, W, Ci, Co, 0, 0, 0, y, overflow, stream);
 }
 
 int ps_conv3x3_f16x3_ex_nhwc(const float *x, const float *scale, const float *shift, const void *packed, const float *bias, const float *res,
-                             int B, int H, int W, int Ci, int Co, int in_s2d, int out_d2s, float *y, int *overflow, void *stream)
+                             int B, int H, int W, int Ci, int Co, int co_live, int in_s2d, int out_d2s, float *y, int *overflow, void *stream)
 {
     using namespace psconv;
     PS_REQUIRE(x && packed && y && overflow, "conv3x3_f16x3: null pointer");
+    PS_REQUIRE(co_live >= 0 && co_live <= Co, "conv3x3_f16x3: co_live in 0 .. Co required (%d)", co_live);
     PS_REQUIRE(!in_s2d || (Ci % 4 == 0 && (Ci / 4) % CK == 0), "conv3x3_f16x3: space-to-depth input needs Ci / 4 a multiple of 32 (Ci = %d)", Ci);
     PS_REQUIRE(!out_d2s || (Co % 4 == 0 && (Co / 4) % 64 == 0 && !res),
                "conv3x3_f16x3: depth-to-space output needs Co / 4 a multiple of 64 and no res (Co = %d)", Co);
@@ -465,6 +486,7 @@ int ps_conv3x3_f16x3_ex_nhwc(const float *x, const float *scale, const float *sh
     a.x = x; a.scale = scale; a.shift = shift; a.wp = (const char *)packed; a.y = y; a.bias = bias; a.res = res; a.overflow = overflow;
     a.H = H; a.W = W; a.Ci = Ci; a.Co = Co;
     a.s2d_C = in_s2d ? Ci / 4 : 0; a.d2s_C = out_d2s ? Co / 4 : 0;
+    a.co_live = co_live > 0 && co_live < Co ? co_live : Co;
     a.tiles_x = W / TW; a.tiles_per_frame = (H / TH) * a.tiles_x; a.ncb = (Co + COT - 1) / COT;
     const size_t nb = (size_t)B * a.tiles_per_frame * a.ncb;
     PS_REQUIRE(nb < ((size_t)1 << 30), "conv3x3_f16x3: too many tiles");

@@ -107,7 +107,7 @@ class _FastPath:
                 raise ValueError("VQ-VAE fast path: a weight fp16 cannot hold")
             packed = torch.empty(L.ps_conv3x3_f16x3_packed_bytes(Cop, Ci), dtype=torch.uint8, device=device)
             _lib.check(L.ps_conv3x3_f16x3_pack(wl.data_ptr(), Cop, Ci, packed.data_ptr(), _lib.current_stream()), "ps_conv3x3_f16x3_pack")
-            return dict(packed=packed, Ci=Ci, Co=Cop, bias=b.contiguous())
+            return dict(packed=packed, Ci=Ci, Co=Cop, live=Co, bias=b.contiguous())
 
         def conv(c):
             return c.weight.detach().float(), c.bias.detach().float()
@@ -182,7 +182,7 @@ class _FastPath:
         sc, sh = self._act(B, C) if relu_in else (None, None)
         p = lambda t: None if t is None else t.data_ptr()
         _lib.check(self.L.ps_conv3x3_f16x3_ex_nhwc(x.data_ptr(), p(sc), p(sh), layer["packed"].data_ptr(), layer["bias"].data_ptr(), None, B, H, W,
-                                                   C, layer["Co"], int(s2d), int(d2s), y.data_ptr(), _overflow_flag(x.device).data_ptr(),
+                                                   C, layer["Co"], layer["live"], int(s2d), int(d2s), y.data_ptr(), _overflow_flag(x.device).data_ptr(),
                                                    _lib.current_stream()), "ps_conv3x3_f16x3_ex_nhwc")
         return y
 

@@ -149,12 +149,48 @@ def test_conv3x3_on_the_fp16_pipe_reads_space_to_depth_blocks_in_place(B, H, W, 
     p = lambda t: None if t is None else t.data_ptr()
     y = torch.full((B, H, W, Co), float("nan"), device=DEV)
     flag = torch.zeros(1, dtype=torch.int32, device=DEV)
-    _lib.check(L.ps_conv3x3_f16x3_ex_nhwc(xl.data_ptr(), p(sc), p(sh), packed.data_ptr(), bias.data_ptr(), None, B, H, W, 4 * C, Co, 1, 0,
+    _lib.check(L.ps_conv3x3_f16x3_ex_nhwc(xl.data_ptr(), p(sc), p(sh), packed.data_ptr(), bias.data_ptr(), None, B, H, W, 4 * C, Co, 0, 1, 0,
                                           y.data_ptr(), flag.data_ptr(), st), "conv")
     err = (y.permute(0, 3, 1, 2).double() - ref).abs().max().item() / ref.abs().max().item()
     assert err < 3e-6 and int(flag.item()) == 0, err
-    assert L.ps_conv3x3_f16x3_ex_nhwc(xl.data_ptr(), None, None, packed.data_ptr(), None, None, B, H, W, 64, Co, 1, 0, y.data_ptr(),
+    assert L.ps_conv3x3_f16x3_ex_nhwc(xl.data_ptr(), None, None, packed.data_ptr(), None, None, B, H, W, 64, Co, 0, 1, 0, y.data_ptr(),
                                       flag.data_ptr(), st) != 0                       # (Ci / 4 = 16: not a multiple of 32)
+
+
+@pytest.mark.parametrize("Co,live", [(64, 32), (64, 0), (128, 96), (128, 40)])
+def test_conv3x3_on_the_fp16_pipe_skips_channel_tiles_that_are_padding(Co, live):
+    """co_live: the output channels from there on carry all-zero weights (the VQ-VAE's 128 -> 32 layers packed as 64; 64 of a 128-channel block
+    by themselves) and their MFMAs are not issued.  Same results as without the hint -- the live channels against an fp64 convolution, the
+    others exactly bias -- whichever tiles of a wave are live (both, the lower one, none)."""
+    from pixelsynth_amd import _lib
+    L, st = _lib.lib(), torch.cuda.current_stream().cuda_stream
+    B, H, W, Ci = 3, 32, 16, 128
+    n = live or Co
+    g = torch.Generator().manual_seed(Co + live)
+    x = torch.randn(B, Ci, H, W, generator=g).to(DEV)
+    w = torch.zeros(Co, Ci, 3, 3)
+    w[:n] = torch.randn(n, Ci, 3, 3, generator=g) / (3 * Ci ** 0.5)
+    w = w.to(DEV)
+    bias = torch.randn(Co, generator=g).to(DEV)
+    ref = torch.nn.functional.conv2d(torch.relu(x).double(), w.double(), bias.double(), 1, 1)
+    wl = w.permute(0, 2, 3, 1).contiguous()
+    packed = torch.empty(L.ps_conv3x3_f16x3_packed_bytes(Co, Ci), dtype=torch.uint8, device=DEV)
+    _lib.check(L.ps_conv3x3_f16x3_pack(wl.data_ptr(), Co, Ci, packed.data_ptr(), st), "pack")
+    xl = x.permute(0, 2, 3, 1).contiguous()
+    sc, sh = torch.ones(B, Ci, device=DEV), torch.zeros(B, Ci, device=DEV)
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    outs = []
+    for hint in (live, 0):
+        y = torch.full((B, H, W, Co), float("nan"), device=DEV)
+        _lib.check(L.ps_conv3x3_f16x3_ex_nhwc(xl.data_ptr(), sc.data_ptr(), sh.data_ptr(), packed.data_ptr(), bias.data_ptr(), None, B, H, W, Ci, Co,
+                                              hint, 0, 0, y.data_ptr(), flag.data_ptr(), st), "conv")
+        outs.append(y)
+    assert torch.equal(outs[0], outs[1])
+    got = outs[0].permute(0, 3, 1, 2).double()
+    assert (got - ref).abs().max().item() / ref.abs().max().item() < 3e-6
+    assert torch.equal(outs[0][..., n:], bias[n:].expand(B, H, W, Co - n))
+    assert L.ps_conv3x3_f16x3_ex_nhwc(xl.data_ptr(), None, None, packed.data_ptr(), None, None, B, H, W, Ci, Co, Co + 1, 0, 0, y.data_ptr(),
+                                      flag.data_ptr(), st) != 0
 
 
 @pytest.mark.parametrize("B,H,W,Ci,C,fuse", [(2, 16, 32, 64, 64, False), (1, 32, 32, 128, 64, True), (3, 16, 16, 32, 128, True)])
@@ -178,11 +214,11 @@ def test_conv3x3_on_the_fp16_pipe_stores_depth_to_space(B, H, W, Ci, C, fuse):
     y = torch.full((B, 2 * H, 2 * W, C), float("nan"), device=DEV)
     flag = torch.zeros(1, dtype=torch.int32, device=DEV)
     b4 = bias.repeat(4).contiguous()
-    _lib.check(L.ps_conv3x3_f16x3_ex_nhwc(xl.data_ptr(), p(sc), p(sh), packed.data_ptr(), b4.data_ptr(), None, B, H, W, Ci, 4 * C, 0, 1,
+    _lib.check(L.ps_conv3x3_f16x3_ex_nhwc(xl.data_ptr(), p(sc), p(sh), packed.data_ptr(), b4.data_ptr(), None, B, H, W, Ci, 4 * C, 0, 0, 1,
                                           y.data_ptr(), flag.data_ptr(), st), "conv")
     err = (y.permute(0, 3, 1, 2).double() - ref).abs().max().item() / ref.abs().max().item()
     assert err < 3e-6 and int(flag.item()) == 0, err
-    assert L.ps_conv3x3_f16x3_ex_nhwc(xl.data_ptr(), None, None, packed.data_ptr(), None, y.data_ptr(), B, H, W, Ci, 4 * C, 0, 1, y.data_ptr(),
+    assert L.ps_conv3x3_f16x3_ex_nhwc(xl.data_ptr(), None, None, packed.data_ptr(), None, y.data_ptr(), B, H, W, Ci, 4 * C, 0, 0, 1, y.data_ptr(),
                                       flag.data_ptr(), st) != 0                       # (res does not go with depth-to-space)
 
 
