@@ -40,6 +40,8 @@ __global__ __launch_bounds__(256) void k_affine_relu(const f32x4 *__restrict__ x
 // convolutions that produced them, not yet added): it reaches the output with the share of the window inside the image
 // `post` (may be null): a tensor of the OUTPUT's shape added after the pooling -- the other branch of a down-sampling block when its
 // 1 x 1 convolution was run on the pooled input instead (pooling and a 1 x 1 convolution commute; the convolution then costs a quarter)
+// (Round 6, measured and not kept: one workgroup per output row with 32-bit index arithmetic, 725 us per launch against this form's 685;
+// the row's input columns summed over their three rows in LDS first -- every input element fetched once instead of 2.25 times --: 1 266 us.)
 __global__ __launch_bounds__(256) void k_pool_add(const f32x4 *__restrict__ a, const f32x4 *__restrict__ b,
                                                   const f32x4 *__restrict__ bias, const f32x4 *__restrict__ post, int H, int W, int C4,
                                                   size_t total4, f32x4 *__restrict__ out)
@@ -87,29 +89,64 @@ __device__ __forceinline__ void up_src(int d, int n, int &i0, int &i1, float &w1
     w1 = s - (float)i0;
 }
 
+// One workgroup per INPUT row (frame, y), grid-stride: a thread owns (x, channel quad) and writes the 2 x 2 output block it grows into
+// from the 3 x 3 input neighbourhood -- 9 fetches per 4 outputs where a thread per output fetched 16 (round 6: the pass was bound by those
+// fetches, 2.7 TB/s of 5 the chip streams).  Every output is the SAME expression of the same four samples and weights as before (up_src's
+// indices and weights, spelled out: output 2 x reads (x - 1, x; 0.75) -- (0, 1; 0) at the border --, output 2 x + 1 reads (x, x + 1; 0.25)).
 __global__ __launch_bounds__(256) void k_upsample_add(const f32x4 *__restrict__ a, const f32x4 *__restrict__ b,
-                                                      const f32x4 *__restrict__ bias, int H, int W, int C4, size_t total4,
+                                                      const f32x4 *__restrict__ bias, int H, int W, int C4, unsigned rows,
                                                       f32x4 *__restrict__ out)
 {
-    const int Ho = 2 * H, Wo = 2 * W;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
-        const int c4 = (int)(i % C4);
-        size_t p = i / C4;
-        const int xo = (int)(p % Wo);
-        p /= Wo;
-        const int yo = (int)(p % Ho);
-        const size_t f = p / Ho;
-        int y0, y1, x0, x1;
-        float wy, wx;
-        up_src(yo, H, y0, y1, wy);
-        up_src(xo, W, x0, x1, wx);
-        const size_t r0 = (f * H + y0) * W, r1 = (f * H + y1) * W;
-        const size_t i00 = (r0 + x0) * C4 + c4, i01 = (r0 + x1) * C4 + c4, i10 = (r1 + x0) * C4 + c4, i11 = (r1 + x1) * C4 + c4;
-        const float w00 = (1.0f - wy) * (1.0f - wx), w01 = (1.0f - wy) * wx, w10 = wy * (1.0f - wx), w11 = wy * wx;
-        f32x4 v = a[i00] * w00 + a[i01] * w01 + a[i10] * w10 + a[i11] * w11;
-        if (b) v += b[i00] * w00 + b[i01] * w01 + b[i10] * w10 + b[i11] * w11;
-        if (bias) v += bias[c4];   // (the interpolation weights add up to one)
-        out[i] = v;
+    const int per_row = W * C4, out_row = 2 * per_row;
+    for (unsigned row = blockIdx.x; row < rows; row += gridDim.x) {
+        const unsigned f = row / (unsigned)H;
+        const int y = (int)(row - f * (unsigned)H);
+        const int yt = max(y - 1, 0), yb = min(y + 1, H - 1);
+        const size_t fb = (size_t)f * H * W * C4;
+        // output row 2 y: (y0, y1, wy) = (y - 1, y, 0.75), at the border (0, 1, 0); output row 2 y + 1: (y, y + 1 clamped, 0.25)
+        const float wy0 = y > 0 ? 0.75f : 0.0f, wy1 = 0.25f;
+        f32x4 *o0 = out + ((size_t)f * 2 * H + 2 * y) * out_row, *o1 = o0 + out_row;
+        for (int e = threadIdx.x; e < per_row; e += 256) {
+            const int x = e / C4, c4 = e - x * C4;
+            const int xl = max(x - 1, 0), xr = min(x + 1, W - 1);
+            const float wx0 = x > 0 ? 0.75f : 0.0f, wx1 = 0.25f;      // output column 2 x: (x - 1, x; 0.75) or (0, 1; 0); 2 x + 1: (x, xr; 0.25)
+            f32x4 res[2][2];
+#pragma unroll
+            for (int src = 0; src < 2; ++src) {
+                const f32x4 *t = src == 0 ? a : b;
+                if (!t) continue;
+                t += fb + c4;
+                const f32x4 *T = t + (size_t)yt * per_row, *C = t + (size_t)y * per_row, *B = t + (size_t)yb * per_row;
+                const f32x4 tl = T[xl * C4], tm = T[x * C4], tr = T[xr * C4], cl = C[xl * C4], cm = C[x * C4], cr = C[xr * C4],
+                            bl = B[xl * C4], bm = B[x * C4], br = B[xr * C4];
+#pragma unroll
+                for (int py = 0; py < 2; ++py) {
+                    // the two source rows of this output row, as (left, middle, right) triples
+                    const bool top_pair = py == 0 && y > 0;          // rows (y - 1, y)
+                    const f32x4 u0l = py == 0 ? (top_pair ? tl : cl) : cl, u0m = py == 0 ? (top_pair ? tm : cm) : cm, u0r = py == 0 ? (top_pair ? tr : cr) : cr;
+                    const f32x4 u1l = py == 0 ? (top_pair ? cl : bl) : bl, u1m = py == 0 ? (top_pair ? cm : bm) : bm, u1r = py == 0 ? (top_pair ? cr : br) : br;
+                    const float wy = py == 0 ? wy0 : wy1;
+#pragma unroll
+                    for (int px = 0; px < 2; ++px) {
+                        const bool left_pair = px == 0 && x > 0;     // columns (x - 1, x)
+                        const f32x4 v00 = px == 0 ? (left_pair ? u0l : u0m) : u0m, v01 = px == 0 ? (left_pair ? u0m : u0r) : u0r;
+                        const f32x4 v10 = px == 0 ? (left_pair ? u1l : u1m) : u1m, v11 = px == 0 ? (left_pair ? u1m : u1r) : u1r;
+                        const float wx = px == 0 ? wx0 : wx1;
+                        const float w00 = (1.0f - wy) * (1.0f - wx), w01 = (1.0f - wy) * wx, w10 = wy * (1.0f - wx), w11 = wy * wx;
+                        const f32x4 v = v00 * w00 + v01 * w01 + v10 * w10 + v11 * w11;
+                        res[py][px] = src == 0 ? v : res[py][px] + v;
+                    }
+                }
+            }
+#pragma unroll
+            for (int py = 0; py < 2; ++py)
+#pragma unroll
+                for (int px = 0; px < 2; ++px) {
+                    f32x4 v = res[py][px];
+                    if (bias) v += bias[c4];   // (the interpolation weights add up to one)
+                    (py == 0 ? o0 : o1)[(2 * x + px) * C4 + c4] = v;
+                }
+        }
     }
 }
 
@@ -199,9 +236,10 @@ int ps_upsample_add_nhwc_f32(const float *a, const float *b, const float *bias, 
 {
     PS_REQUIRE(a && out, "upsample_add: null pointer");
     PS_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "upsample_add: C a positive multiple of 4 required (C = %d)", C);
-    const size_t total4 = (size_t)B * (2 * H) * (2 * W) * (C / 4);
-    hipLaunchKernelGGL(k_upsample_add, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, (const f32x4 *)a, (const f32x4 *)b,
-                       (const f32x4 *)bias, H, W, C / 4, total4, (f32x4 *)out);
+    PS_REQUIRE((size_t)B * H < ((size_t)1 << 31) && (size_t)2 * W * (C / 4) < ((size_t)1 << 31), "upsample_add: frame too large");
+    const unsigned rows = (unsigned)B * (unsigned)H;
+    hipLaunchKernelGGL(k_upsample_add, dim3(std::min(rows, 256u * 64u)), dim3(256), 0, (hipStream_t)stream, (const f32x4 *)a, (const f32x4 *)b,
+                       (const f32x4 *)bias, H, W, C / 4, rows, (f32x4 *)out);
     PS_LAUNCH_CHECK();
     return PS_OK;
 }
