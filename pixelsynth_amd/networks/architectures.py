@@ -633,6 +633,16 @@ class Unet(nn.Module):
         per = self.dconv8.in_channels * H * W * 4
         return max(1, min(self.MAX_BATCH, (_MIOPEN_SAFE_BYTES - 1) // per))
 
+    @staticmethod
+    def _conv(conv, x):
+        """conv(x); in eval mode without autograd with the spectral-normalised weight computed once per checkpoint (_normalised_weight)
+        instead of at every forward -- torch's hook costs five small launches per layer, a fifth of this network's time at 8 images."""
+        if x.is_cuda and not torch.is_grad_enabled() and not conv.training:
+            weight = _plain_conv_weight(conv, x)
+            if weight is not None:
+                return F.conv2d(x, weight, conv.bias, conv.stride, conv.padding, conv.dilation, conv.groups)
+        return conv(x)
+
     def forward(self, input):
         if input.is_cuda and not torch.is_grad_enabled() and not self.training:
             n = self._images_per_call(input.size(2), input.size(3))
@@ -640,13 +650,13 @@ class Unet(nn.Module):
                 return torch.cat([self.forward(input[i:i + n]) for i in range(0, input.size(0), n)])
         skips, h = [], _nhwc(self, input)
         for i in range(8):
-            h = getattr(self, f"conv{i + 1}")(h if i == 0 else F.leaky_relu(h, 0.2))
+            h = self._conv(getattr(self, f"conv{i + 1}"), h if i == 0 else F.leaky_relu(h, 0.2))
             if self._ENC_NORM[i]:
                 h = getattr(self, self._ENC_NORM[i])(h)
             skips.append(h)
         for i in range(8):
             h = F.interpolate(F.relu(h), scale_factor=2, mode="bilinear", align_corners=False)
-            h = getattr(self, f"dconv{i + 1}")(h)
+            h = self._conv(getattr(self, f"dconv{i + 1}"), h)
             if self._DEC_NORM[i]:
                 h = torch.cat((getattr(self, self._DEC_NORM[i])(h), skips[6 - i]), 1)
         return h.contiguous()
