@@ -91,7 +91,7 @@ def test_c5_the_path_the_headline_times_at_its_size(c5):
     `between=` set (where bench.py collects the previous step's gathers).  Three DIFFERENT C5 batches (bench.make_inputs, ranks 0 .. 2)
     through it at C5's size: every batch's codes equal outpaint_planned's bit for bit, batch 0's are the fixture's -- the codes whose
     logits test_c5_teacher_forced_logits_of_three_views_vs_the_torch_twin holds against the torch twin and whose splat the oracle
-    checks -- and the kernels the bench line's roofline names are the ones that ran (launch counters of the 256-frame engine)."""
+    checks -- and the kernels the bench line's roofline names are the ones that ran (launch counters of the 512-frame engine)."""
     import bench
     model, d0, host0, out0 = c5
     V = 128
