@@ -655,7 +655,12 @@ class Unet(nn.Module):
                 h = getattr(self, self._ENC_NORM[i])(h)
             skips.append(h)
         for i in range(8):
-            h = F.interpolate(F.relu(h), scale_factor=2, mode="bilinear", align_corners=False)
+            if h.size(2) == 1 and h.size(3) == 1 and h.is_cuda:
+                # bilinear x 2 of a single pixel is that pixel four times (torch takes its NCHW kernel for a 1 x 1 map: 0.26 ms of the
+                # network's 1.7 per 8 images)
+                h = F.relu(h).expand(-1, -1, 2, 2).contiguous(memory_format=torch.channels_last)
+            else:
+                h = F.interpolate(F.relu(h), scale_factor=2, mode="bilinear", align_corners=False)
             h = self._conv(getattr(self, f"dconv{i + 1}"), h)
             if self._DEC_NORM[i]:
                 h = torch.cat((getattr(self, self._DEC_NORM[i])(h), skips[6 - i]), 1)
