@@ -623,8 +623,12 @@ __global__ __launch_bounds__(64) void k_composite(
                 const float dx = h.x - xf, dy = h.y - yf;
                 const float d2 = dx * dx + dy * dy;
                 float d = RECIP ? d2 * denom : d2 / denom;
-                d = fminf(fmaxf(d, 1e-3f), 1.0f);
-                float a = 1.0f - sqrt_rn_unit(d);
+                d = __builtin_amdgcn_fmed3f(d, 1e-3f, 1.0f);   // = fminf(fmaxf(d, 1e-3f), 1.0f) for every d that is a number, one instruction
+                // The product route (EARLY) takes the hardware's square root as it comes (1 ulp; sqrt_rn_unit's correction is 7 of the walk's
+                // ~38 vector instructions): with the early-out and the fused sum the features stay within 3e-7 x max |feature| of the
+                // oracle's (measured on pile-ups and image-like clouds; 1.8e-7 with the exact root), inside the 1e-6 the parity tests
+                // state.  The list-emitting route -- the one the bit-exact checks go through -- keeps the correctly rounded root.
+                float a = 1.0f - (EARLY ? __builtin_amdgcn_sqrtf(d) : sqrt_rn_unit(d));
                 if (tau != 1.0f) a = powf(a, tau);
                 if (MODE == PS_ACC_WSUMNORM && pass == 0) {
                     tsum = tsum + a;
@@ -632,7 +636,10 @@ __global__ __launch_bounds__(64) void k_composite(
 #pragma unroll
                     for (int c = 0; c < NC; ++c) {
                         const float f = h.f[c];
-                        if (MODE == PS_ACC_ALPHACOMPOSITE) acc[c] = acc[c] + cum * a * f;   // PyTorch3D: cum_alpha * alpha * feature
+                        // PyTorch3D: cum_alpha * alpha * feature.  The product route (EARLY: features at the stated tolerance, no K-nearest
+                        // lists) takes the sum as one fused multiply-add -- what nvcc makes of the reference's own line, and three instead of
+                        // five vector instructions per hit for RGB; the list-emitting route keeps the separately rounded product and sum.
+                        if (MODE == PS_ACC_ALPHACOMPOSITE) acc[c] = EARLY ? __builtin_fmaf(cum * a, f, acc[c]) : acc[c] + cum * a * f;
                         else if (MODE == PS_ACC_WSUM) acc[c] = acc[c] + f * a;
                         else acc[c] = acc[c] + f * a / tsum;
                     }

@@ -108,7 +108,8 @@ def test_product_route_stops_a_walk_below_2_to_the_minus_23_transmittance(scale)
     """The product route (no idx / zbuf / dist asked for) stops a pixel's front-to-back walk once its transmittance is below 2^-23:
     the hits behind can add at most that times max |feature| (csrc/splat.hip: k_composite).  A pile-up -- thousands of points in
     one tile, far more than K = 128 hits per pixel, every walk cut short -- against the oracle, which walks all K: the error stays
-    below 2.5e-7 x max |feature| whatever the features' magnitude, and the background mask (one hit suffices) is the same bits."""
+    below 4e-7 x max |feature| whatever the features' magnitude (the route also takes the hardware's 1-ulp square root and fuses the
+    accumulation's multiply-add: 1.5-2.7e-7 measured), and the background mask (one hit suffices) is the same bits."""
     S, K, N = 32, 128, 6000
     rs = np.random.RandomState(77)
     pts = np.empty((2, N, 3), np.float32)
@@ -120,7 +121,7 @@ def test_product_route_stops_a_walk_below_2_to_the_minus_23_transmittance(scale)
     ref = c_oracle.splat_forward(pts, feat, S, K=K)
     assert np.array_equal(bg.cpu().numpy(), ref["bg"])
     err = np.abs(out.cpu().numpy() - ref["feat"]).max()
-    assert err <= 2.5e-7 * scale, err
+    assert err <= 4e-7 * scale, err
     assert (ref["idx"][..., K - 1] >= 0).mean() > 0.1      # (there really are pixels with K hits: walks the early-out cuts short)
 
 
@@ -226,7 +227,7 @@ def test_forward_justpts_matterport_shaped_vs_oracle(golden_dir):
         f2, bg2, idx, zbuf, dist = pm.splatter(s.permute(0, 2, 1).contiguous(), tt(img).view(B, 3, -1), return_debug=True)
         # (the route that emits idx / zbuf / dist walks EVERY hit; the product route stops a pixel's walk once its transmittance is below
         # 2^-23, csrc/splat.hip: what is left can add less than that times max |feature| -- the mask is the same bits)
-        assert torch.allclose(f2, feat, rtol=0, atol=2.5e-7) and torch.equal(bg2, bg)
+        assert torch.allclose(f2, feat, rtol=0, atol=4e-7) and torch.equal(bg2, bg)
         assert np.array_equal(idx.cpu().numpy(), ref["idx"]) and np.array_equal(dist.cpu().numpy(), ref["dist"])
     assert 0.02 < ref["bg"].mean()
 
@@ -271,7 +272,7 @@ def test_forward_justpts_full_size_vs_oracle(smooth):
     s = pm.project_pts(tt(depth).view(B, 1, -1), tt(cam["K"]), tt(cam["Kinv"]), tt(cam["P"]), tt(cam["Pinv"]), tt(RT2), tt(RT2inv))
     pc = s.permute(0, 2, 1).contiguous()
     f2, bg2, idx, zbuf, dist = pm.splatter(pc, tt(img).view(B, 3, -1), return_debug=True)
-    assert torch.allclose(f2, feat, rtol=0, atol=2.5e-7) and torch.equal(bg2, bg)      # (debug route: every hit; product route: until 2^-23)
+    assert torch.allclose(f2, feat, rtol=0, atol=4e-7) and torch.equal(bg2, bg)      # (debug route: every hit, exact root; product route: until 2^-23, 1-ulp root)
     assert np.array_equal(idx.cpu().numpy(), ref["idx"])
     assert np.array_equal(dist.cpu().numpy(), ref["dist"])
 
