@@ -150,14 +150,19 @@ template <int NCH>
 int launch_conv1x1(const C1Args &a, hipStream_t st)
 {
     const size_t lds = NCH > 0 ? (size_t)a.cot * NCH * 64 * sizeof(f32x4) : (size_t)a.cot * 64 * sizeof(float);
-    static bool attr_set = false;   // (per instantiation; the attribute is a property of the function)
-    if (!attr_set) {
-        PS_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv1x1<NCH>, hipFuncAttributeMaxDynamicSharedMemorySize, C1_MAX_LDS_FLOATS * 4));
-        attr_set = true;
-    }
-    int dev = 0, cus = 256;
+    // per instantiation AND per device: the dynamic-LDS limit is a property of the function on a device (a process may drive several GPUs)
+    constexpr int MAX_DEV = 64;
+    static bool attr_set[MAX_DEV] = {};
+    static int cus_of[MAX_DEV] = {};
+    int dev = 0;
     PS_HIP_CHECK(hipGetDevice(&dev));
-    PS_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    PS_REQUIRE(dev >= 0 && dev < MAX_DEV, "conv1x1: device %d", dev);
+    if (!attr_set[dev]) {
+        PS_HIP_CHECK(hipFuncSetAttribute((const void *)k_conv1x1<NCH>, hipFuncAttributeMaxDynamicSharedMemorySize, C1_MAX_LDS_FLOATS * 4));
+        PS_HIP_CHECK(hipDeviceGetAttribute(&cus_of[dev], hipDeviceAttributeMultiprocessorCount, dev));
+        attr_set[dev] = true;
+    }
+    const int cus = cus_of[dev] > 0 ? cus_of[dev] : 256;
     const size_t ntrips = (a.npix + 16 * C1_PT * C1_WAVES - 1) / (16 * C1_PT * C1_WAVES);
     // workgroups per compute unit the weights leave room for (160 KB of LDS; two waves per SIMD each)
     const int per_cu = lds > 80 * 1024 ? 1 : lds > 40 * 1024 ? 2 : 4;

@@ -144,8 +144,12 @@ __global__ __launch_bounds__(VE_THREADS) void k_vq_head(HeadArgs a)
 
 int grid_waves(size_t ntiles, int per_cu)
 {
+    static int cus_of[64] = {};   // per device, looked up once
     int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+        if (!cus_of[dev] && hipDeviceGetAttribute(&cus_of[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus_of[dev] = 256;
+        cus = cus_of[dev];
+    }
     const size_t wgs = (ntiles + VE_WAVES - 1) / VE_WAVES;
     return (int)std::min<size_t>(wgs, (size_t)cus * per_cu);
 }
