@@ -73,10 +73,14 @@ __global__ __launch_bounds__(256) void k_project(const float *__restrict__ src,
                                                  const float *__restrict__ RTa_inv,
                                                  const float *__restrict__ RT2, int W, int n,
                                                  int out_n, int out_off, float *__restrict__ out,
-                                                 float *__restrict__ cloud)
+                                                 float *__restrict__ cloud, uint32_t *__restrict__ zero_words = nullptr,
+                                                 unsigned zero_count = 0)
 {
     __shared__ float sRT[16], sK[16], sKinv[16];
     const int b = blockIdx.y;
+    // (the fused project + splat call: the binning counters of the splat that follows are cleared here, not by a memset of their own)
+    for (unsigned i = (blockIdx.y * gridDim.x + blockIdx.x) * 256u + threadIdx.x; i < zero_count; i += gridDim.x * gridDim.y * 256u)
+        zero_words[i] = 0u;
     if (threadIdx.x < 16) {
         const int i = threadIdx.x >> 2, j = threadIdx.x & 3;
         const float *A = RT2 + b * 16, *Bm = RTa_inv + b * 16;
@@ -796,7 +800,7 @@ void launch_composite(bool debug, bool recip, dim3 grid, hipStream_t st, const u
 int splat_core(const float *pts, const float *feat, int B, int N, int C, int S, double radius_px,
                int K, float tau, int rad_pow, int accumulation, int bg_ksize, float *out_feat,
                uint8_t *out_bg, int32_t *out_idx, float *out_zbuf, float *out_dist, char *ws,
-               const SplatPlan &p, hipStream_t st)
+               const SplatPlan &p, hipStream_t st, bool counters_cleared = false)
 {
     uint32_t *bbox = (uint32_t *)(ws + p.off_bbox);
     uint32_t *tile_off = (uint32_t *)(ws + p.off_count);
@@ -815,7 +819,8 @@ int splat_core(const float *pts, const float *feat, int B, int N, int C, int S, 
     const float denom_arg = pow2 ? 1.0f / denom : denom;
 
     // counters (count + cursor + worklist are adjacent) start from zero every call
-    PS_HIP_CHECK(hipMemsetAsync(ws + p.off_count, 0, p.off_bg0 - p.off_count, st));
+    // (the fused project + splat call has them cleared by its projection kernel)
+    if (!counters_cleared) PS_HIP_CHECK(hipMemsetAsync(ws + p.off_count, 0, p.off_bg0 - p.off_count, st));
     const dim3 gpt((N + 255) / 256, B);
     hipLaunchKernelGGL(k_bin_count, gpt, dim3(256), 0, st, pts, N, S, p.hw, p.tilesX, p.NT, bbox, tile_off);
     hipLaunchKernelGGL(k_scan, dim3(B), dim3(1024), 0, st, tile_off, p.NT, (uint32_t)((size_t)N * p.max_tiles_pp));
@@ -937,9 +942,10 @@ int ps_project_splat_f32(const float *depth, const float *feat, const float *K, 
     hipStream_t st = (hipStream_t)stream;
     float *pts = (float *)((char *)workspace + p.off_pts);
     hipLaunchKernelGGL((k_project<1, false>), dim3((N + 255) / 256, B), dim3(256), 0, st, depth,
-                       (const int32_t *)nullptr, K, Kinv, RT1inv, RT2, S, N, N, 0, pts, (float *)nullptr);
+                       (const int32_t *)nullptr, K, Kinv, RT1inv, RT2, S, N, N, 0, pts, (float *)nullptr,
+                       (uint32_t *)((char *)workspace + p.off_count), (unsigned)((p.off_bg0 - p.off_count) / sizeof(uint32_t)));
     return splat_core(pts, feat, B, N, C, S, radius_px, Kpp, tau, rad_pow, accumulation, bg_ksize, out_feat, out_bg,
-                      nullptr, nullptr, nullptr, (char *)workspace, p, st);
+                      nullptr, nullptr, nullptr, (char *)workspace, p, st, true);
 }
 
 // ------------------------------------------------------------------------------------------
