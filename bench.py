@@ -59,7 +59,7 @@ VIEWS_PER_SOURCE = 16   # config C5: 8 source images x 16 novel views each
 # PS_BENCH_FORCE_COLLECTIVE=1: a single-rank run creates the RCCL process group all the same and sends its gathers, barrier and
 # max-over-ranks through it -- the multi-GPU code path (`world > 1` in back()) executed on the one GPU a test box has
 FORCE_COLLECTIVE = os.environ.get("PS_BENCH_FORCE_COLLECTIVE") == "1"
-GATE_MIN_VIEWS = 60     # (lmconv.model.TP_MIN_FRAMES: batches of the throughput form)
+GATE_MIN_VIEWS = int(os.environ.get("PS_BENCH_GATE_MIN", "60"))     # batches from this size on: the next step's splat is gated behind the prefix pass
 HOST_TIMES = [] if os.environ.get("PS_BENCH_HOST_TIMES") == "1" else None   # run_steps: host stamps per step, summarised on stderr
 
 

@@ -422,7 +422,9 @@ import os
 # 64: 19.0 / 17.5, 96: 28.2 / 20.6, 128: 38 / 24.4.
 COLUMNS_PER_LAUNCH = int(os.environ.get("PS_WAVE_COLS", "128"))
 COLUMNS_PER_LAUNCH_TP = int(os.environ.get("PS_WAVE_COLS_TP", "1024"))
-TP_MIN_FRAMES = int(os.environ.get("PS_TP_MIN_FRAMES", "60"))
+# frames from which a batch's column launches take the throughput form.  60 until the launches were packed (round 6: up to four batches share a
+# launch, so 24 views already fill it: 56 views 9.6 -> 6.9 ms per step, 40 views 7.6 -> 6.2, 24 views 5.16 -> 5.08; 16 views 3.54 -> 3.70, so not lower)
+TP_MIN_FRAMES = int(os.environ.get("PS_TP_MIN_FRAMES", "24"))
 
 
 import threading

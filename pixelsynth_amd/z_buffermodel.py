@@ -398,17 +398,26 @@ class ZbufferModelPts(nn.Module):
     # ---------------------------------------------------------------- the AR runs of consecutive batches, overlapped
     PIPE_CAP = 1024         # columns a merged launch takes (lmconv.model.COLUMNS_PER_LAUNCH_TP)
     PER_FRAME_PREFIX = True  # outpaint_pipelined: per-frame prefixes where the plan carries their schedule (build_ar_plan, PS_PER_FRAME_PREFIX)
-    PIPE_DEPTH = 4          # batches outpaint_pipelined keeps in flight at most: every launch takes what is left of each batch's current
-    #                         wavefront, oldest batch first, while there is room (lmconv.model.pack_launches) -- with three to four in
-    #                         flight the launches are full whatever the batch size (C5's 128 views: 33 launches of ~1 020 columns per step
+    PIPE_DEPTH = 4          # batches outpaint_pipelined keeps in flight at least (pipe_depth): every launch takes what is left of each batch's
+    #                         current wavefront, oldest batch first, while there is room (lmconv.model.pack_launches) -- with three to four in
+    #                         flight the launches of a large batch are full (C5's 128 views: 33 launches of ~1 020 columns per step
     #                         where head / tail merging ran 45 of 750; 16 views: 33 of 128 where equal parts ran 44)
+    PIPE_FRAMES = 384       # ... and as many as it takes to have about this many frames in the handle, eight at most: the throughput form's
+    #                         launches take 1 024 columns, which middle-sized batches only fill with more of them in flight (ms per step with
+    #                         4 / 6 / 8 in flight -- 24 views: 5.08 / 4.39 / 4.10, 32: 5.21 / 4.53 / 4.36, 48: 6.23 / 5.80 / 5.73, 64: 6.82 / 6.48,
+    #                         96: 9.04 / 8.93; 128: the same from 4 on; 16, latency form: 3.38 / 3.41 / 3.52)
 
     def pipe_depth(self, V):
         """Batches of V views that outpaint_pipelined keeps in flight at most (PS_PIPE_DEPTH overrides): the frames of its engine handle
         are that many batches'; a batch's result comes back at most depth - 1 calls late."""
         import os
+        from .lmconv.model import TP_MIN_FRAMES
         d = os.environ.get("PS_PIPE_DEPTH")
-        return max(2, min(8, int(d))) if d else self.PIPE_DEPTH
+        if d:
+            return max(2, min(8, int(d)))
+        if V < TP_MIN_FRAMES:        # (latency form: launches of 128 columns, full at four)
+            return self.PIPE_DEPTH
+        return max(self.PIPE_DEPTH, min(8, int(round(self.PIPE_FRAMES / V))))
 
     def pipe_frames(self, V):
         """Frames of the engine handle outpaint_pipelined runs batches of V views in."""

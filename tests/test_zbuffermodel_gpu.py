@@ -487,6 +487,45 @@ def test_small_batches_pipelined_four_and_three_deep(monkeypatch, depth):
     assert sum(eng.launch_counts().values()) - n0 < 0.8 * own
 
 
+def test_middle_sized_batches_keep_more_batches_in_flight():
+    """pipe_depth(V): as many batches as it takes to have ~384 frames in the handle, between four and eight -- the throughput form's launches
+    take 1 024 columns, which batches of 24 to 96 views only fill with more of them in flight (lmconv.model.TP_MIN_FRAMES = 24 since the
+    launches are packed).  Ten different batches of 32 views, eight in flight, throughput-form launches: every batch's codes are
+    outpaint_planned's bit for bit, in order, at most seven calls late."""
+    from pixelsynth_amd.lmconv import model as lm
+    m = make_model()
+    assert lm.TP_MIN_FRAMES == 24
+    assert [m.pipe_depth(v) for v in (8, 16, 24, 32, 48, 64, 96, 128, 256)] == [4, 4, 8, 8, 8, 6, 4, 4, 4]
+    V, depth, nb = 32, 8, 10
+    cam = syn.demo_cameras(V)
+    K, Kinv, P, Pinv = (tt(cam[k]) for k in ("K", "Kinv", "P", "Pinv"))
+    batches = []
+    for b in range(nb):
+        img, depth_ = tt(syn.image(481 + b, V, 3, 256)), tt(syn.depth_smooth(491 + b, V, 256, 1.0, 100.0))
+        yaws = np.linspace(-0.6 + 0.03 * b, 0.6 - 0.03 * b, V)
+        rts = [syn.yaw_pose(cam["P"][v:v + 1], float(y)) for v, y in enumerate(yaws)]
+        RT2, RT2inv = tt(np.concatenate([r[1] for r in rts])), tt(np.concatenate([r[0] for r in rts]))
+        batches.append(((img, depth_, K, Kinv, P, Pinv, RT2, RT2inv), tt(syn.codes(501 + b, V)), tt(np.random.RandomState(511 + b).rand(V, 1024).astype(np.float32))))
+    ref = [m.outpaint_planned(m.plan_views(*a), c, temperature=0.7, uniforms=u)["codes"].clone() for a, c, u in batches]
+    eng = m.outpaint2.engine(32, 32, m.pipe_frames(V))
+    assert m.pipe_frames(V) == depth * V
+    n0 = dict(eng.launch_counts())
+    got, late = [], []
+    for a, c, u in batches:
+        done = m.outpaint_pipelined(m.plan_views(*a), c, temperature=0.7, uniforms=u)
+        late.append(done is None)
+        if done is not None:
+            got.append(done["codes"].clone())
+    got += [o["codes"].clone() for o in m.outpaint_flush()]
+    torch.cuda.synchronize()
+    eng.check()
+    assert late[0] and sum(late) <= depth - 1 and len(got) == nb
+    for b in range(nb):
+        assert torch.equal(got[b], ref[b]), (b, int((got[b] != ref[b]).sum()))
+    n1 = eng.launch_counts()
+    assert sum(n1.get(k, 0) - n0.get(k, 0) for k in ("k_column_tp", "k_column_tp8")) > 0      # (the throughput form did run)
+
+
 def test_pipelined_batches_with_different_temperatures_and_a_reset():
     """outpaint_pipelined when the temperature changes from one batch to the next: the tail wavefronts of the batch in flight run as
     launches of their own with THEIR temperature (a merged launch has one), so every batch's codes are still outpaint_planned's at its
